@@ -1,0 +1,171 @@
+"""ctypes binding to oracle/_ref/libtfluids_ref.so -- TEST INFRASTRUCTURE ONLY.
+
+The .so is the REFERENCE's own CPU tfluids code (torch/tfluids/init.cu compiled as C++ against a
+fake TH/luaT shim, recipe: oracle/Makefile target `ref`). This module re-creates the Lua-side
+wrappers of torch/tfluids/init.lua:89-735 on numpy arrays (same names, argument order, defaults,
+temp-buffer shapes and the copy-back of in-place results) so tests can call the reference exactly
+like the Lua drivers do.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+class _RefArg(ctypes.Structure):
+    _fields_ = [("kind", ctypes.c_int), ("num", ctypes.c_double), ("str", ctypes.c_char_p),
+                ("data", ctypes.c_void_p), ("ndim", ctypes.c_int), ("size", ctypes.c_long * 5)]
+
+
+class RefError(RuntimeError):
+    pass
+
+
+def available(fast=False):
+    return os.path.exists(_path(fast))
+
+
+def _path(fast):
+    return os.path.join(_HERE, "_ref", "libtfluids_ref_fast.so" if fast else "libtfluids_ref.so")
+
+
+class RefTfluids:
+    """The reference's tfluids ops (float or double instantiation) on numpy arrays."""
+
+    def __init__(self, dtype=np.float32, fast=False):
+        self.lib = ctypes.CDLL(_path(fast))
+        self.dtype = np.dtype(dtype)
+        self._dt = 0 if self.dtype == np.float32 else 1
+        self.lib.tfluids_ref_call.restype = ctypes.c_int
+
+    # -- raw call --------------------------------------------------------------------------
+    def call(self, op, *args):
+        arr = (_RefArg * len(args))()
+        keep = []
+        for i, a in enumerate(args):
+            r = arr[i]
+            if isinstance(a, bool):
+                r.kind, r.num = 1, float(a)
+            elif isinstance(a, (int, float, np.floating, np.integer)):
+                r.kind, r.num = 0, float(a)
+            elif isinstance(a, str):
+                b = a.encode()
+                keep.append(b)
+                r.kind, r.str = 2, b
+            elif isinstance(a, np.ndarray):
+                assert a.flags["C_CONTIGUOUS"], "reference needs contiguous tensors"
+                if a.dtype == np.int32:
+                    r.kind = 4
+                else:
+                    assert a.dtype == self.dtype, (a.dtype, self.dtype)
+                    r.kind = 3
+                r.data = a.ctypes.data
+                r.ndim = a.ndim
+                for d in range(a.ndim):
+                    r.size[d] = a.shape[d]
+            else:
+                raise TypeError(type(a))
+        ret = ctypes.c_double(0.0)
+        nret = ctypes.c_int(0)
+        err = ctypes.create_string_buffer(512)
+        rc = self.lib.tfluids_ref_call(op.encode(), self._dt, len(args), arr, ctypes.byref(ret),
+                                       ctypes.byref(nret), err, 512)
+        if rc == -1:
+            raise RefError("unknown reference op " + op)
+        if rc != 0:
+            raise RefError(err.value.decode())
+        return ret.value if nret.value else None
+
+    def _tmp(self, *shapes):
+        # init.lua:35-64 getTempStorage: contents undefined on entry -> fill with noise.
+        rng = np.random.RandomState(12345)
+        return [rng.randn(*s).astype(self.dtype) for s in shapes]
+
+    @staticmethod
+    def _dims(flags):
+        b, _, d, h, w = flags.shape
+        return b, d, h, w
+
+    # -- init.lua wrappers -----------------------------------------------------------------
+    def advectScalar(self, dt, s, U, flags, method="maccormackOurs", sDst=None,
+                     sampleOutsideFluid=False, maccormackStrength=0.75, boundaryWidth=1):
+        b, d, h, w = self._dims(flags)
+        C = U.shape[1]
+        is3D = C == 3
+        fwd, bwd, fwdPos, bwdPos, out = self._tmp((b, 1, d, h, w), (b, 1, d, h, w),
+                                                  (b, C, d, h, w), (b, C, d, h, w),
+                                                  (b, 1, d, h, w))
+        self.call("advectScalar", dt, s, U, flags, fwd, bwd, is3D, method, fwdPos, bwdPos,
+                  boundaryWidth, sampleOutsideFluid, maccormackStrength,
+                  sDst if sDst is not None else out)
+        if sDst is None:
+            s[...] = out
+        return {"fwd": fwd, "bwd": bwd, "fwdPos": fwdPos, "bwdPos": bwdPos}
+
+    def advectVel(self, dt, U, flags, method="maccormackOurs", UDst=None,
+                  maccormackStrength=0.75, boundaryWidth=1):
+        is3D = U.shape[1] == 3
+        fwd, bwd, out = self._tmp(U.shape, U.shape, U.shape)
+        self.call("advectVel", dt, U, flags, fwd, bwd, is3D, method, boundaryWidth,
+                  maccormackStrength, UDst if UDst is not None else out)
+        if UDst is None:
+            U[...] = out
+        return {"fwd": fwd, "bwd": bwd}
+
+    def setWallBcsForward(self, U, flags):
+        self.call("setWallBcsForward", U, flags, U.shape[1] == 3)
+
+    def velocityDivergenceForward(self, U, flags, UDiv):
+        self.call("velocityDivergenceForward", U, flags, UDiv, U.shape[1] == 3)
+
+    def velocityUpdateForward(self, U, flags, p):
+        self.call("velocityUpdateForward", U, flags, p, U.shape[1] == 3)
+
+    def vorticityConfinement(self, U, flags, strength):
+        b, d, h, w = self._dims(flags)
+        C = U.shape[1]
+        centered, curl, curlNorm, force = self._tmp((b, C, d, h, w), (b, 3, d, h, w),
+                                                    (b, 1, d, h, w), (b, C, d, h, w))
+        self.call("vorticityConfinement", U, flags, float(strength), centered, curl, curlNorm,
+                  force, C == 3)
+
+    def addBuoyancy(self, U, flags, density, gravity, dt):
+        strength = self._tmp((3,))[0]
+        self.call("addBuoyancy", U, flags, density, gravity, strength, dt, U.shape[1] == 3)
+
+    def addGravity(self, U, flags, gravity, dt):
+        force = self._tmp((3,))[0]
+        self.call("addGravity", U, flags, gravity, dt, U.shape[1] == 3, force)
+
+    def emptyDomain(self, flags, is3D, bnd=1):
+        self.call("emptyDomain", flags, bool(is3D), bnd)
+        return flags
+
+    def flagsToOccupancy(self, flags, occupancy):
+        self.call("flagsToOccupancy", flags, occupancy)
+
+    @staticmethod
+    def getDx(flags):
+        return 1.0 / max(flags.shape[2], flags.shape[3], flags.shape[4])
+
+    # -- direct line trace (generic/calc_line_trace.cc:313) ---------------------------------
+    def calcLineTrace(self, pos, delta, flags3d, is3D=True):
+        assert self._dt == 0
+        f = np.ascontiguousarray(flags3d, dtype=np.float32)
+        zs, ys, xs = f.shape
+        p = np.asarray(pos, dtype=np.float32)
+        d = np.asarray(delta, dtype=np.float32)
+        out = np.zeros(3, dtype=np.float32)
+        hit = ctypes.c_int(0)
+        err = ctypes.create_string_buffer(512)
+        rc = self.lib.tfluids_ref_calcLineTrace(
+            p.ctypes.data_as(ctypes.c_void_p), d.ctypes.data_as(ctypes.c_void_p),
+            f.ctypes.data_as(ctypes.c_void_p), zs, ys, xs, int(is3D),
+            out.ctypes.data_as(ctypes.c_void_p), ctypes.byref(hit), err, 512)
+        if rc != 0:
+            raise RefError(err.value.decode())
+        return out, bool(hit.value)
