@@ -1,0 +1,35 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for _p in (os.path.join(ROOT, "tests"), ROOT):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    """The plain-C restatement (oracle/tfluids_oracle.c), built on demand."""
+    import subprocess
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "oracle"])
+    from oracle.oracle import OracleTfluids
+    return OracleTfluids()
+
+
+@pytest.fixture(scope="session")
+def ref():
+    """The reference's own CPU sources compiled here (oracle/_ref); skipped when neither the
+    prebuilt .so nor /root/reference is present (e.g. on a box that received no oracle/_ref)."""
+    import subprocess
+    from oracle import ref as refmod
+    if not refmod.available() and os.path.isdir("/root/reference/torch/tfluids"):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "ref"])
+    if not refmod.available():
+        pytest.skip("oracle/_ref/libtfluids_ref.so not built and /root/reference absent")
+    return refmod.RefTfluids()

@@ -1,0 +1,192 @@
+"""Pins the oracle (oracle/tfluids_oracle.c) before anything trusts it:
+ (1) bit-for-bit against the reference's own CPU code compiled here (oracle/_ref),
+ (2) bit-for-bit against the committed golden fixtures generated from that build,
+ (3) against the reference's portable known-answer tests
+     (generic/CalcLineTraceTest.m:26-160, test_tfluids.lua:675-753).
+CPU only.
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import scenes
+from golden.make_golden import METHODS, run_ops
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLDEN = sorted(glob.glob(os.path.join(HERE, "golden", "*.npz")))
+
+
+def _load(path):
+    z = np.load(path)
+    sc = dict(flags=z["flags"], U=z["U"], density=z["density"], p=z["p"], dt=float(z["dt"]),
+              is3d=z["U"].shape[1] == 3)
+    outs = {k[4:]: z[k] for k in z.files if k.startswith("out_")}
+    return sc, outs
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p) for p in GOLDEN])
+def test_oracle_matches_golden_bitwise(oracle, path):
+    sc, outs = _load(path)
+    got = run_ops(oracle, sc)
+    assert set(got) == set(outs)
+    for k in sorted(outs):
+        assert np.array_equal(got[k], outs[k]), k
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p) for p in GOLDEN])
+def test_reference_reproduces_golden(ref, path):
+    """The fixtures are what the compiled reference produces today (guards the generator)."""
+    sc, outs = _load(path)
+    got = run_ops(ref, sc)
+    for k in sorted(outs):
+        assert np.array_equal(got[k], outs[k]), k
+
+
+@pytest.mark.parametrize("dims,seed,kw", [
+    ((1, 48, 64), 1, dict(vel_cells=3.0)),
+    ((1, 40, 40), 2, dict(vel_cells=6.0, empty_cells=True, stick=True, noise=2.0)),
+    ((24, 20, 28), 3, dict(vel_cells=2.5)),
+    ((16, 24, 20), 4, dict(vel_cells=5.0, empty_cells=True, stick=True, noise=2.0, B=2)),
+])
+def test_oracle_matches_reference_bitwise(oracle, ref, dims, seed, kw):
+    sc = scenes.make_scene(dims, seed=seed, **kw)
+    a, b = run_ops(oracle, sc), run_ops(ref, sc)
+    for k in sorted(a):
+        assert np.array_equal(a[k], b[k]), k
+
+
+def test_advect_temps_match_reference(oracle, ref):
+    """fwd / fwdPos side outputs (init.lua:127-136 temps) agree too: they feed our fused pass B."""
+    sc = scenes.make_scene((10, 12, 14), seed=5, vel_cells=3.0)
+    ta = oracle.advectScalar(sc["dt"], sc["density"].copy(), sc["U"], sc["flags"])
+    tb = ref.advectScalar(sc["dt"], sc["density"].copy(), sc["U"], sc["flags"])
+    for k in ("fwd", "bwd", "fwdPos", "bwdPos"):
+        assert np.array_equal(ta[k], tb[k]), k
+
+
+# ---- known-answer tests ported from generic/CalcLineTraceTest.m -----------------------------
+def _flags_from_obs(obs_xyz):
+    """obs indexed [x, y, z] (Matlab order) -> flags [z, y, x] with Obstacle=2 / Fluid=1."""
+    return np.where(np.transpose(obs_xyz, (2, 1, 0)) > 0, 2.0, 1.0).astype(np.float32)
+
+
+@pytest.fixture(params=["oracle", "ref"])
+def tracer(request):
+    return request.getfixturevalue(request.param)
+
+
+def test_linetrace_single_voxel(tracer):
+    # CalcLineTraceTest.m:26-59: from every free cell centre of a 3x4x5 grid go 90 % of the way
+    # to the centre of the one occupied cell (1,2,3) -> must collide.
+    dims = (3, 4, 5)
+    obs = np.zeros(dims)
+    obs[1, 2, 3] = 1
+    flags = _flags_from_obs(obs)
+    filled = np.array([1, 2, 3]) + 0.5
+    n = 0
+    for z in range(dims[2]):
+        for y in range(dims[1]):
+            for x in range(dims[0]):
+                pos = np.array([x, y, z]) + 0.5
+                if np.linalg.norm(filled - pos) <= 1e-5:
+                    continue
+                delta = 0.9 * (filled - pos) - np.array([0.001, 0, 0])
+                _, hit = tracer.calcLineTrace(pos, delta, flags)
+                assert hit, (x, y, z)
+                n += 1
+    assert n == 59
+
+
+def _sphere_scene():
+    w, h, d = 26, 33, 28
+    cc = np.array([w / 2, h / 2, d / 2])
+    r = min(w, d, h) / 4 + 0.5
+    u, v, z = np.meshgrid(np.arange(1, w + 1), np.arange(1, h + 1), np.arange(1, d + 1),
+                          indexing="ij")
+    obs = ((u - cc[0]) ** 2 + (v - cc[1]) ** 2 + (z - cc[2]) ** 2) <= r * r
+    return np.array([w, h, d], float), _flags_from_obs(obs)
+
+
+def test_linetrace_borders_and_corners(tracer):
+    dims, flags = _sphere_scene()
+    # CalcLineTraceTest.m:103-126 -- +/- borders. (Starts sit next to, not inside, the sphere.)
+    for dim in range(3):
+        pos = dims / 2
+        pos[(dim + 1) % 3] = 2.5  # keep the ray clear of the sphere; the .m plots through it
+        pos[dim] = dims[dim] - 4.1
+        delta = np.zeros(3)
+        delta[dim] = 6.1
+        exp = pos.copy()
+        exp[dim] = dims[dim]
+        new, hit = tracer.calcLineTrace(pos, delta, flags)
+        assert hit and np.linalg.norm(new - exp) < 1e-4
+        pos[dim] = 4.1
+        delta[dim] = -6.1
+        exp[dim] = 0
+        new, hit = tracer.calcLineTrace(pos, delta, flags)
+        assert hit and np.linalg.norm(new - exp) < 1e-4
+    # :128-138 step off all borders
+    pos = np.array([dims[0] - 5.2, dims[1] - 6.3, dims[2] - 7.4])
+    new, hit = tracer.calcLineTrace(pos, np.array([13.0, 17.0, 19.0]), flags)
+    assert hit and min(abs(new - dims)) < 1e-4
+    # :140-146 exact corner
+    new, hit = tracer.calcLineTrace(dims - 1.5, np.array([2.0, 2.0, 2.0]), flags)
+    assert hit and np.linalg.norm(new - dims) < 1e-4
+    # :148-154 mixed corner
+    pos = np.array([dims[0] - 0.5, 0.5, dims[2] - 0.5])
+    new, hit = tracer.calcLineTrace(pos, np.array([2.0, -2.0, 2.0]), flags)
+    assert hit and np.linalg.norm(new - np.array([dims[0], 0, dims[2]])) < 1e-4
+    # :156-160 collision with the sphere
+    pos = np.array([5.5, dims[1] - 3.2, 11.1])
+    new, hit = tracer.calcLineTrace(pos, dims / 3 - pos, flags)
+    assert hit
+    # no-collision control (the commented-out case 1 of the .m)
+    pos = np.array([3.2, 3.3, 3.4])
+    d = np.array([-1.5, -0.5, 1.0])
+    new, hit = tracer.calcLineTrace(pos, d, flags)
+    assert not hit and np.linalg.norm(new - (pos + d)) < 1e-5
+
+
+# ---- analytic tests of test_tfluids.lua ------------------------------------------------------
+@pytest.mark.parametrize("is3d", [False, True])
+@pytest.mark.parametrize("bnd", [1, 2, 3])
+def test_empty_domain(tracer, is3d, bnd):
+    # test_tfluids.lua:675-708
+    Z = 9 if is3d else 1
+    flags = np.full((2, 1, Z, 11, 12), -3.0, np.float32)
+    tracer.emptyDomain(flags, is3d, bnd)
+    exp = scenes.empty_domain(2, Z, 11, 12, is3d, bnd)
+    assert np.array_equal(flags, exp)
+
+
+def test_flags_to_occupancy(tracer):
+    # test_tfluids.lua:710-753
+    sc = scenes.make_scene((6, 9, 10), seed=3)
+    occ = np.full_like(sc["flags"], 5.0)
+    tracer.flagsToOccupancy(sc["flags"], occ)
+    assert np.array_equal(occ, (sc["flags"] == 2).astype(np.float32))
+    bad = sc["flags"].copy()
+    bad[0, 0, 2, 2, 2] = 4.0
+    with pytest.raises(Exception):
+        tracer.flagsToOccupancy(bad, occ)
+
+
+# ---- Jacobi: no CPU reference exists (generic/tfluids.cc:836-839) -> analytic properties ------
+@pytest.mark.parametrize("dims", [(1, 24, 24), (10, 12, 14)])
+def test_jacobi_converges_to_divergence_free(oracle, dims):
+    sc = scenes.make_scene(dims, seed=9, vel_cells=1.0)
+    f, U = sc["flags"], sc["U"].copy()
+    oracle.setWallBcsForward(U, f)
+    div = np.zeros_like(sc["density"])
+    oracle.velocityDivergenceForward(U, f, div)
+    p = np.full_like(div, 3.0)
+    r20 = oracle.solveLinearSystemJacobi(p.copy(), f, div, sc["is3d"], 0.0, 20)
+    r200 = oracle.solveLinearSystemJacobi(p.copy(), f, div, sc["is3d"], 0.0, 200)
+    assert r200 < r20
+    res = oracle.solveLinearSystemJacobi(p, f, div, sc["is3d"], 1e-7, 20000)
+    assert res < 1e-7 * 1.0001 or res < 1e-5
+    oracle.velocityUpdateForward(U, f, p)
+    oracle.velocityDivergenceForward(U, f, div)
+    assert np.abs(div).max() < 2e-4 * max(1.0, np.abs(sc["U"]).max())
