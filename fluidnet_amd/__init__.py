@@ -1,0 +1,7 @@
+"""fluidnet_amd -- MI355X-native tfluids.simulate() hot path behind FluidNet's tfluids.* API.
+
+  fluidnet_amd.tfluids    host mirror of torch/tfluids/init.lua (operators; ctypes over the C ABI)
+  fluidnet_amd.csrc/      hand-written HIP kernels for gfx950 + the C ABI (include/tfluids_hip.h)
+"""
+from . import tfluids  # noqa: F401
+from ._lib import TfluidsError  # noqa: F401

@@ -1,0 +1,73 @@
+"""ctypes binding of libtfluids_hip.so (C ABI: include/tfluids_hip.h).
+
+The library is the product: there is NO fallback. If it is missing or a HIP call fails, every
+operator raises -- the oracle under oracle/ is test infrastructure and is never imported here.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtfluids_hip.so")
+
+
+class TfluidsError(RuntimeError):
+    """Raised where the reference raises luaL_error / THError (torch/tfluids/init.lua asserts)."""
+
+
+class tfl_tensor(ctypes.Structure):
+    _fields_ = [("data", ctypes.c_void_p), ("B", ctypes.c_int32), ("C", ctypes.c_int32),
+                ("Z", ctypes.c_int32), ("Y", ctypes.c_int32), ("X", ctypes.c_int32)]
+
+
+_T = ctypes.POINTER(tfl_tensor)
+_F3 = ctypes.POINTER(ctypes.c_float)
+_c = ctypes
+
+# name -> (restype, argtypes) for every symbol include/tfluids_hip.h declares.
+SIGNATURES = {
+    "tfl_abi_version": (_c.c_int, []),
+    "tfl_create": (_c.c_void_p, [_c.c_int]),
+    "tfl_destroy": (None, [_c.c_void_p]),
+    "tfl_set_stream": (_c.c_int, [_c.c_void_p, _c.c_void_p]),
+    "tfl_last_error": (_c.c_char_p, [_c.c_void_p]),
+    "tfl_synchronize": (_c.c_int, [_c.c_void_p]),
+    "tfl_trace_errors": (_c.c_int64, [_c.c_void_p]),
+    "tfl_advectScalar": (_c.c_int, [_c.c_void_p, _c.c_float, _T, _T, _T, _T, _T, _c.c_int,
+                                    _c.c_char_p, _T, _T, _c.c_int, _c.c_int, _c.c_float, _T]),
+    "tfl_advectVel": (_c.c_int, [_c.c_void_p, _c.c_float, _T, _T, _T, _T, _c.c_int, _c.c_char_p,
+                                 _c.c_int, _c.c_float, _T]),
+    "tfl_setWallBcsForward": (_c.c_int, [_c.c_void_p, _T, _T, _c.c_int]),
+    "tfl_velocityDivergenceForward": (_c.c_int, [_c.c_void_p, _T, _T, _T, _c.c_int]),
+    "tfl_velocityUpdateForward": (_c.c_int, [_c.c_void_p, _T, _T, _T, _c.c_int]),
+    "tfl_vorticityConfinement": (_c.c_int, [_c.c_void_p, _T, _T, _c.c_float, _T, _T, _T, _T,
+                                            _c.c_int]),
+    "tfl_addBuoyancy": (_c.c_int, [_c.c_void_p, _T, _T, _T, _F3, _c.c_void_p, _c.c_float,
+                                   _c.c_int]),
+    "tfl_addGravity": (_c.c_int, [_c.c_void_p, _T, _T, _F3, _c.c_float, _c.c_int, _c.c_void_p]),
+    "tfl_emptyDomain": (_c.c_int, [_c.c_void_p, _T, _c.c_int, _c.c_int]),
+    "tfl_flagsToOccupancy": (_c.c_int, [_c.c_void_p, _T, _T]),
+    "tfl_solveLinearSystemJacobi": (_c.c_int, [_c.c_void_p, _T, _T, _T, _T, _T, _T, _c.c_int,
+                                               _c.c_float, _c.c_int, _c.c_int,
+                                               _c.POINTER(_c.c_float)]),
+}
+
+_lib = None
+
+
+def load():
+    """dlopen the HIP library (after torch, so both share one libamdhip64.so.7)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise TfluidsError(
+            "libtfluids_hip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; "
+            "g.build()'` or `make -C fluidnet_amd/csrc`. There is no CPU fallback." % LIB_PATH)
+    import torch  # noqa: F401  (loads the HIP runtime the process will use)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here = ABI drift between header and library
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib

@@ -1,0 +1,327 @@
+// abi.cpp -- the C ABI of libtfluids_hip.so (include/tfluids_hip.h): argument validation that
+// mirrors torch/tfluids/init.lua's asserts, then kernel launches on the context's stream.
+// No torch / Lua / C++ types cross the boundary; errors come back as codes + tfl_last_error().
+#include "../../include/tfluids_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "tfl_device.hpp"
+#include "tfl_host.hpp"
+
+struct tfl_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  unsigned long long* d_trace_err = nullptr;  // device word: traces that hit an invariant path
+  double* d_resid = nullptr;                  // Jacobi residual accumulators [kMaxBatch]
+  double* h_resid = nullptr;                  // pinned mirror
+};
+static const int kMaxBatch = 1024;
+
+namespace {
+
+int fail(tfl_ctx* ctx, int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  if (ctx) ctx->err = buf;
+  return code;
+}
+
+#define HIP_TRY(ctx, call)                                                                     \
+  do {                                                                                         \
+    hipError_t e_ = (call);                                                                    \
+    if (e_ != hipSuccess) return fail(ctx, TFL_EHIP, "%s: %s", #call, hipGetErrorString(e_)); \
+  } while (0)
+
+int check_launch(tfl_ctx* ctx, const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(ctx, TFL_EHIP, "%s: %s", what, hipGetErrorString(e));
+  return TFL_OK;
+}
+
+bool same_dims(const tfl_tensor* a, const tfl_tensor* b) {
+  return a->B == b->B && a->Z == b->Z && a->Y == b->Y && a->X == b->X;
+}
+
+// init.lua's shape asserts (e.g. :99-120): flags scalar, U has 2 (2-D, Z==1) or 3 channels, all same B/Z/Y/X.
+int check_flags(tfl_ctx* ctx, const char* op, const tfl_tensor* flags) {
+  if (!ctx) return TFL_EINVAL;
+  if (!flags || !flags->data) return fail(ctx, TFL_EINVAL, "%s: flags is null", op);
+  if (flags->C != 1) return fail(ctx, TFL_EINVAL, "%s: flags is not scalar", op);
+  if (flags->B < 1 || flags->Z < 1 || flags->Y < 1 || flags->X < 1) return fail(ctx, TFL_EINVAL, "%s: empty grid", op);
+  if ((long long)flags->Z * flags->Y * flags->X * 3 >= (1ll << 31))
+    return fail(ctx, TFL_EINVAL, "%s: grid too large for 32-bit cell offsets", op);
+  if ((long long)flags->Z * flags->B > 65535) return fail(ctx, TFL_EINVAL, "%s: B*Z exceeds the launch grid limit", op);
+  return TFL_OK;
+}
+int check_vel(tfl_ctx* ctx, const char* op, const char* name, const tfl_tensor* U, const tfl_tensor* flags, int is3D) {
+  if (!U || !U->data) return fail(ctx, TFL_EINVAL, "%s: %s is null", op, name);
+  if (!same_dims(U, flags)) return fail(ctx, TFL_EINVAL, "%s: %s size mismatch", op, name);
+  if (is3D) {
+    if (U->C != 3) return fail(ctx, TFL_EINVAL, "%s: 3D velocity field must have 3 channels", op);
+  } else {
+    if (flags->Z != 1) return fail(ctx, TFL_EINVAL, "%s: 2D velocity field but zdepth > 1", op);
+    if (U->C != 2) return fail(ctx, TFL_EINVAL, "%s: 2D velocity field must have only 2 channels", op);
+  }
+  return TFL_OK;
+}
+int check_scalar(tfl_ctx* ctx, const char* op, const char* name, const tfl_tensor* s, const tfl_tensor* flags) {
+  if (!s || !s->data) return fail(ctx, TFL_EINVAL, "%s: %s is null", op, name);
+  if (s->C != 1 || !same_dims(s, flags)) return fail(ctx, TFL_EINVAL, "%s: %s size mismatch", op, name);
+  return TFL_OK;
+}
+#define TRY(x) do { int rc_ = (x); if (rc_ != TFL_OK) return rc_; } while (0)
+
+// generic/advect_type.cc:18-37
+int parse_method(const char* m) {
+  if (!m) return -1;
+  static const char* names[] = {"euler", "maccormack", "eulerOurs", "rk2Ours", "rk3Ours", "maccormackOurs"};
+  for (int i = 0; i < 6; i++) if (strcmp(m, names[i]) == 0) return i;
+  return -1;
+}
+
+float get_dx(const tfl_tensor* f) {  // grid.cc:37-40
+  int m = f->X > f->Y ? f->X : f->Y;
+  if (f->Z > m) m = f->Z;
+  return 1.0f / (float)m;
+}
+
+}  // namespace
+
+extern "C" {
+
+int tfl_abi_version(void) { return TFL_ABI_VERSION; }
+
+tfl_ctx* tfl_create(int device) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return nullptr;
+  if (hipSetDevice(device) != hipSuccess) return nullptr;
+  tfl_ctx* c = new tfl_ctx();
+  c->device = device;
+  if (hipMalloc((void**)&c->d_trace_err, sizeof(unsigned long long)) != hipSuccess ||
+      hipMemset(c->d_trace_err, 0, sizeof(unsigned long long)) != hipSuccess ||
+      hipMalloc((void**)&c->d_resid, sizeof(double) * kMaxBatch) != hipSuccess ||
+      hipHostMalloc((void**)&c->h_resid, sizeof(double) * kMaxBatch, hipHostMallocDefault) != hipSuccess) {
+    tfl_destroy(c);
+    return nullptr;
+  }
+  return c;
+}
+
+void tfl_destroy(tfl_ctx* c) {
+  if (!c) return;
+  if (c->d_trace_err) (void)hipFree(c->d_trace_err);
+  if (c->d_resid) (void)hipFree(c->d_resid);
+  if (c->h_resid) (void)hipHostFree(c->h_resid);
+  delete c;
+}
+
+int tfl_set_stream(tfl_ctx* c, void* s) {
+  if (!c) return TFL_EINVAL;
+  c->stream = (hipStream_t)s;
+  return TFL_OK;
+}
+
+const char* tfl_last_error(const tfl_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+int tfl_synchronize(tfl_ctx* c) {
+  if (!c) return TFL_EINVAL;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return TFL_OK;
+}
+
+int64_t tfl_trace_errors(tfl_ctx* c) {
+  if (!c) return -1;
+  unsigned long long v = 0;
+  if (hipMemcpyAsync(&v, c->d_trace_err, sizeof(v), hipMemcpyDeviceToHost, c->stream) != hipSuccess) return -1;
+  if (hipMemsetAsync(c->d_trace_err, 0, sizeof(v), c->stream) != hipSuccess) return -1;
+  if (hipStreamSynchronize(c->stream) != hipSuccess) return -1;
+  return (int64_t)v;
+}
+
+int tfl_advectScalar(tfl_ctx* c, float dt, const tfl_tensor* s, const tfl_tensor* U, const tfl_tensor* flags,
+                     const tfl_tensor* fwd, const tfl_tensor* bwd, int is3D, const char* method,
+                     const tfl_tensor* fwdPos, const tfl_tensor* bwdPos, int boundaryWidth, int sampleOutsideFluid,
+                     float maccormackStrength, const tfl_tensor* sDst) {
+  (void)bwd; (void)bwdPos; (void)boundaryWidth;  // bnd = 1 like the reference (tfluids.cc:436,467)
+  TRY(check_flags(c, "advectScalar", flags));
+  TRY(check_vel(c, "advectScalar", "U", U, flags, is3D));
+  TRY(check_scalar(c, "advectScalar", "s", s, flags));
+  TRY(check_scalar(c, "advectScalar", "sDst", sDst, flags));
+  const int m = parse_method(method);
+  if (m < 0) return fail(c, TFL_EINVAL, "advectScalar: unknown advection method '%s'", method ? method : "(null)");
+  if (sDst->data == s->data) return fail(c, TFL_EINVAL, "advectScalar: sDst must not alias s");
+  float* fwd_p = nullptr;
+  float* bounds_p = nullptr;
+  if (m == tfl::kMacCormack || m == tfl::kMacCormackOurs) {
+    TRY(check_scalar(c, "advectScalar", "fwd", fwd, flags));
+    fwd_p = fwd->data;
+  }
+  if (m == tfl::kMacCormackOurs) {
+    TRY(check_vel(c, "advectScalar", "fwdPos", fwdPos, flags, is3D));
+    bounds_p = fwdPos->data;
+  }
+  tfl::advect_scalar(c->stream, is3D != 0, m, flags->B, flags->Z, flags->Y, flags->X, dt, maccormackStrength,
+                     sampleOutsideFluid != 0, c->d_trace_err, s->data, U->data, flags->data, fwd_p, bounds_p,
+                     sDst->data);
+  return check_launch(c, "advectScalar");
+}
+
+int tfl_advectVel(tfl_ctx* c, float dt, const tfl_tensor* U, const tfl_tensor* flags, const tfl_tensor* fwd,
+                  const tfl_tensor* bwd, int is3D, const char* method, int boundaryWidth, float maccormackStrength,
+                  const tfl_tensor* UDst) {
+  (void)bwd; (void)boundaryWidth;
+  TRY(check_flags(c, "advectVel", flags));
+  TRY(check_vel(c, "advectVel", "U", U, flags, is3D));
+  TRY(check_vel(c, "advectVel", "UDst", UDst, flags, is3D));
+  int m = parse_method(method);
+  if (m < 0) return fail(c, TFL_EINVAL, "advectVel: unknown advection method '%s'", method ? method : "(null)");
+  if (UDst->data == U->data) return fail(c, TFL_EINVAL, "advectVel: UDst must not alias U");
+  float* fwd_p = nullptr;
+  if (m != tfl::kEuler && m != tfl::kEulerOurs) {
+    TRY(check_vel(c, "advectVel", "fwd", fwd, flags, is3D));
+    fwd_p = fwd->data;
+  }
+  tfl::advect_vel(c->stream, is3D != 0, m, flags->B, flags->Z, flags->Y, flags->X, dt, maccormackStrength,
+                  c->d_trace_err, U->data, flags->data, fwd_p, UDst->data);
+  return check_launch(c, "advectVel");
+}
+
+int tfl_setWallBcsForward(tfl_ctx* c, const tfl_tensor* U, const tfl_tensor* flags, int is3D) {
+  TRY(check_flags(c, "setWallBcsForward", flags));
+  TRY(check_vel(c, "setWallBcsForward", "U", U, flags, is3D));
+  tfl::set_wall_bcs(c->stream, is3D != 0, flags->B, flags->Z, flags->Y, flags->X, U->data, flags->data);
+  return check_launch(c, "setWallBcsForward");
+}
+
+int tfl_velocityDivergenceForward(tfl_ctx* c, const tfl_tensor* U, const tfl_tensor* flags, const tfl_tensor* UDiv,
+                                  int is3D) {
+  TRY(check_flags(c, "velocityDivergenceForward", flags));
+  TRY(check_vel(c, "velocityDivergenceForward", "U", U, flags, is3D));
+  TRY(check_scalar(c, "velocityDivergenceForward", "UDiv", UDiv, flags));
+  tfl::velocity_divergence(c->stream, is3D != 0, flags->B, flags->Z, flags->Y, flags->X, U->data, flags->data,
+                           UDiv->data);
+  return check_launch(c, "velocityDivergenceForward");
+}
+
+int tfl_velocityUpdateForward(tfl_ctx* c, const tfl_tensor* U, const tfl_tensor* flags, const tfl_tensor* p,
+                              int is3D) {
+  TRY(check_flags(c, "velocityUpdateForward", flags));
+  TRY(check_vel(c, "velocityUpdateForward", "U", U, flags, is3D));
+  TRY(check_scalar(c, "velocityUpdateForward", "p", p, flags));
+  tfl::velocity_update(c->stream, is3D != 0, flags->B, flags->Z, flags->Y, flags->X, U->data, flags->data, p->data);
+  return check_launch(c, "velocityUpdateForward");
+}
+
+int tfl_vorticityConfinement(tfl_ctx* c, const tfl_tensor* U, const tfl_tensor* flags, float strength,
+                             const tfl_tensor* centered, const tfl_tensor* curl, const tfl_tensor* curlNorm,
+                             const tfl_tensor* force, int is3D) {
+  (void)centered; (void)force;  // fused away (vorticity.hip)
+  TRY(check_flags(c, "vorticityConfinement", flags));
+  TRY(check_vel(c, "vorticityConfinement", "U", U, flags, is3D));
+  if (!curl || !curl->data || curl->C != 3 || !same_dims(curl, flags))
+    return fail(c, TFL_EINVAL, "vorticityConfinement: curl must be a 3-channel grid of the flags size");
+  TRY(check_scalar(c, "vorticityConfinement", "curlNorm", curlNorm, flags));
+  tfl::vorticity_confinement(c->stream, is3D != 0, flags->B, flags->Z, flags->Y, flags->X, U->data, flags->data,
+                             strength, curl->data, curlNorm->data);
+  return check_launch(c, "vorticityConfinement");
+}
+
+int tfl_addBuoyancy(tfl_ctx* c, const tfl_tensor* U, const tfl_tensor* flags, const tfl_tensor* density,
+                    const float gravity[3], float* strengthTmp, float dt, int is3D) {
+  (void)strengthTmp;
+  TRY(check_flags(c, "addBuoyancy", flags));
+  TRY(check_vel(c, "addBuoyancy", "U", U, flags, is3D));
+  TRY(check_scalar(c, "addBuoyancy", "density", density, flags));
+  if (!gravity) return fail(c, TFL_EINVAL, "addBuoyancy: gravity is null");
+  const float sc = dt / get_dx(flags);  // strength = -gravity * (dt / dx), tfluids.cc:1190-1192
+  tfl::add_buoyancy(c->stream, is3D != 0, flags->B, flags->Z, flags->Y, flags->X, U->data, flags->data,
+                    density->data, -gravity[0] * sc, -gravity[1] * sc, -gravity[2] * sc);
+  return check_launch(c, "addBuoyancy");
+}
+
+int tfl_addGravity(tfl_ctx* c, const tfl_tensor* U, const tfl_tensor* flags, const float gravity[3], float dt,
+                   int is3D, float* forceTmp) {
+  (void)forceTmp;
+  TRY(check_flags(c, "addGravity", flags));
+  TRY(check_vel(c, "addGravity", "U", U, flags, is3D));
+  if (!gravity) return fail(c, TFL_EINVAL, "addGravity: gravity is null");
+  const float sc = dt / get_dx(flags);  // force = gravity * (dt / dx), tfluids.cc:1265-1267
+  tfl::add_gravity(c->stream, is3D != 0, flags->B, flags->Z, flags->Y, flags->X, U->data, flags->data,
+                   gravity[0] * sc, gravity[1] * sc, gravity[2] * sc);
+  return check_launch(c, "addGravity");
+}
+
+int tfl_emptyDomain(tfl_ctx* c, const tfl_tensor* flags, int is3D, int bnd) {
+  TRY(check_flags(c, "emptyDomain", flags));
+  if (!is3D && flags->Z != 1) return fail(c, TFL_EINVAL, "emptyDomain: 2D domain but zdepth > 1");
+  tfl::empty_domain(c->stream, is3D != 0, bnd, flags->B, flags->Z, flags->Y, flags->X, flags->data);
+  return check_launch(c, "emptyDomain");
+}
+
+int tfl_flagsToOccupancy(tfl_ctx* c, const tfl_tensor* flags, const tfl_tensor* occupancy) {
+  TRY(check_flags(c, "flagsToOccupancy", flags));
+  TRY(check_scalar(c, "flagsToOccupancy", "occupancy", occupancy, flags));
+  tfl::flags_to_occupancy(c->stream, (long long)flags->B * flags->Z * flags->Y * flags->X, flags->data,
+                          occupancy->data);
+  return check_launch(c, "flagsToOccupancy");
+}
+
+int tfl_solveLinearSystemJacobi(tfl_ctx* c, const tfl_tensor* p, const tfl_tensor* flags, const tfl_tensor* div,
+                                const tfl_tensor* pPrev, const tfl_tensor* pDelta, const tfl_tensor* pDeltaNorm,
+                                int is3D, float pTol, int maxIter, int verbose, float* residual) {
+  (void)pDelta; (void)pDeltaNorm;
+  TRY(check_flags(c, "solveLinearSystemJacobi", flags));
+  TRY(check_scalar(c, "solveLinearSystemJacobi", "p", p, flags));
+  TRY(check_scalar(c, "solveLinearSystemJacobi", "div", div, flags));
+  TRY(check_scalar(c, "solveLinearSystemJacobi", "pPrev", pPrev, flags));
+  if (!is3D && flags->Z != 1) return fail(c, TFL_EINVAL, "solveLinearSystemJacobi: 2D domain but zdepth > 1");
+  if (maxIter < 1) return fail(c, TFL_EINVAL, "solveLinearSystemJacobi: At least 1 iteration is needed (maxIter < 1)");
+  const int B = flags->B;
+  if (B > kMaxBatch) return fail(c, TFL_EINVAL, "solveLinearSystemJacobi: batch size above %d", kMaxBatch);
+  const size_t bytes = sizeof(float) * (size_t)B * flags->Z * flags->Y * flags->X;
+  // generic/tfluids.cu:1869-1872: both buffers start at zero
+  HIP_TRY(c, hipMemsetAsync(p->data, 0, bytes, c->stream));
+  HIP_TRY(c, hipMemsetAsync(pPrev->data, 0, bytes, c->stream));
+  float* cur = p->data;
+  float* prev = pPrev->data;
+  float res = 0.0f;
+  const bool every = pTol > 0.0f;  // the reference reads the residual back every iteration (:1886);
+                                   // with pTol <= 0 it can never stop early, so only the last one matters
+  int iter = 0;
+  for (;;) {
+    const bool last = (iter + 1 >= maxIter);
+    const bool want = every || (last && residual != nullptr);
+    if (want) HIP_TRY(c, hipMemsetAsync(c->d_resid, 0, sizeof(double) * B, c->stream));
+    tfl::jacobi_iteration(c->stream, is3D != 0, B, flags->Z, flags->Y, flags->X, prev, flags->data, div->data, cur,
+                          want ? c->d_resid : nullptr);
+    if (want) {
+      HIP_TRY(c, hipMemcpyAsync(c->h_resid, c->d_resid, sizeof(double) * B, hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(c, hipStreamSynchronize(c->stream));
+      res = 0.0f;
+      for (int b = 0; b < B; b++) {
+        const float r = (float)std::sqrt(c->h_resid[b]);
+        if (r > res) res = r;
+      }
+      if (verbose) printf("Jacobi iteration %d: residual %e\n", iter + 1, (double)res);
+      if (every && res < pTol) break;
+    }
+    iter++;
+    if (iter >= maxIter) break;
+    float* t = cur; cur = prev; prev = t;
+  }
+  if (cur != p->data) HIP_TRY(c, hipMemcpyAsync(p->data, cur, bytes, hipMemcpyDeviceToDevice, c->stream));
+  if (residual) *residual = res;
+  return check_launch(c, "solveLinearSystemJacobi");
+}
+
+}  // extern "C"

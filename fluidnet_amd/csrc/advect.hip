@@ -1,0 +1,370 @@
+// advect.hip -- semi-Lagrangian / MacCormack advection on the MAC grid (gfx950).
+//
+// Replaces third_party/tfluids.cc:23-920 | tfluids.cu:21-963. The reference runs MacCormack as four
+// grid sweeps plus a copy (fwd, bwd, correct, clamp, copy-back); here it is TWO launches, the minimum
+// the method allows because the backward pass samples the complete forward field:
+//   pass A : forward trace + sample -> fwd   (scalar "Ours": also the clamp bounds of the forward
+//            position, so pass B never needs the traced position again)
+//   pass B : backward trace on fwd + MacCormack correction + clamp -> dst
+// One thread per cell, x fastest: a 64-lane wave covers 64 consecutive x of one row, so the
+// cell-aligned loads/stores are 256-B coalesced rows; the data-dependent taps of the back-trace
+// gather through L1/L2 (neighbouring lanes land in neighbouring cells).
+//
+// Algorithmic HBM bytes per cell (fp32, 3-D): advectScalar 52 B (A: s,U3,flags -> fwd; B: fwd,s,U3,
+// flags -> dst), advectVel 68 B (A: U3,flags -> fwd3; B: fwd3,U3,flags -> dst3); SURVEY.md 8d.
+#include "tfl_device.hpp"
+#include "tfl_host.hpp"
+
+namespace tfl {
+
+struct AdvArgs {
+  Dom d;
+  float dt;
+  float strength;
+  int outside;  // sampleOutsideFluid
+  unsigned long long* err;
+};
+
+#define TFL_CELL_INDEX()                                             \
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;               \
+  const int j = blockIdx.y * blockDim.y + threadIdx.y;               \
+  const int kz = blockIdx.z;                                         \
+  const int b = kz / a.d.Z;                                          \
+  const int k = kz - b * a.d.Z;                                      \
+  if (i >= a.d.X || j >= a.d.Y) return;                              \
+  const Dom& d = a.d;                                                \
+  const long long cells = (long long)d.sc;                           \
+  (void)cells
+
+template <bool IS3D>
+__device__ __forceinline__ float sample_s(const Dom& d, const float* g, const float* flags, v3 p, int outside) {
+  return outside ? interpol<IS3D>(d, g, p) : interpol_with_fluid<IS3D>(d, g, flags, p);
+}
+
+// Manta SemiLagrange, tfluids.cc:209-218
+template <bool IS3D>
+__device__ __forceinline__ float sl_manta(const Dom& d, const float* U, const float* src, float dt, int i, int j, int k) {
+  const v3 c = cell_centre(i, j, k), u = get_centered<IS3D>(d, U, i, j, k);
+  return interpol<IS3D>(d, src, mk3(c.x - u.x * dt, c.y - u.y * dt, c.z - u.z * dt));
+}
+
+// SemiLagrangeEulerOurs[SavePos], tfluids.cc:152-207 (fluid cells only; caller handles the rest)
+template <bool IS3D>
+__device__ __forceinline__ float sl_euler_ours(const AdvArgs& a, const float* flags, const float* U, const float* src,
+                                               float dt, int i, int j, int k, v3& back) {
+  const v3 c = cell_centre(i, j, k);
+  const v3 disp = scale3(get_centered<IS3D>(a.d, U, i, j, k), -dt);
+  count_trace_error(line_trace(a.d, flags, c, disp, back), a.err);
+  return sample_s<IS3D>(a.d, src, flags, back, a.outside);
+}
+
+// SemiLagrangeRK2Ours, tfluids.cc:23-77
+template <bool IS3D>
+__device__ float sl_rk2_ours(const AdvArgs& a, const float* flags, const float* U, const float* src, int i, int j, int k) {
+  const v3 c = cell_centre(i, j, k);
+  v3 half, back;
+  int hit = line_trace(a.d, flags, c, scale3(get_centered<IS3D>(a.d, U, i, j, k), -a.dt * 0.5f), half);
+  count_trace_error(hit, a.err);
+  if (hit > 0) return sample_s<IS3D>(a.d, src, flags, half, a.outside);
+  count_trace_error(line_trace(a.d, flags, c, scale3(sample_vel<IS3D>(a.d, U, half), -a.dt), back), a.err);
+  return sample_s<IS3D>(a.d, src, flags, back, a.outside);
+}
+
+// SemiLagrangeRK3Ours, tfluids.cc:79-147 (CPU variant: a k3 hit samples at k3_pos)
+template <bool IS3D>
+__device__ float sl_rk3_ours(const AdvArgs& a, const float* flags, const float* U, const float* src, int i, int j, int k) {
+  const v3 c = cell_centre(i, j, k);
+  const float dt = a.dt;
+  v3 p2, p3, back;
+  const v3 k1 = get_centered<IS3D>(a.d, U, i, j, k);
+  int hit = line_trace(a.d, flags, c, scale3(k1, -dt * 0.5f), p2);
+  count_trace_error(hit, a.err);
+  if (hit > 0) return sample_s<IS3D>(a.d, src, flags, p2, a.outside);
+  const v3 k2 = sample_vel<IS3D>(a.d, U, p2);
+  hit = line_trace(a.d, flags, c, scale3(k2, -dt * 0.75f), p3);
+  count_trace_error(hit, a.err);
+  if (hit > 0) return sample_s<IS3D>(a.d, src, flags, p3, a.outside);
+  const v3 k3 = sample_vel<IS3D>(a.d, U, p3);
+  // (real)(2.0/9.0) etc. are rounded to float before the multiply, tfluids.cc:135-137
+  const v3 e1 = scale3(k1, -dt * (float)(2.0 / 9.0));
+  const v3 e2 = scale3(k2, -dt * (float)(3.0 / 9.0));
+  const v3 e3 = scale3(k3, -dt * (float)(4.0 / 9.0));
+  const v3 disp = mk3((e1.x + e2.x) + e3.x, (e1.y + e2.y) + e3.y, (e1.z + e2.z) + e3.z);
+  count_trace_error(line_trace(a.d, flags, c, disp, back), a.err);
+  return sample_s<IS3D>(a.d, src, flags, back, a.outside);
+}
+
+__device__ __forceinline__ void minmax(float& lo, float& hi, float v) {
+  if (v < lo) lo = v;
+  if (v > hi) hi = v;
+}
+
+// doClampComponent[MAC], tfluids.cc:250-295 and :701-746. g = channel plane of `orig`.
+template <bool IS3D>
+__device__ float manta_clamp_component(const Dom& d, float dst, const float* __restrict__ g, float fwd, v3 pos, v3 vel) {
+  float lo = 3.402823466e+38f, hi = -3.402823466e+38f;
+#pragma unroll
+  for (int l = 0; l < 2; l++) {
+    int px, py, pz;
+    if (l == 0) { px = (int)(pos.x - vel.x); py = (int)(pos.y - vel.y); pz = (int)(pos.z - vel.z); }
+    else { px = (int)(pos.x + vel.x); py = (int)(pos.y + vel.y); pz = (int)(pos.z + vel.z); }
+    const int i0 = iclampi(px, 0, d.X - 2);
+    const int j0 = iclampi(py, 0, d.Y - 2);
+    const int k0 = iclampi(pz, 0, IS3D ? (d.Z - 2) : 1);
+    const int i1 = i0 + 1, j1 = j0 + 1, k1 = IS3D ? k0 + 1 : k0;
+    // isInBounds(p, 0), grid.cc:42-52: in 2-D z must be exactly 0
+    if (IS3D) { if (k0 < 0 || k1 >= d.Z) return fwd; }
+    else if (k0 != 0 || k1 != 0) return fwd;
+    if (i0 < 0 || j0 < 0 || i1 >= d.X || j1 >= d.Y) return fwd;
+    const int a = TFL_AT(d, i0, j0, k0);
+    minmax(lo, hi, g[a]);
+    minmax(lo, hi, g[a + 1]);
+    minmax(lo, hi, g[a + d.sy]);
+    minmax(lo, hi, g[a + 1 + d.sy]);
+    if (IS3D) {
+      const int c = a + d.sz;
+      minmax(lo, hi, g[c]);
+      minmax(lo, hi, g[c + 1]);
+      minmax(lo, hi, g[c + d.sy]);
+      minmax(lo, hi, g[c + 1 + d.sy]);
+    }
+  }
+  return fclampf(dst, lo, hi);
+}
+
+// Manta MacCormackClamp (scalar), tfluids.cc:297-327
+template <bool IS3D>
+__device__ float manta_clamp_scalar(const Dom& d, const float* flags, const float* U, float dval, const float* orig,
+                                    float fwd, float dt, int i, int j, int k) {
+  const v3 ijk = mk3((float)i, (float)j, (float)k);
+  const v3 ud = scale3(get_centered<IS3D>(d, U, i, j, k), dt);
+  dval = manta_clamp_component<IS3D>(d, dval, orig, fwd, ijk, ud);
+  const int fx = (int)((ijk.x + 0.5f) - ud.x), fy = (int)((ijk.y + 0.5f) - ud.y), fz = (int)((ijk.z + 0.5f) - ud.z);
+  const int bx = (int)((ijk.x + 0.5f) + ud.x), by = (int)((ijk.y + 0.5f) + ud.y), bz = (int)((ijk.z + 0.5f) + ud.z);
+  const int ux = d.X - 1, uy = d.Y - 1, uz = d.Z - 1;
+  if (fx < 0 || fy < 0 || fz < 0 || bx < 0 || by < 0 || bz < 0 || fx > ux || fy > uy || (fz > uz && IS3D) ||
+      bx > ux || by > uy || (bz > uz && IS3D))
+    return fwd;
+  if ((flag_at(d, flags, fx, fy, fz) & kObstacle) || (flag_at(d, flags, bx, by, bz) & kObstacle)) return fwd;
+  return dval;
+}
+
+// getClampBounds, tfluids.cc:331-378: min/max of src over the (fluid) 3^dim neighbourhood of int(pos)
+template <bool IS3D>
+__device__ void ours_clamp_bounds(const Dom& d, const float* __restrict__ flags, const float* __restrict__ src,
+                                  v3 pos, int outside, float& lo, float& hi) {
+  lo = __builtin_inff(); hi = -__builtin_inff();
+  const int i0 = iclampi((int)pos.x, 0, d.X - 1), j0 = iclampi((int)pos.y, 0, d.Y - 1);
+  const int k0 = IS3D ? iclampi((int)pos.z, 0, d.Z - 1) : 0;
+  for (int c = (IS3D ? k0 - 1 : 0); c <= (IS3D ? k0 + 1 : 0); c++) {
+    if (c < 0 || c >= d.Z) continue;
+    for (int bb = j0 - 1; bb <= j0 + 1; bb++) {
+      if (bb < 0 || bb >= d.Y) continue;
+#pragma unroll
+      for (int aa = i0 - 1; aa <= i0 + 1; aa++) {
+        if (aa < 0 || aa >= d.X) continue;
+        const int o = TFL_AT(d, aa, bb, c);
+        if (outside || (((int)flags[o]) & kFluid)) minmax(lo, hi, src[o]);
+      }
+    }
+  }
+}
+
+// ---- advectScalar ------------------------------------------------------------------------------
+// Pass A / single-pass methods. For kMacCormackOurs the clamp bounds go to bounds[0], bounds[1]
+// (two channel planes of the caller's fwdPos temp; empty neighbourhood is stored as lo=+inf > hi).
+template <bool IS3D, int METHOD>
+__global__ __launch_bounds__(256) void k_scalar_fwd(AdvArgs a, const float* __restrict__ s, const float* __restrict__ U,
+                                                    const float* __restrict__ flags, float* __restrict__ out,
+                                                    float* __restrict__ bounds) {
+  TFL_CELL_INDEX();
+  const int C = IS3D ? 3 : 2;
+  s += b * cells; flags += b * cells; out += b * cells; U += b * cells * C;
+  const int o = TFL_AT(d, i, j, k);
+  if (on_border<IS3D>(d, i, j, k)) { out[o] = 0.0f; return; }
+  float v;
+  if (METHOD == kEuler || METHOD == kMacCormack) {
+    v = sl_manta<IS3D>(d, U, s, a.dt, i, j, k);
+  } else {
+    const bool fl = fluid_at(d, flags, i, j, k);
+    v3 back = cell_centre(i, j, k);
+    if (!fl) v = s[o];
+    else if (METHOD == kRK2Ours) v = sl_rk2_ours<IS3D>(a, flags, U, s, i, j, k);
+    else if (METHOD == kRK3Ours) v = sl_rk3_ours<IS3D>(a, flags, U, s, i, j, k);
+    else v = sl_euler_ours<IS3D>(a, flags, U, s, a.dt, i, j, k, back);
+    if (METHOD == kMacCormackOurs) {
+      float lo, hi;
+      ours_clamp_bounds<IS3D>(d, flags, s, back, a.outside, lo, hi);
+      bounds += b * cells * C;
+      bounds[o] = lo;
+      bounds[o + d.sc] = hi;
+    }
+  }
+  out[o] = v;
+}
+
+// Pass B of the two MacCormack flavours: bwd + correct (tfluids.cc:220-234) + clamp (:297-413).
+template <bool IS3D, int METHOD>
+__global__ __launch_bounds__(256) void k_scalar_bwd(AdvArgs a, const float* __restrict__ s, const float* __restrict__ U,
+                                                    const float* __restrict__ flags, const float* __restrict__ fwd,
+                                                    const float* __restrict__ bounds, float* __restrict__ dst) {
+  TFL_CELL_INDEX();
+  const int C = IS3D ? 3 : 2;
+  s += b * cells; flags += b * cells; fwd += b * cells; dst += b * cells; U += b * cells * C;
+  const int o = TFL_AT(d, i, j, k);
+  const bool border = on_border<IS3D>(d, i, j, k);
+  const bool fl = fluid_at(d, flags, i, j, k);
+  const float f = fwd[o];
+  float bwd;
+  if (border) bwd = 0.0f;
+  else if (METHOD == kMacCormack) bwd = sl_manta<IS3D>(d, U, fwd, -a.dt, i, j, k);
+  else if (!fl) bwd = f;
+  else { v3 back; bwd = sl_euler_ours<IS3D>(a, flags, U, fwd, -a.dt, i, j, k, back); }
+  // MacCormackCorrect has no border test; the unsuffixed 0.5 makes the reference evaluate the
+  // correction in double and round once (tfluids.cc:231)
+  float v = f;
+  if (fl) v = (float)((double)f + (double)a.strength * 0.5 * (double)(s[o] - bwd));
+  if (!border) {
+    if (METHOD == kMacCormack) {
+      v = manta_clamp_scalar<IS3D>(d, flags, U, v, s, f, a.dt, i, j, k);
+    } else {
+      bounds += b * cells * C;
+      const float lo = bounds[o], hi = bounds[o + d.sc];
+      v = (lo > hi) ? f : fclampf(v, lo, hi);
+    }
+  }
+  dst[o] = v;
+}
+
+// ---- advectVel ---------------------------------------------------------------------------------
+// SemiLagrange[EulerOurs]MAC of one face component, tfluids.cc:594-658
+template <bool IS3D, bool OURS, int AXIS>
+__device__ __forceinline__ float sl_mac_comp(const AdvArgs& a, const float* flags, const float* U, const float* src,
+                                             float dt, int i, int j, int k) {
+  const v3 ctr = cell_centre(i, j, k);
+  const v3 u = get_at_mac<IS3D, AXIS>(a.d, U, i, j, k);
+  v3 p;
+  if (OURS) count_trace_error(line_trace(a.d, flags, ctr, scale3(u, -dt), p), a.err);
+  else p = mk3(ctr.x - u.x * dt, ctr.y - u.y * dt, ctr.z - u.z * dt);
+  return interpol<IS3D>(a.d, src + AXIS * a.d.sc, p);
+}
+
+template <bool IS3D, bool OURS>
+__global__ __launch_bounds__(256) void k_vel_fwd(AdvArgs a, const float* __restrict__ U, const float* __restrict__ flags,
+                                                 float* __restrict__ out) {
+  TFL_CELL_INDEX();
+  const int C = IS3D ? 3 : 2;
+  flags += b * cells; U += b * cells * C; out += b * cells * C;
+  const int o = TFL_AT(d, i, j, k);
+  float vx = 0.0f, vy = 0.0f, vz = 0.0f;
+  if (!on_border<IS3D>(d, i, j, k)) {
+    if (OURS && !fluid_at(d, flags, i, j, k)) {  // tfluids.cc:598-601
+      vx = U[o]; vy = U[o + d.sc]; if (IS3D) vz = U[o + 2 * d.sc];
+    } else {
+      vx = sl_mac_comp<IS3D, OURS, 0>(a, flags, U, U, a.dt, i, j, k);
+      vy = sl_mac_comp<IS3D, OURS, 1>(a, flags, U, U, a.dt, i, j, k);
+      if (IS3D) vz = sl_mac_comp<IS3D, OURS, 2>(a, flags, U, U, a.dt, i, j, k);
+    }
+  }
+  out[o] = vx; out[o + d.sc] = vy; if (IS3D) out[o + 2 * d.sc] = vz;
+}
+
+template <bool IS3D, bool OURS, int AXIS>
+__device__ __forceinline__ float vel_bwd_comp(const AdvArgs& a, const float* flags, const float* U, const float* fwd,
+                                              bool border, bool fl, bool skip, int i, int j, int k, int o) {
+  const Dom& d = a.d;
+  const float f = fwd[o + AXIS * d.sc];
+  float bwd = 0.0f;
+  if (!border) {
+    if (OURS && !fl) bwd = f;
+    else bwd = sl_mac_comp<IS3D, OURS, AXIS>(a, flags, U, fwd, -a.dt, i, j, k);
+  }
+  float v = f;
+  // MacCormackCorrectMAC, tfluids.cc:660-699 (double arithmetic through the unsuffixed 0.5, :693)
+  if (!skip) v = (float)((double)f + (double)a.strength * 0.5 * (double)(U[o + AXIS * d.sc] - bwd));
+  if (!border) {  // MacCormackClampMAC, tfluids.cc:748-774
+    const v3 ud = scale3(get_at_mac<IS3D, AXIS>(d, U, i, j, k), a.dt);
+    v = manta_clamp_component<IS3D>(d, v, U + AXIS * d.sc, f, mk3((float)i, (float)j, (float)k), ud);
+  }
+  return v;
+}
+
+template <bool IS3D, bool OURS>
+__global__ __launch_bounds__(256) void k_vel_bwd(AdvArgs a, const float* __restrict__ U, const float* __restrict__ flags,
+                                                 const float* __restrict__ fwd, float* __restrict__ dst) {
+  TFL_CELL_INDEX();
+  const int C = IS3D ? 3 : 2;
+  flags += b * cells; U += b * cells * C; fwd += b * cells * C; dst += b * cells * C;
+  const int o = TFL_AT(d, i, j, k);
+  const bool border = on_border<IS3D>(d, i, j, k);
+  const bool fl = fluid_at(d, flags, i, j, k);
+  const bool sx = !fl || (i > 0 && !fluid_at(d, flags, i - 1, j, k));
+  const bool sy = !fl || (j > 0 && !fluid_at(d, flags, i, j - 1, k));
+  dst[o] = vel_bwd_comp<IS3D, OURS, 0>(a, flags, U, fwd, border, fl, sx, i, j, k, o);
+  dst[o + d.sc] = vel_bwd_comp<IS3D, OURS, 1>(a, flags, U, fwd, border, fl, sy, i, j, k, o);
+  if (IS3D) {
+    const bool sz = !fl || (k > 0 && !fluid_at(d, flags, i, j, k - 1));
+    dst[o + 2 * d.sc] = vel_bwd_comp<IS3D, OURS, 2>(a, flags, U, fwd, border, fl, sz, i, j, k, o);
+  }
+}
+
+// ---- host launchers ----------------------------------------------------------------------------
+static inline dim3 cell_grid(const Dom& d, int B, dim3 blk) {
+  return dim3((d.X + blk.x - 1) / blk.x, (d.Y + blk.y - 1) / blk.y, (unsigned)(d.Z * B));
+}
+
+template <bool IS3D>
+static void launch_scalar(hipStream_t st, int method, const AdvArgs& a, int B, const float* s, const float* U,
+                          const float* flags, float* fwd, float* bounds, float* dst) {
+  const dim3 blk(64, 4, 1), grd = cell_grid(a.d, B, blk);
+  switch (method) {
+    case kEuler: k_scalar_fwd<IS3D, kEuler><<<grd, blk, 0, st>>>(a, s, U, flags, dst, nullptr); break;
+    case kEulerOurs: k_scalar_fwd<IS3D, kEulerOurs><<<grd, blk, 0, st>>>(a, s, U, flags, dst, nullptr); break;
+    case kRK2Ours: k_scalar_fwd<IS3D, kRK2Ours><<<grd, blk, 0, st>>>(a, s, U, flags, dst, nullptr); break;
+    case kRK3Ours: k_scalar_fwd<IS3D, kRK3Ours><<<grd, blk, 0, st>>>(a, s, U, flags, dst, nullptr); break;
+    case kMacCormack:
+      k_scalar_fwd<IS3D, kMacCormack><<<grd, blk, 0, st>>>(a, s, U, flags, fwd, nullptr);
+      k_scalar_bwd<IS3D, kMacCormack><<<grd, blk, 0, st>>>(a, s, U, flags, fwd, nullptr, dst);
+      break;
+    default:
+      k_scalar_fwd<IS3D, kMacCormackOurs><<<grd, blk, 0, st>>>(a, s, U, flags, fwd, bounds);
+      k_scalar_bwd<IS3D, kMacCormackOurs><<<grd, blk, 0, st>>>(a, s, U, flags, fwd, bounds, dst);
+      break;
+  }
+}
+
+void advect_scalar(hipStream_t st, bool is3d, int method, int B, int Z, int Y, int X, float dt, float strength,
+                   int outside, unsigned long long* err, const float* s, const float* U, const float* flags,
+                   float* fwd, float* bounds, float* dst) {
+  AdvArgs a; a.d = make_dom(Z, Y, X); a.dt = dt; a.strength = strength; a.outside = outside; a.err = err;
+  if (is3d) launch_scalar<true>(st, method, a, B, s, U, flags, fwd, bounds, dst);
+  else launch_scalar<false>(st, method, a, B, s, U, flags, fwd, bounds, dst);
+}
+
+template <bool IS3D>
+static void launch_vel(hipStream_t st, int method, const AdvArgs& a, int B, const float* U, const float* flags,
+                       float* fwd, float* dst) {
+  const dim3 blk(64, 4, 1), grd = cell_grid(a.d, B, blk);
+  switch (method) {
+    case kEuler: k_vel_fwd<IS3D, false><<<grd, blk, 0, st>>>(a, U, flags, dst); break;
+    case kEulerOurs: k_vel_fwd<IS3D, true><<<grd, blk, 0, st>>>(a, U, flags, dst); break;
+    case kMacCormack:
+      k_vel_fwd<IS3D, false><<<grd, blk, 0, st>>>(a, U, flags, fwd);
+      k_vel_bwd<IS3D, false><<<grd, blk, 0, st>>>(a, U, flags, fwd, dst);
+      break;
+    default:
+      k_vel_fwd<IS3D, true><<<grd, blk, 0, st>>>(a, U, flags, fwd);
+      k_vel_bwd<IS3D, true><<<grd, blk, 0, st>>>(a, U, flags, fwd, dst);
+      break;
+  }
+}
+
+void advect_vel(hipStream_t st, bool is3d, int method, int B, int Z, int Y, int X, float dt, float strength,
+                unsigned long long* err, const float* U, const float* flags, float* fwd, float* dst) {
+  if (method == kRK2Ours || method == kRK3Ours) method = kMacCormackOurs;  // tfluids.cc:799-802
+  AdvArgs a; a.d = make_dom(Z, Y, X); a.dt = dt; a.strength = strength; a.outside = 0; a.err = err;
+  if (is3d) launch_vel<true>(st, method, a, B, U, flags, fwd, dst);
+  else launch_vel<false>(st, method, a, B, U, flags, fwd, dst);
+}
+
+}  // namespace tfl

@@ -1,0 +1,183 @@
+// stencil.hip -- the one-sweep MAC-grid operators (gfx950): setWallBcs, velocityDivergence,
+// velocityUpdate, addBuoyancy, addGravity, emptyDomain, flagsToOccupancy.
+//
+// All are HBM-bound: each cell reads its own words plus the -c / +c face neighbours, which the
+// neighbouring lanes (x) or the L2 (y, z rows) already hold. One thread per cell, x fastest, 64x4
+// thread blocks => 256-B coalesced rows. Algorithmic bytes per cell (3-D): setWallBcs 28,
+// divergence 20, velocityUpdate 32, addBuoyancy 32.
+#include "tfl_device.hpp"
+#include "tfl_host.hpp"
+
+namespace tfl {
+
+#define TFL_STENCIL_INDEX()                                          \
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;               \
+  const int j = blockIdx.y * blockDim.y + threadIdx.y;               \
+  const int kz = blockIdx.z;                                         \
+  const int b = kz / d.Z;                                            \
+  const int k = kz - b * d.Z;                                        \
+  if (i >= d.X || j >= d.Y) return;                                  \
+  const long long cells = (long long)d.sc;                           \
+  const int C = IS3D ? 3 : 2;                                        \
+  (void)C; (void)cells;                                              \
+  const int o = TFL_AT(d, i, j, k)
+
+// third_party/tfluids.cc:926-1002
+template <bool IS3D>
+__global__ __launch_bounds__(256) void k_set_wall_bcs(Dom d, float* __restrict__ U, const float* __restrict__ flags) {
+  TFL_STENCIL_INDEX();
+  U += b * cells * C; flags += b * cells;
+  const int fc = (int)flags[o];
+  const bool cf = fc & kFluid, co = fc & kObstacle;
+  if (!cf && !co) return;
+  const int fxm = i > 0 ? (int)flags[o - 1] : 0;
+  const int fym = j > 0 ? (int)flags[o - d.sy] : 0;
+  const int fzm = (IS3D && k > 0) ? (int)flags[o - d.sz] : 0;
+  bool zx = (fxm & kObstacle) || (co && (fxm & kFluid));
+  bool zy = (fym & kObstacle) || (co && (fym & kFluid));
+  bool zz = IS3D && ((fzm & kObstacle) || (co && (fzm & kFluid)));
+  if (cf) {
+    const int fxp = i < d.X - 1 ? (int)flags[o + 1] : 0;
+    const int fyp = j < d.Y - 1 ? (int)flags[o + d.sy] : 0;
+    const int fzp = (IS3D && k < d.Z - 1) ? (int)flags[o + d.sz] : 0;
+    if ((fxm & kStick) || (fxp & kStick)) { zy = true; zz = IS3D; }
+    if ((fym & kStick) || (fyp & kStick)) { zx = true; zz = zz || IS3D; }
+    if (IS3D && ((fzm & kStick) || (fzp & kStick))) { zx = true; zy = true; }
+  }
+  if (zx) U[o] = 0.0f;
+  if (zy) U[o + d.sc] = 0.0f;
+  if (IS3D && zz) U[o + 2 * d.sc] = 0.0f;
+}
+
+// third_party/tfluids.cc:1008-1066 (negative divergence, Manta makeRhs convention)
+template <bool IS3D>
+__global__ __launch_bounds__(256) void k_divergence(Dom d, const float* __restrict__ U, const float* __restrict__ flags,
+                                                    float* __restrict__ div) {
+  TFL_STENCIL_INDEX();
+  U += b * cells * C; flags += b * cells; div += b * cells;
+  float v = 0.0f;
+  if (!on_border<IS3D>(d, i, j, k) && (((int)flags[o]) & kFluid)) {
+    v = U[o] - U[o + 1] + U[o + d.sc] - U[o + d.sc + d.sy];
+    if (IS3D) v += (U[o + 2 * d.sc] - U[o + 2 * d.sc + d.sz]);
+  }
+  div[o] = v;
+}
+
+// third_party/tfluids.cc:1072-1156
+template <bool IS3D>
+__global__ __launch_bounds__(256) void k_velocity_update(Dom d, float* __restrict__ U, const float* __restrict__ flags,
+                                                         const float* __restrict__ p) {
+  TFL_STENCIL_INDEX();
+  if (on_border<IS3D>(d, i, j, k)) return;
+  U += b * cells * C; flags += b * cells; p += b * cells;
+  const int fc = (int)flags[o];
+  const int fx = (int)flags[o - 1], fy = (int)flags[o - d.sy], fz = IS3D ? (int)flags[o - d.sz] : 0;
+  if (fc & kFluid) {
+    const float pc = p[o];
+    float ux = U[o], uy = U[o + d.sc];
+    if (fx & kFluid) ux -= (pc - p[o - 1]);
+    if (fy & kFluid) uy -= (pc - p[o - d.sy]);
+    if (fx & kEmpty) ux -= pc;
+    if (fy & kEmpty) uy -= pc;
+    U[o] = ux; U[o + d.sc] = uy;
+    if (IS3D) {
+      float uz = U[o + 2 * d.sc];
+      if (fz & kFluid) uz -= (pc - p[o - d.sz]);
+      if (fz & kEmpty) uz -= pc;
+      U[o + 2 * d.sc] = uz;
+    }
+  } else if ((fc & kEmpty) && !(fc & kOutflow)) {
+    U[o] = (fx & kFluid) ? U[o] + p[o - 1] : 0.0f;
+    U[o + d.sc] = (fy & kFluid) ? U[o + d.sc] + p[o - d.sy] : 0.0f;
+    if (IS3D) U[o + 2 * d.sc] = (fz & kFluid) ? U[o + 2 * d.sc] + p[o - d.sz] : 0.0f;
+  }
+}
+
+// third_party/tfluids.cc:1162-1233; (sx,sy,sz) = -gravity * dt / dx computed on the host
+template <bool IS3D>
+__global__ __launch_bounds__(256) void k_add_buoyancy(Dom d, float* __restrict__ U, const float* __restrict__ flags,
+                                                      const float* __restrict__ rho, float sx, float sy, float sz) {
+  TFL_STENCIL_INDEX();
+  if (on_border<IS3D>(d, i, j, k)) return;
+  U += b * cells * C; flags += b * cells; rho += b * cells;
+  if (!(((int)flags[o]) & kFluid)) return;
+  const float r = rho[o];
+  if (((int)flags[o - 1]) & kFluid) U[o] += (0.5f * sx * (r + rho[o - 1]));
+  if (((int)flags[o - d.sy]) & kFluid) U[o + d.sc] += (0.5f * sy * (r + rho[o - d.sy]));
+  if (IS3D && (((int)flags[o - d.sz]) & kFluid)) U[o + 2 * d.sc] += (0.5f * sz * (r + rho[o - d.sz]));
+}
+
+// third_party/tfluids.cc:1239-1306
+template <bool IS3D>
+__global__ __launch_bounds__(256) void k_add_gravity(Dom d, float* __restrict__ U, const float* __restrict__ flags,
+                                                     float fx, float fy, float fz) {
+  TFL_STENCIL_INDEX();
+  if (on_border<IS3D>(d, i, j, k)) return;
+  U += b * cells * C; flags += b * cells;
+  const int fc = (int)flags[o];
+  const bool cf = fc & kFluid, ce = fc & kEmpty;
+  if (!cf && !ce) return;
+  const int nx = (int)flags[o - 1], ny = (int)flags[o - d.sy], nz = IS3D ? (int)flags[o - d.sz] : 0;
+  if ((nx & kFluid) || (cf && (nx & kEmpty))) U[o] += fx;
+  if ((ny & kFluid) || (cf && (ny & kEmpty))) U[o + d.sc] += fy;
+  if (IS3D && ((nz & kFluid) || (cf && (nz & kEmpty)))) U[o + 2 * d.sc] += fz;
+}
+
+// generic/tfluids.cc:136-167
+template <bool IS3D>
+__global__ __launch_bounds__(256) void k_empty_domain(Dom d, int bnd, float* __restrict__ flags) {
+  TFL_STENCIL_INDEX();
+  flags += b * cells;
+  const bool border = i < bnd || i > d.X - 1 - bnd || j < bnd || j > d.Y - 1 - bnd ||
+                      (IS3D && (k < bnd || k > d.Z - 1 - bnd));
+  flags[o] = border ? (float)kObstacle : (float)kFluid;
+}
+
+// generic/tfluids.cc:173-210 | generic/tfluids.cu:355-371 (other cell types -> -1 like the CUDA path)
+__global__ __launch_bounds__(256) void k_flags_to_occupancy(long long n, const float* __restrict__ flags,
+                                                            float* __restrict__ occ) {
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) {
+    const int f = (int)flags[t];
+    occ[t] = (f == kFluid) ? 0.0f : ((f == kObstacle) ? 1.0f : -1.0f);
+  }
+}
+
+static inline dim3 cgrid(const Dom& d, int B, dim3 blk) {
+  return dim3((d.X + blk.x - 1) / blk.x, (d.Y + blk.y - 1) / blk.y, (unsigned)(d.Z * B));
+}
+#define TFL_LAUNCH(kern, ...)                                        \
+  do {                                                               \
+    const Dom d = make_dom(Z, Y, X);                                 \
+    const dim3 blk(64, 4, 1), grd = cgrid(d, B, blk);                \
+    if (is3d) kern<true><<<grd, blk, 0, st>>>(d, __VA_ARGS__);       \
+    else kern<false><<<grd, blk, 0, st>>>(d, __VA_ARGS__);           \
+  } while (0)
+
+void set_wall_bcs(hipStream_t st, bool is3d, int B, int Z, int Y, int X, float* U, const float* flags) {
+  TFL_LAUNCH(k_set_wall_bcs, U, flags);
+}
+void velocity_divergence(hipStream_t st, bool is3d, int B, int Z, int Y, int X, const float* U, const float* flags,
+                         float* div) {
+  TFL_LAUNCH(k_divergence, U, flags, div);
+}
+void velocity_update(hipStream_t st, bool is3d, int B, int Z, int Y, int X, float* U, const float* flags,
+                     const float* p) {
+  TFL_LAUNCH(k_velocity_update, U, flags, p);
+}
+void add_buoyancy(hipStream_t st, bool is3d, int B, int Z, int Y, int X, float* U, const float* flags,
+                  const float* density, float sx, float sy, float sz) {
+  TFL_LAUNCH(k_add_buoyancy, U, flags, density, sx, sy, sz);
+}
+void add_gravity(hipStream_t st, bool is3d, int B, int Z, int Y, int X, float* U, const float* flags, float fx,
+                 float fy, float fz) {
+  TFL_LAUNCH(k_add_gravity, U, flags, fx, fy, fz);
+}
+void empty_domain(hipStream_t st, bool is3d, int bnd, int B, int Z, int Y, int X, float* flags) {
+  TFL_LAUNCH(k_empty_domain, bnd, flags);
+}
+void flags_to_occupancy(hipStream_t st, long long numel, const float* flags, float* occ) {
+  const int blocks = (int)((numel + 255) / 256 < 2048 ? (numel + 255) / 256 : 2048);
+  k_flags_to_occupancy<<<blocks > 0 ? blocks : 1, 256, 0, st>>>(numel, flags, occ);
+}
+
+}  // namespace tfl

@@ -1,0 +1,328 @@
+// tfl_device.hpp -- device-side grid primitives of the MI355X tfluids path (gfx950 only).
+//
+// Semantics follow the reference's CPU float path (the parity target):
+//   grid views / samplers   torch/tfluids/third_party/grid.cc:26-515
+//   vec3 thresholded norm   torch/tfluids/generic/vec3.h:119-141
+//   line trace              torch/tfluids/generic/calc_line_trace.cc:313-503
+// Everything is fp32 with the reference's association order; the library is compiled with
+// -ffp-contract=off so no FMA contraction can flip a branch inside the trace or a clamp.
+//
+// Data layout in HBM: contiguous [B][C][Z][Y][X] fp32, x fastest. A MAC component c of cell
+// (i,j,k) lives on the cell's NEGATIVE c-face; cell centres sit at (i+.5, j+.5, k+.5).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace tfl {
+
+enum : int { kFluid = 1, kObstacle = 2, kEmpty = 4, kInflow = 8, kOutflow = 16, kOpen = 32,
+             kStick = 128 };
+// generic/advect_type.h:20-27
+enum : int { kEuler = 0, kMacCormack = 1, kEulerOurs = 2, kRK2Ours = 3, kRK3Ours = 4,
+             kMacCormackOurs = 5 };
+
+struct v3 { float x, y, z; };
+
+__device__ __forceinline__ v3 mk3(float x, float y, float z) { v3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ v3 scale3(v3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
+
+// One batch item's geometry. Element strides fit int32 for every grid the path supports
+// (C*Z*Y*X < 2^31); the batch offset is applied to the base pointers in 64-bit by the caller.
+struct Dom {
+  int X, Y, Z;
+  int sy, sz, sc;  // element strides of y, z and channel
+};
+
+__host__ __device__ inline Dom make_dom(int Z, int Y, int X) {
+  Dom d; d.X = X; d.Y = Y; d.Z = Z; d.sy = X; d.sz = X * Y; d.sc = X * Y * Z; return d;
+}
+
+#define TFL_AT(d, i, j, k) ((i) + (j) * (d).sy + (k) * (d).sz)
+
+template <bool IS3D>
+__device__ __forceinline__ bool on_border(const Dom& d, int i, int j, int k) {
+  // bnd = 1 is hard-coded in every op (third_party/tfluids.cc:467)
+  return i < 1 || i > d.X - 2 || j < 1 || j > d.Y - 2 || (IS3D && (k < 1 || k > d.Z - 2));
+}
+
+__device__ __forceinline__ int flag_at(const Dom& d, const float* __restrict__ f, int i, int j, int k) {
+  return (int)f[TFL_AT(d, i, j, k)];
+}
+__device__ __forceinline__ bool fluid_at(const Dom& d, const float* __restrict__ f, int i, int j, int k) {
+  return (flag_at(d, f, i, j, k) & kFluid) != 0;
+}
+
+__device__ __forceinline__ int iclampi(int v, int lo, int hi) { return max(min(v, hi), lo); }
+// std::min<real>(hi, std::max<real>(lo, v)), third_party/tfluids.cc:246-248
+__device__ __forceinline__ float fclampf(float v, float lo, float hi) {
+  float m = (lo < v) ? v : lo;
+  return (m < hi) ? m : hi;
+}
+__device__ __forceinline__ float stdmin(float a, float b) { return (b < a) ? b : a; }
+__device__ __forceinline__ float stdmax(float a, float b) { return (a < b) ? b : a; }
+
+// vec3::norm / normalize with their thresholds (float kEpsilon = 1e-6f), generic/vec3.h:119-141
+__device__ __forceinline__ float norm3(v3 a) {
+  float l2 = a.x * a.x + a.y * a.y + a.z * a.z;
+  return (l2 > 1e-6f) ? sqrtf(l2) : 0.0f;
+}
+__device__ __forceinline__ v3 normalize3(v3 a) {
+  float n = norm3(a);
+  if (n > 1e-6f) return mk3(a.x / n, a.y / n, a.z / n);
+  return mk3(0.0f, 0.0f, 0.0f);
+}
+
+// ---- MAC samplers, third_party/grid.cc:346-417 ------------------------------------------------
+template <bool IS3D>
+__device__ __forceinline__ v3 get_centered(const Dom& d, const float* __restrict__ U, int i, int j, int k) {
+  const int a = TFL_AT(d, i, j, k);
+  v3 r;
+  r.x = 0.5f * (U[a] + U[a + 1]);
+  r.y = 0.5f * (U[a + d.sc] + U[a + d.sc + d.sy]);
+  r.z = IS3D ? 0.5f * (U[a + 2 * d.sc] + U[a + 2 * d.sc + d.sz]) : 0.0f;
+  return r;
+}
+
+template <bool IS3D, int AXIS>
+__device__ __forceinline__ v3 get_at_mac(const Dom& d, const float* __restrict__ U, int i, int j, int k) {
+  const int a = TFL_AT(d, i, j, k);
+  const float* Ux = U;
+  const float* Uy = U + d.sc;
+  const float* Uz = U + 2 * d.sc;
+  v3 r;
+  if (AXIS == 0) {
+    r.x = Ux[a];
+    r.y = 0.25f * (Uy[a] + Uy[a - 1] + Uy[a + d.sy] + Uy[a - 1 + d.sy]);
+    r.z = IS3D ? 0.25f * (Uz[a] + Uz[a - 1] + Uz[a + d.sz] + Uz[a - 1 + d.sz]) : 0.0f;
+  } else if (AXIS == 1) {
+    r.x = 0.25f * (Ux[a] + Ux[a - d.sy] + Ux[a + 1] + Ux[a + 1 - d.sy]);
+    r.y = Uy[a];
+    r.z = IS3D ? 0.25f * (Uz[a] + Uz[a - d.sy] + Uz[a + d.sz] + Uz[a - d.sy + d.sz]) : 0.0f;
+  } else {
+    r.x = 0.25f * (Ux[a] + Ux[a - d.sz] + Ux[a + 1] + Ux[a + 1 - d.sz]);
+    r.y = 0.25f * (Uy[a] + Uy[a - d.sz] + Uy[a + d.sy] + Uy[a + d.sy - d.sz]);
+    r.z = IS3D ? Uz[a] : 0.0f;
+  }
+  return r;
+}
+
+// ---- interpolation, third_party/grid.cc:82-130 (buildIndex), :182-202, :204-332 ----------------
+struct Lerp { int xi, yi, zi; float s0, s1, t0, t1, f0, f1; };
+
+template <bool IS3D>
+__device__ __forceinline__ Lerp build_index(const Dom& d, v3 pos) {
+  Lerp L;
+  const float px = pos.x - 0.5f, py = pos.y - 0.5f, pz = pos.z - 0.5f;
+  L.xi = (int)px; L.yi = (int)py; L.zi = (int)pz;
+  L.s1 = px - (float)L.xi; L.s0 = 1.0f - L.s1;
+  L.t1 = py - (float)L.yi; L.t0 = 1.0f - L.t1;
+  L.f1 = pz - (float)L.zi; L.f0 = 1.0f - L.f1;
+  if (px < 0.0f) { L.xi = 0; L.s0 = 1.0f; L.s1 = 0.0f; }
+  if (py < 0.0f) { L.yi = 0; L.t0 = 1.0f; L.t1 = 0.0f; }
+  if (pz < 0.0f) { L.zi = 0; L.f0 = 1.0f; L.f1 = 0.0f; }
+  if (L.xi >= d.X - 1) { L.xi = d.X - 2; L.s0 = 0.0f; L.s1 = 1.0f; }
+  if (L.yi >= d.Y - 1) { L.yi = d.Y - 2; L.t0 = 0.0f; L.t1 = 1.0f; }
+  if (IS3D) {
+    if (L.zi >= d.Z - 1) { L.zi = d.Z - 2; L.f0 = 0.0f; L.f1 = 1.0f; }
+  } else {
+    L.zi = 0;  // Z == 1: the 2-D samplers only ever touch plane 0
+  }
+  return L;
+}
+
+// plain bi/tri-linear sample of one channel plane
+template <bool IS3D>
+__device__ __forceinline__ float interpol(const Dom& d, const float* __restrict__ g, v3 pos) {
+  const Lerp L = build_index<IS3D>(d, pos);
+  const int a = TFL_AT(d, L.xi, L.yi, L.zi);
+  const float lo = (g[a] * L.t0 + g[a + d.sy] * L.t1) * L.s0 +
+                   (g[a + 1] * L.t0 + g[a + 1 + d.sy] * L.t1) * L.s1;
+  if (!IS3D) return lo;
+  const int b = a + d.sz;
+  const float hi = (g[b] * L.t0 + g[b + d.sy] * L.t1) * L.s0 +
+                   (g[b + 1] * L.t0 + g[b + 1 + d.sy] * L.t1) * L.s1;
+  return lo * L.f0 + hi * L.f1;
+}
+
+// 1-D lerp that drops non-fluid taps, grid.cc:204-222
+__device__ __forceinline__ void lerp_fluid(float va, bool fa, float vb, bool fb, float ta, float tb,
+                                           bool& fo, float& vo) {
+  if (!fa && !fb) { vo = 0.0f; fo = false; }
+  else if (!fa) { vo = vb; fo = true; }
+  else if (!fb) { vo = va; fo = true; }
+  else { vo = va * ta + vb * tb; fo = true; }
+}
+
+template <bool IS3D>
+__device__ __forceinline__ float interpol_with_fluid(const Dom& d, const float* __restrict__ g,
+                                                     const float* __restrict__ flags, v3 pos) {
+  const Lerp L = build_index<IS3D>(d, pos);
+  const int a = TFL_AT(d, L.xi, L.yi, L.zi);
+  auto fl = [&](int off) { return ((int)flags[off] & kFluid) != 0; };
+  bool f_ab, f_cd, f_abcd, fo;
+  float v_ab, v_cd, v_abcd, val;
+  lerp_fluid(g[a], fl(a), g[a + d.sy], fl(a + d.sy), L.t0, L.t1, f_ab, v_ab);
+  lerp_fluid(g[a + 1], fl(a + 1), g[a + 1 + d.sy], fl(a + 1 + d.sy), L.t0, L.t1, f_cd, v_cd);
+  lerp_fluid(v_ab, f_ab, v_cd, f_cd, L.s0, L.s1, f_abcd, v_abcd);
+  if (IS3D) {
+    const int b = a + d.sz;
+    bool f_ef, f_gh, f_efgh;
+    float v_ef, v_gh, v_efgh;
+    lerp_fluid(g[b], fl(b), g[b + d.sy], fl(b + d.sy), L.t0, L.t1, f_ef, v_ef);
+    lerp_fluid(g[b + 1], fl(b + 1), g[b + 1 + d.sy], fl(b + 1 + d.sy), L.t0, L.t1, f_gh, v_gh);
+    lerp_fluid(v_ef, f_ef, v_gh, f_gh, L.s0, L.s1, f_efgh, v_efgh);
+    lerp_fluid(v_abcd, f_abcd, v_efgh, f_efgh, L.f0, L.f1, fo, val);
+  } else {
+    fo = f_abcd; val = v_abcd;
+  }
+  return fo ? val : interpol<IS3D>(d, g, pos);
+}
+
+template <bool IS3D>
+__device__ __forceinline__ v3 sample_vel(const Dom& d, const float* __restrict__ U, v3 p) {
+  v3 r;
+  r.x = interpol<IS3D>(d, U, p);
+  r.y = interpol<IS3D>(d, U + d.sc, p);
+  r.z = IS3D ? interpol<IS3D>(d, U + 2 * d.sc, p) : 0.0f;
+  return r;
+}
+
+// ---- line trace, generic/calc_line_trace.cc ----------------------------------------------------
+#define TFL_HIT_MARGIN 1e-5f  // calc_line_trace.cc:22
+#define TFL_TRACE_EPS 1e-12f  // calc_line_trace.cc:23
+
+__device__ __forceinline__ bool out_of_domain(const Dom& d, v3 p) {  // :43-51 (walls count as outside)
+  return p.x <= 0.0f || p.x >= (float)d.X || p.y <= 0.0f || p.y >= (float)d.Y || p.z <= 0.0f ||
+         p.z >= (float)d.Z;
+}
+// :86-91 + :53-62; -1 when the cell index falls outside the grid (the CPU reference raises)
+__device__ __forceinline__ int blocked_at(const Dom& d, const float* __restrict__ flags, v3 p) {
+  const int i = (int)p.x, j = (int)p.y, k = (int)p.z;
+  if (i < 0 || i >= d.X || j < 0 || j >= d.Y || k < 0 || k >= d.Z) return -1;
+  return fluid_at(d, flags, i, j, k) ? 0 : 1;
+}
+
+// Ray/box test, calc_line_trace.cc:101-171
+__device__ inline bool ray_box(const float* lo, const float* hi, const float* org, const float* dir,
+                               float* out) {
+  bool inside = true;
+  int quad[3];
+  float plane[3], tmax[3];
+  const float err_tol = 1e-6f;
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+    if (org[a] < lo[a]) { quad[a] = 1; plane[a] = lo[a]; inside = false; }
+    else if (org[a] > hi[a]) { quad[a] = 0; plane[a] = hi[a]; inside = false; }
+    else { quad[a] = 2; plane[a] = 0.0f; }
+  }
+  if (inside) { out[0] = org[0]; out[1] = org[1]; out[2] = org[2]; return true; }
+#pragma unroll
+  for (int a = 0; a < 3; a++)
+    tmax[a] = (quad[a] != 2 && dir[a] != 0.0f) ? (plane[a] - org[a]) / dir[a] : -1.0f;
+  int which = 0;
+  if (tmax[which] < tmax[1]) which = 1;
+  if (tmax[which] < tmax[2]) which = 2;
+  if (tmax[which] < 0.0f) return false;
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+    if (which != a) {
+      out[a] = org[a] + tmax[which] * dir[a];
+      if (out[a] < (lo[a] - err_tol) || out[a] > (hi[a] + err_tol)) return false;
+    } else {
+      out[a] = plane[a];
+    }
+  }
+  return true;
+}
+
+// calc_line_trace.cc:205-286: pull `next` back onto the domain wall inset by the hit margin
+__device__ inline bool ray_border(const Dom& d, v3 pos, v3 next, v3& ipos) {
+  float min_step = 3.402823466e+38f;
+  const float p[3] = {pos.x, pos.y, pos.z}, n[3] = {next.x, next.y, next.z};
+  const float sz[3] = {(float)d.X, (float)d.Y, (float)d.Z};
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+    if (n[a] <= TFL_HIT_MARGIN) {
+      const float dd = n[a] - p[a];
+      if (fabsf(dd) >= TFL_TRACE_EPS) { const float st = (TFL_HIT_MARGIN - p[a]) / dd; if (st < min_step) min_step = st; }
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+    if (n[a] >= (sz[a] - TFL_HIT_MARGIN)) {
+      const float dd = n[a] - p[a];
+      if (fabsf(dd) >= TFL_TRACE_EPS) { const float st = (sz[a] - TFL_HIT_MARGIN - p[a]) / dd; if (st < min_step) min_step = st; }
+    }
+  }
+  if (min_step < 0.0f || min_step >= 3.402823466e+38f) return false;
+  ipos.x = min_step * (next.x - pos.x) + pos.x;
+  ipos.y = min_step * (next.y - pos.y) + pos.y;
+  ipos.z = min_step * (next.z - pos.z) + pos.z;
+  return true;
+}
+
+// calcLineTrace, calc_line_trace.cc:313-503. Returns 1 = hit, 0 = no hit, <0 = an invariant the
+// CPU reference raises on (callers count these into tfl_ctx's error word and carry on with the last
+// valid position, the way the reference's CUDA build does).
+__device__ inline int line_trace(const Dom& d, const float* __restrict__ flags, v3 pos, v3 delta,
+                                 v3& out) {
+  out = pos;
+  const float length = norm3(delta);
+  if (length <= TFL_TRACE_EPS) return 0;
+  const v3 dt = mk3(delta.x / length, delta.y / length, delta.z / length);
+  float cur = 0.0f;
+  while (cur < (length - TFL_HIT_MARGIN)) {
+    const float step = stdmin(length - cur, 1.0f);
+    v3 next = mk3(out.x + dt.x * step, out.y + dt.y * step, out.z + dt.z * step);
+    if (out_of_domain(d, next)) {
+      v3 ip;
+      if (!ray_border(d, out, next, ip)) {
+        ip.x = stdmin(stdmax(next.x, TFL_HIT_MARGIN), (float)d.X - TFL_HIT_MARGIN);
+        ip.y = stdmin(stdmax(next.y, TFL_HIT_MARGIN), (float)d.Y - TFL_HIT_MARGIN);
+        ip.z = stdmin(stdmax(next.z, TFL_HIT_MARGIN), (float)d.Z - TFL_HIT_MARGIN);
+      }
+      if (out_of_domain(d, ip)) return -3;
+      const int blk = blocked_at(d, flags, ip);
+      if (blk < 0) return -4;
+      if (!blk) { out = ip; return 1; }
+      next = ip;
+    }
+    int blk = blocked_at(d, flags, next);
+    if (blk < 0) return -4;
+    if (blk) {
+      for (int count = 0; count <= 4; count++) {
+        blk = blocked_at(d, flags, next);
+        if (blk < 0) return -4;
+        if (!blk) break;
+        if (count == 4) return -5;
+        const float cx = (float)((int)next.x) + 0.5f;
+        const float cy = (float)((int)next.y) + 0.5f;
+        const float cz = (float)((int)next.z) + 0.5f;
+        const float lo[3] = {cx - 0.5f - TFL_HIT_MARGIN, cy - 0.5f - TFL_HIT_MARGIN, cz - 0.5f - TFL_HIT_MARGIN};
+        const float hi[3] = {cx + 0.5f + TFL_HIT_MARGIN, cy + 0.5f + TFL_HIT_MARGIN, cz + 0.5f + TFL_HIT_MARGIN};
+        const float org[3] = {out.x, out.y, out.z};
+        const float dir[3] = {dt.x, dt.y, dt.z};
+        float hitp[3];
+        if (!ray_box(lo, hi, org, dir, hitp)) return 1;  // keep `out` (still a valid fluid position)
+        next = mk3(hitp[0], hitp[1], hitp[2]);
+      }
+      out = next;
+      if (out_of_domain(d, out)) return -6;
+      if (blocked_at(d, flags, out) != 0) return -7;
+      return 1;
+    }
+    out = next;
+    cur += step;
+  }
+  return 0;
+}
+
+__device__ __forceinline__ v3 cell_centre(int i, int j, int k) {
+  return mk3((float)i + 0.5f, (float)j + 0.5f, (float)k + 0.5f);
+}
+
+__device__ __forceinline__ void count_trace_error(int rc, unsigned long long* err) {
+  if (rc < 0) atomicAdd(err, 1ull);
+}
+
+}  // namespace tfl

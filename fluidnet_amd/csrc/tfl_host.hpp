@@ -1,0 +1,35 @@
+// tfl_host.hpp -- host-side launcher prototypes shared by the .hip translation units and abi.cpp.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace tfl {
+
+// advect.hip
+void advect_scalar(hipStream_t st, bool is3d, int method, int B, int Z, int Y, int X, float dt, float strength,
+                   int outside, unsigned long long* err, const float* s, const float* U, const float* flags,
+                   float* fwd, float* bounds, float* dst);
+void advect_vel(hipStream_t st, bool is3d, int method, int B, int Z, int Y, int X, float dt, float strength,
+                unsigned long long* err, const float* U, const float* flags, float* fwd, float* dst);
+
+// stencil.hip
+void set_wall_bcs(hipStream_t st, bool is3d, int B, int Z, int Y, int X, float* U, const float* flags);
+void velocity_divergence(hipStream_t st, bool is3d, int B, int Z, int Y, int X, const float* U, const float* flags,
+                         float* div);
+void velocity_update(hipStream_t st, bool is3d, int B, int Z, int Y, int X, float* U, const float* flags,
+                     const float* p);
+void add_buoyancy(hipStream_t st, bool is3d, int B, int Z, int Y, int X, float* U, const float* flags,
+                  const float* density, float sx, float sy, float sz);
+void add_gravity(hipStream_t st, bool is3d, int B, int Z, int Y, int X, float* U, const float* flags, float fx,
+                 float fy, float fz);
+void empty_domain(hipStream_t st, bool is3d, int bnd, int B, int Z, int Y, int X, float* flags);
+void flags_to_occupancy(hipStream_t st, long long numel, const float* flags, float* occ);
+
+// vorticity.hip
+void vorticity_confinement(hipStream_t st, bool is3d, int B, int Z, int Y, int X, float* U, const float* flags,
+                           float strength, float* curl, float* curl_norm);
+
+// jacobi.hip
+void jacobi_iteration(hipStream_t st, bool is3d, int B, int Z, int Y, int X, const float* p_prev, const float* flags,
+                      const float* div, float* p, double* resid_sq /* [B] or nullptr */);
+
+}  // namespace tfl

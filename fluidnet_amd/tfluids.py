@@ -1,0 +1,264 @@
+"""Host-side mirror of torch/tfluids/init.lua on torch (ROCm) tensors.
+
+Same operator names, argument order, defaults, argument checks and in-place / copy-back behaviour
+as the Lua wrappers (init.lua:89-735), so code written against `tfluids.*` reads the same. Tensors
+are contiguous fp32 [B, C, Z, Y, X] on an MI355X; every call is asynchronous on torch's current
+stream, like the reference's CUDA path. The work is done by libtfluids_hip.so through its C ABI
+(include/tfluids_hip.h) -- torch only owns the memory and the stream.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import TfluidsError, tfl_tensor
+
+# tfluids.CellType (init.cu:108-120 exporting third_party/cell_type.h:22-33)
+CellType = dict(TypeNone=0, TypeFluid=1, TypeObstacle=2, TypeEmpty=4, TypeInflow=8,
+                TypeOutflow=16, TypeOpen=32, TypeStick=128)
+
+_ctx = {}   # device index -> tfl_ctx*
+_tmp = {}   # device index -> grow-only flat scratch tensor (init.lua:22,35-64)
+
+
+def _check(cond, msg):
+    if not cond:
+        raise TfluidsError(msg)
+
+
+def _context(t):
+    _check(t.is_cuda, "tfluids_hip operators need tensors on an MI355X (got a CPU tensor); "
+                      "there is no CPU fallback")
+    dev = t.device.index if t.device.index is not None else torch.cuda.current_device()
+    lib = _lib.load()
+    ctx = _ctx.get(dev)
+    if ctx is None:
+        ctx = lib.tfl_create(dev)
+        if not ctx:
+            raise TfluidsError("tfl_create(%d) failed" % dev)
+        _ctx[dev] = ctx
+    lib.tfl_set_stream(ctx, ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+    return lib, ctx
+
+
+def _tt(t):
+    _check(t.dtype == torch.float32, "tensors must be float32")
+    b, c, z, y, x = t.shape
+    return ctypes.byref(tfl_tensor(t.data_ptr(), b, c, z, y, x))
+
+
+def _call(lib, ctx, rc):
+    if rc != 0:
+        raise TfluidsError(lib.tfl_last_error(ctx).decode())
+
+
+def getTempStorage(like, sizes):
+    """init.lua:35-64: one grow-only buffer per device, carved into views; contents undefined."""
+    dev = like.device.index
+    total = 0
+    numels = []
+    for s in sizes:
+        n = 1
+        for v in s:
+            _check(v > 0, "tensor sizes must be positive non-zero")
+            n *= v
+        numels.append(n)
+        total += n
+    buf = _tmp.get(dev)
+    if buf is None or buf.numel() < total:
+        buf = torch.empty(total, dtype=torch.float32, device=like.device)
+        _tmp[dev] = buf
+    out, off = [], 0
+    for s, n in zip(sizes, numels):
+        out.append(buf[off:off + n].view(*s))
+        off += n
+    return out
+
+
+def _dims(U, flags):
+    _check(U.dim() == 5 and flags.dim() == 5, "Dimension mismatch")
+    _check(flags.size(1) == 1, "flags is not scalar")
+    bsz, _, d, h, w = flags.shape
+    is3D = U.size(1) == 3
+    if not is3D:
+        _check(d == 1, "2D velocity field but zdepth > 1")
+        _check(U.size(1) == 2, "2D velocity field must have only 2 channels")
+    _check(U.size(0) == bsz and U.size(2) == d and U.size(3) == h and U.size(4) == w,
+           "Size mismatch")
+    _check(U.is_contiguous() and flags.is_contiguous(), "Input is not contiguous")
+    return bsz, d, h, w, is3D
+
+
+def advectScalar(dt, s, U, flags, method=None, sDst=None, sampleOutsideFluid=None,
+                 maccormackStrength=None, boundaryWidth=None):
+    """init.lua:89-149. In place on `s` unless sDst is given."""
+    method = method or "maccormackOurs"
+    boundaryWidth = boundaryWidth or 1
+    sampleOutsideFluid = bool(sampleOutsideFluid) if sampleOutsideFluid is not None else False
+    maccormackStrength = 0.75 if maccormackStrength is None else maccormackStrength
+    _check(s.dim() == 5, "Dimension mismatch")
+    bsz, d, h, w, is3D = _dims(U, flags)
+    _check(s.shape == flags.shape, "Size mismatch")
+    _check(s.is_contiguous(), "Input is not contiguous")
+    C = U.size(1)
+    sizes = [(bsz, 1, d, h, w), (bsz, 1, d, h, w), (bsz, C, d, h, w), (bsz, C, d, h, w)]
+    if sDst is None:
+        sizes.append((bsz, 1, d, h, w))
+    else:
+        _check(sDst.dim() == 5 and sDst.shape == s.shape, "Size mismatch")
+        _check(sDst.is_contiguous(), "Input is not contiguous")
+    tmp = getTempStorage(s, sizes)
+    fwd, bwd, fwdPos, bwdPos = tmp[:4]
+    out = sDst if sDst is not None else tmp[4]
+    lib, ctx = _context(s)
+    _call(lib, ctx, lib.tfl_advectScalar(ctx, dt, _tt(s), _tt(U), _tt(flags), _tt(fwd), _tt(bwd),
+                                         int(is3D), method.encode(), _tt(fwdPos), _tt(bwdPos),
+                                         int(boundaryWidth), int(sampleOutsideFluid),
+                                         maccormackStrength, _tt(out)))
+    if sDst is None:
+        s.copy_(out)
+
+
+def advectVel(dt, U, flags, method=None, UDst=None, maccormackStrength=None, boundaryWidth=None):
+    """init.lua:170-219. In place on `U` unless UDst is given."""
+    method = method or "maccormackOurs"
+    boundaryWidth = boundaryWidth or 1
+    maccormackStrength = 0.75 if maccormackStrength is None else maccormackStrength
+    bsz, d, h, w, is3D = _dims(U, flags)
+    C = U.size(1)
+    if UDst is None:
+        tmp = getTempStorage(U, [(bsz, C, d, h, w)] * 3)
+    else:
+        tmp = getTempStorage(U, [(bsz, C, d, h, w)] * 2)
+        _check(UDst.dim() == 5 and UDst.shape == U.shape, "Size mismatch")
+        _check(UDst.is_contiguous(), "Input is not contiguous")
+    fwd, bwd = tmp[0], tmp[1]
+    out = UDst if UDst is not None else tmp[2]
+    lib, ctx = _context(U)
+    _call(lib, ctx, lib.tfl_advectVel(ctx, dt, _tt(U), _tt(flags), _tt(fwd), _tt(bwd), int(is3D),
+                                      method.encode(), int(boundaryWidth), maccormackStrength,
+                                      _tt(out)))
+    if UDst is None:
+        U.copy_(out)
+
+
+def setWallBcsForward(U, flags):
+    """init.lua:226-247 (in place)."""
+    _, _, _, _, is3D = _dims(U, flags)
+    lib, ctx = _context(U)
+    _call(lib, ctx, lib.tfl_setWallBcsForward(ctx, _tt(U), _tt(flags), int(is3D)))
+
+
+def velocityDivergenceForward(U, flags, UDiv):
+    """init.lua:255-279."""
+    _, _, _, _, is3D = _dims(U, flags)
+    _check(UDiv.dim() == 5 and UDiv.shape == flags.shape, "Size mismatch")
+    _check(UDiv.is_contiguous(), "Input is not contiguous")
+    lib, ctx = _context(U)
+    _call(lib, ctx, lib.tfl_velocityDivergenceForward(ctx, _tt(U), _tt(flags), _tt(UDiv),
+                                                      int(is3D)))
+
+
+def velocityUpdateForward(U, flags, p):
+    """init.lua:322-347 (in place on U)."""
+    _, _, _, _, is3D = _dims(U, flags)
+    _check(p.dim() == 5 and p.shape == flags.shape, "Size mismatch")
+    _check(p.is_contiguous(), "Input is not contiguous")
+    lib, ctx = _context(U)
+    _call(lib, ctx, lib.tfl_velocityUpdateForward(ctx, _tt(U), _tt(flags), _tt(p), int(is3D)))
+
+
+def vorticityConfinement(U, flags, strength):
+    """init.lua:394-430 (in place on U)."""
+    bsz, d, h, w, is3D = _dims(U, flags)
+    _check(isinstance(strength, (int, float)), "strength must be a number")
+    C = U.size(1)
+    centered, curl, curlNorm, force = getTempStorage(
+        U, [(bsz, C, d, h, w), (bsz, 3, d, h, w), (bsz, 1, d, h, w), (bsz, C, d, h, w)])
+    lib, ctx = _context(U)
+    _call(lib, ctx, lib.tfl_vorticityConfinement(ctx, _tt(U), _tt(flags), float(strength),
+                                                 _tt(centered), _tt(curl), _tt(curlNorm),
+                                                 _tt(force), int(is3D)))
+
+
+def _vec3(g, name):
+    if torch.is_tensor(g):
+        _check(g.dim() == 1 and g.size(0) == 3, "%s must be a 3D vector (even in 2D)." % name)
+        g = g.detach().cpu().tolist()
+    _check(len(g) == 3, "%s must be a 3D vector (even in 2D)." % name)
+    return (ctypes.c_float * 3)(*[float(v) for v in g])
+
+
+def addBuoyancy(U, flags, density, gravity, dt):
+    """init.lua:442-470 (in place on U). gravity: 3 floats (host tensor, list or tuple)."""
+    _, _, _, _, is3D = _dims(U, flags)
+    _check(density.dim() == 5 and density.shape == flags.shape, "Size mismatch")
+    _check(density.is_contiguous(), "Input is not contiguous")
+    _check(isinstance(dt, (int, float)), "time step must be a number")
+    lib, ctx = _context(U)
+    _call(lib, ctx, lib.tfl_addBuoyancy(ctx, _tt(U), _tt(flags), _tt(density), _vec3(gravity, "gravity"),
+                                        None, float(dt), int(is3D)))
+
+
+def addGravity(U, flags, gravity, dt):
+    """init.lua:481-506 (in place on U)."""
+    _, _, _, _, is3D = _dims(U, flags)
+    _check(isinstance(dt, (int, float)), "time step must be a number")
+    lib, ctx = _context(U)
+    _call(lib, ctx, lib.tfl_addGravity(ctx, _tt(U), _tt(flags), _vec3(gravity, "gravity"), float(dt),
+                                       int(is3D), None))
+
+
+def emptyDomain(flags, is3D, bnd=None):
+    """init.lua:545-553."""
+    bnd = bnd or 1
+    _check(flags.dim() == 5 and flags.size(1) == 1, "Flags should be 5D and scalar")
+    _check(flags.is_contiguous(), "Input is not contiguous")
+    lib, ctx = _context(flags)
+    _call(lib, ctx, lib.tfl_emptyDomain(ctx, _tt(flags), int(bool(is3D)), int(bnd)))
+    return flags
+
+
+def getDx(flags):
+    """init.lua:560-564 | grid.cc:37-40."""
+    _check(flags.dim() == 5, "Dimension mismatch")
+    return 1.0 / max(flags.size(2), flags.size(3), flags.size(4))
+
+
+def flagsToOccupancy(flags, occupancy):
+    """init.lua:567-576."""
+    _check(flags.dim() == 5 and flags.size(1) == 1, "Flags should be 5D and scalar")
+    _check(occupancy.shape == flags.shape, "Size mismatch")
+    _check(flags.is_contiguous() and occupancy.is_contiguous(), "Input is not contiguous")
+    lib, ctx = _context(flags)
+    _call(lib, ctx, lib.tfl_flagsToOccupancy(ctx, _tt(flags), _tt(occupancy)))
+
+
+def solveLinearSystemJacobi(p, flags, div, is3D, pTol=None, maxIter=None, verbose=None):
+    """init.lua:693-735. Returns the final residual (a Python float => one host sync)."""
+    pTol = 1e-5 if pTol is None else pTol
+    maxIter = 1000 if maxIter is None else maxIter
+    verbose = bool(verbose)
+    _check(p.dim() == 5 and flags.dim() == 5 and div.dim() == 5, "Dimension mismatch")
+    _check(flags.size(1) == 1, "flags is not scalar")
+    bsz, _, d, h, w = flags.shape
+    _check(p.shape == flags.shape and div.shape == flags.shape, "size mismatch")
+    if not is3D:
+        _check(d == 1, "d > 1 for a 2D domain")
+    _check(p.is_contiguous() and flags.is_contiguous() and div.is_contiguous(),
+           "Input is not contiguous")
+    pPrev, pDelta, pDeltaNorm = getTempStorage(p, [(bsz, 1, d, h, w), (bsz, 1, d, h, w), (bsz,)])
+    lib, ctx = _context(p)
+    res = ctypes.c_float(0.0)
+    dn = tfl_tensor(pDeltaNorm.data_ptr(), bsz, 1, 1, 1, 1)
+    _call(lib, ctx, lib.tfl_solveLinearSystemJacobi(ctx, _tt(p), _tt(flags), _tt(div), _tt(pPrev),
+                                                    _tt(pDelta), ctypes.byref(dn), int(bool(is3D)),
+                                                    float(pTol), int(maxIter), int(verbose),
+                                                    ctypes.byref(res)))
+    return res.value
+
+
+def traceErrors(like):
+    """Back-traces that hit a calcLineTrace invariant path since the last call (diagnostic)."""
+    lib, ctx = _context(like)
+    return int(lib.tfl_trace_errors(ctx))

@@ -1,0 +1,142 @@
+/*
+ * tfluids_hip.h -- C ABI of the MI355X-native tfluids hot path (libtfluids_hip.so).
+ *
+ * This is the drop-in boundary for FluidNet's native layer. In the reference every operator is a
+ * Lua-C function `static int tfluids_<Real>Main_<op>(lua_State*)` registered on the tensor
+ * metatable (torch/tfluids/generic/tfluids.cc:927-957, generic/tfluids.cu:1932-1962) and called
+ * from torch/tfluids/init.lua as `X.tfluids.<op>(positional args)`. Each tfl_<op> below takes the
+ * SAME positional arguments in the SAME order (the reference call site is cited per function),
+ * with THTensor* replaced by `const tfl_tensor*` (raw device pointer + the five sizes; contiguous
+ * [B][C][Z][Y][X] fp32, x fastest -- third_party/grid.h:68-78) and lua numbers/booleans replaced by
+ * float/int. No torch, Lua or C++ types cross this boundary.
+ *
+ * Semantics shared by every entry point (mirroring the reference's CUDA path):
+ *   - asynchronous: work is enqueued on the context's HIP stream and the call returns without
+ *     synchronising (generic/tfluids.cu:106 uses THCState_getCurrentStream the same way); the
+ *     only exception is tfl_solveLinearSystemJacobi with pTol > 0, which must read the residual
+ *     back every iteration exactly like the reference (generic/tfluids.cu:1886);
+ *   - the caller owns every buffer; nothing is allocated, freed, resized or retained;
+ *   - "temp" tensors (fwd, bwd, fwdPos, bwdPos, centered, curl, ...) are accepted because the
+ *     reference wrappers pass them (init.lua:35-64 getTempStorage); their contents are undefined
+ *     on entry AND on exit, exactly as in the reference. This implementation fuses sweeps and does
+ *     not touch all of them;
+ *   - return value: 0 on success, a negative tfl_status on error; tfl_last_error(ctx) returns a
+ *     message. Errors never longjmp/throw across the ABI (the reference raises luaL_error /
+ *     THError: init.lua asserts, third_party/tfluids.cc:441-466).
+ */
+#ifndef TFLUIDS_HIP_H_
+#define TFLUIDS_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TFL_ABI_VERSION 1
+
+typedef enum tfl_status {
+  TFL_OK = 0,
+  TFL_EINVAL = -1,       /* bad argument (shape / channel / null pointer / unknown method) */
+  TFL_EHIP = -2,         /* HIP runtime error (message carries hipGetErrorString) */
+  TFL_EUNSUPPORTED = -3  /* valid in the reference but not built here */
+} tfl_status;
+
+/* A contiguous fp32 5-D tensor resident in HBM: [B][C][Z][Y][X], x fastest. */
+typedef struct tfl_tensor {
+  float* data;
+  int32_t B, C, Z, Y, X;
+} tfl_tensor;
+
+/* Manta cell types stored as floats in `flags` (third_party/cell_type.h:22-33; exported to Lua as
+ * tfluids.CellType by init.cu:108-120). */
+enum {
+  TFL_TypeNone = 0, TFL_TypeFluid = 1, TFL_TypeObstacle = 2, TFL_TypeEmpty = 4,
+  TFL_TypeInflow = 8, TFL_TypeOutflow = 16, TFL_TypeOpen = 32, TFL_TypeStick = 128
+};
+
+typedef struct tfl_ctx tfl_ctx;
+
+/* ---- context ------------------------------------------------------------------------------ */
+/* Replaces THCState (device + current stream). `device` is a HIP device ordinal. */
+tfl_ctx* tfl_create(int device);
+void tfl_destroy(tfl_ctx* ctx);
+/* `hip_stream` is a hipStream_t (NULL = the legacy default stream). */
+int tfl_set_stream(tfl_ctx* ctx, void* hip_stream);
+const char* tfl_last_error(const tfl_ctx* ctx);
+int tfl_abi_version(void);
+/* Blocks until the context's stream is idle (cutorch.synchronize(), simulate.lua:258). */
+int tfl_synchronize(tfl_ctx* ctx);
+/* Number of back-traces that hit one of calcLineTrace's invariant-violation paths since the last
+ * call (the reference CPU build THErrors there, calc_line_trace.cc:325-330,410,421; its CUDA build
+ * silently substitutes). Synchronises the stream. Diagnostic only. */
+int64_t tfl_trace_errors(tfl_ctx* ctx);
+
+/* ---- operators (one per row of SURVEY.md section 8b) ------------------------------------- */
+
+/* init.lua:142-144 -> third_party/tfluids.cc:415-588 | tfluids.cu:524-633.
+ * method: "euler" | "maccormack" | "eulerOurs" | "rk2Ours" | "rk3Ours" | "maccormackOurs"
+ * (generic/advect_type.cc:18-37). boundaryWidth is parsed and ignored like the reference
+ * (tfluids.cc:436,467: bnd = 1). s_dst must not alias s. */
+int tfl_advectScalar(tfl_ctx* ctx, float dt, const tfl_tensor* s, const tfl_tensor* U,
+                     const tfl_tensor* flags, const tfl_tensor* fwd, const tfl_tensor* bwd,
+                     int is3D, const char* method, const tfl_tensor* fwdPos,
+                     const tfl_tensor* bwdPos, int boundaryWidth, int sampleOutsideFluid,
+                     float maccormackStrength, const tfl_tensor* sDst);
+
+/* init.lua:212-213 -> third_party/tfluids.cc:776-920 | tfluids.cu:876-963.
+ * rk2Ours / rk3Ours map to maccormackOurs like the reference (tfluids.cc:799-802). */
+int tfl_advectVel(tfl_ctx* ctx, float dt, const tfl_tensor* U, const tfl_tensor* flags,
+                  const tfl_tensor* fwd, const tfl_tensor* bwd, int is3D, const char* method,
+                  int boundaryWidth, float maccormackStrength, const tfl_tensor* UDst);
+
+/* init.lua:246 -> third_party/tfluids.cc:926-1002 | tfluids.cu:969-1046 (in place on U). */
+int tfl_setWallBcsForward(tfl_ctx* ctx, const tfl_tensor* U, const tfl_tensor* flags, int is3D);
+
+/* init.lua:278 -> third_party/tfluids.cc:1008-1066 | tfluids.cu:1052-1105. */
+int tfl_velocityDivergenceForward(tfl_ctx* ctx, const tfl_tensor* U, const tfl_tensor* flags,
+                                  const tfl_tensor* UDiv, int is3D);
+
+/* init.lua:346 -> third_party/tfluids.cc:1072-1156 | tfluids.cu:1111-1195 (in place on U). */
+int tfl_velocityUpdateForward(tfl_ctx* ctx, const tfl_tensor* U, const tfl_tensor* flags,
+                              const tfl_tensor* p, int is3D);
+
+/* init.lua:428-429 -> third_party/tfluids.cc:1341-1458 | tfluids.cu:1355-1497 (in place on U).
+ * curl always has 3 channels (tfluids.cc:1363). */
+int tfl_vorticityConfinement(tfl_ctx* ctx, const tfl_tensor* U, const tfl_tensor* flags,
+                             float strength, const tfl_tensor* centered, const tfl_tensor* curl,
+                             const tfl_tensor* curlNorm, const tfl_tensor* force, int is3D);
+
+/* init.lua:469 -> third_party/tfluids.cc:1162-1233 | tfluids.cu:1201-1273 (in place on U).
+ * gravity: 3 floats in HOST memory (the Lua wrapper passes a 3-element tensor, init.lua:455-458);
+ * strengthTmp (a 3-float device scratch in the reference, tfluids.cu:1261-1265) is accepted and
+ * unused: the strength travels as kernel arguments. */
+int tfl_addBuoyancy(tfl_ctx* ctx, const tfl_tensor* U, const tfl_tensor* flags,
+                    const tfl_tensor* density, const float gravity[3], float* strengthTmp,
+                    float dt, int is3D);
+
+/* init.lua:505 -> third_party/tfluids.cc:1239-1306 | tfluids.cu:1279-1349 (in place on U). */
+int tfl_addGravity(tfl_ctx* ctx, const tfl_tensor* U, const tfl_tensor* flags,
+                   const float gravity[3], float dt, int is3D, float* forceTmp);
+
+/* init.lua:552 -> generic/tfluids.cc:136-167 | generic/tfluids.cu:314-353. */
+int tfl_emptyDomain(tfl_ctx* ctx, const tfl_tensor* flags, int is3D, int bnd);
+
+/* init.lua:574 -> generic/tfluids.cc:173-210 | generic/tfluids.cu:355-397. Cells that are neither
+ * exactly Fluid nor Obstacle become -1 (the CUDA behaviour); the CPU reference raises there. */
+int tfl_flagsToOccupancy(tfl_ctx* ctx, const tfl_tensor* flags, const tfl_tensor* occupancy);
+
+/* init.lua:726-727 -> generic/tfluids.cu:1765-1927 (the reference has no CPU version).
+ * p is overwritten (initial guess is zero like the reference, :1869-1872). pPrev is scratch;
+ * pDelta / pDeltaNorm are accepted and unused (the residual is reduced on the fly). The final
+ * residual max_b ||p - pPrev||_2 is written to *residual when non-NULL (one host sync at the
+ * end; every iteration when pTol > 0, like the reference's maxall at :1886). */
+int tfl_solveLinearSystemJacobi(tfl_ctx* ctx, const tfl_tensor* p, const tfl_tensor* flags,
+                                const tfl_tensor* div, const tfl_tensor* pPrev,
+                                const tfl_tensor* pDelta, const tfl_tensor* pDeltaNorm, int is3D,
+                                float pTol, int maxIter, int verbose, float* residual);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TFLUIDS_HIP_H_ */
