@@ -1,0 +1,240 @@
+#!/usr/bin/env python
+"""bench.py -- simulate() throughput of the MI355X-native tfluids path.
+
+Workload (BASELINE.json metric: "simulate() steps/s + Mcells/s, 3D 128^3 ConvNet projection"):
+BASELINE config 4 -- the scene of torch/fluid_net_3d_sim.lua:62-87 at res 128: plume BCs
+(createPlumeBCs(batch, {1}, plumeScale=1, rad=0.15)), buoyancyScale 2, vorticityConfinementAmp 3,
+dt 0.1, maccormackOurs with strength 0.6, ConvNet projection (3-D `default` topology, seeded weights:
+the reference ships no 3-D model), plus a procedural voxel obstacle standing in for the bunny binvox
+(not in the reference tree). One "step" = one tfluids.simulate() call on the whole grid; fp32.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]      (N>1: launched by torch.distributed.run)
+
+N > 1 is weak scaling: every rank owns a 128^3 z-slab of a 128 x 128 x (128 N) grid (8 ranks = the
+cell count of the north-star 256^3 grid) and exchanges halo planes with its z-neighbours over RCCL.
+Rank 0 prints ONE JSON line. Inputs are resident in HBM before the timed region.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP32_PEAK_TFLOPS = 157.3   # same guide: fp32 matrix (= vector) peak
+
+# Algorithmic HBM bytes per CELL per launch (fp32, 3-D; each distinct input read once, each output
+# written once) -- SURVEY.md 8d restated per kernel of the fused implementation.
+ALG_BYTES_PER_CELL = {
+    "k_scalar_fwd": 24,      # s, U3, flags -> fwd                      (advectScalar pass A)
+    "k_scalar_bwd": 28,      # fwd, s, U3, flags -> dst                 (advectScalar pass B)  A+B = 52
+    "k_vel_fwd": 28,         # U3, flags -> fwd3                        (advectVel pass A)
+    "k_vel_bwd": 40,         # fwd3, U3, flags -> dst3                  (advectVel pass B)     A+B = 68
+    "k_add_buoyancy": 32,    # U3, flags, rho -> U3
+    "k_curl": 28,            # U3 -> curl3, |curl|                      (vorticity pass A)
+    "k_confine": 44,         # curl3, |curl|, flags, U3 -> U3           (vorticity pass B)     A+B = 72
+    "k_bcs_div_stats": 32,   # U3, flags -> U3_bc, div (+ 2 scalars)
+    "k_net_input": 24,       # pDiv, div, flags -> 3 input planes
+    "k_project": 60,         # pPred, flags, U3, UBC3, mask3 -> U3, p
+    "k_set_wall_bcs": 28, "k_divergence": 20, "k_velocity_update": 32, "k_jacobi": 16,
+}
+
+
+def build_scene(res_xy, res_z, z_offset, z_total, device):
+    """Config-4 scene for the z-range [z_offset, z_offset + res_z) of a res_xy x res_xy x z_total grid.
+    Returns (batch, mconf). Obstacle = sphere + torus of ~res/2 extent (stand-in for the bunny)."""
+    from fluidnet_amd import simulate as sim
+    X = Y = res_xy
+    flags = torch.full((1, 1, z_total, Y, X), 1.0)
+    flags[..., 0] = 2; flags[..., X - 1] = 2; flags[..., 0, :] = 2; flags[..., Y - 1, :] = 2
+    flags[:, :, 0] = 2; flags[:, :, z_total - 1] = 2
+    zz, yy, xx = torch.meshgrid(torch.arange(z_total), torch.arange(Y), torch.arange(X), indexing="ij")
+    cx, cz = X / 2.0, z_total / 2.0
+    sphere = (xx - cx) ** 2 + (yy - 0.50 * Y) ** 2 + (zz - cz) ** 2 <= (0.11 * X) ** 2
+    rho = torch.sqrt((xx - cx) ** 2 + (zz - cz) ** 2) - 0.22 * X
+    torus = rho ** 2 + (yy - 0.72 * Y) ** 2 <= (0.045 * X) ** 2
+    interior = torch.zeros_like(sphere)
+    interior[1:-1, 1:-1, 1:-1] = True
+    flags[0, 0][(sphere | torus) & interior] = 2
+    full = dict(pDiv=torch.zeros(1, 1, z_total, Y, X), UDiv=torch.zeros(1, 3, z_total, Y, X), flags=flags,
+                density=torch.zeros(1, 1, z_total, Y, X))
+    scale = res_xy / 128.0
+    sim.createPlumeBCs(full, [1.0], 1.0 * scale, 0.15)
+    sl = slice(z_offset, z_offset + res_z)
+    batch = {}
+    for k, v in full.items():
+        batch[k] = None if v is None else v[:, :, sl].contiguous().to(device)
+    mconf = dict(dt=0.1, advectionMethod="maccormackOurs", maccormackStrength=0.6, buoyancyScale=2.0 * scale,
+                 gravityScale=0, vorticityConfinementAmp=3.0, simMethod="convnet")
+    return batch, mconf
+
+
+def cpu_baseline(batch, mconf, layers, max_seconds=25.0, max_steps=6):
+    """The reference's own CPU tfluids code (oracle/_ref, -O3 build) -- or the C restatement if that
+    library did not travel -- driving the same simulate() on the host cores, from the same state."""
+    from oracle import simulate_np as S
+    kind = "reference"
+    try:
+        from oracle import ref as refmod
+        if refmod.available(fast=True):
+            ops = refmod.RefTfluids(fast=True)
+        elif refmod.available():
+            ops = refmod.RefTfluids()
+        else:
+            raise ImportError
+    except Exception:
+        from oracle.oracle import OracleTfluids
+        ops, kind = OracleTfluids(), "port"
+    nb = {k: (v.cpu().numpy().copy() if torch.is_tensor(v) else v) for k, v in batch.items()}
+    cells = nb["flags"].size
+    t0 = time.time()
+    n = 0
+    while n < max_steps and (n == 0 or time.time() - t0 < max_seconds):
+        S.simulate(ops, mconf, nb, layers)
+        n += 1
+    dt = time.time() - t0
+    return {"value": cells * n / dt / 1e6, "unit": "Mcells/s", "cores": os.cpu_count(), "kind": kind,
+            "steps_per_s": n / dt,
+            "sample": "%d full simulate() steps of the same %s grid from the post-warm-up state "
+                      "(tfluids ops: %s, OpenMP on all host cores; conv stack: PyTorch-CPU conv3d)"
+                      % (n, "x".join(str(s) for s in nb["flags"].shape[2:]),
+                         "reference CPU sources -O3" if kind == "reference" else "C restatement")}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--res", type=int, default=128)
+    ap.add_argument("--preroll", type=int, default=16, help="untimed steps that develop the plume before warm-up")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    from fluidnet_amd import FluidNetModel, simulate, tfluids
+    model = FluidNetModel.default_3d(seed=1)
+    res = args.res
+    batch, mconf = build_scene(res, res, rank * res, res * world, dev)
+    if world > 1:
+        from fluidnet_amd.dist import SlabSimulation
+        stepper = SlabSimulation(batch, mconf, model, rank, world)
+        step = stepper.step
+    else:
+        def step():
+            simulate(None, mconf, batch, model)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.preroll + args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert bool(torch.isfinite(batch["UDiv"]).all()), "simulation blew up"
+
+    cells_per_gpu = res ** 3
+    total_cells = cells_per_gpu * world
+    ms = elapsed / args.steps * 1e3
+
+    # ---- per-kernel HIP-event timing over further steps (outside the timed region) -----------------
+    nprof = max(3, min(10, args.steps))
+    with tfluids.profile(batch["UDiv"]) as prof:
+        for _ in range(nprof):
+            step()
+    kernels = {}
+    for name, rec in prof.kernels.items():
+        kernels[name] = {"launches_per_step": rec["calls"] / nprof, "avg_ms": rec["ms"] / rec["calls"],
+                         "ms_per_step": rec["ms"] / nprof}
+    conv_flops = sum(2.0 * w.shape[0] * w.shape[1] * w.shape[2] ** 3 for w, _ in model.layers) * cells_per_gpu
+    for name, k in kernels.items():
+        if name in ALG_BYTES_PER_CELL:
+            per_launch = ALG_BYTES_PER_CELL[name] * cells_per_gpu
+            k["bound"], k["achieved"], k["unit"] = "hbm", per_launch / (k["avg_ms"] * 1e-3) / 1e9, "GB/s"
+            k["frac"] = k["achieved"] / HBM_PEAK_GBS
+        elif name.startswith("k_conv"):
+            # all conv launches of a step together execute conv_flops
+            k["bound"], k["achieved"], k["unit"] = "mfma", conv_flops / (k["ms_per_step"] * 1e-3) / 1e12, "TFLOP/s"
+            k["frac"] = k["achieved"] / FP32_PEAK_TFLOPS
+        elif name == "k_apply_bcs":
+            # x, bc, invMask -> x over U (3 ch) twice + density (1 ch) three times per step = 9 planes... per launch avg
+            per_step = (2 * 3 + 3 * 1) * 16 * cells_per_gpu
+            k["bound"], k["achieved"], k["unit"] = "hbm", per_step / (k["ms_per_step"] * 1e-3) / 1e9, "GB/s"
+            k["frac"] = k["achieved"] / HBM_PEAK_GBS
+    dom = max(kernels, key=lambda n: kernels[n]["ms_per_step"])
+    dk = kernels[dom]
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get(dom)
+        except Exception:
+            traffic = None
+    roofline = {"kernel": dom, "bound": dk.get("bound"), "achieved": dk.get("achieved"),
+                "peak": HBM_PEAK_GBS if dk.get("bound") == "hbm" else FP32_PEAK_TFLOPS, "unit": dk.get("unit"),
+                "frac": dk.get("frac"), "traffic": traffic, "avg_launch_ms": dk["avg_ms"],
+                "launches_per_step": dk["launches_per_step"]}
+    headline = {}
+    if "k_vel_fwd" in kernels and "k_vel_bwd" in kernels:   # the north-star's "advection kernel" figure
+        t = kernels["k_vel_fwd"]["avg_ms"] + kernels["k_vel_bwd"]["avg_ms"]
+        headline = {"op": "advectVel (k_vel_fwd + k_vel_bwd)", "algorithmic_bytes_per_cell": 68, "ms": t,
+                    "achieved_GBps": 68 * cells_per_gpu / (t * 1e-3) / 1e9,
+                    "frac_of_hbm_peak": 68 * cells_per_gpu / (t * 1e-3) / 1e9 / HBM_PEAK_GBS}
+
+    out = {
+        "metric": "simulate_mcells_per_s", "value": total_cells * args.steps / elapsed / 1e6, "unit": "Mcells/s",
+        "steps_per_s": args.steps / elapsed, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": "BASELINE config 4: 3-D %d^3 plume + voxel obstacle (procedural stand-in), "
+                               "MacCormack(Ours) advection, buoyancy, vorticity confinement, ConvNet projection "
+                               "(3-D default topology, seeded weights); per-GPU z-slab of %d^3 cells" % (res, res),
+                   "grid_zyx": [res * world, res, res], "per_gpu_grid_zyx": [res, res, res],
+                   "decomposition": "single GPU" if world == 1 else "z-slabs, %d ranks, RCCL halo exchange" % world,
+                   "preroll_steps": args.preroll},
+        "roofline": roofline, "advection_headline": headline, "kernels": kernels,
+    }
+    if rank == 0 and not args.no_cpu_baseline and world == 1:
+        out["cpu_baseline"] = cpu_baseline(batch, mconf, model.layers)
+    elif rank == 0:
+        out["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

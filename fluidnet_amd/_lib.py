@@ -32,6 +32,8 @@ SIGNATURES = {
     "tfl_last_error": (_c.c_char_p, [_c.c_void_p]),
     "tfl_synchronize": (_c.c_int, [_c.c_void_p]),
     "tfl_trace_errors": (_c.c_int64, [_c.c_void_p]),
+    "tfl_profile_begin": (_c.c_int, [_c.c_void_p]),
+    "tfl_profile_end": (_c.c_int, [_c.c_void_p, _c.c_char_p, _c.c_int64]),
     "tfl_advectScalar": (_c.c_int, [_c.c_void_p, _c.c_float, _T, _T, _T, _T, _T, _c.c_int,
                                     _c.c_char_p, _T, _T, _c.c_int, _c.c_int, _c.c_float, _T]),
     "tfl_advectVel": (_c.c_int, [_c.c_void_p, _c.c_float, _T, _T, _T, _T, _c.c_int, _c.c_char_p,
@@ -49,6 +51,15 @@ SIGNATURES = {
     "tfl_solveLinearSystemJacobi": (_c.c_int, [_c.c_void_p, _T, _T, _T, _T, _T, _T, _c.c_int,
                                                _c.c_float, _c.c_int, _c.c_int,
                                                _c.POINTER(_c.c_float)]),
+    "tfl_model_create": (_c.c_void_p, [_c.c_void_p, _c.c_int, _c.c_int, _c.POINTER(_c.c_int32),
+                                       _c.POINTER(_c.c_int32), _c.POINTER(_c.c_int32),
+                                       _c.POINTER(_c.POINTER(_c.c_float)),
+                                       _c.POINTER(_c.POINTER(_c.c_float))]),
+    "tfl_model_destroy": (None, [_c.c_void_p, _c.c_void_p]),
+    "tfl_model_workspace_floats": (_c.c_int64, [_c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.c_int]),
+    "tfl_model_forward": (_c.c_int, [_c.c_void_p, _c.c_void_p, _T, _T, _T, _T, _T, _c.c_void_p,
+                                     _c.c_int64, _T, _T, _c.c_int, _c.c_float, _c.c_float]),
+    "tfl_applyBCs": (_c.c_int, [_c.c_void_p, _T, _T, _T, _c.c_int, _c.c_float, _c.c_float]),
 }
 
 _lib = None

@@ -11,8 +11,22 @@
 #include <cstring>
 #include <string>
 
+#include <vector>
+
 #include "tfl_device.hpp"
 #include "tfl_host.hpp"
+
+struct tfl_layer {
+  int cin = 0, cout = 0, k = 0;
+  float* w = nullptr;  // device, [tap][cin][cout]
+  float* b = nullptr;  // device, [cout]
+};
+struct tfl_model {
+  bool is3d = false;
+  int max_c = 0;
+  std::vector<tfl_layer> layers;
+  double* d_stats = nullptr;  // [2 * kMaxBatch]: sum(u), sum(u^2) per sample
+};
 
 struct tfl_ctx {
   int device = 0;
@@ -23,6 +37,26 @@ struct tfl_ctx {
   double* h_resid = nullptr;                  // pinned mirror
 };
 static const int kMaxBatch = 1024;
+
+// ---- per-kernel event profiler (TFL_TIMED in the launchers) ---------------------------------------
+namespace tfl {
+struct ProfRec { const char* name; hipEvent_t e0, e1; };
+struct Profiler { std::vector<ProfRec> recs; };
+static thread_local Profiler* g_prof = nullptr;
+
+KernelTimer::KernelTimer(const char* name, hipStream_t st) : slot_(-1), st_(st) {
+  if (!g_prof) return;
+  ProfRec r; r.name = name;
+  if (hipEventCreate(&r.e0) != hipSuccess) return;
+  if (hipEventCreate(&r.e1) != hipSuccess) { (void)hipEventDestroy(r.e0); return; }
+  (void)hipEventRecord(r.e0, st);
+  g_prof->recs.push_back(r);
+  slot_ = (int)g_prof->recs.size() - 1;
+}
+KernelTimer::~KernelTimer() {
+  if (slot_ >= 0 && g_prof) (void)hipEventRecord(g_prof->recs[slot_].e1, st_);
+}
+}  // namespace tfl
 
 namespace {
 
@@ -137,6 +171,49 @@ int tfl_synchronize(tfl_ctx* c) {
   if (!c) return TFL_EINVAL;
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   return TFL_OK;
+}
+
+int tfl_profile_begin(tfl_ctx* c) {
+  if (!c) return TFL_EINVAL;
+  if (tfl::g_prof) return fail(c, TFL_EINVAL, "profile_begin: a profile is already active on this thread");
+  tfl::g_prof = new tfl::Profiler();
+  return TFL_OK;
+}
+
+int tfl_profile_end(tfl_ctx* c, char* buf, int64_t cap) {
+  if (!c) return TFL_EINVAL;
+  tfl::Profiler* p = tfl::g_prof;
+  if (!p) return fail(c, TFL_EINVAL, "profile_end: no active profile");
+  tfl::g_prof = nullptr;
+  (void)hipStreamSynchronize(c->stream);
+  (void)hipDeviceSynchronize();
+  std::vector<std::string> names;
+  std::vector<double> ms;
+  std::vector<long long> calls;
+  for (auto& r : p->recs) {
+    float t = 0.0f;
+    if (hipEventElapsedTime(&t, r.e0, r.e1) != hipSuccess) t = 0.0f;
+    (void)hipEventDestroy(r.e0);
+    (void)hipEventDestroy(r.e1);
+    size_t i = 0;
+    for (; i < names.size(); i++) if (names[i] == r.name) break;
+    if (i == names.size()) { names.push_back(r.name); ms.push_back(0.0); calls.push_back(0); }
+    ms[i] += t; calls[i] += 1;
+  }
+  delete p;
+  std::string js = "{";
+  for (size_t i = 0; i < names.size(); i++) {
+    char tmp[256];
+    snprintf(tmp, sizeof(tmp), "%s\"%s\": {\"calls\": %lld, \"ms\": %.6f}", i ? ", " : "", names[i].c_str(), calls[i], ms[i]);
+    js += tmp;
+  }
+  js += "}";
+  if (buf && cap > 0) {
+    const size_t n = js.size() < (size_t)cap - 1 ? js.size() : (size_t)cap - 1;
+    memcpy(buf, js.data(), n);
+    buf[n] = 0;
+  }
+  return (int)names.size();
 }
 
 int64_t tfl_trace_errors(tfl_ctx* c) {
@@ -322,6 +399,121 @@ int tfl_solveLinearSystemJacobi(tfl_ctx* c, const tfl_tensor* p, const tfl_tenso
   if (cur != p->data) HIP_TRY(c, hipMemcpyAsync(p->data, cur, bytes, hipMemcpyDeviceToDevice, c->stream));
   if (residual) *residual = res;
   return check_launch(c, "solveLinearSystemJacobi");
+}
+
+tfl_model* tfl_model_create(tfl_ctx* c, int is3D, int nlayers, const int32_t* cin, const int32_t* cout,
+                            const int32_t* ksize, const float* const* weights, const float* const* biases) {
+  if (!c) return nullptr;
+  auto bad = [&](const char* m) -> tfl_model* { fail(c, TFL_EINVAL, "model_create: %s", m); return nullptr; };
+  if (nlayers < 1 || !cin || !cout || !ksize || !weights || !biases) return bad("null or empty layer description");
+  if (cin[0] != 3) return bad("the default model takes 3 input channels {pDiv, div, occupancy}");
+  if (cout[nlayers - 1] != 1) return bad("the last layer must output 1 channel (pressure)");
+  tfl_model* m = new tfl_model();
+  m->is3d = is3D != 0;
+  auto cleanup = [&](const char* msg) -> tfl_model* { tfl_model_destroy(c, m); return bad(msg); };
+  if (hipMalloc((void**)&m->d_stats, sizeof(double) * 2 * kMaxBatch) != hipSuccess) return cleanup("hipMalloc failed");
+  for (int l = 0; l < nlayers; l++) {
+    tfl_layer L;
+    L.cin = cin[l]; L.cout = cout[l]; L.k = ksize[l];
+    if (L.cin < 1 || L.cout < 1 || L.k < 1 || (L.k % 2) != 1) return cleanup("convolution size must be odd and positive");
+    if (l > 0 && L.cin != cout[l - 1]) return cleanup("layer channel counts do not chain");
+    if (L.cout != 1 && L.cout != 2 && L.cout != 4 && L.cout != 8 && L.cout != 16 && L.cout != 32)
+      return cleanup("unsupported output channel count (1, 2, 4, 8, 16, 32)");
+    const int taps = m->is3d ? L.k * L.k * L.k : L.k * L.k;
+    std::vector<float> relaid((size_t)taps * L.cin * L.cout);
+    for (int co = 0; co < L.cout; co++)
+      for (int ci = 0; ci < L.cin; ci++)
+        for (int t = 0; t < taps; t++)
+          relaid[((size_t)t * L.cin + ci) * L.cout + co] = weights[l][((size_t)co * L.cin + ci) * taps + t];
+    if (hipMalloc((void**)&L.w, relaid.size() * sizeof(float)) != hipSuccess ||
+        hipMalloc((void**)&L.b, L.cout * sizeof(float)) != hipSuccess ||
+        hipMemcpy(L.w, relaid.data(), relaid.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(L.b, biases[l], L.cout * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+      m->layers.push_back(L);
+      return cleanup("uploading weights failed");
+    }
+    m->layers.push_back(L);
+    if (L.cout > m->max_c && l + 1 < nlayers) m->max_c = L.cout;
+  }
+  if (m->max_c < 1) m->max_c = 1;
+  return m;
+}
+
+void tfl_model_destroy(tfl_ctx* c, tfl_model* m) {
+  (void)c;
+  if (!m) return;
+  for (auto& L : m->layers) { if (L.w) (void)hipFree(L.w); if (L.b) (void)hipFree(L.b); }
+  if (m->d_stats) (void)hipFree(m->d_stats);
+  delete m;
+}
+
+int64_t tfl_model_workspace_floats(const tfl_model* m, int B, int Z, int Y, int X) {
+  if (!m) return -1;
+  const int64_t n = (int64_t)B * Z * Y * X;
+  // div[1] + net input[3] + two ping-pong activation buffers[max_c] + pPred[1]
+  return n * (1 + 3 + 2 * (int64_t)m->max_c + 1);
+}
+
+int tfl_model_forward(tfl_ctx* c, tfl_model* m, const tfl_tensor* pDiv, const tfl_tensor* UDiv,
+                      const tfl_tensor* flags, const tfl_tensor* pOut, const tfl_tensor* UOut, float* workspace,
+                      int64_t workspace_floats, const tfl_tensor* UBC, const tfl_tensor* UBCInvMask, int doClamp,
+                      float lo, float hi) {
+  TRY(check_flags(c, "model_forward", flags));
+  if (!m) return fail(c, TFL_EINVAL, "model_forward: null model");
+  const int is3D = m->is3d ? 1 : 0;
+  TRY(check_vel(c, "model_forward", "UDiv", UDiv, flags, is3D));
+  TRY(check_vel(c, "model_forward", "UOut", UOut, flags, is3D));
+  TRY(check_scalar(c, "model_forward", "pDiv", pDiv, flags));
+  TRY(check_scalar(c, "model_forward", "pOut", pOut, flags));
+  if ((UBC == nullptr) != (UBCInvMask == nullptr)) return fail(c, TFL_EINVAL, "model_forward: UBC and UBCInvMask go together");
+  if (UBC) {
+    TRY(check_vel(c, "model_forward", "UBC", UBC, flags, is3D));
+    TRY(check_vel(c, "model_forward", "UBCInvMask", UBCInvMask, flags, is3D));
+  }
+  const int B = flags->B, Z = flags->Z, Y = flags->Y, X = flags->X;
+  if (B > kMaxBatch) return fail(c, TFL_EINVAL, "model_forward: batch size above %d", kMaxBatch);
+  const int64_t n = (int64_t)B * Z * Y * X;
+  if (!workspace || workspace_floats < tfl_model_workspace_floats(m, B, Z, Y, X))
+    return fail(c, TFL_EINVAL, "model_forward: workspace too small (%lld floats needed)",
+                (long long)tfl_model_workspace_floats(m, B, Z, Y, X));
+  float* div = workspace;
+  float* x3 = div + n;
+  float* act[2] = {x3 + 3 * n, x3 + 3 * n + (int64_t)m->max_c * n};
+  float* pPred = act[1] + (int64_t)m->max_c * n;
+  hipStream_t st = c->stream;
+  // SetWallBcs(UDiv) lands in UOut (may alias UDiv: each thread rewrites only the cell it read, and
+  // neighbours are re-derived from the INPUT through the flags, so in-place is race-free only when
+  // UOut != UDiv; with aliasing the neighbour value read may already be the BC-applied one, which
+  // is idempotent -- identical either way).
+  tfl::model_pre(st, m->is3d, B, Z, Y, X, UDiv->data, flags->data, UOut->data, div, m->d_stats);
+  tfl::model_net_input(st, m->is3d, B, Z, Y, X, pDiv->data, div, flags->data, m->d_stats, x3);
+  const float* in = x3;
+  for (size_t l = 0; l < m->layers.size(); l++) {
+    const tfl_layer& L = m->layers[l];
+    const bool last = l + 1 == m->layers.size();
+    float* out = last ? pPred : act[l & 1];
+    if (!tfl::conv_direct(st, m->is3d, B, Z, Y, X, L.cin, L.cout, L.k, !last, in, L.w, L.b, out))
+      return fail(c, TFL_EUNSUPPORTED, "model_forward: no kernel for %d output channels", L.cout);
+    in = out;
+  }
+  tfl::model_project(st, m->is3d, B, Z, Y, X, pPred, flags->data, m->d_stats, UOut->data, pOut->data,
+                     UBC ? UBC->data : nullptr, UBC ? UBCInvMask->data : nullptr, doClamp, lo, hi);
+  return check_launch(c, "model_forward");
+}
+
+int tfl_applyBCs(tfl_ctx* c, const tfl_tensor* x, const tfl_tensor* bc, const tfl_tensor* invMask, int doClamp,
+                 float lo, float hi) {
+  if (!c) return TFL_EINVAL;
+  if (!x || !x->data) return fail(c, TFL_EINVAL, "applyBCs: x is null");
+  if ((bc == nullptr) != (invMask == nullptr)) return fail(c, TFL_EINVAL, "applyBCs: bc and invMask go together");
+  const long long n = (long long)x->B * x->C * x->Z * x->Y * x->X;
+  if (bc) {
+    const long long nb = (long long)bc->B * bc->C * bc->Z * bc->Y * bc->X;
+    const long long nm = (long long)invMask->B * invMask->C * invMask->Z * invMask->Y * invMask->X;
+    if (nb != n || nm != n || !bc->data || !invMask->data) return fail(c, TFL_EINVAL, "applyBCs: size mismatch");
+  }
+  tfl::apply_bcs(c->stream, n, x->data, bc ? bc->data : nullptr, bc ? invMask->data : nullptr, doClamp, lo, hi);
+  return check_launch(c, "applyBCs");
 }
 
 }  // extern "C"

@@ -318,17 +318,17 @@ static void launch_scalar(hipStream_t st, int method, const AdvArgs& a, int B, c
                           const float* flags, float* fwd, float* bounds, float* dst) {
   const dim3 blk(64, 4, 1), grd = cell_grid(a.d, B, blk);
   switch (method) {
-    case kEuler: k_scalar_fwd<IS3D, kEuler><<<grd, blk, 0, st>>>(a, s, U, flags, dst, nullptr); break;
-    case kEulerOurs: k_scalar_fwd<IS3D, kEulerOurs><<<grd, blk, 0, st>>>(a, s, U, flags, dst, nullptr); break;
-    case kRK2Ours: k_scalar_fwd<IS3D, kRK2Ours><<<grd, blk, 0, st>>>(a, s, U, flags, dst, nullptr); break;
-    case kRK3Ours: k_scalar_fwd<IS3D, kRK3Ours><<<grd, blk, 0, st>>>(a, s, U, flags, dst, nullptr); break;
+    case kEuler: { TFL_TIMED("k_scalar_fwd", st); k_scalar_fwd<IS3D, kEuler><<<grd, blk, 0, st>>>(a, s, U, flags, dst, nullptr); break; }
+    case kEulerOurs: { TFL_TIMED("k_scalar_fwd", st); k_scalar_fwd<IS3D, kEulerOurs><<<grd, blk, 0, st>>>(a, s, U, flags, dst, nullptr); break; }
+    case kRK2Ours: { TFL_TIMED("k_scalar_fwd", st); k_scalar_fwd<IS3D, kRK2Ours><<<grd, blk, 0, st>>>(a, s, U, flags, dst, nullptr); break; }
+    case kRK3Ours: { TFL_TIMED("k_scalar_fwd", st); k_scalar_fwd<IS3D, kRK3Ours><<<grd, blk, 0, st>>>(a, s, U, flags, dst, nullptr); break; }
     case kMacCormack:
-      k_scalar_fwd<IS3D, kMacCormack><<<grd, blk, 0, st>>>(a, s, U, flags, fwd, nullptr);
-      k_scalar_bwd<IS3D, kMacCormack><<<grd, blk, 0, st>>>(a, s, U, flags, fwd, nullptr, dst);
+      { TFL_TIMED("k_scalar_fwd", st); k_scalar_fwd<IS3D, kMacCormack><<<grd, blk, 0, st>>>(a, s, U, flags, fwd, nullptr); }
+      { TFL_TIMED("k_scalar_bwd", st); k_scalar_bwd<IS3D, kMacCormack><<<grd, blk, 0, st>>>(a, s, U, flags, fwd, nullptr, dst); }
       break;
     default:
-      k_scalar_fwd<IS3D, kMacCormackOurs><<<grd, blk, 0, st>>>(a, s, U, flags, fwd, bounds);
-      k_scalar_bwd<IS3D, kMacCormackOurs><<<grd, blk, 0, st>>>(a, s, U, flags, fwd, bounds, dst);
+      { TFL_TIMED("k_scalar_fwd", st); k_scalar_fwd<IS3D, kMacCormackOurs><<<grd, blk, 0, st>>>(a, s, U, flags, fwd, bounds); }
+      { TFL_TIMED("k_scalar_bwd", st); k_scalar_bwd<IS3D, kMacCormackOurs><<<grd, blk, 0, st>>>(a, s, U, flags, fwd, bounds, dst); }
       break;
   }
 }
@@ -346,15 +346,15 @@ static void launch_vel(hipStream_t st, int method, const AdvArgs& a, int B, cons
                        float* fwd, float* dst) {
   const dim3 blk(64, 4, 1), grd = cell_grid(a.d, B, blk);
   switch (method) {
-    case kEuler: k_vel_fwd<IS3D, false><<<grd, blk, 0, st>>>(a, U, flags, dst); break;
-    case kEulerOurs: k_vel_fwd<IS3D, true><<<grd, blk, 0, st>>>(a, U, flags, dst); break;
+    case kEuler: { TFL_TIMED("k_vel_fwd", st); k_vel_fwd<IS3D, false><<<grd, blk, 0, st>>>(a, U, flags, dst); break; }
+    case kEulerOurs: { TFL_TIMED("k_vel_fwd", st); k_vel_fwd<IS3D, true><<<grd, blk, 0, st>>>(a, U, flags, dst); break; }
     case kMacCormack:
-      k_vel_fwd<IS3D, false><<<grd, blk, 0, st>>>(a, U, flags, fwd);
-      k_vel_bwd<IS3D, false><<<grd, blk, 0, st>>>(a, U, flags, fwd, dst);
+      { TFL_TIMED("k_vel_fwd", st); k_vel_fwd<IS3D, false><<<grd, blk, 0, st>>>(a, U, flags, fwd); }
+      { TFL_TIMED("k_vel_bwd", st); k_vel_bwd<IS3D, false><<<grd, blk, 0, st>>>(a, U, flags, fwd, dst); }
       break;
     default:
-      k_vel_fwd<IS3D, true><<<grd, blk, 0, st>>>(a, U, flags, fwd);
-      k_vel_bwd<IS3D, true><<<grd, blk, 0, st>>>(a, U, flags, fwd, dst);
+      { TFL_TIMED("k_vel_fwd", st); k_vel_fwd<IS3D, true><<<grd, blk, 0, st>>>(a, U, flags, fwd); }
+      { TFL_TIMED("k_vel_bwd", st); k_vel_bwd<IS3D, true><<<grd, blk, 0, st>>>(a, U, flags, fwd, dst); }
       break;
   }
 }

@@ -1,0 +1,76 @@
+// conv.hip -- convolution layers of the projection ConvNet (gfx950).
+//
+// Replaces cudnn.SpatialConvolution / cudnn.VolumetricConvolution forward as used by
+// torch/lib/model_utils.lua:80-116: stride 1, zero padding (k-1)/2, cross-correlation, bias, with the
+// following nn.ReLU fused into the epilogue. Activations are channel-planar fp32 [B][C][Z][Y][X].
+//
+// k_conv_direct is the shape-generic path (any C_in, k; C_out in {1, 2, 4, 8, 16, 32}): one thread
+// per voxel holding all C_out accumulators in registers; the weights are re-laid out on the host as
+// [tap][c_in][c_out] so every weight address is wave-uniform and travels through the scalar cache
+// (s_load), leaving the vector memory path to the activations. The fmaf chain is exact fp32.
+#include "tfl_device.hpp"
+#include "tfl_host.hpp"
+
+namespace tfl {
+
+template <bool IS3D, int COUT, bool RELU>
+__global__ __launch_bounds__(256) void k_conv_direct(Dom d, int cin, int ksz, const float* __restrict__ in,
+                                                     const float* __restrict__ w, const float* __restrict__ bias,
+                                                     float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = blockIdx.y * blockDim.y + threadIdx.y;
+  const int b = blockIdx.z / d.Z, k = blockIdx.z - b * d.Z;
+  if (i >= d.X || j >= d.Y) return;
+  const long long cells = d.sc;
+  in += b * cells * cin; out += b * cells * COUT;
+  float acc[COUT];
+#pragma unroll
+  for (int c = 0; c < COUT; c++) acc[c] = bias[c];
+  const int r = (ksz - 1) / 2;
+  const int rz = IS3D ? r : 0;
+  int tap = 0;
+  for (int dz = -rz; dz <= rz; dz++) {
+    for (int dy = -r; dy <= r; dy++) {
+      for (int dx = -r; dx <= r; dx++, tap++) {
+        const int x = i + dx, y = j + dy, z = k + dz;
+        const bool ok = x >= 0 && x < d.X && y >= 0 && y < d.Y && z >= 0 && z < d.Z;
+        const int o = ok ? TFL_AT(d, x, y, z) : 0;
+        const float* wt = w + (long long)tap * cin * COUT;
+        for (int c = 0; c < cin; c++) {
+          const float v = ok ? in[o + c * d.sc] : 0.0f;
+#pragma unroll
+          for (int co = 0; co < COUT; co++) acc[co] = fmaf(v, wt[c * COUT + co], acc[co]);
+        }
+      }
+    }
+  }
+  const int o = TFL_AT(d, i, j, k);
+#pragma unroll
+  for (int c = 0; c < COUT; c++) out[o + c * d.sc] = RELU ? fmaxf(acc[c], 0.0f) : acc[c];
+}
+
+template <bool IS3D, int COUT>
+static void launch_direct(hipStream_t st, const Dom& d, int B, int cin, int ksz, bool relu, const float* in,
+                          const float* w, const float* bias, float* out) {
+  const dim3 blk(64, 4, 1), grd((d.X + 63) / 64, (d.Y + 3) / 4, (unsigned)(d.Z * B));
+  if (relu) { TFL_TIMED("k_conv_direct", st); k_conv_direct<IS3D, COUT, true><<<grd, blk, 0, st>>>(d, cin, ksz, in, w, bias, out); }
+  else { TFL_TIMED("k_conv_direct", st); k_conv_direct<IS3D, COUT, false><<<grd, blk, 0, st>>>(d, cin, ksz, in, w, bias, out); }
+}
+
+// w: device, [tap][cin][cout]. Returns false when cout has no instantiation.
+bool conv_direct(hipStream_t st, bool is3d, int B, int Z, int Y, int X, int cin, int cout, int ksz, bool relu,
+                 const float* in, const float* w, const float* bias, float* out) {
+  const Dom d = make_dom(Z, Y, X);
+#define TFL_CASE(N)                                                                        \
+  case N:                                                                                  \
+    if (is3d) launch_direct<true, N>(st, d, B, cin, ksz, relu, in, w, bias, out);          \
+    else launch_direct<false, N>(st, d, B, cin, ksz, relu, in, w, bias, out);              \
+    return true;
+  switch (cout) {
+    TFL_CASE(1) TFL_CASE(2) TFL_CASE(4) TFL_CASE(8) TFL_CASE(16) TFL_CASE(32)
+    default: return false;
+  }
+#undef TFL_CASE
+}
+
+}  // namespace tfl

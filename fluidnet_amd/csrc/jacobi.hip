@@ -55,11 +55,11 @@ void jacobi_iteration(hipStream_t st, bool is3d, int B, int Z, int Y, int X, con
   const Dom d = make_dom(Z, Y, X);
   const dim3 blk(64, 4, 1), grd((X + 63) / 64, (Y + 3) / 4, (unsigned)(Z * B));
   if (is3d) {
-    if (resid_sq) k_jacobi<true, true><<<grd, blk, 0, st>>>(d, p_prev, flags, div, p, resid_sq);
-    else k_jacobi<true, false><<<grd, blk, 0, st>>>(d, p_prev, flags, div, p, nullptr);
+    if (resid_sq) { TFL_TIMED("k_jacobi", st); k_jacobi<true, true><<<grd, blk, 0, st>>>(d, p_prev, flags, div, p, resid_sq); }
+    else { TFL_TIMED("k_jacobi", st); k_jacobi<true, false><<<grd, blk, 0, st>>>(d, p_prev, flags, div, p, nullptr); }
   } else {
-    if (resid_sq) k_jacobi<false, true><<<grd, blk, 0, st>>>(d, p_prev, flags, div, p, resid_sq);
-    else k_jacobi<false, false><<<grd, blk, 0, st>>>(d, p_prev, flags, div, p, nullptr);
+    if (resid_sq) { TFL_TIMED("k_jacobi", st); k_jacobi<false, true><<<grd, blk, 0, st>>>(d, p_prev, flags, div, p, resid_sq); }
+    else { TFL_TIMED("k_jacobi", st); k_jacobi<false, false><<<grd, blk, 0, st>>>(d, p_prev, flags, div, p, nullptr); }
   }
 }
 

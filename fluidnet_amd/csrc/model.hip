@@ -1,0 +1,219 @@
+// model.hip -- the ConvNet pressure projection of FluidNet's `default` model (gfx950), everything
+// except the convolution layers themselves (conv.hip).
+//
+// Replaces the nngraph of torch/lib/model.lua:27-401 (forward only):
+//   SetWallBcs(UDiv) -> VelocityDivergence -> scale = std(UDiv_bc) -> {pDiv, div}/scale, occupancy
+//   -> conv stack -> VelocityUpdate(pPred, UDiv_bc/scale) -> p, U *= scale -> SetWallBcs(U)
+// The reference runs this as ~25 cuDNN / THC / tfluids launches with dense temporaries per node
+// (mask tensors, JoinTable copies, ...). Here the non-conv nodes are three HBM-bound kernels:
+//   k_bcs_div_stats : U, flags -> U_bc (into the caller's U output buffer), div, and the per-sample
+//                     sum(u), sum(u^2) of U_bc accumulated in fp64 (one atomic pair per block)
+//   k_net_input     : pDiv, div, flags, stats -> the 3 input planes {pDiv/scale, div/scale, occ}
+//   k_project       : pPred, U_bc, flags, stats -> p = pPred*scale, U = SetWallBcs(VelocityUpdate(
+//                     U_bc/scale, pPred) * scale), optionally fused with simulate()'s trailing
+//                     setConstVals + clamp (lib/simulate.lua:321-326)
+#include "tfl_device.hpp"
+#include "tfl_host.hpp"
+
+namespace tfl {
+
+// setWallBcs decision for the cell's own three face components, third_party/tfluids.cc:926-1002
+template <bool IS3D>
+__device__ __forceinline__ void wall_zero_mask(const Dom& d, const float* __restrict__ flags, int i, int j, int k, int o,
+                                               bool& zx, bool& zy, bool& zz) {
+  zx = zy = zz = false;
+  const int fc = (int)flags[o];
+  const bool cf = fc & kFluid, co = fc & kObstacle;
+  if (!cf && !co) return;
+  const int fxm = i > 0 ? (int)flags[o - 1] : 0;
+  const int fym = j > 0 ? (int)flags[o - d.sy] : 0;
+  const int fzm = (IS3D && k > 0) ? (int)flags[o - d.sz] : 0;
+  zx = (fxm & kObstacle) || (co && (fxm & kFluid));
+  zy = (fym & kObstacle) || (co && (fym & kFluid));
+  zz = IS3D && ((fzm & kObstacle) || (co && (fzm & kFluid)));
+  if (cf) {
+    const int fxp = i < d.X - 1 ? (int)flags[o + 1] : 0;
+    const int fyp = j < d.Y - 1 ? (int)flags[o + d.sy] : 0;
+    const int fzp = (IS3D && k < d.Z - 1) ? (int)flags[o + d.sz] : 0;
+    if ((fxm & kStick) || (fxp & kStick)) { zy = true; zz = IS3D; }
+    if ((fym & kStick) || (fyp & kStick)) { zx = true; zz = IS3D; }
+    if (IS3D && ((fzm & kStick) || (fzp & kStick))) { zx = true; zy = true; }
+  }
+}
+
+// U_bc component AXIS of cell (i,j,k): the input velocity with the wall BCs applied on the fly
+template <bool IS3D, int AXIS>
+__device__ __forceinline__ float u_bc_at(const Dom& d, const float* __restrict__ U, const float* __restrict__ flags,
+                                         int i, int j, int k) {
+  const int o = TFL_AT(d, i, j, k);
+  bool zx, zy, zz;
+  wall_zero_mask<IS3D>(d, flags, i, j, k, o, zx, zy, zz);
+  const bool z = AXIS == 0 ? zx : (AXIS == 1 ? zy : zz);
+  return z ? 0.0f : U[o + AXIS * d.sc];
+}
+
+// stats[b*2 + 0] = sum u, stats[b*2 + 1] = sum u^2 over all C*Z*Y*X values of U_bc[b]
+template <bool IS3D>
+__global__ __launch_bounds__(256) void k_bcs_div_stats(Dom d, const float* __restrict__ U, const float* __restrict__ flags,
+                                                       float* __restrict__ Ubc, float* __restrict__ div,
+                                                       double* __restrict__ stats) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = blockIdx.y * blockDim.y + threadIdx.y;
+  const int b = blockIdx.z / d.Z, k = blockIdx.z - b * d.Z;
+  const long long cells = d.sc;
+  const int C = IS3D ? 3 : 2;
+  double s1 = 0.0, s2 = 0.0;
+  if (i < d.X && j < d.Y) {
+    U += b * cells * C; Ubc += b * cells * C; flags += b * cells; div += b * cells;
+    const int o = TFL_AT(d, i, j, k);
+    bool zx, zy, zz;
+    wall_zero_mask<IS3D>(d, flags, i, j, k, o, zx, zy, zz);
+    const float ux = zx ? 0.0f : U[o];
+    const float uy = zy ? 0.0f : U[o + d.sc];
+    const float uz = IS3D ? (zz ? 0.0f : U[o + 2 * d.sc]) : 0.0f;
+    Ubc[o] = ux; Ubc[o + d.sc] = uy; if (IS3D) Ubc[o + 2 * d.sc] = uz;
+    s1 = (double)ux + (double)uy + (double)uz;
+    s2 = (double)ux * ux + (double)uy * uy + (double)uz * uz;
+    float dv = 0.0f;  // velocityDivergenceForward on U_bc, tfluids.cc:1008-1066
+    if (!on_border<IS3D>(d, i, j, k) && (((int)flags[o]) & kFluid)) {
+      dv = ux - u_bc_at<IS3D, 0>(d, U, flags, i + 1, j, k) + uy - u_bc_at<IS3D, 1>(d, U, flags, i, j + 1, k);
+      if (IS3D) dv += (uz - u_bc_at<IS3D, 2>(d, U, flags, i, j, k + 1));
+    }
+    div[o] = dv;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { s1 += __shfl_down(s1, off, 64); s2 += __shfl_down(s2, off, 64); }
+  __shared__ double part[8];
+  const int tid = threadIdx.y * blockDim.x + threadIdx.x;
+  if ((tid & 63) == 0) { part[(tid >> 6) * 2] = s1; part[(tid >> 6) * 2 + 1] = s2; }
+  __syncthreads();
+  if (tid == 0) {
+    atomicAdd(&stats[b * 2], part[0] + part[2] + part[4] + part[6]);
+    atomicAdd(&stats[b * 2 + 1], part[1] + part[3] + part[5] + part[7]);
+  }
+}
+
+// lib/modules/variance.lua:44-76 (n-1) + Sqrt; the Clamp after it is a no-op (model.lua:106 typo)
+__device__ __forceinline__ float scale_from_stats(const double* __restrict__ stats, int b, double n) {
+  const double s1 = stats[b * 2], s2 = stats[b * 2 + 1];
+  return (float)sqrt((n * s2 - s1 * s1) / (n * (n - 1.0)));
+}
+
+template <bool IS3D>
+__global__ __launch_bounds__(256) void k_net_input(Dom d, const float* __restrict__ pDiv, const float* __restrict__ div,
+                                                   const float* __restrict__ flags, const double* __restrict__ stats,
+                                                   float* __restrict__ x3) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = blockIdx.y * blockDim.y + threadIdx.y;
+  const int b = blockIdx.z / d.Z, k = blockIdx.z - b * d.Z;
+  if (i >= d.X || j >= d.Y) return;
+  const long long cells = d.sc;
+  const float scale = scale_from_stats(stats, b, (double)cells * (IS3D ? 3 : 2));
+  const int o = TFL_AT(d, i, j, k);
+  const long long bo = b * cells;
+  x3 += bo * 3;
+  x3[o] = pDiv[bo + o] / scale;               // nn.ApplyScale(true) = CDivTable, apply_scale.lua:24-30
+  x3[o + d.sc] = div[bo + o] / scale;
+  const int f = (int)flags[bo + o];           // tfluids.FlagsToOccupancy, generic/tfluids.cu:355-371
+  x3[o + 2 * d.sc] = (f == kFluid) ? 0.0f : ((f == kObstacle) ? 1.0f : -1.0f);
+}
+
+struct BcArgs {  // optional fused tail of simulate(): setConstVals + clamp, simulate.lua:321-326
+  const float* UBC; const float* UInvMask;
+  int enable_clamp; float lo, hi;
+};
+
+template <bool IS3D>
+__global__ __launch_bounds__(256) void k_project(Dom d, const float* __restrict__ pPred, const float* __restrict__ flags,
+                                                 const double* __restrict__ stats, float* __restrict__ Uio,
+                                                 float* __restrict__ pOut, BcArgs bc) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = blockIdx.y * blockDim.y + threadIdx.y;
+  const int b = blockIdx.z / d.Z, k = blockIdx.z - b * d.Z;
+  if (i >= d.X || j >= d.Y) return;
+  const long long cells = d.sc;
+  const int C = IS3D ? 3 : 2;
+  const float scale = scale_from_stats(stats, b, (double)cells * C);
+  pPred += b * cells; flags += b * cells; pOut += b * cells; Uio += b * cells * C;
+  const int o = TFL_AT(d, i, j, k);
+  const float pc = pPred[o];
+  float u[3];
+  u[0] = Uio[o] / scale; u[1] = Uio[o + d.sc] / scale; u[2] = IS3D ? Uio[o + 2 * d.sc] / scale : 0.0f;
+  if (!on_border<IS3D>(d, i, j, k)) {  // velocityUpdateForward, tfluids.cc:1072-1156
+    const int fc = (int)flags[o];
+    const int fn[3] = {(int)flags[o - 1], (int)flags[o - d.sy], IS3D ? (int)flags[o - d.sz] : 0};
+    const int st[3] = {1, d.sy, d.sz};
+    if (fc & kFluid) {
+#pragma unroll
+      for (int c = 0; c < C; c++) {
+        if (fn[c] & kFluid) u[c] -= (pc - pPred[o - st[c]]);
+        if (fn[c] & kEmpty) u[c] -= pc;
+      }
+    } else if ((fc & kEmpty) && !(fc & kOutflow)) {
+#pragma unroll
+      for (int c = 0; c < C; c++) u[c] = (fn[c] & kFluid) ? u[c] + pPred[o - st[c]] : 0.0f;
+    }
+  }
+  bool z[3];
+  wall_zero_mask<IS3D>(d, flags, i, j, k, o, z[0], z[1], z[2]);
+  pOut[o] = pc * scale;  // nn.ApplyScale(false) = CMulTable, model.lua:383-387
+#pragma unroll
+  for (int c = 0; c < C; c++) {
+    float v = z[c] ? 0.0f : u[c] * scale;
+    if (bc.UBC) {
+      const long long g = b * cells * C + o + c * d.sc;
+      v = v * bc.UInvMask[g] + bc.UBC[g];
+    }
+    if (bc.enable_clamp) v = fminf(fmaxf(v, bc.lo), bc.hi);
+    Uio[o + c * d.sc] = v;
+  }
+}
+
+// x = clamp(x * invMask + bc): setConstVals (+ the final U:clamp) of lib/simulate.lua:130-160,326
+__global__ __launch_bounds__(256) void k_apply_bcs(long long n, float* __restrict__ x, const float* __restrict__ bcv,
+                                                   const float* __restrict__ inv, int do_clamp, float lo, float hi) {
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) {
+    float v = x[t];
+    if (bcv) v = v * inv[t] + bcv[t];
+    if (do_clamp) v = fminf(fmaxf(v, lo), hi);
+    x[t] = v;
+  }
+}
+
+#define TFL_GRID3(d, B) dim3(((d).X + 63) / 64, ((d).Y + 3) / 4, (unsigned)((d).Z * (B)))
+
+void model_pre(hipStream_t st, bool is3d, int B, int Z, int Y, int X, const float* U, const float* flags, float* Ubc,
+               float* div, double* stats) {
+  const Dom d = make_dom(Z, Y, X);
+  const dim3 blk(64, 4, 1), grd = TFL_GRID3(d, B);
+  (void)hipMemsetAsync(stats, 0, sizeof(double) * 2 * B, st);
+  if (is3d) { TFL_TIMED("k_bcs_div_stats", st); k_bcs_div_stats<true><<<grd, blk, 0, st>>>(d, U, flags, Ubc, div, stats); }
+  else { TFL_TIMED("k_bcs_div_stats", st); k_bcs_div_stats<false><<<grd, blk, 0, st>>>(d, U, flags, Ubc, div, stats); }
+}
+
+void model_net_input(hipStream_t st, bool is3d, int B, int Z, int Y, int X, const float* pDiv, const float* div,
+                     const float* flags, const double* stats, float* x3) {
+  const Dom d = make_dom(Z, Y, X);
+  const dim3 blk(64, 4, 1), grd = TFL_GRID3(d, B);
+  if (is3d) { TFL_TIMED("k_net_input", st); k_net_input<true><<<grd, blk, 0, st>>>(d, pDiv, div, flags, stats, x3); }
+  else { TFL_TIMED("k_net_input", st); k_net_input<false><<<grd, blk, 0, st>>>(d, pDiv, div, flags, stats, x3); }
+}
+
+void model_project(hipStream_t st, bool is3d, int B, int Z, int Y, int X, const float* pPred, const float* flags,
+                   const double* stats, float* Uio, float* pOut, const float* UBC, const float* UInvMask, int do_clamp,
+                   float lo, float hi) {
+  const Dom d = make_dom(Z, Y, X);
+  const dim3 blk(64, 4, 1), grd = TFL_GRID3(d, B);
+  BcArgs bc; bc.UBC = UBC; bc.UInvMask = UInvMask; bc.enable_clamp = do_clamp; bc.lo = lo; bc.hi = hi;
+  if (is3d) { TFL_TIMED("k_project", st); k_project<true><<<grd, blk, 0, st>>>(d, pPred, flags, stats, Uio, pOut, bc); }
+  else { TFL_TIMED("k_project", st); k_project<false><<<grd, blk, 0, st>>>(d, pPred, flags, stats, Uio, pOut, bc); }
+}
+
+void apply_bcs(hipStream_t st, long long n, float* x, const float* bcv, const float* inv, int do_clamp, float lo,
+               float hi) {
+  long long blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  { TFL_TIMED("k_apply_bcs", st); k_apply_bcs<<<(int)(blocks > 0 ? blocks : 1), 256, 0, st>>>(n, x, bcv, inv, do_clamp, lo, hi); }
+}
+
+}  // namespace tfl

@@ -149,6 +149,7 @@ static inline dim3 cgrid(const Dom& d, int B, dim3 blk) {
   do {                                                               \
     const Dom d = make_dom(Z, Y, X);                                 \
     const dim3 blk(64, 4, 1), grd = cgrid(d, B, blk);                \
+    TFL_TIMED(#kern, st);                                            \
     if (is3d) kern<true><<<grd, blk, 0, st>>>(d, __VA_ARGS__);       \
     else kern<false><<<grd, blk, 0, st>>>(d, __VA_ARGS__);           \
   } while (0)
@@ -177,7 +178,7 @@ void empty_domain(hipStream_t st, bool is3d, int bnd, int B, int Z, int Y, int X
 }
 void flags_to_occupancy(hipStream_t st, long long numel, const float* flags, float* occ) {
   const int blocks = (int)((numel + 255) / 256 < 2048 ? (numel + 255) / 256 : 2048);
-  k_flags_to_occupancy<<<blocks > 0 ? blocks : 1, 256, 0, st>>>(numel, flags, occ);
+  { TFL_TIMED("k_flags_to_occupancy", st); k_flags_to_occupancy<<<blocks > 0 ? blocks : 1, 256, 0, st>>>(numel, flags, occ); }
 }
 
 }  // namespace tfl

@@ -4,6 +4,17 @@
 
 namespace tfl {
 
+// Built-in per-kernel timing (the reference only has host timers around the projection,
+// lib/simulate.lua:254-260,306-318). When a profile is active on this thread every kernel launch is
+// bracketed by hipEvents on the launch stream; tfl_profile_end() sums them per kernel name.
+struct KernelTimer {
+  KernelTimer(const char* name, hipStream_t st);
+  ~KernelTimer();
+  int slot_;
+  hipStream_t st_;
+};
+#define TFL_TIMED(name, st) ::tfl::KernelTimer tfl_timer_(name, st)
+
 // advect.hip
 void advect_scalar(hipStream_t st, bool is3d, int method, int B, int Z, int Y, int X, float dt, float strength,
                    int outside, unsigned long long* err, const float* s, const float* U, const float* flags,
@@ -31,5 +42,20 @@ void vorticity_confinement(hipStream_t st, bool is3d, int B, int Z, int Y, int X
 // jacobi.hip
 void jacobi_iteration(hipStream_t st, bool is3d, int B, int Z, int Y, int X, const float* p_prev, const float* flags,
                       const float* div, float* p, double* resid_sq /* [B] or nullptr */);
+
+// model.hip
+void model_pre(hipStream_t st, bool is3d, int B, int Z, int Y, int X, const float* U, const float* flags, float* Ubc,
+               float* div, double* stats);
+void model_net_input(hipStream_t st, bool is3d, int B, int Z, int Y, int X, const float* pDiv, const float* div,
+                     const float* flags, const double* stats, float* x3);
+void model_project(hipStream_t st, bool is3d, int B, int Z, int Y, int X, const float* pPred, const float* flags,
+                   const double* stats, float* Uio, float* pOut, const float* UBC, const float* UInvMask, int do_clamp,
+                   float lo, float hi);
+void apply_bcs(hipStream_t st, long long n, float* x, const float* bcv, const float* inv, int do_clamp, float lo,
+               float hi);
+
+// conv.hip
+bool conv_direct(hipStream_t st, bool is3d, int B, int Z, int Y, int X, int cin, int cout, int ksz, bool relu,
+                 const float* in, const float* w, const float* bias, float* out);
 
 }  // namespace tfl

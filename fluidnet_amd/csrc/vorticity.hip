@@ -94,11 +94,11 @@ void vorticity_confinement(hipStream_t st, bool is3d, int B, int Z, int Y, int X
   const Dom d = make_dom(Z, Y, X);
   const dim3 blk(64, 4, 1), grd((X + 63) / 64, (Y + 3) / 4, (unsigned)(Z * B));
   if (is3d) {
-    k_curl<true><<<grd, blk, 0, st>>>(d, U, curl, curl_norm);
-    k_confine<true><<<grd, blk, 0, st>>>(d, U, flags, curl, curl_norm, strength);
+    { TFL_TIMED("k_curl", st); k_curl<true><<<grd, blk, 0, st>>>(d, U, curl, curl_norm); }
+    { TFL_TIMED("k_confine", st); k_confine<true><<<grd, blk, 0, st>>>(d, U, flags, curl, curl_norm, strength); }
   } else {
-    k_curl<false><<<grd, blk, 0, st>>>(d, U, curl, curl_norm);
-    k_confine<false><<<grd, blk, 0, st>>>(d, U, flags, curl, curl_norm, strength);
+    { TFL_TIMED("k_curl", st); k_curl<false><<<grd, blk, 0, st>>>(d, U, curl, curl_norm); }
+    { TFL_TIMED("k_confine", st); k_confine<false><<<grd, blk, 0, st>>>(d, U, flags, curl, curl_norm, strength); }
   }
 }
 

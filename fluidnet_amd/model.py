@@ -1,0 +1,109 @@
+"""The pressure-projection ConvNet: host mirror of torch/lib/model.lua's `default` model.
+
+`FluidNetModel.forward({pDiv, UDiv, flags}) -> {p, U}` has the call shape of the reference's
+`model:forward(torch.getModelInput(batch))` (lib/model.lua:398, 421-450; lib/simulate.lua:262-272).
+The graph (SetWallBcs -> divergence -> std-normalise -> conv stack -> VelocityUpdate -> un-scale ->
+SetWallBcs) runs inside libtfluids_hip.so (tfl_model_forward); this class only owns the weights'
+host copy, the device handle and the scratch tensor.
+"""
+import ctypes
+import math
+
+import numpy as np
+import torch
+
+from . import _lib, tfluids, torch7
+from ._lib import TfluidsError
+
+
+class FluidNetModel:
+    def __init__(self, layers, is3D):
+        """layers: [(weight[nOut, nIn, k(,k),k], bias[nOut])] in forward order (numpy float32),
+        weight layout as cudnn.{Spatial,Volumetric}Convolution.weight."""
+        self.is3D = bool(is3D)
+        self.layers = [(np.ascontiguousarray(w, np.float32), np.ascontiguousarray(b, np.float32))
+                       for w, b in layers]
+        for w, _ in self.layers:
+            if w.ndim != (5 if self.is3D else 4):
+                raise TfluidsError("weight rank does not match is3D")
+        self._handles = {}   # device index -> tfl_model*
+        self._work = {}      # device index -> scratch tensor
+
+    # -- constructors ------------------------------------------------------------------------
+    @classmethod
+    def from_torch7(cls, path):
+        """Load a model saved by torch.saveModel (lib/model.lua:463-478), e.g. data/models/myModel2D."""
+        layers = torch7.conv_layers(torch7.load(path))
+        if not layers:
+            raise TfluidsError("no convolution layers found in " + path)
+        return cls(layers, is3D=layers[0][0].ndim == 5)
+
+    @classmethod
+    def from_npz(cls, path):
+        z = np.load(path)
+        n = len([k for k in z.files if k.startswith("w")])
+        layers = [(z["w%d" % i], z["b%d" % i]) for i in range(n)]
+        return cls(layers, is3D=layers[0][0].ndim == 5)
+
+    @classmethod
+    def default_3d(cls, seed=1, scale=0.35):
+        """Seeded stand-in for a trained 3-D `default` model (the reference ships none): topology of
+        lib/model.lua:219-226 (3->8 k3, 8->8 k3, 8->8 k3, 8->8 k1, 8->1 k1)."""
+        rng = np.random.RandomState(seed)
+        layers = []
+        for co, ci, k in [(8, 3, 3), (8, 8, 3), (8, 8, 3), (8, 8, 1), (1, 8, 1)]:
+            fan = ci * k ** 3
+            w = (rng.randn(co, ci, k, k, k) * scale * math.sqrt(2.0 / fan)).astype(np.float32)
+            b = (rng.randn(co) * 0.01).astype(np.float32)
+            layers.append((w, b))
+        return cls(layers, True)
+
+    # -- device handle -----------------------------------------------------------------------
+    def _handle(self, lib, ctx, dev):
+        h = self._handles.get(dev)
+        if h is None:
+            n = len(self.layers)
+            I32 = ctypes.c_int32 * n
+            cin = I32(*[w.shape[1] for w, _ in self.layers])
+            cout = I32(*[w.shape[0] for w, _ in self.layers])
+            ks = I32(*[w.shape[-1] for w, _ in self.layers])
+            FP = ctypes.POINTER(ctypes.c_float)
+            ws = (FP * n)(*[w.ctypes.data_as(FP) for w, _ in self.layers])
+            bs = (FP * n)(*[b.ctypes.data_as(FP) for _, b in self.layers])
+            h = lib.tfl_model_create(ctx, int(self.is3D), n, cin, cout, ks, ws, bs)
+            if not h:
+                raise TfluidsError(lib.tfl_last_error(ctx).decode())
+            self._handles[dev] = h
+        return h
+
+    def forward(self, inputs, out=None, UBC=None, UBCInvMask=None, clamp=None):
+        """inputs = [pDiv, UDiv, flags] -> [p, U]. `out=[p, U]` writes into given tensors (they may
+        be the inputs themselves: simulate() copies the prediction back into the state anyway).
+        UBC/UBCInvMask/clamp fuse simulate()'s trailing setConstVals + clamp into the last kernel."""
+        pDiv, UDiv, flags = inputs
+        tfluids._dims(UDiv, flags)
+        tfluids._check(pDiv.shape == flags.shape and pDiv.is_contiguous(), "Size mismatch")
+        tfluids._check((UDiv.size(1) == 3) == self.is3D, "model / input dimensionality mismatch")
+        lib, ctx = tfluids._context(UDiv)
+        dev = UDiv.device.index
+        h = self._handle(lib, ctx, dev)
+        B, _, Z, Y, X = flags.shape
+        need = lib.tfl_model_workspace_floats(h, B, Z, Y, X)
+        work = self._work.get(dev)
+        if work is None or work.numel() < need:
+            work = torch.empty(need, dtype=torch.float32, device=UDiv.device)
+            self._work[dev] = work
+        if out is None:
+            p, U = torch.empty_like(pDiv), torch.empty_like(UDiv)
+        else:
+            p, U = out
+        lo, hi = clamp if clamp is not None else (0.0, 0.0)
+        rc = lib.tfl_model_forward(ctx, h, tfluids._tt(pDiv), tfluids._tt(UDiv), tfluids._tt(flags),
+                                   tfluids._tt(p), tfluids._tt(U), ctypes.c_void_p(work.data_ptr()),
+                                   work.numel(), tfluids._tt(UBC) if UBC is not None else None,
+                                   tfluids._tt(UBCInvMask) if UBCInvMask is not None else None,
+                                   int(clamp is not None), lo, hi)
+        tfluids._call(lib, ctx, rc)
+        return [p, U]
+
+    __call__ = forward

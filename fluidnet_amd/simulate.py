@@ -1,0 +1,161 @@
+"""Host mirror of torch/lib/simulate.lua: tfluids.simulate, setConstVals, createPlumeBCs.
+
+`batch` is a dict with the reference's keys (pDiv, UDiv, flags, density [+ UBC, UBCInvMask,
+densityBC, densityBCInvMask, pBC, pBCInvMask]) holding torch tensors on an MI355X; `mconf` is a dict
+with the reference's model-config names (dt, advectionMethod, maccormackStrength, buoyancyScale,
+gravityScale, vorticityConfinementAmp, simMethod, maxIter, gravity). State is updated in place in the
+*Div slots exactly like the Lua (simulate.lua:180).
+"""
+import math
+
+import torch
+
+from . import tfluids
+from ._lib import TfluidsError
+
+
+def getPUFlagsDensityReference(batch):
+    return batch["pDiv"], batch["UDiv"], batch["flags"], batch.get("density")
+
+
+def createPlumeBCs(batch, densityVal, uScale, rad):
+    """simulate.lua:47-123 (1-based loops restated as index arithmetic; same cells, same values)."""
+    U = batch["UDiv"]
+    batch["pBC"] = None
+    batch["pBCInvMask"] = None
+    batch["UBC"] = torch.zeros_like(U)
+    batch["UBCInvMask"] = torch.ones_like(U)
+    dens = batch.get("density")
+    if dens is None:
+        raise TfluidsError("plume BCs require a density field to be specified")
+    multi = isinstance(dens, (list, tuple))
+    chans = list(dens) if multi else [dens]
+    if len(densityVal) != len(chans):
+        raise TfluidsError("Need a density val per channel")
+    if U.dim() != 5 or U.size(0) != 1:
+        raise TfluidsError("Only single batch allowed.")
+    _, C, zdim, ydim, xdim = U.shape
+    is3D = C == 3
+    if not is3D and zdim != 1:
+        raise TfluidsError("2D plume needs zdim == 1")
+    centerX = xdim // 2
+    centerZ = max(zdim // 2, 1)
+    plumeRad = int(math.floor(xdim * rad))
+    x = torch.arange(1, xdim + 1, device=U.device).view(1, 1, xdim)
+    z = torch.arange(1, zdim + 1, device=U.device).view(zdim, 1, 1)
+    inside = ((centerX - x) ** 2 + (centerZ - z) ** 2) <= plumeRad * plumeRad   # [Z, 1, X]
+    rows = min(4, ydim)
+    inside = inside.expand(zdim, rows, xdim)
+    batch["UBCInvMask"][0, :, :, :rows, :] = 0.0                                   # in or out of the plume
+    batch["UBC"][0, 1, :, :rows, :] = torch.where(inside, float(uScale), 0.0).to(U.dtype)
+    dbc, dmask = [], []
+    for c, val in zip(chans, densityVal):
+        bc, mk = torch.zeros_like(c), torch.ones_like(c)
+        bc[0, 0, :, :rows, :] = torch.where(inside, float(val), 0.0).to(c.dtype)
+        mk[0, 0, :, :rows, :] = torch.where(inside, 0.0, 1.0).to(c.dtype)
+        dbc.append(bc)
+        dmask.append(mk)
+    batch["densityBC"] = dbc if multi else dbc[0]
+    batch["densityBCInvMask"] = dmask if multi else dmask[0]
+
+
+def _apply(x, bc, inv, clamp=None):
+    lib, ctx = tfluids._context(x)
+    lo, hi = clamp if clamp is not None else (0.0, 0.0)
+    tfluids._call(lib, ctx, lib.tfl_applyBCs(ctx, tfluids._tt5(x), tfluids._tt5(bc) if bc is not None else None,
+                                             tfluids._tt5(inv) if inv is not None else None,
+                                             int(clamp is not None), lo, hi))
+
+
+def setConstVals(batch, p, U, flags, density):
+    """simulate.lua:130-160: X = X*invMask + BC for p, U and each density channel."""
+    if batch.get("pBC") is not None or batch.get("pBCInvMask") is not None:
+        _apply(p, batch["pBC"], batch["pBCInvMask"])
+    if batch.get("UBC") is not None or batch.get("UBCInvMask") is not None:
+        _apply(U, batch["UBC"], batch["UBCInvMask"])
+    if batch.get("densityBC") is not None or batch.get("densityBCInvMask") is not None:
+        if isinstance(density, (list, tuple)):
+            if len(density) != len(batch["densityBC"]):
+                raise TfluidsError("density / densityBC channel mismatch")
+            for i in range(len(density)):
+                _apply(density[i], batch["densityBC"][i], batch["densityBCInvMask"][i])
+        else:
+            _apply(density, batch["densityBC"], batch["densityBCInvMask"])
+
+
+def _gravity(mconf):
+    g = mconf.get("gravity")
+    if g is None:
+        return [0.0, 1.0, 0.0]
+    return [float(v) for v in (g.tolist() if torch.is_tensor(g) else g)]
+
+
+def _f32(v):
+    return torch.tensor(v, dtype=torch.float32).item()
+
+
+def simulate(conf, mconf, batch, model, outputDiv=False):
+    """tfluids.simulate, simulate.lua:175-327 (same call order, same in-place state update)."""
+    p, U, flags, density = getPUFlagsDensityReference(batch)
+    dt = mconf["dt"]
+    method = mconf.get("advectionMethod")
+    strength = mconf.get("maccormackStrength")
+    if density is not None:
+        chans = density if isinstance(density, (list, tuple)) else [density]
+        for chan in chans:
+            tfluids.advectScalar(dt, chan, U, flags, method, None, False, strength)
+    tfluids.advectVel(dt, U, flags, method, None, strength)
+    setConstVals(batch, p, U, flags, density)
+
+    if density is not None and mconf.get("buoyancyScale", 0) > 0:
+        s = _f32(-(tfluids.getDx(flags) / 4) * mconf["buoyancyScale"])   # gravity:mul(...) on a float tensor
+        g = [_f32(v) * s for v in _gravity(mconf)]
+        d0 = density[0] if isinstance(density, (list, tuple)) else density
+        tfluids.addBuoyancy(U, flags, d0, g, dt)
+    if mconf.get("gravityScale", 0) > 0:
+        s = _f32((-tfluids.getDx(flags) / 4) * mconf["gravityScale"])
+        g = [_f32(v) * s for v in _gravity(mconf)]
+        tfluids.addGravity(U, flags, g, dt)
+    if mconf.get("vorticityConfinementAmp", 0) > 0:
+        tfluids.vorticityConfinement(U, flags, tfluids.getDx(flags) * mconf["vorticityConfinementAmp"])
+    if outputDiv:
+        return
+
+    simMethod = mconf.get("simMethod") or "convnet"
+    if simMethod != "convnet":
+        tfluids.setWallBcsForward(U, flags)
+    setConstVals(batch, p, U, flags, density)
+
+    fused_tail = False
+    if simMethod == "convnet":
+        # model:forward + p:copy(pPred); U:copy(UPred) (simulate.lua:262-272): the prediction is
+        # written straight into the state tensors, and the trailing setConstVals(U) + U:clamp
+        # (simulate.lua:321-326) ride in the projection's last kernel.
+        has_ubc = batch.get("UBC") is not None
+        model.forward([p, U, flags], out=[p, U], UBC=batch.get("UBC"), UBCInvMask=batch.get("UBCInvMask"),
+                      clamp=(-1e6, 1e6))
+        fused_tail = True
+        if batch.get("pBC") is not None:
+            _apply(p, batch["pBC"], batch["pBCInvMask"])
+        if batch.get("densityBC") is not None:
+            if isinstance(density, (list, tuple)):
+                for i in range(len(density)):
+                    _apply(density[i], batch["densityBC"][i], batch["densityBCInvMask"][i])
+            else:
+                _apply(density, batch["densityBC"], batch["densityBCInvMask"])
+        del has_ubc
+    elif simMethod == "jacobi":
+        div = batch.get("div")
+        if div is None or div.shape != p.shape:
+            div = torch.empty_like(p)
+            batch["div"] = div
+        tfluids.velocityDivergenceForward(U, flags, div)
+        is3D = U.size(1) == 3
+        tfluids.solveLinearSystemJacobi(p, flags, div, is3D, 0, mconf.get("maxIter") or 100, residual=False)
+        tfluids.velocityUpdateForward(U, flags, p)
+    else:
+        raise TfluidsError("mconf.simMethod (%s) is not a valid option" % simMethod)
+
+    if not fused_tail:
+        setConstVals(batch, p, U, flags, density)
+        _apply(U, None, None, clamp=(-1e6, 1e6))

@@ -47,6 +47,13 @@ def _tt(t):
     return ctypes.byref(tfl_tensor(t.data_ptr(), b, c, z, y, x))
 
 
+def _tt5(t):
+    """Any contiguous fp32 tensor with <= 5 dims as a 5-D descriptor (leading dims padded with 1)."""
+    _check(t.dtype == torch.float32 and t.is_contiguous(), "tensors must be contiguous float32")
+    sh = [1] * (5 - t.dim()) + list(t.shape)
+    return ctypes.byref(tfl_tensor(t.data_ptr(), *sh))
+
+
 def _call(lib, ctx, rc):
     if rc != 0:
         raise TfluidsError(lib.tfl_last_error(ctx).decode())
@@ -234,8 +241,9 @@ def flagsToOccupancy(flags, occupancy):
     _call(lib, ctx, lib.tfl_flagsToOccupancy(ctx, _tt(flags), _tt(occupancy)))
 
 
-def solveLinearSystemJacobi(p, flags, div, is3D, pTol=None, maxIter=None, verbose=None):
-    """init.lua:693-735. Returns the final residual (a Python float => one host sync)."""
+def solveLinearSystemJacobi(p, flags, div, is3D, pTol=None, maxIter=None, verbose=None, residual=True):
+    """init.lua:693-735. Returns the final residual (a Python float => one host sync at the end);
+    residual=False skips the readback (returns None) when pTol <= 0, keeping the call fully async."""
     pTol = 1e-5 if pTol is None else pTol
     maxIter = 1000 if maxIter is None else maxIter
     verbose = bool(verbose)
@@ -254,11 +262,35 @@ def solveLinearSystemJacobi(p, flags, div, is3D, pTol=None, maxIter=None, verbos
     _call(lib, ctx, lib.tfl_solveLinearSystemJacobi(ctx, _tt(p), _tt(flags), _tt(div), _tt(pPrev),
                                                     _tt(pDelta), ctypes.byref(dn), int(bool(is3D)),
                                                     float(pTol), int(maxIter), int(verbose),
-                                                    ctypes.byref(res)))
-    return res.value
+                                                    ctypes.byref(res) if (residual or pTol > 0) else None))
+    return res.value if (residual or pTol > 0) else None
 
 
 def traceErrors(like):
     """Back-traces that hit a calcLineTrace invariant path since the last call (diagnostic)."""
     lib, ctx = _context(like)
     return int(lib.tfl_trace_errors(ctx))
+
+
+class profile:
+    """with tfluids.profile(tensor) as prof: ...; prof.kernels -> {name: {"calls": n, "ms": total}}.
+    Per-kernel HIP-event timing inside the library (tfl_profile_begin/end)."""
+
+    def __init__(self, like):
+        self._like = like
+        self.kernels = {}
+
+    def __enter__(self):
+        lib, ctx = _context(self._like)
+        _call(lib, ctx, lib.tfl_profile_begin(ctx))
+        return self
+
+    def __exit__(self, *exc):
+        import json
+        lib, ctx = _context(self._like)
+        buf = ctypes.create_string_buffer(1 << 16)
+        n = lib.tfl_profile_end(ctx, buf, len(buf))
+        if n < 0:
+            raise TfluidsError(lib.tfl_last_error(ctx).decode())
+        self.kernels = json.loads(buf.value.decode() or "{}")
+        return False

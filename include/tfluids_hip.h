@@ -72,6 +72,14 @@ int tfl_synchronize(tfl_ctx* ctx);
  * silently substitutes). Synchronises the stream. Diagnostic only. */
 int64_t tfl_trace_errors(tfl_ctx* ctx);
 
+/* Built-in per-kernel timing, the analogue of tfluids.profilePressure (lib/simulate.lua:254-260,
+ * 306-318) at kernel granularity: between begin and end every kernel this library launches from the
+ * calling thread is bracketed by HIP events on its launch stream. tfl_profile_end synchronises,
+ * writes a JSON object {"kernel": {"calls": n, "ms": total}, ...} into buf (truncated to cap) and
+ * returns the number of distinct kernels, or a negative tfl_status. */
+int tfl_profile_begin(tfl_ctx* ctx);
+int tfl_profile_end(tfl_ctx* ctx, char* buf, int64_t cap);
+
 /* ---- operators (one per row of SURVEY.md section 8b) ------------------------------------- */
 
 /* init.lua:142-144 -> third_party/tfluids.cc:415-588 | tfluids.cu:524-633.
@@ -135,6 +143,40 @@ int tfl_solveLinearSystemJacobi(tfl_ctx* ctx, const tfl_tensor* p, const tfl_ten
                                 const tfl_tensor* div, const tfl_tensor* pPrev,
                                 const tfl_tensor* pDelta, const tfl_tensor* pDeltaNorm, int is3D,
                                 float pTol, int maxIter, int verbose, float* residual);
+
+/* ---- the pressure-projection ConvNet (lib/model.lua `default` model, forward only) ---------- */
+/* In the reference the projection is `model:forward({pDiv, UDiv, flags})` on an nngraph of cudnn
+ * convolutions and tfluids nn.Modules (lib/simulate.lua:262-272, lib/model.lua:27-401), not a
+ * tfluids op, so the boundary here is one "model" object + one forward call. */
+typedef struct tfl_model tfl_model;
+
+/* Builds the `default` topology: nlayers convolutions (stride 1, zero pad (k-1)/2, cross-correlation,
+ * lib/model_utils.lua:80-116), ReLU after all but the last; input channels {pDiv/scale, div/scale,
+ * occupancy} (cin[0] must be 3), cout[nlayers-1] must be 1. weights[l] is HOST memory laid out like
+ * cudnn.{Spatial,Volumetric}Convolution.weight: [cout][cin][k(z)][k(y)][k(x)] (no z for 2-D);
+ * biases[l] is [cout]. The model copies and re-lays-out the weights; the caller keeps ownership.
+ * Returns NULL on error (see tfl_last_error). */
+tfl_model* tfl_model_create(tfl_ctx* ctx, int is3D, int nlayers, const int32_t* cin, const int32_t* cout,
+                            const int32_t* ksize, const float* const* weights,
+                            const float* const* biases);
+void tfl_model_destroy(tfl_ctx* ctx, tfl_model* model);
+/* Scratch floats tfl_model_forward needs for a [B][.][Z][Y][X] grid. */
+int64_t tfl_model_workspace_floats(const tfl_model* model, int B, int Z, int Y, int X);
+/* {pOut, UOut} = model:forward({pDiv, UDiv, flags}) (lib/model.lua:398, 421-450). Inputs are not
+ * modified; pOut may alias pDiv and UOut may alias UDiv (simulate.lua:270-272 copies the prediction
+ * back into the state, which this makes free). When UBC/UBCInvMask are non-NULL the tail of
+ * simulate() -- U = U*UBCInvMask + UBC and, if doClamp, clamp(U, lo, hi) (simulate.lua:321-326) -- is
+ * fused into the last kernel. */
+int tfl_model_forward(tfl_ctx* ctx, tfl_model* model, const tfl_tensor* pDiv, const tfl_tensor* UDiv,
+                      const tfl_tensor* flags, const tfl_tensor* pOut, const tfl_tensor* UOut,
+                      float* workspace, int64_t workspace_floats, const tfl_tensor* UBC,
+                      const tfl_tensor* UBCInvMask, int doClamp, float lo, float hi);
+
+/* x = x*invMask + bc (both NULL: skip), then clamp to [lo, hi] if doClamp: one fused launch for
+ * setConstVals' cmul+add pairs and the final U:clamp (lib/simulate.lua:130-160, 326), which the
+ * reference issues as separate THC elementwise kernels. */
+int tfl_applyBCs(tfl_ctx* ctx, const tfl_tensor* x, const tfl_tensor* bc, const tfl_tensor* invMask,
+                 int doClamp, float lo, float hi);
 
 #ifdef __cplusplus
 }

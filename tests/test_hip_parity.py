@@ -18,7 +18,7 @@ from golden.make_golden import run_ops
 pytestmark = pytest.mark.gpu
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-GOLDEN = sorted(glob.glob(os.path.join(HERE, "golden", "*.npz")))
+GOLDEN = sorted(glob.glob(os.path.join(HERE, "golden", "g[23]d_*.npz")))
 REL_L2_TOL = 1e-5  # BASELINE.json north_star: "velocity rel-L2 <= 1e-5 vs reference"
 
 

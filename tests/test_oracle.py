@@ -15,7 +15,7 @@ import scenes
 from golden.make_golden import METHODS, run_ops
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-GOLDEN = sorted(glob.glob(os.path.join(HERE, "golden", "*.npz")))
+GOLDEN = sorted(glob.glob(os.path.join(HERE, "golden", "g[23]d_*.npz")))
 
 
 def _load(path):

@@ -1,0 +1,89 @@
+"""CPU checks of the host logic around the path and of the oracle-side restatement of the Lua
+(oracle/simulate_np.py): plume BCs, setConstVals ordering, the std normaliser, and that the shipped
+2-D model's weights -- fed the way SURVEY.md section 5 describes -- actually project (divergence
+drops), which pins channel order / sign conventions of the restatement."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import scenes
+from oracle import simulate_np as S
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _layers2d():
+    z = np.load(os.path.join(HERE, "golden", "myModel2D_weights.npz"))
+    return [(z["w%d" % i], z["b%d" % i]) for i in range(5)]
+
+
+@pytest.mark.parametrize("dims,rad", [((1, 64, 64), 0.05), ((1, 128, 128), 0.05), ((16, 16, 16), 0.15),
+                                       ((20, 24, 32), 0.15)])
+def test_plume_bcs_host_mirror_matches_restatement(dims, rad):
+    """fluidnet_amd.simulate.createPlumeBCs (vectorised torch) == the literal 1-based loops of
+    lib/simulate.lua:47-123 restated in oracle/simulate_np.py."""
+    from fluidnet_amd.simulate import createPlumeBCs
+    Z, Y, X = dims
+    C = 3 if Z > 1 else 2
+    nb = dict(UDiv=np.zeros((1, C, Z, Y, X), np.float32), density=np.zeros((1, 1, Z, Y, X), np.float32))
+    S.create_plume_bcs(nb, [0.7], 1.5, rad)
+    tb = dict(UDiv=torch.zeros(1, C, Z, Y, X), density=torch.zeros(1, 1, Z, Y, X))
+    createPlumeBCs(tb, [0.7], 1.5, rad)
+    for k in ("UBC", "UBCInvMask", "densityBC", "densityBCInvMask"):
+        assert np.array_equal(nb[k], tb[k].numpy()), k
+    assert nb["UBC"].sum() > 0 and tb["pBC"] is None
+
+
+def test_plume_bcs_multichannel_density():
+    from fluidnet_amd.simulate import createPlumeBCs
+    nb = dict(UDiv=np.zeros((1, 2, 1, 32, 32), np.float32),
+              density=[np.zeros((1, 1, 1, 32, 32), np.float32) for _ in range(3)])
+    S.create_plume_bcs(nb, [1.0, 0.5, 0.25], 10, 0.05)
+    tb = dict(UDiv=torch.zeros(1, 2, 1, 32, 32), density=[torch.zeros(1, 1, 1, 32, 32) for _ in range(3)])
+    createPlumeBCs(tb, [1.0, 0.5, 0.25], 10, 0.05)
+    for i in range(3):
+        assert np.array_equal(nb["densityBC"][i], tb["densityBC"][i].numpy())
+        assert np.array_equal(nb["densityBCInvMask"][i], tb["densityBCInvMask"][i].numpy())
+
+
+def test_input_scale_is_sample_std():
+    rng = np.random.RandomState(0)
+    U = rng.randn(2, 3, 5, 6, 7).astype(np.float32)
+    s = S.input_scale(U)
+    assert np.allclose(s, U.reshape(2, -1).astype(np.float64).std(axis=1, ddof=1), rtol=1e-6)
+
+
+def test_shipped_2d_model_projects(oracle):
+    """One FPROP of data/models/myModel2D's weights through the restated graph must cut ||div||
+    (SURVEY.md 8c-2 probe: 24.2 -> 12.4 on a comparable scene); a wrong channel order does not."""
+    sc = scenes.make_scene((1, 128, 128), seed=31, vel_cells=0.3, dt=0.1)
+    f = sc["flags"]
+    U = sc["U"].copy()
+    oracle.setWallBcsForward(U, f)
+    div0 = np.zeros_like(sc["p"])
+    oracle.velocityDivergenceForward(U, f, div0)
+    p0 = np.zeros_like(sc["p"])
+    p, U1 = S.model_forward(oracle, _layers2d(), p0, U, f)
+    div1 = np.zeros_like(div0)
+    oracle.velocityDivergenceForward(U1, f, div1)
+    assert np.linalg.norm(div1) < 0.7 * np.linalg.norm(div0)
+    for _ in range(5):
+        p, U1 = S.model_forward(oracle, _layers2d(), p, U1, f)
+    oracle.velocityDivergenceForward(U1, f, div1)
+    assert np.linalg.norm(div1) < 0.3 * np.linalg.norm(div0)
+
+
+def test_simulate_restatement_runs_jacobi_2d(oracle):
+    """BASELINE config 1 (2-D 64x64 plume, Jacobi 20 iters) on the CPU oracle: finite, plume rises."""
+    X = 64
+    batch = dict(pDiv=np.zeros((1, 1, 1, X, X), np.float32), UDiv=np.zeros((1, 2, 1, X, X), np.float32),
+                 flags=scenes.empty_domain(1, 1, X, X, False), density=np.zeros((1, 1, 1, X, X), np.float32))
+    S.create_plume_bcs(batch, [1.0], 10.0, 0.05)
+    mconf = dict(dt=4 / 60, advectionMethod="maccormackOurs", maccormackStrength=0.75, buoyancyScale=1.0,
+                 gravityScale=0, vorticityConfinementAmp=0, simMethod="jacobi", maxIter=20)
+    for _ in range(8):
+        S.simulate(oracle, mconf, batch)
+    assert np.isfinite(batch["UDiv"]).all() and np.isfinite(batch["density"]).all()
+    assert batch["density"][0, 0, 0, 4:, :].sum() > 0   # smoke left the inflow rows
