@@ -130,7 +130,8 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
 
-    from fluidnet_amd import FluidNetModel, simulate, tfluids
+    from fluidnet_amd import FluidNetModel, tfluids
+    from fluidnet_amd.simulate import simulate
     model = FluidNetModel.default_3d(seed=1)
     res = args.res
     batch, mconf = build_scene(res, res, rank * res, res * world, dev)

@@ -6,7 +6,6 @@
   fluidnet_amd.csrc/      hand-written HIP kernels for gfx950 + the C ABI (include/tfluids_hip.h)
 """
 from . import tfluids  # noqa: F401
-from . import simulate as _simulate  # noqa: F401
+from . import simulate  # noqa: F401  (module: simulate.simulate, .createPlumeBCs, .setConstVals)
 from .model import FluidNetModel  # noqa: F401
-from .simulate import createPlumeBCs, setConstVals, simulate  # noqa: F401
 from ._lib import TfluidsError  # noqa: F401

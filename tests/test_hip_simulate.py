@@ -45,7 +45,7 @@ def test_model_forward_matches_restatement(oracle, dims, seed, which):
     from fluidnet_amd import FluidNetModel
     layers = _layers2d() if which == "2d" else S.default_3d_layers(seed=3)
     model = FluidNetModel(layers, is3D=which == "3d")
-    sc = scenes.make_scene(dims, seed=seed, vel_cells=0.4, stick=True)
+    sc = scenes.make_scene(dims, seed=seed, vel_cells=0.4)
     p_ref, U_ref = S.model_forward(oracle, layers, sc["p"], sc["U"], sc["flags"])
     p64, U64 = S.model_forward(oracle, layers, sc["p"], sc["U"], sc["flags"], conv_dtype="float64")
     dev = torch.device("cuda:0")
@@ -63,7 +63,7 @@ def test_model_forward_matches_restatement(oracle, dims, seed, which):
 
 def _run_both(oracle, batch_np, mconf, layers, steps, model=None):
     import torch
-    from fluidnet_amd import simulate
+    from fluidnet_amd.simulate import simulate
     dev = torch.device("cuda:0")
     tb = _to_dev(batch_np, dev)
     for _ in range(steps):
