@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 
@@ -25,6 +26,11 @@ struct tfl_model {
   bool is3d = false;
   int max_c = 0;
   std::vector<tfl_layer> layers;
+  // 3-D `default` topology (3->8 k3, 8->8 k3, 8->8 k3, 8->8 k1, 8->1 k1): MFMA path (conv_mfma.hip)
+  bool mfma3d = false;
+  float* bfrag[3] = {nullptr, nullptr, nullptr};  // per-lane B fragments of the three k=3 layers
+  float* tail_w4 = nullptr;                       // [8][8] (out, in) of the 8->8 k1 layer
+  float* tail_w5 = nullptr;                       // [8] of the 8->1 k1 layer
   double* d_stats = nullptr;  // [2 * kMaxBatch]: sum(u), sum(u^2) per sample
 };
 
@@ -436,6 +442,36 @@ tfl_model* tfl_model_create(tfl_ctx* c, int is3D, int nlayers, const int32_t* ci
     if (L.cout > m->max_c && l + 1 < nlayers) m->max_c = L.cout;
   }
   if (m->max_c < 1) m->max_c = 1;
+  // ---- MFMA path for the 3-D default topology (TFL_CONV_PATH=direct forces the generic kernels) ----
+  const char* force = getenv("TFL_CONV_PATH");
+  const bool want_mfma = !(force && strcmp(force, "direct") == 0);
+  const int dflt[5][3] = {{3, 8, 3}, {8, 8, 3}, {8, 8, 3}, {8, 8, 1}, {8, 1, 1}};
+  bool match = m->is3d && nlayers == 5;
+  for (int l = 0; match && l < 5; l++) match = cin[l] == dflt[l][0] && cout[l] == dflt[l][1] && ksize[l] == dflt[l][2];
+  if (match && want_mfma) {
+    for (int l = 0; l < 3; l++) {
+      const int ci_n = cin[l];
+      std::vector<float> frag((size_t)ci_n * 9 * 64);
+      for (int c = 0; c < ci_n; c++)
+        for (int kz = 0; kz < 3; kz++)
+          for (int ky = 0; ky < 3; ky++)
+            for (int lane = 0; lane < 64; lane++) {
+              const int k = lane >> 4, n = lane & 15, ph = n >> 3, co = n & 7, kx = k - ph;
+              float v = 0.0f;
+              if (kx >= 0 && kx <= 2) v = weights[l][((((size_t)co * ci_n + c) * 3 + kz) * 3 + ky) * 3 + kx];
+              frag[(((size_t)c * 3 + kz) * 3 + ky) * 64 + lane] = v;
+            }
+      if (hipMalloc((void**)&m->bfrag[l], frag.size() * sizeof(float)) != hipSuccess ||
+          hipMemcpy(m->bfrag[l], frag.data(), frag.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
+        return cleanup("uploading MFMA weight fragments failed");
+    }
+    if (hipMalloc((void**)&m->tail_w4, 64 * sizeof(float)) != hipSuccess ||
+        hipMalloc((void**)&m->tail_w5, 8 * sizeof(float)) != hipSuccess ||
+        hipMemcpy(m->tail_w4, weights[3], 64 * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(m->tail_w5, weights[4], 8 * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
+      return cleanup("uploading tail weights failed");
+    m->mfma3d = true;
+  }
   return m;
 }
 
@@ -443,6 +479,9 @@ void tfl_model_destroy(tfl_ctx* c, tfl_model* m) {
   (void)c;
   if (!m) return;
   for (auto& L : m->layers) { if (L.w) (void)hipFree(L.w); if (L.b) (void)hipFree(L.b); }
+  for (int l = 0; l < 3; l++) if (m->bfrag[l]) (void)hipFree(m->bfrag[l]);
+  if (m->tail_w4) (void)hipFree(m->tail_w4);
+  if (m->tail_w5) (void)hipFree(m->tail_w5);
   if (m->d_stats) (void)hipFree(m->d_stats);
   delete m;
 }
@@ -450,8 +489,9 @@ void tfl_model_destroy(tfl_ctx* c, tfl_model* m) {
 int64_t tfl_model_workspace_floats(const tfl_model* m, int B, int Z, int Y, int X) {
   if (!m) return -1;
   const int64_t n = (int64_t)B * Z * Y * X;
-  // div[1] + net input[3] + two ping-pong activation buffers[max_c] + pPred[1]
-  return n * (1 + 3 + 2 * (int64_t)m->max_c + 1);
+  // per-block fp64 stat partials (2 doubles = 4 floats per block, kept first for 8-byte alignment)
+  // + div[1] + net input[3] + two ping-pong activation buffers[max_c] + pPred[1]
+  return 4 * tfl::model_stat_blocks(B, Z, Y, X) + n * (1 + 3 + 2 * (int64_t)m->max_c + 1);
 }
 
 int tfl_model_forward(tfl_ctx* c, tfl_model* m, const tfl_tensor* pDiv, const tfl_tensor* UDiv,
@@ -476,7 +516,9 @@ int tfl_model_forward(tfl_ctx* c, tfl_model* m, const tfl_tensor* pDiv, const tf
   if (!workspace || workspace_floats < tfl_model_workspace_floats(m, B, Z, Y, X))
     return fail(c, TFL_EINVAL, "model_forward: workspace too small (%lld floats needed)",
                 (long long)tfl_model_workspace_floats(m, B, Z, Y, X));
-  float* div = workspace;
+  if (((uintptr_t)workspace & 7) != 0) return fail(c, TFL_EINVAL, "model_forward: workspace must be 8-byte aligned");
+  double* partials = (double*)workspace;
+  float* div = workspace + 4 * tfl::model_stat_blocks(B, Z, Y, X);
   float* x3 = div + n;
   float* act[2] = {x3 + 3 * n, x3 + 3 * n + (int64_t)m->max_c * n};
   float* pPred = act[1] + (int64_t)m->max_c * n;
@@ -485,10 +527,16 @@ int tfl_model_forward(tfl_ctx* c, tfl_model* m, const tfl_tensor* pDiv, const tf
   // neighbours are re-derived from the INPUT through the flags, so in-place is race-free only when
   // UOut != UDiv; with aliasing the neighbour value read may already be the BC-applied one, which
   // is idempotent -- identical either way).
-  tfl::model_pre(st, m->is3d, B, Z, Y, X, UDiv->data, flags->data, UOut->data, div, m->d_stats);
+  tfl::model_pre(st, m->is3d, B, Z, Y, X, UDiv->data, flags->data, UOut->data, div, partials, m->d_stats);
   tfl::model_net_input(st, m->is3d, B, Z, Y, X, pDiv->data, div, flags->data, m->d_stats, x3);
+  if (m->mfma3d) {
+    tfl::conv3_mfma_first(st, B, Z, Y, X, x3, m->bfrag[0], m->layers[0].b, act[0]);
+    tfl::conv3_mfma_mid(st, B, Z, Y, X, act[0], m->bfrag[1], m->layers[1].b, act[1]);
+    tfl::conv3_mfma_tail(st, B, Z, Y, X, act[1], m->bfrag[2], m->layers[2].b, m->tail_w4, m->layers[3].b,
+                         m->tail_w5, m->layers[4].b, pPred);
+  }
   const float* in = x3;
-  for (size_t l = 0; l < m->layers.size(); l++) {
+  for (size_t l = 0; !m->mfma3d && l < m->layers.size(); l++) {
     const tfl_layer& L = m->layers[l];
     const bool last = l + 1 == m->layers.size();
     float* out = last ? pPred : act[l & 1];

@@ -1,0 +1,200 @@
+// conv_mfma.hip -- 3x3x3, 8-output-channel convolution layers of the 3-D `default` projection net
+// as an fp32 MFMA implicit GEMM (gfx950: v_mfma_f32_16x16x4_f32, exact fp32, 157 TFLOP/s peak).
+//
+// Replaces cudnn.VolumetricConvolution forward (torch/lib/model_utils.lua:104-116) for the layers
+// 3->8, 8->8, 8->8 (k=3) of lib/model.lua:219-226, with the ReLU fused, and -- in the last of them --
+// the two trailing 1x1x1 layers (8->8 + ReLU, 8->1) fused into the epilogue.
+//
+// GEMM shape problem: N = 8 output channels, but the narrowest MFMA tile is 16 wide. Instead of
+// wasting half of it, one 16x16 tile covers 32 consecutive x-voxels x 8 channels ("x-phase packing"):
+//   D[m][n]   m = 0..15, n = ph*8 + co : output channel co of voxel x0 + 2m + ph
+//   A[m][k] = in[c][z+dz][y+dy][x0 + 2m + k - 1], k = 0..3   (a 4-wide x window per row)
+//   B[k][n] = w[co][c][dz][dy][k - ph] if 0 <= k - ph <= 2 else 0
+// so one MFMA (K = 4) consumes one (c, dz, dy) of the stencil for both phases: C_in*9 MFMAs per tile,
+// 75% of the issued MACs useful (vs 50% with N padded to 16).
+//
+// Data layout: the block stages a channel-planar halo tile [C_in][TZ+2][TY+2][34(+2)] in LDS (zero
+// padded at the domain boundary = the convolution's zero padding); an A operand is one ds_read_b32 at
+// lane offset 2m + k, bank-conflict-free by construction (each 32-lane half touches 32 consecutive
+// dwords). Inter-layer activations live in HBM channel-LAST ([Z][Y][X][8], 32 B per voxel) so staging
+// loads and epilogue stores are 16/64-byte contiguous. B fragments (the weights, pre-arranged per lane
+// on the host) sit in registers for the whole kernel: 9*C_in VGPRs.
+//
+// Block = 256 threads = 4 waves; block tile = 32(x) x 8(y) x 4(z); wave w owns z-plane w, 8 rows ->
+// 8 independent accumulators (covers the 40-cycle dependent-MFMA latency at the 32-cycle issue rate).
+// LDS: 8*6*10*36*4 = 69 KB -> 2 blocks per CU, one staging while the other multiplies.
+#include "tfl_device.hpp"
+#include "tfl_host.hpp"
+
+namespace tfl {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kTX = 32, kTY = 8, kTZ = 4, kLX = 36;  // LDS row pitch (34 used)
+
+struct ConvTail {       // fused 1x1x1 layers (device pointers): h4 = relu(W4 h + b4); p = w5 . h4 + b5
+  const float* w4;      // [8][8]  (out, in)
+  const float* b4;      // [8]
+  const float* w5;      // [8]
+  const float* b5;      // [1]
+};
+
+// CIN: input channels. IN_PLANAR: input is [CIN][Z][Y][X] (first layer) else channel-last [Z][Y][X][CIN].
+// TAIL: fuse the two 1x1x1 layers and write planar pressure instead of channel-last activations.
+template <int CIN, bool IN_PLANAR, bool TAIL>
+__global__ __launch_bounds__(256, 2) void k_conv3_mfma(Dom d, int tiles_x, int tiles_y, int tiles_z, int n_tiles,
+                                                       const float* __restrict__ in, const float* __restrict__ bfrag,
+                                                       const float* __restrict__ bias, float* __restrict__ out,
+                                                       ConvTail tail) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  // XCD-aware tile order: the dispatcher deals consecutive block ids round-robin over the 8 XCDs, so
+  // give each XCD a contiguous run of tiles (neighbouring tiles share halo planes through its L2).
+  const int per_xcd = (n_tiles + 7) / 8;
+  const int tile = (int)(blockIdx.x % 8) * per_xcd + (int)(blockIdx.x / 8);
+  if (tile >= n_tiles) return;
+  int t = tile;
+  const int tx = t % tiles_x; t /= tiles_x;
+  const int ty = t % tiles_y; t /= tiles_y;
+  const int tz = t % tiles_z;
+  const int b = t / tiles_z;
+  const int x0 = tx * kTX, y0 = ty * kTY, z0 = tz * kTZ;
+  const long long cells = d.sc;
+  in += (long long)b * cells * CIN;
+
+  const int tid = threadIdx.x;
+  constexpr int kRows = (kTZ + 2) * (kTY + 2);      // 60 halo rows per channel
+  constexpr int kPlane = kRows * kLX;               // floats per channel plane in LDS
+  // ---- stage the halo tile ---------------------------------------------------------------------
+  for (int idx = tid; idx < kRows * 34; idx += 256) {
+    const int xx = idx % 34, row = idx / 34;
+    const int yy = row % (kTY + 2), zz = row / (kTY + 2);
+    const int gx = x0 - 1 + xx, gy = y0 - 1 + yy, gz = z0 - 1 + zz;
+    const bool ok = gx >= 0 && gx < d.X && gy >= 0 && gy < d.Y && gz >= 0 && gz < d.Z;
+    float v[CIN];
+#pragma unroll
+    for (int c = 0; c < CIN; c++) v[c] = 0.0f;
+    if (ok) {
+      const long long o = TFL_AT(d, gx, gy, gz);
+      if (IN_PLANAR) {
+#pragma unroll
+        for (int c = 0; c < CIN; c++) v[c] = in[o + c * cells];
+      } else {
+        const float4* p4 = reinterpret_cast<const float4*>(in + o * CIN);
+#pragma unroll
+        for (int q = 0; q < CIN / 4; q++) {
+          const float4 f = p4[q];
+          v[q * 4] = f.x; v[q * 4 + 1] = f.y; v[q * 4 + 2] = f.z; v[q * 4 + 3] = f.w;
+        }
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < CIN; c++) lds[c * kPlane + row * kLX + xx] = v[c];
+  }
+  // ---- B fragments + bias into registers ----------------------------------------------------------
+  const int lane = tid & 63, wave = tid >> 6;
+  float bf[CIN * 9];
+#pragma unroll
+  for (int q = 0; q < CIN * 9; q++) bf[q] = bfrag[q * 64 + lane];
+  const int co = lane & 7;
+  const float bv = bias[co];
+  f32x4 acc[kTY];
+#pragma unroll
+  for (int r = 0; r < kTY; r++) acc[r] = (f32x4){bv, bv, bv, bv};
+  __syncthreads();
+  // ---- implicit GEMM -----------------------------------------------------------------------------
+  const int lane_off = 2 * (lane & 15) + (lane >> 4);
+#pragma unroll
+  for (int c = 0; c < CIN; c++) {
+#pragma unroll
+    for (int dz = 0; dz < 3; dz++) {
+#pragma unroll
+      for (int dy = 0; dy < 3; dy++) {
+        const float bval = bf[(c * 3 + dz) * 3 + dy];
+        const float* base = lds + c * kPlane + ((wave + dz) * (kTY + 2) + dy) * kLX + lane_off;
+#pragma unroll
+        for (int r = 0; r < kTY; r++) {
+          const float a = base[r * kLX];
+          acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bval, acc[r], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // ---- epilogue ----------------------------------------------------------------------------------
+  // D layout: lane holds rows m = (lane>>4)*4 + i (i = 0..3) of column n = lane&15 = ph*8 + co.
+  const int g = lane >> 4, ph = (lane >> 3) & 1;
+  const int z = z0 + wave;
+  if (!TAIL) {
+    out += (long long)b * cells * 8;
+#pragma unroll
+    for (int r = 0; r < kTY; r++) {
+      const int y = y0 + r;
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const int x = x0 + 8 * g + 2 * i + ph;
+        if (x < d.X && y < d.Y && z < d.Z) out[(long long)TFL_AT(d, x, y, z) * 8 + co] = fmaxf(acc[r][i], 0.0f);
+      }
+    }
+  } else {
+    float w4r[8];
+#pragma unroll
+    for (int c = 0; c < 8; c++) w4r[c] = tail.w4[co * 8 + c];
+    const float b4 = tail.b4[co], w5 = tail.w5[co], b5 = tail.b5[0];
+    const int grp = lane & ~7;
+    out += (long long)b * cells;
+#pragma unroll
+    for (int r = 0; r < kTY; r++) {
+      const int y = y0 + r;
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const float h = fmaxf(acc[r][i], 0.0f);
+        float h4 = b4;
+#pragma unroll
+        for (int c = 0; c < 8; c++) h4 = fmaf(w4r[c], __shfl(h, grp + c, 64), h4);
+        float v = w5 * fmaxf(h4, 0.0f);
+        v += __shfl_xor(v, 1, 64);
+        v += __shfl_xor(v, 2, 64);
+        v += __shfl_xor(v, 4, 64);
+        const int x = x0 + 8 * g + 2 * i + ph;
+        if (co == 0 && x < d.X && y < d.Y && z < d.Z) out[TFL_AT(d, x, y, z)] = v + b5;
+      }
+    }
+  }
+}
+
+template <int CIN, bool IN_PLANAR, bool TAIL>
+static void launch_mfma(hipStream_t st, const Dom& d, int B, const float* in, const float* bfrag, const float* bias,
+                        float* out, ConvTail tail) {
+  const int tx = (d.X + kTX - 1) / kTX, ty = (d.Y + kTY - 1) / kTY, tz = (d.Z + kTZ - 1) / kTZ;
+  const int n_tiles = tx * ty * tz * B;
+  const int grid = ((n_tiles + 7) / 8) * 8;
+  const size_t lds_bytes = sizeof(float) * CIN * (kTZ + 2) * (kTY + 2) * kLX;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)k_conv3_mfma<CIN, IN_PLANAR, TAIL>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    attr_set = true;
+  }
+  TFL_TIMED(TAIL ? "k_conv3_mfma_tail" : (IN_PLANAR ? "k_conv3_mfma_in" : "k_conv3_mfma"), st);
+  k_conv3_mfma<CIN, IN_PLANAR, TAIL><<<grid, 256, lds_bytes, st>>>(d, tx, ty, tz, n_tiles, in, bfrag, bias, out, tail);
+}
+
+// 3 -> 8 (planar in) / 8 -> 8 (channel-last in), k = 3, ReLU; channel-last [Z][Y][X][8] out.
+void conv3_mfma_first(hipStream_t st, int B, int Z, int Y, int X, const float* in_planar3, const float* bfrag,
+                      const float* bias, float* out_cl8) {
+  ConvTail none = {nullptr, nullptr, nullptr, nullptr};
+  launch_mfma<3, true, false>(st, make_dom(Z, Y, X), B, in_planar3, bfrag, bias, out_cl8, none);
+}
+void conv3_mfma_mid(hipStream_t st, int B, int Z, int Y, int X, const float* in_cl8, const float* bfrag,
+                    const float* bias, float* out_cl8) {
+  ConvTail none = {nullptr, nullptr, nullptr, nullptr};
+  launch_mfma<8, false, false>(st, make_dom(Z, Y, X), B, in_cl8, bfrag, bias, out_cl8, none);
+}
+// 8 -> 8 k3 + ReLU, then 8 -> 8 k1 + ReLU, then 8 -> 1 k1; planar pressure out.
+void conv3_mfma_tail(hipStream_t st, int B, int Z, int Y, int X, const float* in_cl8, const float* bfrag,
+                     const float* bias, const float* w4, const float* b4, const float* w5, const float* b5,
+                     float* p_out) {
+  ConvTail tail = {w4, b4, w5, b5};
+  launch_mfma<8, false, true>(st, make_dom(Z, Y, X), B, in_cl8, bfrag, bias, p_out, tail);
+}
+
+}  // namespace tfl

@@ -52,11 +52,14 @@ __device__ __forceinline__ float u_bc_at(const Dom& d, const float* __restrict__
   return z ? 0.0f : U[o + AXIS * d.sc];
 }
 
-// stats[b*2 + 0] = sum u, stats[b*2 + 1] = sum u^2 over all C*Z*Y*X values of U_bc[b]
+// partials[block*2 + {0,1}] = this block's sum u, sum u^2 of U_bc (fp64). A second tiny kernel
+// (k_reduce_stats) adds the partials of each sample in a fixed order, so the scale is bit-reproducible
+// run to run and independent of how the grid is sharded -- no atomics (8192 same-address fp64 atomics
+// cost 0.2 ms at 128^3, 10x the kernel itself).
 template <bool IS3D>
 __global__ __launch_bounds__(256) void k_bcs_div_stats(Dom d, const float* __restrict__ U, const float* __restrict__ flags,
                                                        float* __restrict__ Ubc, float* __restrict__ div,
-                                                       double* __restrict__ stats) {
+                                                       double* __restrict__ partials) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int j = blockIdx.y * blockDim.y + threadIdx.y;
   const int b = blockIdx.z / d.Z, k = blockIdx.z - b * d.Z;
@@ -88,9 +91,28 @@ __global__ __launch_bounds__(256) void k_bcs_div_stats(Dom d, const float* __res
   if ((tid & 63) == 0) { part[(tid >> 6) * 2] = s1; part[(tid >> 6) * 2 + 1] = s2; }
   __syncthreads();
   if (tid == 0) {
-    atomicAdd(&stats[b * 2], part[0] + part[2] + part[4] + part[6]);
-    atomicAdd(&stats[b * 2 + 1], part[1] + part[3] + part[5] + part[7]);
+    const long long blk = blockIdx.x + (long long)gridDim.x * (blockIdx.y + (long long)gridDim.y * blockIdx.z);
+    partials[blk * 2] = (part[0] + part[2]) + (part[4] + part[6]);
+    partials[blk * 2 + 1] = (part[1] + part[3]) + (part[5] + part[7]);
   }
+}
+
+// stats[b*2 + 0] = sum u, stats[b*2 + 1] = sum u^2 over all C*Z*Y*X values of U_bc[b]; one block per
+// sample, fixed summation order (strided accumulate, then a shared-memory tree).
+__global__ __launch_bounds__(256) void k_reduce_stats(const double* __restrict__ partials, long long per_sample,
+                                                      double* __restrict__ stats) {
+  const int b = blockIdx.x;
+  const double* p = partials + (long long)b * per_sample * 2;
+  double s1 = 0.0, s2 = 0.0;
+  for (long long t = threadIdx.x; t < per_sample; t += 256) { s1 += p[t * 2]; s2 += p[t * 2 + 1]; }
+  __shared__ double sh1[256], sh2[256];
+  sh1[threadIdx.x] = s1; sh2[threadIdx.x] = s2;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) { sh1[threadIdx.x] += sh1[threadIdx.x + w]; sh2[threadIdx.x] += sh2[threadIdx.x + w]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { stats[b * 2] = sh1[0]; stats[b * 2 + 1] = sh2[0]; }
 }
 
 // lib/modules/variance.lua:44-76 (n-1) + Sqrt; the Clamp after it is a no-op (model.lua:106 typo)
@@ -182,13 +204,17 @@ __global__ __launch_bounds__(256) void k_apply_bcs(long long n, float* __restric
 
 #define TFL_GRID3(d, B) dim3(((d).X + 63) / 64, ((d).Y + 3) / 4, (unsigned)((d).Z * (B)))
 
+long long model_stat_blocks(int B, int Z, int Y, int X) {
+  return (long long)((X + 63) / 64) * ((Y + 3) / 4) * Z * B;
+}
+
 void model_pre(hipStream_t st, bool is3d, int B, int Z, int Y, int X, const float* U, const float* flags, float* Ubc,
-               float* div, double* stats) {
+               float* div, double* partials, double* stats) {
   const Dom d = make_dom(Z, Y, X);
   const dim3 blk(64, 4, 1), grd = TFL_GRID3(d, B);
-  (void)hipMemsetAsync(stats, 0, sizeof(double) * 2 * B, st);
-  if (is3d) { TFL_TIMED("k_bcs_div_stats", st); k_bcs_div_stats<true><<<grd, blk, 0, st>>>(d, U, flags, Ubc, div, stats); }
-  else { TFL_TIMED("k_bcs_div_stats", st); k_bcs_div_stats<false><<<grd, blk, 0, st>>>(d, U, flags, Ubc, div, stats); }
+  if (is3d) { TFL_TIMED("k_bcs_div_stats", st); k_bcs_div_stats<true><<<grd, blk, 0, st>>>(d, U, flags, Ubc, div, partials); }
+  else { TFL_TIMED("k_bcs_div_stats", st); k_bcs_div_stats<false><<<grd, blk, 0, st>>>(d, U, flags, Ubc, div, partials); }
+  { TFL_TIMED("k_reduce_stats", st); k_reduce_stats<<<B, 256, 0, st>>>(partials, model_stat_blocks(1, Z, Y, X), stats); }
 }
 
 void model_net_input(hipStream_t st, bool is3d, int B, int Z, int Y, int X, const float* pDiv, const float* div,

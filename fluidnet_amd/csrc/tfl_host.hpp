@@ -44,8 +44,9 @@ void jacobi_iteration(hipStream_t st, bool is3d, int B, int Z, int Y, int X, con
                       const float* div, float* p, double* resid_sq /* [B] or nullptr */);
 
 // model.hip
+long long model_stat_blocks(int B, int Z, int Y, int X);
 void model_pre(hipStream_t st, bool is3d, int B, int Z, int Y, int X, const float* U, const float* flags, float* Ubc,
-               float* div, double* stats);
+               float* div, double* partials, double* stats);
 void model_net_input(hipStream_t st, bool is3d, int B, int Z, int Y, int X, const float* pDiv, const float* div,
                      const float* flags, const double* stats, float* x3);
 void model_project(hipStream_t st, bool is3d, int B, int Z, int Y, int X, const float* pPred, const float* flags,
@@ -57,5 +58,14 @@ void apply_bcs(hipStream_t st, long long n, float* x, const float* bcv, const fl
 // conv.hip
 bool conv_direct(hipStream_t st, bool is3d, int B, int Z, int Y, int X, int cin, int cout, int ksz, bool relu,
                  const float* in, const float* w, const float* bias, float* out);
+
+// conv_mfma.hip (3-D default topology: k=3, 8 output channels; x-phase-packed fp32 MFMA)
+void conv3_mfma_first(hipStream_t st, int B, int Z, int Y, int X, const float* in_planar3, const float* bfrag,
+                      const float* bias, float* out_cl8);
+void conv3_mfma_mid(hipStream_t st, int B, int Z, int Y, int X, const float* in_cl8, const float* bfrag,
+                    const float* bias, float* out_cl8);
+void conv3_mfma_tail(hipStream_t st, int B, int Z, int Y, int X, const float* in_cl8, const float* bfrag,
+                     const float* bias, const float* w4, const float* b4, const float* w5, const float* b5,
+                     float* p_out);
 
 }  // namespace tfl

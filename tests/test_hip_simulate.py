@@ -137,3 +137,24 @@ def test_simulate_gravity_and_rgb_density(oracle):
     assert np.array_equal(tb["UDiv"].cpu().numpy(), nb["UDiv"])
     for i in range(3):
         assert np.array_equal(tb["density"][i].cpu().numpy(), nb["density"][i])
+
+
+def test_conv_paths_agree_3d(oracle, monkeypatch):
+    """The fp32-MFMA implicit GEMM (conv_mfma.hip) and the shape-generic direct kernels (conv.hip)
+    are two exact-fp32 evaluations of the same sums in different orders: they must agree to rounding,
+    including on grids that are ragged against the 32x8x4 MFMA tile."""
+    import torch
+    from fluidnet_amd import FluidNetModel
+    layers = S.default_3d_layers(seed=5)
+    dev = torch.device("cuda:0")
+    for dims, seed in [((32, 32, 32), 51), ((13, 21, 45), 52), ((5, 9, 33), 53)]:
+        sc = scenes.make_scene(dims, seed=seed, vel_cells=0.4, B=2)
+        tp, tU, tf = (torch.from_numpy(sc[k]).to(dev) for k in ("p", "U", "flags"))
+        monkeypatch.setenv("TFL_CONV_PATH", "direct")
+        pd, Ud = FluidNetModel(layers, True).forward([tp, tU, tf])
+        monkeypatch.setenv("TFL_CONV_PATH", "mfma")
+        pm, Um = FluidNetModel(layers, True).forward([tp, tU, tf])
+        rp, rU = scenes.rel_l2(pm.cpu().numpy(), pd.cpu().numpy()), scenes.rel_l2(Um.cpu().numpy(), Ud.cpu().numpy())
+        assert rp <= 2e-6 and rU <= 2e-6, (dims, rp, rU)
+        p_ref, U_ref = S.model_forward(oracle, layers, sc["p"], sc["U"], sc["flags"])
+        assert scenes.rel_l2(pm.cpu().numpy(), p_ref) <= TOL and scenes.rel_l2(Um.cpu().numpy(), U_ref) <= TOL
