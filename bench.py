@@ -47,30 +47,26 @@ ALG_BYTES_PER_CELL = {
 }
 
 
-def build_scene(res_xy, res_z, z_offset, z_total, device):
-    """Config-4 scene for the z-range [z_offset, z_offset + res_z) of a res_xy x res_xy x z_total grid.
-    Returns (batch, mconf). Obstacle = sphere + torus of ~res/2 extent (stand-in for the bunny)."""
+def build_scene(res_xy, z_total, layout, device):
+    """Config-4 scene on a res_xy x res_xy x z_total grid; returns (batch, mconf) holding the planes
+    [layout.lo, layout.hi) (the rank's z-slab plus halos; layout=None: the whole grid). Only the local
+    planes are ever materialised. Obstacle = sphere + torus of ~res/2 extent (stand-in for the bunny)."""
     from fluidnet_amd import simulate as sim
     X = Y = res_xy
-    flags = torch.full((1, 1, z_total, Y, X), 1.0)
-    flags[..., 0] = 2; flags[..., X - 1] = 2; flags[..., 0, :] = 2; flags[..., Y - 1, :] = 2
-    flags[:, :, 0] = 2; flags[:, :, z_total - 1] = 2
-    zz, yy, xx = torch.meshgrid(torch.arange(z_total), torch.arange(Y), torch.arange(X), indexing="ij")
+    lo, hi = (0, z_total) if layout is None else (layout.lo, layout.hi)
+    Zl = hi - lo
+    zz, yy, xx = torch.meshgrid(torch.arange(lo, hi), torch.arange(Y), torch.arange(X), indexing="ij")
+    border = (xx == 0) | (xx == X - 1) | (yy == 0) | (yy == Y - 1) | (zz == 0) | (zz == z_total - 1)
     cx, cz = X / 2.0, z_total / 2.0
     sphere = (xx - cx) ** 2 + (yy - 0.50 * Y) ** 2 + (zz - cz) ** 2 <= (0.11 * X) ** 2
     rho = torch.sqrt((xx - cx) ** 2 + (zz - cz) ** 2) - 0.22 * X
     torus = rho ** 2 + (yy - 0.72 * Y) ** 2 <= (0.045 * X) ** 2
-    interior = torch.zeros_like(sphere)
-    interior[1:-1, 1:-1, 1:-1] = True
-    flags[0, 0][(sphere | torus) & interior] = 2
-    full = dict(pDiv=torch.zeros(1, 1, z_total, Y, X), UDiv=torch.zeros(1, 3, z_total, Y, X), flags=flags,
-                density=torch.zeros(1, 1, z_total, Y, X))
+    flags = torch.where(border | sphere | torus, 2.0, 1.0).to(torch.float32).view(1, 1, Zl, Y, X).contiguous()
+    full = dict(pDiv=torch.zeros(1, 1, Zl, Y, X), UDiv=torch.zeros(1, 3, Zl, Y, X), flags=flags,
+                density=torch.zeros(1, 1, Zl, Y, X))
     scale = res_xy / 128.0
-    sim.createPlumeBCs(full, [1.0], 1.0 * scale, 0.15)
-    sl = slice(z_offset, z_offset + res_z)
-    batch = {}
-    for k, v in full.items():
-        batch[k] = None if v is None else v[:, :, sl].contiguous().to(device)
+    sim.createPlumeBCs(full, [1.0], 1.0 * scale, 0.15, zOffset=lo, zTotal=z_total)
+    batch = {k: (None if v is None else v.contiguous().to(device)) for k, v in full.items()}
     mconf = dict(dt=0.1, advectionMethod="maccormackOurs", maccormackStrength=0.6, buoyancyScale=2.0 * scale,
                  gravityScale=0, vorticityConfinementAmp=3.0, simMethod="convnet")
     return batch, mconf
@@ -134,12 +130,15 @@ def main():
     from fluidnet_amd.simulate import simulate
     model = FluidNetModel.default_3d(seed=1)
     res = args.res
-    batch, mconf = build_scene(res, res, rank * res, res * world, dev)
     if world > 1:
-        from fluidnet_amd.dist import SlabSimulation
-        stepper = SlabSimulation(batch, mconf, model, rank, world)
+        from fluidnet_amd.dist import DistComm, SlabLayout, SlabSimulation
+        layout = SlabLayout(res * world, world, rank)
+        batch, mconf = build_scene(res, res * world, layout, dev)
+        stepper = SlabSimulation(batch, mconf, model, layout, DistComm())
         step = stepper.step
     else:
+        batch, mconf = build_scene(res, res, None, dev)
+
         def step():
             simulate(None, mconf, batch, model)
 
@@ -164,6 +163,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     assert bool(torch.isfinite(batch["UDiv"]).all()), "simulation blew up"
+    halo_planes = 0 if world == 1 else (batch["flags"].size(2) - res)
 
     cells_per_gpu = res ** 3
     total_cells = cells_per_gpu * world
@@ -226,7 +226,7 @@ def main():
                                "(3-D default topology, seeded weights); per-GPU z-slab of %d^3 cells" % (res, res),
                    "grid_zyx": [res * world, res, res], "per_gpu_grid_zyx": [res, res, res],
                    "decomposition": "single GPU" if world == 1 else "z-slabs, %d ranks, RCCL halo exchange" % world,
-                   "preroll_steps": args.preroll},
+                   "preroll_steps": args.preroll, "halo_planes_recomputed_per_rank": halo_planes},
         "roofline": roofline, "advection_headline": headline, "kernels": kernels,
     }
     if rank == 0 and not args.no_cpu_baseline and world == 1:

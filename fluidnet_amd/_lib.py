@@ -59,6 +59,11 @@ SIGNATURES = {
     "tfl_model_workspace_floats": (_c.c_int64, [_c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.c_int]),
     "tfl_model_forward": (_c.c_int, [_c.c_void_p, _c.c_void_p, _T, _T, _T, _T, _T, _c.c_void_p,
                                      _c.c_int64, _T, _T, _c.c_int, _c.c_float, _c.c_float]),
+    "tfl_model_begin": (_c.c_int, [_c.c_void_p, _c.c_void_p, _T, _T, _T, _c.c_void_p, _c.c_int64, _c.c_int,
+                                   _c.c_int, _c.c_void_p]),
+    "tfl_model_finish": (_c.c_int, [_c.c_void_p, _c.c_void_p, _T, _T, _T, _T, _c.c_void_p, _c.c_int64,
+                                    _c.c_void_p, _c.c_double, _T, _T, _c.c_int, _c.c_float, _c.c_float]),
+    "tfl_set_dx_override": (_c.c_int, [_c.c_void_p, _c.c_float]),
     "tfl_applyBCs": (_c.c_int, [_c.c_void_p, _T, _T, _T, _c.c_int, _c.c_float, _c.c_float]),
 }
 

@@ -41,6 +41,7 @@ struct tfl_ctx {
   unsigned long long* d_trace_err = nullptr;  // device word: traces that hit an invariant path
   double* d_resid = nullptr;                  // Jacobi residual accumulators [kMaxBatch]
   double* h_resid = nullptr;                  // pinned mirror
+  float dx_override = 0.0f;                   // > 0: use instead of 1/max(X,Y,Z) (z-slab ranks: global dx)
 };
 static const int kMaxBatch = 1024;
 
@@ -129,7 +130,8 @@ int parse_method(const char* m) {
   return -1;
 }
 
-float get_dx(const tfl_tensor* f) {  // grid.cc:37-40
+float get_dx(const tfl_ctx* c, const tfl_tensor* f) {  // grid.cc:37-40
+  if (c && c->dx_override > 0.0f) return c->dx_override;
   int m = f->X > f->Y ? f->X : f->Y;
   if (f->Z > m) m = f->Z;
   return 1.0f / (float)m;
@@ -172,6 +174,12 @@ int tfl_set_stream(tfl_ctx* c, void* s) {
 }
 
 const char* tfl_last_error(const tfl_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+int tfl_set_dx_override(tfl_ctx* c, float dx) {
+  if (!c) return TFL_EINVAL;
+  c->dx_override = dx > 0.0f ? dx : 0.0f;
+  return TFL_OK;
+}
 
 int tfl_synchronize(tfl_ctx* c) {
   if (!c) return TFL_EINVAL;
@@ -326,7 +334,7 @@ int tfl_addBuoyancy(tfl_ctx* c, const tfl_tensor* U, const tfl_tensor* flags, co
   TRY(check_vel(c, "addBuoyancy", "U", U, flags, is3D));
   TRY(check_scalar(c, "addBuoyancy", "density", density, flags));
   if (!gravity) return fail(c, TFL_EINVAL, "addBuoyancy: gravity is null");
-  const float sc = dt / get_dx(flags);  // strength = -gravity * (dt / dx), tfluids.cc:1190-1192
+  const float sc = dt / get_dx(c, flags);  // strength = -gravity * (dt / dx), tfluids.cc:1190-1192
   tfl::add_buoyancy(c->stream, is3D != 0, flags->B, flags->Z, flags->Y, flags->X, U->data, flags->data,
                     density->data, -gravity[0] * sc, -gravity[1] * sc, -gravity[2] * sc);
   return check_launch(c, "addBuoyancy");
@@ -338,7 +346,7 @@ int tfl_addGravity(tfl_ctx* c, const tfl_tensor* U, const tfl_tensor* flags, con
   TRY(check_flags(c, "addGravity", flags));
   TRY(check_vel(c, "addGravity", "U", U, flags, is3D));
   if (!gravity) return fail(c, TFL_EINVAL, "addGravity: gravity is null");
-  const float sc = dt / get_dx(flags);  // force = gravity * (dt / dx), tfluids.cc:1265-1267
+  const float sc = dt / get_dx(c, flags);  // force = gravity * (dt / dx), tfluids.cc:1265-1267
   tfl::add_gravity(c->stream, is3D != 0, flags->B, flags->Z, flags->Y, flags->X, U->data, flags->data,
                    gravity[0] * sc, gravity[1] * sc, gravity[2] * sc);
   return check_launch(c, "addGravity");
@@ -494,59 +502,97 @@ int64_t tfl_model_workspace_floats(const tfl_model* m, int B, int Z, int Y, int 
   return 4 * tfl::model_stat_blocks(B, Z, Y, X) + n * (1 + 3 + 2 * (int64_t)m->max_c + 1);
 }
 
+namespace {
+struct ModelWs { double* partials; float* div; float* x3; float* act[2]; float* pPred; };
+int model_ws(tfl_ctx* c, const tfl_model* m, const tfl_tensor* flags, float* workspace, int64_t workspace_floats,
+             ModelWs* w) {
+  const int B = flags->B, Z = flags->Z, Y = flags->Y, X = flags->X;
+  if (B > kMaxBatch) return fail(c, TFL_EINVAL, "model: batch size above %d", kMaxBatch);
+  const int64_t n = (int64_t)B * Z * Y * X;
+  if (!workspace || workspace_floats < tfl_model_workspace_floats(m, B, Z, Y, X))
+    return fail(c, TFL_EINVAL, "model: workspace too small (%lld floats needed)",
+                (long long)tfl_model_workspace_floats(m, B, Z, Y, X));
+  if (((uintptr_t)workspace & 7) != 0) return fail(c, TFL_EINVAL, "model: workspace must be 8-byte aligned");
+  w->partials = (double*)workspace;
+  w->div = workspace + 4 * tfl::model_stat_blocks(B, Z, Y, X);
+  w->x3 = w->div + n;
+  w->act[0] = w->x3 + 3 * n;
+  w->act[1] = w->act[0] + (int64_t)m->max_c * n;
+  w->pPred = w->act[1] + (int64_t)m->max_c * n;
+  return TFL_OK;
+}
+}  // namespace
+
+int tfl_model_begin(tfl_ctx* c, tfl_model* m, const tfl_tensor* UDiv, const tfl_tensor* flags, const tfl_tensor* UOut,
+                    float* workspace, int64_t workspace_floats, int zlo, int zhi, double* stats) {
+  TRY(check_flags(c, "model_begin", flags));
+  if (!m) return fail(c, TFL_EINVAL, "model_begin: null model");
+  const int is3D = m->is3d ? 1 : 0;
+  TRY(check_vel(c, "model_begin", "UDiv", UDiv, flags, is3D));
+  TRY(check_vel(c, "model_begin", "UOut", UOut, flags, is3D));
+  if (zlo < 0 || zhi > flags->Z || zlo >= zhi) return fail(c, TFL_EINVAL, "model_begin: bad z range [%d, %d)", zlo, zhi);
+  ModelWs w;
+  TRY(model_ws(c, m, flags, workspace, workspace_floats, &w));
+  // SetWallBcs(UDiv) lands in UOut. UOut may alias UDiv: a thread rewrites only the cell it read, and
+  // neighbour values are re-derived from the flags, so a neighbour already holding the BC-applied
+  // value gives the identical result (the BC is idempotent).
+  tfl::model_pre(c->stream, m->is3d, flags->B, flags->Z, flags->Y, flags->X, UDiv->data, flags->data, UOut->data,
+                 w.div, w.partials, stats ? stats : m->d_stats, zlo, zhi);
+  return check_launch(c, "model_begin");
+}
+
+int tfl_model_finish(tfl_ctx* c, tfl_model* m, const tfl_tensor* pDiv, const tfl_tensor* flags,
+                     const tfl_tensor* pOut, const tfl_tensor* UOut, float* workspace, int64_t workspace_floats,
+                     const double* stats, double count, const tfl_tensor* UBC, const tfl_tensor* UBCInvMask,
+                     int doClamp, float lo, float hi) {
+  TRY(check_flags(c, "model_finish", flags));
+  if (!m) return fail(c, TFL_EINVAL, "model_finish: null model");
+  const int is3D = m->is3d ? 1 : 0;
+  TRY(check_vel(c, "model_finish", "UOut", UOut, flags, is3D));
+  TRY(check_scalar(c, "model_finish", "pDiv", pDiv, flags));
+  TRY(check_scalar(c, "model_finish", "pOut", pOut, flags));
+  if ((UBC == nullptr) != (UBCInvMask == nullptr)) return fail(c, TFL_EINVAL, "model_finish: UBC and UBCInvMask go together");
+  if (UBC) {
+    TRY(check_vel(c, "model_finish", "UBC", UBC, flags, is3D));
+    TRY(check_vel(c, "model_finish", "UBCInvMask", UBCInvMask, flags, is3D));
+  }
+  if (!(count > 1.0)) return fail(c, TFL_EINVAL, "model_finish: Sample variance requires more than one sample.");
+  ModelWs w;
+  TRY(model_ws(c, m, flags, workspace, workspace_floats, &w));
+  const int B = flags->B, Z = flags->Z, Y = flags->Y, X = flags->X;
+  const double* st_in = stats ? stats : m->d_stats;
+  hipStream_t st = c->stream;
+  tfl::model_net_input(st, m->is3d, B, Z, Y, X, pDiv->data, w.div, flags->data, st_in, count, w.x3);
+  if (m->mfma3d) {
+    tfl::conv3_mfma_first(st, B, Z, Y, X, w.x3, m->bfrag[0], m->layers[0].b, w.act[0]);
+    tfl::conv3_mfma_mid(st, B, Z, Y, X, w.act[0], m->bfrag[1], m->layers[1].b, w.act[1]);
+    tfl::conv3_mfma_tail(st, B, Z, Y, X, w.act[1], m->bfrag[2], m->layers[2].b, m->tail_w4, m->layers[3].b,
+                         m->tail_w5, m->layers[4].b, w.pPred);
+  } else {
+    const float* in = w.x3;
+    for (size_t l = 0; l < m->layers.size(); l++) {
+      const tfl_layer& L = m->layers[l];
+      const bool last = l + 1 == m->layers.size();
+      float* out = last ? w.pPred : w.act[l & 1];
+      if (!tfl::conv_direct(st, m->is3d, B, Z, Y, X, L.cin, L.cout, L.k, !last, in, L.w, L.b, out))
+        return fail(c, TFL_EUNSUPPORTED, "model_finish: no kernel for %d output channels", L.cout);
+      in = out;
+    }
+  }
+  tfl::model_project(st, m->is3d, B, Z, Y, X, w.pPred, flags->data, st_in, count, UOut->data, pOut->data,
+                     UBC ? UBC->data : nullptr, UBC ? UBCInvMask->data : nullptr, doClamp, lo, hi);
+  return check_launch(c, "model_finish");
+}
+
 int tfl_model_forward(tfl_ctx* c, tfl_model* m, const tfl_tensor* pDiv, const tfl_tensor* UDiv,
                       const tfl_tensor* flags, const tfl_tensor* pOut, const tfl_tensor* UOut, float* workspace,
                       int64_t workspace_floats, const tfl_tensor* UBC, const tfl_tensor* UBCInvMask, int doClamp,
                       float lo, float hi) {
   TRY(check_flags(c, "model_forward", flags));
-  if (!m) return fail(c, TFL_EINVAL, "model_forward: null model");
-  const int is3D = m->is3d ? 1 : 0;
-  TRY(check_vel(c, "model_forward", "UDiv", UDiv, flags, is3D));
-  TRY(check_vel(c, "model_forward", "UOut", UOut, flags, is3D));
-  TRY(check_scalar(c, "model_forward", "pDiv", pDiv, flags));
-  TRY(check_scalar(c, "model_forward", "pOut", pOut, flags));
-  if ((UBC == nullptr) != (UBCInvMask == nullptr)) return fail(c, TFL_EINVAL, "model_forward: UBC and UBCInvMask go together");
-  if (UBC) {
-    TRY(check_vel(c, "model_forward", "UBC", UBC, flags, is3D));
-    TRY(check_vel(c, "model_forward", "UBCInvMask", UBCInvMask, flags, is3D));
-  }
-  const int B = flags->B, Z = flags->Z, Y = flags->Y, X = flags->X;
-  if (B > kMaxBatch) return fail(c, TFL_EINVAL, "model_forward: batch size above %d", kMaxBatch);
-  const int64_t n = (int64_t)B * Z * Y * X;
-  if (!workspace || workspace_floats < tfl_model_workspace_floats(m, B, Z, Y, X))
-    return fail(c, TFL_EINVAL, "model_forward: workspace too small (%lld floats needed)",
-                (long long)tfl_model_workspace_floats(m, B, Z, Y, X));
-  if (((uintptr_t)workspace & 7) != 0) return fail(c, TFL_EINVAL, "model_forward: workspace must be 8-byte aligned");
-  double* partials = (double*)workspace;
-  float* div = workspace + 4 * tfl::model_stat_blocks(B, Z, Y, X);
-  float* x3 = div + n;
-  float* act[2] = {x3 + 3 * n, x3 + 3 * n + (int64_t)m->max_c * n};
-  float* pPred = act[1] + (int64_t)m->max_c * n;
-  hipStream_t st = c->stream;
-  // SetWallBcs(UDiv) lands in UOut (may alias UDiv: each thread rewrites only the cell it read, and
-  // neighbours are re-derived from the INPUT through the flags, so in-place is race-free only when
-  // UOut != UDiv; with aliasing the neighbour value read may already be the BC-applied one, which
-  // is idempotent -- identical either way).
-  tfl::model_pre(st, m->is3d, B, Z, Y, X, UDiv->data, flags->data, UOut->data, div, partials, m->d_stats);
-  tfl::model_net_input(st, m->is3d, B, Z, Y, X, pDiv->data, div, flags->data, m->d_stats, x3);
-  if (m->mfma3d) {
-    tfl::conv3_mfma_first(st, B, Z, Y, X, x3, m->bfrag[0], m->layers[0].b, act[0]);
-    tfl::conv3_mfma_mid(st, B, Z, Y, X, act[0], m->bfrag[1], m->layers[1].b, act[1]);
-    tfl::conv3_mfma_tail(st, B, Z, Y, X, act[1], m->bfrag[2], m->layers[2].b, m->tail_w4, m->layers[3].b,
-                         m->tail_w5, m->layers[4].b, pPred);
-  }
-  const float* in = x3;
-  for (size_t l = 0; !m->mfma3d && l < m->layers.size(); l++) {
-    const tfl_layer& L = m->layers[l];
-    const bool last = l + 1 == m->layers.size();
-    float* out = last ? pPred : act[l & 1];
-    if (!tfl::conv_direct(st, m->is3d, B, Z, Y, X, L.cin, L.cout, L.k, !last, in, L.w, L.b, out))
-      return fail(c, TFL_EUNSUPPORTED, "model_forward: no kernel for %d output channels", L.cout);
-    in = out;
-  }
-  tfl::model_project(st, m->is3d, B, Z, Y, X, pPred, flags->data, m->d_stats, UOut->data, pOut->data,
-                     UBC ? UBC->data : nullptr, UBC ? UBCInvMask->data : nullptr, doClamp, lo, hi);
-  return check_launch(c, "model_forward");
+  TRY(tfl_model_begin(c, m, UDiv, flags, UOut, workspace, workspace_floats, 0, flags->Z, nullptr));
+  const double count = (double)flags->Z * flags->Y * flags->X * (m->is3d ? 3 : 2);
+  return tfl_model_finish(c, m, pDiv, flags, pOut, UOut, workspace, workspace_floats, nullptr, count, UBC, UBCInvMask,
+                          doClamp, lo, hi);
 }
 
 int tfl_applyBCs(tfl_ctx* c, const tfl_tensor* x, const tfl_tensor* bc, const tfl_tensor* invMask, int doClamp,

@@ -100,11 +100,13 @@ __global__ __launch_bounds__(256) void k_bcs_div_stats(Dom d, const float* __res
 // stats[b*2 + 0] = sum u, stats[b*2 + 1] = sum u^2 over all C*Z*Y*X values of U_bc[b]; one block per
 // sample, fixed summation order (strided accumulate, then a shared-memory tree).
 __global__ __launch_bounds__(256) void k_reduce_stats(const double* __restrict__ partials, long long per_sample,
-                                                      double* __restrict__ stats) {
+                                                      long long first, long long count, double* __restrict__ stats) {
+  // [first, first + count) = the blocks of the z-planes that take part (a z-slab rank reduces only the
+  // planes it owns; the halo planes belong to its neighbours)
   const int b = blockIdx.x;
-  const double* p = partials + (long long)b * per_sample * 2;
+  const double* p = partials + ((long long)b * per_sample + first) * 2;
   double s1 = 0.0, s2 = 0.0;
-  for (long long t = threadIdx.x; t < per_sample; t += 256) { s1 += p[t * 2]; s2 += p[t * 2 + 1]; }
+  for (long long t = threadIdx.x; t < count; t += 256) { s1 += p[t * 2]; s2 += p[t * 2 + 1]; }
   __shared__ double sh1[256], sh2[256];
   sh1[threadIdx.x] = s1; sh2[threadIdx.x] = s2;
   __syncthreads();
@@ -124,13 +126,13 @@ __device__ __forceinline__ float scale_from_stats(const double* __restrict__ sta
 template <bool IS3D>
 __global__ __launch_bounds__(256) void k_net_input(Dom d, const float* __restrict__ pDiv, const float* __restrict__ div,
                                                    const float* __restrict__ flags, const double* __restrict__ stats,
-                                                   float* __restrict__ x3) {
+                                                   double count, float* __restrict__ x3) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int j = blockIdx.y * blockDim.y + threadIdx.y;
   const int b = blockIdx.z / d.Z, k = blockIdx.z - b * d.Z;
   if (i >= d.X || j >= d.Y) return;
   const long long cells = d.sc;
-  const float scale = scale_from_stats(stats, b, (double)cells * (IS3D ? 3 : 2));
+  const float scale = scale_from_stats(stats, b, count);
   const int o = TFL_AT(d, i, j, k);
   const long long bo = b * cells;
   x3 += bo * 3;
@@ -147,15 +149,15 @@ struct BcArgs {  // optional fused tail of simulate(): setConstVals + clamp, sim
 
 template <bool IS3D>
 __global__ __launch_bounds__(256) void k_project(Dom d, const float* __restrict__ pPred, const float* __restrict__ flags,
-                                                 const double* __restrict__ stats, float* __restrict__ Uio,
-                                                 float* __restrict__ pOut, BcArgs bc) {
+                                                 const double* __restrict__ stats, double count,
+                                                 float* __restrict__ Uio, float* __restrict__ pOut, BcArgs bc) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int j = blockIdx.y * blockDim.y + threadIdx.y;
   const int b = blockIdx.z / d.Z, k = blockIdx.z - b * d.Z;
   if (i >= d.X || j >= d.Y) return;
   const long long cells = d.sc;
   const int C = IS3D ? 3 : 2;
-  const float scale = scale_from_stats(stats, b, (double)cells * C);
+  const float scale = scale_from_stats(stats, b, count);
   pPred += b * cells; flags += b * cells; pOut += b * cells; Uio += b * cells * C;
   const int o = TFL_AT(d, i, j, k);
   const float pc = pPred[o];
@@ -209,30 +211,31 @@ long long model_stat_blocks(int B, int Z, int Y, int X) {
 }
 
 void model_pre(hipStream_t st, bool is3d, int B, int Z, int Y, int X, const float* U, const float* flags, float* Ubc,
-               float* div, double* partials, double* stats) {
+               float* div, double* partials, double* stats, int zlo, int zhi) {
   const Dom d = make_dom(Z, Y, X);
   const dim3 blk(64, 4, 1), grd = TFL_GRID3(d, B);
   if (is3d) { TFL_TIMED("k_bcs_div_stats", st); k_bcs_div_stats<true><<<grd, blk, 0, st>>>(d, U, flags, Ubc, div, partials); }
   else { TFL_TIMED("k_bcs_div_stats", st); k_bcs_div_stats<false><<<grd, blk, 0, st>>>(d, U, flags, Ubc, div, partials); }
-  { TFL_TIMED("k_reduce_stats", st); k_reduce_stats<<<B, 256, 0, st>>>(partials, model_stat_blocks(1, Z, Y, X), stats); }
+  { TFL_TIMED("k_reduce_stats", st); k_reduce_stats<<<B, 256, 0, st>>>(partials, model_stat_blocks(1, Z, Y, X), model_stat_blocks(1, zlo, Y, X),
+                                         model_stat_blocks(1, zhi - zlo, Y, X), stats); }
 }
 
 void model_net_input(hipStream_t st, bool is3d, int B, int Z, int Y, int X, const float* pDiv, const float* div,
-                     const float* flags, const double* stats, float* x3) {
+                     const float* flags, const double* stats, double count, float* x3) {
   const Dom d = make_dom(Z, Y, X);
   const dim3 blk(64, 4, 1), grd = TFL_GRID3(d, B);
-  if (is3d) { TFL_TIMED("k_net_input", st); k_net_input<true><<<grd, blk, 0, st>>>(d, pDiv, div, flags, stats, x3); }
-  else { TFL_TIMED("k_net_input", st); k_net_input<false><<<grd, blk, 0, st>>>(d, pDiv, div, flags, stats, x3); }
+  if (is3d) { TFL_TIMED("k_net_input", st); k_net_input<true><<<grd, blk, 0, st>>>(d, pDiv, div, flags, stats, count, x3); }
+  else { TFL_TIMED("k_net_input", st); k_net_input<false><<<grd, blk, 0, st>>>(d, pDiv, div, flags, stats, count, x3); }
 }
 
 void model_project(hipStream_t st, bool is3d, int B, int Z, int Y, int X, const float* pPred, const float* flags,
-                   const double* stats, float* Uio, float* pOut, const float* UBC, const float* UInvMask, int do_clamp,
-                   float lo, float hi) {
+                   const double* stats, double count, float* Uio, float* pOut, const float* UBC, const float* UInvMask,
+                   int do_clamp, float lo, float hi) {
   const Dom d = make_dom(Z, Y, X);
   const dim3 blk(64, 4, 1), grd = TFL_GRID3(d, B);
   BcArgs bc; bc.UBC = UBC; bc.UInvMask = UInvMask; bc.enable_clamp = do_clamp; bc.lo = lo; bc.hi = hi;
-  if (is3d) { TFL_TIMED("k_project", st); k_project<true><<<grd, blk, 0, st>>>(d, pPred, flags, stats, Uio, pOut, bc); }
-  else { TFL_TIMED("k_project", st); k_project<false><<<grd, blk, 0, st>>>(d, pPred, flags, stats, Uio, pOut, bc); }
+  if (is3d) { TFL_TIMED("k_project", st); k_project<true><<<grd, blk, 0, st>>>(d, pPred, flags, stats, count, Uio, pOut, bc); }
+  else { TFL_TIMED("k_project", st); k_project<false><<<grd, blk, 0, st>>>(d, pPred, flags, stats, count, Uio, pOut, bc); }
 }
 
 void apply_bcs(hipStream_t st, long long n, float* x, const float* bcv, const float* inv, int do_clamp, float lo,

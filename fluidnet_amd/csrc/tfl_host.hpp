@@ -46,12 +46,12 @@ void jacobi_iteration(hipStream_t st, bool is3d, int B, int Z, int Y, int X, con
 // model.hip
 long long model_stat_blocks(int B, int Z, int Y, int X);
 void model_pre(hipStream_t st, bool is3d, int B, int Z, int Y, int X, const float* U, const float* flags, float* Ubc,
-               float* div, double* partials, double* stats);
+               float* div, double* partials, double* stats, int zlo, int zhi);
 void model_net_input(hipStream_t st, bool is3d, int B, int Z, int Y, int X, const float* pDiv, const float* div,
-                     const float* flags, const double* stats, float* x3);
+                     const float* flags, const double* stats, double count, float* x3);
 void model_project(hipStream_t st, bool is3d, int B, int Z, int Y, int X, const float* pPred, const float* flags,
-                   const double* stats, float* Uio, float* pOut, const float* UBC, const float* UInvMask, int do_clamp,
-                   float lo, float hi);
+                   const double* stats, double count, float* Uio, float* pOut, const float* UBC, const float* UInvMask,
+                   int do_clamp, float lo, float hi);
 void apply_bcs(hipStream_t st, long long n, float* x, const float* bcv, const float* inv, int do_clamp, float lo,
                float hi);
 

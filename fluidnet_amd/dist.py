@@ -1,0 +1,198 @@
+"""z-slab decomposition of simulate() across the GPUs of one node (BASELINE config 5).
+
+The reference is single-GPU (no communication layer); this is new work defined by
+BASELINE.json. One process per GPU (torch.distributed, backend "nccl" = RCCL over xGMI). The grid is
+cut along z -- the slowest spatial dimension, so a slab and every halo plane are contiguous in HBM --
+and rank r owns planes [z0, z1). It stores [z0 - h, z1 + h) (clipped to the domain), runs the
+UNMODIFIED single-GPU kernels on that extended array, and refreshes the h halo planes from its two
+z-neighbours at two points of the step. xGMI is point-to-point: a slab only ever talks to ranks r-1
+and r+1, each over its own link, so the exchange is two grouped send/recv pairs -- no ring, no
+all-to-all -- plus ONE 2-double all-reduce per step for the ConvNet's global std(U) normaliser
+(lib/model.lua:93-117).
+
+Why the unmodified kernels give the exact single-GPU answer on the owned planes: every operator reads a
+bounded z-neighbourhood, so errors that enter at the artificial ends of the extended array (treated by
+the kernels as the domain's border shell) travel inward by a bounded number of planes per phase:
+  advection (MacCormack, two passes): 2*Rt + 3 planes, Rt = ceil(max|u_z|*dt) the back-trace reach
+  buoyancy 1, vorticity confinement 3 (+1 border plane), ConvNet projection 5 (div 1 + three 3^3 convs
+  3 + pressure gradient 1)
+With h = 10: exchange {U, density} -> advect (<= 7 planes for Rt <= 2) -> exchange {U, density, p} ->
+forces + projection (9 planes) keeps [z0, z1) exact. `check_reach=True` verifies Rt on the device.
+Message size per neighbour and direction: planes * X * Y * 4 B * channels (128^2: 64 KiB per plane and
+channel; 10 planes x 5 channels = 3.1 MiB), far above the latency-bound regime, sent as one buffer.
+"""
+import math
+
+import torch
+
+from . import tfluids
+from .simulate import _apply, _f32, _gravity, setConstVals
+
+DEFAULT_HALO = 10
+
+
+class SlabLayout:
+    """Owned planes [z0, z1) of a Z_total grid and the extended local range [lo, hi)."""
+
+    def __init__(self, z_total, world, rank, halo=DEFAULT_HALO):
+        if z_total % world != 0:
+            raise ValueError("z extent %d is not divisible by %d ranks" % (z_total, world))
+        per = z_total // world
+        if world > 1 and per < halo:
+            raise ValueError("slab thickness %d is smaller than the halo %d" % (per, halo))
+        self.z_total, self.world, self.rank, self.halo = z_total, world, rank, halo
+        self.z0, self.z1 = rank * per, (rank + 1) * per
+        self.lo, self.hi = max(self.z0 - halo, 0), min(self.z1 + halo, z_total)
+        self.c0, self.c1 = self.z0 - self.lo, self.z1 - self.lo   # owned planes in local indices
+        self.has_lower, self.has_upper = rank > 0, rank < world - 1
+
+    def extract(self, t):
+        """Local extended copy of a global [B, C, Z, Y, X] tensor."""
+        return t[:, :, self.lo:self.hi].contiguous()
+
+    def owned(self, t):
+        return t[:, :, self.c0:self.c1]
+
+
+def _pack(fields, a, b):
+    return torch.cat([f[:, :, a:b].reshape(-1) for f in fields])
+
+
+def _unpack(buf, fields, a, b):
+    off = 0
+    for f in fields:
+        view = f[:, :, a:b]
+        n = view.numel()
+        view.copy_(buf[off:off + n].view(view.shape))
+        off += n
+
+
+class DistComm:
+    """Halo exchange + all-reduce over torch.distributed (nccl = RCCL on GPUs, gloo on CPU tensors)."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.group = group
+
+    def exchange(self, lay, fields):
+        dist, h = self.dist, lay.halo
+        ops, recvs = [], []
+        if lay.has_lower:   # my lowest h owned planes -> rank-1's upper halo; its top planes -> my lower halo
+            send = _pack(fields, lay.c0, lay.c0 + h)
+            recv = torch.empty_like(send)
+            ops += [dist.P2POp(dist.isend, send, lay.rank - 1, self.group),
+                    dist.P2POp(dist.irecv, recv, lay.rank - 1, self.group)]
+            recvs.append((recv, lay.c0 - h, lay.c0))
+        if lay.has_upper:
+            send = _pack(fields, lay.c1 - h, lay.c1)
+            recv = torch.empty_like(send)
+            ops += [dist.P2POp(dist.isend, send, lay.rank + 1, self.group),
+                    dist.P2POp(dist.irecv, recv, lay.rank + 1, self.group)]
+            recvs.append((recv, lay.c1, lay.c1 + h))
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        for buf, a, b in recvs:
+            _unpack(buf, fields, a, b)
+
+    def allreduce_sum(self, t):
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+
+
+def run_lockstep(gens_layouts):
+    """Drive several SlabSimulation.step_gen() generators of VIRTUAL ranks living in one process (tests,
+    single-GPU verification of the decomposition): advance all to their next communication request,
+    perform it among them with plain copies, repeat."""
+    gens = [g for g, _ in gens_layouts]
+    lays = [l for _, l in gens_layouts]
+    reqs = [next(g, None) for g in gens]
+    while any(r is not None for r in reqs):
+        kinds = {r[0] for r in reqs}
+        assert len(kinds) == 1, "virtual ranks diverged: %s" % kinds
+        kind = kinds.pop()
+        if kind == "halo":
+            h = lays[0].halo
+            sends = []
+            for (_, fields), lay in zip(reqs, lays):
+                lo_buf = _pack(fields, lay.c0, lay.c0 + h) if lay.has_lower else None
+                hi_buf = _pack(fields, lay.c1 - h, lay.c1) if lay.has_upper else None
+                sends.append((lo_buf, hi_buf))
+            for r, ((_, fields), lay) in enumerate(zip(reqs, lays)):
+                if lay.has_lower:
+                    _unpack(sends[r - 1][1], fields, lay.c0 - h, lay.c0)
+                if lay.has_upper:
+                    _unpack(sends[r + 1][0], fields, lay.c1, lay.c1 + h)
+        elif kind == "allreduce":
+            total = sum(r[1] for r in reqs)
+            for r in reqs:
+                r[1].copy_(total)
+        else:
+            raise AssertionError(kind)
+        reqs = [next(g, None) for g in gens]
+
+
+class SlabSimulation:
+    """tfluids.simulate() (lib/simulate.lua:175-327, ConvNet projection) on one z-slab.
+
+    `batch` holds the EXTENDED local tensors (SlabLayout.extract of the global pDiv, UDiv, flags, density
+    and BC tensors). With world == 1 this is exactly fluidnet_amd.simulate.simulate."""
+
+    def __init__(self, batch, mconf, model, layout, comm=None, check_reach=False):
+        self.batch, self.mconf, self.model, self.lay = batch, mconf, model, layout
+        self.comm = comm
+        self.check_reach = check_reach
+        U = batch["UDiv"]
+        _, C, _, Y, X = U.shape
+        self.dx = 1.0 / max(X, Y, layout.z_total)
+        self.count = float(C * layout.z_total * Y * X)            # global sample count of std(U)
+        self.stats = torch.zeros(U.size(0), 2, dtype=torch.float64, device=U.device)
+        if (mconf.get("simMethod") or "convnet") != "convnet":
+            raise tfluids.TfluidsError("the z-slab path implements the ConvNet projection")
+
+    def step_gen(self):
+        b, m, lay = self.batch, self.mconf, self.lay
+        p, U, flags, rho = b["pDiv"], b["UDiv"], b["flags"], b["density"]
+        dt, method, strength = m["dt"], m.get("advectionMethod"), m.get("maccormackStrength")
+        multi = lay.world > 1
+        if multi:
+            tfluids.setDxOverride(U, self.dx)
+            yield ("halo", [U, rho])
+            if self.check_reach:
+                reach = float(U[:, 2].abs().max()) * dt
+                if 2 * math.ceil(reach) + 3 > lay.halo:
+                    raise tfluids.TfluidsError("back-trace reach %.2f planes exceeds what halo %d covers"
+                                               % (reach, lay.halo))
+        tfluids.advectScalar(dt, rho, U, flags, method, None, False, strength)
+        tfluids.advectVel(dt, U, flags, method, None, strength)
+        if multi:
+            yield ("halo", [U, rho, p])
+        setConstVals(b, p, U, flags, rho)
+        dx = self.dx if multi else tfluids.getDx(flags)
+        if m.get("buoyancyScale", 0) > 0:
+            s = _f32(-(dx / 4) * m["buoyancyScale"])
+            tfluids.addBuoyancy(U, flags, rho, [_f32(v) * s for v in _gravity(m)], dt)
+        if m.get("gravityScale", 0) > 0:
+            s = _f32((-dx / 4) * m["gravityScale"])
+            tfluids.addGravity(U, flags, [_f32(v) * s for v in _gravity(m)], dt)
+        if m.get("vorticityConfinementAmp", 0) > 0:
+            tfluids.vorticityConfinement(U, flags, dx * m["vorticityConfinementAmp"])
+        setConstVals(b, p, U, flags, rho)
+        self.model.begin(U, flags, lay.c0, lay.c1, self.stats)
+        if multi:
+            yield ("allreduce", self.stats)
+        self.model.finish(p, U, flags, self.stats, self.count, UBC=b.get("UBC"), UBCInvMask=b.get("UBCInvMask"),
+                          clamp=(-1e6, 1e6))
+        if b.get("pBC") is not None:
+            _apply(p, b["pBC"], b["pBCInvMask"])
+        if b.get("densityBC") is not None:
+            _apply(rho, b["densityBC"], b["densityBCInvMask"])
+        if multi:
+            tfluids.setDxOverride(U, None)
+
+    def step(self):
+        for req in self.step_gen():
+            if req[0] == "halo":
+                self.comm.exchange(self.lay, req[1])
+            else:
+                self.comm.allreduce_sum(req[1])

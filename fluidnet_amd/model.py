@@ -107,3 +107,38 @@ class FluidNetModel:
         return [p, U]
 
     __call__ = forward
+
+    # -- the same forward in two halves, for z-slab decomposition (fluidnet_amd.dist) --------------
+    def _prep(self, flags):
+        lib, ctx = tfluids._context(flags)
+        dev = flags.device.index
+        h = self._handle(lib, ctx, dev)
+        B, _, Z, Y, X = flags.shape
+        need = lib.tfl_model_workspace_floats(h, B, Z, Y, X)
+        work = self._work.get(dev)
+        if work is None or work.numel() < need:
+            work = torch.empty(need, dtype=torch.float32, device=flags.device)
+            self._work[dev] = work
+        return lib, ctx, h, work
+
+    def begin(self, U, flags, zlo, zhi, stats):
+        """SetWallBcs(U) in place + divergence + {sum u, sum u^2} over z-planes [zlo, zhi) into
+        `stats` (float64 tensor [B, 2] on the device) -- the caller all-reduces it across ranks."""
+        tfluids._dims(U, flags)
+        tfluids._check(stats.dtype == torch.float64 and stats.is_contiguous() and stats.numel() >= 2 * U.size(0),
+                       "stats must be a contiguous float64 [B, 2] tensor")
+        lib, ctx, h, work = self._prep(flags)
+        tfluids._call(lib, ctx, lib.tfl_model_begin(ctx, h, tfluids._tt(U), tfluids._tt(flags), tfluids._tt(U),
+                                                    ctypes.c_void_p(work.data_ptr()), work.numel(), int(zlo),
+                                                    int(zhi), ctypes.c_void_p(stats.data_ptr())))
+
+    def finish(self, p, U, flags, stats, count, UBC=None, UBCInvMask=None, clamp=None):
+        """Everything after the (all-reduced) statistics: net input, conv stack, velocity update,
+        un-scale, wall BCs (+ the fused setConstVals/clamp tail); p and U are updated in place."""
+        lib, ctx, h, work = self._prep(flags)
+        lo, hi = clamp if clamp is not None else (0.0, 0.0)
+        tfluids._call(lib, ctx, lib.tfl_model_finish(
+            ctx, h, tfluids._tt(p), tfluids._tt(flags), tfluids._tt(p), tfluids._tt(U),
+            ctypes.c_void_p(work.data_ptr()), work.numel(), ctypes.c_void_p(stats.data_ptr()), float(count),
+            tfluids._tt(UBC) if UBC is not None else None,
+            tfluids._tt(UBCInvMask) if UBCInvMask is not None else None, int(clamp is not None), lo, hi))

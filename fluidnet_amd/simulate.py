@@ -18,8 +18,10 @@ def getPUFlagsDensityReference(batch):
     return batch["pDiv"], batch["UDiv"], batch["flags"], batch.get("density")
 
 
-def createPlumeBCs(batch, densityVal, uScale, rad):
-    """simulate.lua:47-123 (1-based loops restated as index arithmetic; same cells, same values)."""
+def createPlumeBCs(batch, densityVal, uScale, rad, zOffset=0, zTotal=None):
+    """simulate.lua:47-123 (1-based loops restated as index arithmetic; same cells, same values).
+    zOffset/zTotal (extension for z-slab ranks, fluidnet_amd.dist): the tensors hold planes
+    [zOffset, zOffset + Z) of a zTotal-deep grid; the plume geometry is that of the whole grid."""
     U = batch["UDiv"]
     batch["pBC"] = None
     batch["pBCInvMask"] = None
@@ -39,10 +41,10 @@ def createPlumeBCs(batch, densityVal, uScale, rad):
     if not is3D and zdim != 1:
         raise TfluidsError("2D plume needs zdim == 1")
     centerX = xdim // 2
-    centerZ = max(zdim // 2, 1)
+    centerZ = max((zTotal if zTotal is not None else zdim) // 2, 1)
     plumeRad = int(math.floor(xdim * rad))
     x = torch.arange(1, xdim + 1, device=U.device).view(1, 1, xdim)
-    z = torch.arange(1, zdim + 1, device=U.device).view(zdim, 1, 1)
+    z = torch.arange(1 + zOffset, zdim + 1 + zOffset, device=U.device).view(zdim, 1, 1)
     inside = ((centerX - x) ** 2 + (centerZ - z) ** 2) <= plumeRad * plumeRad   # [Z, 1, X]
     rows = min(4, ydim)
     inside = inside.expand(zdim, rows, xdim)

@@ -226,9 +226,27 @@ def emptyDomain(flags, is3D, bnd=None):
     return flags
 
 
+_dx_override = {}  # device index -> global dx of a z-slab-decomposed grid (fluidnet_amd.dist)
+
+
+def setDxOverride(like, dx):
+    """A z-slab rank holds part of the grid; getDx = 1/max(X,Y,Z) is a property of the whole grid.
+    dx > 0 pins it for this device (Python side and inside libtfluids_hip.so); None/0 clears it."""
+    lib, ctx = _context(like)
+    dev = like.device.index
+    if dx:
+        _dx_override[dev] = float(dx)
+    else:
+        _dx_override.pop(dev, None)
+    _call(lib, ctx, lib.tfl_set_dx_override(ctx, float(dx or 0.0)))
+
+
 def getDx(flags):
     """init.lua:560-564 | grid.cc:37-40."""
     _check(flags.dim() == 5, "Dimension mismatch")
+    ov = _dx_override.get(flags.device.index) if flags.is_cuda else None
+    if ov:
+        return ov
     return 1.0 / max(flags.size(2), flags.size(3), flags.size(4))
 
 

@@ -172,6 +172,24 @@ int tfl_model_forward(tfl_ctx* ctx, tfl_model* model, const tfl_tensor* pDiv, co
                       float* workspace, int64_t workspace_floats, const tfl_tensor* UBC,
                       const tfl_tensor* UBCInvMask, int doClamp, float lo, float hi);
 
+/* The same forward in two halves, for z-slab decomposition (BASELINE config 5): `begin` applies the
+ * wall BCs, computes the divergence and reduces sum(u), sum(u^2) of SetWallBcs(UDiv) over the owned
+ * z-planes [zlo, zhi) into stats[2*B] (device doubles; NULL = the model's internal buffer); the caller
+ * all-reduces stats across ranks; `finish` runs the rest with `count` = the GLOBAL number of velocity
+ * samples per batch item (C*Z*Y*X of the whole grid). tfl_model_forward == begin(0, Z) + finish. */
+int tfl_model_begin(tfl_ctx* ctx, tfl_model* model, const tfl_tensor* UDiv, const tfl_tensor* flags,
+                    const tfl_tensor* UOut, float* workspace, int64_t workspace_floats, int zlo, int zhi,
+                    double* stats);
+int tfl_model_finish(tfl_ctx* ctx, tfl_model* model, const tfl_tensor* pDiv, const tfl_tensor* flags,
+                     const tfl_tensor* pOut, const tfl_tensor* UOut, float* workspace,
+                     int64_t workspace_floats, const double* stats, double count, const tfl_tensor* UBC,
+                     const tfl_tensor* UBCInvMask, int doClamp, float lo, float hi);
+
+/* A z-slab rank holds only part of the grid, but tfluids.getDx = 1/max(X,Y,Z) (grid.cc:37-40) is a
+ * property of the WHOLE grid: dx > 0 overrides the value addBuoyancy / addGravity derive from the
+ * local tensor sizes; 0 restores the default. */
+int tfl_set_dx_override(tfl_ctx* ctx, float dx);
+
 /* x = x*invMask + bc (both NULL: skip), then clamp to [lo, hi] if doClamp: one fused launch for
  * setConstVals' cmul+add pairs and the final U:clamp (lib/simulate.lua:130-160, 326), which the
  * reference issues as separate THC elementwise kernels. */

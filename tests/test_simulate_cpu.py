@@ -87,3 +87,15 @@ def test_simulate_restatement_runs_jacobi_2d(oracle):
         S.simulate(oracle, mconf, batch)
     assert np.isfinite(batch["UDiv"]).all() and np.isfinite(batch["density"]).all()
     assert batch["density"][0, 0, 0, 4:, :].sum() > 0   # smoke left the inflow rows
+
+
+def test_plume_bcs_slab_construction_matches_global_slice():
+    from fluidnet_amd.simulate import createPlumeBCs
+    Zt, Y, X = 24, 12, 20
+    g = dict(UDiv=torch.zeros(1, 3, Zt, Y, X), density=torch.zeros(1, 1, Zt, Y, X))
+    createPlumeBCs(g, [1.0], 2.0, 0.15)
+    for lo, hi in [(0, 10), (7, 19), (14, 24)]:
+        l = dict(UDiv=torch.zeros(1, 3, hi - lo, Y, X), density=torch.zeros(1, 1, hi - lo, Y, X))
+        createPlumeBCs(l, [1.0], 2.0, 0.15, zOffset=lo, zTotal=Zt)
+        for k in ("UBC", "UBCInvMask", "densityBC", "densityBCInvMask"):
+            assert torch.equal(l[k], g[k][:, :, lo:hi]), (k, lo)
