@@ -47,8 +47,9 @@ class SlabLayout:
         self.has_lower, self.has_upper = rank > 0, rank < world - 1
 
     def extract(self, t):
-        """Local extended copy of a global [B, C, Z, Y, X] tensor."""
-        return t[:, :, self.lo:self.hi].contiguous()
+        """Local extended COPY of a global [B, C, Z, Y, X] tensor (clone: a single-channel z-range is
+        already contiguous, and .contiguous() would hand back a view aliasing the global tensor)."""
+        return t[:, :, self.lo:self.hi].clone(memory_format=torch.contiguous_format)
 
     def owned(self, t):
         return t[:, :, self.c0:self.c1]
