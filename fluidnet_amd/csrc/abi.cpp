@@ -243,26 +243,32 @@ int tfl_advectScalar(tfl_ctx* c, float dt, const tfl_tensor* s, const tfl_tensor
                      const tfl_tensor* fwd, const tfl_tensor* bwd, int is3D, const char* method,
                      const tfl_tensor* fwdPos, const tfl_tensor* bwdPos, int boundaryWidth, int sampleOutsideFluid,
                      float maccormackStrength, const tfl_tensor* sDst) {
-  (void)bwd; (void)bwdPos; (void)boundaryWidth;  // bnd = 1 like the reference (tfluids.cc:436,467)
+  (void)bwd; (void)boundaryWidth;  // bnd = 1 like the reference (tfluids.cc:436,467)
   TRY(check_flags(c, "advectScalar", flags));
   TRY(check_vel(c, "advectScalar", "U", U, flags, is3D));
   TRY(check_scalar(c, "advectScalar", "s", s, flags));
   TRY(check_scalar(c, "advectScalar", "sDst", sDst, flags));
   const int m = parse_method(method);
   if (m < 0) return fail(c, TFL_EINVAL, "advectScalar: unknown advection method '%s'", method ? method : "(null)");
-  if (sDst->data == s->data) return fail(c, TFL_EINVAL, "advectScalar: sDst must not alias s");
+  // maccormackOurs' pass B reads `s` only at the cell it writes, so sDst may alias s (in-place, saves the
+  // wrapper's copy-back); every other method gathers from s while writing sDst.
+  if (sDst->data == s->data && m != tfl::kMacCormackOurs)
+    return fail(c, TFL_EINVAL, "advectScalar: sDst must not alias s for method '%s'", method);
   float* fwd_p = nullptr;
   float* bounds_p = nullptr;
+  float* mm_p = nullptr;
   if (m == tfl::kMacCormack || m == tfl::kMacCormackOurs) {
     TRY(check_scalar(c, "advectScalar", "fwd", fwd, flags));
     fwd_p = fwd->data;
   }
   if (m == tfl::kMacCormackOurs) {
     TRY(check_vel(c, "advectScalar", "fwdPos", fwdPos, flags, is3D));
-    bounds_p = fwdPos->data;
+    TRY(check_vel(c, "advectScalar", "bwdPos", bwdPos, flags, is3D));
+    bounds_p = fwdPos->data;   // two planes: clamp bounds of each cell's forward position
+    mm_p = bwdPos->data;       // two planes: 3^dim fluid min / max grid of s
   }
   tfl::advect_scalar(c->stream, is3D != 0, m, flags->B, flags->Z, flags->Y, flags->X, dt, maccormackStrength,
-                     sampleOutsideFluid != 0, c->d_trace_err, s->data, U->data, flags->data, fwd_p, bounds_p,
+                     sampleOutsideFluid != 0, c->d_trace_err, s->data, U->data, flags->data, fwd_p, bounds_p, mm_p,
                      sDst->data);
   return check_launch(c, "advectScalar");
 }
@@ -562,13 +568,15 @@ int tfl_model_finish(tfl_ctx* c, tfl_model* m, const tfl_tensor* pDiv, const tfl
   const int B = flags->B, Z = flags->Z, Y = flags->Y, X = flags->X;
   const double* st_in = stats ? stats : m->d_stats;
   hipStream_t st = c->stream;
-  tfl::model_net_input(st, m->is3d, B, Z, Y, X, pDiv->data, w.div, flags->data, st_in, count, w.x3);
   if (m->mfma3d) {
-    tfl::conv3_mfma_first(st, B, Z, Y, X, w.x3, m->bfrag[0], m->layers[0].b, w.act[0]);
+    // the first MFMA layer builds {pDiv/scale, div/scale, occupancy} while staging its LDS tile
+    tfl::conv3_mfma_first_fused(st, B, Z, Y, X, pDiv->data, w.div, flags->data, st_in, count, m->bfrag[0],
+                                m->layers[0].b, w.act[0]);
     tfl::conv3_mfma_mid(st, B, Z, Y, X, w.act[0], m->bfrag[1], m->layers[1].b, w.act[1]);
     tfl::conv3_mfma_tail(st, B, Z, Y, X, w.act[1], m->bfrag[2], m->layers[2].b, m->tail_w4, m->layers[3].b,
                          m->tail_w5, m->layers[4].b, w.pPred);
   } else {
+    tfl::model_net_input(st, m->is3d, B, Z, Y, X, pDiv->data, w.div, flags->data, st_in, count, w.x3);
     const float* in = w.x3;
     for (size_t l = 0; l < m->layers.size(); l++) {
       const tfl_layer& L = m->layers[l];
@@ -608,6 +616,20 @@ int tfl_applyBCs(tfl_ctx* c, const tfl_tensor* x, const tfl_tensor* bc, const tf
   }
   tfl::apply_bcs(c->stream, n, x->data, bc ? bc->data : nullptr, bc ? invMask->data : nullptr, doClamp, lo, hi);
   return check_launch(c, "applyBCs");
+}
+
+int tfl_applyBCsIndexed(tfl_ctx* c, const tfl_tensor* x, const tfl_tensor* bc, const tfl_tensor* invMask,
+                        const int32_t* idx, int64_t n) {
+  if (!c) return TFL_EINVAL;
+  if (!x || !x->data || !bc || !bc->data || !invMask || !invMask->data) return fail(c, TFL_EINVAL, "applyBCsIndexed: null tensor");
+  const long long nx = (long long)x->B * x->C * x->Z * x->Y * x->X;
+  const long long nb = (long long)bc->B * bc->C * bc->Z * bc->Y * bc->X;
+  const long long nm = (long long)invMask->B * invMask->C * invMask->Z * invMask->Y * invMask->X;
+  if (nb != nx || nm != nx) return fail(c, TFL_EINVAL, "applyBCsIndexed: size mismatch");
+  if (nx >= (1ll << 31)) return fail(c, TFL_EINVAL, "applyBCsIndexed: tensor too large for 32-bit indices");
+  if (n < 0 || (n > 0 && !idx)) return fail(c, TFL_EINVAL, "applyBCsIndexed: bad index list");
+  tfl::apply_bcs_indexed(c->stream, n, idx, x->data, bc->data, invMask->data);
+  return check_launch(c, "applyBCsIndexed");
 }
 
 }  // extern "C"

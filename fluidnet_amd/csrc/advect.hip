@@ -170,13 +170,60 @@ __device__ void ours_clamp_bounds(const Dom& d, const float* __restrict__ flags,
   }
 }
 
+// Precomputed clamp-bound grid: lo3/hi3[cell] = min/max of src over the (fluid) 3^dim neighbourhood of
+// the cell (getClampBounds, tfluids.cc:331-378, evaluated once per CELL instead of once per traced
+// POSITION: pass A then needs two gathers at int(fwd_pos) instead of 27 x 2). min/max are exact, so the
+// evaluation order is free. Block = 64x4 threads of one z-plane; the masked values of the 66x6x3 halo
+// tile are staged in LDS as two planes (lo: non-fluid -> +inf, hi: non-fluid -> -inf).
+template <bool IS3D>
+__global__ __launch_bounds__(256) void k_minmax3(Dom d, int outside, const float* __restrict__ s,
+                                                 const float* __restrict__ flags, float* __restrict__ lo3,
+                                                 float* __restrict__ hi3) {
+  constexpr int NZ = IS3D ? 3 : 1;
+  __shared__ float tlo[NZ][6][66];
+  __shared__ float thi[NZ][6][66];
+  const int b = blockIdx.z / d.Z, k = blockIdx.z - b * d.Z;
+  const long long cells = d.sc;
+  s += b * cells; flags += b * cells; lo3 += b * cells; hi3 += b * cells;
+  const int x0 = blockIdx.x * 64 - 1, y0 = blockIdx.y * 4 - 1, z0 = IS3D ? k - 1 : 0;
+  const int tid = threadIdx.y * 64 + threadIdx.x;
+  for (int idx = tid; idx < NZ * 6 * 66; idx += 256) {
+    const int xx = idx % 66, yy = (idx / 66) % 6, zz = idx / (66 * 6);
+    const int gx = x0 + xx, gy = y0 + yy, gz = z0 + zz;
+    float vlo = __builtin_inff(), vhi = -__builtin_inff();
+    if (gx >= 0 && gx < d.X && gy >= 0 && gy < d.Y && gz >= 0 && gz < d.Z) {
+      const int o = TFL_AT(d, gx, gy, gz);
+      if (outside || (((int)flags[o]) & kFluid)) { vlo = s[o]; vhi = vlo; }
+    }
+    tlo[zz][yy][xx] = vlo; thi[zz][yy][xx] = vhi;
+  }
+  __syncthreads();
+  const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y;
+  if (i >= d.X || j >= d.Y) return;
+  float lo = __builtin_inff(), hi = -__builtin_inff();
+#pragma unroll
+  for (int zz = 0; zz < NZ; zz++)
+#pragma unroll
+    for (int yy = 0; yy < 3; yy++)
+#pragma unroll
+      for (int xx = 0; xx < 3; xx++) {
+        const float a = tlo[zz][threadIdx.y + yy][threadIdx.x + xx];
+        const float c = thi[zz][threadIdx.y + yy][threadIdx.x + xx];
+        if (a < lo) lo = a;
+        if (c > hi) hi = c;
+      }
+  const int o = TFL_AT(d, i, j, k);
+  lo3[o] = lo; hi3[o] = hi;
+}
+
 // ---- advectScalar ------------------------------------------------------------------------------
 // Pass A / single-pass methods. For kMacCormackOurs the clamp bounds go to bounds[0], bounds[1]
 // (two channel planes of the caller's fwdPos temp; empty neighbourhood is stored as lo=+inf > hi).
 template <bool IS3D, int METHOD>
 __global__ __launch_bounds__(256) void k_scalar_fwd(AdvArgs a, const float* __restrict__ s, const float* __restrict__ U,
                                                     const float* __restrict__ flags, float* __restrict__ out,
-                                                    float* __restrict__ bounds) {
+                                                    float* __restrict__ bounds, const float* __restrict__ lo3,
+                                                    const float* __restrict__ hi3) {
   TFL_CELL_INDEX();
   const int C = IS3D ? 3 : 2;
   s += b * cells; flags += b * cells; out += b * cells; U += b * cells * C;
@@ -193,11 +240,13 @@ __global__ __launch_bounds__(256) void k_scalar_fwd(AdvArgs a, const float* __re
     else if (METHOD == kRK3Ours) v = sl_rk3_ours<IS3D>(a, flags, U, s, i, j, k);
     else v = sl_euler_ours<IS3D>(a, flags, U, s, a.dt, i, j, k, back);
     if (METHOD == kMacCormackOurs) {
-      float lo, hi;
-      ours_clamp_bounds<IS3D>(d, flags, s, back, a.outside, lo, hi);
+      // clamp bounds of the forward position = the precomputed 3^dim min/max of the cell it falls in
+      const int i0 = iclampi((int)back.x, 0, d.X - 1), j0 = iclampi((int)back.y, 0, d.Y - 1);
+      const int k0 = IS3D ? iclampi((int)back.z, 0, d.Z - 1) : 0;
+      const long long g = b * cells + TFL_AT(d, i0, j0, k0);
       bounds += b * cells * C;
-      bounds[o] = lo;
-      bounds[o + d.sc] = hi;
+      bounds[o] = lo3[g];
+      bounds[o + d.sc] = hi3[g];
     }
   }
   out[o] = v;
@@ -315,19 +364,20 @@ static inline dim3 cell_grid(const Dom& d, int B, dim3 blk) {
 
 template <bool IS3D>
 static void launch_scalar(hipStream_t st, int method, const AdvArgs& a, int B, const float* s, const float* U,
-                          const float* flags, float* fwd, float* bounds, float* dst) {
+                          const float* flags, float* fwd, float* bounds, float* mm, float* dst) {
   const dim3 blk(64, 4, 1), grd = cell_grid(a.d, B, blk);
   switch (method) {
-    case kEuler: { TFL_TIMED("k_scalar_fwd", st); k_scalar_fwd<IS3D, kEuler><<<grd, blk, 0, st>>>(a, s, U, flags, dst, nullptr); break; }
-    case kEulerOurs: { TFL_TIMED("k_scalar_fwd", st); k_scalar_fwd<IS3D, kEulerOurs><<<grd, blk, 0, st>>>(a, s, U, flags, dst, nullptr); break; }
-    case kRK2Ours: { TFL_TIMED("k_scalar_fwd", st); k_scalar_fwd<IS3D, kRK2Ours><<<grd, blk, 0, st>>>(a, s, U, flags, dst, nullptr); break; }
-    case kRK3Ours: { TFL_TIMED("k_scalar_fwd", st); k_scalar_fwd<IS3D, kRK3Ours><<<grd, blk, 0, st>>>(a, s, U, flags, dst, nullptr); break; }
+    case kEuler: { TFL_TIMED("k_scalar_fwd", st); k_scalar_fwd<IS3D, kEuler><<<grd, blk, 0, st>>>(a, s, U, flags, dst, nullptr, nullptr, nullptr); break; }
+    case kEulerOurs: { TFL_TIMED("k_scalar_fwd", st); k_scalar_fwd<IS3D, kEulerOurs><<<grd, blk, 0, st>>>(a, s, U, flags, dst, nullptr, nullptr, nullptr); break; }
+    case kRK2Ours: { TFL_TIMED("k_scalar_fwd", st); k_scalar_fwd<IS3D, kRK2Ours><<<grd, blk, 0, st>>>(a, s, U, flags, dst, nullptr, nullptr, nullptr); break; }
+    case kRK3Ours: { TFL_TIMED("k_scalar_fwd", st); k_scalar_fwd<IS3D, kRK3Ours><<<grd, blk, 0, st>>>(a, s, U, flags, dst, nullptr, nullptr, nullptr); break; }
     case kMacCormack:
-      { TFL_TIMED("k_scalar_fwd", st); k_scalar_fwd<IS3D, kMacCormack><<<grd, blk, 0, st>>>(a, s, U, flags, fwd, nullptr); }
+      { TFL_TIMED("k_scalar_fwd", st); k_scalar_fwd<IS3D, kMacCormack><<<grd, blk, 0, st>>>(a, s, U, flags, fwd, nullptr, nullptr, nullptr); }
       { TFL_TIMED("k_scalar_bwd", st); k_scalar_bwd<IS3D, kMacCormack><<<grd, blk, 0, st>>>(a, s, U, flags, fwd, nullptr, dst); }
       break;
     default:
-      { TFL_TIMED("k_scalar_fwd", st); k_scalar_fwd<IS3D, kMacCormackOurs><<<grd, blk, 0, st>>>(a, s, U, flags, fwd, bounds); }
+      { TFL_TIMED("k_minmax3", st); k_minmax3<IS3D><<<grd, blk, 0, st>>>(a.d, a.outside, s, flags, mm, mm + (long long)B * a.d.sc); }
+      { TFL_TIMED("k_scalar_fwd", st); k_scalar_fwd<IS3D, kMacCormackOurs><<<grd, blk, 0, st>>>(a, s, U, flags, fwd, bounds, mm, mm + (long long)B * a.d.sc); }
       { TFL_TIMED("k_scalar_bwd", st); k_scalar_bwd<IS3D, kMacCormackOurs><<<grd, blk, 0, st>>>(a, s, U, flags, fwd, bounds, dst); }
       break;
   }
@@ -335,10 +385,10 @@ static void launch_scalar(hipStream_t st, int method, const AdvArgs& a, int B, c
 
 void advect_scalar(hipStream_t st, bool is3d, int method, int B, int Z, int Y, int X, float dt, float strength,
                    int outside, unsigned long long* err, const float* s, const float* U, const float* flags,
-                   float* fwd, float* bounds, float* dst) {
+                   float* fwd, float* bounds, float* mm, float* dst) {
   AdvArgs a; a.d = make_dom(Z, Y, X); a.dt = dt; a.strength = strength; a.outside = outside; a.err = err;
-  if (is3d) launch_scalar<true>(st, method, a, B, s, U, flags, fwd, bounds, dst);
-  else launch_scalar<false>(st, method, a, B, s, U, flags, fwd, bounds, dst);
+  if (is3d) launch_scalar<true>(st, method, a, B, s, U, flags, fwd, bounds, mm, dst);
+  else launch_scalar<false>(st, method, a, B, s, U, flags, fwd, bounds, mm, dst);
 }
 
 template <bool IS3D>

@@ -22,7 +22,8 @@
 //
 // Block = 256 threads = 4 waves; block tile = 32(x) x 8(y) x 4(z); wave w owns z-plane w, 8 rows ->
 // 8 independent accumulators (covers the 40-cycle dependent-MFMA latency at the 32-cycle issue rate).
-// LDS: 8*6*10*36*4 = 69 KB -> 2 blocks per CU, one staging while the other multiplies.
+// The input channels are staged 4 at a time: LDS 4*6*10*36*4 = 34.5 KB -> 4 blocks per CU, so while one
+// block stages or stores, the other three keep the MFMA pipes busy (r01: 2 blocks/CU left them 67% busy).
 #include "tfl_device.hpp"
 #include "tfl_host.hpp"
 
@@ -39,13 +40,21 @@ struct ConvTail {       // fused 1x1x1 layers (device pointers): h4 = relu(W4 h 
   const float* b5;      // [1]
 };
 
+struct ConvIn {         // fused network input (first layer): {pDiv/scale, div/scale, occupancy(flags)}
+  const float* pDiv;    // [B][1][Z][Y][X]
+  const float* div;
+  const float* flags;
+  const double* stats;  // [B][2] = sum u, sum u^2 (model.hip); nullptr -> read the planar `in` instead
+  double count;
+};
+
 // CIN: input channels. IN_PLANAR: input is [CIN][Z][Y][X] (first layer) else channel-last [Z][Y][X][CIN].
 // TAIL: fuse the two 1x1x1 layers and write planar pressure instead of channel-last activations.
 template <int CIN, bool IN_PLANAR, bool TAIL>
-__global__ __launch_bounds__(256, 2) void k_conv3_mfma(Dom d, int tiles_x, int tiles_y, int tiles_z, int n_tiles,
+__global__ __launch_bounds__(256, 4) void k_conv3_mfma(Dom d, int tiles_x, int tiles_y, int tiles_z, int n_tiles,
                                                        const float* __restrict__ in, const float* __restrict__ bfrag,
                                                        const float* __restrict__ bias, float* __restrict__ out,
-                                                       ConvTail tail) {
+                                                       ConvTail tail, ConvIn cin) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   // XCD-aware tile order: the dispatcher deals consecutive block ids round-robin over the 8 XCDs, so
   // give each XCD a contiguous run of tiles (neighbouring tiles share halo planes through its L2).
@@ -64,33 +73,8 @@ __global__ __launch_bounds__(256, 2) void k_conv3_mfma(Dom d, int tiles_x, int t
   const int tid = threadIdx.x;
   constexpr int kRows = (kTZ + 2) * (kTY + 2);      // 60 halo rows per channel
   constexpr int kPlane = kRows * kLX;               // floats per channel plane in LDS
-  // ---- stage the halo tile ---------------------------------------------------------------------
-  for (int idx = tid; idx < kRows * 34; idx += 256) {
-    const int xx = idx % 34, row = idx / 34;
-    const int yy = row % (kTY + 2), zz = row / (kTY + 2);
-    const int gx = x0 - 1 + xx, gy = y0 - 1 + yy, gz = z0 - 1 + zz;
-    const bool ok = gx >= 0 && gx < d.X && gy >= 0 && gy < d.Y && gz >= 0 && gz < d.Z;
-    float v[CIN];
-#pragma unroll
-    for (int c = 0; c < CIN; c++) v[c] = 0.0f;
-    if (ok) {
-      const long long o = TFL_AT(d, gx, gy, gz);
-      if (IN_PLANAR) {
-#pragma unroll
-        for (int c = 0; c < CIN; c++) v[c] = in[o + c * cells];
-      } else {
-        const float4* p4 = reinterpret_cast<const float4*>(in + o * CIN);
-#pragma unroll
-        for (int q = 0; q < CIN / 4; q++) {
-          const float4 f = p4[q];
-          v[q * 4] = f.x; v[q * 4 + 1] = f.y; v[q * 4 + 2] = f.z; v[q * 4 + 3] = f.w;
-        }
-      }
-    }
-#pragma unroll
-    for (int c = 0; c < CIN; c++) lds[c * kPlane + row * kLX + xx] = v[c];
-  }
-  // ---- B fragments + bias into registers ----------------------------------------------------------
+  constexpr int CG = CIN < 4 ? CIN : 4;             // channels staged per pass (34.5 KB -> 4 blocks per CU:
+                                                    // while one block stages, three keep the MFMA pipes busy)
   const int lane = tid & 63, wave = tid >> 6;
   float bf[CIN * 9];
 #pragma unroll
@@ -100,21 +84,63 @@ __global__ __launch_bounds__(256, 2) void k_conv3_mfma(Dom d, int tiles_x, int t
   f32x4 acc[kTY];
 #pragma unroll
   for (int r = 0; r < kTY; r++) acc[r] = (f32x4){bv, bv, bv, bv};
-  __syncthreads();
-  // ---- implicit GEMM -----------------------------------------------------------------------------
   const int lane_off = 2 * (lane & 15) + (lane >> 4);
+  float in_scale = 1.0f;
+  if (IN_PLANAR && cin.stats) {  // lib/modules/variance.lua:44-76 (n-1) + Sqrt, as model.hip scale_from_stats
+    const double s1 = cin.stats[b * 2], s2 = cin.stats[b * 2 + 1], n = cin.count;
+    in_scale = (float)sqrt((n * s2 - s1 * s1) / (n * (n - 1.0)));
+  }
+
 #pragma unroll
-  for (int c = 0; c < CIN; c++) {
+  for (int cg = 0; cg < CIN; cg += CG) {
+    if (cg > 0) __syncthreads();   // everyone is done reading the previous channel group
+    // ---- stage the halo tile of channels [cg, cg + CG) --------------------------------------------
+    for (int idx = tid; idx < kRows * 34; idx += 256) {
+      const int xx = idx % 34, row = idx / 34;
+      const int yy = row % (kTY + 2), zz = row / (kTY + 2);
+      const int gx = x0 - 1 + xx, gy = y0 - 1 + yy, gz = z0 - 1 + zz;
+      const bool ok = gx >= 0 && gx < d.X && gy >= 0 && gy < d.Y && gz >= 0 && gz < d.Z;
+      float v[CG];
 #pragma unroll
-    for (int dz = 0; dz < 3; dz++) {
+      for (int c = 0; c < CG; c++) v[c] = 0.0f;
+      if (ok) {
+        const long long o = TFL_AT(d, gx, gy, gz);
+        if (IN_PLANAR && cin.stats) {
+          // the net input is built here instead of by k_net_input: ApplyScale(true) = CDivTable
+          // (apply_scale.lua:24-30), FlagsToOccupancy (generic/tfluids.cu:355-371)
+          const long long bo = (long long)b * cells + o;
+          v[0] = cin.pDiv[bo] / in_scale;
+          v[1] = cin.div[bo] / in_scale;
+          const int f = (int)cin.flags[bo];
+          v[CG - 1] = (f == kFluid) ? 0.0f : ((f == kObstacle) ? 1.0f : -1.0f);
+        } else if (IN_PLANAR) {
 #pragma unroll
-      for (int dy = 0; dy < 3; dy++) {
-        const float bval = bf[(c * 3 + dz) * 3 + dy];
-        const float* base = lds + c * kPlane + ((wave + dz) * (kTY + 2) + dy) * kLX + lane_off;
+          for (int c = 0; c < CG; c++) v[c] = in[o + (cg + c) * cells];
+        } else {
+          const float4 f = *reinterpret_cast<const float4*>(in + o * CIN + cg);
+          v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w;
+        }
+      }
 #pragma unroll
-        for (int r = 0; r < kTY; r++) {
-          const float a = base[r * kLX];
-          acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bval, acc[r], 0, 0, 0);
+      for (int c = 0; c < CG; c++) lds[c * kPlane + row * kLX + xx] = v[c];
+    }
+    __syncthreads();
+    // ---- implicit GEMM over these channels ---------------------------------------------------------
+    // One step = one (c, dz): the 10 halo rows of LDS plane (wave + dz) feed 3 (dy) x 8 (rows) = 24 MFMAs;
+    // consecutive uses of one accumulator are 8 MFMAs apart (> the 40-cycle dependent latency).
+#pragma unroll
+    for (int cl = 0; cl < CG; cl++) {
+#pragma unroll
+      for (int dz = 0; dz < 3; dz++) {
+        const float* base = lds + cl * kPlane + ((wave + dz) * (kTY + 2)) * kLX + lane_off;
+        float a[kTY + 2];
+#pragma unroll
+        for (int q = 0; q < kTY + 2; q++) a[q] = base[q * kLX];
+#pragma unroll
+        for (int dy = 0; dy < 3; dy++) {
+          const float bval = bf[((cg + cl) * 3 + dz) * 3 + dy];
+#pragma unroll
+          for (int r = 0; r < kTY; r++) acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r + dy], bval, acc[r], 0, 0, 0);
         }
       }
     }
@@ -163,11 +189,11 @@ __global__ __launch_bounds__(256, 2) void k_conv3_mfma(Dom d, int tiles_x, int t
 
 template <int CIN, bool IN_PLANAR, bool TAIL>
 static void launch_mfma(hipStream_t st, const Dom& d, int B, const float* in, const float* bfrag, const float* bias,
-                        float* out, ConvTail tail) {
+                        float* out, ConvTail tail, ConvIn cin) {
   const int tx = (d.X + kTX - 1) / kTX, ty = (d.Y + kTY - 1) / kTY, tz = (d.Z + kTZ - 1) / kTZ;
   const int n_tiles = tx * ty * tz * B;
   const int grid = ((n_tiles + 7) / 8) * 8;
-  const size_t lds_bytes = sizeof(float) * CIN * (kTZ + 2) * (kTY + 2) * kLX;
+  const size_t lds_bytes = sizeof(float) * (CIN < 4 ? CIN : 4) * (kTZ + 2) * (kTY + 2) * kLX;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)k_conv3_mfma<CIN, IN_PLANAR, TAIL>,
@@ -175,26 +201,37 @@ static void launch_mfma(hipStream_t st, const Dom& d, int B, const float* in, co
     attr_set = true;
   }
   TFL_TIMED(TAIL ? "k_conv3_mfma_tail" : (IN_PLANAR ? "k_conv3_mfma_in" : "k_conv3_mfma"), st);
-  k_conv3_mfma<CIN, IN_PLANAR, TAIL><<<grid, 256, lds_bytes, st>>>(d, tx, ty, tz, n_tiles, in, bfrag, bias, out, tail);
+  k_conv3_mfma<CIN, IN_PLANAR, TAIL><<<grid, 256, lds_bytes, st>>>(d, tx, ty, tz, n_tiles, in, bfrag, bias, out, tail, cin);
 }
 
 // 3 -> 8 (planar in) / 8 -> 8 (channel-last in), k = 3, ReLU; channel-last [Z][Y][X][8] out.
 void conv3_mfma_first(hipStream_t st, int B, int Z, int Y, int X, const float* in_planar3, const float* bfrag,
                       const float* bias, float* out_cl8) {
   ConvTail none = {nullptr, nullptr, nullptr, nullptr};
-  launch_mfma<3, true, false>(st, make_dom(Z, Y, X), B, in_planar3, bfrag, bias, out_cl8, none);
+  ConvIn noin = {nullptr, nullptr, nullptr, nullptr, 0.0};
+  launch_mfma<3, true, false>(st, make_dom(Z, Y, X), B, in_planar3, bfrag, bias, out_cl8, none, noin);
+}
+// the same with the network input {pDiv/scale, div/scale, occupancy} built on the fly while staging
+void conv3_mfma_first_fused(hipStream_t st, int B, int Z, int Y, int X, const float* pDiv, const float* div,
+                            const float* flags, const double* stats, double count, const float* bfrag,
+                            const float* bias, float* out_cl8) {
+  ConvTail none = {nullptr, nullptr, nullptr, nullptr};
+  ConvIn ci = {pDiv, div, flags, stats, count};
+  launch_mfma<3, true, false>(st, make_dom(Z, Y, X), B, pDiv, bfrag, bias, out_cl8, none, ci);
 }
 void conv3_mfma_mid(hipStream_t st, int B, int Z, int Y, int X, const float* in_cl8, const float* bfrag,
                     const float* bias, float* out_cl8) {
   ConvTail none = {nullptr, nullptr, nullptr, nullptr};
-  launch_mfma<8, false, false>(st, make_dom(Z, Y, X), B, in_cl8, bfrag, bias, out_cl8, none);
+  ConvIn noin = {nullptr, nullptr, nullptr, nullptr, 0.0};
+  launch_mfma<8, false, false>(st, make_dom(Z, Y, X), B, in_cl8, bfrag, bias, out_cl8, none, noin);
 }
 // 8 -> 8 k3 + ReLU, then 8 -> 8 k1 + ReLU, then 8 -> 1 k1; planar pressure out.
 void conv3_mfma_tail(hipStream_t st, int B, int Z, int Y, int X, const float* in_cl8, const float* bfrag,
                      const float* bias, const float* w4, const float* b4, const float* w5, const float* b5,
                      float* p_out) {
   ConvTail tail = {w4, b4, w5, b5};
-  launch_mfma<8, false, true>(st, make_dom(Z, Y, X), B, in_cl8, bfrag, bias, p_out, tail);
+  ConvIn noin = {nullptr, nullptr, nullptr, nullptr, 0.0};
+  launch_mfma<8, false, true>(st, make_dom(Z, Y, X), B, in_cl8, bfrag, bias, p_out, tail, noin);
 }
 
 }  // namespace tfl

@@ -204,6 +204,17 @@ __global__ __launch_bounds__(256) void k_apply_bcs(long long n, float* __restric
   }
 }
 
+// The same on an index list: BC tensors are dense in the reference API but almost everywhere the
+// identity (invMask = 1, bc = 0: the plume touches 4 of 128 y-rows); the host caches the indices where
+// they are not and only those elements are touched. Skipped elements satisfy x*1+0 == x.
+__global__ __launch_bounds__(256) void k_apply_bcs_indexed(long long n, const int* __restrict__ idx, float* __restrict__ x,
+                                                           const float* __restrict__ bcv, const float* __restrict__ inv) {
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) {
+    const int e = idx[t];
+    x[e] = x[e] * inv[e] + bcv[e];
+  }
+}
+
 #define TFL_GRID3(d, B) dim3(((d).X + 63) / 64, ((d).Y + 3) / 4, (unsigned)((d).Z * (B)))
 
 long long model_stat_blocks(int B, int Z, int Y, int X) {
@@ -243,6 +254,13 @@ void apply_bcs(hipStream_t st, long long n, float* x, const float* bcv, const fl
   long long blocks = (n + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   { TFL_TIMED("k_apply_bcs", st); k_apply_bcs<<<(int)(blocks > 0 ? blocks : 1), 256, 0, st>>>(n, x, bcv, inv, do_clamp, lo, hi); }
+}
+
+void apply_bcs_indexed(hipStream_t st, long long n, const int* idx, float* x, const float* bcv, const float* inv) {
+  if (n <= 0) return;
+  long long blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  { TFL_TIMED("k_apply_bcs_indexed", st); k_apply_bcs_indexed<<<(int)blocks, 256, 0, st>>>(n, idx, x, bcv, inv); }
 }
 
 }  // namespace tfl

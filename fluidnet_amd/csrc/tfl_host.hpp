@@ -18,7 +18,7 @@ struct KernelTimer {
 // advect.hip
 void advect_scalar(hipStream_t st, bool is3d, int method, int B, int Z, int Y, int X, float dt, float strength,
                    int outside, unsigned long long* err, const float* s, const float* U, const float* flags,
-                   float* fwd, float* bounds, float* dst);
+                   float* fwd, float* bounds, float* mm, float* dst);
 void advect_vel(hipStream_t st, bool is3d, int method, int B, int Z, int Y, int X, float dt, float strength,
                 unsigned long long* err, const float* U, const float* flags, float* fwd, float* dst);
 
@@ -55,6 +55,8 @@ void model_project(hipStream_t st, bool is3d, int B, int Z, int Y, int X, const 
 void apply_bcs(hipStream_t st, long long n, float* x, const float* bcv, const float* inv, int do_clamp, float lo,
                float hi);
 
+void apply_bcs_indexed(hipStream_t st, long long n, const int* idx, float* x, const float* bcv, const float* inv);
+
 // conv.hip
 bool conv_direct(hipStream_t st, bool is3d, int B, int Z, int Y, int X, int cin, int cout, int ksz, bool relu,
                  const float* in, const float* w, const float* bias, float* out);
@@ -62,6 +64,9 @@ bool conv_direct(hipStream_t st, bool is3d, int B, int Z, int Y, int X, int cin,
 // conv_mfma.hip (3-D default topology: k=3, 8 output channels; x-phase-packed fp32 MFMA)
 void conv3_mfma_first(hipStream_t st, int B, int Z, int Y, int X, const float* in_planar3, const float* bfrag,
                       const float* bias, float* out_cl8);
+void conv3_mfma_first_fused(hipStream_t st, int B, int Z, int Y, int X, const float* pDiv, const float* div,
+                            const float* flags, const double* stats, double count, const float* bfrag,
+                            const float* bias, float* out_cl8);
 void conv3_mfma_mid(hipStream_t st, int B, int Z, int Y, int X, const float* in_cl8, const float* bfrag,
                     const float* bias, float* out_cl8);
 void conv3_mfma_tail(hipStream_t st, int B, int Z, int Y, int X, const float* in_cl8, const float* bfrag,

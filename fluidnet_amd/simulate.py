@@ -6,6 +6,7 @@ with the reference's model-config names (dt, advectionMethod, maccormackStrength
 gravityScale, vorticityConfinementAmp, simMethod, maxIter, gravity). State is updated in place in the
 *Div slots exactly like the Lua (simulate.lua:180).
 """
+import ctypes
 import math
 
 import torch
@@ -61,8 +62,31 @@ def createPlumeBCs(batch, densityVal, uScale, rad, zOffset=0, zTotal=None):
     batch["densityBCInvMask"] = dmask if multi else dmask[0]
 
 
+_bc_index_cache = {}   # (bc ptr, mask ptr) -> (bc version, mask version, int32 index tensor)
+
+
+def _bc_indices(bc, inv):
+    """Indices where the BC pair is not the identity (invMask != 1 or bc != 0), cached per tensor pair
+    and invalidated by torch's in-place version counters (the 2-D demo edits its BCs interactively)."""
+    key = (bc.data_ptr(), inv.data_ptr(), bc.numel())
+    hit = _bc_index_cache.get(key)
+    if hit is not None and hit[0] == bc._version and hit[1] == inv._version:
+        return hit[2]
+    idx = torch.nonzero((inv.reshape(-1) != 1) | (bc.reshape(-1) != 0)).reshape(-1).to(torch.int32)
+    if len(_bc_index_cache) > 64:
+        _bc_index_cache.clear()
+    _bc_index_cache[key] = (bc._version, inv._version, idx)
+    return idx
+
+
 def _apply(x, bc, inv, clamp=None):
     lib, ctx = tfluids._context(x)
+    if bc is not None and inv is not None and clamp is None and x.numel() < 2 ** 31:
+        idx = _bc_indices(bc, inv)
+        if idx.numel() * 4 < x.numel():     # sparse enough: touch only the BC cells
+            tfluids._call(lib, ctx, lib.tfl_applyBCsIndexed(ctx, tfluids._tt5(x), tfluids._tt5(bc), tfluids._tt5(inv),
+                                                            ctypes.c_void_p(idx.data_ptr()), idx.numel()))
+            return
     lo, hi = clamp if clamp is not None else (0.0, 0.0)
     tfluids._call(lib, ctx, lib.tfl_applyBCs(ctx, tfluids._tt5(x), tfluids._tt5(bc) if bc is not None else None,
                                              tfluids._tt5(inv) if inv is not None else None,

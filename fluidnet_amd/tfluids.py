@@ -109,20 +109,23 @@ def advectScalar(dt, s, U, flags, method=None, sDst=None, sampleOutsideFluid=Non
     _check(s.is_contiguous(), "Input is not contiguous")
     C = U.size(1)
     sizes = [(bsz, 1, d, h, w), (bsz, 1, d, h, w), (bsz, C, d, h, w), (bsz, C, d, h, w)]
-    if sDst is None:
+    # maccormackOurs' second pass reads s only at the cell it writes: the library accepts sDst == s,
+    # which makes init.lua:146-148's copy-back unnecessary for the default method.
+    inplace = sDst is None and method == "maccormackOurs"
+    if sDst is None and not inplace:
         sizes.append((bsz, 1, d, h, w))
-    else:
+    elif sDst is not None:
         _check(sDst.dim() == 5 and sDst.shape == s.shape, "Size mismatch")
         _check(sDst.is_contiguous(), "Input is not contiguous")
     tmp = getTempStorage(s, sizes)
     fwd, bwd, fwdPos, bwdPos = tmp[:4]
-    out = sDst if sDst is not None else tmp[4]
+    out = sDst if sDst is not None else (s if inplace else tmp[4])
     lib, ctx = _context(s)
     _call(lib, ctx, lib.tfl_advectScalar(ctx, dt, _tt(s), _tt(U), _tt(flags), _tt(fwd), _tt(bwd),
                                          int(is3D), method.encode(), _tt(fwdPos), _tt(bwdPos),
                                          int(boundaryWidth), int(sampleOutsideFluid),
                                          maccormackStrength, _tt(out)))
-    if sDst is None:
+    if sDst is None and not inplace:
         s.copy_(out)
 
 

@@ -196,6 +196,13 @@ int tfl_set_dx_override(tfl_ctx* ctx, float dx);
 int tfl_applyBCs(tfl_ctx* ctx, const tfl_tensor* x, const tfl_tensor* bc, const tfl_tensor* invMask,
                  int doClamp, float lo, float hi);
 
+/* tfl_applyBCs restricted to the element indices idx[0..n) (device int32, indices into the flattened
+ * tensors): x[e] = x[e]*invMask[e] + bc[e]. For BC tensors that are the identity (invMask 1, bc 0)
+ * almost everywhere -- the plume BCs touch 4 y-rows -- the host caches the non-identity indices once and
+ * every setConstVals becomes O(|BC cells|) instead of three dense sweeps per field. */
+int tfl_applyBCsIndexed(tfl_ctx* ctx, const tfl_tensor* x, const tfl_tensor* bc, const tfl_tensor* invMask,
+                        const int32_t* idx, int64_t n);
+
 #ifdef __cplusplus
 }
 #endif
