@@ -22,6 +22,16 @@ void advect_scalar(hipStream_t st, bool is3d, int method, int B, int Z, int Y, i
 void advect_vel(hipStream_t st, bool is3d, int method, int B, int Z, int Y, int X, float dt, float strength,
                 unsigned long long* err, const float* U, const float* flags, float* fwd, float* dst);
 
+// advect_lds.hip: LDS-tiled maccormackOurs (the default method); bit-identical to advect.hip's kernels
+void advect_vel_ours_lds(hipStream_t st, bool is3d, int B, int Z, int Y, int X, float dt, float strength,
+                         unsigned long long* err, const float* U, const float* flags, float* fwd, float* dst);
+void advect_scalar_ours_lds(hipStream_t st, bool is3d, int B, int Z, int Y, int X, float dt, float strength,
+                            int outside, unsigned long long* err, const float* s, const float* U, const float* flags,
+                            float* fwd, float* bounds, const float* lo3, const float* hi3, float* dst);
+void minmax3(hipStream_t st, bool is3d, int B, int Z, int Y, int X, int outside, const float* s, const float* flags,
+             float* lo3, float* hi3);
+bool advect_use_lds();  // TFL_ADVECT_PATH=lds selects the LDS-tiled kernels (default: plain gathers, faster in r01)
+
 // stencil.hip
 void set_wall_bcs(hipStream_t st, bool is3d, int B, int Z, int Y, int X, float* U, const float* flags);
 void velocity_divergence(hipStream_t st, bool is3d, int B, int Z, int Y, int X, const float* U, const float* flags,

@@ -121,3 +121,35 @@ def test_hip_argument_errors(hip):
     with pytest.raises(TfluidsError):
         tfluids.advectVel(0.1, torch.zeros(1, 2, 1, 8, 8), torch.ones(1, 1, 1, 8, 8))  # CPU tensors
     del U3
+
+
+def test_lds_tiled_advection_is_bit_identical(oracle):
+    """advect_lds.hip (opt-in, TFL_ADVECT_PATH=lds) must reproduce the default kernels bit for bit,
+    including traces that leave the LDS tile (large displacements) and ragged grids. Runs in a child
+    process because the path is latched from the environment on first use."""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import sys, numpy as np
+        sys.path.insert(0, %r); sys.path.insert(0, %r)
+        import scenes
+        from hip_adapter import HipTfluids
+        from oracle.oracle import OracleTfluids
+        hip, ora = HipTfluids(), OracleTfluids()
+        for dims, seed, kw in [((1, 70, 130), 61, dict(vel_cells=3.0)), ((20, 36, 68), 62, dict(vel_cells=4.0, B=2)),
+                               ((33, 17, 40), 63, dict(vel_cells=0.8))]:
+            sc = scenes.make_scene(dims, seed=seed, **kw)
+            for op, fld in (("advectScalar", "density"), ("advectVel", "U")):
+                a, b = sc[fld].copy(), sc[fld].copy()
+                if op == "advectScalar":
+                    hip.advectScalar(sc["dt"], a, sc["U"], sc["flags"], "maccormackOurs")
+                    ora.advectScalar(sc["dt"], b, sc["U"], sc["flags"], "maccormackOurs")
+                else:
+                    hip.advectVel(sc["dt"], a, sc["flags"], "maccormackOurs")
+                    ora.advectVel(sc["dt"], b, sc["flags"], "maccormackOurs")
+                assert np.array_equal(a, b), (dims, op, int((a != b).sum()))
+        assert hip.traceErrors() == 0
+        print("LDS_OK")
+    """) % (os.path.dirname(HERE), HERE)
+    env = dict(os.environ, TFL_ADVECT_PATH="lds")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "LDS_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
