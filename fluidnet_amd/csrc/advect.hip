@@ -102,10 +102,14 @@ __device__ __forceinline__ void minmax(float& lo, float& hi, float v) {
   if (v > hi) hi = v;
 }
 
-// doClampComponent[MAC], tfluids.cc:250-295 and :701-746. g = channel plane of `orig`.
+// doClampComponent[MAC], tfluids.cc:250-295 and :701-746, split in two so that the 2 x 2^dim corner loads
+// (whose addresses depend only on the cell and its MAC velocity) can be issued BEFORE the back-trace and
+// overlap its latency: manta_clamp_bounds gathers min/max (false <=> the reference returns `fwd`),
+// manta_clamp_component applies them. g = channel plane of `orig`.
 template <bool IS3D>
-__device__ float manta_clamp_component(const Dom& d, float dst, const float* __restrict__ g, float fwd, v3 pos, v3 vel) {
-  float lo = 3.402823466e+38f, hi = -3.402823466e+38f;
+__device__ __forceinline__ bool manta_clamp_bounds(const Dom& d, const float* __restrict__ g, v3 pos, v3 vel, float& lo,
+                                                   float& hi) {
+  lo = 3.402823466e+38f; hi = -3.402823466e+38f;
 #pragma unroll
   for (int l = 0; l < 2; l++) {
     int px, py, pz;
@@ -116,9 +120,9 @@ __device__ float manta_clamp_component(const Dom& d, float dst, const float* __r
     const int k0 = iclampi(pz, 0, IS3D ? (d.Z - 2) : 1);
     const int i1 = i0 + 1, j1 = j0 + 1, k1 = IS3D ? k0 + 1 : k0;
     // isInBounds(p, 0), grid.cc:42-52: in 2-D z must be exactly 0
-    if (IS3D) { if (k0 < 0 || k1 >= d.Z) return fwd; }
-    else if (k0 != 0 || k1 != 0) return fwd;
-    if (i0 < 0 || j0 < 0 || i1 >= d.X || j1 >= d.Y) return fwd;
+    if (IS3D) { if (k0 < 0 || k1 >= d.Z) return false; }
+    else if (k0 != 0 || k1 != 0) return false;
+    if (i0 < 0 || j0 < 0 || i1 >= d.X || j1 >= d.Y) return false;
     const int a = TFL_AT(d, i0, j0, k0);
     minmax(lo, hi, g[a]);
     minmax(lo, hi, g[a + 1]);
@@ -132,7 +136,13 @@ __device__ float manta_clamp_component(const Dom& d, float dst, const float* __r
       minmax(lo, hi, g[c + 1 + d.sy]);
     }
   }
-  return fclampf(dst, lo, hi);
+  return true;
+}
+template <bool IS3D>
+__device__ __forceinline__ float manta_clamp_component(const Dom& d, float dst, const float* __restrict__ g, float fwd,
+                                                       v3 pos, v3 vel) {
+  float lo, hi;
+  return manta_clamp_bounds<IS3D>(d, g, pos, vel, lo, hi) ? fclampf(dst, lo, hi) : fwd;
 }
 
 // Manta MacCormackClamp (scalar), tfluids.cc:297-327
@@ -289,18 +299,23 @@ __global__ __launch_bounds__(256) void k_scalar_bwd(AdvArgs a, const float* __re
 }
 
 // ---- advectVel ---------------------------------------------------------------------------------
-// SemiLagrange[EulerOurs]MAC of one face component, tfluids.cc:594-658
+// SemiLagrange[EulerOurs]MAC of one face component, tfluids.cc:594-658, given the MAC-averaged velocity
+// u of that face. disp = u * (-dt) for the trace, p = centre - u*dt for Manta's variant.
 template <bool IS3D, bool OURS, int AXIS>
-__device__ __forceinline__ float sl_mac_comp(const AdvArgs& a, const float* flags, const float* U, const float* src,
-                                             float dt, int i, int j, int k) {
+__device__ __forceinline__ float sl_mac_from_u(const AdvArgs& a, const float* flags, const float* src, v3 u, float dt,
+                                               int i, int j, int k) {
   const v3 ctr = cell_centre(i, j, k);
-  const v3 u = get_at_mac<IS3D, AXIS>(a.d, U, i, j, k);
   v3 p;
   if (OURS) count_trace_error(line_trace(a.d, flags, ctr, scale3(u, -dt), p), a.err);
   else p = mk3(ctr.x - u.x * dt, ctr.y - u.y * dt, ctr.z - u.z * dt);
   return interpol<IS3D>(a.d, src + AXIS * a.d.sc, p);
 }
 
+// Kernel structure (both passes): FIRST every load whose address does not depend on a back-trace -- the
+// three MAC-averaged face velocities (18 distinct taps), the cell's own words and, in pass B, the 2 x 2^dim
+// clamp corners of all three components -- issued as one batch, THEN the three data-dependent chains
+// trace -> 8-tap sample. hipcc does not hoist loads across the trace loops on its own; in source order
+// "component x completely, then y, then z" the kernel spent 68% of its wave cycles in s_waitcnt (r01 PMC).
 template <bool IS3D, bool OURS>
 __global__ __launch_bounds__(256) void k_vel_fwd(AdvArgs a, const float* __restrict__ U, const float* __restrict__ flags,
                                                  float* __restrict__ out) {
@@ -313,32 +328,15 @@ __global__ __launch_bounds__(256) void k_vel_fwd(AdvArgs a, const float* __restr
     if (OURS && !fluid_at(d, flags, i, j, k)) {  // tfluids.cc:598-601
       vx = U[o]; vy = U[o + d.sc]; if (IS3D) vz = U[o + 2 * d.sc];
     } else {
-      vx = sl_mac_comp<IS3D, OURS, 0>(a, flags, U, U, a.dt, i, j, k);
-      vy = sl_mac_comp<IS3D, OURS, 1>(a, flags, U, U, a.dt, i, j, k);
-      if (IS3D) vz = sl_mac_comp<IS3D, OURS, 2>(a, flags, U, U, a.dt, i, j, k);
+      const v3 u0 = get_at_mac<IS3D, 0>(d, U, i, j, k);
+      const v3 u1 = get_at_mac<IS3D, 1>(d, U, i, j, k);
+      const v3 u2 = IS3D ? get_at_mac<IS3D, 2>(d, U, i, j, k) : mk3(0.0f, 0.0f, 0.0f);
+      vx = sl_mac_from_u<IS3D, OURS, 0>(a, flags, U, u0, a.dt, i, j, k);
+      vy = sl_mac_from_u<IS3D, OURS, 1>(a, flags, U, u1, a.dt, i, j, k);
+      if (IS3D) vz = sl_mac_from_u<IS3D, OURS, 2>(a, flags, U, u2, a.dt, i, j, k);
     }
   }
   out[o] = vx; out[o + d.sc] = vy; if (IS3D) out[o + 2 * d.sc] = vz;
-}
-
-template <bool IS3D, bool OURS, int AXIS>
-__device__ __forceinline__ float vel_bwd_comp(const AdvArgs& a, const float* flags, const float* U, const float* fwd,
-                                              bool border, bool fl, bool skip, int i, int j, int k, int o) {
-  const Dom& d = a.d;
-  const float f = fwd[o + AXIS * d.sc];
-  float bwd = 0.0f;
-  if (!border) {
-    if (OURS && !fl) bwd = f;
-    else bwd = sl_mac_comp<IS3D, OURS, AXIS>(a, flags, U, fwd, -a.dt, i, j, k);
-  }
-  float v = f;
-  // MacCormackCorrectMAC, tfluids.cc:660-699 (double arithmetic through the unsuffixed 0.5, :693)
-  if (!skip) v = (float)((double)f + (double)a.strength * 0.5 * (double)(U[o + AXIS * d.sc] - bwd));
-  if (!border) {  // MacCormackClampMAC, tfluids.cc:748-774
-    const v3 ud = scale3(get_at_mac<IS3D, AXIS>(d, U, i, j, k), a.dt);
-    v = manta_clamp_component<IS3D>(d, v, U + AXIS * d.sc, f, mk3((float)i, (float)j, (float)k), ud);
-  }
-  return v;
 }
 
 template <bool IS3D, bool OURS>
@@ -350,13 +348,39 @@ __global__ __launch_bounds__(256) void k_vel_bwd(AdvArgs a, const float* __restr
   const int o = TFL_AT(d, i, j, k);
   const bool border = on_border<IS3D>(d, i, j, k);
   const bool fl = fluid_at(d, flags, i, j, k);
-  const bool sx = !fl || (i > 0 && !fluid_at(d, flags, i - 1, j, k));
-  const bool sy = !fl || (j > 0 && !fluid_at(d, flags, i, j - 1, k));
-  dst[o] = vel_bwd_comp<IS3D, OURS, 0>(a, flags, U, fwd, border, fl, sx, i, j, k, o);
-  dst[o + d.sc] = vel_bwd_comp<IS3D, OURS, 1>(a, flags, U, fwd, border, fl, sy, i, j, k, o);
-  if (IS3D) {
-    const bool sz = !fl || (k > 0 && !fluid_at(d, flags, i, j, k - 1));
-    dst[o + 2 * d.sc] = vel_bwd_comp<IS3D, OURS, 2>(a, flags, U, fwd, border, fl, sz, i, j, k, o);
+  bool skip[3];
+  skip[0] = !fl || (i > 0 && !fluid_at(d, flags, i - 1, j, k));
+  skip[1] = !fl || (j > 0 && !fluid_at(d, flags, i, j - 1, k));
+  skip[2] = IS3D ? (!fl || (k > 0 && !fluid_at(d, flags, i, j, k - 1))) : true;
+  float f[3], uo[3], lo[3], hi[3], bwd[3] = {0.0f, 0.0f, 0.0f};
+  bool ok[3] = {false, false, false};
+  v3 u[3];
+#pragma unroll
+  for (int c = 0; c < C; c++) { f[c] = fwd[o + c * d.sc]; uo[c] = U[o + c * d.sc]; }
+  if (!border) {
+    u[0] = get_at_mac<IS3D, 0>(d, U, i, j, k);
+    u[1] = get_at_mac<IS3D, 1>(d, U, i, j, k);
+    u[2] = IS3D ? get_at_mac<IS3D, 2>(d, U, i, j, k) : mk3(0.0f, 0.0f, 0.0f);
+    const v3 ijk = mk3((float)i, (float)j, (float)k);
+    // MacCormackClampMAC bounds, tfluids.cc:748-774
+#pragma unroll
+    for (int c = 0; c < C; c++) ok[c] = manta_clamp_bounds<IS3D>(d, U + c * d.sc, ijk, scale3(u[c], a.dt), lo[c], hi[c]);
+    if (OURS && !fl) {
+#pragma unroll
+      for (int c = 0; c < C; c++) bwd[c] = f[c];
+    } else {
+      bwd[0] = sl_mac_from_u<IS3D, OURS, 0>(a, flags, fwd, u[0], -a.dt, i, j, k);
+      bwd[1] = sl_mac_from_u<IS3D, OURS, 1>(a, flags, fwd, u[1], -a.dt, i, j, k);
+      if (IS3D) bwd[2] = sl_mac_from_u<IS3D, OURS, 2>(a, flags, fwd, u[2], -a.dt, i, j, k);
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < C; c++) {
+    float v = f[c];
+    // MacCormackCorrectMAC, tfluids.cc:660-699 (double arithmetic through the unsuffixed 0.5, :693)
+    if (!skip[c]) v = (float)((double)f[c] + (double)a.strength * 0.5 * (double)(uo[c] - bwd[c]));
+    if (!border) v = ok[c] ? fclampf(v, lo[c], hi[c]) : f[c];
+    dst[o + c * d.sc] = v;
   }
 }
 
