@@ -23,6 +23,10 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# cpu_baseline mixes two OpenMP runtimes (libgomp in oracle/_ref, torch's for conv3d); with spinning
+# workers they starve each other on a many-core host. Passive waits give the CPU baseline its best time.
+os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
+os.environ.setdefault("GOMP_SPINCOUNT", "0")
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402

@@ -13,19 +13,23 @@
 
 namespace tfl {
 
-template <bool IS3D, int COUT, bool RELU>
+// CPT = output channels per thread: COUT for large grids (each activation is loaded once), COUT/4 for small
+// ones where the grid would otherwise leave most CUs idle (2-D 128^2 = 64 blocks of 256 threads).
+template <bool IS3D, int COUT, int CPT, bool RELU>
 __global__ __launch_bounds__(256) void k_conv_direct(Dom d, int cin, int ksz, const float* __restrict__ in,
                                                      const float* __restrict__ w, const float* __restrict__ bias,
                                                      float* __restrict__ out) {
+  constexpr int G = COUT / CPT;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int j = blockIdx.y * blockDim.y + threadIdx.y;
-  const int b = blockIdx.z / d.Z, k = blockIdx.z - b * d.Z;
+  const int zg = blockIdx.z / G, co0 = (blockIdx.z - zg * G) * CPT;
+  const int b = zg / d.Z, k = zg - b * d.Z;
   if (i >= d.X || j >= d.Y) return;
   const long long cells = d.sc;
   in += b * cells * cin; out += b * cells * COUT;
-  float acc[COUT];
+  float acc[CPT];
 #pragma unroll
-  for (int c = 0; c < COUT; c++) acc[c] = bias[c];
+  for (int c = 0; c < CPT; c++) acc[c] = bias[co0 + c];
   const int r = (ksz - 1) / 2;
   const int rz = IS3D ? r : 0;
   int tap = 0;
@@ -36,25 +40,48 @@ __global__ __launch_bounds__(256) void k_conv_direct(Dom d, int cin, int ksz, co
         const bool ok = x >= 0 && x < d.X && y >= 0 && y < d.Y && z >= 0 && z < d.Z;
         const int o = ok ? TFL_AT(d, x, y, z) : 0;
         const float* wt = w + (long long)tap * cin * COUT;
-        for (int c = 0; c < cin; c++) {
+        // 8 independent activation loads in flight per batch (a one-load-one-fma loop is a chain of
+        // L1 latencies: 144 taps x ~200 cycles made the 2-D 16-channel layers 27 us at 128^2)
+        int c = 0;
+        for (; c + 8 <= cin; c += 8) {
+          float v[8];
+#pragma unroll
+          for (int q = 0; q < 8; q++) v[q] = ok ? in[o + (c + q) * d.sc] : 0.0f;
+#pragma unroll
+          for (int q = 0; q < 8; q++)
+#pragma unroll
+            for (int co = 0; co < CPT; co++) acc[co] = fmaf(v[q], wt[(c + q) * COUT + co0 + co], acc[co]);
+        }
+        for (; c < cin; c++) {
           const float v = ok ? in[o + c * d.sc] : 0.0f;
 #pragma unroll
-          for (int co = 0; co < COUT; co++) acc[co] = fmaf(v, wt[c * COUT + co], acc[co]);
+          for (int co = 0; co < CPT; co++) acc[co] = fmaf(v, wt[c * COUT + co0 + co], acc[co]);
         }
       }
     }
   }
   const int o = TFL_AT(d, i, j, k);
 #pragma unroll
-  for (int c = 0; c < COUT; c++) out[o + c * d.sc] = RELU ? fmaxf(acc[c], 0.0f) : acc[c];
+  for (int c = 0; c < CPT; c++) out[o + (co0 + c) * d.sc] = RELU ? fmaxf(acc[c], 0.0f) : acc[c];
 }
 
 template <bool IS3D, int COUT>
 static void launch_direct(hipStream_t st, const Dom& d, int B, int cin, int ksz, bool relu, const float* in,
                           const float* w, const float* bias, float* out) {
-  const dim3 blk(64, 4, 1), grd((d.X + 63) / 64, (d.Y + 3) / 4, (unsigned)(d.Z * B));
-  if (relu) { TFL_TIMED("k_conv_direct", st); k_conv_direct<IS3D, COUT, true><<<grd, blk, 0, st>>>(d, cin, ksz, in, w, bias, out); }
-  else { TFL_TIMED("k_conv_direct", st); k_conv_direct<IS3D, COUT, false><<<grd, blk, 0, st>>>(d, cin, ksz, in, w, bias, out); }
+  const dim3 blk(64, 4, 1);
+  const unsigned nxy = ((d.X + 63) / 64) * ((d.Y + 3) / 4);
+  constexpr int CPT_SMALL = COUT >= 4 ? COUT / 4 : COUT;
+  const bool split = COUT >= 4 && (long long)nxy * d.Z * B < 1024;   // fewer than ~4 blocks per CU: split channels
+  TFL_TIMED("k_conv_direct", st);
+  if (split) {
+    const dim3 grd((d.X + 63) / 64, (d.Y + 3) / 4, (unsigned)(d.Z * B * (COUT / CPT_SMALL)));
+    if (relu) k_conv_direct<IS3D, COUT, CPT_SMALL, true><<<grd, blk, 0, st>>>(d, cin, ksz, in, w, bias, out);
+    else k_conv_direct<IS3D, COUT, CPT_SMALL, false><<<grd, blk, 0, st>>>(d, cin, ksz, in, w, bias, out);
+  } else {
+    const dim3 grd((d.X + 63) / 64, (d.Y + 3) / 4, (unsigned)(d.Z * B));
+    if (relu) k_conv_direct<IS3D, COUT, COUT, true><<<grd, blk, 0, st>>>(d, cin, ksz, in, w, bias, out);
+    else k_conv_direct<IS3D, COUT, COUT, false><<<grd, blk, 0, st>>>(d, cin, ksz, in, w, bias, out);
+  }
 }
 
 // w: device, [tap][cin][cout]. Returns false when cout has no instantiation.

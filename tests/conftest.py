@@ -1,6 +1,13 @@
 import os
 import sys
 
+# The checkers use two OpenMP runtimes in one process (libgomp in oracle/*.so, torch's own for the CPU
+# convolutions). On a many-core host their spinning worker pools fight each other (a 10 s suite took 110 s
+# on the 256-core GPU box); passive waiting keeps the test suite fast. Set before either is loaded.
+os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
+os.environ.setdefault("GOMP_SPINCOUNT", "0")
+os.environ.setdefault("KMP_BLOCKTIME", "0")
+
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
