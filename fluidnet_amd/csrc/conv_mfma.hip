@@ -27,6 +27,9 @@
 #include "tfl_device.hpp"
 #include "tfl_host.hpp"
 
+#include <cstdio>
+#include <cstdlib>
+
 namespace tfl {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -54,7 +57,9 @@ template <int CIN, bool IN_PLANAR, bool TAIL>
 __global__ __launch_bounds__(256, 4) void k_conv3_mfma(Dom d, int tiles_x, int tiles_y, int tiles_z, int n_tiles,
                                                        const float* __restrict__ in, const float* __restrict__ bfrag,
                                                        const float* __restrict__ bias, float* __restrict__ out,
-                                                       ConvTail tail, ConvIn cin) {
+                                                       ConvTail tail, ConvIn cin, int dbg) {
+  // dbg (env TFL_CONV_DEBUG, timing experiments only -- results are garbage): bit 0 skips the MFMA loop,
+  // bit 1 skips the staging loads. Block-uniform branches, free when 0.
   extern __shared__ __attribute__((aligned(16))) float lds[];
   // XCD-aware tile order: the dispatcher deals consecutive block ids round-robin over the 8 XCDs, so
   // give each XCD a contiguous run of tiles (neighbouring tiles share halo planes through its L2).
@@ -95,7 +100,7 @@ __global__ __launch_bounds__(256, 4) void k_conv3_mfma(Dom d, int tiles_x, int t
   for (int cg = 0; cg < CIN; cg += CG) {
     if (cg > 0) __syncthreads();   // everyone is done reading the previous channel group
     // ---- stage the halo tile of channels [cg, cg + CG) --------------------------------------------
-    for (int idx = tid; idx < kRows * 34; idx += 256) {
+    for (int idx = tid; idx < ((dbg & 2) ? 0 : kRows * 34); idx += 256) {
       const int xx = idx % 34, row = idx / 34;
       const int yy = row % (kTY + 2), zz = row / (kTY + 2);
       const int gx = x0 - 1 + xx, gy = y0 - 1 + yy, gz = z0 - 1 + zz;
@@ -128,6 +133,7 @@ __global__ __launch_bounds__(256, 4) void k_conv3_mfma(Dom d, int tiles_x, int t
     // ---- implicit GEMM over these channels ---------------------------------------------------------
     // One step = one (c, dz): the 10 halo rows of LDS plane (wave + dz) feed 3 (dy) x 8 (rows) = 24 MFMAs;
     // consecutive uses of one accumulator are 8 MFMAs apart (> the 40-cycle dependent latency).
+    if (!(dbg & 1))
 #pragma unroll
     for (int cl = 0; cl < CG; cl++) {
 #pragma unroll
@@ -199,9 +205,17 @@ static void launch_mfma(hipStream_t st, const Dom& d, int B, const float* in, co
     (void)hipFuncSetAttribute((const void*)k_conv3_mfma<CIN, IN_PLANAR, TAIL>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     attr_set = true;
+    if (getenv("TFL_DEBUG")) {
+      int nb = -1;
+      (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)k_conv3_mfma<CIN, IN_PLANAR, TAIL>, 256,
+                                                         lds_bytes);
+      fprintf(stderr, "[tfl] k_conv3_mfma<%d,%d,%d>: dynamic LDS %zu B, occupancy %d blocks/CU, grid %d\n", CIN,
+              (int)IN_PLANAR, (int)TAIL, lds_bytes, nb, grid);
+    }
   }
   TFL_TIMED(TAIL ? "k_conv3_mfma_tail" : (IN_PLANAR ? "k_conv3_mfma_in" : "k_conv3_mfma"), st);
-  k_conv3_mfma<CIN, IN_PLANAR, TAIL><<<grid, 256, lds_bytes, st>>>(d, tx, ty, tz, n_tiles, in, bfrag, bias, out, tail, cin);
+  static const int dbg = getenv("TFL_CONV_DEBUG") ? atoi(getenv("TFL_CONV_DEBUG")) : 0;
+  k_conv3_mfma<CIN, IN_PLANAR, TAIL><<<grid, 256, lds_bytes, st>>>(d, tx, ty, tz, n_tiles, in, bfrag, bias, out, tail, cin, dbg);
 }
 
 // 3 -> 8 (planar in) / 8 -> 8 (channel-last in), k = 3, ReLU; channel-last [Z][Y][X][8] out.
