@@ -31,6 +31,9 @@ struct tfl_model {
   float* bfrag[3] = {nullptr, nullptr, nullptr};  // per-lane B fragments of the three k=3 layers
   float* tail_w4 = nullptr;                       // [8][8] (out, in) of the 8->8 k1 layer
   float* tail_w5 = nullptr;                       // [8] of the 8->1 k1 layer
+  // 2-D `default` topology (3->16, 16->16 x3 k3, 16->1 k1): MFMA path (conv2d_mfma.hip)
+  bool mfma2d = false;
+  float* bfrag2[4] = {nullptr, nullptr, nullptr, nullptr};
   double* d_stats = nullptr;  // [2 * kMaxBatch]: sum(u), sum(u^2) per sample
 };
 
@@ -486,6 +489,29 @@ tfl_model* tfl_model_create(tfl_ctx* c, int is3D, int nlayers, const int32_t* ci
       return cleanup("uploading tail weights failed");
     m->mfma3d = true;
   }
+  const int dflt2[5][3] = {{3, 16, 3}, {16, 16, 3}, {16, 16, 3}, {16, 16, 3}, {16, 1, 1}};
+  bool match2 = !m->is3d && nlayers == 5;
+  for (int l = 0; match2 && l < 5; l++) match2 = cin[l] == dflt2[l][0] && cout[l] == dflt2[l][1] && ksize[l] == dflt2[l][2];
+  if (match2 && want_mfma) {
+    for (int l = 0; l < 4; l++) {
+      const int ci_n = cin[l], c4n = (ci_n + 3) / 4;
+      // B[k][n] of MFMA (tap, c4): lane = k*16 + n holds w[n][4*c4 + k][dy][dx] (0 for padded channels)
+      std::vector<float> frag((size_t)9 * c4n * 64);
+      for (int tap = 0; tap < 9; tap++)
+        for (int c4 = 0; c4 < c4n; c4++)
+          for (int lane = 0; lane < 64; lane++) {
+            const int k = lane >> 4, n = lane & 15, c = 4 * c4 + k;
+            frag[((size_t)tap * c4n + c4) * 64 + lane] = c < ci_n ? weights[l][((size_t)n * ci_n + c) * 9 + tap] : 0.0f;
+          }
+      if (hipMalloc((void**)&m->bfrag2[l], frag.size() * sizeof(float)) != hipSuccess ||
+          hipMemcpy(m->bfrag2[l], frag.data(), frag.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
+        return cleanup("uploading 2-D MFMA weight fragments failed");
+    }
+    if (hipMalloc((void**)&m->tail_w5, 16 * sizeof(float)) != hipSuccess ||
+        hipMemcpy(m->tail_w5, weights[4], 16 * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
+      return cleanup("uploading tail weights failed");
+    m->mfma2d = true;
+  }
   return m;
 }
 
@@ -494,6 +520,7 @@ void tfl_model_destroy(tfl_ctx* c, tfl_model* m) {
   if (!m) return;
   for (auto& L : m->layers) { if (L.w) (void)hipFree(L.w); if (L.b) (void)hipFree(L.b); }
   for (int l = 0; l < 3; l++) if (m->bfrag[l]) (void)hipFree(m->bfrag[l]);
+  for (int l = 0; l < 4; l++) if (m->bfrag2[l]) (void)hipFree(m->bfrag2[l]);
   if (m->tail_w4) (void)hipFree(m->tail_w4);
   if (m->tail_w5) (void)hipFree(m->tail_w5);
   if (m->d_stats) (void)hipFree(m->d_stats);
@@ -575,6 +602,12 @@ int tfl_model_finish(tfl_ctx* c, tfl_model* m, const tfl_tensor* pDiv, const tfl
     tfl::conv3_mfma_mid(st, B, Z, Y, X, w.act[0], m->bfrag[1], m->layers[1].b, w.act[1]);
     tfl::conv3_mfma_tail(st, B, Z, Y, X, w.act[1], m->bfrag[2], m->layers[2].b, m->tail_w4, m->layers[3].b,
                          m->tail_w5, m->layers[4].b, w.pPred);
+  } else if (m->mfma2d) {
+    tfl::conv2_mfma_first_fused(st, B, Y, X, pDiv->data, w.div, flags->data, st_in, count, m->bfrag2[0],
+                                m->layers[0].b, w.act[0]);
+    tfl::conv2_mfma_mid(st, B, Y, X, w.act[0], m->bfrag2[1], m->layers[1].b, w.act[1]);
+    tfl::conv2_mfma_mid(st, B, Y, X, w.act[1], m->bfrag2[2], m->layers[2].b, w.act[0]);
+    tfl::conv2_mfma_tail(st, B, Y, X, w.act[0], m->bfrag2[3], m->layers[3].b, m->tail_w5, m->layers[4].b, w.pPred);
   } else {
     tfl::model_net_input(st, m->is3d, B, Z, Y, X, pDiv->data, w.div, flags->data, st_in, count, w.x3);
     const float* in = w.x3;

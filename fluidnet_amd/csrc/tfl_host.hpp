@@ -83,4 +83,12 @@ void conv3_mfma_tail(hipStream_t st, int B, int Z, int Y, int X, const float* in
                      const float* bias, const float* w4, const float* b4, const float* w5, const float* b5,
                      float* p_out);
 
+// conv2d_mfma.hip (2-D default topology: 16 channels, k = 3; one MFMA = one tap x four input channels)
+void conv2_mfma_first_fused(hipStream_t st, int B, int Y, int X, const float* pDiv, const float* div, const float* flags,
+                            const double* stats, double count, const float* bfrag, const float* bias, float* out16);
+void conv2_mfma_mid(hipStream_t st, int B, int Y, int X, const float* in16, const float* bfrag, const float* bias,
+                    float* out16);
+void conv2_mfma_tail(hipStream_t st, int B, int Y, int X, const float* in16, const float* bfrag, const float* bias,
+                     const float* w5, const float* b5, float* p_out);
+
 }  // namespace tfl

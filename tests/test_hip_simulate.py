@@ -219,3 +219,23 @@ def test_graphed_simulate_equals_eager(which):
     for k in ("pDiv", "UDiv", "density"):
         assert torch.equal(eager[k], graphed[k]), k
     assert float(eager["UDiv"].abs().max()) > 0
+
+
+def test_conv_paths_agree_2d(oracle, monkeypatch):
+    """2-D: the 16-channel MFMA kernels (conv2d_mfma.hip) vs the shape-generic direct kernels (conv.hip) on the
+    shipped myModel2D weights, including grids ragged against the 32x4 tile and unaligned row pitches."""
+    import torch
+    from fluidnet_amd import FluidNetModel
+    layers = _layers2d()
+    dev = torch.device("cuda:0")
+    for dims, seed in [((1, 128, 128), 71), ((1, 37, 53), 72), ((1, 5, 130), 73)]:
+        sc = scenes.make_scene(dims, seed=seed, vel_cells=0.4, B=2)
+        tp, tU, tf = (torch.from_numpy(sc[k]).to(dev) for k in ("p", "U", "flags"))
+        monkeypatch.setenv("TFL_CONV_PATH", "direct")
+        pd, Ud = FluidNetModel(layers, False).forward([tp, tU, tf])
+        monkeypatch.setenv("TFL_CONV_PATH", "mfma")
+        pm, Um = FluidNetModel(layers, False).forward([tp, tU, tf])
+        rp, rU = scenes.rel_l2(pm.cpu().numpy(), pd.cpu().numpy()), scenes.rel_l2(Um.cpu().numpy(), Ud.cpu().numpy())
+        assert rp <= 2e-6 and rU <= 2e-6, (dims, rp, rU)
+        p_ref, U_ref = S.model_forward(oracle, layers, sc["p"], sc["U"], sc["flags"])
+        assert scenes.rel_l2(pm.cpu().numpy(), p_ref) <= TOL and scenes.rel_l2(Um.cpu().numpy(), U_ref) <= TOL
