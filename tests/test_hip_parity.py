@@ -153,3 +153,81 @@ def test_lds_tiled_advection_is_bit_identical(oracle):
     env = dict(os.environ, TFL_ADVECT_PATH="lds")
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "LDS_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+@pytest.mark.parametrize("dims,seed", [((1, 48, 40), 81), ((14, 18, 22), 82)])
+def test_hip_sample_outside_fluid_and_explicit_dst(hip, oracle, dims, seed):
+    """Non-default wrapper arguments of init.lua:89-219: sampleOutsideFluid=true (temperature-like fields)
+    and explicit sDst / UDst (no copy-back) -- bit-exact against the oracle for every method."""
+    sc = scenes.make_scene(dims, seed=seed, vel_cells=3.0, stick=True)
+    f, dt = sc["flags"], sc["dt"]
+    for m in ("maccormackOurs", "eulerOurs", "rk2Ours", "rk3Ours", "euler", "maccormack"):
+        a, b = sc["density"].copy(), sc["density"].copy()
+        hip.advectScalar(dt, a, sc["U"], f, m, None, True, 0.9)
+        oracle.advectScalar(dt, b, sc["U"], f, m, None, True, 0.9)
+        assert np.array_equal(a, b), ("outside", m)
+        s0 = sc["density"].copy()
+        da, db = np.full_like(s0, 9.0), np.full_like(s0, -9.0)
+        hip.advectScalar(dt, s0, sc["U"], f, m, da, False, 0.5)
+        oracle.advectScalar(dt, sc["density"].copy(), sc["U"], f, m, db, False, 0.5)
+        assert np.array_equal(da, db) and np.array_equal(s0, sc["density"]), ("sDst", m)
+        U0 = sc["U"].copy()
+        ua, ub = np.full_like(U0, 9.0), np.full_like(U0, -9.0)
+        hip.advectVel(dt, U0, f, m, ua, 0.5)
+        oracle.advectVel(dt, sc["U"].copy(), f, m, ub, 0.5)
+        assert np.array_equal(ua, ub) and np.array_equal(U0, sc["U"]), ("UDst", m)
+    assert hip.traceErrors() == 0
+
+
+@pytest.mark.parametrize("res", [128, 256])
+def test_hip_fullsize_properties(res):
+    """BASELINE.json's full sizes (128^3, 256^3), where the CPU oracle takes minutes: size-independent
+    properties of the operators instead. All exact (bitwise) statements."""
+    import torch
+    from fluidnet_amd import tfluids
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(5)
+    flags = tfluids.emptyDomain(torch.empty(1, 1, res, res, res, device=dev), True)
+    assert float(flags.sum()) == float(res ** 3 + 6 * res * res - 12 * res + 8)       # 2 on the shell, 1 inside
+    occ = torch.empty_like(flags)
+    tfluids.flagsToOccupancy(flags, occ)
+    assert torch.equal(occ, flags - 1)
+    plane = torch.rand(res, res, generator=g)
+    s = (plane[None, :, :] * torch.linspace(0.5, 1.5, res)[:, None, None]).view(1, 1, res, res, res).contiguous().to(dev)
+    interior = torch.zeros_like(s, dtype=torch.bool)
+    interior[..., 1:-1, 1:-1, 1:-1] = True
+    # (1) zero velocity: MacCormack advection is the identity on the interior and zeroes the border shell
+    U0 = torch.zeros(1, 3, res, res, res, device=dev)
+    out = torch.empty_like(s)
+    for m in ("maccormackOurs", "eulerOurs", "maccormack"):
+        tfluids.advectScalar(0.1, s, U0, flags, m, out)
+        assert torch.equal(out, torch.where(interior, s, torch.zeros_like(s))), m
+    # (2) uniform whole-cell displacement: the result is the field shifted by exactly that many cells
+    #     (trilinear weights degenerate to 1/0, the MacCormack correction cancels, the clamp is inactive)
+    U1 = torch.zeros(1, 3, res, res, res, device=dev)
+    U1[:, 0] = 2.0            # dt = 0.5 -> one cell in +x per step
+    tfluids.advectScalar(0.5, s, U1, flags, "maccormackOurs", out)
+    core = (slice(None), slice(None), slice(4, -4), slice(4, -4), slice(4, -4))
+    shifted = torch.roll(s, shifts=1, dims=4)
+    assert torch.equal(out[core], shifted[core])
+    Uout = torch.empty_like(U1)
+    tfluids.advectVel(0.5, U1, flags, "maccormackOurs", Uout)
+    assert torch.equal(Uout[core], U1[core])                      # a uniform flow advects itself unchanged
+    # (3) wall BCs are idempotent; divergence of a curl-free uniform flow is zero away from walls
+    U = torch.rand(1, 3, res, res, res, generator=g).to(dev)
+    a = U.clone()
+    tfluids.setWallBcsForward(a, flags)
+    b = a.clone()
+    tfluids.setWallBcsForward(b, flags)
+    assert torch.equal(a, b) and not torch.equal(a, U)
+    div = torch.empty_like(s)
+    tfluids.velocityDivergenceForward(U1, flags, div)
+    assert float(div[core].abs().max()) == 0.0
+    # (4) velocityUpdate with a linear pressure p = c*x subtracts exactly c from u_x on fluid/fluid faces
+    p = (torch.arange(res, dtype=torch.float32) * 0.25).view(1, 1, 1, 1, res).expand(1, 1, res, res, res).contiguous().to(dev)
+    Uu = torch.zeros(1, 3, res, res, res, device=dev)
+    tfluids.velocityUpdateForward(Uu, flags, p)
+    assert torch.equal(Uu[:, 0][(slice(None), slice(2, -2), slice(2, -2), slice(2, -1))],
+                       torch.full((1, res - 4, res - 4, res - 3), -0.25, device=dev))
+    assert float(Uu[:, 1:].abs().max()) == 0.0
+    assert tfluids.traceErrors(s) == 0

@@ -239,3 +239,32 @@ def test_conv_paths_agree_2d(oracle, monkeypatch):
         assert rp <= 2e-6 and rU <= 2e-6, (dims, rp, rU)
         p_ref, U_ref = S.model_forward(oracle, layers, sc["p"], sc["U"], sc["flags"])
         assert scenes.rel_l2(pm.cpu().numpy(), p_ref) <= TOL and scenes.rel_l2(Um.cpu().numpy(), U_ref) <= TOL
+
+
+def test_zslab_decomposition_fullsize_128():
+    """The same invariance at BASELINE's full 128^3 (where the CPU oracle takes minutes per step): splitting
+    the grid into two z-slabs must not change the owned planes. Scene = bench.py's config-4 scene."""
+    import torch
+    import bench
+    from fluidnet_amd import FluidNetModel
+    from fluidnet_amd.dist import SlabLayout, SlabSimulation, run_lockstep
+    from fluidnet_amd.simulate import simulate
+    dev = torch.device("cuda:0")
+    res = 128
+    ref, mconf = bench.build_scene(res, res, None, dev)
+    model = FluidNetModel.default_3d(seed=1)
+    lays = [SlabLayout(res, 2, r, 10) for r in range(2)]
+    sims = []
+    for lay in lays:
+        loc, _ = bench.build_scene(res, res, lay, dev)
+        sims.append(SlabSimulation(loc, mconf, FluidNetModel.default_3d(seed=1), lay, None, check_reach=True))
+    for _ in range(6):
+        simulate(None, mconf, ref, model)
+        run_lockstep([(s.step_gen(), s.lay) for s in sims])
+    assert float(ref["UDiv"].abs().max()) > 0 and bool(torch.isfinite(ref["UDiv"]).all())
+    for s in sims:
+        for k in ("pDiv", "UDiv", "density"):
+            got = s.lay.owned(s.batch[k])
+            want = ref[k][:, :, s.lay.z0:s.lay.z1]
+            rel = float((got - want).norm() / want.norm().clamp_min(1e-30))
+            assert rel <= 1e-6, (s.lay.rank, k, rel)
