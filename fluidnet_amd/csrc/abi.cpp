@@ -665,4 +665,23 @@ int tfl_applyBCsIndexed(tfl_ctx* c, const tfl_tensor* x, const tfl_tensor* bc, c
   return check_launch(c, "applyBCsIndexed");
 }
 
+int tfl_packPlanes(tfl_ctx* c, int n, const tfl_tensor* const* fields, int zlo, int zhi, float* buf, int unpack) {
+  if (!c) return TFL_EINVAL;
+  if (n < 1 || n > 8 || !fields || !buf) return fail(c, TFL_EINVAL, "packPlanes: 1..8 fields and a buffer are required");
+  const tfl_tensor* f0 = fields[0];
+  if (!f0 || zlo < 0 || zhi > f0->Z || zlo >= zhi) return fail(c, TFL_EINVAL, "packPlanes: bad plane range [%d, %d)", zlo, zhi);
+  float* ptrs[8];
+  int rows[8];
+  for (int i = 0; i < n; i++) {
+    const tfl_tensor* f = fields[i];
+    if (!f || !f->data || f->Z != f0->Z || f->Y != f0->Y || f->X != f0->X)
+      return fail(c, TFL_EINVAL, "packPlanes: field %d does not match the grid of field 0", i);
+    ptrs[i] = f->data;
+    rows[i] = f->B * f->C;
+  }
+  const long long yx = (long long)f0->Y * f0->X;
+  tfl::pack_planes(c->stream, n, ptrs, rows, yx * f0->Z, yx * (zhi - zlo), yx * zlo, buf, unpack);
+  return check_launch(c, "packPlanes");
+}
+
 }  // extern "C"

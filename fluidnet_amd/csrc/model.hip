@@ -215,6 +215,29 @@ __global__ __launch_bounds__(256) void k_apply_bcs_indexed(long long n, const in
   }
 }
 
+// Halo planes of several fields <-> one contiguous message buffer (fluidnet_amd/dist.py): buffer layout
+// [field][b][channel][plane zlo..zhi)[Y][X]. One launch per direction instead of a dozen strided copies.
+struct PackArgs {
+  float* ptr[8];
+  int chans[8];        // B*C "rows" of each field (each row = Z*Y*X floats)
+  long long start[9];  // prefix sums of elements per field in the buffer
+  int n;
+};
+__global__ __launch_bounds__(256) void k_pack_planes(PackArgs a, long long zstride, long long plane_elems, long long zlo_off,
+                                                     float* __restrict__ buf, int unpack) {
+  const long long total = a.start[a.n];
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+    int f = 0;
+#pragma unroll
+    for (int q = 1; q < 8; q++) if (q < a.n && t >= a.start[q]) f = q;
+    const long long r = t - a.start[f];
+    const long long row = r / plane_elems, within = r - row * plane_elems;   // row = b*C + c
+    float* g = a.ptr[f] + row * zstride + zlo_off + within;
+    if (unpack) *g = buf[t];
+    else buf[t] = *g;
+  }
+}
+
 #define TFL_GRID3(d, B) dim3(((d).X + 63) / 64, ((d).Y + 3) / 4, (unsigned)((d).Z * (B)))
 
 long long model_stat_blocks(int B, int Z, int Y, int X) {
@@ -254,6 +277,22 @@ void apply_bcs(hipStream_t st, long long n, float* x, const float* bcv, const fl
   long long blocks = (n + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   { TFL_TIMED("k_apply_bcs", st); k_apply_bcs<<<(int)(blocks > 0 ? blocks : 1), 256, 0, st>>>(n, x, bcv, inv, do_clamp, lo, hi); }
+}
+
+void pack_planes(hipStream_t st, int n, float* const* ptrs, const int* rows, long long zstride, long long plane_elems,
+                 long long zlo_off, float* buf, int unpack) {
+  PackArgs a;
+  a.n = n;
+  a.start[0] = 0;
+  for (int i = 0; i < 8; i++) {
+    a.ptr[i] = i < n ? ptrs[i] : nullptr;
+    a.chans[i] = i < n ? rows[i] : 0;
+    a.start[i + 1] = a.start[i] + (i < n ? (long long)rows[i] * plane_elems : 0);
+  }
+  long long blocks = (a.start[n] + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) return;
+  { TFL_TIMED(unpack ? "k_unpack_planes" : "k_pack_planes", st); k_pack_planes<<<(int)blocks, 256, 0, st>>>(a, zstride, plane_elems, zlo_off, buf, unpack); }
 }
 
 void apply_bcs_indexed(hipStream_t st, long long n, const int* idx, float* x, const float* bcv, const float* inv) {

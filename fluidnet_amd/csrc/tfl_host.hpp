@@ -67,6 +67,9 @@ void apply_bcs(hipStream_t st, long long n, float* x, const float* bcv, const fl
 
 void apply_bcs_indexed(hipStream_t st, long long n, const int* idx, float* x, const float* bcv, const float* inv);
 
+void pack_planes(hipStream_t st, int n, float* const* ptrs, const int* rows, long long zstride, long long plane_elems,
+                 long long zlo_off, float* buf, int unpack);
+
 // conv.hip
 bool conv_direct(hipStream_t st, bool is3d, int B, int Z, int Y, int X, int cin, int cout, int ksz, bool relu,
                  const float* in, const float* w, const float* bias, float* out);

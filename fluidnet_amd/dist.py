@@ -55,11 +55,35 @@ class SlabLayout:
         return t[:, :, self.c0:self.c1]
 
 
-def _pack(fields, a, b):
-    return torch.cat([f[:, :, a:b].reshape(-1) for f in fields])
+def _msg_numel(fields, a, b):
+    return sum(f.size(0) * f.size(1) * (b - a) * f.size(3) * f.size(4) for f in fields)
+
+
+def _hip_pack(fields, a, b, buf, unpack):
+    """One kernel launch (tfl_packPlanes) instead of a dozen strided torch copies per message."""
+    import ctypes
+    from ._lib import tfl_tensor
+    lib, ctx = tfluids._context(fields[0])
+    descs = [tfl_tensor(f.data_ptr(), *f.shape) for f in fields]
+    arr = (ctypes.POINTER(tfl_tensor) * len(descs))(*[ctypes.pointer(d) for d in descs])
+    tfluids._call(lib, ctx, lib.tfl_packPlanes(ctx, len(descs), arr, int(a), int(b), ctypes.c_void_p(buf.data_ptr()),
+                                               int(unpack)))
+
+
+def _pack(fields, a, b, out=None):
+    """Planes [a, b) of every field -> one contiguous message, layout [field][b][c][plane][Y][X]."""
+    if fields[0].is_cuda:
+        buf = out if out is not None else torch.empty(_msg_numel(fields, a, b), dtype=torch.float32,
+                                                       device=fields[0].device)
+        _hip_pack(fields, a, b, buf, 0)
+        return buf
+    return torch.cat([f[:, :, a:b].reshape(-1) for f in fields])     # CPU tensors (gloo tests)
 
 
 def _unpack(buf, fields, a, b):
+    if fields[0].is_cuda:
+        _hip_pack(fields, a, b, buf, 1)
+        return
     off = 0
     for f in fields:
         view = f[:, :, a:b]
@@ -75,19 +99,29 @@ class DistComm:
         import torch.distributed as dist
         self.dist = dist
         self.group = group
+        self._bufs = {}   # (direction, numel) -> (send, recv) message buffers, allocated once
+
+    def _buffers(self, key, fields, a, b):
+        n = _msg_numel(fields, a, b)
+        hit = self._bufs.get((key, n))
+        if hit is None:
+            hit = (torch.empty(n, dtype=torch.float32, device=fields[0].device),
+                   torch.empty(n, dtype=torch.float32, device=fields[0].device))
+            self._bufs[(key, n)] = hit
+        return hit
 
     def exchange(self, lay, fields):
         dist, h = self.dist, lay.halo
         ops, recvs = [], []
         if lay.has_lower:   # my lowest h owned planes -> rank-1's upper halo; its top planes -> my lower halo
-            send = _pack(fields, lay.c0, lay.c0 + h)
-            recv = torch.empty_like(send)
+            sbuf, recv = self._buffers("lo", fields, lay.c0, lay.c0 + h)
+            send = _pack(fields, lay.c0, lay.c0 + h, out=sbuf if fields[0].is_cuda else None)
             ops += [dist.P2POp(dist.isend, send, lay.rank - 1, self.group),
                     dist.P2POp(dist.irecv, recv, lay.rank - 1, self.group)]
             recvs.append((recv, lay.c0 - h, lay.c0))
         if lay.has_upper:
-            send = _pack(fields, lay.c1 - h, lay.c1)
-            recv = torch.empty_like(send)
+            sbuf, recv = self._buffers("hi", fields, lay.c1 - h, lay.c1)
+            send = _pack(fields, lay.c1 - h, lay.c1, out=sbuf if fields[0].is_cuda else None)
             ops += [dist.P2POp(dist.isend, send, lay.rank + 1, self.group),
                     dist.P2POp(dist.irecv, recv, lay.rank + 1, self.group)]
             recvs.append((recv, lay.c1, lay.c1 + h))

@@ -203,6 +203,13 @@ int tfl_applyBCs(tfl_ctx* ctx, const tfl_tensor* x, const tfl_tensor* bc, const 
 int tfl_applyBCsIndexed(tfl_ctx* ctx, const tfl_tensor* x, const tfl_tensor* bc, const tfl_tensor* invMask,
                         const int32_t* idx, int64_t n);
 
+/* z-slab halo messages (BASELINE config 5): gather planes [zlo, zhi) of n <= 8 fields (each with its own
+ * B and C; all with the same Z, Y, X) into one contiguous buffer laid out
+ * [field][b][c][plane][Y][X] (unpack = 0), or scatter such a buffer back into the fields (unpack = 1).
+ * One launch per neighbour and direction; the buffer is what RCCL send/recv moves over xGMI. */
+int tfl_packPlanes(tfl_ctx* ctx, int n, const tfl_tensor* const* fields, int zlo, int zhi, float* buf,
+                   int unpack);
+
 #ifdef __cplusplus
 }
 #endif
