@@ -15,30 +15,43 @@
 #include "tfl_device.hpp"
 #include "tfl_host.hpp"
 
+#include <cstdlib>
+
 namespace tfl {
 
-// setWallBcs decision for the cell's own three face components, third_party/tfluids.cc:926-1002
+// setWallBcs decision for the cell's own three face components, third_party/tfluids.cc:926-1002, as a pure
+// function of the cell's flag word and its six neighbours' (0 where the neighbour is outside the grid).
 template <bool IS3D>
-__device__ __forceinline__ void wall_zero_mask(const Dom& d, const float* __restrict__ flags, int i, int j, int k, int o,
-                                               bool& zx, bool& zy, bool& zz) {
+__device__ __forceinline__ void wall_mask_from(int fc, int fxm, int fxp, int fym, int fyp, int fzm, int fzp, bool& zx,
+                                               bool& zy, bool& zz) {
   zx = zy = zz = false;
-  const int fc = (int)flags[o];
   const bool cf = fc & kFluid, co = fc & kObstacle;
   if (!cf && !co) return;
-  const int fxm = i > 0 ? (int)flags[o - 1] : 0;
-  const int fym = j > 0 ? (int)flags[o - d.sy] : 0;
-  const int fzm = (IS3D && k > 0) ? (int)flags[o - d.sz] : 0;
   zx = (fxm & kObstacle) || (co && (fxm & kFluid));
   zy = (fym & kObstacle) || (co && (fym & kFluid));
   zz = IS3D && ((fzm & kObstacle) || (co && (fzm & kFluid)));
   if (cf) {
-    const int fxp = i < d.X - 1 ? (int)flags[o + 1] : 0;
-    const int fyp = j < d.Y - 1 ? (int)flags[o + d.sy] : 0;
-    const int fzp = (IS3D && k < d.Z - 1) ? (int)flags[o + d.sz] : 0;
     if ((fxm & kStick) || (fxp & kStick)) { zy = true; zz = IS3D; }
     if ((fym & kStick) || (fyp & kStick)) { zx = true; zz = IS3D; }
     if (IS3D && ((fzm & kStick) || (fzp & kStick))) { zx = true; zy = true; }
   }
+}
+
+template <bool IS3D>
+__device__ __forceinline__ void wall_zero_mask(const Dom& d, const float* __restrict__ flags, int i, int j, int k, int o,
+                                               bool& zx, bool& zy, bool& zz) {
+  const int fc = (int)flags[o];
+  if (!(fc & (kFluid | kObstacle))) { zx = zy = zz = false; return; }
+  const int fxm = i > 0 ? (int)flags[o - 1] : 0;
+  const int fym = j > 0 ? (int)flags[o - d.sy] : 0;
+  const int fzm = (IS3D && k > 0) ? (int)flags[o - d.sz] : 0;
+  int fxp = 0, fyp = 0, fzp = 0;
+  if (fc & kFluid) {
+    fxp = i < d.X - 1 ? (int)flags[o + 1] : 0;
+    fyp = j < d.Y - 1 ? (int)flags[o + d.sy] : 0;
+    fzp = (IS3D && k < d.Z - 1) ? (int)flags[o + d.sz] : 0;
+  }
+  wall_mask_from<IS3D>(fc, fxm, fxp, fym, fyp, fzm, fzp, zx, zy, zz);
 }
 
 // U_bc component AXIS of cell (i,j,k): the input velocity with the wall BCs applied on the fly
@@ -193,6 +206,88 @@ __global__ __launch_bounds__(256) void k_project(Dom d, const float* __restrict_
   }
 }
 
+// k_project with four consecutive x cells per thread (X % 4 == 0, 16-byte aligned rows): every access is
+// a 16-byte vector, the x-1 / x+4 neighbours are single scalar loads. Same per-cell arithmetic (bit-exact).
+__device__ __forceinline__ void unpack4(const float4 v, float* o) { o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
+
+template <bool IS3D>
+__global__ __launch_bounds__(256) void k_project_v4(Dom d, const float* __restrict__ pPred, const float* __restrict__ flags,
+                                                    const double* __restrict__ stats, double count,
+                                                    float* __restrict__ Uio, float* __restrict__ pOut, BcArgs bc) {
+  const int i0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  const int j = blockIdx.y * blockDim.y + threadIdx.y;
+  const int b = blockIdx.z / d.Z, k = blockIdx.z - b * d.Z;
+  if (i0 >= d.X || j >= d.Y) return;
+  const long long cells = d.sc;
+  const int C = IS3D ? 3 : 2;
+  const float scale = scale_from_stats(stats, b, count);
+  pPred += b * cells; flags += b * cells; pOut += b * cells; Uio += b * cells * C;
+  const int o = TFL_AT(d, i0, j, k);
+  const float4 z4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  auto ld4 = [&](const float* p, bool ok) { return ok ? *reinterpret_cast<const float4*>(p) : z4; };
+  // flags: the row itself (+ one cell either side) and the four neighbouring rows
+  float fc[4], fym[4], fyp[4], fzm[4], fzp[4], pc[4], pym[4], pzm[4];
+  unpack4(ld4(flags + o, true), fc);
+  unpack4(ld4(flags + o - d.sy, j > 0), fym);
+  unpack4(ld4(flags + o + d.sy, j < d.Y - 1), fyp);
+  unpack4(ld4(flags + o - d.sz, IS3D && k > 0), fzm);
+  unpack4(ld4(flags + o + d.sz, IS3D && k < d.Z - 1), fzp);
+  const float f_left = i0 > 0 ? flags[o - 1] : 0.0f, f_right = i0 + 4 < d.X ? flags[o + 4] : 0.0f;
+  unpack4(ld4(pPred + o, true), pc);
+  unpack4(ld4(pPred + o - d.sy, j > 0), pym);
+  unpack4(ld4(pPred + o - d.sz, IS3D && k > 0), pzm);
+  const float p_left = i0 > 0 ? pPred[o - 1] : 0.0f;
+  float u[3][4];
+#pragma unroll
+  for (int c = 0; c < 3; c++) unpack4(ld4(Uio + o + c * d.sc, c < C), u[c]);
+  float ubc[3][4], umk[3][4];
+  if (bc.UBC) {
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      unpack4(ld4(bc.UBC + b * cells * C + o + c * d.sc, c < C), ubc[c]);
+      unpack4(ld4(bc.UInvMask + b * cells * C + o + c * d.sc, c < C), umk[c]);
+    }
+  }
+  float po[4];
+  const bool row_border = j < 1 || j > d.Y - 2 || (IS3D && (k < 1 || k > d.Z - 2));
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const int i = i0 + q;
+    const int f = (int)fc[q];
+    const int fxm = q > 0 ? (int)fc[q - 1] : (int)f_left, fxp = q < 3 ? (int)fc[q + 1] : (int)f_right;
+    const float pxm = q > 0 ? pc[q - 1] : p_left;
+    float v[3] = {u[0][q] / scale, u[1][q] / scale, IS3D ? u[2][q] / scale : 0.0f};
+    if (!(row_border || i < 1 || i > d.X - 2)) {   // velocityUpdateForward, tfluids.cc:1072-1156
+      const int fn[3] = {fxm, (int)fym[q], IS3D ? (int)fzm[q] : 0};
+      const float pn[3] = {pxm, pym[q], pzm[q]};
+      if (f & kFluid) {
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+          if (fn[c] & kFluid) v[c] -= (pc[q] - pn[c]);
+          if (fn[c] & kEmpty) v[c] -= pc[q];
+        }
+      } else if ((f & kEmpty) && !(f & kOutflow)) {
+#pragma unroll
+        for (int c = 0; c < C; c++) v[c] = (fn[c] & kFluid) ? v[c] + pn[c] : 0.0f;
+      }
+    }
+    bool z[3];
+    wall_mask_from<IS3D>(f, fxm, fxp, (int)fym[q], (int)fyp[q], (int)fzm[q], (int)fzp[q], z[0], z[1], z[2]);
+    po[q] = pc[q] * scale;
+#pragma unroll
+    for (int c = 0; c < C; c++) {
+      float w = z[c] ? 0.0f : v[c] * scale;
+      if (bc.UBC) w = w * umk[c][q] + ubc[c][q];
+      if (bc.enable_clamp) w = fminf(fmaxf(w, bc.lo), bc.hi);
+      u[c][q] = w;
+    }
+  }
+  *reinterpret_cast<float4*>(pOut + o) = make_float4(po[0], po[1], po[2], po[3]);
+#pragma unroll
+  for (int c = 0; c < 3; c++)
+    if (c < C) *reinterpret_cast<float4*>(Uio + o + c * d.sc) = make_float4(u[c][0], u[c][1], u[c][2], u[c][3]);
+}
+
 // x = clamp(x * invMask + bc): setConstVals (+ the final U:clamp) of lib/simulate.lua:130-160,326
 __global__ __launch_bounds__(256) void k_apply_bcs(long long n, float* __restrict__ x, const float* __restrict__ bcv,
                                                    const float* __restrict__ inv, int do_clamp, float lo, float hi) {
@@ -268,6 +363,15 @@ void model_project(hipStream_t st, bool is3d, int B, int Z, int Y, int X, const 
   const Dom d = make_dom(Z, Y, X);
   const dim3 blk(64, 4, 1), grd = TFL_GRID3(d, B);
   BcArgs bc; bc.UBC = UBC; bc.UInvMask = UInvMask; bc.enable_clamp = do_clamp; bc.lo = lo; bc.hi = hi;
+  const uintptr_t al = (uintptr_t)pPred | (uintptr_t)flags | (uintptr_t)Uio | (uintptr_t)pOut | (uintptr_t)UBC |
+                       (uintptr_t)UInvMask;
+  if (X % 4 == 0 && (al & 15) == 0 && !getenv("TFL_NO_VEC4")) {
+    const dim3 vb(32, 8, 1), vg((X / 4 + 31) / 32, (Y + 7) / 8, (unsigned)(Z * B));
+    TFL_TIMED("k_project", st);
+    if (is3d) k_project_v4<true><<<vg, vb, 0, st>>>(d, pPred, flags, stats, count, Uio, pOut, bc);
+    else k_project_v4<false><<<vg, vb, 0, st>>>(d, pPred, flags, stats, count, Uio, pOut, bc);
+    return;
+  }
   if (is3d) { TFL_TIMED("k_project", st); k_project<true><<<grd, blk, 0, st>>>(d, pPred, flags, stats, count, Uio, pOut, bc); }
   else { TFL_TIMED("k_project", st); k_project<false><<<grd, blk, 0, st>>>(d, pPred, flags, stats, count, Uio, pOut, bc); }
 }
