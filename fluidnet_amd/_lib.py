@@ -64,6 +64,10 @@ SIGNATURES = {
     "tfl_model_finish": (_c.c_int, [_c.c_void_p, _c.c_void_p, _T, _T, _T, _T, _c.c_void_p, _c.c_int64,
                                     _c.c_void_p, _c.c_double, _T, _T, _c.c_int, _c.c_float, _c.c_float]),
     "tfl_set_dx_override": (_c.c_int, [_c.c_void_p, _c.c_float]),
+    "tfl_velocityDivergenceBackward": (_c.c_int, [_c.c_void_p, _T, _T, _T, _c.c_int, _T]),
+    "tfl_velocityUpdateBackward": (_c.c_int, [_c.c_void_p, _T, _T, _T, _T, _c.c_int, _T]),
+    "tfl_volumetricUpSamplingNearestForward": (_c.c_int, [_c.c_void_p, _c.c_int, _T, _T]),
+    "tfl_volumetricUpSamplingNearestBackward": (_c.c_int, [_c.c_void_p, _c.c_int, _T, _T, _T]),
     "tfl_packPlanes": (_c.c_int, [_c.c_void_p, _c.c_int, _c.POINTER(_T), _c.c_int, _c.c_int, _c.c_void_p, _c.c_int]),
     "tfl_applyBCsIndexed": (_c.c_int, [_c.c_void_p, _T, _T, _T, _c.c_void_p, _c.c_int64]),
     "tfl_applyBCs": (_c.c_int, [_c.c_void_p, _T, _T, _T, _c.c_int, _c.c_float, _c.c_float]),

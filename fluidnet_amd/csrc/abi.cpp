@@ -684,4 +684,54 @@ int tfl_packPlanes(tfl_ctx* c, int n, const tfl_tensor* const* fields, int zlo, 
   return check_launch(c, "packPlanes");
 }
 
+int tfl_velocityDivergenceBackward(tfl_ctx* c, const tfl_tensor* U, const tfl_tensor* flags, const tfl_tensor* gradOutput,
+                                   int is3D, const tfl_tensor* gradU) {
+  TRY(check_flags(c, "velocityDivergenceBackward", flags));
+  TRY(check_vel(c, "velocityDivergenceBackward", "U", U, flags, is3D));
+  TRY(check_vel(c, "velocityDivergenceBackward", "gradU", gradU, flags, is3D));
+  TRY(check_scalar(c, "velocityDivergenceBackward", "gradOutput", gradOutput, flags));
+  tfl::velocity_divergence_bwd(c->stream, is3D != 0, flags->B, flags->Z, flags->Y, flags->X, flags->data,
+                               gradOutput->data, gradU->data);
+  return check_launch(c, "velocityDivergenceBackward");
+}
+
+int tfl_velocityUpdateBackward(tfl_ctx* c, const tfl_tensor* U, const tfl_tensor* flags, const tfl_tensor* p,
+                               const tfl_tensor* gradOutput, int is3D, const tfl_tensor* gradP) {
+  TRY(check_flags(c, "velocityUpdateBackward", flags));
+  TRY(check_vel(c, "velocityUpdateBackward", "U", U, flags, is3D));
+  TRY(check_vel(c, "velocityUpdateBackward", "gradOutput", gradOutput, flags, is3D));
+  TRY(check_scalar(c, "velocityUpdateBackward", "p", p, flags));
+  TRY(check_scalar(c, "velocityUpdateBackward", "gradP", gradP, flags));
+  tfl::velocity_update_bwd(c->stream, is3D != 0, flags->B, flags->Z, flags->Y, flags->X, flags->data, gradOutput->data,
+                           gradP->data);
+  return check_launch(c, "velocityUpdateBackward");
+}
+
+int tfl_volumetricUpSamplingNearestForward(tfl_ctx* c, int ratio, const tfl_tensor* input, const tfl_tensor* output) {
+  if (!c) return TFL_EINVAL;
+  if (!input || !output || !input->data || !output->data) return fail(c, TFL_EINVAL, "ERROR: input and output must be dim 5");
+  if (ratio < 1 || output->B != input->B || output->C != input->C || output->Z != input->Z * ratio ||
+      output->Y != input->Y * ratio || output->X != input->X * ratio)
+    return fail(c, TFL_EINVAL, "ERROR: input : output size mismatch.");
+  tfl::upsample_nearest_fwd(c->stream, ratio, (long long)input->B * input->C, output->Z, output->Y, output->X,
+                            input->data, output->data);
+  return check_launch(c, "volumetricUpSamplingNearestForward");
+}
+
+int tfl_volumetricUpSamplingNearestBackward(tfl_ctx* c, int ratio, const tfl_tensor* input, const tfl_tensor* gradOutput,
+                                            const tfl_tensor* gradInput) {
+  if (!c) return TFL_EINVAL;
+  if (!input || !gradOutput || !gradInput || !gradOutput->data || !gradInput->data)
+    return fail(c, TFL_EINVAL, "ERROR: input, gradOutput and gradInput must be dim 5");
+  if (ratio < 1 || gradOutput->B != input->B || gradOutput->C != input->C || gradOutput->Z != input->Z * ratio ||
+      gradOutput->Y != input->Y * ratio || gradOutput->X != input->X * ratio)
+    return fail(c, TFL_EINVAL, "ERROR: input : gradOutput size mismatch.");
+  if (gradInput->B != input->B || gradInput->C != input->C || gradInput->Z != input->Z || gradInput->Y != input->Y ||
+      gradInput->X != input->X)
+    return fail(c, TFL_EINVAL, "ERROR: input : gradInput size mismatch.");
+  tfl::upsample_nearest_bwd(c->stream, ratio, (long long)input->B * input->C, input->Z, input->Y, input->X,
+                            gradOutput->data, gradInput->data);
+  return check_launch(c, "volumetricUpSamplingNearestBackward");
+}
+
 }  // extern "C"

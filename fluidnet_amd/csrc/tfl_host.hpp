@@ -86,6 +86,14 @@ void conv3_mfma_tail(hipStream_t st, int B, int Z, int Y, int X, const float* in
                      const float* bias, const float* w4, const float* b4, const float* w5, const float* b5,
                      float* p_out);
 
+// backward.hip
+void velocity_divergence_bwd(hipStream_t st, bool is3d, int B, int Z, int Y, int X, const float* flags,
+                             const float* grad_out, float* grad_U);
+void velocity_update_bwd(hipStream_t st, bool is3d, int B, int Z, int Y, int X, const float* flags,
+                         const float* grad_out, float* grad_p);
+void upsample_nearest_fwd(hipStream_t st, int ratio, long long rows, int Zo, int Yo, int Xo, const float* in, float* out);
+void upsample_nearest_bwd(hipStream_t st, int ratio, long long rows, int Zi, int Yi, int Xi, const float* go, float* gi);
+
 // conv2d_mfma.hip (2-D default topology: 16 channels, k = 3; one MFMA = one tap x four input channels)
 void conv2_mfma_first_fused(hipStream_t st, int B, int Y, int X, const float* pDiv, const float* div, const float* flags,
                             const double* stats, double count, const float* bfrag, const float* bias, float* out16);

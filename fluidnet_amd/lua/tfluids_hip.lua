@@ -42,6 +42,13 @@ int tfl_addGravity(tfl_ctx*, const tfl_tensor* U, const tfl_tensor* flags, const
                    int is3D, float* forceTmp);
 int tfl_emptyDomain(tfl_ctx*, const tfl_tensor* flags, int is3D, int bnd);
 int tfl_flagsToOccupancy(tfl_ctx*, const tfl_tensor* flags, const tfl_tensor* occupancy);
+int tfl_velocityDivergenceBackward(tfl_ctx*, const tfl_tensor* U, const tfl_tensor* flags, const tfl_tensor* gradOutput,
+                                   int is3D, const tfl_tensor* gradU);
+int tfl_velocityUpdateBackward(tfl_ctx*, const tfl_tensor* U, const tfl_tensor* flags, const tfl_tensor* p,
+                               const tfl_tensor* gradOutput, int is3D, const tfl_tensor* gradP);
+int tfl_volumetricUpSamplingNearestForward(tfl_ctx*, int ratio, const tfl_tensor* input, const tfl_tensor* output);
+int tfl_volumetricUpSamplingNearestBackward(tfl_ctx*, int ratio, const tfl_tensor* input, const tfl_tensor* gradOutput,
+                                            const tfl_tensor* gradInput);
 int tfl_solveLinearSystemJacobi(tfl_ctx*, const tfl_tensor* p, const tfl_tensor* flags, const tfl_tensor* div,
                                 const tfl_tensor* pPrev, const tfl_tensor* pDelta,
                                 const tfl_tensor* pDeltaNorm, int is3D, float pTol, int maxIter, int verbose,
@@ -105,6 +112,18 @@ function ops.emptyDomain(flags, is3D, bnd)
 end
 function ops.flagsToOccupancy(flags, occupancy)
   check(lib.tfl_flagsToOccupancy(ctx, T(flags), T(occupancy)))
+end
+function ops.velocityDivergenceBackward(U, flags, gradOutput, is3D, gradU)
+  check(lib.tfl_velocityDivergenceBackward(ctx, T(U), T(flags), T(gradOutput), is3D and 1 or 0, T(gradU)))
+end
+function ops.velocityUpdateBackward(U, flags, p, gradOutput, is3D, gradP)
+  check(lib.tfl_velocityUpdateBackward(ctx, T(U), T(flags), T(p), T(gradOutput), is3D and 1 or 0, T(gradP)))
+end
+function ops.volumetricUpSamplingNearestForward(ratio, input, output)
+  check(lib.tfl_volumetricUpSamplingNearestForward(ctx, ratio, T(input), T(output)))
+end
+function ops.volumetricUpSamplingNearestBackward(ratio, input, gradOutput, gradInput)
+  check(lib.tfl_volumetricUpSamplingNearestBackward(ctx, ratio, T(input), T(gradOutput), T(gradInput)))
 end
 function ops.solveLinearSystemJacobi(p, flags, div, pPrev, pDelta, pDeltaNorm, is3D, pTol, maxIter, verbose)
   local res = ffi.new('float[1]')

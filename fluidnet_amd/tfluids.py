@@ -178,6 +178,46 @@ def velocityUpdateForward(U, flags, p):
     _call(lib, ctx, lib.tfl_velocityUpdateForward(ctx, _tt(U), _tt(flags), _tt(p), int(is3D)))
 
 
+def velocityDivergenceBackward(U, flags, gradOutput, gradU):
+    """init.lua:288-313."""
+    _, _, _, _, is3D = _dims(U, flags)
+    _check(gradOutput.dim() == 5 and gradU.dim() == 5, "Dimension mismatch")
+    _check(gradOutput.shape == flags.shape and gradU.shape == U.shape, "Size mismatch")
+    _check(gradOutput.is_contiguous() and gradU.is_contiguous(), "Input is not contiguous")
+    lib, ctx = _context(U)
+    _call(lib, ctx, lib.tfl_velocityDivergenceBackward(ctx, _tt(U), _tt(flags), _tt(gradOutput), int(is3D),
+                                                       _tt(gradU)))
+
+
+def velocityUpdateBackward(U, flags, p, gradOutput, gradP):
+    """init.lua:358-383."""
+    _, _, _, _, is3D = _dims(U, flags)
+    _check(p.dim() == 5 and gradOutput.dim() == 5 and gradP.dim() == 5, "Dimension mismatch")
+    _check(gradP.shape == p.shape and p.shape == flags.shape and gradOutput.shape == U.shape, "Size mismatch")
+    _check(p.is_contiguous() and gradOutput.is_contiguous() and gradP.is_contiguous(), "Input is not contiguous")
+    lib, ctx = _context(U)
+    _call(lib, ctx, lib.tfl_velocityUpdateBackward(ctx, _tt(U), _tt(flags), _tt(p), _tt(gradOutput), int(is3D),
+                                                   _tt(gradP)))
+
+
+def volumetricUpSamplingNearestForward(ratio, input, output):
+    """init.lua:618-622."""
+    _check(input.dim() == 5 and output.dim() == 5, "ERROR: input and output must be dim 5")
+    _check(input.is_contiguous() and output.is_contiguous(), "Input is not contiguous")
+    lib, ctx = _context(input)
+    _call(lib, ctx, lib.tfl_volumetricUpSamplingNearestForward(ctx, int(ratio), _tt(input), _tt(output)))
+
+
+def volumetricUpSamplingNearestBackward(ratio, input, gradOutput, gradInput):
+    """init.lua:623-627."""
+    _check(input.dim() == 5 and gradOutput.dim() == 5 and gradInput.dim() == 5,
+           "ERROR: input, gradOutput and gradInput must be dim 5")
+    _check(gradOutput.is_contiguous() and gradInput.is_contiguous(), "Input is not contiguous")
+    lib, ctx = _context(input)
+    _call(lib, ctx, lib.tfl_volumetricUpSamplingNearestBackward(ctx, int(ratio), _tt(input), _tt(gradOutput),
+                                                                _tt(gradInput)))
+
+
 def vorticityConfinement(U, flags, strength):
     """init.lua:394-430 (in place on U)."""
     bsz, d, h, w, is3D = _dims(U, flags)

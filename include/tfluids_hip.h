@@ -144,6 +144,20 @@ int tfl_solveLinearSystemJacobi(tfl_ctx* ctx, const tfl_tensor* p, const tfl_ten
                                 const tfl_tensor* pDelta, const tfl_tensor* pDeltaNorm, int is3D,
                                 float pTol, int maxIter, int verbose, float* residual);
 
+/* ---- training-side callers and the multi-resolution resampler --------------------- */
+/* init.lua:310-313 -> generic/tfluids.cc:49-130 | generic/tfluids.cu:224-291. gradU is overwritten. */
+int tfl_velocityDivergenceBackward(tfl_ctx* ctx, const tfl_tensor* U, const tfl_tensor* flags,
+                                   const tfl_tensor* gradOutput, int is3D, const tfl_tensor* gradU);
+/* init.lua:358-383 -> generic/tfluids.cc:216-344 | generic/tfluids.cu:407-513. gradP is overwritten; each word
+ * gathers its contributions in the reference's serial order (deterministic; the reference scatters atomically). */
+int tfl_velocityUpdateBackward(tfl_ctx* ctx, const tfl_tensor* U, const tfl_tensor* flags, const tfl_tensor* p,
+                               const tfl_tensor* gradOutput, int is3D, const tfl_tensor* gradP);
+/* init.lua:618-627 -> generic/tfluids.cc:509-633 | generic/tfluids.cu:516-686. */
+int tfl_volumetricUpSamplingNearestForward(tfl_ctx* ctx, int ratio, const tfl_tensor* input,
+                                           const tfl_tensor* output);
+int tfl_volumetricUpSamplingNearestBackward(tfl_ctx* ctx, int ratio, const tfl_tensor* input,
+                                            const tfl_tensor* gradOutput, const tfl_tensor* gradInput);
+
 /* ---- the pressure-projection ConvNet (lib/model.lua `default` model, forward only) ---------- */
 /* In the reference the projection is `model:forward({pDiv, UDiv, flags})` on an nngraph of cudnn
  * convolutions and tfluids nn.Modules (lib/simulate.lua:262-272, lib/model.lua:27-401), not a

@@ -127,6 +127,23 @@ class OracleTfluids:
     def getDx(flags):
         return 1.0 / max(flags.shape[2], flags.shape[3], flags.shape[4])
 
+    def velocityDivergenceBackward(self, U, flags, gradOutput, gradU):
+        b, d, h, w = self._dims(flags)
+        self.lib.ora_velocityDivergenceBackward(_p(flags), _p(gradOutput), _p(gradU), int(U.shape[1] == 3), b, d, h, w)
+
+    def velocityUpdateBackward(self, U, flags, p, gradOutput, gradP):
+        b, d, h, w = self._dims(flags)
+        self.lib.ora_velocityUpdateBackward(_p(flags), _p(gradOutput), _p(gradP), int(U.shape[1] == 3), b, d, h, w)
+
+    def volumetricUpSamplingNearestForward(self, ratio, inp, out):
+        b, f, d, h, w = inp.shape
+        self.lib.ora_volumetricUpSamplingNearestForward(int(ratio), _p(inp), _p(out), ctypes.c_long(b * f), d, h, w)
+
+    def volumetricUpSamplingNearestBackward(self, ratio, inp, gradOutput, gradInput):
+        b, f, d, h, w = inp.shape
+        self.lib.ora_volumetricUpSamplingNearestBackward(int(ratio), _p(gradOutput), _p(gradInput),
+                                                         ctypes.c_long(b * f), d, h, w)
+
     def solveLinearSystemJacobi(self, p, flags, div, is3D, pTol=1e-5, maxIter=1000,
                                 verbose=False):
         b, d, h, w = self._dims(flags)

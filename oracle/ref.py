@@ -141,6 +141,25 @@ class RefTfluids:
         force = self._tmp((3,))[0]
         self.call("addGravity", U, flags, gravity, dt, U.shape[1] == 3, force)
 
+    def velocityDivergenceBackward(self, U, flags, gradOutput, gradU):
+        self.call("velocityDivergenceBackward", U, flags, gradOutput, U.shape[1] == 3, gradU)
+
+    def velocityUpdateBackward(self, U, flags, p, gradOutput, gradP):
+        # the reference scatters with `omp atomic`: one thread makes the summation order (and the last bit) fixed
+        omp = ctypes.CDLL("libgomp.so.1")
+        nthreads = omp.omp_get_max_threads()
+        omp.omp_set_num_threads(1)
+        try:
+            self.call("velocityUpdateBackward", U, flags, p, gradOutput, U.shape[1] == 3, gradP)
+        finally:
+            omp.omp_set_num_threads(nthreads)
+
+    def volumetricUpSamplingNearestForward(self, ratio, inp, out):
+        self.call("volumetricUpSamplingNearestForward", int(ratio), inp, out)
+
+    def volumetricUpSamplingNearestBackward(self, ratio, inp, gradOutput, gradInput):
+        self.call("volumetricUpSamplingNearestBackward", int(ratio), inp, gradOutput, gradInput)
+
     def emptyDomain(self, flags, is3D, bnd=1):
         self.call("emptyDomain", flags, bool(is3D), bnd)
         return flags

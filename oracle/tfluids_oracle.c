@@ -936,6 +936,101 @@ void ora_vorticityConfinement(float* U, const float* flags, float strength, floa
   }
 }
 
+/* ------------------------------------------------------------------------------------------
+ * Training-side operators and the nearest-neighbour resampler (8f-1).
+ * The reference scatters with `#pragma omp atomic`; with one thread its loop order (k, j, i ascending) fixes the
+ * order in which contributions reach a word. These restatements are that serial loop, no OpenMP, so they are
+ * deterministic and bit-equal to the reference run with one thread.
+ * ---------------------------------------------------------------------------------------- */
+/* generic/tfluids.cc:49-130 */
+void ora_velocityDivergenceBackward(const float* flags, const float* grad_out, float* grad_u, int is3d, int B,
+                                    int Z, int Y, int X) {
+  dom_t dm = mkdom(Z, Y, X, is3d);
+  const dom_t* d = &dm;
+  int C = is3d ? 3 : 2, b, i, j, k;
+  long N = (long)X * Y * Z;
+  for (b = 0; b < B; b++) {
+    const float* fb = flags + b * N;
+    const float* go = grad_out + b * N;
+    float* gu = grad_u + b * N * C;
+    memset(gu, 0, sizeof(float) * N * C);
+    for (k = 0; k < Z; k++)
+      for (j = 0; j < Y; j++)
+        for (i = 0; i < X; i++) {
+          float g;
+          if (on_border(d, i, j, k) || !is_fluid(d, fb, i, j, k)) continue;
+          g = go[AT(d, i, j, k)];
+          gu[ATC(d, i, j, k, 0)] += g; gu[ATC(d, i + 1, j, k, 0)] -= g;
+          gu[ATC(d, i, j, k, 1)] += g; gu[ATC(d, i, j + 1, k, 1)] -= g;
+          if (is3d) { gu[ATC(d, i, j, k, 2)] += g; gu[ATC(d, i, j, k + 1, 2)] -= g; }
+        }
+  }
+}
+
+/* generic/tfluids.cc:216-344 */
+void ora_velocityUpdateBackward(const float* flags, const float* grad_out, float* grad_p, int is3d, int B, int Z,
+                                int Y, int X) {
+  dom_t dm = mkdom(Z, Y, X, is3d);
+  const dom_t* d = &dm;
+  int C = is3d ? 3 : 2, b, i, j, k;
+  long N = (long)X * Y * Z;
+  for (b = 0; b < B; b++) {
+    const float* fb = flags + b * N;
+    const float* go = grad_out + b * N * C;
+    float* gp = grad_p + b * N;
+    memset(gp, 0, sizeof(float) * N);
+    for (k = 0; k < Z; k++)
+      for (j = 0; j < Y; j++)
+        for (i = 0; i < X; i++) {
+          float gx, gy, gz;
+          if (on_border(d, i, j, k)) continue;
+          gx = go[ATC(d, i, j, k, 0)]; gy = go[ATC(d, i, j, k, 1)]; gz = is3d ? go[ATC(d, i, j, k, 2)] : 0.0f;
+          if (is_fluid(d, fb, i, j, k)) {
+            if (is_fluid(d, fb, i - 1, j, k)) { gp[AT(d, i, j, k)] -= gx; gp[AT(d, i - 1, j, k)] += gx; }
+            if (is_fluid(d, fb, i, j - 1, k)) { gp[AT(d, i, j, k)] -= gy; gp[AT(d, i, j - 1, k)] += gy; }
+            if (is3d && is_fluid(d, fb, i, j, k - 1)) { gp[AT(d, i, j, k)] -= gz; gp[AT(d, i, j, k - 1)] += gz; }
+            if (is_empty(d, fb, i - 1, j, k)) gp[AT(d, i, j, k)] -= gx;
+            if (is_empty(d, fb, i, j - 1, k)) gp[AT(d, i, j, k)] -= gy;
+            if (is3d && is_empty(d, fb, i, j, k - 1)) gp[AT(d, i, j, k)] -= gz;
+          } else if (is_empty(d, fb, i, j, k) && !is_outflow(d, fb, i, j, k)) {
+            if (is_fluid(d, fb, i - 1, j, k)) gp[AT(d, i - 1, j, k)] += gx;
+            if (is_fluid(d, fb, i, j - 1, k)) gp[AT(d, i, j - 1, k)] += gy;
+            if (is3d && is_fluid(d, fb, i, j, k - 1)) gp[AT(d, i, j, k - 1)] += gz;
+          }
+        }
+  }
+}
+
+/* generic/tfluids.cc:509-556; rows = B * nfeat */
+void ora_volumetricUpSamplingNearestForward(int ratio, const float* in, float* out, long rows, int Zi, int Yi,
+                                            int Xi) {
+  long r; int z, y, x;
+  int Zo = Zi * ratio, Yo = Yi * ratio, Xo = Xi * ratio;
+  for (r = 0; r < rows; r++)
+    for (z = 0; z < Zo; z++)
+      for (y = 0; y < Yo; y++)
+        for (x = 0; x < Xo; x++)
+          out[((r * Zo + z) * Yo + y) * (long)Xo + x] = in[((r * Zi + z / ratio) * Yi + y / ratio) * (long)Xi + x / ratio];
+}
+
+/* generic/tfluids.cc:562-633 (float accumulator, window order z, y, x) */
+void ora_volumetricUpSamplingNearestBackward(int ratio, const float* grad_out, float* grad_in, long rows, int Zi,
+                                             int Yi, int Xi) {
+  long r; int z, y, x, zu, yu, xu;
+  int Zo = Zi * ratio, Yo = Yi * ratio, Xo = Xi * ratio;
+  for (r = 0; r < rows; r++)
+    for (z = 0; z < Zi; z++)
+      for (y = 0; y < Yi; y++)
+        for (x = 0; x < Xi; x++) {
+          float sum = 0.0f;
+          for (zu = 0; zu < ratio; zu++)
+            for (yu = 0; yu < ratio; yu++)
+              for (xu = 0; xu < ratio; xu++)
+                sum += grad_out[((r * Zo + z * ratio + zu) * Yo + y * ratio + yu) * (long)Xo + x * ratio + xu];
+          grad_in[((r * Zi + z) * Yi + y) * (long)Xi + x] = sum;
+        }
+}
+
 /* generic/tfluids.cc:136-167 */
 void ora_emptyDomain(float* flags, int is3d, int bnd, int B, int Z, int Y, int X) {
   long N = (long)X * Y * Z;

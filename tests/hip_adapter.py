@@ -63,6 +63,26 @@ class HipTfluids:
         self._inplace_u(tfluids.addGravity, U, self._up(flags), [float(g) for g in gravity],
                         float(dt))
 
+    def velocityDivergenceBackward(self, U, flags, gradOutput, gradU):
+        tg = self._up(gradU)
+        tfluids.velocityDivergenceBackward(self._up(U), self._up(flags), self._up(gradOutput), tg)
+        gradU[...] = tg.cpu().numpy()
+
+    def velocityUpdateBackward(self, U, flags, p, gradOutput, gradP):
+        tg = self._up(gradP)
+        tfluids.velocityUpdateBackward(self._up(U), self._up(flags), self._up(p), self._up(gradOutput), tg)
+        gradP[...] = tg.cpu().numpy()
+
+    def volumetricUpSamplingNearestForward(self, ratio, inp, out):
+        to = self._up(out)
+        tfluids.volumetricUpSamplingNearestForward(ratio, self._up(inp), to)
+        out[...] = to.cpu().numpy()
+
+    def volumetricUpSamplingNearestBackward(self, ratio, inp, gradOutput, gradInput):
+        tg = self._up(gradInput)
+        tfluids.volumetricUpSamplingNearestBackward(ratio, self._up(inp), self._up(gradOutput), tg)
+        gradInput[...] = tg.cpu().numpy()
+
     def emptyDomain(self, flags, is3D, bnd=1):
         tf = self._up(flags)
         tfluids.emptyDomain(tf, is3D, bnd)

@@ -231,3 +231,15 @@ def test_hip_fullsize_properties(res):
                        torch.full((1, res - 4, res - 4, res - 3), -0.25, device=dev))
     assert float(Uu[:, 1:].abs().max()) == 0.0
     assert tfluids.traceErrors(s) == 0
+
+
+from backward_cases import CASES as BWD_CASES, run_backward_ops  # noqa: E402
+
+
+@pytest.mark.parametrize("dims,seed,kw", BWD_CASES)
+def test_hip_backward_ops_bit_exact(hip, oracle, dims, seed, kw):
+    """velocityDivergenceBackward / velocityUpdateBackward / volumetricUpSamplingNearest{Forward,Backward}: the
+    gather kernels reproduce the reference's serial summation order bit for bit."""
+    a, b = run_backward_ops(hip, dims, seed, **kw), run_backward_ops(oracle, dims, seed, **kw)
+    for k in sorted(b):
+        assert np.array_equal(a[k], b[k]), (k, int((a[k] != b[k]).sum()))

@@ -190,3 +190,28 @@ def test_jacobi_converges_to_divergence_free(oracle, dims):
     oracle.velocityUpdateForward(U, f, p)
     oracle.velocityDivergenceForward(U, f, div)
     assert np.abs(div).max() < 2e-4 * max(1.0, np.abs(sc["U"]).max())
+
+
+# ---- training-side operators + resampler -------------------------------------------------
+from backward_cases import CASES as BWD_CASES, run_backward_ops  # noqa: E402
+
+
+@pytest.mark.parametrize("dims,seed,kw", BWD_CASES)
+def test_backward_ops_oracle_matches_reference_bitwise(oracle, ref, dims, seed, kw):
+    a, b = run_backward_ops(oracle, dims, seed, **kw), run_backward_ops(ref, dims, seed, **kw)
+    for k in sorted(a):
+        assert np.array_equal(a[k], b[k]), k
+
+
+def test_divergence_backward_is_the_adjoint(oracle):
+    """<div(U), g> == <U, divBackward(g)> for any U: the backward op is the exact transpose of the forward."""
+    sc = scenes.make_scene((7, 9, 11), seed=95, vel_cells=1.0)
+    rng = np.random.RandomState(1)
+    g = rng.randn(*sc["p"].shape).astype(np.float32)
+    div = np.zeros_like(sc["p"])
+    oracle.velocityDivergenceForward(sc["U"], sc["flags"], div)
+    gU = np.zeros_like(sc["U"])
+    oracle.velocityDivergenceBackward(sc["U"], sc["flags"], g, gU)
+    lhs = float((div.astype(np.float64) * g).sum())
+    rhs = float((sc["U"].astype(np.float64) * gU).sum())
+    assert abs(lhs - rhs) <= 1e-4 * max(abs(lhs), 1.0)
