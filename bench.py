@@ -124,11 +124,18 @@ def main():
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
+    # TFL_DIST_BACKEND=gloo (+ ranks sharing GPUs) exists only to validate the multi-rank control flow on a box
+    # with fewer GPUs than ranks; the measured configuration is one rank per GPU over nccl (= RCCL).
+    backend = os.environ.get("TFL_DIST_BACKEND", "nccl")
+    local = local % torch.cuda.device_count() if backend != "nccl" else local
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from fluidnet_amd import FluidNetModel, tfluids
     from fluidnet_amd.simulate import simulate
@@ -153,6 +160,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+
     for _ in range(args.preroll + args.warmup):
         step()
     barrier()
@@ -163,7 +171,7 @@ def main():
     elapsed = time.perf_counter() - t0
     if world > 1:
         import torch.distributed as dist
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     assert bool(torch.isfinite(batch["UDiv"]).all()), "simulation blew up"

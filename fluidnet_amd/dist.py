@@ -100,6 +100,9 @@ class DistComm:
         self.dist = dist
         self.group = group
         self._bufs = {}   # (direction, numel) -> (send, recv) message buffers, allocated once
+        # gloo moves host memory: GPU messages are staged through the host. Only used to validate the multi-rank
+        # control flow on a box without one GPU per rank (TFL_DIST_BACKEND=gloo); production = nccl (RCCL).
+        self.stage_host = dist.get_backend(group) == "gloo"
 
     def _buffers(self, key, fields, a, b):
         n = _msg_numel(fields, a, b)
@@ -125,13 +128,29 @@ class DistComm:
             ops += [dist.P2POp(dist.isend, send, lay.rank + 1, self.group),
                     dist.P2POp(dist.irecv, recv, lay.rank + 1, self.group)]
             recvs.append((recv, lay.c1, lay.c1 + h))
-        if ops:
+        if ops and self.stage_host and fields[0].is_cuda:
+            host_ops, pairs = [], []
+            for op in ops:
+                h = op.tensor.cpu() if op.op == dist.isend else torch.empty(op.tensor.shape, dtype=op.tensor.dtype)
+                host_ops.append(dist.P2POp(op.op, h, op.peer, self.group))
+                if op.op == dist.irecv:
+                    pairs.append((op.tensor, h))
+            for w in dist.batch_isend_irecv(host_ops):
+                w.wait()
+            for dev_t, h in pairs:
+                dev_t.copy_(h)
+        elif ops:
             for w in dist.batch_isend_irecv(ops):
                 w.wait()
         for buf, a, b in recvs:
             _unpack(buf, fields, a, b)
 
     def allreduce_sum(self, t):
+        if self.stage_host and t.is_cuda:
+            h = t.cpu()
+            self.dist.all_reduce(h, op=self.dist.ReduceOp.SUM, group=self.group)
+            t.copy_(h)
+            return
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
 
 
