@@ -6,7 +6,7 @@
  * to /root/reference/torch/tfluids). It is never linked into, imported by, or called from the
  * product; only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use it.
  *
- * PINNING: every function here is checked bit-for-bit (tests/test_oracle_vs_ref.py) against the
+ * PINNING: every function here is checked bit-for-bit (tests/test_oracle.py) against the
  * reference's own sources compiled in this container (oracle/_ref, recipe in oracle/Makefile),
  * against golden vectors generated from that build (tests/golden/, generator
  * tests/golden/make_golden.py) and against the portable known-answer cases of
