@@ -86,6 +86,15 @@ void conv3_mfma_tail(hipStream_t st, int B, int Z, int Y, int X, const float* in
                      const float* bias, const float* w4, const float* b4, const float* w5, const float* b5,
                      float* p_out);
 
+// conv_mfma_ws.hip: the same layers, wave-specialised (4 MFMA waves + 4 load/store waves per persistent block)
+void conv3_ws_first_fused(hipStream_t st, int B, int Z, int Y, int X, const float* pDiv, const float* div,
+                          const float* flags, const double* stats, double count, const float* bfrag, const float* bias,
+                          float* out_cl8);
+void conv3_ws_mid(hipStream_t st, int B, int Z, int Y, int X, const float* in_cl8, const float* bfrag, const float* bias,
+                  float* out_cl8);
+void conv3_ws_tail(hipStream_t st, int B, int Z, int Y, int X, const float* in_cl8, const float* bfrag, const float* bias,
+                   const float* w4, const float* b4, const float* w5, const float* b5, float* p_out);
+
 // backward.hip
 void velocity_divergence_bwd(hipStream_t st, bool is3d, int B, int Z, int Y, int X, const float* flags,
                              const float* grad_out, float* grad_U);
