@@ -55,3 +55,24 @@ def test_cpu_tensors_are_refused():
     from fluidnet_amd import tfluids, TfluidsError
     with pytest.raises(TfluidsError):
         tfluids.setWallBcsForward(torch.zeros(1, 2, 1, 8, 8), torch.ones(1, 1, 1, 8, 8))
+
+
+def _build_c_example(tmp_path):
+    exe = str(tmp_path / "step_from_c")
+    subprocess.check_call(["gcc", "-std=c99", "-D__HIP_PLATFORM_AMD__", os.path.join(ROOT, "examples", "step_from_c.c"),
+                           "-I" + os.path.join(ROOT, "include"), "-I/opt/rocm/include",
+                           "-L" + os.path.join(ROOT, "fluidnet_amd"), "-ltfluids_hip", "-L/opt/rocm/lib", "-lamdhip64", "-lm",
+                           "-Wl,-rpath," + os.path.join(ROOT, "fluidnet_amd"), "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+    return exe
+
+
+def test_plain_c_host_links_against_the_abi(lib_path, tmp_path):
+    """A C99 translation unit that includes only tfluids_hip.h compiles (gcc, not hipcc) and links: the boundary
+    has no C++/torch types in it (what a cgo / JNI / LuaJIT-FFI binding relies on)."""
+    assert os.path.exists(_build_c_example(tmp_path))
+
+
+@pytest.mark.gpu
+def test_plain_c_host_runs(lib_path, tmp_path):
+    out = subprocess.run([_build_c_example(tmp_path)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "OK" in out.stdout, out.stdout + out.stderr
