@@ -14,6 +14,7 @@
 // flags -> dst), advectVel 68 B (A: U3,flags -> fwd3; B: fwd3,U3,flags -> dst3); SURVEY.md 8d.
 #include "tfl_device.hpp"
 #include "tfl_host.hpp"
+#include "tfl_vec4.hpp"
 
 #include <cstdlib>
 #include <cstring>
@@ -228,6 +229,54 @@ __global__ __launch_bounds__(256) void k_minmax3(Dom d, int outside, const float
   lo3[o] = lo; hi3[o] = hi;
 }
 
+// The same grid with four x-cells per thread and no LDS (tfl_vec4.hpp): per cell row of the 3^dim
+// neighbourhood one 16-byte load of src and of flags; a masked-out cell is carried as NaN (every
+// comparison with it is false -- exactly the reference's "skip", and a NaN in src itself is skipped by the
+// reference's comparisons too), so ONE value per cell crosses lanes. Same ascending z,y,x visiting order
+// as getClampBounds (matters only for the sign of a zero bound).
+template <bool IS3D>
+__global__ __launch_bounds__(256) void k_minmax3_v4(Dom d, int outside, const float* __restrict__ s,
+                                                    const float* __restrict__ flags, float* __restrict__ lo3,
+                                                    float* __restrict__ hi3) {
+  const V4Ctx c = v4_ctx(d);
+  const int j = blockIdx.y * blockDim.y + threadIdx.y;
+  const int b = blockIdx.z / d.Z, k = blockIdx.z - b * d.Z;
+  const bool live = c.i0 < d.X && j < d.Y;
+  const long long cells = d.sc;
+  s += b * cells; flags += b * cells; lo3 += b * cells; hi3 += b * cells;
+  const float qnan = __builtin_nanf("");
+  float lo[4], hi[4];
+#pragma unroll
+  for (int q = 0; q < 4; q++) { lo[q] = __builtin_inff(); hi[q] = -__builtin_inff(); }
+  auto masked = [&](float v, float f) { return (outside || (((int)f) & kFluid)) ? v : qnan; };
+#pragma unroll
+  for (int dz = (IS3D ? -1 : 0); dz <= (IS3D ? 1 : 0); dz++)
+#pragma unroll
+    for (int dy = -1; dy <= 1; dy++) {
+      const int jj = j + dy, kk = k + dz;
+      const bool ok = live && jj >= 0 && jj < d.Y && kk >= 0 && kk < d.Z;
+      const int o = TFL_AT(d, c.i0, jj, kk);
+      float sv[4], fv[4], e[6];
+      v4_load(s, o, ok, qnan, sv);
+      v4_load(flags, o, ok, 0.0f, fv);
+#pragma unroll
+      for (int q = 0; q < 4; q++) e[q + 1] = ok ? masked(sv[q], fv[q]) : qnan;
+      e[0] = from_lane_below(e[4]);
+      e[5] = from_lane_above(e[1]);
+      if (c.first) e[0] = (ok && c.has_l) ? masked(s[o - 1], flags[o - 1]) : qnan;
+      if (c.last) e[5] = (ok && c.has_r) ? masked(s[o + 4], flags[o + 4]) : qnan;
+#pragma unroll
+      for (int q = 0; q < 4; q++)
+#pragma unroll
+        for (int t = 0; t < 3; t++) minmax(lo[q], hi[q], e[q + t]);
+    }
+  if (live) {
+    const int o = TFL_AT(d, c.i0, j, k);
+    v4_store(lo3, o, lo);
+    v4_store(hi3, o, hi);
+  }
+}
+
 // ---- advectScalar ------------------------------------------------------------------------------
 // Pass A / single-pass methods. For kMacCormackOurs the clamp bounds go to bounds[0], bounds[1]
 // (two channel planes of the caller's fwdPos temp; empty neighbourhood is stored as lo=+inf > hi).
@@ -402,7 +451,7 @@ static void launch_scalar(hipStream_t st, int method, const AdvArgs& a, int B, c
       { TFL_TIMED("k_scalar_bwd", st); k_scalar_bwd<IS3D, kMacCormack><<<grd, blk, 0, st>>>(a, s, U, flags, fwd, nullptr, dst); }
       break;
     default:
-      { TFL_TIMED("k_minmax3", st); k_minmax3<IS3D><<<grd, blk, 0, st>>>(a.d, a.outside, s, flags, mm, mm + (long long)B * a.d.sc); }
+      minmax3(st, IS3D, B, a.d.Z, a.d.Y, a.d.X, a.outside, s, flags, mm, mm + (long long)B * a.d.sc);
       { TFL_TIMED("k_scalar_fwd", st); k_scalar_fwd<IS3D, kMacCormackOurs><<<grd, blk, 0, st>>>(a, s, U, flags, fwd, bounds, mm, mm + (long long)B * a.d.sc); }
       { TFL_TIMED("k_scalar_bwd", st); k_scalar_bwd<IS3D, kMacCormackOurs><<<grd, blk, 0, st>>>(a, s, U, flags, fwd, bounds, dst); }
       break;
@@ -426,6 +475,12 @@ void minmax3(hipStream_t st, bool is3d, int B, int Z, int Y, int X, int outside,
   const Dom d = make_dom(Z, Y, X);
   const dim3 blk(64, 4, 1), grd = cell_grid(d, B, blk);
   TFL_TIMED("k_minmax3", st);
+  const Vec4Launch v = vec4_launch(B, Z, Y, X, {s, flags, lo3, hi3});
+  if (v.ok) {
+    if (is3d) k_minmax3_v4<true><<<v.grd, v.blk, 0, st>>>(d, outside, s, flags, lo3, hi3);
+    else k_minmax3_v4<false><<<v.grd, v.blk, 0, st>>>(d, outside, s, flags, lo3, hi3);
+    return;
+  }
   if (is3d) k_minmax3<true><<<grd, blk, 0, st>>>(d, outside, s, flags, lo3, hi3);
   else k_minmax3<false><<<grd, blk, 0, st>>>(d, outside, s, flags, lo3, hi3);
 }

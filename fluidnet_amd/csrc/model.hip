@@ -14,6 +14,7 @@
 //                     setConstVals + clamp (lib/simulate.lua:321-326)
 #include "tfl_device.hpp"
 #include "tfl_host.hpp"
+#include "tfl_vec4.hpp"
 
 #include <cstdlib>
 
@@ -96,6 +97,115 @@ __global__ __launch_bounds__(256) void k_bcs_div_stats(Dom d, const float* __res
       if (IS3D) dv += (uz - u_bc_at<IS3D, 2>(d, U, flags, i, j, k + 1));
     }
     div[o] = dv;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { s1 += __shfl_down(s1, off, 64); s2 += __shfl_down(s2, off, 64); }
+  __shared__ double part[8];
+  const int tid = threadIdx.y * blockDim.x + threadIdx.x;
+  if ((tid & 63) == 0) { part[(tid >> 6) * 2] = s1; part[(tid >> 6) * 2 + 1] = s2; }
+  __syncthreads();
+  if (tid == 0) {
+    const long long blk = blockIdx.x + (long long)gridDim.x * (blockIdx.y + (long long)gridDim.y * blockIdx.z);
+    partials[blk * 2] = (part[0] + part[2]) + (part[4] + part[6]);
+    partials[blk * 2 + 1] = (part[1] + part[3]) + (part[5] + part[7]);
+  }
+}
+
+// k_bcs_div_stats with four x-cells per thread (tfl_vec4.hpp). The wall-BC masks of the cell's +x / +y / +z
+// neighbours (needed for the divergence of U_bc) are rebuilt in registers from the flag rows already
+// loaded for the cell's own mask plus four more rows (the stick test of the +y / +z neighbour looks two rows
+// away); U_bc.x of cell i0+4 comes from the next lane. ~26 vector loads per 4 cells instead of ~120 dword loads.
+template <bool IS3D>
+__global__ __launch_bounds__(256) void k_bcs_div_stats_v4(Dom d, const float* __restrict__ U, const float* __restrict__ flags,
+                                                          float* __restrict__ Ubc, float* __restrict__ div,
+                                                          double* __restrict__ partials) {
+  const V4Ctx c = v4_ctx(d);
+  const int j = blockIdx.y * blockDim.y + threadIdx.y;
+  const int b = blockIdx.z / d.Z, k = blockIdx.z - b * d.Z;
+  const bool live = c.i0 < d.X && j < d.Y;
+  const long long cells = d.sc;
+  const int C = IS3D ? 3 : 2;
+  U += b * cells * C; Ubc += b * cells * C; flags += b * cells; div += b * cells;
+  const int o = TFL_AT(d, c.i0, j, k);
+  const bool ym = live && j > 0, yp = live && j < d.Y - 1, yp2 = live && j < d.Y - 2;
+  const bool zm = live && IS3D && k > 0, zp = live && IS3D && k < d.Z - 1, zp2 = live && IS3D && k < d.Z - 2;
+  // flag rows: own (6 wide), y-1, y+1 (6 wide), z-1, z+1 (6 wide); for the +y / +z neighbours' stick tests:
+  // (y+2,z), (y+1,z-1), (y+1,z+1), (y,z+2), (y-1,z+1)
+  float fc[6], fym[4], fyp[6], fzm[4], fzp[6], fyp2[4], fypzm[4], fypzp[4], fzp2[4], fymzp[4];
+  v4_load6<true, true>(c, flags, o, live, 0.0f, fc);
+  v4_load(flags, o - d.sy, ym, 0.0f, fym);
+  v4_load6<true, true>(c, flags, o + d.sy, yp, 0.0f, fyp);
+  v4_load(flags, o - d.sz, zm, 0.0f, fzm);
+  v4_load6<true, true>(c, flags, o + d.sz, zp, 0.0f, fzp);
+  v4_load(flags, o + 2 * d.sy, yp2, 0.0f, fyp2);
+  v4_load(flags, o + d.sy - d.sz, yp && zm, 0.0f, fypzm);
+  v4_load(flags, o + d.sy + d.sz, yp && zp, 0.0f, fypzp);
+  v4_load(flags, o + 2 * d.sz, zp2, 0.0f, fzp2);
+  v4_load(flags, o - d.sy + d.sz, ym && zp, 0.0f, fymzp);
+  float u[3][4], uyp[4], uzp[4];
+#pragma unroll
+  for (int a = 0; a < 3; a++) v4_load(U, o + a * d.sc, live && a < C, 0.0f, u[a]);
+  v4_load(U, o + d.sc + d.sy, yp, 0.0f, uyp);
+  v4_load(U, o + 2 * d.sc + d.sz, zp, 0.0f, uzp);
+  // own cells
+  double s1 = 0.0, s2 = 0.0;
+  float ubx[5];
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    bool zx, zy, zz;
+    wall_mask_from<IS3D>((int)fc[q + 1], (int)fc[q], (int)fc[q + 2], (int)fym[q], (int)fyp[q + 1], (int)fzm[q], (int)fzp[q + 1],
+                         zx, zy, zz);
+    if (zx) u[0][q] = 0.0f;
+    if (zy) u[1][q] = 0.0f;
+    if (!IS3D || zz) u[2][q] = 0.0f;
+    ubx[q] = u[0][q];
+    if (live) {
+      s1 += (double)u[0][q] + (double)u[1][q] + (double)u[2][q];
+      s2 += (double)u[0][q] * u[0][q] + (double)u[1][q] * u[1][q] + (double)u[2][q] * u[2][q];
+    }
+  }
+  // U_bc.x of cell i0+4: the next lane's first cell, or (segment end) rebuilt from memory
+  ubx[4] = from_lane_above(ubx[0]);
+  if (c.last) {
+    float v = 0.0f;
+    if (live && c.has_r) {
+      const int oo = o + 4;
+      const int f = (int)fc[5];
+      bool zx, zy, zz;
+      wall_mask_from<IS3D>(f, (int)fc[4], 0, ym ? (int)flags[oo - d.sy] : 0, yp ? (int)flags[oo + d.sy] : 0,
+                           zm ? (int)flags[oo - d.sz] : 0, zp ? (int)flags[oo + d.sz] : 0, zx, zy, zz);
+      v = zx ? 0.0f : U[oo];
+    }
+    ubx[4] = v;
+  }
+  float dv[4];
+  const bool row_inner = live && j >= 1 && j <= d.Y - 2 && (!IS3D || (k >= 1 && k <= d.Z - 2));
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const int i = c.i0 + q;
+    dv[q] = 0.0f;
+    if (row_inner && i >= 1 && i <= d.X - 2 && (((int)fc[q + 1]) & kFluid)) {   // tfluids.cc:1008-1066 on U_bc
+      bool zx, zy, zz;
+      // +y neighbour (i, j+1, k): its -y neighbour is this cell
+      wall_mask_from<IS3D>((int)fyp[q + 1], (int)fyp[q], (int)fyp[q + 2], (int)fc[q + 1], (int)fyp2[q], (int)fypzm[q],
+                           (int)fypzp[q], zx, zy, zz);
+      const float by = zy ? 0.0f : uyp[q];
+      float t = u[0][q] - ubx[q + 1] + u[1][q] - by;
+      if (IS3D) {
+        // +z neighbour (i, j, k+1): its -z neighbour is this cell
+        wall_mask_from<IS3D>((int)fzp[q + 1], (int)fzp[q], (int)fzp[q + 2], (int)fymzp[q], (int)fypzp[q], (int)fc[q + 1],
+                             (int)fzp2[q], zx, zy, zz);
+        const float bz = zz ? 0.0f : uzp[q];
+        t += (u[2][q] - bz);
+      }
+      dv[q] = t;
+    }
+  }
+  if (live) {
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+      if (a < C) v4_store(Ubc, o + a * d.sc, u[a]);
+    v4_store(div, o, dv);
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) { s1 += __shfl_down(s1, off, 64); s2 += __shfl_down(s2, off, 64); }
@@ -343,10 +453,16 @@ void model_pre(hipStream_t st, bool is3d, int B, int Z, int Y, int X, const floa
                float* div, double* partials, double* stats, int zlo, int zhi) {
   const Dom d = make_dom(Z, Y, X);
   const dim3 blk(64, 4, 1), grd = TFL_GRID3(d, B);
-  if (is3d) { TFL_TIMED("k_bcs_div_stats", st); k_bcs_div_stats<true><<<grd, blk, 0, st>>>(d, U, flags, Ubc, div, partials); }
+  const Vec4Launch v = vec4_launch(B, Z, Y, X, {U, flags, Ubc, div});
+  long long per_plane = (long long)grd.x * grd.y;   // partials per z-plane (never more than model_stat_blocks assumes)
+  if (v.ok) {
+    per_plane = (long long)v.grd.x * v.grd.y;
+    TFL_TIMED("k_bcs_div_stats", st);
+    if (is3d) k_bcs_div_stats_v4<true><<<v.grd, v.blk, 0, st>>>(d, U, flags, Ubc, div, partials);
+    else k_bcs_div_stats_v4<false><<<v.grd, v.blk, 0, st>>>(d, U, flags, Ubc, div, partials);
+  } else if (is3d) { TFL_TIMED("k_bcs_div_stats", st); k_bcs_div_stats<true><<<grd, blk, 0, st>>>(d, U, flags, Ubc, div, partials); }
   else { TFL_TIMED("k_bcs_div_stats", st); k_bcs_div_stats<false><<<grd, blk, 0, st>>>(d, U, flags, Ubc, div, partials); }
-  { TFL_TIMED("k_reduce_stats", st); k_reduce_stats<<<B, 256, 0, st>>>(partials, model_stat_blocks(1, Z, Y, X), model_stat_blocks(1, zlo, Y, X),
-                                         model_stat_blocks(1, zhi - zlo, Y, X), stats); }
+  { TFL_TIMED("k_reduce_stats", st); k_reduce_stats<<<B, 256, 0, st>>>(partials, per_plane * Z, per_plane * zlo, per_plane * (zhi - zlo), stats); }
 }
 
 void model_net_input(hipStream_t st, bool is3d, int B, int Z, int Y, int X, const float* pDiv, const float* div,

@@ -1,0 +1,93 @@
+// tfl_vec4.hpp -- "four x-cells per thread" building blocks for the streaming stencil kernels (gfx950).
+//
+// A thread owns cells i0..i0+3 of one grid row and moves them as one 16-byte vector (global_load_dwordx4:
+// a wave moves 1 KB per instruction instead of 256 B). Stencil taps at i0-1 / i0+4 live in the float4 of
+// the neighbouring LANE: they are fetched with a DPP wave shift (one v_mov_b32_dpp, no memory traffic);
+// only the first / last lane of a row segment goes to memory for them.
+//
+// Launch contract (vec4_launch): blockDim = (BX, 256/BX, 1) with BX a power of two <= 32, so that the BX
+// threads of a row segment are BX consecutive lanes of one wave; X % 4 == 0 and every pointer 16-byte
+// aligned. Kernels built on these helpers must not return before their last DPP (a lane that has left
+// delivers garbage to its neighbour): they predicate loads and stores instead.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdlib>
+#include <initializer_list>
+
+#include "tfl_device.hpp"
+
+namespace tfl {
+
+// value held by lane-1 / lane+1 of the wave (undefined for lane 0 / 63: callers patch segment ends)
+__device__ __forceinline__ float from_lane_below(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x138 /*wave_shr:1*/, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float from_lane_above(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x130 /*wave_shl:1*/, 0xf, 0xf, false));
+}
+
+struct V4Ctx {
+  int i0;        // first of the thread's four cells
+  bool first;    // first lane of the row segment (its i0-1 neighbour is not in a lane)
+  bool last;     // last lane of the row segment, or the last float4 of the grid row
+  bool has_l;    // cell i0-1 exists
+  bool has_r;    // cell i0+4 exists
+};
+__device__ __forceinline__ V4Ctx v4_ctx(const Dom& d) {
+  V4Ctx c;
+  c.i0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  c.first = threadIdx.x == 0;
+  c.last = threadIdx.x == blockDim.x - 1 || c.i0 + 4 >= d.X;
+  c.has_l = c.i0 > 0;
+  c.has_r = c.i0 + 4 < d.X;
+  return c;
+}
+
+// r[0..3] = p[o..o+3] (pad when !ok)
+__device__ __forceinline__ void v4_load(const float* __restrict__ p, int o, bool ok, float pad, float* r) {
+  float4 v = make_float4(pad, pad, pad, pad);
+  if (ok) v = *reinterpret_cast<const float4*>(p + o);
+  r[0] = v.x; r[1] = v.y; r[2] = v.z; r[3] = v.w;
+}
+__device__ __forceinline__ void v4_store(float* __restrict__ p, int o, const float* r) {
+  *reinterpret_cast<float4*>(p + o) = make_float4(r[0], r[1], r[2], r[3]);
+}
+// e[0..5] = cells i0-1 .. i0+4 given e[1..4] already in registers (pad outside the grid / when !ok).
+// EVERY lane of the wave must call this (DPP).
+template <bool LEFT, bool RIGHT>
+__device__ __forceinline__ void v4_edges(const V4Ctx& c, const float* __restrict__ p, int o, bool ok, float pad, float* e) {
+  if (LEFT) {
+    e[0] = from_lane_below(e[4]);
+    if (c.first) e[0] = (ok && c.has_l) ? p[o - 1] : pad;
+  }
+  if (RIGHT) {
+    e[5] = from_lane_above(e[1]);
+    if (c.last) e[5] = (ok && c.has_r) ? p[o + 4] : pad;
+  }
+}
+// e[0..5] = p[o-1 .. o+4]
+template <bool LEFT, bool RIGHT>
+__device__ __forceinline__ void v4_load6(const V4Ctx& c, const float* __restrict__ p, int o, bool ok, float pad, float* e) {
+  v4_load(p, o, ok, pad, e + 1);
+  v4_edges<LEFT, RIGHT>(c, p, o, ok, pad, e);
+}
+
+// Host side: launch geometry for a vec4 kernel, or ok=false when the contract does not hold (odd X, a
+// misaligned view, or TFL_NO_VEC4 set: callers then fall back to their one-cell-per-thread kernel).
+struct Vec4Launch { bool ok; dim3 blk, grd; };
+inline Vec4Launch vec4_launch(int B, int Z, int Y, int X, std::initializer_list<const void*> ptrs) {
+  Vec4Launch l; l.ok = false;
+  static const bool disabled = getenv("TFL_NO_VEC4") != nullptr;
+  uintptr_t al = 0;
+  for (const void* q : ptrs) al |= (uintptr_t)q;
+  if (disabled || X % 4 != 0 || (al & 15) != 0) return l;
+  const int nx = X / 4, bx = nx <= 8 ? 8 : (nx <= 16 ? 16 : 32), by = 256 / bx;
+  l.blk = dim3(bx, by, 1);
+  l.grd = dim3((nx + bx - 1) / bx, (Y + by - 1) / by, (unsigned)(Z * B));
+  l.ok = true;
+  return l;
+}
+
+}  // namespace tfl

@@ -10,6 +10,7 @@
 // Algorithmic bytes per cell (3-D): A 7 words + B 11 words = 72 B. HBM-bound.
 #include "tfl_device.hpp"
 #include "tfl_host.hpp"
+#include "tfl_vec4.hpp"
 
 namespace tfl {
 
@@ -89,10 +90,208 @@ __global__ __launch_bounds__(256) void k_confine(Dom d, float* __restrict__ U, c
   if (az) U[o + 2 * d.sc] += (0.5f * (force_at<IS3D>(d, curl, cn, strength, i, j, k - 1).z + f0.z));
 }
 
+// ---- four x-cells per thread (tfl_vec4.hpp): same per-cell arithmetic, 16-byte accesses -----------------
+// k_curl_v4: 16 row loads per 4 cells instead of 24 dword loads per cell. Tap (i+-1, j+-1, k+-1) of a
+// non-border cell is on the border shell iff its moved coordinate is 0 or N-1 -> contributes 0.
+template <bool IS3D>
+__global__ __launch_bounds__(256) void k_curl_v4(Dom d, const float* __restrict__ U, float* __restrict__ curl,
+                                                 float* __restrict__ cnorm) {
+  const V4Ctx c = v4_ctx(d);
+  const int j = blockIdx.y * blockDim.y + threadIdx.y;
+  const int b = blockIdx.z / d.Z, k = blockIdx.z - b * d.Z;
+  const bool live = c.i0 < d.X && j < d.Y;
+  const long long cells = d.sc;
+  U += b * cells * (IS3D ? 3 : 2); curl += b * cells * 3; cnorm += b * cells;
+  const int o = TFL_AT(d, c.i0, j, k);
+  const bool in = live && j >= 1 && j <= d.Y - 2 && (!IS3D || (k >= 1 && k <= d.Z - 2));   // not a border row
+  const float* Ux = U;
+  const float* Uy = U + d.sc;
+  const float* Uz = U + 2 * d.sc;   // only touched when IS3D
+  const bool ypb = j + 1 == d.Y - 1, ymb = j - 1 == 0, zpb = k + 1 == d.Z - 1, zmb = k - 1 == 0;
+  float uy_a[6], uy_b[6], ux_p[6], ux_m[6];
+  v4_load6<true, true>(c, Uy, o, in, 0.0f, uy_a);
+  v4_load6<true, true>(c, Uy, o + d.sy, in, 0.0f, uy_b);
+  v4_load6<false, true>(c, Ux, o + d.sy, in, 0.0f, ux_p);
+  v4_load6<false, true>(c, Ux, o - d.sy, in, 0.0f, ux_m);
+  float uz_p0[4], uz_p1[4], uz_m0[4], uz_m1[4], uy_zp0[4], uy_zp1[4], uy_zm0[4], uy_zm1[4], ux_zp[6], ux_zm[6], uz_a[6], uz_b[6];
+  if (IS3D) {
+    v4_load(Uz, o + d.sy, in, 0.0f, uz_p0);
+    v4_load(Uz, o + d.sy + d.sz, in, 0.0f, uz_p1);
+    v4_load(Uz, o - d.sy, in, 0.0f, uz_m0);
+    v4_load(Uz, o - d.sy + d.sz, in, 0.0f, uz_m1);
+    v4_load(Uy, o + d.sz, in, 0.0f, uy_zp0);
+    v4_load(Uy, o + d.sz + d.sy, in, 0.0f, uy_zp1);
+    v4_load(Uy, o - d.sz, in, 0.0f, uy_zm0);
+    v4_load(Uy, o - d.sz + d.sy, in, 0.0f, uy_zm1);
+    v4_load6<false, true>(c, Ux, o + d.sz, in, 0.0f, ux_zp);
+    v4_load6<false, true>(c, Ux, o - d.sz, in, 0.0f, ux_zm);
+    v4_load6<true, true>(c, Uz, o, in, 0.0f, uz_a);
+    v4_load6<true, true>(c, Uz, o + d.sz, in, 0.0f, uz_b);
+  }
+  float wx[4], wy[4], wz[4], nr[4];
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const int i = c.i0 + q;
+    v3 w = mk3(0.0f, 0.0f, 0.0f);
+    float nrm = 0.0f;
+    if (in && i >= 1 && i <= d.X - 2) {   // VecGrid::curl, grid.cc:497-515
+      const bool xpb = i + 1 == d.X - 1, xmb = i - 1 == 0;
+      const float cy_xp = xpb ? 0.0f : 0.5f * (uy_a[q + 2] + uy_b[q + 2]);
+      const float cy_xm = xmb ? 0.0f : 0.5f * (uy_a[q] + uy_b[q]);
+      const float cx_yp = ypb ? 0.0f : 0.5f * (ux_p[q + 1] + ux_p[q + 2]);
+      const float cx_ym = ymb ? 0.0f : 0.5f * (ux_m[q + 1] + ux_m[q + 2]);
+      w.z = 0.5f * ((cy_xp - cy_xm) - (cx_yp - cx_ym));
+      if (IS3D) {
+        const float cz_yp = ypb ? 0.0f : 0.5f * (uz_p0[q] + uz_p1[q]);
+        const float cz_ym = ymb ? 0.0f : 0.5f * (uz_m0[q] + uz_m1[q]);
+        const float cy_zp = zpb ? 0.0f : 0.5f * (uy_zp0[q] + uy_zp1[q]);
+        const float cy_zm = zmb ? 0.0f : 0.5f * (uy_zm0[q] + uy_zm1[q]);
+        const float cx_zp = zpb ? 0.0f : 0.5f * (ux_zp[q + 1] + ux_zp[q + 2]);
+        const float cx_zm = zmb ? 0.0f : 0.5f * (ux_zm[q + 1] + ux_zm[q + 2]);
+        const float cz_xp = xpb ? 0.0f : 0.5f * (uz_a[q + 2] + uz_b[q + 2]);
+        const float cz_xm = xmb ? 0.0f : 0.5f * (uz_a[q] + uz_b[q]);
+        w.x = 0.5f * ((cz_yp - cz_ym) - (cy_zp - cy_zm));
+        w.y = 0.5f * ((cx_zp - cx_zm) - (cz_xp - cz_xm));
+      }
+      nrm = norm3(w);
+    }
+    wx[q] = w.x; wy[q] = w.y; wz[q] = w.z; nr[q] = nrm;
+  }
+  if (live) {
+    v4_store(curl, o, wx);
+    v4_store(curl, o + d.sc, wy);
+    v4_store(curl, o + 2 * d.sc, wz);
+    v4_store(cnorm, o, nr);
+  }
+}
+
+// confinement force of four cells of row (jj,kk) given that row's |curl| (6 wide) and its four neighbour
+// rows; cells on the border shell get 0. NEED: which components the caller uses (bit 0 x, 1 y, 2 z).
+template <bool IS3D>
+__device__ __forceinline__ void force_row(const Dom& d, float strength, int i0, bool row_inner, const float* cn6,
+                                          const float* cn_ym, const float* cn_yp, const float* cn_zm, const float* cn_zp,
+                                          const float* wx, const float* wy, const float* wz, v3* f) {
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const int i = i0 + q;
+    f[q] = mk3(0.0f, 0.0f, 0.0f);
+    if (row_inner && i >= 1 && i <= d.X - 2) {
+      v3 g = mk3(0.5f * (cn6[q + 2] - cn6[q]), 0.5f * (cn_yp[q] - cn_ym[q]), 0.0f);
+      if (IS3D) g.z = 0.5f * (cn_zp[q] - cn_zm[q]);
+      g = normalize3(g);
+      const v3 w = mk3(wx[q], wy[q], wz[q]);
+      f[q] = mk3(((g.y * w.z) - (g.z * w.y)) * strength, ((g.z * w.x) - (g.x * w.z)) * strength,
+                 ((g.x * w.y) - (g.y * w.x)) * strength);
+    }
+  }
+}
+
+// k_confine_v4: the force of the thread's own four cells, of the four cells one row down (y-1) and one plane
+// down (z-1) are evaluated in registers from 10 |curl| rows + 7 curl rows; force.x of cell i0-1 comes from the
+// previous lane. U is rewritten in full rows (unchanged cells get their own value back).
+template <bool IS3D>
+__global__ __launch_bounds__(256) void k_confine_v4(Dom d, float* __restrict__ U, const float* __restrict__ flags,
+                                                    const float* __restrict__ curl, const float* __restrict__ cn,
+                                                    float strength) {
+  const V4Ctx c = v4_ctx(d);
+  const int j = blockIdx.y * blockDim.y + threadIdx.y;
+  const int b = blockIdx.z / d.Z, k = blockIdx.z - b * d.Z;
+  const bool live = c.i0 < d.X && j < d.Y;
+  const long long cells = d.sc;
+  const int C = IS3D ? 3 : 2;
+  U += b * cells * C; flags += b * cells; curl += b * cells * 3; cn += b * cells;
+  const int o = TFL_AT(d, c.i0, j, k);
+  const bool in = live && j >= 1 && j <= d.Y - 2 && (!IS3D || (k >= 1 && k <= d.Z - 2));   // the cells' own row
+  const bool in_ym = in && j - 1 >= 1;                 // row (j-1,k) is not a border row
+  const bool in_zm = in && IS3D && k - 1 >= 1;         // row (j,k-1) is not a border row
+  // |curl| rows. Own row and the two "minus" rows 6 wide (x gradient), the others 4 wide.
+  float n_c[6], n_ym[6], n_zm[6], n_yp[4], n_zp[4], n_ym2[4], n_ymzp[4], n_ymzm[4], n_ypzm[4], n_zm2[4];
+  v4_load6<true, true>(c, cn, o, in, 0.0f, n_c);
+  v4_load6<true, true>(c, cn, o - d.sy, in, 0.0f, n_ym);
+  v4_load(cn, o + d.sy, in, 0.0f, n_yp);
+  v4_load(cn, o - 2 * d.sy, in_ym, 0.0f, n_ym2);
+  if (IS3D) {
+    v4_load6<true, true>(c, cn, o - d.sz, in, 0.0f, n_zm);
+    v4_load(cn, o + d.sz, in, 0.0f, n_zp);
+    v4_load(cn, o - d.sy + d.sz, in_ym, 0.0f, n_ymzp);
+    v4_load(cn, o - d.sy - d.sz, in_ym || in_zm, 0.0f, n_ymzm);
+    v4_load(cn, o + d.sy - d.sz, in_zm, 0.0f, n_ypzm);
+    v4_load(cn, o - 2 * d.sz, in_zm, 0.0f, n_zm2);
+  }
+  float wx[4], wy[4], wz[4], wx_ym[4], wy_ym[4], wz_ym[4], wx_zm[4], wy_zm[4], wz_zm[4];
+  v4_load(curl, o, in, 0.0f, wx);
+  v4_load(curl, o + d.sc, in, 0.0f, wy);
+  v4_load(curl, o + 2 * d.sc, in, 0.0f, wz);
+  v4_load(curl, o - d.sy, in_ym, 0.0f, wx_ym);              // force.y needs w.x, w.z
+  v4_load(curl, o - d.sy + 2 * d.sc, in_ym, 0.0f, wz_ym);
+#pragma unroll
+  for (int q = 0; q < 4; q++) { wy_ym[q] = 0.0f; wz_zm[q] = 0.0f; wx_zm[q] = 0.0f; wy_zm[q] = 0.0f; }
+  if (IS3D) {
+    v4_load(curl, o - d.sz, in_zm, 0.0f, wx_zm);            // force.z needs w.x, w.y
+    v4_load(curl, o - d.sz + d.sc, in_zm, 0.0f, wy_zm);
+  }
+  float fl_c[6], fl_ym[4], fl_zm[4], u[3][4];
+  v4_load6<true, false>(c, flags, o, in, 0.0f, fl_c);
+  v4_load(flags, o - d.sy, in, 0.0f, fl_ym);
+  v4_load(flags, o - d.sz, in && IS3D, 0.0f, fl_zm);
+#pragma unroll
+  for (int a = 0; a < 3; a++) v4_load(U, o + a * d.sc, live && a < C, 0.0f, u[a]);
+
+  v3 f0[4], fy[4], fz[4];
+  force_row<IS3D>(d, strength, c.i0, in, n_c, n_ym + 1, n_yp, n_zm + 1, n_zp, wx, wy, wz, f0);
+  force_row<IS3D>(d, strength, c.i0, in_ym, n_ym, n_ym2, n_c + 1, n_ymzm, n_ymzp, wx_ym, wy_ym, wz_ym, fy);
+  if (IS3D) force_row<IS3D>(d, strength, c.i0, in_zm, n_zm, n_ymzm, n_ypzm, n_zm2, n_c + 1, wx_zm, wy_zm, wz_zm, fz);
+  // force.x of cell i0-1: previous lane's last cell; at a segment start rebuilt from memory
+  float fxl = from_lane_below(f0[3].x);
+  if (c.first) {
+    fxl = 0.0f;
+    const int i = c.i0 - 1;
+    if (in && i >= 1) {   // i <= X-2 always
+      const int oo = o - 1;
+      v3 g = mk3(0.5f * (cn[oo + 1] - cn[oo - 1]), 0.5f * (cn[oo + d.sy] - cn[oo - d.sy]), 0.0f);
+      if (IS3D) g.z = 0.5f * (cn[oo + d.sz] - cn[oo - d.sz]);
+      g = normalize3(g);
+      fxl = ((g.y * curl[oo + 2 * d.sc]) - (g.z * curl[oo + d.sc])) * strength;
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const int i = c.i0 + q;
+    if (!(in && i >= 1 && i <= d.X - 2)) continue;
+    const int fc = (int)fl_c[q + 1];
+    const bool cf = fc & kFluid, ce = fc & kEmpty;
+    if (!cf && !ce) continue;  // AddForceField, tfluids.cc:1312-1339
+    const int nx = (int)fl_c[q], ny = (int)fl_ym[q], nz = IS3D ? (int)fl_zm[q] : 0;
+    const bool ax = (nx & kFluid) || (cf && (nx & kEmpty));
+    const bool ay = (ny & kFluid) || (cf && (ny & kEmpty));
+    const bool az = IS3D && ((nz & kFluid) || (cf && (nz & kEmpty)));
+    const float fxm = q > 0 ? f0[q > 0 ? q - 1 : 0].x : fxl;
+    if (ax) u[0][q] += (0.5f * (fxm + f0[q].x));
+    if (ay) u[1][q] += (0.5f * (fy[q].y + f0[q].y));
+    if (az) u[2][q] += (0.5f * (fz[q].z + f0[q].z));
+  }
+  if (live) {
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+      if (a < C) v4_store(U, o + a * d.sc, u[a]);
+  }
+}
+
 void vorticity_confinement(hipStream_t st, bool is3d, int B, int Z, int Y, int X, float* U, const float* flags,
                            float strength, float* curl, float* curl_norm) {
   const Dom d = make_dom(Z, Y, X);
   const dim3 blk(64, 4, 1), grd((X + 63) / 64, (Y + 3) / 4, (unsigned)(Z * B));
+  const Vec4Launch v = vec4_launch(B, Z, Y, X, {U, flags, curl, curl_norm});
+  if (v.ok) {
+    if (is3d) {
+      { TFL_TIMED("k_curl", st); k_curl_v4<true><<<v.grd, v.blk, 0, st>>>(d, U, curl, curl_norm); }
+      { TFL_TIMED("k_confine", st); k_confine_v4<true><<<v.grd, v.blk, 0, st>>>(d, U, flags, curl, curl_norm, strength); }
+    } else {
+      { TFL_TIMED("k_curl", st); k_curl_v4<false><<<v.grd, v.blk, 0, st>>>(d, U, curl, curl_norm); }
+      { TFL_TIMED("k_confine", st); k_confine_v4<false><<<v.grd, v.blk, 0, st>>>(d, U, flags, curl, curl_norm, strength); }
+    }
+    return;
+  }
   if (is3d) {
     { TFL_TIMED("k_curl", st); k_curl<true><<<grd, blk, 0, st>>>(d, U, curl, curl_norm); }
     { TFL_TIMED("k_confine", st); k_confine<true><<<grd, blk, 0, st>>>(d, U, flags, curl, curl_norm, strength); }
