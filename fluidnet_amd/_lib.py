@@ -8,6 +8,9 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libtfluids_hip.so")
+# Development aid: TFL_LIBRARY points at another build of the SAME library (A/B timing of two kernel versions
+# inside one GPU session -- box-to-box variance on the pool is ~10%). It is still the HIP library; no fallback.
+LIB_PATH = os.environ.get("TFL_LIBRARY", LIB_PATH)
 
 
 class TfluidsError(RuntimeError):
@@ -70,6 +73,8 @@ SIGNATURES = {
     "tfl_volumetricUpSamplingNearestBackward": (_c.c_int, [_c.c_void_p, _c.c_int, _T, _T, _T]),
     "tfl_packPlanes": (_c.c_int, [_c.c_void_p, _c.c_int, _c.POINTER(_T), _c.c_int, _c.c_int, _c.c_void_p, _c.c_int]),
     "tfl_applyBCsIndexed": (_c.c_int, [_c.c_void_p, _T, _T, _T, _c.c_void_p, _c.c_int64]),
+    "tfl_applyBCsIndexedMulti": (_c.c_int, [_c.c_void_p, _c.c_int, _c.POINTER(_T), _c.POINTER(_T), _c.POINTER(_T),
+                                            _c.POINTER(_c.c_void_p), _c.POINTER(_c.c_int64)]),
     "tfl_applyBCs": (_c.c_int, [_c.c_void_p, _T, _T, _T, _c.c_int, _c.c_float, _c.c_float]),
 }
 

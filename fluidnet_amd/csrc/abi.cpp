@@ -673,6 +673,30 @@ int tfl_applyBCsIndexed(tfl_ctx* c, const tfl_tensor* x, const tfl_tensor* bc, c
   return check_launch(c, "applyBCsIndexed");
 }
 
+int tfl_applyBCsIndexedMulti(tfl_ctx* c, int count, const tfl_tensor* const* x, const tfl_tensor* const* bc,
+                             const tfl_tensor* const* invMask, const int32_t* const* idx, const int64_t* n) {
+  if (!c) return TFL_EINVAL;
+  if (count < 1 || count > 8 || !x || !bc || !invMask || !idx || !n)
+    return fail(c, TFL_EINVAL, "applyBCsIndexedMulti: 1..8 (x, bc, invMask, idx) tuples are required");
+  long long nn[8];
+  const int* ii[8];
+  float* xx[8];
+  const float *bb[8], *mm[8];
+  for (int i = 0; i < count; i++) {
+    const tfl_tensor *xi = x[i], *bi = bc[i], *mi = invMask[i];
+    if (!xi || !xi->data || !bi || !bi->data || !mi || !mi->data) return fail(c, TFL_EINVAL, "applyBCsIndexedMulti: null tensor in tuple %d", i);
+    const long long nx = (long long)xi->B * xi->C * xi->Z * xi->Y * xi->X;
+    const long long nb = (long long)bi->B * bi->C * bi->Z * bi->Y * bi->X;
+    const long long nm = (long long)mi->B * mi->C * mi->Z * mi->Y * mi->X;
+    if (nb != nx || nm != nx) return fail(c, TFL_EINVAL, "applyBCsIndexedMulti: size mismatch in tuple %d", i);
+    if (nx >= (1ll << 31)) return fail(c, TFL_EINVAL, "applyBCsIndexedMulti: tensor %d too large for 32-bit indices", i);
+    if (n[i] < 0 || (n[i] > 0 && !idx[i])) return fail(c, TFL_EINVAL, "applyBCsIndexedMulti: bad index list %d", i);
+    nn[i] = n[i]; ii[i] = idx[i]; xx[i] = xi->data; bb[i] = bi->data; mm[i] = mi->data;
+  }
+  tfl::apply_bcs_indexed_multi(c->stream, count, nn, ii, xx, bb, mm);
+  return check_launch(c, "applyBCsIndexedMulti");
+}
+
 int tfl_packPlanes(tfl_ctx* c, int n, const tfl_tensor* const* fields, int zlo, int zhi, float* buf, int unpack) {
   if (!c) return TFL_EINVAL;
   if (n < 1 || n > 8 || !fields || !buf) return fail(c, TFL_EINVAL, "packPlanes: 1..8 fields and a buffer are required");

@@ -16,6 +16,7 @@
 #include "tfl_host.hpp"
 #include "tfl_vec4.hpp"
 
+#include <algorithm>
 #include <cstdlib>
 
 namespace tfl {
@@ -420,6 +421,21 @@ __global__ __launch_bounds__(256) void k_apply_bcs_indexed(long long n, const in
   }
 }
 
+// Several index lists in one launch: blockIdx.y picks the (x, bc, invMask, idx) tuple.
+struct BcMultiArgs { long long n[8]; const int* idx[8]; float* x[8]; const float* bc[8]; const float* inv[8]; };
+__global__ __launch_bounds__(256) void k_apply_bcs_indexed_multi(BcMultiArgs a) {
+  const int f = blockIdx.y;
+  const long long n = a.n[f];
+  const int* __restrict__ idx = a.idx[f];
+  float* __restrict__ x = a.x[f];
+  const float* __restrict__ bcv = a.bc[f];
+  const float* __restrict__ inv = a.inv[f];
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) {
+    const int e = idx[t];
+    x[e] = x[e] * inv[e] + bcv[e];
+  }
+}
+
 // Halo planes of several fields <-> one contiguous message buffer (fluidnet_amd/dist.py): buffer layout
 // [field][b][channel][plane zlo..zhi)[Y][X]. One launch per direction instead of a dozen strided copies.
 struct PackArgs {
@@ -513,6 +529,21 @@ void pack_planes(hipStream_t st, int n, float* const* ptrs, const int* rows, lon
   if (blocks > 2048) blocks = 2048;
   if (blocks < 1) return;
   { TFL_TIMED(unpack ? "k_unpack_planes" : "k_pack_planes", st); k_pack_planes<<<(int)blocks, 256, 0, st>>>(a, zstride, plane_elems, zlo_off, buf, unpack); }
+}
+
+void apply_bcs_indexed_multi(hipStream_t st, int count, const long long* n, const int* const* idx, float* const* x,
+                             const float* const* bcv, const float* const* inv) {
+  BcMultiArgs a;
+  long long nmax = 0;
+  for (int i = 0; i < 8; i++) {
+    a.n[i] = i < count ? n[i] : 0; a.idx[i] = i < count ? idx[i] : nullptr; a.x[i] = i < count ? x[i] : nullptr;
+    a.bc[i] = i < count ? bcv[i] : nullptr; a.inv[i] = i < count ? inv[i] : nullptr;
+    if (a.n[i] > nmax) nmax = a.n[i];
+  }
+  if (nmax == 0) return;
+  const unsigned bx = (unsigned)std::min<long long>((nmax + 255) / 256, 4096);
+  TFL_TIMED("k_apply_bcs_indexed", st);
+  k_apply_bcs_indexed_multi<<<dim3(bx, (unsigned)count, 1), 256, 0, st>>>(a);
 }
 
 void apply_bcs_indexed(hipStream_t st, long long n, const int* idx, float* x, const float* bcv, const float* inv) {

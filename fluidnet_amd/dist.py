@@ -231,16 +231,14 @@ class SlabSimulation:
             tfluids.addGravity(U, flags, [_f32(v) * s for v in _gravity(m)], dt)
         if m.get("vorticityConfinementAmp", 0) > 0:
             tfluids.vorticityConfinement(U, flags, dx * m["vorticityConfinementAmp"])
-        setConstVals(b, p, U, flags, rho)
+        setConstVals(b, p, U, flags, rho, unchanged=("p", "density"))
         self.model.begin(U, flags, lay.c0, lay.c1, self.stats)
         if multi:
             yield ("allreduce", self.stats)
         self.model.finish(p, U, flags, self.stats, self.count, UBC=b.get("UBC"), UBCInvMask=b.get("UBCInvMask"),
                           clamp=(-1e6, 1e6))
-        if b.get("pBC") is not None:
-            _apply(p, b["pBC"], b["pBCInvMask"])
-        if b.get("densityBC") is not None:
-            _apply(rho, b["densityBC"], b["densityBCInvMask"])
+        rest = {k: v for k, v in b.items() if k not in ("UBC", "UBCInvMask")}
+        setConstVals(rest, p, U, flags, rho, unchanged=("density",))
         if multi:
             tfluids.setDxOverride(U, None)
 

@@ -62,51 +62,101 @@ def createPlumeBCs(batch, densityVal, uScale, rad, zOffset=0, zTotal=None):
     batch["densityBCInvMask"] = dmask if multi else dmask[0]
 
 
-_bc_index_cache = {}   # (bc ptr, mask ptr) -> (bc version, mask version, int32 index tensor)
+_bc_index_cache = {}   # (bc ptr, mask ptr, numel) -> (bc version, mask version, int32 index tensor, idempotent)
 
 
 def _bc_indices(bc, inv):
-    """Indices where the BC pair is not the identity (invMask != 1 or bc != 0), cached per tensor pair
-    and invalidated by torch's in-place version counters (the 2-D demo edits its BCs interactively)."""
+    """(idx, idempotent): idx = the element indices where the BC pair is not the identity (invMask != 1 or
+    bc != 0); idempotent = every such element has invMask == 0, i.e. x*0 + bc applied twice equals applied once,
+    bit for bit. Cached per tensor pair and invalidated by torch's in-place version counters (the 2-D demo
+    edits its BCs interactively)."""
     key = (bc.data_ptr(), inv.data_ptr(), bc.numel())
     hit = _bc_index_cache.get(key)
     if hit is not None and hit[0] == bc._version and hit[1] == inv._version:
-        return hit[2]
-    idx = torch.nonzero((inv.reshape(-1) != 1) | (bc.reshape(-1) != 0)).reshape(-1).to(torch.int32)
+        return hit[2], hit[3]
+    flat_inv = inv.reshape(-1)
+    idx = torch.nonzero((flat_inv != 1) | (bc.reshape(-1) != 0)).reshape(-1)
+    idem = bool((flat_inv[idx] == 0).all().item())
+    idx = idx.to(torch.int32)
     if len(_bc_index_cache) > 64:
         _bc_index_cache.clear()
-    _bc_index_cache[key] = (bc._version, inv._version, idx)
-    return idx
+    _bc_index_cache[key] = (bc._version, inv._version, idx, idem)
+    return idx, idem
+
+
+def _sparse_bc(x, bc, inv):
+    """The index list of a BC pair if it is worth using (fewer than a quarter of the elements), else None."""
+    if bc is None or inv is None or x.numel() >= 2 ** 31:
+        return None
+    idx, idem = _bc_indices(bc, inv)
+    return (idx, idem) if idx.numel() * 4 < x.numel() else None
 
 
 def _apply(x, bc, inv, clamp=None):
     lib, ctx = tfluids._context(x)
-    if bc is not None and inv is not None and clamp is None and x.numel() < 2 ** 31:
-        idx = _bc_indices(bc, inv)
-        if idx.numel() * 4 < x.numel():     # sparse enough: touch only the BC cells
-            tfluids._call(lib, ctx, lib.tfl_applyBCsIndexed(ctx, tfluids._tt5(x), tfluids._tt5(bc), tfluids._tt5(inv),
-                                                            ctypes.c_void_p(idx.data_ptr()), idx.numel()))
-            return
+    sp = _sparse_bc(x, bc, inv) if clamp is None else None
+    if sp is not None:
+        idx = sp[0]
+        tfluids._call(lib, ctx, lib.tfl_applyBCsIndexed(ctx, tfluids._tt5(x), tfluids._tt5(bc), tfluids._tt5(inv),
+                                                        ctypes.c_void_p(idx.data_ptr()), idx.numel()))
+        return
     lo, hi = clamp if clamp is not None else (0.0, 0.0)
     tfluids._call(lib, ctx, lib.tfl_applyBCs(ctx, tfluids._tt5(x), tfluids._tt5(bc) if bc is not None else None,
                                              tfluids._tt5(inv) if inv is not None else None,
                                              int(clamp is not None), lo, hi))
 
 
-def setConstVals(batch, p, U, flags, density):
-    """simulate.lua:130-160: X = X*invMask + BC for p, U and each density channel."""
+def _apply_many(triples, unchanged=False):
+    """x = x*invMask + bc for several (x, bc, invMask) triples: the sparse ones go out as ONE launch
+    (tfl_applyBCsIndexedMulti), dense ones one launch each. unchanged=True: x still holds the result of an
+    earlier application of the same pair -- an idempotent pair (invMask == 0 on all its cells) is then skipped."""
+    sparse = []
+    for x, bc, inv in triples:
+        sp = _sparse_bc(x, bc, inv)
+        if sp is None:
+            _apply(x, bc, inv)
+        elif not (unchanged and sp[1]):
+            sparse.append((x, bc, inv, sp[0]))
+    if not sparse:
+        return
+    if len(sparse) == 1:
+        x, bc, inv, _ = sparse[0]
+        _apply(x, bc, inv)
+        return
+    for lo in range(0, len(sparse), 8):
+        part = sparse[lo:lo + 8]
+        lib, ctx = tfluids._context(part[0][0])
+        n = len(part)
+        kx, ax = tfluids._desc_array([t[0] for t in part])
+        kb, ab = tfluids._desc_array([t[1] for t in part])
+        km, am = tfluids._desc_array([t[2] for t in part])
+        ai = (ctypes.c_void_p * n)(*[t[3].data_ptr() for t in part])
+        an = (ctypes.c_int64 * n)(*[t[3].numel() for t in part])
+        tfluids._call(lib, ctx, lib.tfl_applyBCsIndexedMulti(ctx, n, ax, ab, am, ai, an))
+        del kx, kb, km
+
+
+def setConstVals(batch, p, U, flags, density, unchanged=()):
+    """simulate.lua:130-160: X = X*invMask + BC for p, U and each density channel. `unchanged` names the fields
+    ('p', 'U', 'density') that nothing has written since the previous setConstVals of this step (simulate()
+    knows; idempotent BC pairs on them are skipped -- the result is identical)."""
+    fresh, stale = [], []
+    def add(name, x, bc, inv):
+        (stale if name in unchanged else fresh).append((x, bc, inv))
     if batch.get("pBC") is not None or batch.get("pBCInvMask") is not None:
-        _apply(p, batch["pBC"], batch["pBCInvMask"])
+        add("p", p, batch["pBC"], batch["pBCInvMask"])
     if batch.get("UBC") is not None or batch.get("UBCInvMask") is not None:
-        _apply(U, batch["UBC"], batch["UBCInvMask"])
+        add("U", U, batch["UBC"], batch["UBCInvMask"])
     if batch.get("densityBC") is not None or batch.get("densityBCInvMask") is not None:
         if isinstance(density, (list, tuple)):
             if len(density) != len(batch["densityBC"]):
                 raise TfluidsError("density / densityBC channel mismatch")
             for i in range(len(density)):
-                _apply(density[i], batch["densityBC"][i], batch["densityBCInvMask"][i])
+                add("density", density[i], batch["densityBC"][i], batch["densityBCInvMask"][i])
         else:
-            _apply(density, batch["densityBC"], batch["densityBCInvMask"])
+            add("density", density, batch["densityBC"], batch["densityBCInvMask"])
+    _apply_many(fresh)
+    _apply_many(stale, unchanged=True)
 
 
 def _gravity(mconf):
@@ -150,26 +200,20 @@ def simulate(conf, mconf, batch, model, outputDiv=False):
     simMethod = mconf.get("simMethod") or "convnet"
     if simMethod != "convnet":
         tfluids.setWallBcsForward(U, flags)
-    setConstVals(batch, p, U, flags, density)
+    # only U has been written since the first setConstVals (buoyancy, gravity, confinement, wall BCs)
+    setConstVals(batch, p, U, flags, density, unchanged=("p", "density"))
 
     fused_tail = False
     if simMethod == "convnet":
         # model:forward + p:copy(pPred); U:copy(UPred) (simulate.lua:262-272): the prediction is
         # written straight into the state tensors, and the trailing setConstVals(U) + U:clamp
         # (simulate.lua:321-326) ride in the projection's last kernel.
-        has_ubc = batch.get("UBC") is not None
         model.forward([p, U, flags], out=[p, U], UBC=batch.get("UBC"), UBCInvMask=batch.get("UBCInvMask"),
                       clamp=(-1e6, 1e6))
         fused_tail = True
-        if batch.get("pBC") is not None:
-            _apply(p, batch["pBC"], batch["pBCInvMask"])
-        if batch.get("densityBC") is not None:
-            if isinstance(density, (list, tuple)):
-                for i in range(len(density)):
-                    _apply(density[i], batch["densityBC"][i], batch["densityBCInvMask"][i])
-            else:
-                _apply(density, batch["densityBC"], batch["densityBCInvMask"])
-        del has_ubc
+        # U is done (fused tail); p was rewritten by the model, density has not changed since setConstVals #2
+        rest = {k: v for k, v in batch.items() if k not in ("UBC", "UBCInvMask")}
+        setConstVals(rest, p, U, flags, density, unchanged=("density",))
     elif simMethod == "jacobi":
         div = batch.get("div")
         if div is None or div.shape != p.shape:
@@ -183,7 +227,7 @@ def simulate(conf, mconf, batch, model, outputDiv=False):
         raise TfluidsError("mconf.simMethod (%s) is not a valid option" % simMethod)
 
     if not fused_tail:
-        setConstVals(batch, p, U, flags, density)
+        setConstVals(batch, p, U, flags, density, unchanged=("density",))
         _apply(U, None, None, clamp=(-1e6, 1e6))
 
 

@@ -54,6 +54,20 @@ def _tt5(t):
     return ctypes.byref(tfl_tensor(t.data_ptr(), *sh))
 
 
+def _desc5(t):
+    """_tt5 as a tfl_tensor struct (for arrays of descriptors)."""
+    _check(t.dtype == torch.float32 and t.is_contiguous(), "tensors must be contiguous float32")
+    sh = [1] * (5 - t.dim()) + list(t.shape)
+    return tfl_tensor(t.data_ptr(), *sh)
+
+
+def _desc_array(tensors):
+    """(keepalive, array of tfl_tensor*) for a `const tfl_tensor* const*` argument."""
+    descs = [_desc5(t) for t in tensors]
+    arr = (ctypes.POINTER(tfl_tensor) * len(descs))(*[ctypes.pointer(d) for d in descs])
+    return descs, arr
+
+
 def _call(lib, ctx, rc):
     if rc != 0:
         raise TfluidsError(lib.tfl_last_error(ctx).decode())

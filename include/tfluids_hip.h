@@ -217,6 +217,12 @@ int tfl_applyBCs(tfl_ctx* ctx, const tfl_tensor* x, const tfl_tensor* bc, const 
 int tfl_applyBCsIndexed(tfl_ctx* ctx, const tfl_tensor* x, const tfl_tensor* bc, const tfl_tensor* invMask,
                         const int32_t* idx, int64_t n);
 
+/* count <= 8 tfl_applyBCsIndexed calls in ONE launch (setConstVals touches p, U and every density channel
+ * back to back, lib/simulate.lua:130-160; each list is a few thousand cells, so the launches themselves were
+ * the cost). x[i], bc[i], invMask[i] as in tfl_applyBCsIndexed; idx[i] / n[i] the device index list of pair i. */
+int tfl_applyBCsIndexedMulti(tfl_ctx* ctx, int count, const tfl_tensor* const* x, const tfl_tensor* const* bc,
+                             const tfl_tensor* const* invMask, const int32_t* const* idx, const int64_t* n);
+
 /* z-slab halo messages (BASELINE config 5): gather planes [zlo, zhi) of n <= 8 fields (each with its own
  * B and C; all with the same Z, Y, X) into one contiguous buffer laid out
  * [field][b][c][plane][Y][X] (unpack = 0), or scatter such a buffer back into the fields (unpack = 1).
