@@ -48,6 +48,7 @@ SIGNATURES = {
                                             _c.c_int]),
     "tfl_addBuoyancy": (_c.c_int, [_c.c_void_p, _T, _T, _T, _F3, _c.c_void_p, _c.c_float,
                                    _c.c_int]),
+    "tfl_addBuoyancyFrom": (_c.c_int, [_c.c_void_p, _T, _T, _T, _T, _F3, _c.c_float, _c.c_int]),
     "tfl_addGravity": (_c.c_int, [_c.c_void_p, _T, _T, _F3, _c.c_float, _c.c_int, _c.c_void_p]),
     "tfl_emptyDomain": (_c.c_int, [_c.c_void_p, _T, _c.c_int, _c.c_int]),
     "tfl_flagsToOccupancy": (_c.c_int, [_c.c_void_p, _T, _T]),

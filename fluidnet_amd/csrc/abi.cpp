@@ -337,17 +337,23 @@ int tfl_vorticityConfinement(tfl_ctx* c, const tfl_tensor* U, const tfl_tensor* 
   return check_launch(c, "vorticityConfinement");
 }
 
-int tfl_addBuoyancy(tfl_ctx* c, const tfl_tensor* U, const tfl_tensor* flags, const tfl_tensor* density,
-                    const float gravity[3], float* strengthTmp, float dt, int is3D) {
-  (void)strengthTmp;
+int tfl_addBuoyancyFrom(tfl_ctx* c, const tfl_tensor* USrc, const tfl_tensor* U, const tfl_tensor* flags,
+                        const tfl_tensor* density, const float gravity[3], float dt, int is3D) {
   TRY(check_flags(c, "addBuoyancy", flags));
   TRY(check_vel(c, "addBuoyancy", "U", U, flags, is3D));
+  TRY(check_vel(c, "addBuoyancy", "USrc", USrc, flags, is3D));
   TRY(check_scalar(c, "addBuoyancy", "density", density, flags));
   if (!gravity) return fail(c, TFL_EINVAL, "addBuoyancy: gravity is null");
   const float sc = dt / get_dx(c, flags);  // strength = -gravity * (dt / dx), tfluids.cc:1190-1192
-  tfl::add_buoyancy(c->stream, is3D != 0, flags->B, flags->Z, flags->Y, flags->X, U->data, flags->data,
+  tfl::add_buoyancy(c->stream, is3D != 0, flags->B, flags->Z, flags->Y, flags->X, USrc->data, U->data, flags->data,
                     density->data, -gravity[0] * sc, -gravity[1] * sc, -gravity[2] * sc);
   return check_launch(c, "addBuoyancy");
+}
+
+int tfl_addBuoyancy(tfl_ctx* c, const tfl_tensor* U, const tfl_tensor* flags, const tfl_tensor* density,
+                    const float gravity[3], float* strengthTmp, float dt, int is3D) {
+  (void)strengthTmp;
+  return tfl_addBuoyancyFrom(c, U, U, flags, density, gravity, dt, is3D);
 }
 
 int tfl_addGravity(tfl_ctx* c, const tfl_tensor* U, const tfl_tensor* flags, const float gravity[3], float dt,

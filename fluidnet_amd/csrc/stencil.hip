@@ -112,28 +112,36 @@ __global__ __launch_bounds__(256) void k_add_buoyancy(Dom d, float* __restrict__
 // The same, four consecutive x cells per thread (X % 4 == 0, 16-byte aligned rows): every access is a
 // 16-byte vector; the x-1 neighbour of the first cell is one extra scalar load. Identical arithmetic per cell.
 template <bool IS3D>
-__global__ __launch_bounds__(256) void k_add_buoyancy_v4(Dom d, float* __restrict__ U, const float* __restrict__ flags,
-                                                         const float* __restrict__ rho, float sx, float sy, float sz) {
+__global__ __launch_bounds__(256) void k_add_buoyancy_v4(Dom d, const float* __restrict__ Usrc, float* __restrict__ U,
+                                                         const float* __restrict__ flags, const float* __restrict__ rho,
+                                                         float sx, float sy, float sz) {
+  // U = Usrc + buoyancy. Usrc == U: the reference's in-place op. Usrc != U (tfl_addBuoyancyFrom): every cell is
+  // written, which folds the `U:copy(advected)` that precedes it in simulate() into this pass.
   const int i0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
   const int j = blockIdx.y * blockDim.y + threadIdx.y;
   const int b = blockIdx.z / d.Z, k = blockIdx.z - b * d.Z;
   if (i0 >= d.X || j >= d.Y) return;
-  if (j < 1 || j > d.Y - 2 || (IS3D && (k < 1 || k > d.Z - 2))) return;
+  const bool inner = !(j < 1 || j > d.Y - 2 || (IS3D && (k < 1 || k > d.Z - 2)));
+  if (!inner && Usrc == U) return;
   const long long cells = d.sc;
   const int C = IS3D ? 3 : 2;
-  U += b * cells * C; flags += b * cells; rho += b * cells;
+  U += b * cells * C; Usrc += b * cells * C; flags += b * cells; rho += b * cells;
   const int o = TFL_AT(d, i0, j, k);
-  const float4 f4 = *reinterpret_cast<const float4*>(flags + o);
-  const float4 r4 = *reinterpret_cast<const float4*>(rho + o);
-  const float4 fy4 = *reinterpret_cast<const float4*>(flags + o - d.sy);
-  const float4 ry4 = *reinterpret_cast<const float4*>(rho + o - d.sy);
-  float4 fz4 = make_float4(0, 0, 0, 0), rz4 = fz4;
-  if (IS3D) { fz4 = *reinterpret_cast<const float4*>(flags + o - d.sz); rz4 = *reinterpret_cast<const float4*>(rho + o - d.sz); }
-  const float fm = i0 > 0 ? flags[o - 1] : 0.0f, rm = i0 > 0 ? rho[o - 1] : 0.0f;
-  float4 ux = *reinterpret_cast<const float4*>(U + o);
-  float4 uy = *reinterpret_cast<const float4*>(U + o + d.sc);
-  float4 uz = make_float4(0, 0, 0, 0);
-  if (IS3D) uz = *reinterpret_cast<const float4*>(U + o + 2 * d.sc);
+  const float4 z4 = make_float4(0, 0, 0, 0);
+  float4 f4 = z4, r4 = z4, fy4 = z4, ry4 = z4, fz4 = z4, rz4 = z4;
+  float fm = 0.0f, rm = 0.0f;
+  if (inner) {
+    f4 = *reinterpret_cast<const float4*>(flags + o);
+    r4 = *reinterpret_cast<const float4*>(rho + o);
+    fy4 = *reinterpret_cast<const float4*>(flags + o - d.sy);
+    ry4 = *reinterpret_cast<const float4*>(rho + o - d.sy);
+    if (IS3D) { fz4 = *reinterpret_cast<const float4*>(flags + o - d.sz); rz4 = *reinterpret_cast<const float4*>(rho + o - d.sz); }
+    if (i0 > 0) { fm = flags[o - 1]; rm = rho[o - 1]; }
+  }
+  float4 ux = *reinterpret_cast<const float4*>(Usrc + o);
+  float4 uy = *reinterpret_cast<const float4*>(Usrc + o + d.sc);
+  float4 uz = z4;
+  if (IS3D) uz = *reinterpret_cast<const float4*>(Usrc + o + 2 * d.sc);
   const float fc[4] = {f4.x, f4.y, f4.z, f4.w}, rc[4] = {r4.x, r4.y, r4.z, r4.w};
   const float fxm[4] = {fm, f4.x, f4.y, f4.z}, rxm[4] = {rm, r4.x, r4.y, r4.z};
   const float fym[4] = {fy4.x, fy4.y, fy4.z, fy4.w}, rym[4] = {ry4.x, ry4.y, ry4.z, ry4.w};
@@ -142,7 +150,7 @@ __global__ __launch_bounds__(256) void k_add_buoyancy_v4(Dom d, float* __restric
 #pragma unroll
   for (int q = 0; q < 4; q++) {
     const int i = i0 + q;
-    if (i < 1 || i > d.X - 2) continue;                      // border shell
+    if (!inner || i < 1 || i > d.X - 2) continue;            // border shell
     if (!(((int)fc[q]) & kFluid)) continue;
     if (((int)fxm[q]) & kFluid) vx[q] += (0.5f * sx * (rc[q] + rxm[q]));
     if (((int)fym[q]) & kFluid) vy[q] += (0.5f * sy * (rc[q] + rym[q]));
@@ -211,18 +219,20 @@ void velocity_update(hipStream_t st, bool is3d, int B, int Z, int Y, int X, floa
                      const float* p) {
   TFL_LAUNCH(k_velocity_update, U, flags, p);
 }
-void add_buoyancy(hipStream_t st, bool is3d, int B, int Z, int Y, int X, float* U, const float* flags,
+void add_buoyancy(hipStream_t st, bool is3d, int B, int Z, int Y, int X, const float* Usrc, float* U, const float* flags,
                   const float* density, float sx, float sy, float sz) {
-  const bool vec = (X % 4 == 0) && ((((uintptr_t)U | (uintptr_t)flags | (uintptr_t)density) & 15) == 0) &&
+  const bool vec = (X % 4 == 0) && ((((uintptr_t)U | (uintptr_t)Usrc | (uintptr_t)flags | (uintptr_t)density) & 15) == 0) &&
                    !getenv("TFL_NO_VEC4");
   if (vec) {
     const Dom d = make_dom(Z, Y, X);
     const dim3 blk(32, 8, 1), grd((X / 4 + 31) / 32, (Y + 7) / 8, (unsigned)(Z * B));
     TFL_TIMED("k_add_buoyancy", st);
-    if (is3d) k_add_buoyancy_v4<true><<<grd, blk, 0, st>>>(d, U, flags, density, sx, sy, sz);
-    else k_add_buoyancy_v4<false><<<grd, blk, 0, st>>>(d, U, flags, density, sx, sy, sz);
+    if (is3d) k_add_buoyancy_v4<true><<<grd, blk, 0, st>>>(d, Usrc, U, flags, density, sx, sy, sz);
+    else k_add_buoyancy_v4<false><<<grd, blk, 0, st>>>(d, Usrc, U, flags, density, sx, sy, sz);
     return;
   }
+  if (Usrc != U)   // the one-cell-per-thread kernel skips the cells it does not change
+    (void)hipMemcpyAsync(U, Usrc, sizeof(float) * (size_t)B * (is3d ? 3 : 2) * Z * Y * X, hipMemcpyDeviceToDevice, st);
   TFL_LAUNCH(k_add_buoyancy, U, flags, density, sx, sy, sz);
 }
 void add_gravity(hipStream_t st, bool is3d, int B, int Z, int Y, int X, float* U, const float* flags, float fx,

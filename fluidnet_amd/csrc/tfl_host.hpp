@@ -38,7 +38,7 @@ void velocity_divergence(hipStream_t st, bool is3d, int B, int Z, int Y, int X, 
                          float* div);
 void velocity_update(hipStream_t st, bool is3d, int B, int Z, int Y, int X, float* U, const float* flags,
                      const float* p);
-void add_buoyancy(hipStream_t st, bool is3d, int B, int Z, int Y, int X, float* U, const float* flags,
+void add_buoyancy(hipStream_t st, bool is3d, int B, int Z, int Y, int X, const float* Usrc, float* U, const float* flags,
                   const float* density, float sx, float sy, float sz);
 void add_gravity(hipStream_t st, bool is3d, int B, int Z, int Y, int X, float* U, const float* flags, float fx,
                  float fy, float fz);

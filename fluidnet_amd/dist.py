@@ -205,6 +205,21 @@ class SlabSimulation:
             raise tfluids.TfluidsError("the z-slab path implements the ConvNet projection")
 
     def step_gen(self):
+        """One simulate() step as a generator of communication requests ('halo', fields) / ('allreduce', stats).
+        Several virtual ranks may interleave in one process (run_lockstep), and advectVel's deferred copy keeps
+        a scratch tensor alive across a yield: each SlabSimulation therefore works in its own scratch scope."""
+        gen = self._step_gen()
+        while True:
+            prev, tfluids._scratch_scope = tfluids._scratch_scope, ("slab", id(self))
+            try:
+                req = next(gen, None)
+            finally:
+                tfluids._scratch_scope = prev
+            if req is None:
+                return
+            yield req
+
+    def _step_gen(self):
         b, m, lay = self.batch, self.mconf, self.lay
         p, U, flags, rho = b["pDiv"], b["UDiv"], b["flags"], b["density"]
         dt, method, strength = m["dt"], m.get("advectionMethod"), m.get("maccormackStrength")
@@ -218,14 +233,18 @@ class SlabSimulation:
                     raise tfluids.TfluidsError("back-trace reach %.2f planes exceeds what halo %d covers"
                                                % (reach, lay.halo))
         tfluids.advectScalar(dt, rho, U, flags, method, None, False, strength)
-        tfluids.advectVel(dt, U, flags, method, None, strength)
+        # as in simulate(): the advected field stays in advectVel's scratch (halo exchange and BCs happen there)
+        # and addBuoyancy writes U = scratch + buoyancy, which replaces the U:copy sweep
+        buoyant = m.get("buoyancyScale", 0) > 0
+        Uadv = tfluids.advectVel(dt, U, flags, method, None, strength, _deferCopy=buoyant)
+        Ucur = Uadv if buoyant else U
         if multi:
-            yield ("halo", [U, rho, p])
-        setConstVals(b, p, U, flags, rho)
+            yield ("halo", [Ucur, rho, p])
+        setConstVals(b, p, Ucur, flags, rho)
         dx = self.dx if multi else tfluids.getDx(flags)
-        if m.get("buoyancyScale", 0) > 0:
+        if buoyant:
             s = _f32(-(dx / 4) * m["buoyancyScale"])
-            tfluids.addBuoyancy(U, flags, rho, [_f32(v) * s for v in _gravity(m)], dt)
+            tfluids.addBuoyancy(U, flags, rho, [_f32(v) * s for v in _gravity(m)], dt, USrc=Uadv)
         if m.get("gravityScale", 0) > 0:
             s = _f32((-dx / 4) * m["gravityScale"])
             tfluids.addGravity(U, flags, [_f32(v) * s for v in _gravity(m)], dt)

@@ -180,14 +180,17 @@ def simulate(conf, mconf, batch, model, outputDiv=False):
         chans = density if isinstance(density, (list, tuple)) else [density]
         for chan in chans:
             tfluids.advectScalar(dt, chan, U, flags, method, None, False, strength)
-    tfluids.advectVel(dt, U, flags, method, None, strength)
-    setConstVals(batch, p, U, flags, density)
+    # U:copy(advected) (init.lua:216-218) is folded into addBuoyancy when buoyancy is on: the advected field
+    # stays in advectVel's scratch, takes the BCs there, and addBuoyancy writes U = scratch + buoyancy.
+    buoyant = density is not None and mconf.get("buoyancyScale", 0) > 0
+    Uadv = tfluids.advectVel(dt, U, flags, method, None, strength, _deferCopy=buoyant)
+    setConstVals(batch, p, Uadv if buoyant else U, flags, density)
 
-    if density is not None and mconf.get("buoyancyScale", 0) > 0:
+    if buoyant:
         s = _f32(-(tfluids.getDx(flags) / 4) * mconf["buoyancyScale"])   # gravity:mul(...) on a float tensor
         g = [_f32(v) * s for v in _gravity(mconf)]
         d0 = density[0] if isinstance(density, (list, tuple)) else density
-        tfluids.addBuoyancy(U, flags, d0, g, dt)
+        tfluids.addBuoyancy(U, flags, d0, g, dt, USrc=Uadv)
     if mconf.get("gravityScale", 0) > 0:
         s = _f32((-tfluids.getDx(flags) / 4) * mconf["gravityScale"])
         g = [_f32(v) * s for v in _gravity(mconf)]

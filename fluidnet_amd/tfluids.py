@@ -18,7 +18,8 @@ CellType = dict(TypeNone=0, TypeFluid=1, TypeObstacle=2, TypeEmpty=4, TypeInflow
                 TypeOutflow=16, TypeOpen=32, TypeStick=128)
 
 _ctx = {}   # device index -> tfl_ctx*
-_tmp = {}   # device index -> grow-only flat scratch tensor (init.lua:22,35-64)
+_tmp = {}   # (device index, scope) -> grow-only flat scratch tensor (init.lua:22,35-64)
+_scratch_scope = None   # virtual z-slab ranks sharing one process each get their own scratch (dist.py)
 
 
 def _check(cond, msg):
@@ -85,10 +86,11 @@ def getTempStorage(like, sizes):
             n *= v
         numels.append(n)
         total += n
-    buf = _tmp.get(dev)
+    key = (dev, _scratch_scope)
+    buf = _tmp.get(key)
     if buf is None or buf.numel() < total:
         buf = torch.empty(total, dtype=torch.float32, device=like.device)
-        _tmp[dev] = buf
+        _tmp[key] = buf
     out, off = [], 0
     for s, n in zip(sizes, numels):
         out.append(buf[off:off + n].view(*s))
@@ -143,8 +145,10 @@ def advectScalar(dt, s, U, flags, method=None, sDst=None, sampleOutsideFluid=Non
         s.copy_(out)
 
 
-def advectVel(dt, U, flags, method=None, UDst=None, maccormackStrength=None, boundaryWidth=None):
-    """init.lua:170-219. In place on `U` unless UDst is given."""
+def advectVel(dt, U, flags, method=None, UDst=None, maccormackStrength=None, boundaryWidth=None, _deferCopy=False):
+    """init.lua:170-219. In place on `U` unless UDst is given.
+    _deferCopy (simulate() only): with UDst None, skip the trailing U:copy and return the scratch tensor that
+    holds the result -- the caller folds the copy into its next pass over U (addBuoyancy(..., USrc=))."""
     method = method or "maccormackOurs"
     boundaryWidth = boundaryWidth or 1
     maccormackStrength = 0.75 if maccormackStrength is None else maccormackStrength
@@ -163,7 +167,10 @@ def advectVel(dt, U, flags, method=None, UDst=None, maccormackStrength=None, bou
                                       method.encode(), int(boundaryWidth), maccormackStrength,
                                       _tt(out)))
     if UDst is None:
+        if _deferCopy:
+            return out
         U.copy_(out)
+    return None
 
 
 def setWallBcsForward(U, flags):
@@ -253,13 +260,19 @@ def _vec3(g, name):
     return (ctypes.c_float * 3)(*[float(v) for v in g])
 
 
-def addBuoyancy(U, flags, density, gravity, dt):
-    """init.lua:442-470 (in place on U). gravity: 3 floats (host tensor, list or tuple)."""
+def addBuoyancy(U, flags, density, gravity, dt, USrc=None):
+    """init.lua:442-470 (in place on U). gravity: 3 floats (host tensor, list or tuple).
+    USrc (extension): U = USrc + buoyancy, every cell of U written (tfl_addBuoyancyFrom)."""
     _, _, _, _, is3D = _dims(U, flags)
     _check(density.dim() == 5 and density.shape == flags.shape, "Size mismatch")
     _check(density.is_contiguous(), "Input is not contiguous")
     _check(isinstance(dt, (int, float)), "time step must be a number")
     lib, ctx = _context(U)
+    if USrc is not None and USrc.data_ptr() != U.data_ptr():
+        _check(USrc.shape == U.shape and USrc.is_contiguous(), "Size mismatch")
+        _call(lib, ctx, lib.tfl_addBuoyancyFrom(ctx, _tt(USrc), _tt(U), _tt(flags), _tt(density),
+                                                _vec3(gravity, "gravity"), float(dt), int(is3D)))
+        return
     _call(lib, ctx, lib.tfl_addBuoyancy(ctx, _tt(U), _tt(flags), _tt(density), _vec3(gravity, "gravity"),
                                         None, float(dt), int(is3D)))
 

@@ -123,6 +123,12 @@ int tfl_addBuoyancy(tfl_ctx* ctx, const tfl_tensor* U, const tfl_tensor* flags,
                     const tfl_tensor* density, const float gravity[3], float* strengthTmp,
                     float dt, int is3D);
 
+/* tfl_addBuoyancy out of place: U = USrc + buoyancy(flags, density), every cell of U written. simulate() uses it
+ * with USrc = advectVel's output buffer, which makes the reference's `U:copy(UDst)` after the advection
+ * (init.lua:216-218) part of this pass instead of a sweep of its own. USrc == U is tfl_addBuoyancy. */
+int tfl_addBuoyancyFrom(tfl_ctx* ctx, const tfl_tensor* USrc, const tfl_tensor* U, const tfl_tensor* flags,
+                        const tfl_tensor* density, const float gravity[3], float dt, int is3D);
+
 /* init.lua:505 -> third_party/tfluids.cc:1239-1306 | tfluids.cu:1279-1349 (in place on U). */
 int tfl_addGravity(tfl_ctx* ctx, const tfl_tensor* U, const tfl_tensor* flags,
                    const float gravity[3], float dt, int is3D, float* forceTmp);
