@@ -21,6 +21,7 @@
 
 namespace tfl {
 
+
 struct AdvArgs {
   Dom d;
   float dt;
@@ -125,6 +126,7 @@ __device__ __forceinline__ bool manta_clamp_bounds(const Dom& d, const float* __
     else if (k0 != 0 || k1 != 0) return false;
     if (i0 < 0 || j0 < 0 || i1 >= d.X || j1 >= d.Y) return false;
     const int a = TFL_AT(d, i0, j0, k0);
+#ifdef TFL_EXACT_MINMAX
     minmax(lo, hi, g[a]);
     minmax(lo, hi, g[a + 1]);
     minmax(lo, hi, g[a + d.sy]);
@@ -136,6 +138,22 @@ __device__ __forceinline__ bool manta_clamp_bounds(const Dom& d, const float* __
       minmax(lo, hi, g[c + d.sy]);
       minmax(lo, hi, g[c + 1 + d.sy]);
     }
+#else
+    // v_min3_f32 / v_max3_f32: one instruction per corner pair instead of four. Equal to the reference's
+    // compare-and-keep chain in value; only the SIGN of a zero bound can differ (min prefers -0, the chain the
+    // first zero it met), which no later operation of the step can turn into a different number.
+    lo = __builtin_fminf(__builtin_fminf(lo, g[a]), g[a + 1]);
+    hi = __builtin_fmaxf(__builtin_fmaxf(hi, g[a]), g[a + 1]);
+    lo = __builtin_fminf(__builtin_fminf(lo, g[a + d.sy]), g[a + 1 + d.sy]);
+    hi = __builtin_fmaxf(__builtin_fmaxf(hi, g[a + d.sy]), g[a + 1 + d.sy]);
+    if (IS3D) {
+      const int c = a + d.sz;
+      lo = __builtin_fminf(__builtin_fminf(lo, g[c]), g[c + 1]);
+      hi = __builtin_fmaxf(__builtin_fmaxf(hi, g[c]), g[c + 1]);
+      lo = __builtin_fminf(__builtin_fminf(lo, g[c + d.sy]), g[c + 1 + d.sy]);
+      hi = __builtin_fmaxf(__builtin_fmaxf(hi, g[c + d.sy]), g[c + 1 + d.sy]);
+    }
+#endif
   }
   return true;
 }
@@ -230,10 +248,9 @@ __global__ __launch_bounds__(256) void k_minmax3(Dom d, int outside, const float
 }
 
 // The same grid with four x-cells per thread and no LDS (tfl_vec4.hpp): per cell row of the 3^dim
-// neighbourhood one 16-byte load of src and of flags; a masked-out cell is carried as NaN (every
-// comparison with it is false -- exactly the reference's "skip", and a NaN in src itself is skipped by the
-// reference's comparisons too), so ONE value per cell crosses lanes. Same ascending z,y,x visiting order
-// as getClampBounds (matters only for the sign of a zero bound).
+// neighbourhood one 16-byte load of src and of flags; a masked-out cell is carried as NaN (min/max ignore it --
+// exactly the reference's "skip", and a NaN in src itself is skipped by the reference's comparisons too), so
+// ONE value per cell crosses lanes.
 template <bool IS3D>
 __global__ __launch_bounds__(256) void k_minmax3_v4(Dom d, int outside, const float* __restrict__ s,
                                                     const float* __restrict__ flags, float* __restrict__ lo3,
@@ -265,10 +282,13 @@ __global__ __launch_bounds__(256) void k_minmax3_v4(Dom d, int outside, const fl
       e[5] = from_lane_above(e[1]);
       if (c.first) e[0] = (ok && c.has_l) ? masked(s[o - 1], flags[o - 1]) : qnan;
       if (c.last) e[5] = (ok && c.has_r) ? masked(s[o + 4], flags[o + 4]) : qnan;
+      // v_min3 / v_max3 skip NaN operands like the reference's comparisons do; against its compare-and-keep
+      // chain only the sign of a zero bound can differ (see manta_clamp_bounds)
 #pragma unroll
-      for (int q = 0; q < 4; q++)
-#pragma unroll
-        for (int t = 0; t < 3; t++) minmax(lo[q], hi[q], e[q + t]);
+      for (int q = 0; q < 4; q++) {
+        lo[q] = __builtin_fminf(__builtin_fminf(__builtin_fminf(lo[q], e[q]), e[q + 1]), e[q + 2]);
+        hi[q] = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(hi[q], e[q]), e[q + 1]), e[q + 2]);
+      }
     }
   if (live) {
     const int o = TFL_AT(d, c.i0, j, k);

@@ -109,23 +109,31 @@ __device__ __forceinline__ v3 get_at_mac(const Dom& d, const float* __restrict__
 // ---- interpolation, third_party/grid.cc:82-130 (buildIndex), :182-202, :204-332 ----------------
 struct Lerp { int xi, yi, zi; float s0, s1, t0, t1, f0, f1; };
 
+// buildIndex clamps in two branches per axis (pos < 0.5 -> cell 0, weights 1/0; cell >= N-1 -> cell N-2, weights
+// 0/1). Clamping the shifted coordinate to [0, N-1] FIRST gives the same cell and the same weights without
+// branches (6 VALU per axis instead of 12): inside the range nothing changes (s1 = px - float(int(px)), the same
+// subtraction), below it px = 0 -> cell 0, s1 = 0, s0 = 1; above it px = N-1 -> cell N-2, s1 = 1, s0 = 0.
+__device__ __forceinline__ void lerp_axis(float p, int n, int& idx, float& w0, float& w1) {
+  const float pc = __builtin_fminf(__builtin_fmaxf(p, 0.0f), (float)(n - 1));
+  idx = min((int)pc, n - 2);
+  w1 = pc - (float)idx;
+  w0 = 1.0f - w1;
+}
+
 template <bool IS3D>
 __device__ __forceinline__ Lerp build_index(const Dom& d, v3 pos) {
   Lerp L;
-  const float px = pos.x - 0.5f, py = pos.y - 0.5f, pz = pos.z - 0.5f;
-  L.xi = (int)px; L.yi = (int)py; L.zi = (int)pz;
-  L.s1 = px - (float)L.xi; L.s0 = 1.0f - L.s1;
-  L.t1 = py - (float)L.yi; L.t0 = 1.0f - L.t1;
-  L.f1 = pz - (float)L.zi; L.f0 = 1.0f - L.f1;
-  if (px < 0.0f) { L.xi = 0; L.s0 = 1.0f; L.s1 = 0.0f; }
-  if (py < 0.0f) { L.yi = 0; L.t0 = 1.0f; L.t1 = 0.0f; }
-  if (pz < 0.0f) { L.zi = 0; L.f0 = 1.0f; L.f1 = 0.0f; }
-  if (L.xi >= d.X - 1) { L.xi = d.X - 2; L.s0 = 0.0f; L.s1 = 1.0f; }
-  if (L.yi >= d.Y - 1) { L.yi = d.Y - 2; L.t0 = 0.0f; L.t1 = 1.0f; }
+  lerp_axis(pos.x - 0.5f, d.X, L.xi, L.s0, L.s1);
+  lerp_axis(pos.y - 0.5f, d.Y, L.yi, L.t0, L.t1);
   if (IS3D) {
-    if (L.zi >= d.Z - 1) { L.zi = d.Z - 2; L.f0 = 0.0f; L.f1 = 1.0f; }
+    lerp_axis(pos.z - 0.5f, d.Z, L.zi, L.f0, L.f1);
   } else {
-    L.zi = 0;  // Z == 1: the 2-D samplers only ever touch plane 0
+    // Z == 1: the 2-D samplers only ever touch plane 0 (weights as the reference computes them)
+    const float pz = pos.z - 0.5f;
+    L.zi = (int)pz;
+    L.f1 = pz - (float)L.zi; L.f0 = 1.0f - L.f1;
+    if (pz < 0.0f) { L.f0 = 1.0f; L.f1 = 0.0f; }
+    L.zi = 0;
   }
   return L;
 }
@@ -200,6 +208,12 @@ __device__ __forceinline__ int blocked_at(const Dom& d, const float* __restrict_
   const int i = (int)p.x, j = (int)p.y, k = (int)p.z;
   if (i < 0 || i >= d.X || j < 0 || j >= d.Y || k < 0 || k >= d.Z) return -1;
   return fluid_at(d, flags, i, j, k) ? 0 : 1;
+}
+
+// blocked_at for a position already known to be inside the domain (0 < p < N on every axis, so the truncated
+// cell index is in range and the reference's out-of-grid error cannot fire): skips the six range tests
+__device__ __forceinline__ int blocked_inside(const Dom& d, const float* __restrict__ flags, v3 p) {
+  return fluid_at(d, flags, (int)p.x, (int)p.y, (int)p.z) ? 0 : 1;
 }
 
 // Ray/box test, calc_line_trace.cc:101-171
@@ -282,13 +296,11 @@ __device__ inline int line_trace(const Dom& d, const float* __restrict__ flags, 
         ip.z = stdmin(stdmax(next.z, TFL_HIT_MARGIN), (float)d.Z - TFL_HIT_MARGIN);
       }
       if (out_of_domain(d, ip)) return -3;
-      const int blk = blocked_at(d, flags, ip);
-      if (blk < 0) return -4;
-      if (!blk) { out = ip; return 1; }
+      if (!blocked_inside(d, flags, ip)) { out = ip; return 1; }
       next = ip;
     }
-    int blk = blocked_at(d, flags, next);
-    if (blk < 0) return -4;
+    // here `next` is inside the domain (either it never left, or it is the checked `ip`)
+    int blk = blocked_inside(d, flags, next);
     if (blk) {
       for (int count = 0; count <= 4; count++) {
         blk = blocked_at(d, flags, next);
