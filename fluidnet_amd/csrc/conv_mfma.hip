@@ -20,6 +20,13 @@
 // loads and epilogue stores are 16/64-byte contiguous. B fragments (the weights, pre-arranged per lane
 // on the host) sit in registers for the whole kernel: 9*C_in VGPRs.
 //
+// The MFMA is issued TRANSPOSED (weights as the A operand, the x window as B): D'[n][m] = D[m][n], so a lane
+// ends up with FOUR CONSECUTIVE CHANNELS of one voxel (rows n = 4*(lane/16) + 0..3 of column m = lane%16):
+// the epilogue is one 16-byte store per lane and row (a wave writes 1 KB contiguous), and D' is already in the
+// B-operand layout of a further MFMA that contracts over n -- which is how the last layer's fused 1x1x1
+// convolution (8 -> 8) is evaluated: 4 more MFMAs per row against a block-diagonal [16][16] copy of its weights,
+// no cross-lane traffic.
+//
 // Block = 256 threads = 4 waves; block tile = 32(x) x 8(y) x 4(z); wave w owns z-plane w, 8 rows ->
 // 8 independent accumulators (covers the 40-cycle dependent-MFMA latency at the 32-cycle issue rate).
 // The input channels are staged 4 at a time: LDS 4*6*10*36*4 = 34.5 KB -> 4 blocks per CU, so while one
@@ -84,11 +91,12 @@ __global__ __launch_bounds__(256, 4) void k_conv3_mfma(Dom d, int tiles_x, int t
   float bf[CIN * 9];
 #pragma unroll
   for (int q = 0; q < CIN * 9; q++) bf[q] = bfrag[q * 64 + lane];
-  const int co = lane & 7;
-  const float bv = bias[co];
+  // D' layout: lane holds rows n = 4*g + i (i = 0..3) of column m = lane & 15; n = ph*8 + co
+  const int g = lane >> 4, ph = g >> 1, co0 = 4 * (g & 1);
+  const f32x4 bv = {bias[co0], bias[co0 + 1], bias[co0 + 2], bias[co0 + 3]};
   f32x4 acc[kTY];
 #pragma unroll
-  for (int r = 0; r < kTY; r++) acc[r] = (f32x4){bv, bv, bv, bv};
+  for (int r = 0; r < kTY; r++) acc[r] = bv;
   const int lane_off = 2 * (lane & 15) + (lane >> 4);
   float in_scale = 1.0f;
   if (IN_PLANAR && cin.stats) {  // lib/modules/variance.lua:44-76 (n-1) + Sqrt, as model.hip scale_from_stats
@@ -146,49 +154,54 @@ __global__ __launch_bounds__(256, 4) void k_conv3_mfma(Dom d, int tiles_x, int t
         for (int dy = 0; dy < 3; dy++) {
           const float bval = bf[((cg + cl) * 3 + dz) * 3 + dy];
 #pragma unroll
-          for (int r = 0; r < kTY; r++) acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r + dy], bval, acc[r], 0, 0, 0);
+          for (int r = 0; r < kTY; r++) acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(bval, a[r + dy], acc[r], 0, 0, 0);
         }
       }
     }
   }
   // ---- epilogue ----------------------------------------------------------------------------------
-  // D layout: lane holds rows m = (lane>>4)*4 + i (i = 0..3) of column n = lane&15 = ph*8 + co.
-  const int g = lane >> 4, ph = (lane >> 3) & 1;
   const int z = z0 + wave;
+  const int x = x0 + 2 * (lane & 15) + ph;      // the lane's voxel; its channels co0 .. co0+3
   if (!TAIL) {
     out += (long long)b * cells * 8;
 #pragma unroll
     for (int r = 0; r < kTY; r++) {
       const int y = y0 + r;
-#pragma unroll
-      for (int i = 0; i < 4; i++) {
-        const int x = x0 + 8 * g + 2 * i + ph;
-        if (x < d.X && y < d.Y && z < d.Z) out[(long long)TFL_AT(d, x, y, z) * 8 + co] = fmaxf(acc[r][i], 0.0f);
+      if (x < d.X && y < d.Y && z < d.Z) {
+        const float4 v = make_float4(fmaxf(acc[r][0], 0.0f), fmaxf(acc[r][1], 0.0f), fmaxf(acc[r][2], 0.0f),
+                                     fmaxf(acc[r][3], 0.0f));
+        *reinterpret_cast<float4*>(out + (long long)TFL_AT(d, x, y, z) * 8 + co0) = v;
       }
     }
   } else {
-    float w4r[8];
+    // 8 -> 8 (k = 1) + ReLU as a second MFMA: E'[n'][m] = b4 + sum_n W4big[n'][n] * relu(D')[n][m], where
+    // W4big = diag(w4, w4) over the two x phases. relu(D') register i of lane (k = g, m) is element
+    // [4k + i][m], i.e. exactly the B operand of the partial product over n = 4k + i, k = 0..3.
+    float a4[4];
+    {
+      const int np = lane & 15, php = np >> 3, cop = np & 7;
 #pragma unroll
-    for (int c = 0; c < 8; c++) w4r[c] = tail.w4[co * 8 + c];
-    const float b4 = tail.b4[co], w5 = tail.w5[co], b5 = tail.b5[0];
-    const int grp = lane & ~7;
+      for (int i = 0; i < 4; i++) {
+        const int n = 4 * g + i;
+        a4[i] = ((n >> 3) == php) ? tail.w4[cop * 8 + (n & 7)] : 0.0f;
+      }
+    }
+    const f32x4 b4v = {tail.b4[co0], tail.b4[co0 + 1], tail.b4[co0 + 2], tail.b4[co0 + 3]};
+    const float w5v[4] = {tail.w5[co0], tail.w5[co0 + 1], tail.w5[co0 + 2], tail.w5[co0 + 3]};
+    const float b5 = tail.b5[0];
     out += (long long)b * cells;
 #pragma unroll
     for (int r = 0; r < kTY; r++) {
+      f32x4 e = b4v;
+#pragma unroll
+      for (int i = 0; i < 4; i++) e = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[i], fmaxf(acc[r][i], 0.0f), e, 0, 0, 0);
+      // 8 -> 1: this lane's four channels, then the other four from lane ^ 16 (same voxel, co0 ^ 4)
+      float v = w5v[0] * fmaxf(e[0], 0.0f);
+#pragma unroll
+      for (int i = 1; i < 4; i++) v = fmaf(w5v[i], fmaxf(e[i], 0.0f), v);
+      const float other = __shfl_xor(v, 16, 64);
       const int y = y0 + r;
-#pragma unroll
-      for (int i = 0; i < 4; i++) {
-        const float h = fmaxf(acc[r][i], 0.0f);
-        float h4 = b4;
-#pragma unroll
-        for (int c = 0; c < 8; c++) h4 = fmaf(w4r[c], __shfl(h, grp + c, 64), h4);
-        float v = w5 * fmaxf(h4, 0.0f);
-        v += __shfl_xor(v, 1, 64);
-        v += __shfl_xor(v, 2, 64);
-        v += __shfl_xor(v, 4, 64);
-        const int x = x0 + 8 * g + 2 * i + ph;
-        if (co == 0 && x < d.X && y < d.Y && z < d.Z) out[TFL_AT(d, x, y, z)] = v + b5;
-      }
+      if (co0 == 0 && x < d.X && y < d.Y && z < d.Z) out[TFL_AT(d, x, y, z)] = (v + other) + b5;
     }
   }
 }
