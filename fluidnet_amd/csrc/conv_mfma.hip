@@ -108,9 +108,11 @@ __global__ __launch_bounds__(256, 4) void k_conv3_mfma(Dom d, int tiles_x, int t
   for (int cg = 0; cg < CIN; cg += CG) {
     if (cg > 0) __syncthreads();   // everyone is done reading the previous channel group
     // ---- stage the halo tile of channels [cg, cg + CG) --------------------------------------------
-    for (int idx = tid; idx < ((dbg & 2) ? 0 : kRows * 34); idx += 256) {
-      const int xx = idx % 34, row = idx / 34;
-      const int yy = row % (kTY + 2), zz = row / (kTY + 2);
+    // element -> (row, xx) without integer division by 34: the 32 interior columns are dealt 32 per row
+    // (shift/mask), the two halo columns (xx = 0, 33) of the 60 rows go to the first 120 threads.
+    auto stage_one = [&](int row, int xx) {
+      const int zz = (row * 205) >> 11;            // row / 10 for row < 1024
+      const int yy = row - zz * (kTY + 2);
       const int gx = x0 - 1 + xx, gy = y0 - 1 + yy, gz = z0 - 1 + zz;
       const bool ok = gx >= 0 && gx < d.X && gy >= 0 && gy < d.Y && gz >= 0 && gz < d.Z;
       float v[CG];
@@ -136,6 +138,14 @@ __global__ __launch_bounds__(256, 4) void k_conv3_mfma(Dom d, int tiles_x, int t
       }
 #pragma unroll
       for (int c = 0; c < CG; c++) lds[c * kPlane + row * kLX + xx] = v[c];
+    };
+    if (!(dbg & 2)) {
+#pragma unroll
+      for (int it = 0; it < (kRows * 32 + 255) / 256; it++) {
+        const int row = (tid >> 5) + it * 8;
+        if (row < kRows) stage_one(row, (tid & 31) + 1);
+      }
+      if (tid < 2 * kRows) stage_one(tid >> 1, (tid & 1) * 33);
     }
     __syncthreads();
     // ---- implicit GEMM over these channels ---------------------------------------------------------
