@@ -297,11 +297,14 @@ __global__ __launch_bounds__(256) void k_minmax3_v4(Dom d, int outside, const fl
   }
 }
 
+// 8 waves per SIMD for the scalar passes (their traces are latency-bound; measured -2 us each at 128^3, r01)
+#define TFL_SCALAR_OCC __attribute__((amdgpu_waves_per_eu(8, 8)))
+
 // ---- advectScalar ------------------------------------------------------------------------------
 // Pass A / single-pass methods. For kMacCormackOurs the clamp bounds go to bounds[0], bounds[1]
 // (two channel planes of the caller's fwdPos temp; empty neighbourhood is stored as lo=+inf > hi).
 template <bool IS3D, int METHOD>
-__global__ __launch_bounds__(256) void k_scalar_fwd(AdvArgs a, const float* __restrict__ s, const float* __restrict__ U,
+__global__ __launch_bounds__(256) TFL_SCALAR_OCC void k_scalar_fwd(AdvArgs a, const float* __restrict__ s, const float* __restrict__ U,
                                                     const float* __restrict__ flags, float* __restrict__ out,
                                                     float* __restrict__ bounds, const float* __restrict__ lo3,
                                                     const float* __restrict__ hi3) {
@@ -335,7 +338,7 @@ __global__ __launch_bounds__(256) void k_scalar_fwd(AdvArgs a, const float* __re
 
 // Pass B of the two MacCormack flavours: bwd + correct (tfluids.cc:220-234) + clamp (:297-413).
 template <bool IS3D, int METHOD>
-__global__ __launch_bounds__(256) void k_scalar_bwd(AdvArgs a, const float* __restrict__ s, const float* __restrict__ U,
+__global__ __launch_bounds__(256) TFL_SCALAR_OCC void k_scalar_bwd(AdvArgs a, const float* __restrict__ s, const float* __restrict__ U,
                                                     const float* __restrict__ flags, const float* __restrict__ fwd,
                                                     const float* __restrict__ bounds, float* __restrict__ dst) {
   TFL_CELL_INDEX();
