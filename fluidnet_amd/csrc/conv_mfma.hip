@@ -34,8 +34,10 @@
 #include "tfl_device.hpp"
 #include "tfl_host.hpp"
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <vector>
 
 namespace tfl {
 
@@ -64,15 +66,18 @@ template <int CIN, bool IN_PLANAR, bool TAIL>
 __global__ __launch_bounds__(256, 4) void k_conv3_mfma(Dom d, int tiles_x, int tiles_y, int tiles_z, int n_tiles,
                                                        const float* __restrict__ in, const float* __restrict__ bfrag,
                                                        const float* __restrict__ bias, float* __restrict__ out,
-                                                       ConvTail tail, ConvIn cin, int dbg) {
+                                                       ConvTail tail, ConvIn cin, int dbg, unsigned long long* __restrict__ trace) {
   // dbg (env TFL_CONV_DEBUG, timing experiments only -- results are garbage): bit 0 skips the MFMA loop,
   // bit 1 skips the staging loads. Block-uniform branches, free when 0.
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  // phase timestamps of wave 0 of every block (TFL_CONV_TRACE=1, development aid): s_memtime = shader clock
+#define TFL_STAMP(slot) do { if (trace && threadIdx.x == 0) trace[(long long)blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
   // XCD-aware tile order: the dispatcher deals consecutive block ids round-robin over the 8 XCDs, so
   // give each XCD a contiguous run of tiles (neighbouring tiles share halo planes through its L2).
   const int per_xcd = (n_tiles + 7) / 8;
   const int tile = (int)(blockIdx.x % 8) * per_xcd + (int)(blockIdx.x / 8);
   if (tile >= n_tiles) return;
+  TFL_STAMP(0);
   int t = tile;
   const int tx = t % tiles_x; t /= tiles_x;
   const int ty = t % tiles_y; t /= tiles_y;
@@ -148,6 +153,7 @@ __global__ __launch_bounds__(256, 4) void k_conv3_mfma(Dom d, int tiles_x, int t
       if (tid < 2 * kRows) stage_one(tid >> 1, (tid & 1) * 33);
     }
     __syncthreads();
+    TFL_STAMP(1 + 2 * (cg / CG));
     // ---- implicit GEMM over these channels ---------------------------------------------------------
     // One step = one (c, dz): the 10 halo rows of LDS plane (wave + dz) feed 3 (dy) x 8 (rows) = 24 MFMAs;
     // consecutive uses of one accumulator are 8 MFMAs apart (> the 40-cycle dependent latency).
@@ -168,7 +174,9 @@ __global__ __launch_bounds__(256, 4) void k_conv3_mfma(Dom d, int tiles_x, int t
         }
       }
     }
+    TFL_STAMP(2 + 2 * (cg / CG));
   }
+  TFL_STAMP(1 + 2 * ((CIN + CG - 1) / CG));
   // ---- epilogue ----------------------------------------------------------------------------------
   const int z = z0 + wave;
   const int x = x0 + 2 * (lane & 15) + ph;      // the lane's voxel; its channels co0 .. co0+3
@@ -214,6 +222,8 @@ __global__ __launch_bounds__(256, 4) void k_conv3_mfma(Dom d, int tiles_x, int t
       if (co0 == 0 && x < d.X && y < d.Y && z < d.Z) out[TFL_AT(d, x, y, z)] = (v + other) + b5;
     }
   }
+  TFL_STAMP(7);
+#undef TFL_STAMP
 }
 
 template <int CIN, bool IN_PLANAR, bool TAIL>
@@ -238,7 +248,46 @@ static void launch_mfma(hipStream_t st, const Dom& d, int B, const float* in, co
   }
   TFL_TIMED(TAIL ? "k_conv3_mfma_tail" : (IN_PLANAR ? "k_conv3_mfma_in" : "k_conv3_mfma"), st);
   static const int dbg = getenv("TFL_CONV_DEBUG") ? atoi(getenv("TFL_CONV_DEBUG")) : 0;
-  k_conv3_mfma<CIN, IN_PLANAR, TAIL><<<grid, 256, lds_bytes, st>>>(d, tx, ty, tz, n_tiles, in, bfrag, bias, out, tail, cin, dbg);
+  static const bool want_trace = getenv("TFL_CONV_TRACE") != nullptr;
+  if (want_trace) {
+    // development aid: per-block phase timestamps of this launch, summarised on stderr (synchronises!)
+    unsigned long long* dev = nullptr;
+    const size_t n = (size_t)grid * 8;
+    if (hipMalloc((void**)&dev, n * 8) != hipSuccess) return;
+    (void)hipMemsetAsync(dev, 0, n * 8, st);
+    k_conv3_mfma<CIN, IN_PLANAR, TAIL><<<grid, 256, lds_bytes, st>>>(d, tx, ty, tz, n_tiles, in, bfrag, bias, out, tail, cin, dbg, dev);
+    std::vector<unsigned long long> h(n);
+    (void)hipStreamSynchronize(st);
+    (void)hipMemcpy(h.data(), dev, n * 8, hipMemcpyDeviceToHost);
+    (void)hipFree(dev);
+    // s_memtime bases differ between XCDs: compare only within one XCD (block b runs on XCD b % 8). Blocks whose
+    // start lies within 2000 cycles of their XCD's first start are the first dispatch round.
+    const int nst = 2 * ((CIN + 3) / 4) + 1;   // slot of the epilogue start
+    double seg[2][8] = {{0}}; int cnt[2] = {0, 0}; double life[2] = {0, 0}; double xspan = 0;
+    for (int x = 0; x < 8; x++) {
+      unsigned long long t0 = ~0ull, t1 = 0;
+      for (int b = x; b < grid; b += 8) if (h[b * 8]) { t0 = std::min(t0, h[b * 8]); t1 = std::max(t1, h[b * 8 + 7]); }
+      xspan += (double)(t1 - t0) / 8;
+      for (int b = x; b < grid; b += 8) {
+        if (!h[b * 8]) continue;
+        const int late = (h[b * 8] - t0) > 2000 ? 1 : 0;
+        cnt[late]++;
+        for (int q = 1; q <= nst; q++) seg[late][q] += (double)(h[b * 8 + q] - h[b * 8 + q - 1]);
+        seg[late][7] += (double)(h[b * 8 + 7] - h[b * 8 + nst]);
+        life[late] += (double)(h[b * 8 + 7] - h[b * 8]);
+      }
+    }
+    fprintf(stderr, "[tfl] conv trace <%d,%d,%d>: kernel span %.0f cyc (per XCD);", CIN, (int)IN_PLANAR, (int)TAIL, xspan);
+    for (int l = 0; l < 2; l++) {
+      if (!cnt[l]) continue;
+      fprintf(stderr, " %s %d blocks: life %.0f =", l ? "| later" : "first-round", cnt[l], life[l] / cnt[l]);
+      for (int q = 1; q < nst; q++) fprintf(stderr, " %s%d %.0f", (q & 1) ? "stage" : "mfma", (q + 1) / 2, seg[l][q] / cnt[l]);
+      fprintf(stderr, " epilogue %.0f", seg[l][7] / cnt[l]);
+    }
+    fprintf(stderr, "\n");
+    return;
+  }
+  k_conv3_mfma<CIN, IN_PLANAR, TAIL><<<grid, 256, lds_bytes, st>>>(d, tx, ty, tz, n_tiles, in, bfrag, bias, out, tail, cin, dbg, nullptr);
 }
 
 // 3 -> 8 (planar in) / 8 -> 8 (channel-last in), k = 3, ReLU; channel-last [Z][Y][X][8] out.
