@@ -26,7 +26,7 @@ import math
 import torch
 
 from . import tfluids
-from .simulate import _apply, _f32, _gravity, setConstVals
+from .simulate import _f32, _gravity, _sparse_bc, setConstVals
 
 DEFAULT_HALO = 10
 
@@ -254,9 +254,12 @@ class SlabSimulation:
         self.model.begin(U, flags, lay.c0, lay.c1, self.stats)
         if multi:
             yield ("allreduce", self.stats)
-        self.model.finish(p, U, flags, self.stats, self.count, UBC=b.get("UBC"), UBCInvMask=b.get("UBCInvMask"),
-                          clamp=(-1e6, 1e6))
-        rest = {k: v for k, v in b.items() if k not in ("UBC", "UBCInvMask")}
+        ubc, umask = b.get("UBC"), b.get("UBCInvMask")
+        sp = _sparse_bc(U, ubc, umask)
+        late_ubc = sp is not None and sp[1]      # as in simulate(): sparse idempotent U BCs go after the projection
+        self.model.finish(p, U, flags, self.stats, self.count, UBC=None if late_ubc else ubc,
+                          UBCInvMask=None if late_ubc else umask, clamp=(-1e6, 1e6))
+        rest = b if late_ubc else {k: v for k, v in b.items() if k not in ("UBC", "UBCInvMask")}
         setConstVals(rest, p, U, flags, rho, unchanged=("density",))
         if multi:
             tfluids.setDxOverride(U, None)

@@ -67,8 +67,8 @@ _bc_index_cache = {}   # (bc ptr, mask ptr, numel) -> (bc version, mask version,
 
 def _bc_indices(bc, inv):
     """(idx, idempotent): idx = the element indices where the BC pair is not the identity (invMask != 1 or
-    bc != 0); idempotent = every such element has invMask == 0, i.e. x*0 + bc applied twice equals applied once,
-    bit for bit. Cached per tensor pair and invalidated by torch's in-place version counters (the 2-D demo
+    bc != 0); idempotent = every such element has invMask == 0 (and |bc| <= 1e6), i.e. x*0 + bc applied twice
+    equals applied once, bit for bit, and commutes with the step's final clamp to +-1e6. Cached per tensor pair and invalidated by torch's in-place version counters (the 2-D demo
     edits its BCs interactively)."""
     key = (bc.data_ptr(), inv.data_ptr(), bc.numel())
     hit = _bc_index_cache.get(key)
@@ -77,6 +77,8 @@ def _bc_indices(bc, inv):
     flat_inv = inv.reshape(-1)
     idx = torch.nonzero((flat_inv != 1) | (bc.reshape(-1) != 0)).reshape(-1)
     idem = bool((flat_inv[idx] == 0).all().item())
+    if idem and idx.numel():     # "idempotent" also promises |bc| <= 1e6: the final U:clamp(-1e6, 1e6) leaves them alone
+        idem = bool((bc.reshape(-1)[idx].abs() <= 1e6).all().item())
     idx = idx.to(torch.int32)
     if len(_bc_index_cache) > 64:
         _bc_index_cache.clear()
@@ -208,14 +210,19 @@ def simulate(conf, mconf, batch, model, outputDiv=False):
 
     fused_tail = False
     if simMethod == "convnet":
-        # model:forward + p:copy(pPred); U:copy(UPred) (simulate.lua:262-272): the prediction is
-        # written straight into the state tensors, and the trailing setConstVals(U) + U:clamp
-        # (simulate.lua:321-326) ride in the projection's last kernel.
-        model.forward([p, U, flags], out=[p, U], UBC=batch.get("UBC"), UBCInvMask=batch.get("UBCInvMask"),
+        # model:forward + p:copy(pPred); U:copy(UPred) (simulate.lua:262-272): the prediction is written straight
+        # into the state tensors, and the trailing setConstVals(U) + U:clamp (simulate.lua:321-326) ride in the
+        # projection's last kernel. When the U BC pair is a
+        # sparse idempotent one (the plume: 4 of 128 rows, invMask 0), reading two dense BC fields there costs
+        # more than touching the BC cells afterwards: clamp(0*u + bc) = bc, so the index-list form is exact.
+        ubc, umask = batch.get("UBC"), batch.get("UBCInvMask")
+        sp = _sparse_bc(U, ubc, umask)
+        late_ubc = sp is not None and sp[1]
+        model.forward([p, U, flags], out=[p, U], UBC=None if late_ubc else ubc, UBCInvMask=None if late_ubc else umask,
                       clamp=(-1e6, 1e6))
         fused_tail = True
-        # U is done (fused tail); p was rewritten by the model, density has not changed since setConstVals #2
-        rest = {k: v for k, v in batch.items() if k not in ("UBC", "UBCInvMask")}
+        # p was rewritten by the model, density has not changed since setConstVals #2
+        rest = batch if late_ubc else {k: v for k, v in batch.items() if k not in ("UBC", "UBCInvMask")}
         setConstVals(rest, p, U, flags, density, unchanged=("density",))
     elif simMethod == "jacobi":
         div = batch.get("div")
