@@ -383,6 +383,32 @@ int tfl_flagsToOccupancy(tfl_ctx* c, const tfl_tensor* flags, const tfl_tensor* 
   return check_launch(c, "flagsToOccupancy");
 }
 
+int64_t tfl_pcg_workspace_floats(int32_t Z, int32_t Y, int32_t X) { return tfl::pcg_workspace_floats(Z, Y, X); }
+
+int tfl_solveLinearSystemPCG(tfl_ctx* c, const tfl_tensor* p, const tfl_tensor* flags, const tfl_tensor* div, int is3D,
+                             const char* precondType, float tol, int maxIter, int verbose, float* workspace,
+                             int64_t workspace_floats, float* residual) {
+  TRY(check_flags(c, "solveLinearSystemPCG", flags));
+  TRY(check_scalar(c, "solveLinearSystemPCG", "p", p, flags));
+  TRY(check_scalar(c, "solveLinearSystemPCG", "div", div, flags));
+  if (!is3D && flags->Z != 1) return fail(c, TFL_EINVAL, "solveLinearSystemPCG: d > 1 for a 2D domain");
+  int pc = -1;
+  const std::string pt = precondType ? precondType : "ic0";
+  if (pt == "none") pc = 0; else if (pt == "ilu0") pc = 1; else if (pt == "ic0") pc = 2;
+  if (pc < 0) return fail(c, TFL_EINVAL, "solveLinearSystemPCG: precondType is not supported.");
+  if (!workspace || ((uintptr_t)workspace & 7) != 0) return fail(c, TFL_EINVAL, "solveLinearSystemPCG: workspace must be 8-byte aligned");
+  if (workspace_floats < tfl::pcg_workspace_floats(flags->Z, flags->Y, flags->X))
+    return fail(c, TFL_EINVAL, "solveLinearSystemPCG: workspace too small (tfl_pcg_workspace_floats)");
+  if ((long long)flags->Z * flags->Y * flags->X >= (1ll << 31)) return fail(c, TFL_EINVAL, "solveLinearSystemPCG: grid too large for 32-bit cell indices");
+  char msg[256] = {0};
+  const int rc = tfl::pcg_solve(c->stream, is3D != 0, flags->B, flags->Z, flags->Y, flags->X, p->data, flags->data, div->data,
+                                pc, tol, maxIter, verbose, workspace, residual, msg, sizeof(msg));
+  if (rc == -1 || rc == -3) return fail(c, TFL_EINVAL, "%s", msg);
+  if (rc == -2) return fail(c, TFL_EINVAL, "%s", msg);
+  if (rc != 0) return fail(c, TFL_EHIP, "%s", msg);
+  return check_launch(c, "solveLinearSystemPCG");
+}
+
 int tfl_solveLinearSystemJacobi(tfl_ctx* c, const tfl_tensor* p, const tfl_tensor* flags, const tfl_tensor* div,
                                 const tfl_tensor* pPrev, const tfl_tensor* pDelta, const tfl_tensor* pDeltaNorm,
                                 int is3D, float pTol, int maxIter, int verbose, float* residual) {

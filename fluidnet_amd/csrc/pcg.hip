@@ -1,0 +1,500 @@
+// pcg.hip -- the reference's baseline pressure solver, solveLinearSystemPCG (gfx950).
+//
+// Replaces tfluids_CudaMain_solveLinearSystemPCG (generic/tfluids.cu:864-1759) and its helpers
+// findConnectedFluidComponents (generic/find_connected_fluid_components.cc), createReducedSystemIndices /
+// setupLaplacian (generic/tfluids.cu:864-1093), which build a CSR matrix on the CPU for every call and run CG
+// through cuSPARSE / cuBLAS with a host read-back after every dot product.
+//
+// Here the solver is matrix-free and stays on the device:
+//   * connected fluid components: union-find label propagation on the grid (hook + compress sweeps); a
+//     component is named by its smallest cell index, so components come out in the reference's scan order;
+//   * A = the 5/7-point Laplacian of setupLaplacian, applied straight from the flag grid: diagonal = number of
+//     non-obstacle neighbours, -1 for every fluid neighbour; vectors are grid-shaped, masked by the component;
+//   * CG is Golub & Van Loan alg. 10.3.1 exactly as the reference codes it (same update order, same
+//     clampToEpsilon guards, same `r.r > tol^2 && iter <= maxIter` loop), with alpha / beta / the residual living
+//     in a device struct: the host enqueues a chunk of iterations and reads one flag back per chunk; kernels of
+//     iterations past convergence see `done` and return;
+//   * preconditioners: for this stencil ILU(0) and IC(0) touch only the diagonal (every fill-in position is
+//     outside the pattern): d(n) = a(n,n) - sum over lower fluid neighbours m of 1/d(m), in lexicographic order.
+//     ilu0: L = unit lower with l(n,m) = -1/d(m), U = upper part of A with d on the diagonal.
+//     ic0:  R upper with R(n,n) = sqrt(d(n)), R(n,q) = -1/R(n,n); M = R^T R.
+//     Cells of one hyperplane i+j+k = const are independent, so factorisation and the two triangular solves are
+//     wavefront sweeps, one launch per hyperplane (what cusparse's csrsv level analysis discovers at run time).
+//     On this hardware the unpreconditioned solve is the fast one (a sweep is ~X+Y+Z tiny launches); the
+//     preconditioned forms exist for API parity.
+// Dot products are two-stage fp64 reductions with a fixed order (bit-reproducible run to run).
+#include "tfl_device.hpp"
+#include "tfl_host.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <limits>
+#include <vector>
+
+namespace tfl {
+
+namespace {
+
+constexpr int kRedBlocks = 512;    // partial sums per dot product
+constexpr int kMaxComponents = 4096;
+
+// Device-resident solver state of one component solve.
+struct PcgState {
+  double rr1, rr0;         // current / previous ||r||^2
+  double num, prev_num;    // r.z of this / the previous iteration (preconditioned form)
+  double den;              // s.A s
+  float alpha, beta;
+  float tol2;
+  int iter, max_iter, done, first, bad;   // bad: a NaN residual was seen
+  double sum_x;
+};
+
+__device__ __forceinline__ float clamp_to_epsilon(float v) {   // generic/tfluids.cu:1203-1214
+  const float eps = 1.17549435e-38f;
+  if (fabsf(v) < eps) return v < 0.0f ? fminf(v, -eps) : fmaxf(v, eps);
+  return v;
+}
+
+__device__ __forceinline__ bool cell_fluid(const float* __restrict__ flags, int o) { return (((int)flags[o]) & kFluid) != 0; }
+__device__ __forceinline__ bool cell_obstacle(const float* __restrict__ flags, int o) { return (((int)flags[o]) & kObstacle) != 0; }
+
+// ---- connected components -------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_cc_init(Dom d, bool is3d, const float* __restrict__ flags, int* __restrict__ label,
+                                                 int* __restrict__ border_fluid) {
+  const int o = blockIdx.x * 256 + threadIdx.x;
+  if (o >= d.sc) return;
+  const bool f = cell_fluid(flags, o);
+  label[o] = f ? o : -1;
+  if (f) {
+    const int i = o % d.X, j = (o / d.X) % d.Y, k = o / (d.X * d.Y);
+    if (i < 1 || i > d.X - 2 || j < 1 || j > d.Y - 2 || (is3d && (k < 1 || k > d.Z - 2))) atomicAdd(border_fluid, 1);
+  }
+}
+
+// hook: a cell that sees a smaller label next door pulls its own label AND its current root down to it
+__global__ __launch_bounds__(256) void k_cc_hook(Dom d, bool is3d, int* __restrict__ label, int* __restrict__ changed) {
+  const int o = blockIdx.x * 256 + threadIdx.x;
+  if (o >= d.sc) return;
+  const int l = label[o];
+  if (l < 0) return;
+  const int i = o % d.X, j = (o / d.X) % d.Y, k = o / (d.X * d.Y);
+  int m = l;
+  auto look = [&](int n) { const int ln = label[n]; if (ln >= 0 && ln < m) m = ln; };
+  if (i > 0) look(o - 1);
+  if (i < d.X - 1) look(o + 1);
+  if (j > 0) look(o - d.sy);
+  if (j < d.Y - 1) look(o + d.sy);
+  if (is3d && k > 0) look(o - d.sz);
+  if (is3d && k < d.Z - 1) look(o + d.sz);
+  if (m < l) {
+    atomicMin(&label[l], m);
+    atomicMin(&label[o], m);
+    *changed = 1;
+  }
+}
+// compress: point every cell at the root of its tree
+__global__ __launch_bounds__(256) void k_cc_compress(Dom d, int* __restrict__ label) {
+  const int o = blockIdx.x * 256 + threadIdx.x;
+  if (o >= d.sc) return;
+  int l = label[o];
+  if (l < 0) return;
+  while (true) { const int p = label[l]; if (p == l) break; l = p; }
+  label[o] = l;
+}
+// roots[0..count) = the cells that name a component; size_at[root] = cells in it
+__global__ __launch_bounds__(256) void k_cc_count(Dom d, const int* __restrict__ label, int* __restrict__ size_at,
+                                                  int* __restrict__ roots, int* __restrict__ count) {
+  const int o = blockIdx.x * 256 + threadIdx.x;
+  if (o >= d.sc) return;
+  const int l = label[o];
+  if (l < 0) return;
+  // wave-aggregated: in the common case (one big component) all lanes carry the same label -> one atomic per wave
+  const unsigned long long act = __ballot(1);
+  const int leader = __ffsll((long long)act) - 1;
+  const int l0 = __shfl(l, leader, 64);
+  if (__ballot(l == l0) == act) { if ((int)(threadIdx.x & 63) == leader) atomicAdd(&size_at[l0], __popcll(act)); }
+  else atomicAdd(&size_at[l], 1);
+  if (l == o) { const int pos = atomicAdd(count, 1); if (pos < kMaxComponents) roots[pos] = o; }
+}
+
+// ---- reductions -----------------------------------------------------------------------------------------
+__device__ __forceinline__ void block_partial(double v, double* __restrict__ partials) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  __shared__ double part[4];
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) partials[blockIdx.x] = (part[0] + part[1]) + (part[2] + part[3]);
+}
+__device__ __forceinline__ double reduce_partials(const double* __restrict__ partials) {   // one block of 256
+  double v = 0.0;
+  for (int t = threadIdx.x; t < kRedBlocks; t += 256) v += partials[t];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  __shared__ double part[4];
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return (part[0] + part[1]) + (part[2] + part[3]);   // valid in thread 0 (and everywhere: all read part[])
+}
+
+// ---- CG pieces ------------------------------------------------------------------------------------------
+// x = 0, r = rhs on the component (0 elsewhere), partial r.r
+__global__ __launch_bounds__(256) void k_pcg_setup(long long n, const int* __restrict__ label, int root,
+                                                   const float* __restrict__ div, float* __restrict__ x,
+                                                   float* __restrict__ r, float* __restrict__ s, double* __restrict__ partials) {
+  double acc = 0.0;
+  for (long long o = (long long)blockIdx.x * 256 + threadIdx.x; o < n; o += (long long)gridDim.x * 256) {
+    const float v = (label[o] == root) ? div[o] : 0.0f;
+    x[o] = 0.0f; r[o] = v; s[o] = 0.0f;
+    acc += (double)v * v;
+  }
+  block_partial(acc, partials);
+}
+__global__ __launch_bounds__(256) void k_pcg_begin(PcgState* __restrict__ S, const double* __restrict__ partials, float tol,
+                                                   int max_iter) {
+  const double rr = reduce_partials(partials);
+  if (threadIdx.x == 0) {
+    S->rr1 = rr; S->rr0 = 0.0; S->num = 0.0; S->prev_num = 0.0; S->den = 0.0; S->alpha = 0.0f; S->beta = 0.0f;
+    S->tol2 = tol * tol; S->iter = 0; S->max_iter = max_iter; S->first = 1; S->sum_x = 0.0;
+    S->bad = (rr != rr) ? 1 : 0;
+    S->done = (!((float)rr > S->tol2) || S->bad) ? 1 : 0;   // while (r_norm_sq1 > tol * tol && iter <= max_iter)
+  }
+}
+// top of an iteration: the loop condition, then iter++
+__global__ void k_pcg_loop_top(PcgState* __restrict__ S) {
+  if (S->done) return;
+  if (!((float)S->rr1 > S->tol2) || S->iter > S->max_iter) { S->done = 1; return; }
+  S->iter++;
+}
+// partial a.b over the grid (vectors are 0 off the component)
+__global__ __launch_bounds__(256) void k_pcg_dot(const PcgState* __restrict__ S, long long n, const float* __restrict__ a,
+                                                 const float* __restrict__ b, double* __restrict__ partials) {
+  if (S->done) return;
+  double acc = 0.0;
+  for (long long o = (long long)blockIdx.x * 256 + threadIdx.x; o < n; o += (long long)gridDim.x * 256) acc += (double)a[o] * b[o];
+  block_partial(acc, partials);
+}
+// beta and the new search direction's scalar: num = r.z (preconditioned) from `partials`
+__global__ __launch_bounds__(256) void k_pcg_beta(PcgState* __restrict__ S, const double* __restrict__ partials, int precond) {
+  if (S->done) return;
+  double num = 0.0;
+  if (precond) num = reduce_partials(partials);
+  if (threadIdx.x != 0) return;
+  if (precond) {
+    // beta_k = r_{k-1}.z_{k-1} / (r_{k-2}.z_{k-2}); the second is last iteration's numerator
+    S->num = num;
+    S->beta = S->first ? 0.0f : (float)num / clamp_to_epsilon((float)S->prev_num);
+  } else {
+    S->num = S->rr1;
+    S->beta = S->first ? 0.0f : (float)S->rr1 / clamp_to_epsilon((float)S->rr0);
+  }
+}
+// s = z + beta * s   (iteration 1: s = z; the reference's scal-then-axpy order: (beta*s) + z)
+__global__ __launch_bounds__(256) void k_pcg_dir(const PcgState* __restrict__ S, long long n, const float* __restrict__ z,
+                                                 float* __restrict__ s) {
+  if (S->done) return;
+  const bool first = S->first != 0;
+  const float beta = S->beta;
+  for (long long o = (long long)blockIdx.x * 256 + threadIdx.x; o < n; o += (long long)gridDim.x * 256)
+    s[o] = first ? z[o] : (beta * s[o] + 1.0f * z[o]);
+}
+// w = A s on the component, partial s.w
+template <bool IS3D>
+__global__ __launch_bounds__(256) void k_pcg_apply(const PcgState* __restrict__ S, Dom d, const float* __restrict__ flags,
+                                                   const int* __restrict__ label, int root, const float* __restrict__ s,
+                                                   float* __restrict__ w, double* __restrict__ partials) {
+  if (S->done) return;
+  double acc = 0.0;
+  for (long long o = (long long)blockIdx.x * 256 + threadIdx.x; o < d.sc; o += (long long)gridDim.x * 256) {
+    float v = 0.0f;
+    if (label[o] == root) {
+      // setupLaplacian, generic/tfluids.cu:938-1075: the row of an interior fluid cell
+      const int nb[6] = {(int)o - d.sz, (int)o - d.sy, (int)o - 1, (int)o + 1, (int)o + d.sy, (int)o + d.sz};
+      float diag = 0.0f, off = 0.0f;
+#pragma unroll
+      for (int q = 0; q < 6; q++) {
+        if (!IS3D && (q == 0 || q == 5)) continue;
+        const int f = (int)flags[nb[q]];
+        if (!(f & kObstacle)) diag += 1.0f;
+        if (f & kFluid) off += s[nb[q]];
+      }
+      v = diag * s[o] - off;
+    }
+    w[o] = v;
+    acc += (double)s[o] * v;
+  }
+  block_partial(acc, partials);
+}
+__global__ __launch_bounds__(256) void k_pcg_alpha(PcgState* __restrict__ S, const double* __restrict__ partials) {
+  if (S->done) return;
+  const double den = reduce_partials(partials);
+  if (threadIdx.x != 0) return;
+  S->den = den;
+  S->alpha = (float)S->num / clamp_to_epsilon((float)den);
+}
+// x += alpha s; r -= alpha w; partial r.r
+__global__ __launch_bounds__(256) void k_pcg_update(const PcgState* __restrict__ S, long long n, const float* __restrict__ s,
+                                                    const float* __restrict__ w, float* __restrict__ x, float* __restrict__ r,
+                                                    double* __restrict__ partials) {
+  if (S->done) return;
+  const float alpha = S->alpha, nalpha = -alpha;
+  double acc = 0.0;
+  for (long long o = (long long)blockIdx.x * 256 + threadIdx.x; o < n; o += (long long)gridDim.x * 256) {
+    x[o] = alpha * s[o] + x[o];
+    const float rv = nalpha * w[o] + r[o];
+    r[o] = rv;
+    acc += (double)rv * rv;
+  }
+  block_partial(acc, partials);
+}
+__global__ __launch_bounds__(256) void k_pcg_end(PcgState* __restrict__ S, const double* __restrict__ partials) {
+  if (S->done) return;
+  const double rr = reduce_partials(partials);
+  if (threadIdx.x != 0) return;
+  S->prev_num = S->num;
+  S->rr0 = S->rr1;
+  S->rr1 = rr;
+  S->first = 0;
+  if (rr != rr) { S->bad = 1; S->done = 1; }
+}
+// sum of x over the component (for the mean), then p = x - mean on the component
+__global__ __launch_bounds__(256) void k_pcg_sum(long long n, const float* __restrict__ x, double* __restrict__ partials) {
+  double acc = 0.0;
+  for (long long o = (long long)blockIdx.x * 256 + threadIdx.x; o < n; o += (long long)gridDim.x * 256) acc += (double)x[o];
+  block_partial(acc, partials);
+}
+__global__ __launch_bounds__(256) void k_pcg_sum_end(PcgState* __restrict__ S, const double* __restrict__ partials) {
+  const double v = reduce_partials(partials);
+  if (threadIdx.x == 0) S->sum_x = v;
+}
+__global__ __launch_bounds__(256) void k_pcg_write(const PcgState* __restrict__ S, long long n, const int* __restrict__ label,
+                                                   int root, int size, const float* __restrict__ x, float* __restrict__ p) {
+  const float mean = (float)(S->sum_x / (double)size);
+  for (long long o = (long long)blockIdx.x * 256 + threadIdx.x; o < n; o += (long long)gridDim.x * 256)
+    if (label[o] == root) p[o] = x[o] - mean;      // copyPressureFromSystem, generic/tfluids.cu:1216-1240
+}
+
+// ---- ILU(0) / IC(0) on the 5/7-point pattern: wavefront sweeps over hyperplanes h = i + j + k -------------
+// thread -> (j, k) of the hyperplane, i = h - j - k
+struct Wave { int i, j, k, o; bool ok; };
+template <bool IS3D>
+__device__ __forceinline__ Wave wave_cell(const Dom& d, int h, const int* __restrict__ label, int root) {
+  Wave c;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  c.j = 1 + t % (d.Y - 2);
+  c.k = IS3D ? 1 + t / (d.Y - 2) : 0;
+  c.i = h - c.j - c.k;
+  c.ok = c.i >= 1 && c.i <= d.X - 2 && (!IS3D || c.k <= d.Z - 2) && t < (d.Y - 2) * (IS3D ? d.Z - 2 : 1);
+  c.o = c.ok ? TFL_AT(d, c.i, c.j, c.k) : 0;
+  if (c.ok && label[c.o] != root) c.ok = false;
+  return c;
+}
+// dg(n) = a(n,n) - sum_{lower fluid nbrs m} 1/dg(m)
+template <bool IS3D>
+__global__ __launch_bounds__(256) void k_ilu_factor(Dom d, int h, const float* __restrict__ flags, const int* __restrict__ label,
+                                                    int root, float* __restrict__ dg) {
+  const Wave c = wave_cell<IS3D>(d, h, label, root);
+  if (!c.ok) return;
+  const int nb[6] = {c.o - d.sz, c.o - d.sy, c.o - 1, c.o + 1, c.o + d.sy, c.o + d.sz};
+  float diag = 0.0f;
+#pragma unroll
+  for (int q = 0; q < 6; q++) {
+    if (!IS3D && (q == 0 || q == 5)) continue;
+    if (!(((int)flags[nb[q]]) & kObstacle)) diag += 1.0f;
+  }
+#pragma unroll
+  for (int q = 0; q < 3; q++) {       // lower neighbours in column order: z-1, y-1, x-1
+    if (!IS3D && q == 0) continue;
+    if (((int)flags[nb[q]]) & kFluid) diag -= 1.0f / dg[nb[q]];
+  }
+  dg[c.o] = diag;
+}
+// forward solve.  ilu0: y(n) = r(n) + sum_m y(m)/dg(m).   ic0: y(n) = (r(n) + sum_m y(m)/R(m,m)) / R(n,n)
+template <bool IS3D, bool IC>
+__global__ __launch_bounds__(256) void k_ilu_forward(const PcgState* __restrict__ S, Dom d, int h, const float* __restrict__ flags,
+                                                     const int* __restrict__ label, int root, const float* __restrict__ dg,
+                                                     const float* __restrict__ r, float* __restrict__ y) {
+  if (S->done) return;
+  const Wave c = wave_cell<IS3D>(d, h, label, root);
+  if (!c.ok) return;
+  const int nb[3] = {c.o - d.sz, c.o - d.sy, c.o - 1};
+  float v = r[c.o];
+#pragma unroll
+  for (int q = 0; q < 3; q++) {
+    if (!IS3D && q == 0) continue;
+    if (((int)flags[nb[q]]) & kFluid) v += IC ? y[nb[q]] / sqrtf(dg[nb[q]]) : y[nb[q]] / dg[nb[q]];
+  }
+  y[c.o] = IC ? v / sqrtf(dg[c.o]) : v;
+}
+// backward solve. ilu0: z(n) = (y(n) + sum_q z(q)) / dg(n).   ic0: z(n) = (y(n) + (sum_q z(q)) / R(n,n)) / R(n,n)
+template <bool IS3D, bool IC>
+__global__ __launch_bounds__(256) void k_ilu_backward(const PcgState* __restrict__ S, Dom d, int h, const float* __restrict__ flags,
+                                                      const int* __restrict__ label, int root, const float* __restrict__ dg,
+                                                      const float* __restrict__ y, float* __restrict__ z) {
+  if (S->done) return;
+  const Wave c = wave_cell<IS3D>(d, h, label, root);
+  if (!c.ok) return;
+  const int nb[3] = {c.o + 1, c.o + d.sy, c.o + d.sz};
+  float acc = 0.0f;
+#pragma unroll
+  for (int q = 0; q < 3; q++) {
+    if (!IS3D && q == 2) continue;
+    if (((int)flags[nb[q]]) & kFluid) acc += z[nb[q]];
+  }
+  if (IC) { const float rnn = sqrtf(dg[c.o]); z[c.o] = (y[c.o] + acc / rnn) / rnn; }
+  else z[c.o] = (y[c.o] + acc) / dg[c.o];
+}
+
+inline int cdiv(long long a, int b) { return (int)((a + b - 1) / b); }
+
+}  // namespace
+
+long long pcg_workspace_floats(int Z, int Y, int X) {
+  const long long n = (long long)Z * Y * X;
+  // label, size_at (int32) + x, r, z, s, w, dg, y (fp32) + roots + partials/state (fp64, kept 8-byte aligned first)
+  return 2 * (kRedBlocks + 64) + 9 * n + kMaxComponents + 64;
+}
+
+// Solves every component of every batch element. Returns 0, or a negative code with `msg` filled:
+// -1 invalid flags (fluid on the border), -2 NaN residual, -3 too many components, -4 HIP error.
+int pcg_solve(hipStream_t st, bool is3d, int B, int Z, int Y, int X, float* p, const float* flags, const float* div,
+              int precond /*0 none, 1 ilu0, 2 ic0*/, float tol, int max_iter, int verbose, float* workspace, float* residual,
+              char* msg, size_t msg_len) {
+  const Dom d = make_dom(Z, Y, X);
+  const long long n = d.sc;
+  double* partials = reinterpret_cast<double*>(workspace);
+  PcgState* S = reinterpret_cast<PcgState*>(partials + kRedBlocks);
+  float* base = workspace + 2 * (kRedBlocks + 64);
+  int* label = reinterpret_cast<int*>(base);
+  int* size_at = reinterpret_cast<int*>(base + n);
+  float* x = base + 2 * n; float* r = base + 3 * n; float* z = base + 4 * n; float* s = base + 5 * n;
+  float* w = base + 6 * n; float* dg = base + 7 * n; float* y = base + 8 * n;
+  int* roots = reinterpret_cast<int*>(base + 9 * n);
+  int* counters = roots + kMaxComponents;   // [0] changed, [1] count, [2] border fluid
+  auto hip_ok = [&](hipError_t e, const char* what) {
+    if (e == hipSuccess) return true;
+    snprintf(msg, msg_len, "solveLinearSystemPCG: %s: %s", what, hipGetErrorString(e));
+    return false;
+  };
+  if (!hip_ok(hipMemsetAsync(p, 0, sizeof(float) * (size_t)B * n, st), "memset p")) return -4;   // :1341
+  const int gcell = cdiv(n, 256);
+  float max_res = -std::numeric_limits<float>::infinity();
+  const int nlev = (X - 2) + (Y - 2) + (is3d ? Z - 2 : 0);        // hyperplanes h = hmin .. hmin + nlev - dims
+  const int hmin = is3d ? 3 : 2, hmax = (X - 2) + (Y - 2) + (is3d ? Z - 2 : 0);
+  (void)nlev;
+  const int gwave = cdiv((long long)(Y - 2) * (is3d ? Z - 2 : 1), 256);
+  for (int b = 0; b < B; b++) {
+    const float* fl = flags + (long long)b * n;
+    const float* dv = div + (long long)b * n;
+    float* pb = p + (long long)b * n;
+    // ---- components -----------------------------------------------------------------------------------
+    int h_cnt[3] = {0, 0, 0};
+    if (!hip_ok(hipMemsetAsync(counters, 0, 3 * sizeof(int), st), "memset")) return -4;
+    if (!hip_ok(hipMemsetAsync(size_at, 0, sizeof(int) * (size_t)n, st), "memset")) return -4;
+    { TFL_TIMED("k_cc", st); k_cc_init<<<gcell, 256, 0, st>>>(d, is3d, fl, label, counters + 2); }
+    for (int round = 0;; round++) {
+      if (!hip_ok(hipMemsetAsync(counters, 0, sizeof(int), st), "memset")) return -4;
+      { TFL_TIMED("k_cc", st);
+        k_cc_hook<<<gcell, 256, 0, st>>>(d, is3d, label, counters);
+        k_cc_compress<<<gcell, 256, 0, st>>>(d, label); }
+      if (!hip_ok(hipMemcpyAsync(h_cnt, counters, 3 * sizeof(int), hipMemcpyDeviceToHost, st), "memcpy")) return -4;
+      if (!hip_ok(hipStreamSynchronize(st), "sync")) return -4;
+      if (!h_cnt[0]) break;
+      if (round > 100000) { snprintf(msg, msg_len, "solveLinearSystemPCG: component labelling did not converge"); return -4; }
+    }
+    if (h_cnt[2] > 0) {   // generic/tfluids.cu:1083-1091 raises for a fluid cell on the border
+      snprintf(msg, msg_len, "solveLinearSystemPCG: Non fluid cell found in a connected component or fluid cell found on the "
+               "domain border (%d fluid border cells)", h_cnt[2]);
+      return -1;
+    }
+    { TFL_TIMED("k_cc", st); k_cc_count<<<gcell, 256, 0, st>>>(d, label, size_at, roots, counters + 1); }
+    if (!hip_ok(hipMemcpyAsync(h_cnt, counters, 3 * sizeof(int), hipMemcpyDeviceToHost, st), "memcpy")) return -4;
+    if (!hip_ok(hipStreamSynchronize(st), "sync")) return -4;
+    const int ncomp = h_cnt[1];
+    if (ncomp > kMaxComponents) {
+      snprintf(msg, msg_len, "solveLinearSystemPCG: %d fluid components (the solver handles %d)", ncomp, kMaxComponents);
+      return -3;
+    }
+    std::vector<int> h_roots(ncomp), h_sizes(ncomp);
+    if (ncomp) {
+      if (!hip_ok(hipMemcpy(h_roots.data(), roots, sizeof(int) * ncomp, hipMemcpyDeviceToHost), "memcpy roots")) return -4;
+      std::sort(h_roots.begin(), h_roots.end());   // scan order of the first cell = the reference's numbering
+      for (int cidx = 0; cidx < ncomp; cidx++)
+        if (!hip_ok(hipMemcpy(&h_sizes[cidx], size_at + h_roots[cidx], sizeof(int), hipMemcpyDeviceToHost), "memcpy size")) return -4;
+    }
+    // ---- one CG solve per component -------------------------------------------------------------------
+    for (int cidx = 0; cidx < ncomp; cidx++) {
+      const int root = h_roots[cidx], size = h_sizes[cidx];
+      if (size == 1) {   // :1375-1383: no valid solution, pressure stays 0
+        if (verbose) printf("PCG batch %d component %d has size 1, skipping.\n", b + 1, cidx + 1);
+        continue;
+      }
+      int pc = precond;
+      if (size < 5) pc = 0;   // :1390-1393
+      if (verbose) printf("PCG batch %d component %d has size %d.\nPCG: %d component %d using precond type %s\n", b + 1, cidx + 1,
+                          size, b + 1, cidx + 1, pc == 0 ? "none" : (pc == 1 ? "ilu0" : "ic0"));
+      // z is only ever written on the component; its other cells must read as 0 in s = z and r.z
+      if (pc && !hip_ok(hipMemsetAsync(z, 0, sizeof(float) * (size_t)n, st), "memset z")) return -4;
+      { TFL_TIMED("k_pcg", st);
+        k_pcg_setup<<<kRedBlocks, 256, 0, st>>>(n, label, root, dv, x, r, s, partials);
+        k_pcg_begin<<<1, 256, 0, st>>>(S, partials, tol, max_iter); }
+      if (pc) {
+        TFL_TIMED("k_pcg_precond", st);
+        for (int h = hmin; h <= hmax; h++) {
+          if (is3d) k_ilu_factor<true><<<gwave, 256, 0, st>>>(d, h, fl, label, root, dg);
+          else k_ilu_factor<false><<<gwave, 256, 0, st>>>(d, h, fl, label, root, dg);
+        }
+      }
+      PcgState hs;
+      const int chunk = verbose ? 1 : (pc ? 4 : 32);
+      for (;;) {
+        for (int it = 0; it < chunk; it++) {
+          k_pcg_loop_top<<<1, 1, 0, st>>>(S);
+          const float* dir_src = r;
+          if (pc) {
+            TFL_TIMED("k_pcg_precond", st);
+            for (int h = hmin; h <= hmax; h++) {
+              if (is3d) { if (pc == 2) k_ilu_forward<true, true><<<gwave, 256, 0, st>>>(S, d, h, fl, label, root, dg, r, y);
+                          else k_ilu_forward<true, false><<<gwave, 256, 0, st>>>(S, d, h, fl, label, root, dg, r, y); }
+              else { if (pc == 2) k_ilu_forward<false, true><<<gwave, 256, 0, st>>>(S, d, h, fl, label, root, dg, r, y);
+                     else k_ilu_forward<false, false><<<gwave, 256, 0, st>>>(S, d, h, fl, label, root, dg, r, y); }
+            }
+            for (int h = hmax; h >= hmin; h--) {
+              if (is3d) { if (pc == 2) k_ilu_backward<true, true><<<gwave, 256, 0, st>>>(S, d, h, fl, label, root, dg, y, z);
+                          else k_ilu_backward<true, false><<<gwave, 256, 0, st>>>(S, d, h, fl, label, root, dg, y, z); }
+              else { if (pc == 2) k_ilu_backward<false, true><<<gwave, 256, 0, st>>>(S, d, h, fl, label, root, dg, y, z);
+                     else k_ilu_backward<false, false><<<gwave, 256, 0, st>>>(S, d, h, fl, label, root, dg, y, z); }
+            }
+            dir_src = z;
+          }
+          TFL_TIMED("k_pcg", st);
+          if (pc) k_pcg_dot<<<kRedBlocks, 256, 0, st>>>(S, n, r, z, partials);
+          k_pcg_beta<<<1, 256, 0, st>>>(S, partials, pc ? 1 : 0);
+          k_pcg_dir<<<kRedBlocks, 256, 0, st>>>(S, n, dir_src, s);
+          if (is3d) k_pcg_apply<true><<<kRedBlocks, 256, 0, st>>>(S, d, fl, label, root, s, w, partials);
+          else k_pcg_apply<false><<<kRedBlocks, 256, 0, st>>>(S, d, fl, label, root, s, w, partials);
+          k_pcg_alpha<<<1, 256, 0, st>>>(S, partials);
+          k_pcg_update<<<kRedBlocks, 256, 0, st>>>(S, n, s, w, x, r, partials);
+          k_pcg_end<<<1, 256, 0, st>>>(S, partials);
+        }
+        if (!hip_ok(hipMemcpyAsync(&hs, S, sizeof(PcgState), hipMemcpyDeviceToHost, st), "memcpy state")) return -4;
+        if (!hip_ok(hipStreamSynchronize(st), "sync")) return -4;
+        if (verbose && !hs.done)
+          printf("PCG batch %d comp %d iter %d: residual %g (tol %g)\n", b + 1, cidx + 1, hs.iter, std::sqrt(hs.rr1), (double)tol);
+        if (hs.bad) { snprintf(msg, msg_len, "solveLinearSystemPCG: ERROR: r_norm_sq1 is nan!"); return -2; }
+        // the loop ends when the NEXT top-of-loop test fails
+        if (hs.done || !((float)hs.rr1 > tol * tol) || hs.iter > max_iter) break;
+      }
+      max_res = std::max(max_res, (float)std::sqrt((float)hs.rr1));
+      { TFL_TIMED("k_pcg", st);
+        k_pcg_sum<<<kRedBlocks, 256, 0, st>>>(n, x, partials);
+        k_pcg_sum_end<<<1, 256, 0, st>>>(S, partials);
+        k_pcg_write<<<kRedBlocks, 256, 0, st>>>(S, n, label, root, size, x, pb); }
+    }
+  }
+  if (residual) *residual = max_res;
+  return 0;
+}
+
+}  // namespace tfl

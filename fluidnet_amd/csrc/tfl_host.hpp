@@ -53,6 +53,11 @@ void vorticity_confinement(hipStream_t st, bool is3d, int B, int Z, int Y, int X
 void jacobi_iteration(hipStream_t st, bool is3d, int B, int Z, int Y, int X, const float* p_prev, const float* flags,
                       const float* div, float* p, double* resid_sq /* [B] or nullptr */);
 
+// pcg.hip
+long long pcg_workspace_floats(int Z, int Y, int X);
+int pcg_solve(hipStream_t st, bool is3d, int B, int Z, int Y, int X, float* p, const float* flags, const float* div,
+              int precond, float tol, int max_iter, int verbose, float* workspace, float* residual, char* msg, size_t msg_len);
+
 // model.hip
 long long model_stat_blocks(int B, int Z, int Y, int X);
 void model_pre(hipStream_t st, bool is3d, int B, int Z, int Y, int X, const float* U, const float* flags, float* Ubc,

@@ -329,6 +329,32 @@ def flagsToOccupancy(flags, occupancy):
     _call(lib, ctx, lib.tfl_flagsToOccupancy(ctx, _tt(flags), _tt(occupancy)))
 
 
+def solveLinearSystemPCG(p, flags, div, is3D, tol=None, maxIter=None, precondType=None, verbose=None):
+    """init.lua:645-677: the baseline (P)CG pressure solve, A p = div per connected fluid component.
+    precondType 'none' | 'ilu0' | 'ic0' (default 'ic0'), tol default 1e-6, maxIter default 1000.
+    Returns the max residual over the solved systems (host sync, as in the reference)."""
+    _check(p.dim() == 5 and flags.dim() == 5 and div.dim() == 5, "Dimension mismatch")
+    _check(flags.size(1) == 1, "flags is not scalar")
+    bsz, _, d, h, w = flags.shape
+    _check(p.shape == flags.shape, "size mismatch")
+    _check(div.shape == flags.shape, "size mismatch")
+    if not is3D:
+        _check(d == 1, "d > 1 for a 2D domain")
+    verbose = bool(verbose)
+    precondType = precondType or "ic0"
+    tol = 1e-6 if tol is None else tol
+    maxIter = 1000 if maxIter is None else maxIter
+    _check(p.is_contiguous() and flags.is_contiguous() and div.is_contiguous(), "Input is not contiguous")
+    lib, ctx = _context(p)
+    nws = int(lib.tfl_pcg_workspace_floats(d, h, w))
+    ws = getTempStorage(p, [(nws,)])[0]
+    res = ctypes.c_float(0.0)
+    _call(lib, ctx, lib.tfl_solveLinearSystemPCG(ctx, _tt(p), _tt(flags), _tt(div), int(bool(is3D)),
+                                                 str(precondType).encode(), float(tol), int(maxIter), int(verbose),
+                                                 ctypes.c_void_p(ws.data_ptr()), nws, ctypes.byref(res)))
+    return res.value
+
+
 def solveLinearSystemJacobi(p, flags, div, is3D, pTol=None, maxIter=None, verbose=None, residual=True):
     """init.lua:693-735. Returns the final residual (a Python float => one host sync at the end);
     residual=False skips the readback (returns None) when pTol <= 0, keeping the call fully async."""

@@ -140,6 +140,22 @@ int tfl_emptyDomain(tfl_ctx* ctx, const tfl_tensor* flags, int is3D, int bnd);
  * exactly Fluid nor Obstacle become -1 (the CUDA behaviour); the CPU reference raises there. */
 int tfl_flagsToOccupancy(tfl_ctx* ctx, const tfl_tensor* flags, const tfl_tensor* occupancy);
 
+/* init.lua:645-677 `tfluids.solveLinearSystemPCG(p, flags, div, is3D, tol, maxIter, precondType, verbose)` ->
+ * tfluids_CudaMain_solveLinearSystemPCG, generic/tfluids.cu:1257-1759 (CUDA only in the reference; the baseline
+ * "exact" pressure solver and the accuracy yard-stick of the paper). p is zeroed, then every connected fluid
+ * component (generic/find_connected_fluid_components.cc) of every batch element is solved by (P)CG from x = 0 with
+ * the Laplacian of setupLaplacian (generic/tfluids.cu:904-1093), the component's mean is removed and the result
+ * scattered into p; components of one cell are skipped, of fewer than five use no preconditioner.
+ * precondType: "none" | "ilu0" | "ic0" (init.lua default "ic0"); tol (default 1e-6) on ||r||; maxIter (default
+ * 1000); *residual = max over the solves of the final ||r|| (-inf if there was nothing to solve).
+ * The reference keeps its temporaries in the tfluids._tmpPCG table; here the caller passes a workspace of
+ * tfl_pcg_workspace_floats(Z, Y, X) floats (8-byte aligned). Synchronises the stream (as the reference does after
+ * every dot product). Returns TFL_EINVAL for a fluid cell on the domain border (the reference raises). */
+int64_t tfl_pcg_workspace_floats(int32_t Z, int32_t Y, int32_t X);
+int tfl_solveLinearSystemPCG(tfl_ctx* ctx, const tfl_tensor* p, const tfl_tensor* flags, const tfl_tensor* div,
+                             int is3D, const char* precondType, float tol, int maxIter, int verbose,
+                             float* workspace, int64_t workspace_floats, float* residual);
+
 /* init.lua:726-727 -> generic/tfluids.cu:1765-1927 (the reference has no CPU version).
  * p is overwritten (initial guess is zero like the reference, :1869-1872). pPrev is scratch;
  * pDelta / pDeltaNorm are accepted and unused (the residual is reduced on the fly). The final

@@ -154,6 +154,21 @@ class OracleTfluids:
             _p(p), _p(flags), _p(div), _p(prev), int(bool(is3D)), ctypes.c_float(pTol),
             int(maxIter), b, d, h, w))
 
+    def solveLinearSystemPCG(self, p, flags, div, is3D, tol=1e-6, maxIter=1000, precondType="ic0", verbose=False):
+        """init.lua:645-677; restated from the CUDA-only generic/tfluids.cu:864-1759 (see tfluids_oracle.c)."""
+        b, d, h, w = self._dims(flags)
+        pc = {"none": 0, "ilu0": 1, "ic0": 2}.get(precondType)
+        if pc is None:
+            raise OracleError("precondType is not supported.")
+        res = ctypes.c_float(0.0)
+        rc = self.lib.ora_solveLinearSystemPCG(_p(p), _p(flags), _p(div), int(bool(is3D)), pc, ctypes.c_float(tol),
+                                               int(maxIter), b, d, h, w, ctypes.byref(res))
+        if rc == -1:
+            raise OracleError("Non fluid cell found in a connected component or fluid cell found on the domain border")
+        if rc == -2:
+            raise OracleError("ERROR: r_norm_sq1 is nan!")
+        return float(res.value)
+
     def calcLineTrace(self, pos, delta, flags3d, is3D=True):
         f = np.ascontiguousarray(flags3d, dtype=np.float32)
         zs, ys, xs = f.shape

@@ -1117,3 +1117,224 @@ float ora_solveLinearSystemJacobi(float* p, const float* flags, const float* div
   if (cur == p_prev) memcpy(p, p_prev, sizeof(float) * N * B);
   return residual;
 }
+
+/* ------------------------------------------------------------------------------------------
+ * solveLinearSystemPCG -- restates the CUDA-only reference path generic/tfluids.cu:864-1759 the way the
+ * reference structures it: flood-fill components (generic/find_connected_fluid_components.cc), reduced
+ * system indices (:864-906), CSR Laplacian (setupLaplacian :908-1093), then PCG (Golub & Van Loan 10.3.1,
+ * :1527-1714) with GENERIC CSR ILU(0) / IC(0) factorisations and triangular solves standing in for
+ * cusparseScsrilu0 / cusparseScsric0 / cusparseScsrsv (cuSPARSE and cuBLAS are not in the tree: their
+ * published algorithms are restated; summation orders inside them are unknown, so the iteration path is
+ * "parity unpinned" and tests compare converged solutions + the properties test_tfluids.lua:836-906 checks).
+ * precond: 0 none, 1 ilu0, 2 ic0. Returns 0, -1 (fluid cell on the border / non-fluid in a component), -2 NaN.
+ * ---------------------------------------------------------------------------------------- */
+static float clamp_to_eps(float v) {   /* generic/tfluids.cu:1203-1214 */
+  const float eps = FLT_MIN;
+  if (fabsf(v) < eps) return v < 0 ? fminf(v, -eps) : fmaxf(v, eps);
+  return v;
+}
+static float sdot(long n, const float* a, const float* b) {
+  double acc = 0.0; long t;
+  for (t = 0; t < n; t++) acc += (double)a[t] * b[t];
+  return (float)acc;
+}
+/* y = A x, CSR; sym_upper: only the upper triangle is stored (CUSPARSE_MATRIX_TYPE_SYMMETRIC) */
+static void csrmv(long n, const int* row, const int* col, const float* val, int sym_upper, const float* x, float* y) {
+  long r; int q;
+  for (r = 0; r < n; r++) y[r] = 0.0f;
+  for (r = 0; r < n; r++)
+    for (q = row[r]; q < row[r + 1]; q++) {
+      y[r] += val[q] * x[col[q]];
+      if (sym_upper && col[q] != r) y[col[q]] += val[q] * x[r];
+    }
+}
+static int csr_find(const int* row, const int* col, long r, int c) {
+  int q;
+  for (q = row[r]; q < row[r + 1]; q++) if (col[q] == c) return q;
+  return -1;
+}
+/* in-place ILU(0) of a full CSR matrix with sorted columns (IKJ variant) */
+static void csr_ilu0(long n, const int* row, const int* col, float* val) {
+  long i; int q, q2;
+  for (i = 1; i < n; i++)
+    for (q = row[i]; q < row[i + 1] && col[q] < i; q++) {
+      const int k = col[q];
+      val[q] = val[q] / val[csr_find(row, col, k, k)];
+      for (q2 = q + 1; q2 < row[i + 1]; q2++) {
+        const int kj = csr_find(row, col, k, col[q2]);
+        if (kj >= 0) val[q2] -= val[q] * val[kj];
+      }
+    }
+}
+/* in-place IC(0) of an upper-triangular CSR matrix: A ~ R^T R */
+static void csr_ic0_upper(long n, const int* row, const int* col, float* val) {
+  long k; int q, q2;
+  for (k = 0; k < n; k++) {
+    const int dq = row[k];             /* the diagonal is the first entry of an upper-triangular row */
+    val[dq] = sqrtf(val[dq]);
+    for (q = dq + 1; q < row[k + 1]; q++) val[q] = val[q] / val[dq];
+    for (q = dq + 1; q < row[k + 1]; q++) {
+      const int j = col[q];
+      for (q2 = q; q2 < row[k + 1]; q2++) {      /* a(j,l) -= r(k,j) r(k,l) for l >= j in the pattern of row j */
+        const int jl = csr_find(row, col, j, col[q2]);
+        if (jl >= 0) val[jl] -= val[q] * val[q2];
+      }
+    }
+  }
+}
+/* lower solve with the strictly-lower part of a full CSR (unit diagonal): L y = b */
+static void csr_lsolve_unit(long n, const int* row, const int* col, const float* val, const float* b, float* y) {
+  long i; int q;
+  for (i = 0; i < n; i++) {
+    float v = b[i];
+    for (q = row[i]; q < row[i + 1] && col[q] < i; q++) v -= val[q] * y[col[q]];
+    y[i] = v;
+  }
+}
+/* upper solve with the upper part (incl. diagonal) of a CSR: U z = y; works for full and upper-only storage */
+static void csr_usolve(long n, const int* row, const int* col, const float* val, const float* y, float* z) {
+  long i; int q;
+  for (i = n - 1; i >= 0; i--) {
+    float v = y[i], dg = 1.0f;
+    for (q = row[i]; q < row[i + 1]; q++) {
+      if (col[q] == i) dg = val[q];
+      else if (col[q] > i) v -= val[q] * z[col[q]];
+    }
+    z[i] = v / dg;
+  }
+}
+/* R^T y = b with R upper-triangular CSR (column-oriented forward substitution) */
+static void csr_utsolve(long n, const int* row, const int* col, const float* val, const float* b, float* y) {
+  long i; int q;
+  for (i = 0; i < n; i++) y[i] = b[i];
+  for (i = 0; i < n; i++) {
+    y[i] = y[i] / val[row[i]];
+    for (q = row[i] + 1; q < row[i + 1]; q++) y[col[q]] -= val[q] * y[i];
+  }
+}
+
+int ora_solveLinearSystemPCG(float* p, const float* flags, const float* div, int is3d, int precond, float tol,
+                             int max_iter, int B, int Z, int Y, int X, float* out_residual) {
+  dom_t dm = mkdom(Z, Y, X, is3d);
+  const dom_t* d = &dm;
+  const long N = (long)X * Y * Z;
+  int* comp = (int*)malloc(sizeof(int) * N);
+  int* sysidx = (int*)malloc(sizeof(int) * N);
+  int* stack = (int*)malloc(sizeof(int) * N);
+  int* row = (int*)malloc(sizeof(int) * (N + 1));
+  int* col = (int*)malloc(sizeof(int) * N * 7);
+  float* val = (float*)malloc(sizeof(float) * N * 7);
+  float* valp = (float*)malloc(sizeof(float) * N * 7);
+  float* vec = (float*)malloc(sizeof(float) * N * 8);
+  float max_res = -INFINITY;
+  int b, status = 0;
+  memset(p, 0, sizeof(float) * N * B);
+  for (b = 0; b < B && status == 0; b++) {
+    const float* fb = flags + b * N;
+    const float* db = div + b * N;
+    float* pb = p + b * N;
+    int ncomp = 0, c, i, j, k;
+    long n;
+    int* sizes;
+    /* findConnectedFluidComponents: scan order, depth-first stack */
+    for (n = 0; n < N; n++) comp[n] = -1;
+    sizes = (int*)calloc((size_t)N + 1, sizeof(int));
+    for (n = 0; n < N; n++) {
+      int sp = 0;
+      if (comp[n] != -1 || !(((int)fb[n]) & F_FLUID)) continue;
+      stack[sp++] = (int)n;
+      while (sp > 0) {
+        const int cur = stack[--sp];
+        const int ci = cur % X, cj = (cur / X) % Y, ck = cur / (X * Y);
+        const int nb[6][3] = {{ci - 1, cj, ck}, {ci + 1, cj, ck}, {ci, cj - 1, ck}, {ci, cj + 1, ck}, {ci, cj, ck - 1}, {ci, cj, ck + 1}};
+        int q;
+        comp[cur] = ncomp; sizes[ncomp]++;
+        for (q = 0; q < (is3d ? 6 : 4); q++) {
+          const int xi = nb[q][0], yj = nb[q][1], zk = nb[q][2];
+          long m;
+          if (xi < 0 || xi >= X || yj < 0 || yj >= Y || zk < 0 || zk >= Z) continue;
+          m = AT(d, xi, yj, zk);
+          if ((((int)fb[m]) & F_FLUID) && comp[m] == -1) { comp[m] = -2; stack[sp++] = (int)m; }
+        }
+      }
+      ncomp++;
+    }
+    for (c = 0; c < ncomp && status == 0; c++) {
+      long numel = 0, nz = 0, r;
+      int pc = precond, iter = 0, upper;
+      float *rhs, *x, *rv, *z, *s, *w, *y, *tmp;
+      float rr1, rr0 = 0.0f, num, den, alpha, beta, prev_num = 0.0f, mean;
+      if (sizes[c] == 1) continue;
+      if (sizes[c] < 5) pc = 0;
+      upper = (pc == 2);
+      for (n = 0; n < N; n++) sysidx[n] = (comp[n] == c) ? (int)numel++ : -1;
+      /* setupLaplacian */
+      row[0] = 0; r = 0;
+      for (k = 0; k < Z && status == 0; k++)
+        for (j = 0; j < Y && status == 0; j++)
+          for (i = 0; i < X; i++) {
+            const long o = AT(d, i, j, k);
+            float diag = 0.0f;
+            if (comp[o] != c) continue;
+            if (on_border(d, i, j, k) || !is_fluid(d, fb, i, j, k)) { status = -1; break; }
+            if (!is_obst(d, fb, i - 1, j, k)) diag += 1;
+            if (!is_obst(d, fb, i + 1, j, k)) diag += 1;
+            if (!is_obst(d, fb, i, j - 1, k)) diag += 1;
+            if (!is_obst(d, fb, i, j + 1, k)) diag += 1;
+            if (is3d && !is_obst(d, fb, i, j, k - 1)) diag += 1;
+            if (is3d && !is_obst(d, fb, i, j, k + 1)) diag += 1;
+            if (is3d && !upper && is_fluid(d, fb, i, j, k - 1)) { val[nz] = -1.0f; col[nz++] = sysidx[AT(d, i, j, k - 1)]; }
+            if (!upper && is_fluid(d, fb, i, j - 1, k)) { val[nz] = -1.0f; col[nz++] = sysidx[AT(d, i, j - 1, k)]; }
+            if (!upper && is_fluid(d, fb, i - 1, j, k)) { val[nz] = -1.0f; col[nz++] = sysidx[AT(d, i - 1, j, k)]; }
+            val[nz] = diag; col[nz++] = sysidx[o];
+            if (is_fluid(d, fb, i + 1, j, k)) { val[nz] = -1.0f; col[nz++] = sysidx[AT(d, i + 1, j, k)]; }
+            if (is_fluid(d, fb, i, j + 1, k)) { val[nz] = -1.0f; col[nz++] = sysidx[AT(d, i, j + 1, k)]; }
+            if (is3d && is_fluid(d, fb, i, j, k + 1)) { val[nz] = -1.0f; col[nz++] = sysidx[AT(d, i, j, k + 1)]; }
+            row[++r] = (int)nz;
+          }
+      if (status) break;
+      rhs = vec; x = vec + numel; rv = vec + 2 * numel; z = vec + 3 * numel; s = vec + 4 * numel; w = vec + 5 * numel;
+      y = vec + 6 * numel; tmp = vec + 7 * numel; (void)tmp;
+      for (n = 0; n < N; n++) if (sysidx[n] >= 0) rhs[sysidx[n]] = db[n];
+      memcpy(valp, val, sizeof(float) * nz);
+      if (pc == 1) csr_ilu0(numel, row, col, valp);
+      if (pc == 2) csr_ic0_upper(numel, row, col, valp);
+      for (r = 0; r < numel; r++) { x[r] = 0.0f; rv[r] = rhs[r]; }
+      rr1 = sdot(numel, rv, rv);
+      if (rr1 != rr1) { status = -2; break; }
+      while (rr1 > tol * tol && iter <= max_iter) {
+        if (pc == 1) { csr_lsolve_unit(numel, row, col, valp, rv, y); csr_usolve(numel, row, col, valp, y, z); }
+        else if (pc == 2) { csr_utsolve(numel, row, col, valp, rv, y); csr_usolve(numel, row, col, valp, y, z); }
+        iter++;
+        if (iter == 1) {
+          memcpy(s, pc ? z : rv, sizeof(float) * numel);
+        } else if (pc) {
+          num = sdot(numel, rv, z);
+          beta = num / clamp_to_eps(prev_num);
+          for (r = 0; r < numel; r++) s[r] = beta * s[r] + z[r];
+        } else {
+          beta = rr1 / clamp_to_eps(rr0);
+          for (r = 0; r < numel; r++) s[r] = beta * s[r] + rv[r];
+        }
+        csrmv(numel, row, col, val, upper, s, w);
+        num = pc ? sdot(numel, rv, z) : rr1;
+        den = sdot(numel, s, w);
+        alpha = num / clamp_to_eps(den);
+        for (r = 0; r < numel; r++) x[r] = alpha * s[r] + x[r];
+        prev_num = num;                       /* rm2.zm2 of the next iteration */
+        for (r = 0; r < numel; r++) rv[r] = -alpha * w[r] + rv[r];
+        rr0 = rr1;
+        rr1 = sdot(numel, rv, rv);
+        if (rr1 != rr1) { status = -2; break; }
+      }
+      if (status) break;
+      if (sqrtf(rr1) > max_res) max_res = sqrtf(rr1);
+      { double acc = 0.0; for (r = 0; r < numel; r++) acc += x[r]; mean = (float)(acc / (double)numel); }
+      for (n = 0; n < N; n++) if (sysidx[n] >= 0) pb[n] = x[sysidx[n]] - mean;
+    }
+    free(sizes);
+  }
+  free(comp); free(sysidx); free(stack); free(row); free(col); free(val); free(valp); free(vec);
+  if (out_residual) *out_residual = max_res;
+  return status;
+}

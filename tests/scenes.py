@@ -86,3 +86,28 @@ def rel_l2(a, b):
     a = np.asarray(a, np.float64)
     b = np.asarray(b, np.float64)
     return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+def pcg_problem(tf, dims, seed, vel_cells=2.0, split=False, **kw):
+    """flags + the divergence of a wall-BC'd random velocity field: the right-hand side of the reference's PCG test
+    (test_tfluids.lua:836-906 does the same from its Manta fixtures). split=True walls off part of the domain (a
+    second fluid component) and leaves one fluid cell enclosed on its own (a size-1 component, which the solver
+    skips). tf = any object with the tfluids operator methods (oracle / ref / HIP adapter)."""
+    sc = make_scene(dims, seed=seed, vel_cells=vel_cells, **kw)
+    f = sc["flags"]
+    if split:
+        Z, Y, X = dims
+        xs = X // 2
+        f[..., xs] = 2.0                         # a wall across x
+        f[..., xs + 1:xs + 4] = np.where(f[..., xs + 1:xs + 4] == 1.0, 1.0, f[..., xs + 1:xs + 4])
+        j0, k0 = Y // 2, (Z // 2 if Z > 1 else 0)
+        if Z > 1:
+            f[:, :, k0 - 1:k0 + 2, j0 - 1:j0 + 2, 2:5] = 2.0
+        else:
+            f[:, :, :, j0 - 1:j0 + 2, 2:5] = 2.0
+        f[:, :, k0, j0, 3] = 1.0                 # one fluid cell inside a 3^dim obstacle block
+    U = sc["U"].copy()
+    tf.setWallBcsForward(U, f)
+    div = np.zeros_like(sc["p"])
+    tf.velocityDivergenceForward(U, f, div)
+    return sc, f, U, div

@@ -192,6 +192,43 @@ def test_jacobi_converges_to_divergence_free(oracle, dims):
     assert np.abs(div).max() < 2e-4 * max(1.0, np.abs(sc["U"]).max())
 
 
+# ---- solveLinearSystemPCG: CUDA-only in the reference, so the oracle is a restatement ------------
+@pytest.mark.parametrize("dims,seed,split", [((1, 24, 28), 3, False), ((9, 11, 13), 4, False), ((1, 30, 34), 5, True),
+                                            ((8, 10, 16), 6, True)])
+def test_pcg_oracle_has_the_properties_the_reference_tests(oracle, dims, seed, split):
+    """test_tfluids.lua:836-906 without the Manta fixtures: for every preconditioner the residual is below 2 tol,
+    p has no NaN, and velocityUpdate(p) leaves (almost) no divergence. Plus: the three preconditioners agree, p is
+    zero outside the fluid, a one-cell component is skipped, each component's mean pressure is zero."""
+    sc, f, U, div = scenes.pcg_problem(oracle, dims, seed, split=split)
+    tol, sols = 1e-5, {}
+    for pc in ("none", "ilu0", "ic0"):
+        p = np.random.RandomState(1).rand(*div.shape).astype(np.float32)
+        res = oracle.solveLinearSystemPCG(p, f, div, sc["is3d"], tol, 1000, pc)
+        assert res < 2 * tol and np.isfinite(p).all()
+        Un = U.copy()
+        oracle.velocityUpdateForward(Un, f, p)
+        d2 = np.zeros_like(div)
+        oracle.velocityDivergenceForward(Un, f, d2)
+        assert np.abs(d2).max() < 2e-5 * max(1.0, np.abs(div).max()), (pc, np.abs(d2).max())
+        assert np.all(p[f != 1.0] == 0.0)
+        sols[pc] = p
+    scale = np.abs(sols["ic0"]).max()
+    assert np.abs(sols["none"] - sols["ic0"]).max() < 1e-4 * scale and np.abs(sols["ilu0"] - sols["ic0"]).max() < 1e-4 * scale
+    if split:
+        Z, Y, X = dims
+        assert sols["ic0"][0, 0, Z // 2 if Z > 1 else 0, Y // 2, 3] == 0.0      # the enclosed single cell
+        left = sols["ic0"][..., :X // 2][f[..., :X // 2] == 1.0]
+        assert abs(left.sum()) < 1e-3 * scale * left.size ** 0.5
+
+
+def test_pcg_oracle_rejects_fluid_on_the_border(oracle):
+    sc, f, U, div = scenes.pcg_problem(oracle, (1, 12, 12), 7)
+    f[0, 0, 0, 0, 5] = 1.0
+    from oracle.oracle import OracleError
+    with pytest.raises(OracleError):
+        oracle.solveLinearSystemPCG(np.zeros_like(div), f, div, False, 1e-5, 100, "none")
+
+
 # ---- training-side operators + resampler (SURVEY.md 8f-4 / 8f-1) -------------------------------------------------
 from backward_cases import CASES as BWD_CASES, run_backward_ops  # noqa: E402
 
