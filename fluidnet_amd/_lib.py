@@ -74,6 +74,8 @@ SIGNATURES = {
     "tfl_volumetricUpSamplingNearestBackward": (_c.c_int, [_c.c_void_p, _c.c_int, _T, _T, _T]),
     "tfl_packPlanes": (_c.c_int, [_c.c_void_p, _c.c_int, _c.POINTER(_T), _c.c_int, _c.c_int, _c.c_void_p, _c.c_int]),
     "tfl_applyBCsIndexed": (_c.c_int, [_c.c_void_p, _T, _T, _T, _c.c_void_p, _c.c_int64]),
+    "tfl_normalize_workspace_floats": (_c.c_int64, [_c.c_int32, _c.c_int32, _c.c_int32]),
+    "tfl_normalizePressureMean": (_c.c_int, [_c.c_void_p, _T, _T, _c.c_int, _c.c_void_p, _c.c_int64]),
     "tfl_pcg_workspace_floats": (_c.c_int64, [_c.c_int32, _c.c_int32, _c.c_int32]),
     "tfl_solveLinearSystemPCG": (_c.c_int, [_c.c_void_p, _T, _T, _T, _c.c_int, _c.c_char_p, _c.c_float, _c.c_int, _c.c_int,
                                             _c.c_void_p, _c.c_int64, _c.c_void_p]),

@@ -409,6 +409,24 @@ int tfl_solveLinearSystemPCG(tfl_ctx* c, const tfl_tensor* p, const tfl_tensor* 
   return check_launch(c, "solveLinearSystemPCG");
 }
 
+int64_t tfl_normalize_workspace_floats(int32_t Z, int32_t Y, int32_t X) { return tfl::npm_workspace_floats(Z, Y, X); }
+
+int tfl_normalizePressureMean(tfl_ctx* c, const tfl_tensor* p, const tfl_tensor* flags, int is3D, float* workspace,
+                              int64_t workspace_floats) {
+  TRY(check_flags(c, "normalizePressureMean", flags));
+  TRY(check_scalar(c, "normalizePressureMean", "p", p, flags));
+  if (!is3D && flags->Z != 1) return fail(c, TFL_EINVAL, "normalizePressureMean: 2D domain but zdepth > 1");
+  if (!workspace || ((uintptr_t)workspace & 7) != 0) return fail(c, TFL_EINVAL, "normalizePressureMean: workspace must be 8-byte aligned");
+  if (workspace_floats < tfl::npm_workspace_floats(flags->Z, flags->Y, flags->X))
+    return fail(c, TFL_EINVAL, "normalizePressureMean: workspace too small (tfl_normalize_workspace_floats)");
+  if ((long long)flags->Z * flags->Y * flags->X >= (1ll << 31)) return fail(c, TFL_EINVAL, "normalizePressureMean: grid too large for 32-bit cell indices");
+  char msg[256] = {0};
+  const int rc = tfl::normalize_pressure_mean(c->stream, is3D != 0, flags->B, flags->Z, flags->Y, flags->X, p->data,
+                                              flags->data, workspace, msg, sizeof(msg));
+  if (rc != 0) return fail(c, TFL_EHIP, "%s", msg);
+  return check_launch(c, "normalizePressureMean");
+}
+
 int tfl_solveLinearSystemJacobi(tfl_ctx* c, const tfl_tensor* p, const tfl_tensor* flags, const tfl_tensor* div,
                                 const tfl_tensor* pPrev, const tfl_tensor* pDelta, const tfl_tensor* pDeltaNorm,
                                 int is3D, float pTol, int maxIter, int verbose, float* residual) {

@@ -346,6 +346,34 @@ __global__ __launch_bounds__(256) void k_ilu_backward(const PcgState* __restrict
   else z[c.o] = (y[c.o] + acc) / dg[c.o];
 }
 
+// ---- normalizePressureMean (generic/tfluids.cc:845-925): p -= mean of p over the cell's fluid component ----
+__global__ __launch_bounds__(256) void k_npm_sum(Dom d, const int* __restrict__ label, const float* __restrict__ p,
+                                                 double* __restrict__ sum_at) {
+  const int o = blockIdx.x * 256 + threadIdx.x;
+  const int l = o < d.sc ? label[o] : -1;
+  const bool valid = l >= 0;
+  const unsigned long long vm = __ballot(valid);
+  if (!vm) return;                                   // wave-uniform
+  // one fp64 atomic per wave when every fluid lane of the wave sits in the same component (the common case)
+  const int l0 = __shfl(l, __ffsll((long long)vm) - 1, 64);
+  double v = valid ? (double)p[o] : 0.0;
+  if (__ballot(valid && l != l0) == 0ull) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(&sum_at[l0], v);
+  } else if (valid) {
+    atomicAdd(&sum_at[l], v);
+  }
+}
+__global__ __launch_bounds__(256) void k_npm_sub(Dom d, const int* __restrict__ label, const int* __restrict__ size_at,
+                                                 const double* __restrict__ sum_at, float* __restrict__ p) {
+  const int o = blockIdx.x * 256 + threadIdx.x;
+  if (o >= d.sc) return;
+  const int l = label[o];
+  if (l < 0) return;
+  p[o] = p[o] - (float)(sum_at[l] / (double)size_at[l]);
+}
+
 inline int cdiv(long long a, int b) { return (int)((a + b - 1) / b); }
 
 }  // namespace
@@ -494,6 +522,49 @@ int pcg_solve(hipStream_t st, bool is3d, int B, int Z, int Y, int X, float* p, c
     }
   }
   if (residual) *residual = max_res;
+  return 0;
+}
+
+long long npm_workspace_floats(int Z, int Y, int X) { return 4ll * Z * Y * X + 16 + kMaxComponents; }
+
+// normalizePressureMean for every batch element. workspace: sum_at (fp64, first for alignment), label, size_at, counters.
+int normalize_pressure_mean(hipStream_t st, bool is3d, int B, int Z, int Y, int X, float* p, const float* flags,
+                            float* workspace, char* msg, size_t msg_len) {
+  const Dom d = make_dom(Z, Y, X);
+  const long long n = d.sc;
+  double* sum_at = reinterpret_cast<double*>(workspace);
+  int* label = reinterpret_cast<int*>(workspace + 2 * n);
+  int* size_at = reinterpret_cast<int*>(workspace + 3 * n);
+  int* counters = reinterpret_cast<int*>(workspace + 4 * n);    // [0] changed, [1] count, [2] border fluid, [3..] roots sink
+  auto hip_ok = [&](hipError_t e, const char* what) {
+    if (e == hipSuccess) return true;
+    snprintf(msg, msg_len, "normalizePressureMean: %s: %s", what, hipGetErrorString(e));
+    return false;
+  };
+  const int gcell = cdiv(n, 256);
+  for (int b = 0; b < B; b++) {
+    const float* fl = flags + (long long)b * n;
+    float* pb = p + (long long)b * n;
+    int h_cnt[3] = {0, 0, 0};
+    if (!hip_ok(hipMemsetAsync(counters, 0, 3 * sizeof(int), st), "memset")) return -4;
+    if (!hip_ok(hipMemsetAsync(size_at, 0, sizeof(int) * (size_t)n, st), "memset")) return -4;
+    if (!hip_ok(hipMemsetAsync(sum_at, 0, sizeof(double) * (size_t)n, st), "memset")) return -4;
+    TFL_TIMED("k_cc", st);
+    k_cc_init<<<gcell, 256, 0, st>>>(d, is3d, fl, label, counters + 2);
+    for (int round = 0;; round++) {
+      if (!hip_ok(hipMemsetAsync(counters, 0, sizeof(int), st), "memset")) return -4;
+      k_cc_hook<<<gcell, 256, 0, st>>>(d, is3d, label, counters);
+      k_cc_compress<<<gcell, 256, 0, st>>>(d, label);
+      if (!hip_ok(hipMemcpyAsync(h_cnt, counters, 3 * sizeof(int), hipMemcpyDeviceToHost, st), "memcpy")) return -4;
+      if (!hip_ok(hipStreamSynchronize(st), "sync")) return -4;
+      if (!h_cnt[0]) break;
+      if (round > 100000) { snprintf(msg, msg_len, "normalizePressureMean: component labelling did not converge"); return -4; }
+    }
+    // sizes only (the roots list is not needed: means are looked up through the label)
+    k_cc_count<<<gcell, 256, 0, st>>>(d, label, size_at, counters + 3, counters + 1);
+    k_npm_sum<<<gcell, 256, 0, st>>>(d, label, pb, sum_at);
+    k_npm_sub<<<gcell, 256, 0, st>>>(d, label, size_at, sum_at, pb);
+  }
   return 0;
 }
 

@@ -58,6 +58,10 @@ long long pcg_workspace_floats(int Z, int Y, int X);
 int pcg_solve(hipStream_t st, bool is3d, int B, int Z, int Y, int X, float* p, const float* flags, const float* div,
               int precond, float tol, int max_iter, int verbose, float* workspace, float* residual, char* msg, size_t msg_len);
 
+long long npm_workspace_floats(int Z, int Y, int X);
+int normalize_pressure_mean(hipStream_t st, bool is3d, int B, int Z, int Y, int X, float* p, const float* flags,
+                            float* workspace, char* msg, size_t msg_len);
+
 // model.hip
 long long model_stat_blocks(int B, int Z, int Y, int X);
 void model_pre(hipStream_t st, bool is3d, int B, int Z, int Y, int X, const float* U, const float* flags, float* Ubc,

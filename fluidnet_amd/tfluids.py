@@ -355,6 +355,21 @@ def solveLinearSystemPCG(p, flags, div, is3D, tol=None, maxIter=None, precondTyp
     return res.value
 
 
+def normalizePressureMean(p, flags, is3D):
+    """init.lua:747-764: subtract from p the mean over each connected fluid component (in place; on the device,
+    where the reference round-trips through the host)."""
+    _check(p.dim() == 5 and flags.dim() == 5 and flags.size(1) == 1, "Dimension mismatch")
+    _check(p.shape == flags.shape, "size mismatch")
+    _check(p.is_contiguous() and flags.is_contiguous(), "Input is not contiguous")
+    _, _, d, h, w = flags.shape
+    if not is3D:
+        _check(d == 1, "d > 1 for a 2D domain")
+    lib, ctx = _context(p)
+    nws = int(lib.tfl_normalize_workspace_floats(d, h, w))
+    ws = getTempStorage(p, [(nws,)])[0]
+    _call(lib, ctx, lib.tfl_normalizePressureMean(ctx, _tt(p), _tt(flags), int(bool(is3D)), ctypes.c_void_p(ws.data_ptr()), nws))
+
+
 def solveLinearSystemJacobi(p, flags, div, is3D, pTol=None, maxIter=None, verbose=None, residual=True):
     """init.lua:693-735. Returns the final residual (a Python float => one host sync at the end);
     residual=False skips the readback (returns None) when pTol <= 0, keeping the call fully async."""

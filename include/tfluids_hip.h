@@ -156,6 +156,15 @@ int tfl_solveLinearSystemPCG(tfl_ctx* ctx, const tfl_tensor* p, const tfl_tensor
                              int is3D, const char* precondType, float tol, int maxIter, int verbose,
                              float* workspace, int64_t workspace_floats, float* residual);
 
+/* init.lua:747-764 `tfluids.normalizePressureMean(p, flags, is3D)` -> tfluids_<Real>Main_normalizePressureMean,
+ * generic/tfluids.cc:845-925 (CPU only in the reference: CUDA tensors are copied to the host and back): subtracts
+ * from p, per batch element, the mean of p over each connected component of fluid cells (non-fluid cells untouched).
+ * Runs on the device here (the component labelling of tfl_solveLinearSystemPCG). The reference's `inds` IntTensor
+ * temp becomes a workspace of tfl_normalize_workspace_floats(Z, Y, X) floats, 8-byte aligned. */
+int64_t tfl_normalize_workspace_floats(int32_t Z, int32_t Y, int32_t X);
+int tfl_normalizePressureMean(tfl_ctx* ctx, const tfl_tensor* p, const tfl_tensor* flags, int is3D, float* workspace,
+                              int64_t workspace_floats);
+
 /* init.lua:726-727 -> generic/tfluids.cu:1765-1927 (the reference has no CPU version).
  * p is overwritten (initial guess is zero like the reference, :1869-1872). pPrev is scratch;
  * pDelta / pDeltaNorm are accepted and unused (the residual is reduced on the fly). The final

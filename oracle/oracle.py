@@ -154,6 +154,10 @@ class OracleTfluids:
             _p(p), _p(flags), _p(div), _p(prev), int(bool(is3D)), ctypes.c_float(pTol),
             int(maxIter), b, d, h, w))
 
+    def normalizePressureMean(self, p, flags, is3D):
+        b, d, h, w = self._dims(flags)
+        self.lib.ora_normalizePressureMean(_p(p), _p(flags), int(bool(is3D)), b, d, h, w)
+
     def solveLinearSystemPCG(self, p, flags, div, is3D, tol=1e-6, maxIter=1000, precondType="ic0", verbose=False):
         """init.lua:645-677; restated from the CUDA-only generic/tfluids.cu:864-1759 (see tfluids_oracle.c)."""
         b, d, h, w = self._dims(flags)

@@ -164,6 +164,11 @@ class RefTfluids:
         self.call("emptyDomain", flags, bool(is3D), bnd)
         return flags
 
+    def normalizePressureMean(self, p, flags, is3D):
+        """init.lua:747-764 (CPU path): inds is an IntTensor temp the size of p."""
+        inds = np.zeros(p.shape[:1] + p.shape[2:], dtype=np.int32)
+        self.call("normalizePressureMean", p, flags, bool(is3D), inds)
+
     def flagsToOccupancy(self, flags, occupancy):
         self.call("flagsToOccupancy", flags, occupancy)
 

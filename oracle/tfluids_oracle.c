@@ -1338,3 +1338,48 @@ int ora_solveLinearSystemPCG(float* p, const float* flags, const float* div, int
   if (out_residual) *out_residual = max_res;
   return status;
 }
+
+/* ------------------------------------------------------------------------------------------
+ * normalizePressureMean, generic/tfluids.cc:845-925: per batch element, flood-fill the fluid components
+ * (generic/find_connected_fluid_components.cc) and subtract each component's mean pressure. The reference
+ * accumulates the mean with `#pragma omp atomic` float adds (order not fixed); here it is a double sum
+ * rounded once, so agreement with the compiled reference is to rounding, not bitwise.
+ * ---------------------------------------------------------------------------------------- */
+void ora_normalizePressureMean(float* p, const float* flags, int is3d, int B, int Z, int Y, int X) {
+  const long N = (long)X * Y * Z;
+  int* comp = (int*)malloc(sizeof(int) * N);
+  int* stack = (int*)malloc(sizeof(int) * N);
+  double* sum = (double*)malloc(sizeof(double) * (N + 1));
+  int* cnt = (int*)malloc(sizeof(int) * (N + 1));
+  int b;
+  for (b = 0; b < B; b++) {
+    const float* fb = flags + b * N;
+    float* pb = p + b * N;
+    long n;
+    int ncomp = 0;
+    for (n = 0; n < N; n++) comp[n] = -1;
+    for (n = 0; n < N; n++) {
+      int sp = 0;
+      if (comp[n] != -1 || !(((int)fb[n]) & F_FLUID)) continue;
+      stack[sp++] = (int)n; sum[ncomp] = 0.0; cnt[ncomp] = 0;
+      while (sp > 0) {
+        const int cur = stack[--sp];
+        const int ci = cur % X, cj = (cur / X) % Y, ck = cur / (X * Y);
+        const int nb[6][3] = {{ci - 1, cj, ck}, {ci + 1, cj, ck}, {ci, cj - 1, ck}, {ci, cj + 1, ck}, {ci, cj, ck - 1}, {ci, cj, ck + 1}};
+        int q;
+        comp[cur] = ncomp; cnt[ncomp]++; sum[ncomp] += (double)pb[cur];
+        for (q = 0; q < (is3d ? 6 : 4); q++) {
+          const int xi = nb[q][0], yj = nb[q][1], zk = nb[q][2];
+          long m;
+          if (xi < 0 || xi >= X || yj < 0 || yj >= Y || zk < 0 || zk >= Z) continue;
+          m = (long)xi + (long)yj * X + (long)zk * X * Y;
+          if ((((int)fb[m]) & F_FLUID) && comp[m] == -1) { comp[m] = -2; stack[sp++] = (int)m; }
+        }
+      }
+      ncomp++;
+    }
+    for (n = 0; n < N; n++)
+      if (comp[n] >= 0) pb[n] = pb[n] - (float)(sum[comp[n]] / (double)cnt[comp[n]]);
+  }
+  free(comp); free(stack); free(sum); free(cnt);
+}

@@ -101,6 +101,11 @@ class HipTfluids:
         p[...] = tp.cpu().numpy()
         return r
 
+    def normalizePressureMean(self, p, flags, is3D):
+        tp = self._up(p)
+        tfluids.normalizePressureMean(tp, self._up(flags), is3D)
+        p[...] = tp.cpu().numpy()
+
     def solveLinearSystemPCG(self, p, flags, div, is3D, tol=1e-6, maxIter=1000, precondType="ic0", verbose=False):
         tp = self._up(p)
         r = tfluids.solveLinearSystemPCG(tp, self._up(flags), self._up(div), is3D, tol, maxIter, precondType, verbose)

@@ -347,3 +347,16 @@ def test_hip_pcg_errors_and_defaults(hip, oracle):
     p3 = np.ones_like(div)
     r3 = hip.solveLinearSystemPCG(p3, fo, div, False, 1e-5, 10, "ic0")
     assert r3 == -np.inf and not p3.any()
+
+
+@pytest.mark.parametrize("dims,seed,split", [((1, 30, 34), 5, True), ((8, 10, 16), 6, True), ((20, 24, 40), 13, False)])
+def test_hip_normalize_pressure_mean(hip, oracle, dims, seed, split):
+    """generic/tfluids.cc:845-925 on the device (labelling shared with the PCG solver) vs the oracle: equal to
+    rounding (fp64 component sums on both sides, different orders), non-fluid cells bit-untouched."""
+    sc, f, U, div = scenes.pcg_problem(oracle, dims, seed, split=split, B=2)
+    p0 = (np.random.RandomState(seed).randn(*div.shape) * 3 + 5).astype(np.float32)
+    a, b = p0.copy(), p0.copy()
+    hip.normalizePressureMean(a, f, sc["is3d"])
+    oracle.normalizePressureMean(b, f, sc["is3d"])
+    assert np.abs(a - b).max() < 2e-6 * np.abs(p0).max()
+    assert np.array_equal(a[f != 1.0], p0[f != 1.0])

@@ -221,6 +221,20 @@ def test_pcg_oracle_has_the_properties_the_reference_tests(oracle, dims, seed, s
         assert abs(left.sum()) < 1e-3 * scale * left.size ** 0.5
 
 
+@pytest.mark.parametrize("dims,seed,split", [((1, 30, 34), 5, True), ((8, 10, 16), 6, True), ((6, 7, 9), 12, False)])
+def test_normalize_pressure_mean_oracle_matches_reference(oracle, ref, dims, seed, split):
+    """generic/tfluids.cc:845-925 compiled from the reference vs the restatement: equal to rounding (the reference
+    sums each component with unordered float atomics), non-fluid cells untouched, component means zero afterwards."""
+    sc, f, U, div = scenes.pcg_problem(oracle, dims, seed, split=split, B=2)
+    p0 = (np.random.RandomState(seed).randn(*div.shape) * 3 + 5).astype(np.float32)
+    a, b = p0.copy(), p0.copy()
+    oracle.normalizePressureMean(a, f, sc["is3d"])
+    ref.normalizePressureMean(b, f, sc["is3d"])
+    assert np.abs(a - b).max() < 1e-5 * np.abs(p0).max()
+    assert np.array_equal(a[f != 1.0], p0[f != 1.0])
+    assert abs(a[f == 1.0].mean()) < 1.0        # sanity: the bulk offset (5) is gone
+
+
 def test_pcg_oracle_rejects_fluid_on_the_border(oracle):
     sc, f, U, div = scenes.pcg_problem(oracle, (1, 12, 12), 7)
     f[0, 0, 0, 0, 5] = 1.0
