@@ -174,6 +174,11 @@ def simulate(ops, mconf, batch, layers=None, output_div=False, conv_dtype="float
         ops.velocityDivergenceForward(U, flags, div)
         ops.solveLinearSystemJacobi(p, flags, div, is3d, 0.0, mconf.get("maxIter") or 100)
         ops.velocityUpdateForward(U, flags, p)
+    elif sim == "pcg":      # simulate.lua:281-286: tol 1e-4, ic0
+        div = np.zeros_like(p)
+        ops.velocityDivergenceForward(U, flags, div)
+        ops.solveLinearSystemPCG(p, flags, div, is3d, 1e-4, mconf.get("maxIter") or 100, "ic0")
+        ops.velocityUpdateForward(U, flags, p)
     else:
         raise ValueError("mconf.simMethod (%s) is not a valid option" % sim)
     set_const_vals(batch, p, U, flags, density)

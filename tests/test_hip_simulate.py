@@ -97,6 +97,35 @@ def test_simulate_config1_2d_jacobi_bit_exact(oracle):
     assert nb["density"][0, 0, 0, 4:].sum() > 0
 
 
+@pytest.mark.parametrize("dims,rad,usc", [((1, 48, 48), 0.08, 4.0), ((20, 24, 24), 0.15, 1.0)])
+def test_simulate_pcg_projection(oracle, dims, rad, usc):
+    """simMethod = 'pcg' (simulate.lua:281-286: tol 1e-4, ic0): the baseline solver inside the step. The solve is
+    iterative in fp32 on both sides (different summation orders), so fields are held to the north-star tolerance
+    scaled by the solver's own tol, and the projected velocity must be divergence-free to that tol."""
+    from fluidnet_amd import tfluids
+    b = _plume_batch(dims, rad, usc, obstacles_seed=5)
+    # an inflow into a closed box makes A p = div singular AND inconsistent (what (P)CG then returns is rounding);
+    # open the top: a row of empty cells under the upper wall (p = 0 there) makes the system well posed
+    Y = dims[1]
+    top = b["flags"][:, :, 1:-1, Y - 2, 1:-1] if dims[0] > 1 else b["flags"][:, :, :, Y - 2, 1:-1]
+    top[...] = 4.0
+    mconf = dict(dt=0.1, advectionMethod="maccormackOurs", maccormackStrength=0.75, buoyancyScale=1.0,
+                 gravityScale=0, vorticityConfinementAmp=0.5, simMethod="pcg", maxIter=400)
+    nb, tb = _run_both(oracle, b, mconf, None, 5)
+    for k in ("UDiv", "density"):
+        r = scenes.rel_l2(tb[k].cpu().numpy(), nb[k])
+        assert np.isfinite(tb[k].cpu().numpy()).all() and r <= 2e-4, (k, r)
+    assert np.abs(tb["pDiv"].cpu().numpy() - nb["pDiv"]).max() <= 1e-3 * max(1.0, np.abs(nb["pDiv"]).max())
+    import torch
+    U = tb["UDiv"].clone()
+    tfluids.setWallBcsForward(U, tb["flags"])
+    div = torch.empty_like(tb["pDiv"])
+    tfluids.velocityDivergenceForward(U, tb["flags"], div)
+    inner = div[..., 5:Y - 3, :]       # rows 0..3 carry the plume inflow BC (re-imposed after the projection)
+    assert float(inner.abs().max()) < 5e-4, float(inner.abs().max())
+    assert nb["density"][0, 0, :, 4:].sum() > 0
+
+
 def test_simulate_config2_2d_convnet(oracle):
     """BASELINE config 2: 2-D 128x128, ConvNet projection with the shipped myModel2D weights."""
     from fluidnet_amd import FluidNetModel
