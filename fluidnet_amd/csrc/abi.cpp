@@ -486,23 +486,32 @@ tfl_model* tfl_model_create(tfl_ctx* c, int is3D, int nlayers, const int32_t* ci
   m->is3d = is3D != 0;
   auto cleanup = [&](const char* msg) -> tfl_model* { tfl_model_destroy(c, m); return bad(msg); };
   if (hipMalloc((void**)&m->d_stats, sizeof(double) * 2 * kMaxBatch) != hipSuccess) return cleanup("hipMalloc failed");
+  // The shape-generic kernels are instantiated for 1, 2, 4, 8, 16, 32 output channels. Any other width (the
+  // `yang` topology of model.lua:188-205 has 6) is zero-padded to the next one: the extra channels carry
+  // relu(0 + 0) = 0 into zero weights of the next layer, i.e. every sum gains exact `+ 0 * 0` terms only.
+  auto padded = [](int cch) { for (int w : {1, 2, 4, 8, 16, 32}) if (cch <= w) return w; return -1; };
+  int prev_cout_padded = 3;
   for (int l = 0; l < nlayers; l++) {
     tfl_layer L;
-    L.cin = cin[l]; L.cout = cout[l]; L.k = ksize[l];
-    if (L.cin < 1 || L.cout < 1 || L.k < 1 || (L.k % 2) != 1) return cleanup("convolution size must be odd and positive");
-    if (l > 0 && L.cin != cout[l - 1]) return cleanup("layer channel counts do not chain");
-    if (L.cout != 1 && L.cout != 2 && L.cout != 4 && L.cout != 8 && L.cout != 16 && L.cout != 32)
-      return cleanup("unsupported output channel count (1, 2, 4, 8, 16, 32)");
+    if (cin[l] < 1 || cout[l] < 1 || ksize[l] < 1 || (ksize[l] % 2) != 1) return cleanup("convolution size must be odd and positive");
+    if (l > 0 && cin[l] != cout[l - 1]) return cleanup("layer channel counts do not chain");
+    const int cout_p = (l + 1 == nlayers) ? cout[l] : padded(cout[l]);
+    if (cout_p < 0) return cleanup("unsupported output channel count (at most 32)");
+    const int cin_p = prev_cout_padded;
+    L.cin = cin_p; L.cout = cout_p; L.k = ksize[l];
+    prev_cout_padded = cout_p;
     const int taps = m->is3d ? L.k * L.k * L.k : L.k * L.k;
-    std::vector<float> relaid((size_t)taps * L.cin * L.cout);
-    for (int co = 0; co < L.cout; co++)
-      for (int ci = 0; ci < L.cin; ci++)
+    std::vector<float> relaid((size_t)taps * L.cin * L.cout, 0.0f);
+    for (int co = 0; co < cout[l]; co++)
+      for (int ci = 0; ci < cin[l]; ci++)
         for (int t = 0; t < taps; t++)
-          relaid[((size_t)t * L.cin + ci) * L.cout + co] = weights[l][((size_t)co * L.cin + ci) * taps + t];
+          relaid[((size_t)t * L.cin + ci) * L.cout + co] = weights[l][((size_t)co * cin[l] + ci) * taps + t];
+    std::vector<float> bias_p((size_t)L.cout, 0.0f);
+    for (int co = 0; co < cout[l]; co++) bias_p[co] = biases[l][co];
     if (hipMalloc((void**)&L.w, relaid.size() * sizeof(float)) != hipSuccess ||
         hipMalloc((void**)&L.b, L.cout * sizeof(float)) != hipSuccess ||
         hipMemcpy(L.w, relaid.data(), relaid.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(L.b, biases[l], L.cout * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+        hipMemcpy(L.b, bias_p.data(), L.cout * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
       m->layers.push_back(L);
       return cleanup("uploading weights failed");
     }

@@ -193,6 +193,32 @@ def test_conv_paths_agree_3d(oracle, monkeypatch):
         assert scenes.rel_l2(pm.cpu().numpy(), p_ref) <= TOL and scenes.rel_l2(Um.cpu().numpy(), U_ref) <= TOL
 
 
+@pytest.mark.parametrize("is3d,shapes", [(False, [(6, 3, 3), (6, 6, 1), (6, 6, 1), (1, 6, 1)]),       # `yang`, model.lua:188-205
+                                         (True, [(6, 3, 3), (6, 6, 1), (6, 6, 1), (1, 6, 1)]),
+                                         (True, [(5, 3, 3), (12, 5, 3), (1, 12, 1)]),
+                                         (False, [(3, 3, 5), (20, 3, 3), (1, 20, 1)])])
+def test_other_topologies_through_the_generic_kernels(oracle, is3d, shapes):
+    """Any `default`-style conv stack (odd kernel sizes, up to 32 channels) runs through conv.hip; channel counts
+    the kernels are not instantiated for (the `yang` model's 6) are zero-padded at model creation. Seeded weights
+    (no such model is shipped), same non-conv graph, against the oracle's PyTorch-CPU convolutions."""
+    import torch
+    from fluidnet_amd import FluidNetModel
+    rng = np.random.RandomState(17)
+    layers = []
+    for co, ci, k in shapes:
+        taps = k ** (3 if is3d else 2)
+        shape = (co, ci) + ((k, k, k) if is3d else (k, k))
+        layers.append(((rng.randn(*shape) * np.sqrt(2.0 / (ci * taps))).astype(np.float32),
+                       (rng.randn(co) * 0.05).astype(np.float32)))
+    dev = torch.device("cuda:0")
+    dims = (11, 14, 18) if is3d else (1, 37, 45)
+    sc = scenes.make_scene(dims, seed=23, vel_cells=0.4, B=2)
+    tp, tU, tf = (torch.from_numpy(sc[k]).to(dev) for k in ("p", "U", "flags"))
+    pm, Um = FluidNetModel(layers, is3d).forward([tp, tU, tf])
+    p_ref, U_ref = S.model_forward(oracle, layers, sc["p"], sc["U"], sc["flags"])
+    assert scenes.rel_l2(pm.cpu().numpy(), p_ref) <= TOL and scenes.rel_l2(Um.cpu().numpy(), U_ref) <= TOL
+
+
 @pytest.mark.parametrize("world", [2, 4])
 def test_zslab_decomposition_equals_single_gpu(world):
     """BASELINE config 5's decomposition, verified on ONE GPU with in-process virtual ranks: every
