@@ -262,10 +262,15 @@ __global__ __launch_bounds__(256) void k_minmax3_v4(Dom d, int outside, const fl
   const long long cells = d.sc;
   s += b * cells; flags += b * cells; lo3 += b * cells; hi3 += b * cells;
   const float qnan = __builtin_nanf("");
-  float lo[4], hi[4];
-#pragma unroll
-  for (int q = 0; q < 4; q++) { lo[q] = __builtin_inff(); hi[q] = -__builtin_inff(); }
   auto masked = [&](float v, float f) { return (outside || (((int)f) & kFluid)) ? v : qnan; };
+  // Separable: first the extrema of each of the thread's four COLUMNS over the 3 (2-D) / 9 (3-D) rows of the
+  // neighbourhood, then a 3-wide min/max along x; the columns i0-1 and i0+4 are the neighbouring lanes' last /
+  // first column (4 DPP moves per thread instead of 2 per row). v_min3 / v_max3 skip NaN operands like the
+  // reference's comparisons do; against its compare-and-keep chain only the sign of a zero bound can differ
+  // (see manta_clamp_bounds).
+  float clo[6], chi[6];
+#pragma unroll
+  for (int q = 0; q < 6; q++) { clo[q] = __builtin_inff(); chi[q] = -__builtin_inff(); }
 #pragma unroll
   for (int dz = (IS3D ? -1 : 0); dz <= (IS3D ? 1 : 0); dz++)
 #pragma unroll
@@ -273,23 +278,31 @@ __global__ __launch_bounds__(256) void k_minmax3_v4(Dom d, int outside, const fl
       const int jj = j + dy, kk = k + dz;
       const bool ok = live && jj >= 0 && jj < d.Y && kk >= 0 && kk < d.Z;
       const int o = TFL_AT(d, c.i0, jj, kk);
-      float sv[4], fv[4], e[6];
+      float sv[4], fv[4];
       v4_load(s, o, ok, qnan, sv);
       v4_load(flags, o, ok, 0.0f, fv);
 #pragma unroll
-      for (int q = 0; q < 4; q++) e[q + 1] = ok ? masked(sv[q], fv[q]) : qnan;
-      e[0] = from_lane_below(e[4]);
-      e[5] = from_lane_above(e[1]);
-      if (c.first) e[0] = (ok && c.has_l) ? masked(s[o - 1], flags[o - 1]) : qnan;
-      if (c.last) e[5] = (ok && c.has_r) ? masked(s[o + 4], flags[o + 4]) : qnan;
-      // v_min3 / v_max3 skip NaN operands like the reference's comparisons do; against its compare-and-keep
-      // chain only the sign of a zero bound can differ (see manta_clamp_bounds)
-#pragma unroll
       for (int q = 0; q < 4; q++) {
-        lo[q] = __builtin_fminf(__builtin_fminf(__builtin_fminf(lo[q], e[q]), e[q + 1]), e[q + 2]);
-        hi[q] = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(hi[q], e[q]), e[q + 1]), e[q + 2]);
+        const float m = ok ? masked(sv[q], fv[q]) : qnan;
+        clo[q + 1] = __builtin_fminf(clo[q + 1], m);
+        chi[q + 1] = __builtin_fmaxf(chi[q + 1], m);
       }
+      // a segment's end lanes walk the outside columns themselves (only when the row continues: X > 128)
+      if (c.first && ok && c.has_l) { const float m = masked(s[o - 1], flags[o - 1]); clo[0] = __builtin_fminf(clo[0], m); chi[0] = __builtin_fmaxf(chi[0], m); }
+      if (c.last && ok && c.has_r) { const float m = masked(s[o + 4], flags[o + 4]); clo[5] = __builtin_fminf(clo[5], m); chi[5] = __builtin_fmaxf(chi[5], m); }
     }
+  {
+    const float l0 = from_lane_below(clo[4]), h0 = from_lane_below(chi[4]);
+    const float l5 = from_lane_above(clo[1]), h5 = from_lane_above(chi[1]);
+    if (!c.first) { clo[0] = l0; chi[0] = h0; }
+    if (!c.last) { clo[5] = l5; chi[5] = h5; }
+  }
+  float lo[4], hi[4];
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    lo[q] = __builtin_fminf(__builtin_fminf(clo[q], clo[q + 1]), clo[q + 2]);
+    hi[q] = __builtin_fmaxf(__builtin_fmaxf(chi[q], chi[q + 1]), chi[q + 2]);
+  }
   if (live) {
     const int o = TFL_AT(d, c.i0, j, k);
     v4_store(lo3, o, lo);
