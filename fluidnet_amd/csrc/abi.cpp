@@ -55,18 +55,20 @@ struct ProfRec { const char* name; hipEvent_t e0, e1; };
 struct Profiler { std::vector<ProfRec> recs; };
 static thread_local Profiler* g_prof = nullptr;
 
-KernelTimer::KernelTimer(const char* name, hipStream_t st) : slot_(-1), st_(st) {
+KernelTimer::KernelTimer(const char* name, hipStream_t st, bool ext) : slot_(-1), st_(st), ext_(ext) {
   if (!g_prof) return;
   ProfRec r; r.name = name;
   if (hipEventCreate(&r.e0) != hipSuccess) return;
   if (hipEventCreate(&r.e1) != hipSuccess) { (void)hipEventDestroy(r.e0); return; }
-  (void)hipEventRecord(r.e0, st);
+  if (!ext_) (void)hipEventRecord(r.e0, st);
   g_prof->recs.push_back(r);
   slot_ = (int)g_prof->recs.size() - 1;
 }
 KernelTimer::~KernelTimer() {
-  if (slot_ >= 0 && g_prof) (void)hipEventRecord(g_prof->recs[slot_].e1, st_);
+  if (slot_ >= 0 && g_prof && !ext_) (void)hipEventRecord(g_prof->recs[slot_].e1, st_);
 }
+hipEvent_t KernelTimer::start() const { return (slot_ >= 0 && g_prof) ? g_prof->recs[slot_].e0 : nullptr; }
+hipEvent_t KernelTimer::stop() const { return (slot_ >= 0 && g_prof) ? g_prof->recs[slot_].e1 : nullptr; }
 }  // namespace tfl
 
 namespace {

@@ -488,8 +488,8 @@ static void launch_scalar(hipStream_t st, int method, const AdvArgs& a, int B, c
       break;
     default:
       minmax3(st, IS3D, B, a.d.Z, a.d.Y, a.d.X, a.outside, s, flags, mm, mm + (long long)B * a.d.sc);
-      { TFL_TIMED("k_scalar_fwd", st); k_scalar_fwd<IS3D, kMacCormackOurs><<<grd, blk, 0, st>>>(a, s, U, flags, fwd, bounds, mm, mm + (long long)B * a.d.sc); }
-      { TFL_TIMED("k_scalar_bwd", st); k_scalar_bwd<IS3D, kMacCormackOurs><<<grd, blk, 0, st>>>(a, s, U, flags, fwd, bounds, dst); }
+      { TFL_TIMED_EXT("k_scalar_fwd", st); TFL_LAUNCH_EXT((k_scalar_fwd<IS3D, kMacCormackOurs>), grd, blk, 0, st, a, s, U, flags, fwd, bounds, (const float*)mm, (const float*)(mm + (long long)B * a.d.sc)); }
+      { TFL_TIMED_EXT("k_scalar_bwd", st); TFL_LAUNCH_EXT((k_scalar_bwd<IS3D, kMacCormackOurs>), grd, blk, 0, st, a, s, U, flags, (const float*)fwd, (const float*)bounds, dst); }
       break;
   }
 }
@@ -510,13 +510,14 @@ void minmax3(hipStream_t st, bool is3d, int B, int Z, int Y, int X, int outside,
              float* lo3, float* hi3) {
   const Dom d = make_dom(Z, Y, X);
   const dim3 blk(64, 4, 1), grd = cell_grid(d, B, blk);
-  TFL_TIMED("k_minmax3", st);
   const Vec4Launch v = vec4_launch(B, Z, Y, X, {s, flags, lo3, hi3});
   if (v.ok) {
-    if (is3d) k_minmax3_v4<true><<<v.grd, v.blk, 0, st>>>(d, outside, s, flags, lo3, hi3);
-    else k_minmax3_v4<false><<<v.grd, v.blk, 0, st>>>(d, outside, s, flags, lo3, hi3);
+    TFL_TIMED_EXT("k_minmax3", st);
+    if (is3d) TFL_LAUNCH_EXT((k_minmax3_v4<true>), v.grd, v.blk, 0, st, d, outside, s, flags, lo3, hi3);
+    else TFL_LAUNCH_EXT((k_minmax3_v4<false>), v.grd, v.blk, 0, st, d, outside, s, flags, lo3, hi3);
     return;
   }
+  TFL_TIMED("k_minmax3", st);
   if (is3d) k_minmax3<true><<<grd, blk, 0, st>>>(d, outside, s, flags, lo3, hi3);
   else k_minmax3<false><<<grd, blk, 0, st>>>(d, outside, s, flags, lo3, hi3);
 }
@@ -548,8 +549,8 @@ static void launch_vel(hipStream_t st, int method, const AdvArgs& a, int B, cons
       { TFL_TIMED("k_vel_bwd", st); k_vel_bwd<IS3D, false><<<grd, blk, 0, st>>>(a, U, flags, fwd, dst); }
       break;
     default:
-      { TFL_TIMED("k_vel_fwd", st); k_vel_fwd<IS3D, true><<<grd, blk, 0, st>>>(a, U, flags, fwd); }
-      { TFL_TIMED("k_vel_bwd", st); k_vel_bwd<IS3D, true><<<grd, blk, 0, st>>>(a, U, flags, fwd, dst); }
+      { TFL_TIMED_EXT("k_vel_fwd", st); TFL_LAUNCH_EXT((k_vel_fwd<IS3D, true>), grd, blk, 0, st, a, U, flags, fwd); }
+      { TFL_TIMED_EXT("k_vel_bwd", st); TFL_LAUNCH_EXT((k_vel_bwd<IS3D, true>), grd, blk, 0, st, a, U, flags, fwd, dst); }
       break;
   }
 }

@@ -274,7 +274,7 @@ static void launch_mfma(hipStream_t st, const Dom& d, int B, const float* in, co
               (int)IN_PLANAR, (int)TAIL, lds_bytes, nb, grid);
     }
   }
-  TFL_TIMED(TAIL ? "k_conv3_mfma_tail" : (IN_PLANAR ? "k_conv3_mfma_in" : "k_conv3_mfma"), st);
+  TFL_TIMED_EXT(TAIL ? "k_conv3_mfma_tail" : (IN_PLANAR ? "k_conv3_mfma_in" : "k_conv3_mfma"), st);
   static const int dbg = getenv("TFL_CONV_DEBUG") ? atoi(getenv("TFL_CONV_DEBUG")) : 0;
   static const bool want_trace = getenv("TFL_CONV_TRACE") != nullptr;
   if (want_trace) {
@@ -315,7 +315,8 @@ static void launch_mfma(hipStream_t st, const Dom& d, int B, const float* in, co
     fprintf(stderr, "\n");
     return;
   }
-  k_conv3_mfma<CIN, IN_PLANAR, TAIL><<<grid, 256, lds_bytes, st>>>(d, tx, ty, tz, n_tiles, in, bfrag, bias, out, tail, cin, dbg, nullptr);
+  TFL_LAUNCH_EXT((k_conv3_mfma<CIN, IN_PLANAR, TAIL>), grid, 256, lds_bytes, st, d, tx, ty, tz, n_tiles, in, bfrag, bias, out, tail,
+                 cin, dbg, (unsigned long long*)nullptr);
 }
 
 // 3 -> 8 (planar in) / 8 -> 8 (channel-last in), k = 3, ReLU; channel-last [Z][Y][X][8] out.

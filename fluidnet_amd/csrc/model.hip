@@ -473,12 +473,12 @@ void model_pre(hipStream_t st, bool is3d, int B, int Z, int Y, int X, const floa
   long long per_plane = (long long)grd.x * grd.y;   // partials per z-plane (never more than model_stat_blocks assumes)
   if (v.ok) {
     per_plane = (long long)v.grd.x * v.grd.y;
-    TFL_TIMED("k_bcs_div_stats", st);
-    if (is3d) k_bcs_div_stats_v4<true><<<v.grd, v.blk, 0, st>>>(d, U, flags, Ubc, div, partials);
-    else k_bcs_div_stats_v4<false><<<v.grd, v.blk, 0, st>>>(d, U, flags, Ubc, div, partials);
+    TFL_TIMED_EXT("k_bcs_div_stats", st);
+    if (is3d) TFL_LAUNCH_EXT((k_bcs_div_stats_v4<true>), v.grd, v.blk, 0, st, d, U, flags, Ubc, div, partials);
+    else TFL_LAUNCH_EXT((k_bcs_div_stats_v4<false>), v.grd, v.blk, 0, st, d, U, flags, Ubc, div, partials);
   } else if (is3d) { TFL_TIMED("k_bcs_div_stats", st); k_bcs_div_stats<true><<<grd, blk, 0, st>>>(d, U, flags, Ubc, div, partials); }
   else { TFL_TIMED("k_bcs_div_stats", st); k_bcs_div_stats<false><<<grd, blk, 0, st>>>(d, U, flags, Ubc, div, partials); }
-  { TFL_TIMED("k_reduce_stats", st); k_reduce_stats<<<B, 256, 0, st>>>(partials, per_plane * Z, per_plane * zlo, per_plane * (zhi - zlo), stats); }
+  { TFL_TIMED_EXT("k_reduce_stats", st); TFL_LAUNCH_EXT(k_reduce_stats, B, 256, 0, st, (const double*)partials, per_plane * Z, per_plane * zlo, per_plane * (zhi - zlo), stats); }
 }
 
 void model_net_input(hipStream_t st, bool is3d, int B, int Z, int Y, int X, const float* pDiv, const float* div,
@@ -499,9 +499,9 @@ void model_project(hipStream_t st, bool is3d, int B, int Z, int Y, int X, const 
                        (uintptr_t)UInvMask;
   if (X % 4 == 0 && (al & 15) == 0 && !getenv("TFL_NO_VEC4")) {
     const dim3 vb(32, 8, 1), vg((X / 4 + 31) / 32, (Y + 7) / 8, (unsigned)(Z * B));
-    TFL_TIMED("k_project", st);
-    if (is3d) k_project_v4<true><<<vg, vb, 0, st>>>(d, pPred, flags, stats, count, Uio, pOut, bc);
-    else k_project_v4<false><<<vg, vb, 0, st>>>(d, pPred, flags, stats, count, Uio, pOut, bc);
+    TFL_TIMED_EXT("k_project", st);
+    if (is3d) TFL_LAUNCH_EXT((k_project_v4<true>), vg, vb, 0, st, d, pPred, flags, stats, count, Uio, pOut, bc);
+    else TFL_LAUNCH_EXT((k_project_v4<false>), vg, vb, 0, st, d, pPred, flags, stats, count, Uio, pOut, bc);
     return;
   }
   if (is3d) { TFL_TIMED("k_project", st); k_project<true><<<grd, blk, 0, st>>>(d, pPred, flags, stats, count, Uio, pOut, bc); }
@@ -542,15 +542,15 @@ void apply_bcs_indexed_multi(hipStream_t st, int count, const long long* n, cons
   }
   if (nmax == 0) return;
   const unsigned bx = (unsigned)std::min<long long>((nmax + 255) / 256, 4096);
-  TFL_TIMED("k_apply_bcs_indexed", st);
-  k_apply_bcs_indexed_multi<<<dim3(bx, (unsigned)count, 1), 256, 0, st>>>(a);
+  TFL_TIMED_EXT("k_apply_bcs_indexed", st);
+  TFL_LAUNCH_EXT(k_apply_bcs_indexed_multi, dim3(bx, (unsigned)count, 1), 256, 0, st, a);
 }
 
 void apply_bcs_indexed(hipStream_t st, long long n, const int* idx, float* x, const float* bcv, const float* inv) {
   if (n <= 0) return;
   long long blocks = (n + 255) / 256;
   if (blocks > 4096) blocks = 4096;
-  { TFL_TIMED("k_apply_bcs_indexed", st); k_apply_bcs_indexed<<<(int)blocks, 256, 0, st>>>(n, idx, x, bcv, inv); }
+  { TFL_TIMED_EXT("k_apply_bcs_indexed", st); TFL_LAUNCH_EXT(k_apply_bcs_indexed, (int)blocks, 256, 0, st, n, idx, x, bcv, inv); }
 }
 
 }  // namespace tfl

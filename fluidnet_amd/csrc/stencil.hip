@@ -226,9 +226,9 @@ void add_buoyancy(hipStream_t st, bool is3d, int B, int Z, int Y, int X, const f
   if (vec) {
     const Dom d = make_dom(Z, Y, X);
     const dim3 blk(32, 8, 1), grd((X / 4 + 31) / 32, (Y + 7) / 8, (unsigned)(Z * B));
-    TFL_TIMED("k_add_buoyancy", st);
-    if (is3d) k_add_buoyancy_v4<true><<<grd, blk, 0, st>>>(d, Usrc, U, flags, density, sx, sy, sz);
-    else k_add_buoyancy_v4<false><<<grd, blk, 0, st>>>(d, Usrc, U, flags, density, sx, sy, sz);
+    TFL_TIMED_EXT("k_add_buoyancy", st);
+    if (is3d) TFL_LAUNCH_EXT((k_add_buoyancy_v4<true>), grd, blk, 0, st, d, Usrc, U, flags, density, sx, sy, sz);
+    else TFL_LAUNCH_EXT((k_add_buoyancy_v4<false>), grd, blk, 0, st, d, Usrc, U, flags, density, sx, sy, sz);
     return;
   }
   if (Usrc != U)   // the one-cell-per-thread kernel skips the cells it does not change

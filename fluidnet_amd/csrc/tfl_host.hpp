@@ -1,6 +1,7 @@
 // tfl_host.hpp -- host-side launcher prototypes shared by the .hip translation units and abi.cpp.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 namespace tfl {
 
@@ -8,12 +9,30 @@ namespace tfl {
 // lib/simulate.lua:254-260,306-318). When a profile is active on this thread every kernel launch is
 // bracketed by hipEvents on the launch stream; tfl_profile_end() sums them per kernel name.
 struct KernelTimer {
-  KernelTimer(const char* name, hipStream_t st);
+  // ext = false: the events are recorded on the stream around whatever the scope launches (adds the command
+  // processor's event handling to the reading: +2..7 us per kernel). ext = true: nothing is recorded here; the
+  // scope passes start()/stop() to hipExtLaunchKernelGGL, which stamps them with the dispatch's own begin / end
+  // (the numbers rocprofv3 reports). Both are null when no profile is active.
+  KernelTimer(const char* name, hipStream_t st, bool ext = false);
   ~KernelTimer();
+  hipEvent_t start() const;
+  hipEvent_t stop() const;
   int slot_;
   hipStream_t st_;
+  bool ext_;
 };
 #define TFL_TIMED(name, st) ::tfl::KernelTimer tfl_timer_(name, st)
+#define TFL_TIMED_EXT(name, st) ::tfl::KernelTimer tfl_timer_(name, st, true)
+// one launch inside a TFL_TIMED_EXT scope; `kernel` in parentheses when it is a template-id with commas
+// (the plain launch when no profile is active: hipExtLaunchKernelGGL costs a few us more on the host)
+#define TFL_LAUNCH_EXT(kernel, grid, block, shmem, st, ...)                                                        \
+  do {                                                                                                             \
+    if (tfl_timer_.start())                                                                                        \
+      hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(block), (uint32_t)(shmem), st, tfl_timer_.start(),            \
+                            tfl_timer_.stop(), 0, __VA_ARGS__);                                                    \
+    else                                                                                                           \
+      hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), (uint32_t)(shmem), st, __VA_ARGS__);                      \
+  } while (0)
 
 // advect.hip
 void advect_scalar(hipStream_t st, bool is3d, int method, int B, int Z, int Y, int X, float dt, float strength,

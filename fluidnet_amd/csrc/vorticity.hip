@@ -284,8 +284,8 @@ void vorticity_confinement(hipStream_t st, bool is3d, int B, int Z, int Y, int X
   const Vec4Launch v = vec4_launch(B, Z, Y, X, {U, flags, curl, curl_norm});
   if (v.ok) {
     if (is3d) {
-      { TFL_TIMED("k_curl", st); k_curl_v4<true><<<v.grd, v.blk, 0, st>>>(d, U, curl, curl_norm); }
-      { TFL_TIMED("k_confine", st); k_confine_v4<true><<<v.grd, v.blk, 0, st>>>(d, U, flags, curl, curl_norm, strength); }
+      { TFL_TIMED_EXT("k_curl", st); TFL_LAUNCH_EXT((k_curl_v4<true>), v.grd, v.blk, 0, st, d, (const float*)U, curl, curl_norm); }
+      { TFL_TIMED_EXT("k_confine", st); TFL_LAUNCH_EXT((k_confine_v4<true>), v.grd, v.blk, 0, st, d, U, flags, (const float*)curl, (const float*)curl_norm, strength); }
     } else {
       { TFL_TIMED("k_curl", st); k_curl_v4<false><<<v.grd, v.blk, 0, st>>>(d, U, curl, curl_norm); }
       { TFL_TIMED("k_confine", st); k_confine_v4<false><<<v.grd, v.blk, 0, st>>>(d, U, flags, curl, curl_norm, strength); }
