@@ -142,16 +142,16 @@ __device__ __forceinline__ bool manta_clamp_bounds(const Dom& d, const float* __
     // v_min3_f32 / v_max3_f32: one instruction per corner pair instead of four. Equal to the reference's
     // compare-and-keep chain in value; only the SIGN of a zero bound can differ (min prefers -0, the chain the
     // first zero it met), which no later operation of the step can turn into a different number.
-    lo = __builtin_fminf(__builtin_fminf(lo, g[a]), g[a + 1]);
-    hi = __builtin_fmaxf(__builtin_fmaxf(hi, g[a]), g[a + 1]);
-    lo = __builtin_fminf(__builtin_fminf(lo, g[a + d.sy]), g[a + 1 + d.sy]);
-    hi = __builtin_fmaxf(__builtin_fmaxf(hi, g[a + d.sy]), g[a + 1 + d.sy]);
+    lo = __builtin_fminf(__builtin_fminf(lo, g[a]), g[a + TFL_P1(d)]);
+    hi = __builtin_fmaxf(__builtin_fmaxf(hi, g[a]), g[a + TFL_P1(d)]);
+    lo = __builtin_fminf(__builtin_fminf(lo, g[a + d.sy]), g[a + TFL_P1(d) + d.sy]);
+    hi = __builtin_fmaxf(__builtin_fmaxf(hi, g[a + d.sy]), g[a + TFL_P1(d) + d.sy]);
     if (IS3D) {
       const int c = a + d.sz;
-      lo = __builtin_fminf(__builtin_fminf(lo, g[c]), g[c + 1]);
-      hi = __builtin_fmaxf(__builtin_fmaxf(hi, g[c]), g[c + 1]);
-      lo = __builtin_fminf(__builtin_fminf(lo, g[c + d.sy]), g[c + 1 + d.sy]);
-      hi = __builtin_fmaxf(__builtin_fmaxf(hi, g[c + d.sy]), g[c + 1 + d.sy]);
+      lo = __builtin_fminf(__builtin_fminf(lo, g[c]), g[c + TFL_P1(d)]);
+      hi = __builtin_fmaxf(__builtin_fmaxf(hi, g[c]), g[c + TFL_P1(d)]);
+      lo = __builtin_fminf(__builtin_fminf(lo, g[c + d.sy]), g[c + TFL_P1(d) + d.sy]);
+      hi = __builtin_fmaxf(__builtin_fmaxf(hi, g[c + d.sy]), g[c + TFL_P1(d) + d.sy]);
     }
 #endif
   }

@@ -31,13 +31,20 @@ __device__ __forceinline__ v3 scale3(v3 a, float s) { return mk3(a.x * s, a.y * 
 struct Dom {
   int X, Y, Z;
   int sy, sz, sc;  // element strides of y, z and channel
+  int one;         // always 1, but opaque to the compiler (see TFL_P1)
 };
 
 __host__ __device__ inline Dom make_dom(int Z, int Y, int X) {
-  Dom d; d.X = X; d.Y = Y; d.Z = Z; d.sy = X; d.sz = X * Y; d.sc = X * Y * Z; return d;
+  Dom d; d.X = X; d.Y = Y; d.Z = Z; d.sy = X; d.sz = X * Y; d.sc = X * Y * Z; d.one = 1; return d;
 }
 
 #define TFL_AT(d, i, j, k) ((i) + (j) * (d).sy + (k) * (d).sz)
+// The +1 x-neighbour of a GATHERED tap (interpolation corners, clamp boxes: positions that depend on a back-trace).
+// hipcc merges g[a], g[a + 1] into one global_load_dwordx2 at a 4-byte-aligned address, and on gfx950 that costs
+// more texture-addresser time than two dword loads (r01 A/B: k_vel_bwd 57.4 -> 53.5 us, k_vel_fwd 26.4 -> 24.3,
+// scalar passes -1 us each). Dom::one is a kernel argument equal to 1: adding it keeps the two loads apart. The
+// cell-aligned MAC taps (get_at_mac) stay merged: there the wide load wins.
+#define TFL_P1(d) ((d).one)
 
 template <bool IS3D>
 __device__ __forceinline__ bool on_border(const Dom& d, int i, int j, int k) {
@@ -77,7 +84,7 @@ template <bool IS3D>
 __device__ __forceinline__ v3 get_centered(const Dom& d, const float* __restrict__ U, int i, int j, int k) {
   const int a = TFL_AT(d, i, j, k);
   v3 r;
-  r.x = 0.5f * (U[a] + U[a + 1]);
+  r.x = 0.5f * (U[a] + U[a + TFL_P1(d)]);
   r.y = 0.5f * (U[a + d.sc] + U[a + d.sc + d.sy]);
   r.z = IS3D ? 0.5f * (U[a + 2 * d.sc] + U[a + 2 * d.sc + d.sz]) : 0.0f;
   return r;
@@ -144,11 +151,11 @@ __device__ __forceinline__ float interpol(const Dom& d, const float* __restrict_
   const Lerp L = build_index<IS3D>(d, pos);
   const int a = TFL_AT(d, L.xi, L.yi, L.zi);
   const float lo = (g[a] * L.t0 + g[a + d.sy] * L.t1) * L.s0 +
-                   (g[a + 1] * L.t0 + g[a + 1 + d.sy] * L.t1) * L.s1;
+                   (g[a + TFL_P1(d)] * L.t0 + g[a + TFL_P1(d) + d.sy] * L.t1) * L.s1;
   if (!IS3D) return lo;
   const int b = a + d.sz;
   const float hi = (g[b] * L.t0 + g[b + d.sy] * L.t1) * L.s0 +
-                   (g[b + 1] * L.t0 + g[b + 1 + d.sy] * L.t1) * L.s1;
+                   (g[b + TFL_P1(d)] * L.t0 + g[b + TFL_P1(d) + d.sy] * L.t1) * L.s1;
   return lo * L.f0 + hi * L.f1;
 }
 
@@ -170,14 +177,14 @@ __device__ __forceinline__ float interpol_with_fluid(const Dom& d, const float* 
   bool f_ab, f_cd, f_abcd, fo;
   float v_ab, v_cd, v_abcd, val;
   lerp_fluid(g[a], fl(a), g[a + d.sy], fl(a + d.sy), L.t0, L.t1, f_ab, v_ab);
-  lerp_fluid(g[a + 1], fl(a + 1), g[a + 1 + d.sy], fl(a + 1 + d.sy), L.t0, L.t1, f_cd, v_cd);
+  lerp_fluid(g[a + TFL_P1(d)], fl(a + TFL_P1(d)), g[a + TFL_P1(d) + d.sy], fl(a + TFL_P1(d) + d.sy), L.t0, L.t1, f_cd, v_cd);
   lerp_fluid(v_ab, f_ab, v_cd, f_cd, L.s0, L.s1, f_abcd, v_abcd);
   if (IS3D) {
     const int b = a + d.sz;
     bool f_ef, f_gh, f_efgh;
     float v_ef, v_gh, v_efgh;
     lerp_fluid(g[b], fl(b), g[b + d.sy], fl(b + d.sy), L.t0, L.t1, f_ef, v_ef);
-    lerp_fluid(g[b + 1], fl(b + 1), g[b + 1 + d.sy], fl(b + 1 + d.sy), L.t0, L.t1, f_gh, v_gh);
+    lerp_fluid(g[b + TFL_P1(d)], fl(b + TFL_P1(d)), g[b + TFL_P1(d) + d.sy], fl(b + TFL_P1(d) + d.sy), L.t0, L.t1, f_gh, v_gh);
     lerp_fluid(v_ef, f_ef, v_gh, f_gh, L.s0, L.s1, f_efgh, v_efgh);
     lerp_fluid(v_abcd, f_abcd, v_efgh, f_efgh, L.f0, L.f1, fo, val);
   } else {
