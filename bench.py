@@ -138,7 +138,7 @@ def main():
             dist.init_process_group(backend)
 
     from fluidnet_amd import FluidNetModel, tfluids
-    from fluidnet_amd.simulate import simulate
+    from fluidnet_amd.simulate import simulate_native
     model = FluidNetModel.default_3d(seed=1)
     res = args.res
     if world > 1:
@@ -151,7 +151,8 @@ def main():
         batch, mconf = build_scene(res, res, None, dev)
 
         def step():
-            simulate(None, mconf, batch, model)
+            # the whole simulate() step through ONE C-ABI call (tfl_simulate_step, csrc/simulate.cpp)
+            simulate_native(None, mconf, batch, model)
 
     def barrier():
         torch.cuda.synchronize()

@@ -27,6 +27,21 @@ _F3 = ctypes.POINTER(ctypes.c_float)
 _c = ctypes
 
 # name -> (restype, argtypes) for every symbol include/tfluids_hip.h declares.
+class tfl_sim_params(_c.Structure):
+    """include/tfluids_hip.h tfl_sim_params (mconf of lib/simulate.lua)."""
+    _fields_ = [("dt", _c.c_float), ("advectionMethod", _c.c_char_p), ("maccormackStrength", _c.c_float),
+                ("buoyancyScale", _c.c_float), ("gravityScale", _c.c_float), ("gravity", _c.c_float * 3),
+                ("vorticityConfinementAmp", _c.c_float), ("simMethod", _c.c_char_p), ("maxIter", _c.c_int32),
+                ("pcgPrecond", _c.c_char_p), ("outputDiv", _c.c_int32)]
+
+
+class tfl_sim_state(_c.Structure):
+    """include/tfluids_hip.h tfl_sim_state."""
+    _fields_ = [("p", _c.POINTER(tfl_tensor)), ("U", _c.POINTER(tfl_tensor)), ("flags", _c.POINTER(tfl_tensor)),
+                ("n_density", _c.c_int32), ("density", _c.POINTER(tfl_tensor) * 8), ("pBC", _c.c_void_p),
+                ("UBC", _c.c_void_p), ("densityBC", _c.c_void_p * 8), ("model", _c.c_void_p)]
+
+
 SIGNATURES = {
     "tfl_abi_version": (_c.c_int, []),
     "tfl_create": (_c.c_void_p, [_c.c_int]),
@@ -79,6 +94,13 @@ SIGNATURES = {
     "tfl_pcg_workspace_floats": (_c.c_int64, [_c.c_int32, _c.c_int32, _c.c_int32]),
     "tfl_solveLinearSystemPCG": (_c.c_int, [_c.c_void_p, _T, _T, _T, _c.c_int, _c.c_char_p, _c.c_float, _c.c_int, _c.c_int,
                                             _c.c_void_p, _c.c_int64, _c.c_void_p]),
+    "tfl_getDx": (_c.c_double, [_c.c_void_p, _T]),
+    "tfl_copy": (_c.c_int, [_c.c_void_p, _T, _T]),
+    "tfl_bc_plan_create": (_c.c_void_p, [_c.c_void_p, _T, _T]),
+    "tfl_bc_plan_destroy": (None, [_c.c_void_p, _c.c_void_p]),
+    "tfl_simulate_workspace_floats": (_c.c_int64, [_c.c_void_p, _c.POINTER(tfl_sim_params), _c.POINTER(tfl_sim_state)]),
+    "tfl_simulate_step": (_c.c_int, [_c.c_void_p, _c.POINTER(tfl_sim_params), _c.POINTER(tfl_sim_state), _c.c_void_p,
+                                     _c.c_int64]),
     "tfl_applyBCsIndexedMulti": (_c.c_int, [_c.c_void_p, _c.c_int, _c.POINTER(_T), _c.POINTER(_T), _c.POINTER(_T),
                                             _c.POINTER(_c.c_void_p), _c.POINTER(_c.c_int64)]),
     "tfl_applyBCs": (_c.c_int, [_c.c_void_p, _T, _T, _T, _c.c_int, _c.c_float, _c.c_float]),

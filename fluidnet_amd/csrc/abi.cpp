@@ -705,6 +705,23 @@ int tfl_model_forward(tfl_ctx* c, tfl_model* m, const tfl_tensor* pDiv, const tf
                           doClamp, lo, hi);
 }
 
+double tfl_getDx(tfl_ctx* c, const tfl_tensor* flags) {
+  if (!flags) return 0.0;
+  if (c && c->dx_override > 0.0f) return (double)c->dx_override;
+  int m = flags->X > flags->Y ? flags->X : flags->Y;
+  if (flags->Z > m) m = flags->Z;
+  return 1.0 / (double)m;
+}
+
+int tfl_copy(tfl_ctx* c, const tfl_tensor* dst, const tfl_tensor* src) {
+  if (!c) return TFL_EINVAL;
+  if (!dst || !src || !dst->data || !src->data) return fail(c, TFL_EINVAL, "copy: null tensor");
+  const long long n = (long long)dst->B * dst->C * dst->Z * dst->Y * dst->X;
+  if (n != (long long)src->B * src->C * src->Z * src->Y * src->X) return fail(c, TFL_EINVAL, "copy: size mismatch");
+  HIP_TRY(c, hipMemcpyAsync(dst->data, src->data, sizeof(float) * (size_t)n, hipMemcpyDeviceToDevice, c->stream));
+  return TFL_OK;
+}
+
 int tfl_applyBCs(tfl_ctx* c, const tfl_tensor* x, const tfl_tensor* bc, const tfl_tensor* invMask, int doClamp,
                  float lo, float hi) {
   if (!c) return TFL_EINVAL;

@@ -436,6 +436,21 @@ __global__ __launch_bounds__(256) void k_apply_bcs_indexed_multi(BcMultiArgs a) 
   }
 }
 
+// tfl_bc_plan_create: the cells where a (bc, invMask) pair is not the identity. Pass 1 (idx == nullptr) counts,
+// pass 2 fills; counters[0] = count, counters[1] = 1 if some listed cell has invMask != 0 or |bc| > 1e6 (the pair is
+// then not idempotent / does not commute with the step's final clamp). The order of the list is irrelevant.
+__global__ __launch_bounds__(256) void k_bc_scan(long long n, const float* __restrict__ bcv, const float* __restrict__ inv,
+                                                 int* __restrict__ counters, int* __restrict__ idx) {
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x) {
+    const float m = inv[e], b = bcv[e];
+    if (m != 1.0f || b != 0.0f) {
+      const int pos = atomicAdd(&counters[0], 1);
+      if (idx) idx[pos] = (int)e;
+      if (m != 0.0f || !(fabsf(b) <= 1e6f)) counters[1] = 1;
+    }
+  }
+}
+
 // Halo planes of several fields <-> one contiguous message buffer (fluidnet_amd/dist.py): buffer layout
 // [field][b][channel][plane zlo..zhi)[Y][X]. One launch per direction instead of a dozen strided copies.
 struct PackArgs {
@@ -529,6 +544,11 @@ void pack_planes(hipStream_t st, int n, float* const* ptrs, const int* rows, lon
   if (blocks > 2048) blocks = 2048;
   if (blocks < 1) return;
   { TFL_TIMED(unpack ? "k_unpack_planes" : "k_pack_planes", st); k_pack_planes<<<(int)blocks, 256, 0, st>>>(a, zstride, plane_elems, zlo_off, buf, unpack); }
+}
+
+void bc_scan(hipStream_t st, long long n, const float* bcv, const float* inv, int* counters, int* idx) {
+  const int blocks = (int)std::min<long long>((n + 255) / 256, 4096);
+  k_bc_scan<<<blocks > 0 ? blocks : 1, 256, 0, st>>>(n, bcv, inv, counters, idx);
 }
 
 void apply_bcs_indexed_multi(hipStream_t st, int count, const long long* n, const int* const* idx, float* const* x,

@@ -93,6 +93,7 @@ void model_project(hipStream_t st, bool is3d, int B, int Z, int Y, int X, const 
 void apply_bcs(hipStream_t st, long long n, float* x, const float* bcv, const float* inv, int do_clamp, float lo,
                float hi);
 
+void bc_scan(hipStream_t st, long long n, const float* bcv, const float* inv, int* counters, int* idx);
 void apply_bcs_indexed_multi(hipStream_t st, int count, const long long* n, const int* const* idx, float* const* x,
                              const float* const* bcv, const float* const* inv);
 void apply_bcs_indexed(hipStream_t st, long long n, const int* idx, float* x, const float* bcv, const float* inv);

@@ -53,6 +53,18 @@ int tfl_solveLinearSystemJacobi(tfl_ctx*, const tfl_tensor* p, const tfl_tensor*
                                 const tfl_tensor* pPrev, const tfl_tensor* pDelta,
                                 const tfl_tensor* pDeltaNorm, int is3D, float pTol, int maxIter, int verbose,
                                 float* residual);
+/* the whole step in one call (csrc/simulate.cpp) */
+typedef struct tfl_bc_plan tfl_bc_plan;
+typedef struct tfl_model tfl_model;
+tfl_bc_plan* tfl_bc_plan_create(tfl_ctx*, const tfl_tensor* bc, const tfl_tensor* invMask);
+void tfl_bc_plan_destroy(tfl_ctx*, tfl_bc_plan*);
+typedef struct tfl_sim_params { float dt; const char* advectionMethod; float maccormackStrength, buoyancyScale,
+  gravityScale; float gravity[3]; float vorticityConfinementAmp; const char* simMethod; int32_t maxIter;
+  const char* pcgPrecond; int32_t outputDiv; } tfl_sim_params;
+typedef struct tfl_sim_state { const tfl_tensor *p, *U, *flags; int32_t n_density; const tfl_tensor* density[8];
+  const tfl_bc_plan *pBC, *UBC; const tfl_bc_plan* densityBC[8]; tfl_model* model; } tfl_sim_state;
+int64_t tfl_simulate_workspace_floats(tfl_ctx*, const tfl_sim_params*, const tfl_sim_state*);
+int tfl_simulate_step(tfl_ctx*, const tfl_sim_params*, const tfl_sim_state*, float* workspace, int64_t workspace_floats);
 ]]
 
 local M = {}

@@ -252,6 +252,73 @@ def simulate(conf, mconf, batch, model, outputDiv=False):
         _apply(U, None, None, clamp=(-1e6, 1e6))
 
 
+_plan_cache = {}   # (bc ptr, mask ptr, numel) -> (bc version, mask version, tfl_bc_plan*)
+
+
+def _bc_plan(lib, ctx, bc, inv):
+    """tfl_bc_plan of a (BC, BCInvMask) pair, cached like _bc_indices (re-created when either tensor is edited)."""
+    if bc is None or inv is None:
+        return None
+    key = (bc.data_ptr(), inv.data_ptr(), bc.numel())
+    hit = _plan_cache.get(key)
+    if hit is not None and hit[0] == bc._version and hit[1] == inv._version:
+        return hit[2]
+    if hit is not None:
+        lib.tfl_bc_plan_destroy(ctx, hit[2])
+    plan = lib.tfl_bc_plan_create(ctx, tfluids._tt5(bc), tfluids._tt5(inv))
+    if not plan:
+        raise TfluidsError("tfl_bc_plan_create failed")
+    _plan_cache[key] = (bc._version, inv._version, plan)
+    return plan
+
+
+def simulate_native(conf, mconf, batch, model, outputDiv=False):
+    """The same step through ONE C-ABI call, tfl_simulate_step (fluidnet_amd/csrc/simulate.cpp): what a LuaJIT / cgo
+    host would bind instead of re-implementing this file's orchestration. Bit-identical to simulate()."""
+    from ._lib import tfl_sim_params, tfl_sim_state, tfl_tensor
+    p, U, flags, density = getPUFlagsDensityReference(batch)
+    lib, ctx = tfluids._context(U)
+    chans = [] if density is None else (list(density) if isinstance(density, (list, tuple)) else [density])
+    prm = tfl_sim_params()
+    prm.dt = float(mconf["dt"])
+    method = mconf.get("advectionMethod")
+    prm.advectionMethod = method.encode() if method else None
+    strength = mconf.get("maccormackStrength")
+    prm.maccormackStrength = 0.75 if strength is None else float(strength)
+    prm.buoyancyScale = float(mconf.get("buoyancyScale", 0) or 0)
+    prm.gravityScale = float(mconf.get("gravityScale", 0) or 0)
+    for i, v in enumerate(_gravity(mconf)):
+        prm.gravity[i] = v
+    prm.vorticityConfinementAmp = float(mconf.get("vorticityConfinementAmp", 0) or 0)
+    sm = mconf.get("simMethod")
+    prm.simMethod = sm.encode() if sm else None
+    prm.maxIter = int(mconf.get("maxIter") or 0)
+    pc = mconf.get("pcgPrecond")
+    prm.pcgPrecond = pc.encode() if pc else None
+    prm.outputDiv = int(bool(outputDiv))
+    keep = [tfluids._desc5(t) for t in (p, U, flags)] + [tfluids._desc5(c) for c in chans]
+    st = tfl_sim_state()
+    st.p, st.U, st.flags = (ctypes.pointer(k) for k in keep[:3])
+    st.n_density = len(chans)
+    for i in range(len(chans)):
+        st.density[i] = ctypes.pointer(keep[3 + i])
+    st.pBC = _bc_plan(lib, ctx, batch.get("pBC"), batch.get("pBCInvMask"))
+    st.UBC = _bc_plan(lib, ctx, batch.get("UBC"), batch.get("UBCInvMask"))
+    if chans and batch.get("densityBC") is not None:
+        dbc, dmk = batch["densityBC"], batch["densityBCInvMask"]
+        if not isinstance(dbc, (list, tuple)):
+            dbc, dmk = [dbc], [dmk]
+        if len(dbc) != len(chans):
+            raise TfluidsError("density / densityBC channel mismatch")
+        for i in range(len(chans)):
+            st.densityBC[i] = _bc_plan(lib, ctx, dbc[i], dmk[i])
+    st.model = model._handle(lib, ctx, U.device.index) if model is not None else None
+    nws = int(lib.tfl_simulate_workspace_floats(ctx, ctypes.byref(prm), ctypes.byref(st)))
+    ws = tfluids.getTempStorage(U, [(nws,)])[0]
+    tfluids._call(lib, ctx, lib.tfl_simulate_step(ctx, ctypes.byref(prm), ctypes.byref(st), ctypes.c_void_p(ws.data_ptr()), nws))
+    del keep, tfl_tensor
+
+
 class GraphedSimulate:
     """simulate() captured once into a HIP graph and replayed: one host call per step instead of ~25
     kernel launches + Python dispatch. The reference's 2-D path is launch-bound (~70

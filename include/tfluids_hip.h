@@ -254,6 +254,58 @@ int tfl_applyBCsIndexed(tfl_ctx* ctx, const tfl_tensor* x, const tfl_tensor* bc,
 int tfl_applyBCsIndexedMulti(tfl_ctx* ctx, int count, const tfl_tensor* const* x, const tfl_tensor* const* bc,
                              const tfl_tensor* const* invMask, const int32_t* const* idx, const int64_t* n);
 
+/* init.lua:560-564 `tfluids.getDx(flags)`: 1 / max(X, Y, Z) as a double (a Lua number), or the override of
+ * tfl_set_dx_override. */
+double tfl_getDx(tfl_ctx* ctx, const tfl_tensor* flags);
+
+/* `dst:copy(src)` on the context's stream (same element count). */
+int tfl_copy(tfl_ctx* ctx, const tfl_tensor* dst, const tfl_tensor* src);
+
+/* ---- the whole step as one call: lib/simulate.lua:175-327 in native code -------------------------------------
+ * For hosts that are not Python (the LuaJIT binding): tfl_simulate_step runs tfluids.simulate() -- advectScalar
+ * per density channel, advectVel, setConstVals, addBuoyancy / addGravity / vorticityConfinement, setConstVals, the
+ * pressure projection (ConvNet | Jacobi | PCG), setConstVals, U:clamp(+-1e6) -- with the same launch-saving
+ * orchestration as fluidnet_amd/simulate.py: index-list BCs, idempotent BC pairs skipped on fields nothing has
+ * written, the U:copy after advectVel folded into addBuoyancy, setConstVals(U) + clamp fused into the projection.
+ * State tensors are updated in place like the reference's batchGPU.
+ *
+ * tfl_bc_plan: the precomputed form of one (BC, BCInvMask) pair of lib/simulate.lua:130-160 (the list of cells where
+ * the pair is not the identity; whether it is sparse; whether it is idempotent). Create once per pair, re-create
+ * when the BC tensors change (createPlumeBCs, the 2-D demo's interactive edits). The plan keeps the two pointers. */
+typedef struct tfl_bc_plan tfl_bc_plan;
+tfl_bc_plan* tfl_bc_plan_create(tfl_ctx* ctx, const tfl_tensor* bc, const tfl_tensor* invMask);
+void tfl_bc_plan_destroy(tfl_ctx* ctx, tfl_bc_plan* plan);
+
+typedef struct tfl_sim_params {      /* mconf of lib/simulate.lua (defaults of lib/default_conf.lua in brackets) */
+  float dt;
+  const char* advectionMethod;       /* NULL = "maccormackOurs" */
+  float maccormackStrength;
+  float buoyancyScale;               /* 0 = off */
+  float gravityScale;                /* 0 = off */
+  float gravity[3];                  /* direction, simulate.lua:204-211 [0, 1, 0] */
+  float vorticityConfinementAmp;     /* 0 = off */
+  const char* simMethod;             /* NULL | "convnet" | "jacobi" | "pcg" */
+  int32_t maxIter;                   /* jacobi / pcg; <= 0 -> 100 */
+  const char* pcgPrecond;            /* NULL = "ic0" (simulate.lua:283) */
+  int32_t outputDiv;                 /* 1: return before the projection (simulate.lua:241-245) */
+} tfl_sim_params;
+
+typedef struct tfl_sim_state {
+  const tfl_tensor* p;               /* batch.pDiv   [B][1][Z][Y][X] */
+  const tfl_tensor* U;               /* batch.UDiv   [B][C][Z][Y][X] */
+  const tfl_tensor* flags;
+  int32_t n_density;                 /* 0..8 scalar channels (the RGB table of the 2-D demo = 3) */
+  const tfl_tensor* density[8];
+  const tfl_bc_plan* pBC;            /* NULL = no such BC pair */
+  const tfl_bc_plan* UBC;
+  const tfl_bc_plan* densityBC[8];
+  tfl_model* model;                  /* needed for simMethod convnet */
+} tfl_sim_state;
+
+int64_t tfl_simulate_workspace_floats(tfl_ctx* ctx, const tfl_sim_params* params, const tfl_sim_state* state);
+int tfl_simulate_step(tfl_ctx* ctx, const tfl_sim_params* params, const tfl_sim_state* state, float* workspace,
+                      int64_t workspace_floats);
+
 /* z-slab halo messages (BASELINE config 5): gather planes [zlo, zhi) of n <= 8 fields (each with its own
  * B and C; all with the same Z, Y, X) into one contiguous buffer laid out
  * [field][b][c][plane][Y][X] (unpack = 0), or scatter such a buffer back into the fields (unpack = 1).

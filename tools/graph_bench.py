@@ -6,7 +6,7 @@ import numpy as np, torch
 from oracle import simulate_np as S
 from test_hip_simulate import _plume_batch, _to_dev, _layers2d
 from fluidnet_amd import FluidNetModel
-from fluidnet_amd.simulate import GraphedSimulate, simulate
+from fluidnet_amd.simulate import GraphedSimulate, simulate, simulate_native
 dev=torch.device('cuda:0')
 def run(name, dims, mconf, model, rad, usc, steps=200):
     b=_to_dev(_plume_batch(dims, rad, usc), dev)
@@ -14,13 +14,17 @@ def run(name, dims, mconf, model, rad, usc, steps=200):
     torch.cuda.synchronize(); t0=time.perf_counter()
     for _ in range(steps): simulate(None, mconf, b, model)
     torch.cuda.synchronize(); te=(time.perf_counter()-t0)/steps
+    for _ in range(5): simulate_native(None, mconf, b, model)
+    torch.cuda.synchronize(); t0=time.perf_counter()
+    for _ in range(steps): simulate_native(None, mconf, b, model)
+    torch.cuda.synchronize(); tn=(time.perf_counter()-t0)/steps
     g=GraphedSimulate(None, mconf, b, model)
     for _ in range(5): g.step()
     torch.cuda.synchronize(); t0=time.perf_counter()
     for _ in range(steps): g.step()
     torch.cuda.synchronize(); tg=(time.perf_counter()-t0)/steps
     n=np.prod(dims)
-    print("%-34s eager %7.3f ms (%7.0f steps/s)   graph %7.3f ms (%7.0f steps/s, %7.1f Mcells/s)"%(name, te*1e3, 1/te, tg*1e3, 1/tg, n/tg/1e6))
+    print("%-34s eager %7.3f ms (%7.0f steps/s)   native step %7.3f ms   graph %7.3f ms (%7.0f steps/s, %7.1f Mcells/s)"%(name, te*1e3, 1/te, tn*1e3, tg*1e3, 1/tg, n/tg/1e6))
 m2=dict(dt=4/60, advectionMethod="maccormackOurs", maccormackStrength=0.75, buoyancyScale=1.0, gravityScale=0, vorticityConfinementAmp=0)
 run("cfg1 2D 64^2 jacobi20", (1,64,64), dict(m2, simMethod="jacobi", maxIter=20), None, 0.05, 10.0)
 run("cfg2 2D 128^2 convnet", (1,128,128), dict(m2, simMethod="convnet"), FluidNetModel(_layers2d(), False), 0.05, 10.0)
