@@ -84,6 +84,7 @@ tfl_bc_plan* tfl_bc_plan_create(tfl_ctx* c, const tfl_tensor* bc, const tfl_tens
   p->bc = *bc; p->inv = *invMask; p->numel = numel_of(bc);
   int* d_cnt = nullptr;
   int h_cnt[2] = {0, 0};
+  (void)hipDeviceSynchronize();   // one-time set-up: whoever filled the BC tensors (any stream) is done
   if (hipMalloc((void**)&d_cnt, 2 * sizeof(int)) != hipSuccess) { delete p; return nullptr; }
   (void)hipMemset(d_cnt, 0, 2 * sizeof(int));
   tfl::bc_scan(nullptr, p->numel, bc->data, invMask->data, d_cnt, nullptr);
