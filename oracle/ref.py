@@ -29,6 +29,21 @@ def available(fast=False):
     return os.path.exists(_path(fast))
 
 
+_JACOBI = None
+
+
+def jacobi_available():
+    return os.path.exists(os.path.join(_HERE, "_ref", "libtfluids_ref_jacobi.so"))
+
+
+def _jacobi_lib():
+    global _JACOBI
+    if _JACOBI is None:
+        _JACOBI = ctypes.CDLL(os.path.join(_HERE, "_ref", "libtfluids_ref_jacobi.so"))
+        _JACOBI.tfluids_ref_jacobi.restype = ctypes.c_int
+    return _JACOBI
+
+
 def _path(fast):
     return os.path.join(_HERE, "_ref", "libtfluids_ref_fast.so" if fast else "libtfluids_ref.so")
 
@@ -171,6 +186,23 @@ class RefTfluids:
 
     def flagsToOccupancy(self, flags, occupancy):
         self.call("flagsToOccupancy", flags, occupancy)
+
+    def solveLinearSystemJacobi(self, p, flags, div, is3D, pTol=1e-5, maxIter=1000, verbose=False):
+        """init.lua:693-735. CUDA only in the reference: runs the reference's own kernel and host loop
+        (generic/tfluids.cu:1765-1927) compiled for the host (oracle/ref_jacobi.cc, `make ref_jacobi`)."""
+        assert self._dt == 0, "the reference's Jacobi solver is float only"
+        lib = _jacobi_lib()
+        b, d, h, w = self._dims(flags)
+        pPrev, pDelta = self._tmp(p.shape, p.shape)
+        norm = self._tmp((b,))[0]
+        res = ctypes.c_double(0.0)
+        err = ctypes.create_string_buffer(512)
+        vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+        rc = lib.tfluids_ref_jacobi(vp(p), vp(flags), vp(div), vp(pPrev), vp(pDelta), vp(norm), b, d, h, w,
+                                    int(bool(is3D)), ctypes.c_float(pTol), int(maxIter), ctypes.byref(res), err, 512)
+        if rc != 0:
+            raise RefError(err.value.decode())
+        return float(res.value)
 
     @staticmethod
     def getDx(flags):

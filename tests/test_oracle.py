@@ -266,3 +266,32 @@ def test_divergence_backward_is_the_adjoint(oracle):
     lhs = float((div.astype(np.float64) * g).sum())
     rhs = float((sc["U"].astype(np.float64) * gU).sum())
     assert abs(lhs - rhs) <= 1e-4 * max(abs(lhs), 1.0)
+
+
+# ---- Jacobi pinned to the reference's own CUDA kernel + host loop, compiled for the host ----------------------
+@pytest.mark.parametrize("dims,seed", [((1, 33, 47), 61), ((14, 19, 23), 62), ((1, 64, 64), 63)])
+def test_jacobi_restatement_equals_compiled_reference_kernel(oracle, ref, dims, seed):
+    """generic/tfluids.cu:1765-1927 (kernel_jacobiIteration + the ping-pong loop) built by `make ref_jacobi`
+    through oracle/ref_shim/cuda_host.h vs oracle/tfluids_oracle.c: identical pressure, bit for bit, for fixed
+    iteration counts of both parities (the copy-back branch, :1913-1915) and for early termination on pTol."""
+    import subprocess
+    from oracle import ref as refmod
+    if not refmod.jacobi_available():
+        if not os.path.isdir("/root/reference/torch/tfluids"):
+            pytest.skip("oracle/_ref/libtfluids_ref_jacobi.so not built and /root/reference absent")
+        subprocess.check_call(["make", "-s", "-C", os.path.join(os.path.dirname(HERE), "oracle"), "ref_jacobi"])
+    sc, f, U, div = scenes.pcg_problem(oracle, dims, seed, B=2, empty_cells=True)
+    for iters in (1, 2, 7, 20):
+        pa, pb = np.full_like(sc["p"], 3.0), np.full_like(sc["p"], -1.0)   # the initial guess is ignored (zeroed)
+        ra = oracle.solveLinearSystemJacobi(pa, f, div, sc["is3d"], 0.0, iters)
+        rb = ref.solveLinearSystemJacobi(pb, f, div, sc["is3d"], 0.0, iters)
+        assert np.array_equal(pa, pb), iters
+        assert abs(ra - rb) <= 1e-5 * max(1.0, abs(rb)), (ra, rb)
+    assert np.abs(pa).max() > 0
+    tol = 0.5 * rb
+    pa, pb = np.zeros_like(sc["p"]), np.zeros_like(sc["p"])
+    ra = oracle.solveLinearSystemJacobi(pa, f, div, sc["is3d"], tol, 5000)
+    rb = ref.solveLinearSystemJacobi(pb, f, div, sc["is3d"], tol, 5000)
+    assert np.array_equal(pa, pb) and ra < tol and rb < tol
+    with pytest.raises(Exception):
+        ref.solveLinearSystemJacobi(pb, f, div, sc["is3d"], 0.0, 0)
