@@ -30,8 +30,8 @@ _c = ctypes
 class tfl_sim_params(_c.Structure):
     """include/tfluids_hip.h tfl_sim_params (mconf of lib/simulate.lua)."""
     _fields_ = [("dt", _c.c_float), ("advectionMethod", _c.c_char_p), ("maccormackStrength", _c.c_float),
-                ("buoyancyScale", _c.c_float), ("gravityScale", _c.c_float), ("gravity", _c.c_float * 3),
-                ("vorticityConfinementAmp", _c.c_float), ("simMethod", _c.c_char_p), ("maxIter", _c.c_int32),
+                ("buoyancyScale", _c.c_double), ("gravityScale", _c.c_double), ("gravity", _c.c_float * 3),
+                ("vorticityConfinementAmp", _c.c_double), ("simMethod", _c.c_char_p), ("maxIter", _c.c_int32),
                 ("pcgPrecond", _c.c_char_p), ("outputDiv", _c.c_int32)]
 
 

@@ -28,7 +28,6 @@ struct tfl_model {
   std::vector<tfl_layer> layers;
   // 3-D `default` topology (3->8 k3, 8->8 k3, 8->8 k3, 8->8 k1, 8->1 k1): MFMA path (conv_mfma.hip)
   bool mfma3d = false;
-  bool mfma3d_ws = false;                         // TFL_CONV_PATH=mfma_ws: wave-specialised kernels (conv_mfma_ws.hip)
   float* bfrag[3] = {nullptr, nullptr, nullptr};  // per-lane B fragments of the three k=3 layers
   float* tail_w4 = nullptr;                       // [8][8] (out, in) of the 8->8 k1 layer
   float* tail_w5 = nullptr;                       // [8] of the 8->1 k1 layer
@@ -550,7 +549,6 @@ tfl_model* tfl_model_create(tfl_ctx* c, int is3D, int nlayers, const int32_t* ci
         hipMemcpy(m->tail_w5, weights[4], 8 * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
       return cleanup("uploading tail weights failed");
     m->mfma3d = true;
-    m->mfma3d_ws = force && strcmp(force, "mfma_ws") == 0;   // opt-in: measured slower than conv_mfma.hip (r01)
   }
   const int dflt2[5][3] = {{3, 16, 3}, {16, 16, 3}, {16, 16, 3}, {16, 16, 3}, {16, 1, 1}};
   bool match2 = !m->is3d && nlayers == 5;
@@ -658,13 +656,7 @@ int tfl_model_finish(tfl_ctx* c, tfl_model* m, const tfl_tensor* pDiv, const tfl
   const int B = flags->B, Z = flags->Z, Y = flags->Y, X = flags->X;
   const double* st_in = stats ? stats : m->d_stats;
   hipStream_t st = c->stream;
-  if (m->mfma3d && m->mfma3d_ws) {
-    tfl::conv3_ws_first_fused(st, B, Z, Y, X, pDiv->data, w.div, flags->data, st_in, count, m->bfrag[0],
-                              m->layers[0].b, w.act[0]);
-    tfl::conv3_ws_mid(st, B, Z, Y, X, w.act[0], m->bfrag[1], m->layers[1].b, w.act[1]);
-    tfl::conv3_ws_tail(st, B, Z, Y, X, w.act[1], m->bfrag[2], m->layers[2].b, m->tail_w4, m->layers[3].b,
-                       m->tail_w5, m->layers[4].b, w.pPred);
-  } else if (m->mfma3d) {
+  if (m->mfma3d) {
     // the first MFMA layer builds {pDiv/scale, div/scale, occupancy} while staging its LDS tile
     tfl::conv3_mfma_first_fused(st, B, Z, Y, X, pDiv->data, w.div, flags->data, st_in, count, m->bfrag[0],
                                 m->layers[0].b, w.act[0]);

@@ -494,18 +494,6 @@ static void launch_scalar(hipStream_t st, int method, const AdvArgs& a, int B, c
   }
 }
 
-bool advect_use_lds() {
-  static const int use = [] {
-    // Default: the plain-gather kernels of this file. The LDS-tiled variants (advect_lds.hip, bit-identical
-    // results) are opt-in with TFL_ADVECT_PATH=lds: on MI355X they measured SLOWER at 128^3 (r01: k_vel_bwd
-    // 128-177 us vs 79 us) -- the hardware L1 already serves the gathers, and staging 7 fields per tile plus
-    // the dual LDS/global code path costs more than it saves. Kept as a tested base for further work.
-    const char* e = getenv("TFL_ADVECT_PATH");
-    return (e && strcmp(e, "lds") == 0) ? 1 : 0;
-  }();
-  return use != 0;
-}
-
 void minmax3(hipStream_t st, bool is3d, int B, int Z, int Y, int X, int outside, const float* s, const float* flags,
              float* lo3, float* hi3) {
   const Dom d = make_dom(Z, Y, X);
@@ -525,13 +513,6 @@ void minmax3(hipStream_t st, bool is3d, int B, int Z, int Y, int X, int outside,
 void advect_scalar(hipStream_t st, bool is3d, int method, int B, int Z, int Y, int X, float dt, float strength,
                    int outside, unsigned long long* err, const float* s, const float* U, const float* flags,
                    float* fwd, float* bounds, float* mm, float* dst) {
-  if (method == kMacCormackOurs && advect_use_lds()) {
-    float* lo3 = mm;
-    float* hi3 = mm + (long long)B * Z * Y * X;
-    minmax3(st, is3d, B, Z, Y, X, outside, s, flags, lo3, hi3);
-    advect_scalar_ours_lds(st, is3d, B, Z, Y, X, dt, strength, outside, err, s, U, flags, fwd, bounds, lo3, hi3, dst);
-    return;
-  }
   AdvArgs a; a.d = make_dom(Z, Y, X); a.dt = dt; a.strength = strength; a.outside = outside; a.err = err;
   if (is3d) launch_scalar<true>(st, method, a, B, s, U, flags, fwd, bounds, mm, dst);
   else launch_scalar<false>(st, method, a, B, s, U, flags, fwd, bounds, mm, dst);
@@ -558,10 +539,6 @@ static void launch_vel(hipStream_t st, int method, const AdvArgs& a, int B, cons
 void advect_vel(hipStream_t st, bool is3d, int method, int B, int Z, int Y, int X, float dt, float strength,
                 unsigned long long* err, const float* U, const float* flags, float* fwd, float* dst) {
   if (method == kRK2Ours || method == kRK3Ours) method = kMacCormackOurs;  // tfluids.cc:799-802
-  if (method == kMacCormackOurs && advect_use_lds()) {
-    advect_vel_ours_lds(st, is3d, B, Z, Y, X, dt, strength, err, U, flags, fwd, dst);
-    return;
-  }
   AdvArgs a; a.d = make_dom(Z, Y, X); a.dt = dt; a.strength = strength; a.outside = 0; a.err = err;
   if (is3d) launch_vel<true>(st, method, a, B, U, flags, fwd, dst);
   else launch_vel<false>(st, method, a, B, U, flags, fwd, dst);

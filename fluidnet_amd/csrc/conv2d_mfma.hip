@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256) void k_conv2_mfma(int B, int Y, int X, const f
   float in_scale = 1.0f;
   if (FUSED) {   // lib/modules/variance.lua:44-76 (n-1) + Sqrt
     const double s1 = ci.stats[b * 2], s2 = ci.stats[b * 2 + 1], n = ci.count;
-    in_scale = (float)sqrt((n * s2 - s1 * s1) / (n * (n - 1.0)));
+    in_scale = (float)sqrt(fmax(n * s2 - s1 * s1, 0.0) / (n * (n - 1.0)));
   }
   // ---- stage the halo tile (zero outside the image = the convolution's zero padding) -----------------
   constexpr int CREAL = FUSED ? 3 : CIN4;

@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256, 4) void k_conv3_mfma(Dom d, int tiles_x, int t
   float in_scale = 1.0f;
   if (IN_PLANAR && cin.stats) {  // lib/modules/variance.lua:44-76 (n-1) + Sqrt, as model.hip scale_from_stats
     const double s1 = cin.stats[b * 2], s2 = cin.stats[b * 2 + 1], n = cin.count;
-    in_scale = (float)sqrt((n * s2 - s1 * s1) / (n * (n - 1.0)));
+    in_scale = (float)sqrt(fmax(n * s2 - s1 * s1, 0.0) / (n * (n - 1.0)));
   }
 
 #pragma unroll

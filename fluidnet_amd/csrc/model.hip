@@ -241,10 +241,12 @@ __global__ __launch_bounds__(256) void k_reduce_stats(const double* __restrict__
   if (threadIdx.x == 0) { stats[b * 2] = sh1[0]; stats[b * 2 + 1] = sh2[0]; }
 }
 
-// lib/modules/variance.lua:44-76 (n-1) + Sqrt; the Clamp after it is a no-op (model.lua:106 typo)
+// lib/modules/variance.lua:44-76 (n-1) + Sqrt; the Clamp after it is a no-op (model.lua:106 typo). One-pass form
+// n*s2 - s1^2 in fp64 (the reference: two passes in fp32 THC reductions); the numerator is clamped at 0 because
+// rounding can take it slightly negative for a near-constant U, where the two-pass variance is >= 0.
 __device__ __forceinline__ float scale_from_stats(const double* __restrict__ stats, int b, double n) {
   const double s1 = stats[b * 2], s2 = stats[b * 2 + 1];
-  return (float)sqrt((n * s2 - s1 * s1) / (n * (n - 1.0)));
+  return (float)sqrt(fmax(n * s2 - s1 * s1, 0.0) / (n * (n - 1.0)));
 }
 
 template <bool IS3D>

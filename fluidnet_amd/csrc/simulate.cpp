@@ -146,7 +146,7 @@ int tfl_simulate_step(tfl_ctx* c, const tfl_sim_params* prm, const tfl_sim_state
   rc = tfl_advectVel(c, prm->dt, s->U, s->flags, &vfwd, &vbwd, is3D, method, 1, prm->maccormackStrength, &Uadv);
   if (rc) return rc;
   // U:copy(advected) (init.lua:216-218) is folded into addBuoyancy when buoyancy is on
-  const bool buoyant = s->n_density > 0 && prm->buoyancyScale > 0.0f;
+  const bool buoyant = s->n_density > 0 && prm->buoyancyScale > 0.0;
   if (!buoyant) {
     rc = tfl_copy(c, s->U, &Uadv);
     if (rc) return rc;
@@ -157,21 +157,21 @@ int tfl_simulate_step(tfl_ctx* c, const tfl_sim_params* prm, const tfl_sim_state
   // ---- forces (simulate.lua:204-239) -------------------------------------------------------------------------
   const double dx = tfl_getDx(c, s->flags);
   if (buoyant) {
-    const float sc = (float)(-(dx / 4.0) * (double)prm->buoyancyScale);
+    const float sc = (float)(-(dx / 4.0) * prm->buoyancyScale);
     const float g[3] = {prm->gravity[0] * sc, prm->gravity[1] * sc, prm->gravity[2] * sc};
     rc = tfl_addBuoyancyFrom(c, &Uadv, s->U, s->flags, s->density[0], g, prm->dt, is3D);
     if (rc) return rc;
   }
-  if (prm->gravityScale > 0.0f) {
-    const float sc = (float)((-dx / 4.0) * (double)prm->gravityScale);
+  if (prm->gravityScale > 0.0) {
+    const float sc = (float)((-dx / 4.0) * prm->gravityScale);
     const float g[3] = {prm->gravity[0] * sc, prm->gravity[1] * sc, prm->gravity[2] * sc};
     rc = tfl_addGravity(c, s->U, s->flags, g, prm->dt, is3D, nullptr);
     if (rc) return rc;
   }
-  if (prm->vorticityConfinementAmp > 0.0f) {
+  if (prm->vorticityConfinementAmp > 0.0) {
     tfl_tensor centered = view(ws, (int)z.C), curl = view(ws + z.C * z.N, 3), cnorm = view(ws + (z.C + 3) * z.N, 1),
                force = view(ws + (z.C + 4) * z.N, (int)z.C);
-    rc = tfl_vorticityConfinement(c, s->U, s->flags, (float)(dx * (double)prm->vorticityConfinementAmp), &centered, &curl,
+    rc = tfl_vorticityConfinement(c, s->U, s->flags, (float)(dx * prm->vorticityConfinementAmp), &centered, &curl,
                                   &cnorm, &force, is3D);
     if (rc) return rc;
   }

@@ -41,15 +41,8 @@ void advect_scalar(hipStream_t st, bool is3d, int method, int B, int Z, int Y, i
 void advect_vel(hipStream_t st, bool is3d, int method, int B, int Z, int Y, int X, float dt, float strength,
                 unsigned long long* err, const float* U, const float* flags, float* fwd, float* dst);
 
-// advect_lds.hip: LDS-tiled maccormackOurs (the default method); bit-identical to advect.hip's kernels
-void advect_vel_ours_lds(hipStream_t st, bool is3d, int B, int Z, int Y, int X, float dt, float strength,
-                         unsigned long long* err, const float* U, const float* flags, float* fwd, float* dst);
-void advect_scalar_ours_lds(hipStream_t st, bool is3d, int B, int Z, int Y, int X, float dt, float strength,
-                            int outside, unsigned long long* err, const float* s, const float* U, const float* flags,
-                            float* fwd, float* bounds, const float* lo3, const float* hi3, float* dst);
 void minmax3(hipStream_t st, bool is3d, int B, int Z, int Y, int X, int outside, const float* s, const float* flags,
              float* lo3, float* hi3);
-bool advect_use_lds();  // TFL_ADVECT_PATH=lds selects the LDS-tiled kernels (default: plain gathers, faster in r01)
 
 // stencil.hip
 void set_wall_bcs(hipStream_t st, bool is3d, int B, int Z, int Y, int X, float* U, const float* flags);
@@ -116,15 +109,6 @@ void conv3_mfma_mid(hipStream_t st, int B, int Z, int Y, int X, const float* in_
 void conv3_mfma_tail(hipStream_t st, int B, int Z, int Y, int X, const float* in_cl8, const float* bfrag,
                      const float* bias, const float* w4, const float* b4, const float* w5, const float* b5,
                      float* p_out);
-
-// conv_mfma_ws.hip: the same layers, wave-specialised (4 MFMA waves + 4 load/store waves per persistent block)
-void conv3_ws_first_fused(hipStream_t st, int B, int Z, int Y, int X, const float* pDiv, const float* div,
-                          const float* flags, const double* stats, double count, const float* bfrag, const float* bias,
-                          float* out_cl8);
-void conv3_ws_mid(hipStream_t st, int B, int Z, int Y, int X, const float* in_cl8, const float* bfrag, const float* bias,
-                  float* out_cl8);
-void conv3_ws_tail(hipStream_t st, int B, int Z, int Y, int X, const float* in_cl8, const float* bfrag, const float* bias,
-                   const float* w4, const float* b4, const float* w5, const float* b5, float* p_out);
 
 // backward.hip
 void velocity_divergence_bwd(hipStream_t st, bool is3d, int B, int Z, int Y, int X, const float* flags,

@@ -62,27 +62,63 @@ def createPlumeBCs(batch, densityVal, uScale, rad, zOffset=0, zTotal=None):
     batch["densityBCInvMask"] = dmask if multi else dmask[0]
 
 
-_bc_index_cache = {}   # (bc ptr, mask ptr, numel) -> (bc version, mask version, int32 index tensor, idempotent)
+class _PairCache:
+    """Per-(BC, BCInvMask) cache. Entries are keyed by the IDENTITY of the two tensor objects (held through
+    weak references) and validated by torch's in-place version counters, so neither an address re-used by the
+    caching allocator after the tensors were freed nor an interactive edit (the 2-D demo) can resurrect a
+    stale payload; an entry is dropped -- and `on_evict(payload)` called -- when either tensor dies."""
+
+    def __init__(self, on_evict=None):
+        self._entries = {}
+        self._on_evict = on_evict
+
+    def _drop(self, key):
+        ent = self._entries.pop(key, None)
+        if ent is not None and self._on_evict is not None:
+            self._on_evict(ent[4])
+
+    def get(self, bc, inv):
+        ent = self._entries.get((id(bc), id(inv)))
+        if ent is None:
+            return None
+        if ent[0]() is bc and ent[1]() is inv and ent[2] == bc._version and ent[3] == inv._version:
+            return ent[4]
+        self._drop((id(bc), id(inv)))
+        return None
+
+    def put(self, bc, inv, payload):
+        import weakref
+        key = (id(bc), id(inv))
+        self._drop(key)
+        dead = lambda _ref, key=key: self._drop(key)
+        self._entries[key] = (weakref.ref(bc, dead), weakref.ref(inv, dead), bc._version, inv._version, payload)
+
+    def clear(self):
+        for key in list(self._entries):
+            self._drop(key)
+
+    def __len__(self):
+        return len(self._entries)
+
+
+_bc_index_cache = _PairCache()   # -> (int32 index tensor, idempotent)
 
 
 def _bc_indices(bc, inv):
     """(idx, idempotent): idx = the element indices where the BC pair is not the identity (invMask != 1 or
     bc != 0); idempotent = every such element has invMask == 0 (and |bc| <= 1e6), i.e. x*0 + bc applied twice
-    equals applied once, bit for bit, and commutes with the step's final clamp to +-1e6. Cached per tensor pair and invalidated by torch's in-place version counters (the 2-D demo
-    edits its BCs interactively)."""
-    key = (bc.data_ptr(), inv.data_ptr(), bc.numel())
-    hit = _bc_index_cache.get(key)
-    if hit is not None and hit[0] == bc._version and hit[1] == inv._version:
-        return hit[2], hit[3]
+    equals applied once, bit for bit, and commutes with the step's final clamp to +-1e6. Cached per tensor pair
+    (_PairCache: object identity + in-place version counters; the 2-D demo edits its BCs interactively)."""
+    hit = _bc_index_cache.get(bc, inv)
+    if hit is not None:
+        return hit
     flat_inv = inv.reshape(-1)
     idx = torch.nonzero((flat_inv != 1) | (bc.reshape(-1) != 0)).reshape(-1)
     idem = bool((flat_inv[idx] == 0).all().item())
     if idem and idx.numel():     # "idempotent" also promises |bc| <= 1e6: the final U:clamp(-1e6, 1e6) leaves them alone
         idem = bool((bc.reshape(-1)[idx].abs() <= 1e6).all().item())
     idx = idx.to(torch.int32)
-    if len(_bc_index_cache) > 64:
-        _bc_index_cache.clear()
-    _bc_index_cache[key] = (bc._version, inv._version, idx, idem)
+    _bc_index_cache.put(bc, inv, (idx, idem))
     return idx, idem
 
 
@@ -252,23 +288,27 @@ def simulate(conf, mconf, batch, model, outputDiv=False):
         _apply(U, None, None, clamp=(-1e6, 1e6))
 
 
-_plan_cache = {}   # (bc ptr, mask ptr, numel) -> (bc version, mask version, tfl_bc_plan*)
+def _destroy_plan(payload):
+    lib, ctx, plan = payload
+    lib.tfl_bc_plan_destroy(ctx, plan)
+
+
+_plan_cache = _PairCache(on_evict=_destroy_plan)   # -> (lib, ctx, tfl_bc_plan*)
 
 
 def _bc_plan(lib, ctx, bc, inv):
-    """tfl_bc_plan of a (BC, BCInvMask) pair, cached like _bc_indices (re-created when either tensor is edited)."""
+    """tfl_bc_plan of a (BC, BCInvMask) pair. The plan keeps raw device pointers into the two tensors, so it lives
+    exactly as long as they do: cached by tensor identity (_PairCache), re-created when either tensor is edited in
+    place, destroyed (tfl_bc_plan_destroy) when either is freed or replaced."""
     if bc is None or inv is None:
         return None
-    key = (bc.data_ptr(), inv.data_ptr(), bc.numel())
-    hit = _plan_cache.get(key)
-    if hit is not None and hit[0] == bc._version and hit[1] == inv._version:
+    hit = _plan_cache.get(bc, inv)
+    if hit is not None and hit[1] == ctx:
         return hit[2]
-    if hit is not None:
-        lib.tfl_bc_plan_destroy(ctx, hit[2])
     plan = lib.tfl_bc_plan_create(ctx, tfluids._tt5(bc), tfluids._tt5(inv))
     if not plan:
         raise TfluidsError("tfl_bc_plan_create failed")
-    _plan_cache[key] = (bc._version, inv._version, plan)
+    _plan_cache.put(bc, inv, (lib, ctx, plan))
     return plan
 
 
@@ -333,7 +373,17 @@ class GraphedSimulate:
     def __init__(self, conf, mconf, batch, model=None, warmup=2):
         self.conf, self.mconf, self.batch, self.model = conf, mconf, batch, model
         self.graph = None
+        self._pinned = []     # every buffer the captured launches point into, kept alive with the graph
         self.capture(warmup)
+
+    def _simulate(self):
+        # the captured launches hold raw pointers into the tfluids scratch and the model workspace: run in a
+        # scratch scope of our own (no other caller can grow / replace that buffer) -- see capture()
+        prev, tfluids._scratch_scope = tfluids._scratch_scope, ("graph", id(self))
+        try:
+            simulate(self.conf, self.mconf, self.batch, self.model)
+        finally:
+            tfluids._scratch_scope = prev
 
     def capture(self, warmup=2):
         dev = self.batch["UDiv"].device
@@ -342,15 +392,28 @@ class GraphedSimulate:
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
             for _ in range(max(1, warmup)):     # sizes scratch buffers, builds BC index caches, loads code
-                simulate(self.conf, self.mconf, self.batch, self.model)
+                self._simulate()
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         for k, v in self._state().items():      # warm-up must not advance the simulation
             v.copy_(keep[k])
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
-            simulate(self.conf, self.mconf, self.batch, self.model)
+            self._simulate()
         torch.cuda.synchronize(dev)
+        # Pin what the graph points into. The scratch is ours alone (private scope); the model workspace is shared
+        # with eager callers of the same model, which may REPLACE it by a larger one: holding the reference keeps
+        # the captured pointers valid (the old buffer cannot go back to the allocator), and step() re-captures
+        # when it sees a different workspace object.
+        key = (dev.index, ("graph", id(self)))
+        self._pinned = [tfluids._tmp.get(key)]
+        self._work = self.model._work.get(dev.index) if self.model is not None else None
+        self._pinned.append(self._work)
+        for t in self._state().values():
+            self._pinned.append(t)
+        for k in ("flags", "UBC", "UBCInvMask", "densityBC", "densityBCInvMask", "pBC", "pBCInvMask", "div"):
+            v = self.batch.get(k)
+            self._pinned.extend(v if isinstance(v, (list, tuple)) else [v])
         for k, v in self._state().items():      # neither must the capture pass (it does not execute, but
             v.copy_(keep[k])                    # keep the contract explicit)
         self.graph = g
@@ -367,6 +430,11 @@ class GraphedSimulate:
         return out
 
     def step(self):
+        if self.model is not None and self.model._work.get(self.batch["UDiv"].device.index) is not self._work:
+            self.capture(1)      # an eager forward on a larger grid replaced the model workspace
         self.graph.replay()
+
+    def __del__(self):
+        tfluids._tmp.pop((self.batch["UDiv"].device.index, ("graph", id(self))), None)
 
     __call__ = step

@@ -280,10 +280,10 @@ typedef struct tfl_sim_params {      /* mconf of lib/simulate.lua (defaults of l
   float dt;
   const char* advectionMethod;       /* NULL = "maccormackOurs" */
   float maccormackStrength;
-  float buoyancyScale;               /* 0 = off */
-  float gravityScale;                /* 0 = off */
+  double buoyancyScale;              /* 0 = off. Lua numbers: (dx/4)*scale is formed in double and rounded once, */
+  double gravityScale;               /* 0 = off.  exactly like simulate.lua:204-239 does on its float tensors   */
   float gravity[3];                  /* direction, simulate.lua:204-211 [0, 1, 0] */
-  float vorticityConfinementAmp;     /* 0 = off */
+  double vorticityConfinementAmp;    /* 0 = off */
   const char* simMethod;             /* NULL | "convnet" | "jacobi" | "pcg" */
   int32_t maxIter;                   /* jacobi / pcg; <= 0 -> 100 */
   const char* pcgPrecond;            /* NULL = "ic0" (simulate.lua:283) */

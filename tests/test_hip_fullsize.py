@@ -1,0 +1,64 @@
+"""GPU parity at the sizes BASELINE.json STATES (configs 3, 4, 5: 64^3, 128^3, 256^3), not at oracle-sized stand-ins.
+
+The checker is the reference's own CPU tfluids code (oracle/_ref, parity build: -O2 -ffp-contract=off, OpenMP) driven
+by oracle/simulate_np.py (lib/simulate.lua + lib/model.lua restated in numpy, PyTorch-CPU conv3d for the conv stack);
+the C restatement takes its place only if oracle/_ref did not travel to the box. Each case develops the plume with
+untimed HIP steps first (so the compared steps advect, confine and project a non-trivial flow), copies that state to
+the host, then runs the SAME further steps on both sides.
+
+Tolerance: rel-L2 <= 1e-5 on p, U and density (BASELINE.json north_star).
+"""
+import os
+
+import numpy as np
+import pytest
+
+import scenes
+from oracle import simulate_np as S
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def _checker(request):
+    from oracle import ref as refmod
+    if refmod.available():
+        return refmod.RefTfluids(), "reference"
+    return request.getfixturevalue("oracle"), "port"
+
+
+def _scene(res, config):
+    """fluid_net_3d_sim.lua:62-87 at `res` (buoyancyScale, plumeScale by the res/128 rule). Config 4 = bench.py's scene
+    (voxel obstacle stand-in for the bunny, vorticity confinement on); configs 3 and 5 = no obstacle, no confinement."""
+    import torch
+    import bench
+    dev = torch.device("cuda:0")
+    batch, mconf = bench.build_scene(res, res, None, dev)
+    if config != 4:
+        Z = Y = X = res
+        batch["flags"] = torch.from_numpy(scenes.empty_domain(1, Z, Y, X, True)).to(dev)
+        mconf = dict(mconf, vorticityConfinementAmp=0)
+    return batch, mconf
+
+
+@pytest.mark.parametrize("res,config,preroll,steps", [(64, 3, 12, 3), (128, 4, 12, 2), (256, 5, 8, 2)])
+def test_simulate_parity_at_baseline_size(request, res, config, preroll, steps):
+    import torch
+    from fluidnet_amd import FluidNetModel
+    from fluidnet_amd.simulate import simulate_native
+    ops, kind = _checker(request)
+    batch, mconf = _scene(res, config)
+    model = FluidNetModel.default_3d(seed=1)
+    for _ in range(preroll):
+        simulate_native(None, mconf, batch, model)
+    nb = {k: (v.cpu().numpy().copy() if torch.is_tensor(v) else v) for k, v in batch.items()}
+    assert float(np.abs(nb["UDiv"]).max()) > 0.1 and float(nb["density"].sum()) > 0      # a developed plume
+    for _ in range(steps):
+        simulate_native(None, mconf, batch, model)
+        S.simulate(ops, mconf, nb, model.layers)
+    from fluidnet_amd import tfluids
+    assert tfluids.traceErrors(batch["UDiv"]) == 0
+    for k in ("pDiv", "UDiv", "density"):
+        got = batch[k].cpu().numpy()
+        r = scenes.rel_l2(got, nb[k])
+        assert np.isfinite(got).all() and r <= TOL, (res, kind, k, r)
