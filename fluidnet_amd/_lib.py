@@ -42,6 +42,24 @@ class tfl_sim_state(_c.Structure):
                 ("UBC", _c.c_void_p), ("densityBC", _c.c_void_p * 8), ("model", _c.c_void_p)]
 
 
+class tfl_slab(_c.Structure):
+    """include/tfluids_hip.h tfl_slab."""
+    _fields_ = [("z_total", _c.c_int32), ("z_first", _c.c_int32), ("own_lo", _c.c_int32), ("own_hi", _c.c_int32),
+                ("reach", _c.c_int32), ("overlap", _c.c_int32), ("check_reach", _c.c_int32), ("in_flight", _c.c_int32)]
+
+
+COMM_START = _c.CFUNCTYPE(_c.c_int, _c.c_void_p, _c.c_int, _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_int64,
+                          _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_int64)
+COMM_WAIT = _c.CFUNCTYPE(_c.c_int, _c.c_void_p, _c.c_int)
+COMM_ALLREDUCE = _c.CFUNCTYPE(_c.c_int, _c.c_void_p, _c.c_void_p, _c.c_int64)
+
+
+class tfl_comm(_c.Structure):
+    """include/tfluids_hip.h tfl_comm: the transport callbacks of the z-slab step."""
+    _fields_ = [("user", _c.c_void_p), ("exchange_start", COMM_START), ("exchange_wait", COMM_WAIT),
+                ("allreduce_sum", COMM_ALLREDUCE)]
+
+
 SIGNATURES = {
     "tfl_abi_version": (_c.c_int, []),
     "tfl_create": (_c.c_void_p, [_c.c_int]),
@@ -104,6 +122,16 @@ SIGNATURES = {
     "tfl_applyBCsIndexedMulti": (_c.c_int, [_c.c_void_p, _c.c_int, _c.POINTER(_T), _c.POINTER(_T), _c.POINTER(_T),
                                             _c.POINTER(_c.c_void_p), _c.POINTER(_c.c_int64)]),
     "tfl_applyBCs": (_c.c_int, [_c.c_void_p, _T, _T, _T, _c.c_int, _c.c_float, _c.c_float]),
+    "tfl_set_z_window": (_c.c_int, [_c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.c_int]),
+    "tfl_set_stages": (_c.c_int, [_c.c_void_p, _c.c_int]),
+    "tfl_model_div": (_c.c_void_p, [_c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p]),
+    "tfl_slab_halo": (_c.c_int32, [_c.c_int32]),
+    "tfl_simulate_slab_workspace_floats": (_c.c_int64, [_c.c_void_p, _c.POINTER(tfl_sim_params), _c.POINTER(tfl_sim_state),
+                                                        _c.POINTER(tfl_slab)]),
+    "tfl_simulate_step_slab": (_c.c_int, [_c.c_void_p, _c.POINTER(tfl_sim_params), _c.POINTER(tfl_sim_state),
+                                          _c.POINTER(tfl_slab), _c.POINTER(tfl_comm), _c.c_void_p, _c.c_int64]),
+    "tfl_slab_drain": (_c.c_int, [_c.c_void_p, _c.POINTER(tfl_sim_state), _c.POINTER(tfl_slab), _c.POINTER(tfl_comm),
+                                  _c.c_void_p, _c.c_int64]),
 }
 
 _lib = None

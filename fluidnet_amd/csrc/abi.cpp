@@ -37,19 +37,12 @@ struct tfl_model {
   double* d_stats = nullptr;  // [2 * kMaxBatch]: sum(u), sum(u^2) per sample
 };
 
-struct tfl_ctx {
-  int device = 0;
-  hipStream_t stream = nullptr;
-  std::string err;
-  unsigned long long* d_trace_err = nullptr;  // device word: traces that hit an invariant path
-  double* d_resid = nullptr;                  // Jacobi residual accumulators [kMaxBatch]
-  double* h_resid = nullptr;                  // pinned mirror
-  float dx_override = 0.0f;                   // > 0: use instead of 1/max(X,Y,Z) (z-slab ranks: global dx)
-};
+#include "tfl_ctx.hpp"
 static const int kMaxBatch = 1024;
 
 // ---- per-kernel event profiler (TFL_TIMED in the launchers) ---------------------------------------
 namespace tfl {
+thread_local ZWin g_zwin = {0, 0, 0, 0};
 struct ProfRec { const char* name; hipEvent_t e0, e1; };
 struct Profiler { std::vector<ProfRec> recs; };
 static thread_local Profiler* g_prof = nullptr;
@@ -127,6 +120,15 @@ int check_scalar(tfl_ctx* ctx, const char* op, const char* name, const tfl_tenso
 }
 #define TRY(x) do { int rc_ = (x); if (rc_ != TFL_OK) return rc_; } while (0)
 
+// Operators that honour tfl_set_z_window open one of these before launching: the launchers read the window from the
+// calling thread (tfl_host.hpp make_dom); it is cleared again on the way out so that every other operator -- and every
+// other context used from this thread -- sees the whole array.
+struct WindowScope {
+  explicit WindowScope(const tfl_ctx* c) { tfl::g_zwin = c->zwin; }
+  ~WindowScope() { tfl::g_zwin = tfl::ZWin{0, 0, 0, 0}; }
+};
+int stages_of(const tfl_ctx* c) { return c->stages ? c->stages : 0xff; }
+
 // generic/advect_type.cc:18-37
 int parse_method(const char* m) {
   if (!m) return -1;
@@ -157,15 +159,20 @@ tfl_ctx* tfl_create(int device) {
   if (hipMalloc((void**)&c->d_trace_err, sizeof(unsigned long long)) != hipSuccess ||
       hipMemset(c->d_trace_err, 0, sizeof(unsigned long long)) != hipSuccess ||
       hipMalloc((void**)&c->d_resid, sizeof(double) * kMaxBatch) != hipSuccess ||
-      hipHostMalloc((void**)&c->h_resid, sizeof(double) * kMaxBatch, hipHostMallocDefault) != hipSuccess) {
+      hipHostMalloc((void**)&c->h_resid, sizeof(double) * kMaxBatch, hipHostMallocDefault) != hipSuccess ||
+      hipMalloc((void**)&c->d_reach, sizeof(float)) != hipSuccess ||
+      hipHostMalloc((void**)&c->h_reach, sizeof(float), hipHostMallocDefault) != hipSuccess) {
     tfl_destroy(c);
     return nullptr;
   }
+  c->h_reach[0] = 0.0f;
   return c;
 }
 
 void tfl_destroy(tfl_ctx* c) {
   if (!c) return;
+  if (c->d_reach) (void)hipFree(c->d_reach);
+  if (c->h_reach) (void)hipHostFree(c->h_reach);
   if (c->d_trace_err) (void)hipFree(c->d_trace_err);
   if (c->d_resid) (void)hipFree(c->d_resid);
   if (c->h_resid) (void)hipHostFree(c->h_resid);
@@ -183,6 +190,20 @@ const char* tfl_last_error(const tfl_ctx* c) { return c ? c->err.c_str() : "null
 int tfl_set_dx_override(tfl_ctx* c, float dx) {
   if (!c) return TFL_EINVAL;
   c->dx_override = dx > 0.0f ? dx : 0.0f;
+  return TFL_OK;
+}
+
+int tfl_set_z_window(tfl_ctx* c, int a0, int a1, int b0, int b1) {
+  if (!c) return TFL_EINVAL;
+  if (a0 < 0 || a1 < a0 || b0 < 0 || b1 < b0 || (a1 > a0 && b1 > b0 && b0 < a1))
+    return fail(c, TFL_EINVAL, "set_z_window: [%d,%d) [%d,%d) is not an ordered pair of plane runs", a0, a1, b0, b1);
+  c->zwin = tfl::ZWin{a0, a1, b0, b1};
+  return TFL_OK;
+}
+
+int tfl_set_stages(tfl_ctx* c, int mask) {
+  if (!c || mask < 0) return TFL_EINVAL;
+  c->stages = mask;
   return TFL_OK;
 }
 
@@ -272,9 +293,10 @@ int tfl_advectScalar(tfl_ctx* c, float dt, const tfl_tensor* s, const tfl_tensor
     bounds_p = fwdPos->data;   // two planes: clamp bounds of each cell's forward position
     mm_p = bwdPos->data;       // two planes: 3^dim fluid min / max grid of s
   }
+  WindowScope win(c);
   tfl::advect_scalar(c->stream, is3D != 0, m, flags->B, flags->Z, flags->Y, flags->X, dt, maccormackStrength,
                      sampleOutsideFluid != 0, c->d_trace_err, s->data, U->data, flags->data, fwd_p, bounds_p, mm_p,
-                     sDst->data);
+                     sDst->data, stages_of(c));
   return check_launch(c, "advectScalar");
 }
 
@@ -293,8 +315,9 @@ int tfl_advectVel(tfl_ctx* c, float dt, const tfl_tensor* U, const tfl_tensor* f
     TRY(check_vel(c, "advectVel", "fwd", fwd, flags, is3D));
     fwd_p = fwd->data;
   }
+  WindowScope win(c);
   tfl::advect_vel(c->stream, is3D != 0, m, flags->B, flags->Z, flags->Y, flags->X, dt, maccormackStrength,
-                  c->d_trace_err, U->data, flags->data, fwd_p, UDst->data);
+                  c->d_trace_err, U->data, flags->data, fwd_p, UDst->data, stages_of(c));
   return check_launch(c, "advectVel");
 }
 
@@ -333,8 +356,10 @@ int tfl_vorticityConfinement(tfl_ctx* c, const tfl_tensor* U, const tfl_tensor* 
   if (!curl || !curl->data || curl->C != 3 || !same_dims(curl, flags))
     return fail(c, TFL_EINVAL, "vorticityConfinement: curl must be a 3-channel grid of the flags size");
   TRY(check_scalar(c, "vorticityConfinement", "curlNorm", curlNorm, flags));
+  WindowScope win(c);
+  const int stg = stages_of(c);   // tfl_set_stages: 2 = pass A (curl), 4 = pass B (confinement force)
   tfl::vorticity_confinement(c->stream, is3D != 0, flags->B, flags->Z, flags->Y, flags->X, U->data, flags->data,
-                             strength, curl->data, curlNorm->data);
+                             strength, curl->data, curlNorm->data, ((stg & 2) ? 1 : 0) | ((stg & 4) ? 2 : 0));
   return check_launch(c, "vorticityConfinement");
 }
 
@@ -346,6 +371,7 @@ int tfl_addBuoyancyFrom(tfl_ctx* c, const tfl_tensor* USrc, const tfl_tensor* U,
   TRY(check_scalar(c, "addBuoyancy", "density", density, flags));
   if (!gravity) return fail(c, TFL_EINVAL, "addBuoyancy: gravity is null");
   const float sc = dt / get_dx(c, flags);  // strength = -gravity * (dt / dx), tfluids.cc:1190-1192
+  WindowScope win(c);
   tfl::add_buoyancy(c->stream, is3D != 0, flags->B, flags->Z, flags->Y, flags->X, USrc->data, U->data, flags->data,
                     density->data, -gravity[0] * sc, -gravity[1] * sc, -gravity[2] * sc);
   return check_launch(c, "addBuoyancy");
@@ -364,6 +390,7 @@ int tfl_addGravity(tfl_ctx* c, const tfl_tensor* U, const tfl_tensor* flags, con
   TRY(check_vel(c, "addGravity", "U", U, flags, is3D));
   if (!gravity) return fail(c, TFL_EINVAL, "addGravity: gravity is null");
   const float sc = dt / get_dx(c, flags);  // force = gravity * (dt / dx), tfluids.cc:1265-1267
+  WindowScope win(c);
   tfl::add_gravity(c->stream, is3D != 0, flags->B, flags->Z, flags->Y, flags->X, U->data, flags->data,
                    gravity[0] * sc, gravity[1] * sc, gravity[2] * sc);
   return check_launch(c, "addGravity");
@@ -617,6 +644,11 @@ int model_ws(tfl_ctx* c, const tfl_model* m, const tfl_tensor* flags, float* wor
 }
 }  // namespace
 
+float* tfl_model_div(const tfl_model* m, int B, int Z, int Y, int X, float* workspace) {
+  if (!m || !workspace) return nullptr;
+  return workspace + 4 * tfl::model_stat_blocks(B, Z, Y, X);
+}
+
 int tfl_model_begin(tfl_ctx* c, tfl_model* m, const tfl_tensor* UDiv, const tfl_tensor* flags, const tfl_tensor* UOut,
                     float* workspace, int64_t workspace_floats, int zlo, int zhi, double* stats) {
   TRY(check_flags(c, "model_begin", flags));
@@ -630,8 +662,10 @@ int tfl_model_begin(tfl_ctx* c, tfl_model* m, const tfl_tensor* UDiv, const tfl_
   // SetWallBcs(UDiv) lands in UOut. UOut may alias UDiv: a thread rewrites only the cell it read, and
   // neighbour values are re-derived from the flags, so a neighbour already holding the BC-applied
   // value gives the identical result (the BC is idempotent).
+  WindowScope win(c);
+  const int stg = stages_of(c);   // tfl_set_stages: 2 = wall BCs + divergence + partial sums, 4 = reduce [zlo, zhi)
   tfl::model_pre(c->stream, m->is3d, flags->B, flags->Z, flags->Y, flags->X, UDiv->data, flags->data, UOut->data,
-                 w.div, w.partials, stats ? stats : m->d_stats, zlo, zhi);
+                 w.div, w.partials, stats ? stats : m->d_stats, zlo, zhi, ((stg & 2) ? 1 : 0) | ((stg & 4) ? 2 : 0));
   return check_launch(c, "model_begin");
 }
 
@@ -656,13 +690,20 @@ int tfl_model_finish(tfl_ctx* c, tfl_model* m, const tfl_tensor* pDiv, const tfl
   const int B = flags->B, Z = flags->Z, Y = flags->Y, X = flags->X;
   const double* st_in = stats ? stats : m->d_stats;
   hipStream_t st = c->stream;
+  WindowScope win(c);
+  // tfl_set_stages (z-slab ranks run each layer under its own z-window): 1 = first conv layer, 2 = second, 4 = third
+  // + the two 1x1x1 layers, 8 = velocity update / un-scale / wall BCs. Only the 3-D MFMA path is staged.
+  const int stg = stages_of(c);
+  if (c->stages && !m->mfma3d) return fail(c, TFL_EUNSUPPORTED, "model_finish: stage masks need the 3-D default topology");
   if (m->mfma3d) {
     // the first MFMA layer builds {pDiv/scale, div/scale, occupancy} while staging its LDS tile
-    tfl::conv3_mfma_first_fused(st, B, Z, Y, X, pDiv->data, w.div, flags->data, st_in, count, m->bfrag[0],
-                                m->layers[0].b, w.act[0]);
-    tfl::conv3_mfma_mid(st, B, Z, Y, X, w.act[0], m->bfrag[1], m->layers[1].b, w.act[1]);
-    tfl::conv3_mfma_tail(st, B, Z, Y, X, w.act[1], m->bfrag[2], m->layers[2].b, m->tail_w4, m->layers[3].b,
-                         m->tail_w5, m->layers[4].b, w.pPred);
+    if (stg & 1)
+      tfl::conv3_mfma_first_fused(st, B, Z, Y, X, pDiv->data, w.div, flags->data, st_in, count, m->bfrag[0],
+                                  m->layers[0].b, w.act[0]);
+    if (stg & 2) tfl::conv3_mfma_mid(st, B, Z, Y, X, w.act[0], m->bfrag[1], m->layers[1].b, w.act[1]);
+    if (stg & 4)
+      tfl::conv3_mfma_tail(st, B, Z, Y, X, w.act[1], m->bfrag[2], m->layers[2].b, m->tail_w4, m->layers[3].b,
+                           m->tail_w5, m->layers[4].b, w.pPred);
   } else if (m->mfma2d) {
     tfl::conv2_mfma_first_fused(st, B, Y, X, pDiv->data, w.div, flags->data, st_in, count, m->bfrag2[0],
                                 m->layers[0].b, w.act[0]);
@@ -681,8 +722,9 @@ int tfl_model_finish(tfl_ctx* c, tfl_model* m, const tfl_tensor* pDiv, const tfl
       in = out;
     }
   }
-  tfl::model_project(st, m->is3d, B, Z, Y, X, w.pPred, flags->data, st_in, count, UOut->data, pOut->data,
-                     UBC ? UBC->data : nullptr, UBC ? UBCInvMask->data : nullptr, doClamp, lo, hi);
+  if (stg & 8)
+    tfl::model_project(st, m->is3d, B, Z, Y, X, w.pPred, flags->data, st_in, count, UOut->data, pOut->data,
+                       UBC ? UBC->data : nullptr, UBC ? UBCInvMask->data : nullptr, doClamp, lo, hi);
   return check_launch(c, "model_finish");
 }
 
@@ -691,6 +733,8 @@ int tfl_model_forward(tfl_ctx* c, tfl_model* m, const tfl_tensor* pDiv, const tf
                       int64_t workspace_floats, const tfl_tensor* UBC, const tfl_tensor* UBCInvMask, int doClamp,
                       float lo, float hi) {
   TRY(check_flags(c, "model_forward", flags));
+  if (c->stages || c->zwin.a1 > c->zwin.a0 || c->zwin.b1 > c->zwin.b0)
+    return fail(c, TFL_EINVAL, "model_forward: clear the z-window / stage mask first (use tfl_model_begin / _finish)");
   TRY(tfl_model_begin(c, m, UDiv, flags, UOut, workspace, workspace_floats, 0, flags->Z, nullptr));
   const double count = (double)flags->Z * flags->Y * flags->X * (m->is3d ? 3 : 2);
   return tfl_model_finish(c, m, pDiv, flags, pOut, UOut, workspace, workspace_floats, nullptr, count, UBC, UBCInvMask,
@@ -773,16 +817,17 @@ int tfl_packPlanes(tfl_ctx* c, int n, const tfl_tensor* const* fields, int zlo, 
   const tfl_tensor* f0 = fields[0];
   if (!f0 || zlo < 0 || zhi > f0->Z || zlo >= zhi) return fail(c, TFL_EINVAL, "packPlanes: bad plane range [%d, %d)", zlo, zhi);
   float* ptrs[8];
-  int rows[8];
+  int rows[8], los[8], nps[8];
   for (int i = 0; i < n; i++) {
     const tfl_tensor* f = fields[i];
     if (!f || !f->data || f->Z != f0->Z || f->Y != f0->Y || f->X != f0->X)
       return fail(c, TFL_EINVAL, "packPlanes: field %d does not match the grid of field 0", i);
     ptrs[i] = f->data;
     rows[i] = f->B * f->C;
+    los[i] = zlo; nps[i] = zhi - zlo;
   }
   const long long yx = (long long)f0->Y * f0->X;
-  tfl::pack_planes(c->stream, n, ptrs, rows, yx * f0->Z, yx * (zhi - zlo), yx * zlo, buf, unpack);
+  tfl::pack_planes(c->stream, n, ptrs, rows, los, nps, yx * f0->Z, yx, buf, unpack);
   return check_launch(c, "packPlanes");
 }
 

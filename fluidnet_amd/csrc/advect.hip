@@ -33,11 +33,9 @@ struct AdvArgs {
 #define TFL_CELL_INDEX()                                             \
   const int i = blockIdx.x * blockDim.x + threadIdx.x;               \
   const int j = blockIdx.y * blockDim.y + threadIdx.y;               \
-  const int kz = blockIdx.z;                                         \
-  const int b = kz / a.d.Z;                                          \
-  const int k = kz - b * a.d.Z;                                      \
-  if (i >= a.d.X || j >= a.d.Y) return;                              \
   const Dom& d = a.d;                                                \
+  int b, k; dom_bk(d, b, k);                                         \
+  if (i >= d.X || j >= d.Y) return;                                  \
   const long long cells = (long long)d.sc;                           \
   (void)cells
 
@@ -214,7 +212,7 @@ __global__ __launch_bounds__(256) void k_minmax3(Dom d, int outside, const float
   constexpr int NZ = IS3D ? 3 : 1;
   // {lo, hi} packed per tile cell: one ds_read_b64 fetches both (same LDS cycles as a b32 read)
   __shared__ float2 tile[NZ][6][66];
-  const int b = blockIdx.z / d.Z, k = blockIdx.z - b * d.Z;
+  int b, k; dom_bk(d, b, k);
   const long long cells = d.sc;
   s += b * cells; flags += b * cells; lo3 += b * cells; hi3 += b * cells;
   const int x0 = blockIdx.x * 64 - 1, y0 = blockIdx.y * 4 - 1, z0 = IS3D ? k - 1 : 0;
@@ -257,7 +255,7 @@ __global__ __launch_bounds__(256) void k_minmax3_v4(Dom d, int outside, const fl
                                                     float* __restrict__ hi3) {
   const V4Ctx c = v4_ctx(d);
   const int j = blockIdx.y * blockDim.y + threadIdx.y;
-  const int b = blockIdx.z / d.Z, k = blockIdx.z - b * d.Z;
+  int b, k; dom_bk(d, b, k);
   const bool live = c.i0 < d.X && j < d.Y;
   const long long cells = d.sc;
   s += b * cells; flags += b * cells; lo3 += b * cells; hi3 += b * cells;
@@ -470,26 +468,29 @@ __global__ __launch_bounds__(256) void k_vel_bwd(AdvArgs a, const float* __restr
 
 // ---- host launchers ----------------------------------------------------------------------------
 static inline dim3 cell_grid(const Dom& d, int B, dim3 blk) {
-  return dim3((d.X + blk.x - 1) / blk.x, (d.Y + blk.y - 1) / blk.y, (unsigned)(d.Z * B));
+  return dim3((d.X + blk.x - 1) / blk.x, (d.Y + blk.y - 1) / blk.y, (unsigned)(d.nw * B));
 }
 
 template <bool IS3D>
 static void launch_scalar(hipStream_t st, int method, const AdvArgs& a, int B, const float* s, const float* U,
-                          const float* flags, float* fwd, float* bounds, float* mm, float* dst) {
+                          const float* flags, float* fwd, float* bounds, float* mm, float* dst, int stages) {
   const dim3 blk(64, 4, 1), grd = cell_grid(a.d, B, blk);
+  // stages (tfl_set_stages): 1 = the 3^dim min/max grid, 2 = pass A, 4 = pass B; single-pass methods are "pass A"
+  const bool pm = stages & 1, pa = stages & 2, pb = stages & 4;
+  if (method != kMacCormack && method != kMacCormackOurs && !pa) return;
   switch (method) {
     case kEuler: { TFL_TIMED("k_scalar_fwd", st); k_scalar_fwd<IS3D, kEuler><<<grd, blk, 0, st>>>(a, s, U, flags, dst, nullptr, nullptr, nullptr); break; }
     case kEulerOurs: { TFL_TIMED("k_scalar_fwd", st); k_scalar_fwd<IS3D, kEulerOurs><<<grd, blk, 0, st>>>(a, s, U, flags, dst, nullptr, nullptr, nullptr); break; }
     case kRK2Ours: { TFL_TIMED("k_scalar_fwd", st); k_scalar_fwd<IS3D, kRK2Ours><<<grd, blk, 0, st>>>(a, s, U, flags, dst, nullptr, nullptr, nullptr); break; }
     case kRK3Ours: { TFL_TIMED("k_scalar_fwd", st); k_scalar_fwd<IS3D, kRK3Ours><<<grd, blk, 0, st>>>(a, s, U, flags, dst, nullptr, nullptr, nullptr); break; }
     case kMacCormack:
-      { TFL_TIMED("k_scalar_fwd", st); k_scalar_fwd<IS3D, kMacCormack><<<grd, blk, 0, st>>>(a, s, U, flags, fwd, nullptr, nullptr, nullptr); }
-      { TFL_TIMED("k_scalar_bwd", st); k_scalar_bwd<IS3D, kMacCormack><<<grd, blk, 0, st>>>(a, s, U, flags, fwd, nullptr, dst); }
+      if (pa) { TFL_TIMED("k_scalar_fwd", st); k_scalar_fwd<IS3D, kMacCormack><<<grd, blk, 0, st>>>(a, s, U, flags, fwd, nullptr, nullptr, nullptr); }
+      if (pb) { TFL_TIMED("k_scalar_bwd", st); k_scalar_bwd<IS3D, kMacCormack><<<grd, blk, 0, st>>>(a, s, U, flags, fwd, nullptr, dst); }
       break;
     default:
-      minmax3(st, IS3D, B, a.d.Z, a.d.Y, a.d.X, a.outside, s, flags, mm, mm + (long long)B * a.d.sc);
-      { TFL_TIMED_EXT("k_scalar_fwd", st); TFL_LAUNCH_EXT((k_scalar_fwd<IS3D, kMacCormackOurs>), grd, blk, 0, st, a, s, U, flags, fwd, bounds, (const float*)mm, (const float*)(mm + (long long)B * a.d.sc)); }
-      { TFL_TIMED_EXT("k_scalar_bwd", st); TFL_LAUNCH_EXT((k_scalar_bwd<IS3D, kMacCormackOurs>), grd, blk, 0, st, a, s, U, flags, (const float*)fwd, (const float*)bounds, dst); }
+      if (pm) minmax3(st, IS3D, B, a.d.Z, a.d.Y, a.d.X, a.outside, s, flags, mm, mm + (long long)B * a.d.sc);
+      if (pa) { TFL_TIMED_EXT("k_scalar_fwd", st); TFL_LAUNCH_EXT((k_scalar_fwd<IS3D, kMacCormackOurs>), grd, blk, 0, st, a, s, U, flags, fwd, bounds, (const float*)mm, (const float*)(mm + (long long)B * a.d.sc)); }
+      if (pb) { TFL_TIMED_EXT("k_scalar_bwd", st); TFL_LAUNCH_EXT((k_scalar_bwd<IS3D, kMacCormackOurs>), grd, blk, 0, st, a, s, U, flags, (const float*)fwd, (const float*)bounds, dst); }
       break;
   }
 }
@@ -512,36 +513,38 @@ void minmax3(hipStream_t st, bool is3d, int B, int Z, int Y, int X, int outside,
 
 void advect_scalar(hipStream_t st, bool is3d, int method, int B, int Z, int Y, int X, float dt, float strength,
                    int outside, unsigned long long* err, const float* s, const float* U, const float* flags,
-                   float* fwd, float* bounds, float* mm, float* dst) {
+                   float* fwd, float* bounds, float* mm, float* dst, int stages) {
   AdvArgs a; a.d = make_dom(Z, Y, X); a.dt = dt; a.strength = strength; a.outside = outside; a.err = err;
-  if (is3d) launch_scalar<true>(st, method, a, B, s, U, flags, fwd, bounds, mm, dst);
-  else launch_scalar<false>(st, method, a, B, s, U, flags, fwd, bounds, mm, dst);
+  if (is3d) launch_scalar<true>(st, method, a, B, s, U, flags, fwd, bounds, mm, dst, stages);
+  else launch_scalar<false>(st, method, a, B, s, U, flags, fwd, bounds, mm, dst, stages);
 }
 
 template <bool IS3D>
 static void launch_vel(hipStream_t st, int method, const AdvArgs& a, int B, const float* U, const float* flags,
-                       float* fwd, float* dst) {
+                       float* fwd, float* dst, int stages) {
   const dim3 blk(64, 4, 1), grd = cell_grid(a.d, B, blk);
+  const bool pa = stages & 2, pb = stages & 4;   // as in launch_scalar
+  if (method != kMacCormack && method != kMacCormackOurs && !pa) return;
   switch (method) {
     case kEuler: { TFL_TIMED("k_vel_fwd", st); k_vel_fwd<IS3D, false><<<grd, blk, 0, st>>>(a, U, flags, dst); break; }
     case kEulerOurs: { TFL_TIMED("k_vel_fwd", st); k_vel_fwd<IS3D, true><<<grd, blk, 0, st>>>(a, U, flags, dst); break; }
     case kMacCormack:
-      { TFL_TIMED("k_vel_fwd", st); k_vel_fwd<IS3D, false><<<grd, blk, 0, st>>>(a, U, flags, fwd); }
-      { TFL_TIMED("k_vel_bwd", st); k_vel_bwd<IS3D, false><<<grd, blk, 0, st>>>(a, U, flags, fwd, dst); }
+      if (pa) { TFL_TIMED("k_vel_fwd", st); k_vel_fwd<IS3D, false><<<grd, blk, 0, st>>>(a, U, flags, fwd); }
+      if (pb) { TFL_TIMED("k_vel_bwd", st); k_vel_bwd<IS3D, false><<<grd, blk, 0, st>>>(a, U, flags, fwd, dst); }
       break;
     default:
-      { TFL_TIMED_EXT("k_vel_fwd", st); TFL_LAUNCH_EXT((k_vel_fwd<IS3D, true>), grd, blk, 0, st, a, U, flags, fwd); }
-      { TFL_TIMED_EXT("k_vel_bwd", st); TFL_LAUNCH_EXT((k_vel_bwd<IS3D, true>), grd, blk, 0, st, a, U, flags, fwd, dst); }
+      if (pa) { TFL_TIMED_EXT("k_vel_fwd", st); TFL_LAUNCH_EXT((k_vel_fwd<IS3D, true>), grd, blk, 0, st, a, U, flags, fwd); }
+      if (pb) { TFL_TIMED_EXT("k_vel_bwd", st); TFL_LAUNCH_EXT((k_vel_bwd<IS3D, true>), grd, blk, 0, st, a, U, flags, fwd, dst); }
       break;
   }
 }
 
 void advect_vel(hipStream_t st, bool is3d, int method, int B, int Z, int Y, int X, float dt, float strength,
-                unsigned long long* err, const float* U, const float* flags, float* fwd, float* dst) {
+                unsigned long long* err, const float* U, const float* flags, float* fwd, float* dst, int stages) {
   if (method == kRK2Ours || method == kRK3Ours) method = kMacCormackOurs;  // tfluids.cc:799-802
   AdvArgs a; a.d = make_dom(Z, Y, X); a.dt = dt; a.strength = strength; a.outside = 0; a.err = err;
-  if (is3d) launch_vel<true>(st, method, a, B, U, flags, fwd, dst);
-  else launch_vel<false>(st, method, a, B, U, flags, fwd, dst);
+  if (is3d) launch_vel<true>(st, method, a, B, U, flags, fwd, dst, stages);
+  else launch_vel<false>(st, method, a, B, U, flags, fwd, dst, stages);
 }
 
 }  // namespace tfl

@@ -27,7 +27,7 @@ __global__ __launch_bounds__(256) void k_divergence_bwd(Dom d, const float* __re
                                                         const float* __restrict__ go, float* __restrict__ gU) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int j = blockIdx.y * blockDim.y + threadIdx.y;
-  const int b = blockIdx.z / d.Z, k = blockIdx.z - b * d.Z;
+  int b, k; dom_bk(d, b, k);
   if (i >= d.X || j >= d.Y) return;
   const long long cells = d.sc;
   const int C = IS3D ? 3 : 2;
@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void k_velocity_update_bwd(Dom d, const float*
                                                              const float* __restrict__ go, float* __restrict__ gP) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int j = blockIdx.y * blockDim.y + threadIdx.y;
-  const int b = blockIdx.z / d.Z, k = blockIdx.z - b * d.Z;
+  int b, k; dom_bk(d, b, k);
   if (i >= d.X || j >= d.Y) return;
   const long long cells = d.sc;
   const int C = IS3D ? 3 : 2;
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256) void k_upsample_bwd(int ratio, long long rows,
 #define TFL_BWD_LAUNCH(kern, name, ...)                                             \
   do {                                                                              \
     const Dom d = make_dom(Z, Y, X);                                                \
-    const dim3 blk(64, 4, 1), grd((X + 63) / 64, (Y + 3) / 4, (unsigned)(Z * B));   \
+    const dim3 blk(64, 4, 1), grd((X + 63) / 64, (Y + 3) / 4, (unsigned)(zwin_planes(Z) * B)); \
     TFL_TIMED(name, st);                                                            \
     if (is3d) kern<true><<<grd, blk, 0, st>>>(d, __VA_ARGS__);                      \
     else kern<false><<<grd, blk, 0, st>>>(d, __VA_ARGS__);                          \

@@ -83,7 +83,11 @@ __global__ __launch_bounds__(256, 4) void k_conv3_mfma(Dom d, int tiles_x, int t
   const int ty = t % tiles_y; t /= tiles_y;
   const int tz = t % tiles_z;
   const int b = t / tiles_z;
-  const int x0 = tx * kTX, y0 = ty * kTY, z0 = tz * kTZ;
+  // z-window (tfl_device.hpp Dom): the z-tiles cover the plane run [w0, w0 + n0) and then [w1, w1 + nw - n0)
+  const int tz_a = (d.n0 + kTZ - 1) / kTZ;
+  const int z0 = tz < tz_a ? d.w0 + tz * kTZ : d.w1 + (tz - tz_a) * kTZ;
+  const int z_end = tz < tz_a ? d.w0 + d.n0 : d.w1 + (d.nw - d.n0);
+  const int x0 = tx * kTX, y0 = ty * kTY;
   const long long cells = d.sc;
   in += (long long)b * cells * CIN;
 
@@ -213,7 +217,7 @@ __global__ __launch_bounds__(256, 4) void k_conv3_mfma(Dom d, int tiles_x, int t
 #pragma unroll
     for (int r = 0; r < kTY; r++) {
       const int y = y0 + r;
-      if (x < d.X && y < d.Y && z < d.Z) {
+      if (x < d.X && y < d.Y && z < z_end) {
         const float4 v = make_float4(fmaxf(acc[r][0], 0.0f), fmaxf(acc[r][1], 0.0f), fmaxf(acc[r][2], 0.0f),
                                      fmaxf(acc[r][3], 0.0f));
         *reinterpret_cast<float4*>(out + (long long)TFL_AT(d, x, y, z) * 8 + co0) = v;
@@ -247,7 +251,7 @@ __global__ __launch_bounds__(256, 4) void k_conv3_mfma(Dom d, int tiles_x, int t
       for (int i = 1; i < 4; i++) v = fmaf(w5v[i], fmaxf(e[i], 0.0f), v);
       const float other = __shfl_xor(v, 16, 64);
       const int y = y0 + r;
-      if (co0 == 0 && x < d.X && y < d.Y && z < d.Z) out[TFL_AT(d, x, y, z)] = (v + other) + b5;
+      if (co0 == 0 && x < d.X && y < d.Y && z < z_end) out[TFL_AT(d, x, y, z)] = (v + other) + b5;
     }
   }
   TFL_STAMP(7);
@@ -257,7 +261,8 @@ __global__ __launch_bounds__(256, 4) void k_conv3_mfma(Dom d, int tiles_x, int t
 template <int CIN, bool IN_PLANAR, bool TAIL>
 static void launch_mfma(hipStream_t st, const Dom& d, int B, const float* in, const float* bfrag, const float* bias,
                         float* out, ConvTail tail, ConvIn cin) {
-  const int tx = (d.X + kTX - 1) / kTX, ty = (d.Y + kTY - 1) / kTY, tz = (d.Z + kTZ - 1) / kTZ;
+  const int tx = (d.X + kTX - 1) / kTX, ty = (d.Y + kTY - 1) / kTY;
+  const int tz = (d.n0 + kTZ - 1) / kTZ + (d.nw - d.n0 + kTZ - 1) / kTZ;   // z-tiles of the compute window's two plane runs
   const int n_tiles = tx * ty * tz * B;
   const int grid = ((n_tiles + 7) / 8) * 8;
   const size_t lds_bytes = sizeof(float) * (CIN < 4 ? CIN : 4) * (kTZ + 2) * (kTY + 2) * kLX;

@@ -13,7 +13,7 @@ __global__ __launch_bounds__(256) void k_jacobi(Dom d, const float* __restrict__
                                                 double* __restrict__ resid_sq) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int j = blockIdx.y * blockDim.y + threadIdx.y;
-  const int b = blockIdx.z / d.Z, k = blockIdx.z - b * d.Z;
+  int b, k; dom_bk(d, b, k);
   const long long cells = d.sc;
   double e2 = 0.0;
   if (i < d.X && j < d.Y) {
@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void k_jacobi(Dom d, const float* __restrict__
 void jacobi_iteration(hipStream_t st, bool is3d, int B, int Z, int Y, int X, const float* p_prev, const float* flags,
                       const float* div, float* p, double* resid_sq) {
   const Dom d = make_dom(Z, Y, X);
-  const dim3 blk(64, 4, 1), grd((X + 63) / 64, (Y + 3) / 4, (unsigned)(Z * B));
+  const dim3 blk(64, 4, 1), grd((X + 63) / 64, (Y + 3) / 4, (unsigned)(zwin_planes(Z) * B));
   if (is3d) {
     if (resid_sq) { TFL_TIMED("k_jacobi", st); k_jacobi<true, true><<<grd, blk, 0, st>>>(d, p_prev, flags, div, p, resid_sq); }
     else { TFL_TIMED("k_jacobi", st); k_jacobi<true, false><<<grd, blk, 0, st>>>(d, p_prev, flags, div, p, nullptr); }

@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void k_bcs_div_stats(Dom d, const float* __res
                                                        double* __restrict__ partials) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int j = blockIdx.y * blockDim.y + threadIdx.y;
-  const int b = blockIdx.z / d.Z, k = blockIdx.z - b * d.Z;
+  int b, k; dom_bk(d, b, k);
   const long long cells = d.sc;
   const int C = IS3D ? 3 : 2;
   double s1 = 0.0, s2 = 0.0;
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256) void k_bcs_div_stats(Dom d, const float* __res
   if ((tid & 63) == 0) { part[(tid >> 6) * 2] = s1; part[(tid >> 6) * 2 + 1] = s2; }
   __syncthreads();
   if (tid == 0) {
-    const long long blk = blockIdx.x + (long long)gridDim.x * (blockIdx.y + (long long)gridDim.y * blockIdx.z);
+    const long long blk = blockIdx.x + (long long)gridDim.x * (blockIdx.y + (long long)gridDim.y * ((long long)b * d.Z + k));
     partials[blk * 2] = (part[0] + part[2]) + (part[4] + part[6]);
     partials[blk * 2 + 1] = (part[1] + part[3]) + (part[5] + part[7]);
   }
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256) void k_bcs_div_stats_v4(Dom d, const float* __
                                                           double* __restrict__ partials) {
   const V4Ctx c = v4_ctx(d);
   const int j = blockIdx.y * blockDim.y + threadIdx.y;
-  const int b = blockIdx.z / d.Z, k = blockIdx.z - b * d.Z;
+  int b, k; dom_bk(d, b, k);
   const bool live = c.i0 < d.X && j < d.Y;
   const long long cells = d.sc;
   const int C = IS3D ? 3 : 2;
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(256) void k_bcs_div_stats_v4(Dom d, const float* __
   if ((tid & 63) == 0) { part[(tid >> 6) * 2] = s1; part[(tid >> 6) * 2 + 1] = s2; }
   __syncthreads();
   if (tid == 0) {
-    const long long blk = blockIdx.x + (long long)gridDim.x * (blockIdx.y + (long long)gridDim.y * blockIdx.z);
+    const long long blk = blockIdx.x + (long long)gridDim.x * (blockIdx.y + (long long)gridDim.y * ((long long)b * d.Z + k));
     partials[blk * 2] = (part[0] + part[2]) + (part[4] + part[6]);
     partials[blk * 2 + 1] = (part[1] + part[3]) + (part[5] + part[7]);
   }
@@ -255,7 +255,7 @@ __global__ __launch_bounds__(256) void k_net_input(Dom d, const float* __restric
                                                    double count, float* __restrict__ x3) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int j = blockIdx.y * blockDim.y + threadIdx.y;
-  const int b = blockIdx.z / d.Z, k = blockIdx.z - b * d.Z;
+  int b, k; dom_bk(d, b, k);
   if (i >= d.X || j >= d.Y) return;
   const long long cells = d.sc;
   const float scale = scale_from_stats(stats, b, count);
@@ -279,7 +279,7 @@ __global__ __launch_bounds__(256) void k_project(Dom d, const float* __restrict_
                                                  float* __restrict__ Uio, float* __restrict__ pOut, BcArgs bc) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int j = blockIdx.y * blockDim.y + threadIdx.y;
-  const int b = blockIdx.z / d.Z, k = blockIdx.z - b * d.Z;
+  int b, k; dom_bk(d, b, k);
   if (i >= d.X || j >= d.Y) return;
   const long long cells = d.sc;
   const int C = IS3D ? 3 : 2;
@@ -329,7 +329,7 @@ __global__ __launch_bounds__(256) void k_project_v4(Dom d, const float* __restri
                                                     float* __restrict__ Uio, float* __restrict__ pOut, BcArgs bc) {
   const int i0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
   const int j = blockIdx.y * blockDim.y + threadIdx.y;
-  const int b = blockIdx.z / d.Z, k = blockIdx.z - b * d.Z;
+  int b, k; dom_bk(d, b, k);
   if (i0 >= d.X || j >= d.Y) return;
   const long long cells = d.sc;
   const int C = IS3D ? 3 : 2;
@@ -453,49 +453,53 @@ __global__ __launch_bounds__(256) void k_bc_scan(long long n, const float* __res
   }
 }
 
-// Halo planes of several fields <-> one contiguous message buffer (fluidnet_amd/dist.py): buffer layout
-// [field][b][channel][plane zlo..zhi)[Y][X]. One launch per direction instead of a dozen strided copies.
+// Halo planes of several fields <-> one contiguous message buffer (z-slab decomposition): buffer layout
+// [field][b][channel][that field's planes][Y][X]; every field has its own plane range (the halo depth a phase needs
+// differs per field). One launch per message instead of a dozen strided copies.
 struct PackArgs {
   float* ptr[8];
-  int chans[8];        // B*C "rows" of each field (each row = Z*Y*X floats)
-  long long start[9];  // prefix sums of elements per field in the buffer
+  long long start[9];   // prefix sums of elements per field in the buffer
+  long long per_row[8]; // elements per (b, channel) row of the field in the buffer = its planes * Y * X
+  long long zoff[8];    // element offset of the field's first plane inside a (b, channel) row of the array
   int n;
 };
-__global__ __launch_bounds__(256) void k_pack_planes(PackArgs a, long long zstride, long long plane_elems, long long zlo_off,
-                                                     float* __restrict__ buf, int unpack) {
+__global__ __launch_bounds__(256) void k_pack_planes(PackArgs a, long long zstride, float* __restrict__ buf, int unpack) {
   const long long total = a.start[a.n];
   for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
     int f = 0;
 #pragma unroll
     for (int q = 1; q < 8; q++) if (q < a.n && t >= a.start[q]) f = q;
     const long long r = t - a.start[f];
-    const long long row = r / plane_elems, within = r - row * plane_elems;   // row = b*C + c
-    float* g = a.ptr[f] + row * zstride + zlo_off + within;
+    const long long row = r / a.per_row[f], within = r - row * a.per_row[f];   // row = b*C + c
+    float* g = a.ptr[f] + row * zstride + a.zoff[f] + within;
     if (unpack) *g = buf[t];
     else buf[t] = *g;
   }
 }
 
-#define TFL_GRID3(d, B) dim3(((d).X + 63) / 64, ((d).Y + 3) / 4, (unsigned)((d).Z * (B)))
+#define TFL_GRID3(d, B) dim3(((d).X + 63) / 64, ((d).Y + 3) / 4, (unsigned)((d).nw * (B)))
 
 long long model_stat_blocks(int B, int Z, int Y, int X) {
   return (long long)((X + 63) / 64) * ((Y + 3) / 4) * Z * B;
 }
 
+// stages: bit 0 = k_bcs_div_stats on the current z-window (per-plane partial sums land in absolute slots, so the
+// launch may be split into boundary / interior windows), bit 1 = reduce the partials of planes [zlo, zhi) into stats
 void model_pre(hipStream_t st, bool is3d, int B, int Z, int Y, int X, const float* U, const float* flags, float* Ubc,
-               float* div, double* partials, double* stats, int zlo, int zhi) {
+               float* div, double* partials, double* stats, int zlo, int zhi, int stages) {
   const Dom d = make_dom(Z, Y, X);
   const dim3 blk(64, 4, 1), grd = TFL_GRID3(d, B);
   const Vec4Launch v = vec4_launch(B, Z, Y, X, {U, flags, Ubc, div});
-  long long per_plane = (long long)grd.x * grd.y;   // partials per z-plane (never more than model_stat_blocks assumes)
-  if (v.ok) {
-    per_plane = (long long)v.grd.x * v.grd.y;
-    TFL_TIMED_EXT("k_bcs_div_stats", st);
-    if (is3d) TFL_LAUNCH_EXT((k_bcs_div_stats_v4<true>), v.grd, v.blk, 0, st, d, U, flags, Ubc, div, partials);
-    else TFL_LAUNCH_EXT((k_bcs_div_stats_v4<false>), v.grd, v.blk, 0, st, d, U, flags, Ubc, div, partials);
-  } else if (is3d) { TFL_TIMED("k_bcs_div_stats", st); k_bcs_div_stats<true><<<grd, blk, 0, st>>>(d, U, flags, Ubc, div, partials); }
-  else { TFL_TIMED("k_bcs_div_stats", st); k_bcs_div_stats<false><<<grd, blk, 0, st>>>(d, U, flags, Ubc, div, partials); }
-  { TFL_TIMED_EXT("k_reduce_stats", st); TFL_LAUNCH_EXT(k_reduce_stats, B, 256, 0, st, (const double*)partials, per_plane * Z, per_plane * zlo, per_plane * (zhi - zlo), stats); }
+  const long long per_plane = v.ok ? (long long)v.grd.x * v.grd.y : (long long)grd.x * grd.y;   // <= model_stat_blocks / (Z*B)
+  if (stages & 1) {
+    if (v.ok) {
+      TFL_TIMED_EXT("k_bcs_div_stats", st);
+      if (is3d) TFL_LAUNCH_EXT((k_bcs_div_stats_v4<true>), v.grd, v.blk, 0, st, d, U, flags, Ubc, div, partials);
+      else TFL_LAUNCH_EXT((k_bcs_div_stats_v4<false>), v.grd, v.blk, 0, st, d, U, flags, Ubc, div, partials);
+    } else if (is3d) { TFL_TIMED("k_bcs_div_stats", st); k_bcs_div_stats<true><<<grd, blk, 0, st>>>(d, U, flags, Ubc, div, partials); }
+    else { TFL_TIMED("k_bcs_div_stats", st); k_bcs_div_stats<false><<<grd, blk, 0, st>>>(d, U, flags, Ubc, div, partials); }
+  }
+  if (stages & 2) { TFL_TIMED_EXT("k_reduce_stats", st); TFL_LAUNCH_EXT(k_reduce_stats, B, 256, 0, st, (const double*)partials, per_plane * Z, per_plane * zlo, per_plane * (zhi - zlo), stats); }
 }
 
 void model_net_input(hipStream_t st, bool is3d, int B, int Z, int Y, int X, const float* pDiv, const float* div,
@@ -515,7 +519,7 @@ void model_project(hipStream_t st, bool is3d, int B, int Z, int Y, int X, const 
   const uintptr_t al = (uintptr_t)pPred | (uintptr_t)flags | (uintptr_t)Uio | (uintptr_t)pOut | (uintptr_t)UBC |
                        (uintptr_t)UInvMask;
   if (X % 4 == 0 && (al & 15) == 0 && !getenv("TFL_NO_VEC4")) {
-    const dim3 vb(32, 8, 1), vg((X / 4 + 31) / 32, (Y + 7) / 8, (unsigned)(Z * B));
+    const dim3 vb(32, 8, 1), vg((X / 4 + 31) / 32, (Y + 7) / 8, (unsigned)(d.nw * B));
     TFL_TIMED_EXT("k_project", st);
     if (is3d) TFL_LAUNCH_EXT((k_project_v4<true>), vg, vb, 0, st, d, pPred, flags, stats, count, Uio, pOut, bc);
     else TFL_LAUNCH_EXT((k_project_v4<false>), vg, vb, 0, st, d, pPred, flags, stats, count, Uio, pOut, bc);
@@ -532,20 +536,22 @@ void apply_bcs(hipStream_t st, long long n, float* x, const float* bcv, const fl
   { TFL_TIMED("k_apply_bcs", st); k_apply_bcs<<<(int)(blocks > 0 ? blocks : 1), 256, 0, st>>>(n, x, bcv, inv, do_clamp, lo, hi); }
 }
 
-void pack_planes(hipStream_t st, int n, float* const* ptrs, const int* rows, long long zstride, long long plane_elems,
-                 long long zlo_off, float* buf, int unpack) {
+long long pack_planes(hipStream_t st, int n, float* const* ptrs, const int* rows, const int* zlo, const int* nplanes,
+                      long long zstride, long long yx, float* buf, int unpack) {
   PackArgs a;
   a.n = n;
   a.start[0] = 0;
   for (int i = 0; i < 8; i++) {
     a.ptr[i] = i < n ? ptrs[i] : nullptr;
-    a.chans[i] = i < n ? rows[i] : 0;
-    a.start[i + 1] = a.start[i] + (i < n ? (long long)rows[i] * plane_elems : 0);
+    a.per_row[i] = i < n ? (long long)nplanes[i] * yx : 1;
+    a.zoff[i] = i < n ? (long long)zlo[i] * yx : 0;
+    a.start[i + 1] = a.start[i] + (i < n ? (long long)rows[i] * a.per_row[i] : 0);
   }
   long long blocks = (a.start[n] + 255) / 256;
   if (blocks > 2048) blocks = 2048;
-  if (blocks < 1) return;
-  { TFL_TIMED(unpack ? "k_unpack_planes" : "k_pack_planes", st); k_pack_planes<<<(int)blocks, 256, 0, st>>>(a, zstride, plane_elems, zlo_off, buf, unpack); }
+  if (blocks < 1) return 0;
+  { TFL_TIMED(unpack ? "k_unpack_planes" : "k_pack_planes", st); k_pack_planes<<<(int)blocks, 256, 0, st>>>(a, zstride, buf, unpack); }
+  return a.start[n];
 }
 
 void bc_scan(hipStream_t st, long long n, const float* bcv, const float* inv, int* counters, int* idx) {

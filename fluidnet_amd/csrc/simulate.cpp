@@ -3,10 +3,12 @@
 // own except the one-time BC scan): the same sequence, temp layout and launch-saving rules as
 // fluidnet_amd/simulate.py, which it is tested against bit for bit (tests/test_hip_simulate.py).
 #include "../../include/tfluids_hip.h"
+#include "tfl_ctx.hpp"
 #include "tfl_host.hpp"
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstring>
 #include <string>
 
@@ -219,6 +221,359 @@ int tfl_simulate_step(tfl_ctx* c, const tfl_sim_params* prm, const tfl_sim_state
   rc = set_const_vals(c, s, s->U, true, Unchanged{false, false, true});
   if (rc) return rc;
   return tfl_applyBCs(c, s->U, nullptr, nullptr, 1, -1e6f, 1e6f);
+}
+
+
+// ================================================================================================================
+// z-slab decomposition: tfl_simulate_step on one slab of a grid cut along z (include/tfluids_hip.h, "z-slab" section).
+//
+// Valid-plane bookkeeping. Write (a, b) for "planes [own_lo - a, own_hi + b)", clipped to the local array (at a domain
+// end the slab simply ends there). With R = back-trace reach in cells (max|u_z|*dt < R) the per-phase z-dependencies are
+//   3^3 min/max grid of rho  +-1      pass A of MacCormack  rho +-(R+1) incl. the min/max lookup, U +-(R+1)
+//   pass B                   fwd +-R, U +-(R+1)             buoyancy  rho -1         curl  U -1..+2
+//   confinement              curl -1, |curl| -2..+1         divergence  U_bc +1 (flags +2)
+//   3 conv layers            +-1 each                       velocity update  p -1
+// so, working backwards from "owned planes exact":
+//   project (0,0) <- conv3 (1,0) <- conv2 (2,1) <- conv1 (3,2) <- {p, div} (4,3)            [T1: p, T3: div]
+//   confine (0,0) <- curl (2,1) <- buoyancy/gravity (3,3) <- {U_adv (3,3), rho (4,3)}        [T2]
+//   pass B (0,0) <- pass A (R,R) <- min/max (2R,2R) <- {rho (2R+1,2R+1), U (R+1,R+1)}        [T0: U; rho is still
+//                                                                                             valid from T2]
+// Local array ends are treated by the kernels as the domain's border shell (zeros); with halo >= max(4, 2R+1) no window
+// above ever evaluates a tap there except through data that is exchanged instead (div, p).
+namespace {
+
+struct Halo { const tfl_tensor* t; int below, above; };   // planes of `t` refreshed below / above the owned range
+
+struct Msg {                 // one neighbour exchange: buffers inside the workspace
+  int tag, n;
+  Halo f[3];
+  float *send_lo, *recv_lo, *send_hi, *recv_hi;
+  long long n_send_lo, n_recv_lo, n_send_hi, n_recv_hi;   // floats
+};
+
+struct SlabGeom {
+  int Zl, o0, o1, R, H;
+  bool lower, upper;
+  long long yx, N;           // Y*X, B*Zl*Y*X
+  int B;
+};
+
+int slab_geom(tfl_ctx* c, const tfl_sim_state* s, const tfl_slab* sl, SlabGeom* g) {
+  if (!s || !s->flags || !s->U || !sl) return TFL_EINVAL;
+  g->Zl = s->flags->Z; g->B = s->flags->B;
+  g->o0 = sl->own_lo; g->o1 = sl->own_hi;
+  g->R = sl->reach > 0 ? sl->reach : 1;
+  g->H = tfl_slab_halo(g->R);
+  g->yx = (long long)s->flags->Y * s->flags->X;
+  g->N = (long long)g->B * g->Zl * g->yx;
+  g->lower = sl->z_first + sl->own_lo > 0;
+  g->upper = sl->z_first + sl->own_hi < sl->z_total;
+  const bool ok = g->o0 >= 0 && g->o1 > g->o0 && g->o1 <= g->Zl && sl->z_first >= 0 && sl->z_first + g->Zl <= sl->z_total &&
+                  (g->lower ? g->o0 >= g->H : (g->o0 == 0 && sl->z_first == 0)) &&
+                  (g->upper ? g->Zl - g->o1 >= g->H : (g->o1 == g->Zl && sl->z_first + g->Zl == sl->z_total)) &&
+                  ((!g->lower && !g->upper) || g->o1 - g->o0 >= g->H);
+  if (!ok) { if (c) c->err = "simulate_step_slab: inconsistent slab description (halo too thin, or owned range thinner than the halo)"; return TFL_EINVAL; }
+  return TFL_OK;
+}
+
+long long msg_floats(const SlabGeom& g, const Halo* f, int n, bool to_lower, bool send) {
+  // to lower neighbour: I send what it needs ABOVE its range (my lowest `above` planes) and receive my `below` planes
+  long long planes = 0;
+  for (int i = 0; i < n; i++) {
+    const int cnt = (to_lower == send) ? f[i].above : f[i].below;
+    planes += (long long)f[i].t->B * f[i].t->C * cnt;
+  }
+  return planes * g.yx;
+}
+
+// carve the four buffers of each message out of `base`; returns the floats used
+long long msg_layout(const SlabGeom& g, Msg* m, int count, float* base) {
+  long long off = 0;
+  auto take = [&](long long n) { float* p = base ? base + off : nullptr; off += (n + 3) & ~3ll; return p; };
+  for (int i = 0; i < count; i++) {
+    Msg& q = m[i];
+    q.n_send_lo = g.lower ? msg_floats(g, q.f, q.n, true, true) : 0;
+    q.n_recv_lo = g.lower ? msg_floats(g, q.f, q.n, true, false) : 0;
+    q.n_send_hi = g.upper ? msg_floats(g, q.f, q.n, false, true) : 0;
+    q.n_recv_hi = g.upper ? msg_floats(g, q.f, q.n, false, false) : 0;
+    q.send_lo = take(q.n_send_lo); q.recv_lo = take(q.n_recv_lo); q.send_hi = take(q.n_send_hi); q.recv_hi = take(q.n_recv_hi);
+  }
+  return off;
+}
+
+void pack_side(tfl_ctx* c, const SlabGeom& g, const Msg& q, bool lower, bool unpack) {
+  float* ptrs[3]; int rows[3], zlo[3], np[3];
+  for (int i = 0; i < q.n; i++) {
+    const Halo& h = q.f[i];
+    ptrs[i] = h.t->data; rows[i] = h.t->B * h.t->C;
+    if (!unpack) { np[i] = lower ? h.above : h.below; zlo[i] = lower ? g.o0 : g.o1 - h.below; }     // owned planes out
+    else { np[i] = lower ? h.below : h.above; zlo[i] = lower ? g.o0 - h.below : g.o1; }              // halo planes in
+  }
+  float* buf = unpack ? (lower ? q.recv_lo : q.recv_hi) : (lower ? q.send_lo : q.send_hi);
+  tfl::pack_planes(c->stream, q.n, ptrs, rows, zlo, np, g.yx * g.Zl, g.yx, buf, unpack ? 1 : 0);
+}
+
+int msg_start(tfl_ctx* c, const SlabGeom& g, const tfl_comm* comm, const Msg& q) {
+  if (!g.lower && !g.upper) return TFL_OK;
+  if (g.lower) pack_side(c, g, q, true, false);
+  if (g.upper) pack_side(c, g, q, false, false);
+  if (comm->exchange_start(comm->user, q.tag, q.send_lo, q.n_send_lo, q.recv_lo, q.n_recv_lo, q.send_hi, q.n_send_hi,
+                           q.recv_hi, q.n_recv_hi) != 0) { c->err = "simulate_step_slab: comm callback failed (exchange_start)"; return TFL_EINVAL; }
+  return TFL_OK;
+}
+int msg_finish(tfl_ctx* c, const SlabGeom& g, const tfl_comm* comm, const Msg& q) {
+  if (!g.lower && !g.upper) return TFL_OK;
+  if (comm->exchange_wait(comm->user, q.tag) != 0) { c->err = "simulate_step_slab: comm callback failed (exchange_wait)"; return TFL_EINVAL; }
+  if (g.lower) pack_side(c, g, q, true, true);
+  if (g.upper) pack_side(c, g, q, false, true);
+  return TFL_OK;
+}
+
+// the four messages of a step; `div` / `Uadv` may be null tensors when only the layout of T0 / T1 is wanted
+void slab_messages(const SlabGeom& g, const tfl_sim_state* s, const tfl_tensor* Uadv, const tfl_tensor* div, Msg m[4]) {
+  const int rr = 2 * g.R + 1;
+  m[0].tag = 0; m[0].n = 1; m[0].f[0] = Halo{s->U, g.R + 1, g.R + 1};
+  m[1].tag = 1; m[1].n = 1; m[1].f[0] = Halo{s->p, 4, 3};
+  m[2].tag = 2; m[2].n = s->n_density > 0 ? 2 : 1; m[2].f[0] = Halo{Uadv, 3, 3};
+  if (s->n_density > 0) m[2].f[1] = Halo{s->density[0], rr > 4 ? rr : 4, rr > 3 ? rr : 3};
+  m[3].tag = 3; m[3].n = 1; m[3].f[0] = Halo{div, 4, 3};
+}
+
+struct SlabWs { float* msg; double* stats; float* compute; long long compute_floats; };
+
+// workspace = [message buffers][stats: 2*B doubles][compute region]
+long long slab_ws(const SlabGeom& g, const tfl_sim_state* s, float* ws, SlabWs* out) {
+  tfl_tensor u3 = *s->U, s1 = *s->flags;
+  Msg m[4];
+  slab_messages(g, s, &u3, &s1, m);
+  long long off = msg_layout(g, m, 4, nullptr);
+  off = (off + 3) & ~3ll;
+  const long long stats_off = off;
+  off += 4ll * g.B;                                   // 2*B doubles
+  off = (off + 3) & ~3ll;
+  long long model = s->model ? tfl_model_workspace_floats(s->model, g.B, g.Zl, s->flags->Y, s->flags->X) : 0;
+  const long long comp = std::max<long long>(13 * g.N, model) + 4;
+  if (out) { out->msg = ws; out->stats = ws ? (double*)(ws + stats_off) : nullptr; out->compute = ws ? ws + off : nullptr; out->compute_floats = comp; }
+  return off + comp;
+}
+
+struct Win { int a, b; };
+Win ext(const SlabGeom& g, int below, int above) {
+  Win w; w.a = g.o0 - below < 0 ? 0 : g.o0 - below; w.b = g.o1 + above > g.Zl ? g.Zl : g.o1 + above; return w;
+}
+int set_win(tfl_ctx* c, Win w) { return tfl_set_z_window(c, w.a, w.b, 0, 0); }
+#define WIN(call) do { int wrc_ = (call); if (wrc_) return wrc_; } while (0)
+
+// boundary strips of the owned range (k planes next to each existing neighbour) and what is left between them
+struct Split { int a0, a1, b0, b1, i0, i1; bool has_strips, has_interior; };
+Split split_owned(const SlabGeom& g, int k) {
+  Split sp;
+  sp.a0 = g.o0; sp.a1 = g.lower ? std::min(g.o0 + k, g.o1) : g.o0;
+  sp.b1 = g.o1; sp.b0 = g.upper ? std::max(g.o1 - k, sp.a1) : g.o1;
+  sp.i0 = sp.a1; sp.i1 = sp.b0;
+  sp.has_strips = sp.a1 > sp.a0 || sp.b1 > sp.b0;
+  sp.has_interior = sp.i1 > sp.i0;
+  return sp;
+}
+
+struct StageGuard {          // whatever happens, leave the context with no window / stage mask / dx override
+  tfl_ctx* c;
+  explicit StageGuard(tfl_ctx* ctx) : c(ctx) {}
+  ~StageGuard() { (void)tfl_set_z_window(c, 0, 0, 0, 0); (void)tfl_set_stages(c, 0); (void)tfl_set_dx_override(c, 0.0f); }
+};
+
+}  // namespace
+
+int32_t tfl_slab_halo(int32_t reach) {
+  const int r = reach > 0 ? reach : 1;
+  return 2 * r + 1 > 4 ? 2 * r + 1 : 4;
+}
+
+int64_t tfl_simulate_slab_workspace_floats(tfl_ctx* c, const tfl_sim_params* prm, const tfl_sim_state* s, const tfl_slab* sl) {
+  (void)prm;
+  SlabGeom g;
+  if (slab_geom(c, s, sl, &g) != TFL_OK) return 0;
+  return slab_ws(g, s, nullptr, nullptr);
+}
+
+int tfl_slab_drain(tfl_ctx* c, const tfl_sim_state* s, tfl_slab* sl, const tfl_comm* comm, float* ws, int64_t ws_floats) {
+  if (!c || !s || !sl || !comm || !ws) return TFL_EINVAL;
+  SlabGeom g;
+  int rc = slab_geom(c, s, sl, &g);
+  if (rc) return rc;
+  if (ws_floats < slab_ws(g, s, nullptr, nullptr)) return TFL_EINVAL;
+  Msg m[4];
+  tfl_tensor u3 = *s->U, s1 = *s->flags;
+  slab_messages(g, s, &u3, &s1, m);
+  msg_layout(g, m, 4, ws);
+  for (int t = 0; t < 2; t++)
+    if (sl->in_flight & (1 << t)) { rc = msg_finish(c, g, comm, m[t]); if (rc) return rc; sl->in_flight &= ~(1 << t); }
+  return TFL_OK;
+}
+
+int tfl_simulate_step_slab(tfl_ctx* c, const tfl_sim_params* prm, const tfl_sim_state* s, tfl_slab* sl, const tfl_comm* comm,
+                           float* ws, int64_t ws_floats) {
+  if (!c || !prm || !s || !s->p || !s->U || !s->flags || !sl) return TFL_EINVAL;
+  auto bad = [&](const char* m) { c->err = std::string("simulate_step_slab: ") + m; return TFL_EUNSUPPORTED; };
+  SlabGeom g;
+  int rc = slab_geom(c, s, sl, &g);
+  if (rc) return rc;
+  const bool multi = g.lower || g.upper;
+  if (multi && (!comm || !comm->exchange_start || !comm->exchange_wait || !comm->allreduce_sum)) return TFL_EINVAL;
+  const Sizes z = sizes_of(s);
+  if (!z.is3d) return bad("2-D grids have no z to cut (run replicas)");
+  const char* method = (prm->advectionMethod && prm->advectionMethod[0]) ? prm->advectionMethod : "maccormackOurs";
+  if (std::strcmp(method, "maccormackOurs") != 0) return bad("only advectionMethod maccormackOurs");
+  if (method_of(prm) != "convnet" || !s->model) return bad("only the ConvNet projection");
+  if (s->n_density < 0 || s->n_density > 1) return bad("at most one density channel");
+  if (!ws || ((uintptr_t)ws & 15) != 0 || ws_floats < slab_ws(g, s, nullptr, nullptr)) { c->err = "simulate_step_slab: workspace too small or misaligned"; return TFL_EINVAL; }
+  SlabWs W;
+  slab_ws(g, s, ws, &W);
+  StageGuard guard(c);
+  const int is3D = 1;
+  const long long N = g.N;
+  float* cw = W.compute;
+  auto view = [&](float* base, int C) { tfl_tensor t = *s->flags; t.data = base; t.C = C; return t; };
+  // compute region: scalar temps [fwd N][fwdPos 3N][bwdPos 3N] | velocity temps [vfwd 3N][Uadv 3N]; the vorticity temps
+  // and the model workspace re-use the region once the advection is done (Uadv lives until addBuoyancy)
+  tfl_tensor fwd = view(cw, 1), fwdPos = view(cw + N, 3), bwdPos = view(cw + 4 * N, 3);
+  tfl_tensor vfwd = view(cw + 7 * N, 3), Uadv = view(cw + 10 * N, 3);
+  tfl_tensor curl = view(cw, 3), cnorm = view(cw + 3 * N, 1);
+  tfl_tensor div = view(tfl_model_div(s->model, g.B, g.Zl, s->flags->Y, s->flags->X, cw), 1);
+  Msg m[4];
+  slab_messages(g, s, &Uadv, &div, m);
+  msg_layout(g, m, 4, W.msg);
+
+  // ---- reach check of the PREVIOUS step's velocity (no host sync: the word was copied back behind that step) ---------
+  if (sl->check_reach) {
+    if (c->h_reach[0] * prm->dt >= (float)g.R) {
+      char buf[160];
+      snprintf(buf, sizeof(buf), "simulate_step_slab: max|u_z|*dt = %.3f cells reached the slab's back-trace reach %d", c->h_reach[0] * prm->dt, g.R);
+      c->err = buf; c->h_reach[0] = 0.0f;
+      return TFL_EINVAL;
+    }
+  }
+  if (sl->in_flight & 1) { rc = msg_finish(c, g, comm, m[0]); if (rc) return rc; sl->in_flight &= ~1; }     // U halos
+  if (sl->check_reach) {
+    for (int b = 0; b < g.B; b++)                                                                            // u_z of every batch item
+      tfl::absmax(c->stream, (long long)g.Zl * g.yx, s->U->data + (3ll * b + 2) * g.Zl * g.yx, c->d_reach, b == 0);
+    (void)hipMemcpyAsync(c->h_reach, c->d_reach, sizeof(float), hipMemcpyDeviceToHost, c->stream);
+  }
+  (void)tfl_set_dx_override(c, (float)(1.0 / (double)std::max(std::max(s->flags->X, s->flags->Y), sl->z_total)));
+  const bool buoyant = s->n_density > 0 && prm->buoyancyScale > 0.0;
+  const tfl_tensor* rho = s->n_density > 0 ? s->density[0] : nullptr;
+
+  // ---- advection -------------------------------------------------------------------------------------------------
+  auto adv_scalar = [&]() { return tfl_advectScalar(c, prm->dt, rho, s->U, s->flags, &fwd, &fwd, is3D, method, &fwdPos, &bwdPos, 1, 0,
+                                                    prm->maccormackStrength, rho); };
+  auto adv_vel = [&]() { return tfl_advectVel(c, prm->dt, s->U, s->flags, &vfwd, &vfwd, is3D, method, 1, prm->maccormackStrength, &Uadv); };
+  if (rho) {
+    (void)tfl_set_stages(c, 1); WIN(set_win(c, ext(g, 2 * g.R, 2 * g.R)));
+    rc = adv_scalar(); if (rc) return rc;
+  }
+  (void)tfl_set_stages(c, 2); WIN(set_win(c, ext(g, g.R, g.R)));
+  if (rho) { rc = adv_scalar(); if (rc) return rc; }
+  rc = adv_vel(); if (rc) return rc;
+  (void)tfl_set_stages(c, 4);
+  const int strip = 4 > 2 * g.R + 1 ? 4 : 2 * g.R + 1;        // deepest plane count message T2 sends
+  const Split spB = split_owned(g, strip);
+  const bool ovl = sl->overlap && multi;
+  if (ovl && spB.has_strips && spB.has_interior) {
+    WIN(tfl_set_z_window(c, spB.a0, spB.a1, spB.b0, spB.b1));
+    if (rho) { rc = adv_scalar(); if (rc) return rc; }
+    rc = adv_vel(); if (rc) return rc;
+    rc = msg_start(c, g, comm, m[2]); if (rc) return rc;
+    WIN(tfl_set_z_window(c, spB.i0, spB.i1, 0, 0));
+    if (rho) { rc = adv_scalar(); if (rc) return rc; }
+    rc = adv_vel(); if (rc) return rc;
+  } else {
+    WIN(set_win(c, ext(g, 0, 0)));
+    if (rho) { rc = adv_scalar(); if (rc) return rc; }
+    rc = adv_vel(); if (rc) return rc;
+    rc = msg_start(c, g, comm, m[2]); if (rc) return rc;
+  }
+  rc = msg_finish(c, g, comm, m[2]); if (rc) return rc;
+  (void)tfl_set_stages(c, 0); (void)tfl_set_z_window(c, 0, 0, 0, 0);
+  if (!buoyant) { rc = tfl_copy(c, s->U, &Uadv); if (rc) return rc; }
+  rc = set_const_vals(c, s, buoyant ? &Uadv : s->U, true, Unchanged{false, false, false});
+  if (rc) return rc;
+
+  // ---- forces --------------------------------------------------------------------------------------------------------
+  const double dx = tfl_getDx(c, s->flags);
+  WIN(set_win(c, ext(g, 3, 3)));
+  if (buoyant) {
+    const float sc = (float)(-(dx / 4.0) * prm->buoyancyScale);
+    const float gv[3] = {prm->gravity[0] * sc, prm->gravity[1] * sc, prm->gravity[2] * sc};
+    rc = tfl_addBuoyancyFrom(c, &Uadv, s->U, s->flags, rho, gv, prm->dt, is3D); if (rc) return rc;
+  }
+  if (prm->gravityScale > 0.0) {
+    const float sc = (float)((-dx / 4.0) * prm->gravityScale);
+    const float gv[3] = {prm->gravity[0] * sc, prm->gravity[1] * sc, prm->gravity[2] * sc};
+    rc = tfl_addGravity(c, s->U, s->flags, gv, prm->dt, is3D, nullptr); if (rc) return rc;
+  }
+  if (prm->vorticityConfinementAmp > 0.0) {
+    const float strength = (float)(dx * prm->vorticityConfinementAmp);
+    (void)tfl_set_stages(c, 2); WIN(set_win(c, ext(g, 2, 1)));
+    rc = tfl_vorticityConfinement(c, s->U, s->flags, strength, &curl, &curl, &cnorm, &curl, is3D); if (rc) return rc;
+    (void)tfl_set_stages(c, 4); WIN(set_win(c, ext(g, 0, 0)));
+    rc = tfl_vorticityConfinement(c, s->U, s->flags, strength, &curl, &curl, &cnorm, &curl, is3D); if (rc) return rc;
+  }
+  (void)tfl_set_stages(c, 0); (void)tfl_set_z_window(c, 0, 0, 0, 0);
+  if (prm->outputDiv) return TFL_OK;
+  rc = set_const_vals(c, s, s->U, true, Unchanged{true, false, true});
+  if (rc) return rc;
+
+  // ---- projection ----------------------------------------------------------------------------------------------------
+  const long long mws = ws_floats - (cw - ws);
+  (void)tfl_set_stages(c, 2);
+  const Split spD = split_owned(g, 4);
+  if (ovl && spD.has_strips && spD.has_interior) {
+    WIN(tfl_set_z_window(c, spD.a0, spD.a1, spD.b0, spD.b1));
+    rc = tfl_model_begin(c, s->model, s->U, s->flags, s->U, cw, mws, g.o0, g.o1, W.stats); if (rc) return rc;
+    rc = msg_start(c, g, comm, m[3]); if (rc) return rc;
+    WIN(tfl_set_z_window(c, spD.i0, spD.i1, 0, 0));
+    rc = tfl_model_begin(c, s->model, s->U, s->flags, s->U, cw, mws, g.o0, g.o1, W.stats); if (rc) return rc;
+  } else {
+    WIN(set_win(c, ext(g, 0, 0)));
+    rc = tfl_model_begin(c, s->model, s->U, s->flags, s->U, cw, mws, g.o0, g.o1, W.stats); if (rc) return rc;
+    rc = msg_start(c, g, comm, m[3]); if (rc) return rc;
+  }
+  (void)tfl_set_stages(c, 4);
+  rc = tfl_model_begin(c, s->model, s->U, s->flags, s->U, cw, mws, g.o0, g.o1, W.stats); if (rc) return rc;
+  if (multi && comm->allreduce_sum(comm->user, W.stats, 2ll * g.B) != 0) { c->err = "simulate_step_slab: comm callback failed (allreduce_sum)"; return TFL_EINVAL; }
+  if (sl->in_flight & 2) { rc = msg_finish(c, g, comm, m[1]); if (rc) return rc; sl->in_flight &= ~2; }     // p halos
+  const double count = 3.0 * (double)sl->z_total * (double)g.yx;
+  const bool late_ubc = s->UBC && s->UBC->sparse && s->UBC->idem;
+  const tfl_tensor* ubc = (s->UBC && !late_ubc) ? &s->UBC->bc : nullptr;
+  const tfl_tensor* umask = (s->UBC && !late_ubc) ? &s->UBC->inv : nullptr;
+  auto finish = [&]() { return tfl_model_finish(c, s->model, s->p, s->flags, s->p, s->U, cw, mws, W.stats, count, ubc, umask, 1, -1e6f, 1e6f); };
+  (void)tfl_set_stages(c, 1);
+  const Win w1 = ext(g, 3, 2);
+  if (ovl && g.o1 - 1 > g.o0 + 1) {
+    // interior of conv 1 needs only owned planes of div / p: it runs while the div halos travel
+    WIN(tfl_set_z_window(c, g.lower ? g.o0 + 1 : w1.a, g.upper ? g.o1 - 1 : w1.b, 0, 0));
+    rc = finish(); if (rc) return rc;
+    rc = msg_finish(c, g, comm, m[3]); if (rc) return rc;
+    WIN(tfl_set_z_window(c, g.lower ? w1.a : 0, g.lower ? g.o0 + 1 : 0, g.upper ? g.o1 - 1 : 0, g.upper ? w1.b : 0));
+    rc = finish(); if (rc) return rc;
+  } else {
+    rc = msg_finish(c, g, comm, m[3]); if (rc) return rc;
+    WIN(set_win(c, w1));
+    rc = finish(); if (rc) return rc;
+  }
+  (void)tfl_set_stages(c, 2); WIN(set_win(c, ext(g, 2, 1))); rc = finish(); if (rc) return rc;
+  (void)tfl_set_stages(c, 4); WIN(set_win(c, ext(g, 1, 0))); rc = finish(); if (rc) return rc;
+  (void)tfl_set_stages(c, 8); WIN(set_win(c, ext(g, 0, 0))); rc = finish(); if (rc) return rc;
+  (void)tfl_set_stages(c, 0); (void)tfl_set_z_window(c, 0, 0, 0, 0);
+  rc = set_const_vals(c, s, s->U, late_ubc, Unchanged{false, false, true});
+  if (rc) return rc;
+  // the next step's U and p halos leave now; they are consumed at its start / before its first conv layer
+  if (multi) {
+    rc = msg_start(c, g, comm, m[0]); if (rc) return rc;
+    rc = msg_start(c, g, comm, m[1]); if (rc) return rc;
+    sl->in_flight |= 3;
+  }
+  return TFL_OK;
 }
 
 }  // extern "C"

@@ -15,9 +15,7 @@ namespace tfl {
 #define TFL_STENCIL_INDEX()                                          \
   const int i = blockIdx.x * blockDim.x + threadIdx.x;               \
   const int j = blockIdx.y * blockDim.y + threadIdx.y;               \
-  const int kz = blockIdx.z;                                         \
-  const int b = kz / d.Z;                                            \
-  const int k = kz - b * d.Z;                                        \
+  int b, k; dom_bk(d, b, k);                                         \
   if (i >= d.X || j >= d.Y) return;                                  \
   const long long cells = (long long)d.sc;                           \
   const int C = IS3D ? 3 : 2;                                        \
@@ -119,7 +117,7 @@ __global__ __launch_bounds__(256) void k_add_buoyancy_v4(Dom d, const float* __r
   // written, which folds the `U:copy(advected)` that precedes it in simulate() into this pass.
   const int i0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
   const int j = blockIdx.y * blockDim.y + threadIdx.y;
-  const int b = blockIdx.z / d.Z, k = blockIdx.z - b * d.Z;
+  int b, k; dom_bk(d, b, k);
   if (i0 >= d.X || j >= d.Y) return;
   const bool inner = !(j < 1 || j > d.Y - 2 || (IS3D && (k < 1 || k > d.Z - 2)));
   if (!inner && Usrc == U) return;
@@ -196,8 +194,25 @@ __global__ __launch_bounds__(256) void k_flags_to_occupancy(long long n, const f
   }
 }
 
+// *out = max(*out, max_i |x[i]|): the z-slab reach check (max |u_z| * dt bounds how many planes a back-trace crosses).
+// Non-negative floats order like their bit patterns, so the maximum is one integer atomic per block.
+__global__ __launch_bounds__(256) void k_absmax(long long n, const float* __restrict__ x, float* __restrict__ out) {
+  float m = 0.0f;
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x)
+    m = fmaxf(m, fabsf(x[t]));
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_down(m, off, 64));
+  if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned int*>(out), __float_as_uint(m));
+}
+
+void absmax(hipStream_t st, long long n, const float* x, float* out, bool reset) {
+  if (reset) (void)hipMemsetAsync(out, 0, sizeof(float), st);
+  const int blocks = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
+  { TFL_TIMED("k_absmax", st); k_absmax<<<blocks > 0 ? blocks : 1, 256, 0, st>>>(n, x, out); }
+}
+
 static inline dim3 cgrid(const Dom& d, int B, dim3 blk) {
-  return dim3((d.X + blk.x - 1) / blk.x, (d.Y + blk.y - 1) / blk.y, (unsigned)(d.Z * B));
+  return dim3((d.X + blk.x - 1) / blk.x, (d.Y + blk.y - 1) / blk.y, (unsigned)(d.nw * B));
 }
 #define TFL_LAUNCH(kern, ...)                                        \
   do {                                                               \
@@ -225,7 +240,7 @@ void add_buoyancy(hipStream_t st, bool is3d, int B, int Z, int Y, int X, const f
                    !getenv("TFL_NO_VEC4");
   if (vec) {
     const Dom d = make_dom(Z, Y, X);
-    const dim3 blk(32, 8, 1), grd((X / 4 + 31) / 32, (Y + 7) / 8, (unsigned)(Z * B));
+    const dim3 blk(32, 8, 1), grd((X / 4 + 31) / 32, (Y + 7) / 8, (unsigned)(d.nw * B));
     TFL_TIMED_EXT("k_add_buoyancy", st);
     if (is3d) TFL_LAUNCH_EXT((k_add_buoyancy_v4<true>), grd, blk, 0, st, d, Usrc, U, flags, density, sx, sy, sz);
     else TFL_LAUNCH_EXT((k_add_buoyancy_v4<false>), grd, blk, 0, st, d, Usrc, U, flags, density, sx, sy, sz);

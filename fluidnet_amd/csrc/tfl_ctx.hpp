@@ -1,0 +1,22 @@
+// tfl_ctx.hpp -- the context object behind the opaque tfl_ctx* of include/tfluids_hip.h (private to the library:
+// abi.cpp owns it, simulate.cpp reads the stream and the z-slab reach-check words).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <string>
+
+#include "tfl_host.hpp"
+
+struct tfl_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  unsigned long long* d_trace_err = nullptr;  // device word: traces that hit an invariant path
+  double* d_resid = nullptr;                  // Jacobi residual accumulators [kMaxBatch]
+  double* h_resid = nullptr;                  // pinned mirror
+  float dx_override = 0.0f;                   // > 0: use instead of 1/max(X,Y,Z) (z-slab ranks: global dx)
+  tfl::ZWin zwin = {0, 0, 0, 0};              // tfl_set_z_window: planes the next operators compute (all zero = all)
+  int stages = 0;                             // tfl_set_stages: which passes of a multi-pass operator run (0 = all)
+  float* d_reach = nullptr;                   // z-slab reach check: max|u_z| of the current step (device word)
+  float* h_reach = nullptr;                   // pinned mirror, read by the NEXT tfl_simulate_step_slab call
+};

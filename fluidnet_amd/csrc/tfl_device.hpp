@@ -32,10 +32,18 @@ struct Dom {
   int X, Y, Z;
   int sy, sz, sc;  // element strides of y, z and channel
   int one;         // always 1, but opaque to the compiler (see TFL_P1)
+  // Compute window: a launch covers the z-planes [w0, w0 + n0) and then [w1, w1 + (nw - n0)) of the array (nw planes
+  // per batch item in all; default = all Z planes). Addressing always uses the full Z: a z-slab rank computes each
+  // phase only on the planes whose inputs are valid (tfl_set_z_window, csrc/simulate.cpp), in at most two runs
+  // (the two boundary strips of an interior/boundary split go out as ONE launch).
+  int w0, n0, w1, nw;
 };
 
-__host__ __device__ inline Dom make_dom(int Z, int Y, int X) {
-  Dom d; d.X = X; d.Y = Y; d.Z = Z; d.sy = X; d.sz = X * Y; d.sc = X * Y * Z; d.one = 1; return d;
+// (batch item, z-plane) of a block: blockIdx.z enumerates the window's planes, batch item by batch item
+__device__ __forceinline__ void dom_bk(const Dom& d, int& b, int& k) {
+  b = (int)blockIdx.z / d.nw;
+  const int r = (int)blockIdx.z - b * d.nw;
+  k = r < d.n0 ? d.w0 + r : d.w1 + (r - d.n0);
 }
 
 #define TFL_AT(d, i, j, k) ((i) + (j) * (d).sy + (k) * (d).sz)

@@ -3,7 +3,29 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 
+#include "tfl_device.hpp"
+
 namespace tfl {
+
+// The z-window of the calling thread's current operator (set by abi.cpp from tfl_set_z_window, cleared after the
+// launch): planes [a0, a1) and [b0, b1) in array indices; all zero = the whole array.
+struct ZWin { int a0, a1, b0, b1; };
+extern thread_local ZWin g_zwin;
+
+inline Dom make_dom(int Z, int Y, int X) {
+  Dom d; d.X = X; d.Y = Y; d.Z = Z; d.sy = X; d.sz = X * Y; d.sc = X * Y * Z; d.one = 1;
+  d.w0 = 0; d.n0 = Z; d.w1 = 0; d.nw = Z;
+  const ZWin w = g_zwin;
+  if (w.a1 > w.a0 || w.b1 > w.b0) {
+    auto clip = [Z](int v) { return v < 0 ? 0 : (v > Z ? Z : v); };
+    const int a0 = clip(w.a0), a1 = clip(w.a1) > a0 ? clip(w.a1) : a0;
+    const int b0 = clip(w.b0), b1 = clip(w.b1) > b0 ? clip(w.b1) : b0;
+    d.w0 = a0; d.n0 = a1 - a0; d.w1 = b0; d.nw = d.n0 + (b1 - b0);
+  }
+  return d;
+}
+// number of planes a launch over a Z-deep array covers under the current window (grid.z = this * B)
+inline int zwin_planes(int Z) { return make_dom(Z, 1, 1).nw; }
 
 // Built-in per-kernel timing (the reference only has host timers around the projection,
 // lib/simulate.lua:254-260,306-318). When a profile is active on this thread every kernel launch is
@@ -37,9 +59,9 @@ struct KernelTimer {
 // advect.hip
 void advect_scalar(hipStream_t st, bool is3d, int method, int B, int Z, int Y, int X, float dt, float strength,
                    int outside, unsigned long long* err, const float* s, const float* U, const float* flags,
-                   float* fwd, float* bounds, float* mm, float* dst);
+                   float* fwd, float* bounds, float* mm, float* dst, int stages = 7);
 void advect_vel(hipStream_t st, bool is3d, int method, int B, int Z, int Y, int X, float dt, float strength,
-                unsigned long long* err, const float* U, const float* flags, float* fwd, float* dst);
+                unsigned long long* err, const float* U, const float* flags, float* fwd, float* dst, int stages = 7);
 
 void minmax3(hipStream_t st, bool is3d, int B, int Z, int Y, int X, int outside, const float* s, const float* flags,
              float* lo3, float* hi3);
@@ -56,10 +78,13 @@ void add_gravity(hipStream_t st, bool is3d, int B, int Z, int Y, int X, float* U
                  float fy, float fz);
 void empty_domain(hipStream_t st, bool is3d, int bnd, int B, int Z, int Y, int X, float* flags);
 void flags_to_occupancy(hipStream_t st, long long numel, const float* flags, float* occ);
+void absmax(hipStream_t st, long long n, const float* x, float* out, bool reset);   // *out = max(*out, max |x|)
 
 // vorticity.hip
+// stages: bit 0 = pass A (U -> curl, |curl|), bit 1 = pass B (curl, |curl|, flags, U -> U); a z-slab rank runs the two
+// passes under different z-windows
 void vorticity_confinement(hipStream_t st, bool is3d, int B, int Z, int Y, int X, float* U, const float* flags,
-                           float strength, float* curl, float* curl_norm);
+                           float strength, float* curl, float* curl_norm, int stages = 3);
 
 // jacobi.hip
 void jacobi_iteration(hipStream_t st, bool is3d, int B, int Z, int Y, int X, const float* p_prev, const float* flags,
@@ -77,7 +102,7 @@ int normalize_pressure_mean(hipStream_t st, bool is3d, int B, int Z, int Y, int 
 // model.hip
 long long model_stat_blocks(int B, int Z, int Y, int X);
 void model_pre(hipStream_t st, bool is3d, int B, int Z, int Y, int X, const float* U, const float* flags, float* Ubc,
-               float* div, double* partials, double* stats, int zlo, int zhi);
+               float* div, double* partials, double* stats, int zlo, int zhi, int stages = 3);
 void model_net_input(hipStream_t st, bool is3d, int B, int Z, int Y, int X, const float* pDiv, const float* div,
                      const float* flags, const double* stats, double count, float* x3);
 void model_project(hipStream_t st, bool is3d, int B, int Z, int Y, int X, const float* pPred, const float* flags,
@@ -91,8 +116,10 @@ void apply_bcs_indexed_multi(hipStream_t st, int count, const long long* n, cons
                              const float* const* bcv, const float* const* inv);
 void apply_bcs_indexed(hipStream_t st, long long n, const int* idx, float* x, const float* bcv, const float* inv);
 
-void pack_planes(hipStream_t st, int n, float* const* ptrs, const int* rows, long long zstride, long long plane_elems,
-                 long long zlo_off, float* buf, int unpack);
+// planes [zlo[i], zlo[i] + nplanes[i]) of field i (rows[i] = B*C rows of zstride floats each) <-> buf; returns the
+// number of floats moved
+long long pack_planes(hipStream_t st, int n, float* const* ptrs, const int* rows, const int* zlo, const int* nplanes,
+                      long long zstride, long long yx, float* buf, int unpack);
 
 // conv.hip
 bool conv_direct(hipStream_t st, bool is3d, int B, int Z, int Y, int X, int cin, int cout, int ksz, bool relu,

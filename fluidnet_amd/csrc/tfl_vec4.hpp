@@ -17,6 +17,7 @@
 #include <initializer_list>
 
 #include "tfl_device.hpp"
+#include "tfl_host.hpp"
 
 namespace tfl {
 
@@ -85,7 +86,7 @@ inline Vec4Launch vec4_launch(int B, int Z, int Y, int X, std::initializer_list<
   if (disabled || X % 4 != 0 || (al & 15) != 0) return l;
   const int nx = X / 4, bx = nx <= 8 ? 8 : (nx <= 16 ? 16 : 32), by = 256 / bx;
   l.blk = dim3(bx, by, 1);
-  l.grd = dim3((nx + bx - 1) / bx, (Y + by - 1) / by, (unsigned)(Z * B));
+  l.grd = dim3((nx + bx - 1) / bx, (Y + by - 1) / by, (unsigned)(zwin_planes(Z) * B));
   l.ok = true;
   return l;
 }

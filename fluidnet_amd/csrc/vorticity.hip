@@ -28,7 +28,7 @@ __global__ __launch_bounds__(256) void k_curl(Dom d, const float* __restrict__ U
                                               float* __restrict__ cnorm) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int j = blockIdx.y * blockDim.y + threadIdx.y;
-  const int b = blockIdx.z / d.Z, k = blockIdx.z - b * d.Z;
+  int b, k; dom_bk(d, b, k);
   if (i >= d.X || j >= d.Y) return;
   const long long cells = d.sc;
   U += b * cells * (IS3D ? 3 : 2); curl += b * cells * 3; cnorm += b * cells;
@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void k_confine(Dom d, float* __restrict__ U, c
                                                  float strength) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int j = blockIdx.y * blockDim.y + threadIdx.y;
-  const int b = blockIdx.z / d.Z, k = blockIdx.z - b * d.Z;
+  int b, k; dom_bk(d, b, k);
   if (i >= d.X || j >= d.Y) return;
   if (on_border<IS3D>(d, i, j, k)) return;
   const long long cells = d.sc;
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void k_curl_v4(Dom d, const float* __restrict_
                                                  float* __restrict__ cnorm) {
   const V4Ctx c = v4_ctx(d);
   const int j = blockIdx.y * blockDim.y + threadIdx.y;
-  const int b = blockIdx.z / d.Z, k = blockIdx.z - b * d.Z;
+  int b, k; dom_bk(d, b, k);
   const bool live = c.i0 < d.X && j < d.Y;
   const long long cells = d.sc;
   U += b * cells * (IS3D ? 3 : 2); curl += b * cells * 3; cnorm += b * cells;
@@ -195,7 +195,7 @@ __global__ __launch_bounds__(256) void k_confine_v4(Dom d, float* __restrict__ U
                                                     float strength) {
   const V4Ctx c = v4_ctx(d);
   const int j = blockIdx.y * blockDim.y + threadIdx.y;
-  const int b = blockIdx.z / d.Z, k = blockIdx.z - b * d.Z;
+  int b, k; dom_bk(d, b, k);
   const bool live = c.i0 < d.X && j < d.Y;
   const long long cells = d.sc;
   const int C = IS3D ? 3 : 2;
@@ -278,26 +278,27 @@ __global__ __launch_bounds__(256) void k_confine_v4(Dom d, float* __restrict__ U
 }
 
 void vorticity_confinement(hipStream_t st, bool is3d, int B, int Z, int Y, int X, float* U, const float* flags,
-                           float strength, float* curl, float* curl_norm) {
+                           float strength, float* curl, float* curl_norm, int stages) {
   const Dom d = make_dom(Z, Y, X);
-  const dim3 blk(64, 4, 1), grd((X + 63) / 64, (Y + 3) / 4, (unsigned)(Z * B));
+  const dim3 blk(64, 4, 1), grd((X + 63) / 64, (Y + 3) / 4, (unsigned)(d.nw * B));
   const Vec4Launch v = vec4_launch(B, Z, Y, X, {U, flags, curl, curl_norm});
+  const bool pa = stages & 1, pb = stages & 2;
   if (v.ok) {
     if (is3d) {
-      { TFL_TIMED_EXT("k_curl", st); TFL_LAUNCH_EXT((k_curl_v4<true>), v.grd, v.blk, 0, st, d, (const float*)U, curl, curl_norm); }
-      { TFL_TIMED_EXT("k_confine", st); TFL_LAUNCH_EXT((k_confine_v4<true>), v.grd, v.blk, 0, st, d, U, flags, (const float*)curl, (const float*)curl_norm, strength); }
+      if (pa) { TFL_TIMED_EXT("k_curl", st); TFL_LAUNCH_EXT((k_curl_v4<true>), v.grd, v.blk, 0, st, d, (const float*)U, curl, curl_norm); }
+      if (pb) { TFL_TIMED_EXT("k_confine", st); TFL_LAUNCH_EXT((k_confine_v4<true>), v.grd, v.blk, 0, st, d, U, flags, (const float*)curl, (const float*)curl_norm, strength); }
     } else {
-      { TFL_TIMED("k_curl", st); k_curl_v4<false><<<v.grd, v.blk, 0, st>>>(d, U, curl, curl_norm); }
-      { TFL_TIMED("k_confine", st); k_confine_v4<false><<<v.grd, v.blk, 0, st>>>(d, U, flags, curl, curl_norm, strength); }
+      if (pa) { TFL_TIMED("k_curl", st); k_curl_v4<false><<<v.grd, v.blk, 0, st>>>(d, U, curl, curl_norm); }
+      if (pb) { TFL_TIMED("k_confine", st); k_confine_v4<false><<<v.grd, v.blk, 0, st>>>(d, U, flags, curl, curl_norm, strength); }
     }
     return;
   }
   if (is3d) {
-    { TFL_TIMED("k_curl", st); k_curl<true><<<grd, blk, 0, st>>>(d, U, curl, curl_norm); }
-    { TFL_TIMED("k_confine", st); k_confine<true><<<grd, blk, 0, st>>>(d, U, flags, curl, curl_norm, strength); }
+    if (pa) { TFL_TIMED("k_curl", st); k_curl<true><<<grd, blk, 0, st>>>(d, U, curl, curl_norm); }
+    if (pb) { TFL_TIMED("k_confine", st); k_confine<true><<<grd, blk, 0, st>>>(d, U, flags, curl, curl_norm, strength); }
   } else {
-    { TFL_TIMED("k_curl", st); k_curl<false><<<grd, blk, 0, st>>>(d, U, curl, curl_norm); }
-    { TFL_TIMED("k_confine", st); k_confine<false><<<grd, blk, 0, st>>>(d, U, flags, curl, curl_norm, strength); }
+    if (pa) { TFL_TIMED("k_curl", st); k_curl<false><<<grd, blk, 0, st>>>(d, U, curl, curl_norm); }
+    if (pb) { TFL_TIMED("k_confine", st); k_confine<false><<<grd, blk, 0, st>>>(d, U, flags, curl, curl_norm, strength); }
   }
 }
 

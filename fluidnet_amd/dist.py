@@ -1,46 +1,47 @@
-"""z-slab decomposition of simulate() across the GPUs of one node (BASELINE config 5).
+"""z-slab decomposition of simulate() across the GPUs of one node (BASELINE config 5; 128^3 strong scaling).
 
 The reference is single-GPU (no communication layer); this is new work defined by
-BASELINE.json. One process per GPU (torch.distributed, backend "nccl" = RCCL over xGMI). The grid is
-cut along z -- the slowest spatial dimension, so a slab and every halo plane are contiguous in HBM --
-and rank r owns planes [z0, z1). It stores [z0 - h, z1 + h) (clipped to the domain), runs the
-UNMODIFIED single-GPU kernels on that extended array, and refreshes the h halo planes from its two
-z-neighbours at two points of the step. xGMI is point-to-point: a slab only ever talks to ranks r-1
-and r+1, each over its own link, so the exchange is two grouped send/recv pairs -- no ring, no
-all-to-all -- plus ONE 2-double all-reduce per step for the ConvNet's global std(U) normaliser
-(lib/model.lua:93-117).
+BASELINE.json. One process per GPU (torch.distributed, backend "nccl" = RCCL over xGMI). The grid is cut along z --
+the slowest spatial dimension, so a slab and every halo plane are contiguous in HBM -- and rank r owns planes
+[z0, z1), storing `halo` = max(4, 2R+1) more planes next to each neighbour (R = back-trace reach in cells, 1 unless
+the flow moves more than a cell per step).
 
-Why the unmodified kernels give the exact single-GPU answer on the owned planes: every operator reads a
-bounded z-neighbourhood, so errors that enter at the artificial ends of the extended array (treated by
-the kernels as the domain's border shell) travel inward by a bounded number of planes per phase:
-  advection (MacCormack, two passes): 2*Rt + 3 planes, Rt = ceil(max|u_z|*dt) the back-trace reach
-  buoyancy 1, vorticity confinement 3 (+1 border plane), ConvNet projection 5 (div 1 + three 3^3 convs
-  3 + pressure gradient 1)
-With h = 10: exchange {U, density} -> advect (<= 7 planes for Rt <= 2) -> exchange {U, density, p} ->
-forces + projection (9 planes) keeps [z0, z1) exact. `check_reach=True` verifies Rt on the device.
-Message size per neighbour and direction: planes * X * Y * 4 B * channels (128^2: 64 KiB per plane and
-channel; 10 planes x 5 channels = 3.1 MiB), far above the latency-bound regime, sent as one buffer.
+The step itself is native: tfl_simulate_step_slab (fluidnet_amd/csrc/simulate.cpp) runs every phase of simulate() under
+the narrowest z-window that keeps the owned planes exact (a few redundant planes per phase instead of a fixed wide
+halo), packs the halo messages, and calls back into THIS module only to move them:
+    U (R+1 planes) and p (4 / 3 planes)      leave at the end of a step, are consumed by the next one
+    advected U (3) + density (max(4, 2R+1))  after MacCormack pass B, overlapped with the interior of pass B
+    divergence (4 / 3)                        overlapped with the interior of the first conv layer
+plus one 2-double all-reduce for the ConvNet's global std(U) normaliser (lib/model.lua:93-117). xGMI is point-to-point:
+a slab only ever talks to ranks r-1 and r+1, each over its own link, so every exchange is one grouped send/recv pair
+per neighbour -- no ring, no all-to-all.
 """
-import math
+import ctypes
+import threading
 
 import torch
 
-from . import tfluids
-from .simulate import _f32, _gravity, _sparse_bc, setConstVals
+from . import _lib, tfluids
+from ._lib import COMM_ALLREDUCE, COMM_START, COMM_WAIT, TfluidsError, tfl_comm, tfl_slab
 
-DEFAULT_HALO = 10
+
+def slab_halo(reach=1):
+    """Planes a slab stores next to each neighbour (tfl_slab_halo): max(4, 2*reach + 1)."""
+    r = max(int(reach), 1)
+    return max(4, 2 * r + 1)
 
 
 class SlabLayout:
-    """Owned planes [z0, z1) of a Z_total grid and the extended local range [lo, hi)."""
+    """Owned planes [z0, z1) of a z_total grid and the extended local range [lo, hi)."""
 
-    def __init__(self, z_total, world, rank, halo=DEFAULT_HALO):
+    def __init__(self, z_total, world, rank, reach=1):
         if z_total % world != 0:
             raise ValueError("z extent %d is not divisible by %d ranks" % (z_total, world))
         per = z_total // world
+        halo = slab_halo(reach) if world > 1 else 0
         if world > 1 and per < halo:
             raise ValueError("slab thickness %d is smaller than the halo %d" % (per, halo))
-        self.z_total, self.world, self.rank, self.halo = z_total, world, rank, halo
+        self.z_total, self.world, self.rank, self.reach, self.halo = z_total, world, rank, max(int(reach), 1), halo
         self.z0, self.z1 = rank * per, (rank + 1) * per
         self.lo, self.hi = max(self.z0 - halo, 0), min(self.z1 + halo, z_total)
         self.c0, self.c1 = self.z0 - self.lo, self.z1 - self.lo   # owned planes in local indices
@@ -55,218 +56,222 @@ class SlabLayout:
         return t[:, :, self.c0:self.c1]
 
 
-def _msg_numel(fields, a, b):
-    return sum(f.size(0) * f.size(1) * (b - a) * f.size(3) * f.size(4) for f in fields)
+class _CommBase:
+    """Turns (pointer, count) pairs of the C callbacks into views of the step's workspace tensor and keeps the
+    ctypes trampolines alive. Subclasses implement start / wait / allreduce on torch tensors."""
+
+    def __init__(self):
+        self.ws = None
+        self.error = None
+        self._cb = (COMM_START(self._c_start), COMM_WAIT(self._c_wait), COMM_ALLREDUCE(self._c_allreduce))
+        self.struct = tfl_comm(None, *self._cb)
+
+    def bind(self, ws):
+        self.ws = ws
+
+    def _view(self, ptr, n, dtype=torch.float32):
+        if not ptr or n <= 0:
+            return None
+        off = (int(ptr) - self.ws.data_ptr()) // 4
+        if dtype == torch.float64:
+            return self.ws[off:off + 2 * n].view(torch.float64)
+        return self.ws[off:off + n]
+
+    def _guard(self, fn, *a):
+        try:
+            fn(*a)
+            return 0
+        except Exception as e:   # never let an exception cross the C frames: report through the return code
+            self.error = e
+            return 1
+
+    def _c_start(self, _user, tag, slo, nslo, rlo, nrlo, shi, nshi, rhi, nrhi):
+        return self._guard(self.start, int(tag), self._view(slo, nslo), self._view(rlo, nrlo), self._view(shi, nshi),
+                           self._view(rhi, nrhi))
+
+    def _c_wait(self, _user, tag):
+        return self._guard(self.wait, int(tag))
+
+    def _c_allreduce(self, _user, ptr, n):
+        return self._guard(self.allreduce, self._view(ptr, int(n), torch.float64))
 
 
-def _hip_pack(fields, a, b, buf, unpack):
-    """One kernel launch (tfl_packPlanes) instead of a dozen strided torch copies per message."""
-    import ctypes
-    from ._lib import tfl_tensor
-    lib, ctx = tfluids._context(fields[0])
-    descs = [tfl_tensor(f.data_ptr(), *f.shape) for f in fields]
-    arr = (ctypes.POINTER(tfl_tensor) * len(descs))(*[ctypes.pointer(d) for d in descs])
-    tfluids._call(lib, ctx, lib.tfl_packPlanes(ctx, len(descs), arr, int(a), int(b), ctypes.c_void_p(buf.data_ptr()),
-                                               int(unpack)))
+class DistComm(_CommBase):
+    """Halo exchange + all-reduce over torch.distributed: nccl (= RCCL over xGMI) on GPU tensors; with the gloo
+    backend messages are staged through the host (CPU tensors directly) -- that path only validates the multi-rank
+    control flow on a box with fewer GPUs than ranks (TFL_DIST_BACKEND=gloo), it is not a measured configuration."""
 
-
-def _pack(fields, a, b, out=None):
-    """Planes [a, b) of every field -> one contiguous message, layout [field][b][c][plane][Y][X]."""
-    if fields[0].is_cuda:
-        buf = out if out is not None else torch.empty(_msg_numel(fields, a, b), dtype=torch.float32,
-                                                       device=fields[0].device)
-        _hip_pack(fields, a, b, buf, 0)
-        return buf
-    return torch.cat([f[:, :, a:b].reshape(-1) for f in fields])     # CPU tensors (gloo tests)
-
-
-def _unpack(buf, fields, a, b):
-    if fields[0].is_cuda:
-        _hip_pack(fields, a, b, buf, 1)
-        return
-    off = 0
-    for f in fields:
-        view = f[:, :, a:b]
-        n = view.numel()
-        view.copy_(buf[off:off + n].view(view.shape))
-        off += n
-
-
-class DistComm:
-    """Halo exchange + all-reduce over torch.distributed (nccl = RCCL on GPUs, gloo on CPU tensors)."""
-
-    def __init__(self, group=None):
+    def __init__(self, rank, world, group=None):
+        super().__init__()
         import torch.distributed as dist
-        self.dist = dist
-        self.group = group
-        self._bufs = {}   # (direction, numel) -> (send, recv) message buffers, allocated once
-        # gloo moves host memory: GPU messages are staged through the host. Only used to validate the multi-rank
-        # control flow on a box without one GPU per rank (TFL_DIST_BACKEND=gloo); production = nccl (RCCL).
+        self.dist, self.group, self.rank, self.world = dist, group, rank, world
         self.stage_host = dist.get_backend(group) == "gloo"
+        self._pending = {}
 
-    def _buffers(self, key, fields, a, b):
-        n = _msg_numel(fields, a, b)
-        hit = self._bufs.get((key, n))
-        if hit is None:
-            hit = (torch.empty(n, dtype=torch.float32, device=fields[0].device),
-                   torch.empty(n, dtype=torch.float32, device=fields[0].device))
-            self._bufs[(key, n)] = hit
-        return hit
+    def start(self, tag, send_lo, recv_lo, send_hi, recv_hi):
+        dist = self.dist
+        ops, back = [], []
 
-    def exchange(self, lay, fields):
-        dist, h = self.dist, lay.halo
-        ops, recvs = [], []
-        if lay.has_lower:   # my lowest h owned planes -> rank-1's upper halo; its top planes -> my lower halo
-            sbuf, recv = self._buffers("lo", fields, lay.c0, lay.c0 + h)
-            send = _pack(fields, lay.c0, lay.c0 + h, out=sbuf if fields[0].is_cuda else None)
-            ops += [dist.P2POp(dist.isend, send, lay.rank - 1, self.group),
-                    dist.P2POp(dist.irecv, recv, lay.rank - 1, self.group)]
-            recvs.append((recv, lay.c0 - h, lay.c0))
-        if lay.has_upper:
-            sbuf, recv = self._buffers("hi", fields, lay.c1 - h, lay.c1)
-            send = _pack(fields, lay.c1 - h, lay.c1, out=sbuf if fields[0].is_cuda else None)
-            ops += [dist.P2POp(dist.isend, send, lay.rank + 1, self.group),
-                    dist.P2POp(dist.irecv, recv, lay.rank + 1, self.group)]
-            recvs.append((recv, lay.c1, lay.c1 + h))
-        if ops and self.stage_host and fields[0].is_cuda:
-            host_ops, pairs = [], []
-            for op in ops:
-                h = op.tensor.cpu() if op.op == dist.isend else torch.empty(op.tensor.shape, dtype=op.tensor.dtype)
-                host_ops.append(dist.P2POp(op.op, h, op.peer, self.group))
-                if op.op == dist.irecv:
-                    pairs.append((op.tensor, h))
-            for w in dist.batch_isend_irecv(host_ops):
-                w.wait()
-            for dev_t, h in pairs:
-                dev_t.copy_(h)
-        elif ops:
-            for w in dist.batch_isend_irecv(ops):
-                w.wait()
-        for buf, a, b in recvs:
-            _unpack(buf, fields, a, b)
+        def add(kind, t, peer):
+            if t is None:
+                return
+            if self.stage_host and t.is_cuda:
+                h = t.cpu() if kind is dist.isend else torch.empty(t.shape, dtype=t.dtype)
+                if kind is dist.irecv:
+                    back.append((t, h))
+                t = h
+            ops.append(dist.P2POp(kind, t, peer, self.group))
 
-    def allreduce_sum(self, t):
-        if self.stage_host and t.is_cuda:
-            h = t.cpu()
+        add(dist.isend, send_lo, self.rank - 1)
+        add(dist.irecv, recv_lo, self.rank - 1)
+        add(dist.isend, send_hi, self.rank + 1)
+        add(dist.irecv, recv_hi, self.rank + 1)
+        # nccl: the grouped send/recv runs on the process group's own stream behind the packing kernels already queued
+        # on the current stream; nothing blocks the host, and compute enqueued next overlaps the transfer
+        self._pending[tag] = (dist.batch_isend_irecv(ops) if ops else [], back)
+
+    def wait(self, tag):
+        works, back = self._pending.pop(tag)
+        for w in works:
+            w.wait()          # nccl: the current stream waits; gloo: the host does
+        for dev_t, h in back:
+            dev_t.copy_(h)
+
+    def allreduce(self, stats):
+        if self.stage_host and stats.is_cuda:
+            h = stats.cpu()
             self.dist.all_reduce(h, op=self.dist.ReduceOp.SUM, group=self.group)
-            t.copy_(h)
+            stats.copy_(h)
             return
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+        self.dist.all_reduce(stats, op=self.dist.ReduceOp.SUM, group=self.group)
 
 
-def run_lockstep(gens_layouts):
-    """Drive several SlabSimulation.step_gen() generators of VIRTUAL ranks living in one process (tests,
-    single-GPU verification of the decomposition): advance all to their next communication request,
-    perform it among them with plain copies, repeat."""
-    gens = [g for g, _ in gens_layouts]
-    lays = [l for _, l in gens_layouts]
-    reqs = [next(g, None) for g in gens]
-    while any(r is not None for r in reqs):
-        kinds = {r[0] for r in reqs}
-        assert len(kinds) == 1, "virtual ranks diverged: %s" % kinds
-        kind = kinds.pop()
-        if kind == "halo":
-            h = lays[0].halo
-            sends = []
-            for (_, fields), lay in zip(reqs, lays):
-                lo_buf = _pack(fields, lay.c0, lay.c0 + h) if lay.has_lower else None
-                hi_buf = _pack(fields, lay.c1 - h, lay.c1) if lay.has_upper else None
-                sends.append((lo_buf, hi_buf))
-            for r, ((_, fields), lay) in enumerate(zip(reqs, lays)):
-                if lay.has_lower:
-                    _unpack(sends[r - 1][1], fields, lay.c0 - h, lay.c0)
-                if lay.has_upper:
-                    _unpack(sends[r + 1][0], fields, lay.c1, lay.c1 + h)
-        elif kind == "allreduce":
-            total = sum(r[1] for r in reqs)
-            for r in reqs:
-                r[1].copy_(total)
-        else:
-            raise AssertionError(kind)
-        reqs = [next(g, None) for g in gens]
+class ThreadComm(_CommBase):
+    """Transport between VIRTUAL ranks living in threads of one process on one GPU (tests, single-GPU verification
+    of the decomposition): a shared mailbox and barriers. All ranks enqueue on the same HIP stream, so device-side
+    ordering follows the host-side order the barriers enforce."""
+
+    class Hub:
+        def __init__(self, world):
+            self.world = world
+            self.barrier = threading.Barrier(world)
+            self.box = {}
+
+    def __init__(self, hub, rank):
+        super().__init__()
+        self.hub, self.rank = hub, rank
+
+    def start(self, tag, send_lo, recv_lo, send_hi, recv_hi):
+        hub = self.hub
+        hub.box[(tag, self.rank)] = (send_lo, send_hi)
+        hub.barrier.wait()                      # every rank has queued its packing kernels
+        if recv_lo is not None:
+            recv_lo.copy_(hub.box[(tag, self.rank - 1)][1])
+        if recv_hi is not None:
+            recv_hi.copy_(hub.box[(tag, self.rank + 1)][0])
+        hub.barrier.wait()                      # every copy is queued before a sender may repack its buffer
+
+    def wait(self, tag):
+        pass
+
+    def allreduce(self, stats):
+        hub = self.hub
+        hub.box[("sum", self.rank)] = stats
+        hub.barrier.wait()
+        total = sum(hub.box[("sum", r)] for r in range(hub.world))
+        hub.barrier.wait()                      # everyone has read the inputs before anyone overwrites its own
+        stats.copy_(total)
+        hub.barrier.wait()
 
 
 class SlabSimulation:
-    """tfluids.simulate() (lib/simulate.lua:175-327, ConvNet projection) on one z-slab.
+    """tfluids.simulate() (lib/simulate.lua:175-327, ConvNet projection) on one z-slab through ONE native call per
+    step (tfl_simulate_step_slab). `batch` holds the EXTENDED local tensors (SlabLayout.extract of the global pDiv,
+    UDiv, flags, density and BC tensors). With world == 1 the result is exactly simulate_native()'s."""
 
-    `batch` holds the EXTENDED local tensors (SlabLayout.extract of the global pDiv, UDiv, flags, density
-    and BC tensors). With world == 1 this is exactly fluidnet_amd.simulate.simulate."""
-
-    def __init__(self, batch, mconf, model, layout, comm=None, check_reach=False):
-        self.batch, self.mconf, self.model, self.lay = batch, mconf, model, layout
-        self.comm = comm
-        self.check_reach = check_reach
+    def __init__(self, batch, mconf, model, layout, comm=None, check_reach=True, overlap=None, own_context=False):
+        from .simulate import _native_args
+        self.batch, self.mconf, self.model, self.lay, self.comm = batch, mconf, model, layout, comm
         U = batch["UDiv"]
-        _, C, _, Y, X = U.shape
-        self.dx = 1.0 / max(X, Y, layout.z_total)
-        self.count = float(C * layout.z_total * Y * X)            # global sample count of std(U)
-        self.stats = torch.zeros(U.size(0), 2, dtype=torch.float64, device=U.device)
         if (mconf.get("simMethod") or "convnet") != "convnet":
-            raise tfluids.TfluidsError("the z-slab path implements the ConvNet projection")
+            raise TfluidsError("the z-slab path implements the ConvNet projection")
+        if layout.world > 1 and comm is None:
+            raise TfluidsError("a slab with neighbours needs a transport (DistComm / ThreadComm)")
+        self.lib = _lib.load()
+        self._own_ctx = None
+        if own_context:      # virtual ranks in threads: the context carries per-step state (window, stream, reach word)
+            dev = U.device.index if U.device.index is not None else torch.cuda.current_device()
+            self._own_ctx = self.lib.tfl_create(dev)
+            if not self._own_ctx:
+                raise TfluidsError("tfl_create(%d) failed" % dev)
+        lib, ctx = self._context()
+        self.prm, self.st, self._keep = _native_args(lib, ctx, mconf, batch, model)
+        cells = (layout.c1 - layout.c0) * U.size(3) * U.size(4)
+        self.slab = tfl_slab(layout.z_total, layout.lo, layout.c0, layout.c1, layout.reach,
+                             int(cells >= (1 << 20)) if overlap is None else int(bool(overlap)), int(bool(check_reach)), 0)
+        n = int(lib.tfl_simulate_slab_workspace_floats(ctx, ctypes.byref(self.prm), ctypes.byref(self.st),
+                                                       ctypes.byref(self.slab)))
+        if n <= 0:
+            raise TfluidsError(lib.tfl_last_error(ctx).decode() or "bad slab description")
+        self.ws = torch.zeros(n, dtype=torch.float32, device=U.device)    # persistent: messages live here across steps
+        if comm is not None:
+            comm.bind(self.ws)
 
-    def step_gen(self):
-        """One simulate() step as a generator of communication requests ('halo', fields) / ('allreduce', stats).
-        Several virtual ranks may interleave in one process (run_lockstep), and advectVel's deferred copy keeps
-        a scratch tensor alive across a yield: each SlabSimulation therefore works in its own scratch scope."""
-        gen = self._step_gen()
-        while True:
-            prev, tfluids._scratch_scope = tfluids._scratch_scope, ("slab", id(self))
-            try:
-                req = next(gen, None)
-            finally:
-                tfluids._scratch_scope = prev
-            if req is None:
-                return
-            yield req
+    def _context(self):
+        if self._own_ctx is None:
+            return tfluids._context(self.batch["UDiv"])
+        dev = self.batch["UDiv"].device.index
+        self.lib.tfl_set_stream(self._own_ctx, ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+        return self.lib, self._own_ctx
 
-    def _step_gen(self):
-        b, m, lay = self.batch, self.mconf, self.lay
-        p, U, flags, rho = b["pDiv"], b["UDiv"], b["flags"], b["density"]
-        dt, method, strength = m["dt"], m.get("advectionMethod"), m.get("maccormackStrength")
-        multi = lay.world > 1
-        if multi:
-            tfluids.setDxOverride(U, self.dx)
-            yield ("halo", [U, rho])
-            if self.check_reach:
-                reach = float(U[:, 2].abs().max()) * dt
-                if 2 * math.ceil(reach) + 3 > lay.halo:
-                    raise tfluids.TfluidsError("back-trace reach %.2f planes exceeds what halo %d covers"
-                                               % (reach, lay.halo))
-        tfluids.advectScalar(dt, rho, U, flags, method, None, False, strength)
-        # as in simulate(): the advected field stays in advectVel's scratch (halo exchange and BCs happen there)
-        # and addBuoyancy writes U = scratch + buoyancy, which replaces the U:copy sweep
-        buoyant = m.get("buoyancyScale", 0) > 0
-        Uadv = tfluids.advectVel(dt, U, flags, method, None, strength, _deferCopy=buoyant)
-        Ucur = Uadv if buoyant else U
-        if multi:
-            yield ("halo", [Ucur, rho, p])
-        setConstVals(b, p, Ucur, flags, rho)
-        dx = self.dx if multi else tfluids.getDx(flags)
-        if buoyant:
-            s = _f32(-(dx / 4) * m["buoyancyScale"])
-            tfluids.addBuoyancy(U, flags, rho, [_f32(v) * s for v in _gravity(m)], dt, USrc=Uadv)
-        if m.get("gravityScale", 0) > 0:
-            s = _f32((-dx / 4) * m["gravityScale"])
-            tfluids.addGravity(U, flags, [_f32(v) * s for v in _gravity(m)], dt)
-        if m.get("vorticityConfinementAmp", 0) > 0:
-            tfluids.vorticityConfinement(U, flags, dx * m["vorticityConfinementAmp"])
-        setConstVals(b, p, U, flags, rho, unchanged=("p", "density"))
-        self.model.begin(U, flags, lay.c0, lay.c1, self.stats)
-        if multi:
-            yield ("allreduce", self.stats)
-        ubc, umask = b.get("UBC"), b.get("UBCInvMask")
-        sp = _sparse_bc(U, ubc, umask)
-        late_ubc = sp is not None and sp[1]      # as in simulate(): sparse idempotent U BCs go after the projection
-        self.model.finish(p, U, flags, self.stats, self.count, UBC=None if late_ubc else ubc,
-                          UBCInvMask=None if late_ubc else umask, clamp=(-1e6, 1e6))
-        rest = b if late_ubc else {k: v for k, v in b.items() if k not in ("UBC", "UBCInvMask")}
-        setConstVals(rest, p, U, flags, rho, unchanged=("density",))
-        if multi:
-            tfluids.setDxOverride(U, None)
+    def _call(self, fn, *args):
+        lib, ctx = self._context()
+        cptr = ctypes.byref(self.comm.struct) if self.comm is not None else None
+        if self.comm is not None:
+            self.comm.error = None
+        rc = fn(ctx, *args, ctypes.byref(self.slab), cptr, ctypes.c_void_p(self.ws.data_ptr()), self.ws.numel())
+        if rc != 0:
+            if self.comm is not None and self.comm.error is not None:
+                raise self.comm.error
+            raise TfluidsError(lib.tfl_last_error(ctx).decode())
 
     def step(self):
-        for req in self.step_gen():
-            if req[0] == "halo":
-                self.comm.exchange(self.lay, req[1])
-            else:
-                self.comm.allreduce_sum(req[1])
+        self._call(self.lib.tfl_simulate_step_slab, ctypes.byref(self.prm), ctypes.byref(self.st))
+
+    def drain(self):
+        """Finish the p / U halo messages the last step left in flight (before reading halo planes)."""
+        if self.slab.in_flight:
+            self._call(self.lib.tfl_slab_drain, ctypes.byref(self.st))
+
+    def close(self):
+        if self._own_ctx is not None:
+            self.lib.tfl_destroy(self._own_ctx)
+            self._own_ctx = None
+
+
+def run_virtual_ranks(sims, steps):
+    """Advance several SlabSimulation objects (ThreadComm transport, own_context=True) `steps` steps, one thread each."""
+    errs = []
+    dev = sims[0].batch["UDiv"].device
+
+    def work(sim):
+        try:
+            torch.cuda.set_device(dev)
+            for _ in range(steps):
+                sim.step()
+            sim.drain()
+        except Exception as e:   # noqa: BLE001
+            errs.append(e)
+            try:
+                sim.comm.hub.barrier.abort()
+            except Exception:
+                pass
+
+    ts = [threading.Thread(target=work, args=(s,)) for s in sims]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    torch.cuda.synchronize(dev)
+    if errs:
+        raise errs[0]

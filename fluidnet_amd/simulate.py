@@ -312,12 +312,10 @@ def _bc_plan(lib, ctx, bc, inv):
     return plan
 
 
-def simulate_native(conf, mconf, batch, model, outputDiv=False):
-    """The same step through ONE C-ABI call, tfl_simulate_step (fluidnet_amd/csrc/simulate.cpp): what a LuaJIT / cgo
-    host would bind instead of re-implementing this file's orchestration. Bit-identical to simulate()."""
-    from ._lib import tfl_sim_params, tfl_sim_state, tfl_tensor
+def _native_args(lib, ctx, mconf, batch, model, outputDiv=False):
+    """(tfl_sim_params, tfl_sim_state, keep-alive list) of a batch / mconf pair for the native step entry points."""
+    from ._lib import tfl_sim_params, tfl_sim_state
     p, U, flags, density = getPUFlagsDensityReference(batch)
-    lib, ctx = tfluids._context(U)
     chans = [] if density is None else (list(density) if isinstance(density, (list, tuple)) else [density])
     prm = tfl_sim_params()
     prm.dt = float(mconf["dt"])
@@ -353,10 +351,19 @@ def simulate_native(conf, mconf, batch, model, outputDiv=False):
         for i in range(len(chans)):
             st.densityBC[i] = _bc_plan(lib, ctx, dbc[i], dmk[i])
     st.model = model._handle(lib, ctx, U.device.index) if model is not None else None
+    return prm, st, keep
+
+
+def simulate_native(conf, mconf, batch, model, outputDiv=False):
+    """The same step through ONE C-ABI call, tfl_simulate_step (fluidnet_amd/csrc/simulate.cpp): what a LuaJIT / cgo
+    host would bind instead of re-implementing this file's orchestration. Bit-identical to simulate()."""
+    U = batch["UDiv"]
+    lib, ctx = tfluids._context(U)
+    prm, st, keep = _native_args(lib, ctx, mconf, batch, model, outputDiv)
     nws = int(lib.tfl_simulate_workspace_floats(ctx, ctypes.byref(prm), ctypes.byref(st)))
     ws = tfluids.getTempStorage(U, [(nws,)])[0]
     tfluids._call(lib, ctx, lib.tfl_simulate_step(ctx, ctypes.byref(prm), ctypes.byref(st), ctypes.c_void_p(ws.data_ptr()), nws))
-    del keep, tfl_tensor
+    del keep
 
 
 class GraphedSimulate:

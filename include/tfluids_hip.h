@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define TFL_ABI_VERSION 1
+#define TFL_ABI_VERSION 2
 
 typedef enum tfl_status {
   TFL_OK = 0,
@@ -306,12 +306,93 @@ int64_t tfl_simulate_workspace_floats(tfl_ctx* ctx, const tfl_sim_params* params
 int tfl_simulate_step(tfl_ctx* ctx, const tfl_sim_params* params, const tfl_sim_state* state, float* workspace,
                       int64_t workspace_floats);
 
-/* z-slab halo messages (BASELINE config 5): gather planes [zlo, zhi) of n <= 8 fields (each with its own
- * B and C; all with the same Z, Y, X) into one contiguous buffer laid out
- * [field][b][c][plane][Y][X] (unpack = 0), or scatter such a buffer back into the fields (unpack = 1).
- * One launch per neighbour and direction; the buffer is what RCCL send/recv moves over xGMI. */
+/* ---- z-slab decomposition across the GPUs of a node (BASELINE config 5; no counterpart in the reference, which is
+ * single-GPU). A rank holds planes [z_first, z_first + Zlocal) of a z_total-deep grid: the planes it OWNS,
+ * [own_lo, own_hi) in local indices, plus `halo` planes of its neighbours on each side that has one (none at the domain
+ * ends). Building blocks first, the assembled step last. ------------------------------------------------------- */
+
+/* Gather planes [zlo, zhi) of n <= 8 fields (each with its own B and C; all with the same Z, Y, X) into one contiguous
+ * buffer laid out [field][b][c][plane][Y][X] (unpack = 0), or scatter such a buffer back (unpack = 1): what RCCL
+ * send/recv moves over xGMI. */
 int tfl_packPlanes(tfl_ctx* ctx, int n, const tfl_tensor* const* fields, int zlo, int zhi, float* buf,
                    int unpack);
+
+/* Compute window: until changed, advectScalar, advectVel, addBuoyancy[From], addGravity, vorticityConfinement,
+ * tfl_model_begin and tfl_model_finish compute ONLY the z-planes [a0, a1) and [b0, b1) of their tensors (the two runs
+ * go out as one launch; an empty second run is b0 == b1); reads still address the whole array. All zero = every plane
+ * (the default). The other operators ignore the window. A slab rank uses it to run each phase of the step on exactly
+ * the planes whose inputs are valid, and to split a phase into boundary strips (computed first, so their halo message
+ * can leave) and interior (computed while the message is in flight). */
+int tfl_set_z_window(tfl_ctx* ctx, int a0, int a1, int b0, int b1);
+
+/* Pass selection for the multi-pass operators (0 = all passes, the default), so that each pass can get its own
+ * window: advectScalar 1 = 3^dim min/max grid, 2 = pass A (forward), 4 = pass B (backward + correct + clamp);
+ * advectVel 2 / 4 likewise; vorticityConfinement 2 = curl, 4 = confinement force; tfl_model_begin 2 = wall BCs +
+ * divergence + partial sums, 4 = reduction over [zlo, zhi); tfl_model_finish (3-D default topology only) 1 / 2 / 4 =
+ * first / second / third(+1x1x1) conv layer, 8 = velocity update + un-scale + wall BCs. */
+int tfl_set_stages(tfl_ctx* ctx, int mask);
+
+/* The divergence plane tfl_model_begin wrote inside `workspace` (a [B][1][Z][Y][X] field): a slab rank exchanges its
+ * halo planes before the first conv layer. */
+float* tfl_model_div(const tfl_model* model, int B, int Z, int Y, int X, float* workspace);
+
+typedef struct tfl_slab {
+  int32_t z_total;        /* planes of the whole grid */
+  int32_t z_first;        /* global index of local plane 0 */
+  int32_t own_lo, own_hi; /* owned planes [own_lo, own_hi), local indices; own_lo = 0 at the lower domain end, else the
+                             stored halo depth (>= tfl_slab_halo(reach)); likewise above */
+  int32_t reach;          /* R: the step is exact while max|u_z|*dt < R cells (the back-trace of the advection);
+                             0 = 1. Halo depth needed = max(4, 2R + 1) */
+  int32_t overlap;        /* 1: split the phases that feed a message into boundary strips + interior so that the
+                             transfer overlaps compute (worth it when a slab holds >~ 1M cells); 0: one launch each */
+  int32_t check_reach;    /* 1: every step reduces max|u_z| on the device; a violation found by step n is reported
+                             by the call for step n+1 (no host sync is added) */
+  int32_t in_flight;      /* OUT/IN, initialise to 0: bit mask of halo messages started by the previous call and not
+                             yet consumed (tfl_simulate_step_slab finishes them; tfl_slab_drain does so explicitly) */
+} tfl_slab;
+
+/* Transport supplied by the host (RCCL send/recv through torch.distributed in fluidnet_amd/dist.py; any MPI-like
+ * layer works). All buffers are device memory inside the step's workspace. Every callback is called from the thread
+ * that called tfl_simulate_step_slab, after the library has enqueued the packing kernels on the context's stream:
+ *   exchange_start: begin sending send_lo[0..n_send_lo) to rank-1 and receiving recv_lo from it, send_hi / recv_hi with
+ *                   rank+1 (n == 0 / NULL: no such neighbour). Must order the transfer after the work enqueued so far
+ *                   on the stream; should not block the host.
+ *   exchange_wait:  make the stream wait until the transfers of exchange_start(tag) have landed.
+ *   allreduce_sum:  in-place sum of n device doubles over all ranks, ordered on the stream.
+ * Return 0, or non-zero to abort the step (reported as TFL_EINVAL with "comm callback failed"). */
+typedef struct tfl_comm {
+  void* user;
+  int (*exchange_start)(void* user, int tag, const float* send_lo, int64_t n_send_lo, float* recv_lo, int64_t n_recv_lo,
+                        const float* send_hi, int64_t n_send_hi, float* recv_hi, int64_t n_recv_hi);
+  int (*exchange_wait)(void* user, int tag);
+  int (*allreduce_sum)(void* user, double* dev, int64_t n);
+} tfl_comm;
+
+/* Halo depth a slab must store next to each neighbour for reach R (>= 4). */
+int32_t tfl_slab_halo(int32_t reach);
+int64_t tfl_simulate_slab_workspace_floats(tfl_ctx* ctx, const tfl_sim_params* params, const tfl_sim_state* state,
+                                           const tfl_slab* slab);
+
+/* tfl_simulate_step on one z-slab: the owned planes of p, U and density come out as the single-GPU step would compute
+ * them (bit for bit, except for the summation order of the std normaliser's all-reduce). State tensors are the LOCAL
+ * extended arrays; BC plans are made on the local BC tensors; flags halos are static (filled by the caller once).
+ * Preconditions: 3-D, maccormackOurs, ConvNet projection with the 3-D default topology, at most one density channel,
+ * B*C layout as in tfl_simulate_step; on the first call every halo plane holds valid data (the caller cut its arrays
+ * out of a global initial state); `workspace` must be the SAME buffer on every call (halo messages of p and U started
+ * at the end of one step are consumed by the next).
+ * Per step: three neighbour exchanges + one 2*B-double all-reduce --
+ *   U(R+1 planes) | p(4 below, 3 above)   started at the end of the previous step, consumed at the start / before conv 1
+ *   advected U(3) + density(max(4, 2R+1)) after MacCormack pass B, overlapped with the interior of pass B
+ *   divergence(4 below, 3 above)          overlapped with the interior of the first conv layer
+ * and every phase runs under the narrowest z-window that keeps the owned planes exact, so the redundant compute is a
+ * few planes per phase instead of a fixed wide halo. */
+int tfl_simulate_step_slab(tfl_ctx* ctx, const tfl_sim_params* params, const tfl_sim_state* state, tfl_slab* slab,
+                           const tfl_comm* comm, float* workspace, int64_t workspace_floats);
+
+/* Finish the messages a previous tfl_simulate_step_slab left in flight: afterwards the halo planes of U and p are
+ * valid too (call before reading halos on the host, or before freeing the workspace). */
+int tfl_slab_drain(tfl_ctx* ctx, const tfl_sim_state* state, tfl_slab* slab, const tfl_comm* comm, float* workspace,
+                   int64_t workspace_floats);
 
 #ifdef __cplusplus
 }

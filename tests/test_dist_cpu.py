@@ -1,15 +1,17 @@
-"""Multi-process CPU tests (gloo, world_size 2 and 3) of the N > 1 host path: slab layout, halo
-exchange and the statistics all-reduce of fluidnet_amd.dist. The kernels themselves need a GPU; what
-is verified here is that every rank ends up holding exactly the planes of the global field it should."""
+"""Multi-process CPU tests (gloo, world_size 2 and 3) of the N > 1 host path of fluidnet_amd.dist: slab layout and the
+transport callbacks tfl_simulate_step_slab drives (exchange_start / exchange_wait / allreduce_sum). The step itself needs
+a GPU (tests/test_hip_simulate.py runs it on virtual ranks); what is verified here is the C-callback plumbing -- raw
+(pointer, count) pairs into views of the workspace, neighbour pairing, tags in flight at the same time -- through the
+very ctypes trampolines the library calls."""
+import ctypes
 import os
 import socket
 
-import numpy as np
 import pytest
 import torch
 import torch.multiprocessing as mp
 
-from fluidnet_amd.dist import DistComm, SlabLayout, run_lockstep
+from fluidnet_amd.dist import DistComm, SlabLayout, ThreadComm, slab_halo
 
 
 def _free_port():
@@ -20,79 +22,125 @@ def _free_port():
     return port
 
 
-def _global_fields(z_total):
-    g = torch.Generator().manual_seed(7)
-    return [torch.rand(1, 3, z_total, 6, 5, generator=g), torch.rand(1, 1, z_total, 6, 5, generator=g)]
+def _drive(comm, rank, world, ws):
+    """What the native step does with a transport: two messages in flight at once (tags 0, 1) with different sizes per
+    direction, a third one started and finished in between, one all-reduce. Returns True when every received buffer
+    holds exactly what the neighbour sent."""
+    base = ws.data_ptr()
+    P = lambda off: ctypes.c_void_p(base + 4 * off)
+    lower, upper = rank > 0, rank < world - 1
+    n_lo_s, n_lo_r, n_hi_s, n_hi_r = 24, 40, 40, 24          # send_lo pairs with the lower rank's recv_hi, etc.
+    ok = True
+
+    def payload(src_rank, tag, direction, n):
+        return torch.arange(n, dtype=torch.float32) + 1000.0 * src_rank + 100.0 * tag + (0.5 if direction == "hi" else 0.0)
+
+    def fill(tag):
+        o = 200 * tag
+        ws[o:o + n_lo_s] = payload(rank, tag, "lo", n_lo_s)
+        ws[o + 50:o + 50 + n_hi_s] = payload(rank, tag, "hi", n_hi_s)
+        ws[o + 100:o + 100 + n_lo_r] = -1.0
+        ws[o + 150:o + 150 + n_hi_r] = -1.0
+
+    def start(tag):
+        o = 200 * tag
+        return comm.struct.exchange_start(None, tag, P(o) if lower else None, n_lo_s if lower else 0,
+                                          P(o + 100) if lower else None, n_lo_r if lower else 0,
+                                          P(o + 50) if upper else None, n_hi_s if upper else 0,
+                                          P(o + 150) if upper else None, n_hi_r if upper else 0)
+
+    def check(tag):
+        o = 200 * tag
+        good = True
+        if lower:    # my recv_lo = the lower rank's send_hi
+            good &= torch.equal(ws[o + 100:o + 100 + n_lo_r], payload(rank - 1, tag, "hi", n_hi_s))
+        if upper:
+            good &= torch.equal(ws[o + 150:o + 150 + n_hi_r], payload(rank + 1, tag, "lo", n_lo_s))
+        return good
+
+    for t in (0, 1, 2):
+        fill(t)
+    assert start(0) == 0 and start(1) == 0
+    assert start(2) == 0 and comm.struct.exchange_wait(None, 2) == 0
+    ok &= check(2)
+    so = 800                                       # 8-byte aligned slot for two doubles
+    ws[so:so + 4].view(torch.float64)[:] = torch.tensor([float(rank + 1), 2.0 * (rank + 1)], dtype=torch.float64)
+    assert comm.struct.allreduce_sum(None, P(so), 2) == 0
+    tot = world * (world + 1) / 2
+    ok &= ws[so:so + 4].view(torch.float64).tolist() == [tot, 2 * tot]
+    assert comm.struct.exchange_wait(None, 0) == 0 and comm.struct.exchange_wait(None, 1) == 0
+    ok &= check(0) and check(1)
+    return bool(ok)
 
 
-def _worker(rank, world, port, z_total, halo, out):
+def _worker(rank, world, port, out):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        lay = SlabLayout(z_total, world, rank, halo)
-        glob = _global_fields(z_total)
-        local = [lay.extract(t) for t in glob]
-        for t in local:   # poison the halos: the exchange must restore them from the neighbours
-            if lay.has_lower:
-                t[:, :, :lay.c0] = -1.0
-            if lay.has_upper:
-                t[:, :, lay.c1:] = -2.0
-        comm = DistComm()
-        comm.exchange(lay, local)
-        ok = all(torch.equal(l, lay.extract(g)) for l, g in zip(local, glob))
-        stats = torch.tensor([[float(rank + 1), 2.0 * (rank + 1)]], dtype=torch.float64)
-        comm.allreduce_sum(stats)
-        tot = world * (world + 1) / 2
-        ok = ok and stats.tolist() == [[tot, 2 * tot]]
-        out[rank] = bool(ok)
+        ws = torch.zeros(1024)
+        comm = DistComm(rank, world)
+        comm.bind(ws)
+        out[rank] = _drive(comm, rank, world, ws)
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,z_total,halo", [(2, 16, 3), (3, 24, 4), (2, 8, 4)])
-def test_halo_exchange_and_allreduce_gloo(world, z_total, halo):
+@pytest.mark.parametrize("world", [2, 3])
+def test_transport_callbacks_gloo(world):
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_worker, args=(world, _free_port(), z_total, halo, out), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
     assert dict(out) == {r: True for r in range(world)}
 
 
+def test_transport_callbacks_threads():
+    """ThreadComm (virtual ranks of the single-GPU decomposition tests) obeys the same contract."""
+    import threading
+    world = 3
+    hub = ThreadComm.Hub(world)
+    res = {}
+
+    def work(r):
+        ws = torch.zeros(1024)
+        comm = ThreadComm(hub, r)
+        comm.bind(ws)
+        res[r] = _drive(comm, r, world, ws)
+
+    ts = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert res == {r: True for r in range(world)}
+
+
+def test_callback_exceptions_become_return_codes():
+    comm = DistComm.__new__(DistComm)
+    from fluidnet_amd.dist import _CommBase
+    _CommBase.__init__(comm)
+    comm.bind(torch.zeros(16))
+    comm.wait = lambda tag: (_ for _ in ()).throw(RuntimeError("link down"))
+    assert comm.struct.exchange_wait(None, 3) == 1 and isinstance(comm.error, RuntimeError)
+
+
 def test_layout_partition_covers_grid():
-    for world, z in [(1, 17), (2, 32), (4, 64), (8, 256)]:
-        lays = [SlabLayout(z, world, r, 10 if world > 1 else 0) for r in range(world)]
+    assert (slab_halo(1), slab_halo(2), slab_halo(3)) == (4, 5, 7)
+    for world, z in [(1, 17), (2, 32), (4, 64), (8, 256), (8, 128)]:
+        lays = [SlabLayout(z, world, r) for r in range(world)]
         assert lays[0].z0 == 0 and lays[-1].z1 == z
         for a, b in zip(lays, lays[1:]):
             assert a.z1 == b.z0
         for l in lays:
+            assert l.halo == (4 if world > 1 else 0)
             assert l.lo == max(l.z0 - l.halo, 0) and l.hi == min(l.z1 + l.halo, z)
             assert l.c1 - l.c0 == z // world and (l.has_lower, l.has_upper) == (l.rank > 0, l.rank < world - 1)
+    t = torch.arange(2 * 3 * 16 * 2 * 2, dtype=torch.float32).view(2, 3, 16, 2, 2)
+    lay = SlabLayout(16, 2, 1)
+    loc = lay.extract(t)
+    assert loc.is_contiguous() and torch.equal(lay.owned(loc), t[:, :, 8:16]) and loc.data_ptr() != t.data_ptr()
     with pytest.raises(ValueError):
         SlabLayout(30, 4, 0)
     with pytest.raises(ValueError):
-        SlabLayout(32, 4, 0, halo=10)
-
-
-def test_lockstep_virtual_ranks_match_dist_semantics():
-    """run_lockstep (in-process virtual ranks, used by the GPU equivalence test) moves the same planes."""
-    z_total, world, halo = 24, 3, 4
-    glob = _global_fields(z_total)
-    lays = [SlabLayout(z_total, world, r, halo) for r in range(world)]
-    locs = []
-    for lay in lays:
-        l = [lay.extract(t) for t in glob]
-        for t in l:
-            t[:, :, :lay.c0] = -1.0
-            t[:, :, lay.c1:] = -2.0
-        locs.append(l)
-    stats = [torch.tensor([[1.0 + r, 3.0]], dtype=torch.float64) for r in range(world)]
-
-    def gen(r):
-        yield ("halo", locs[r])
-        yield ("allreduce", stats[r])
-
-    run_lockstep([(gen(r), lays[r]) for r in range(world)])
-    for lay, l in zip(lays, locs):
-        assert all(torch.equal(a, lay.extract(g)) for a, g in zip(l, glob))
-    assert all(s.tolist() == [[6.0, 9.0]] for s in stats)
+        SlabLayout(24, 8, 0)          # 3-plane slabs cannot hold a 4-plane halo

@@ -62,3 +62,34 @@ def test_simulate_parity_at_baseline_size(request, res, config, preroll, steps):
         got = batch[k].cpu().numpy()
         r = scenes.rel_l2(got, nb[k])
         assert np.isfinite(got).all() and r <= TOL, (res, kind, k, r)
+
+
+@pytest.mark.parametrize("res,world,config", [(256, 8, 5), (128, 8, 4), (128, 2, 4)])
+def test_zslab_decomposition_at_baseline_size(res, world, config):
+    """BASELINE config 5 (256^3 in 8 z-slabs of 32 planes) and the metric's 128^3 strong-scaling series (8 slabs of 16,
+    2 of 64): the native slab step on virtual ranks of ONE GPU vs the unsplit step, from a developed plume. The unsplit
+    step is itself held to the reference at these sizes by test_simulate_parity_at_baseline_size."""
+    import torch
+    from fluidnet_amd import FluidNetModel
+    from fluidnet_amd.dist import SlabLayout, SlabSimulation, ThreadComm, run_virtual_ranks
+    from fluidnet_amd.simulate import simulate_native
+    ref, mconf = _scene(res, config)
+    model = FluidNetModel.default_3d(seed=1)
+    for _ in range(8):
+        simulate_native(None, mconf, ref, model)
+    hub = ThreadComm.Hub(world)
+    sims = []
+    for r in range(world):
+        lay = SlabLayout(res, world, r)
+        loc = {k: (lay.extract(v) if torch.is_tensor(v) else v) for k, v in ref.items()}
+        sims.append(SlabSimulation(loc, mconf, FluidNetModel.default_3d(seed=1), lay, ThreadComm(hub, r), own_context=True))
+    for _ in range(3):
+        simulate_native(None, mconf, ref, model)
+    run_virtual_ranks(sims, 3)
+    assert float(ref["UDiv"].abs().max()) > 0.1 and bool(torch.isfinite(ref["UDiv"]).all())
+    for s in sims:
+        for k in ("pDiv", "UDiv", "density"):
+            got, want = s.lay.owned(s.batch[k]), ref[k][:, :, s.lay.z0:s.lay.z1]
+            rel = float((got - want).norm() / want.norm().clamp_min(1e-30))
+            assert rel <= 1e-6, (s.lay.rank, k, rel)
+        s.close()

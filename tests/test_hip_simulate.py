@@ -259,38 +259,85 @@ def test_native_simulate_step_equals_python_orchestration(which):
     assert float(ta["UDiv"].abs().max()) > 0.1
 
 
-@pytest.mark.parametrize("world", [2, 4])
-def test_zslab_decomposition_equals_single_gpu(world):
-    """BASELINE config 5's decomposition, verified on ONE GPU with in-process virtual ranks: every
-    rank runs the unmodified kernels on its slab + 10 halo planes; owned planes must equal the
-    unsplit run (bit-exact up to the fp64 summation order of the std all-reduce)."""
+def _slab_sims(ref, mconf, world, layers_seed, reach=1, overlap=None, check_reach=True):
+    """Cut the global state `ref` (dict of device tensors) into `world` virtual z-slab ranks (threads + ThreadComm)."""
     import torch
     from fluidnet_amd import FluidNetModel
-    from fluidnet_amd.dist import SlabLayout, SlabSimulation, run_lockstep
-    from fluidnet_amd.simulate import simulate
-    dev = torch.device("cuda:0")
-    Zt, Y, X = 16 * world, 24, 32
-    b = _plume_batch((Zt, Y, X), 0.15, 0.6, obstacles_seed=11)
-    mconf = dict(dt=0.1, advectionMethod="maccormackOurs", maccormackStrength=0.6, buoyancyScale=1.0,
-                 gravityScale=0, vorticityConfinementAmp=2.0, simMethod="convnet")
-    model = FluidNetModel(S.default_3d_layers(seed=2), True)
-    ref = _to_dev(b, dev)
-    lays = [SlabLayout(Zt, world, r, 10) for r in range(world)]
+    from fluidnet_amd.dist import SlabLayout, SlabSimulation, ThreadComm
+    Zt = ref["flags"].size(2)
+    hub = ThreadComm.Hub(world)
     sims = []
-    for lay in lays:
+    for r in range(world):
+        lay = SlabLayout(Zt, world, r, reach)
         loc = {k: (lay.extract(v) if torch.is_tensor(v) else v) for k, v in ref.items()}
-        # one model object (own scratch) per virtual rank, as each process has in a real run
-        sims.append(SlabSimulation(loc, mconf, FluidNetModel(S.default_3d_layers(seed=2), True), lay, None,
-                                   check_reach=True))
-    for _ in range(5):
-        simulate(None, mconf, ref, model)
-        run_lockstep([(s.step_gen(), s.lay) for s in sims])
-    assert float(ref["UDiv"].abs().max()) > 0
+        model = FluidNetModel(layers_seed, True) if isinstance(layers_seed, list) else FluidNetModel.default_3d(seed=layers_seed)
+        sims.append(SlabSimulation(loc, mconf, model, lay, ThreadComm(hub, r) if world > 1 else None,
+                                   check_reach=check_reach, overlap=overlap, own_context=True))
+    return sims
+
+
+def _assert_slabs_equal(sims, ref, tol=1e-6):
     for s in sims:
         for k in ("pDiv", "UDiv", "density"):
-            got = s.lay.owned(s.batch[k]).cpu().numpy()
-            want = ref[k][:, :, s.lay.z0:s.lay.z1].cpu().numpy()
-            assert scenes.rel_l2(got, want) <= 1e-6, (s.lay.rank, k, scenes.rel_l2(got, want))
+            got = s.lay.owned(s.batch[k])
+            want = ref[k][:, :, s.lay.z0:s.lay.z1]
+            rel = float((got - want).norm() / want.norm().clamp_min(1e-30))
+            assert rel <= tol, (s.lay.rank, k, rel)
+
+
+@pytest.mark.parametrize("world,overlap", [(1, False), (2, False), (2, True), (4, True), (3, False)])
+def test_zslab_decomposition_equals_single_gpu(world, overlap):
+    """tfl_simulate_step_slab, verified on ONE GPU with virtual ranks (threads + an in-process transport): every rank
+    runs the native slab step on its planes + 4 halo planes, each phase under its own z-window; after 6 steps the owned
+    planes must equal the unsplit tfl_simulate_step (bit-exact up to the fp64 summation order of the std all-reduce;
+    world = 1 must be bit-exact). overlap = boundary strips first, interior while the message is in flight."""
+    import torch
+    from fluidnet_amd import FluidNetModel
+    from fluidnet_amd.dist import run_virtual_ranks
+    from fluidnet_amd.simulate import simulate_native
+    dev = torch.device("cuda:0")
+    Zt, Y, X = 12 * world, 24, 32
+    b = _plume_batch((Zt, Y, X), 0.15, 0.6, obstacles_seed=11)
+    mconf = dict(dt=0.1, advectionMethod="maccormackOurs", maccormackStrength=0.6, buoyancyScale=1.0,
+                 gravityScale=0.2, vorticityConfinementAmp=2.0, simMethod="convnet")
+    layers = S.default_3d_layers(seed=2)
+    ref = _to_dev(b, dev)
+    model = FluidNetModel(layers, True)
+    sims = _slab_sims(ref, mconf, world, layers, overlap=overlap)
+    for _ in range(3):                       # two rounds: messages left in flight by one call feed the next
+        for _ in range(2):
+            simulate_native(None, mconf, ref, model)
+        run_virtual_ranks(sims, 2)
+        _assert_slabs_equal(sims, ref, 0.0 if world == 1 else 1e-6)
+    assert float(ref["UDiv"].abs().max()) > 0
+    for s in sims:       # after drain() the halo planes are valid too
+        for k in ("pDiv", "UDiv"):
+            got, want = s.batch[k], ref[k][:, :, s.lay.lo:s.lay.hi]
+            assert float((got - want).norm() / want.norm().clamp_min(1e-30)) <= 1e-6, (s.lay.rank, k)
+        s.close()
+
+
+def test_zslab_reach_violation_is_reported():
+    """A flow faster than the slab's back-trace reach (max|u_z|*dt >= R) breaks the halo contract: the step after the
+    offending one must raise instead of silently returning wrong planes (unchecked precondition)."""
+    import torch
+    from fluidnet_amd import tfluids
+    from fluidnet_amd.dist import run_virtual_ranks
+    dev = torch.device("cuda:0")
+    b = _plume_batch((24, 16, 16), 0.15, 0.6)
+    b["UDiv"][:, 2, 4:20, 4:12, 4:12] = 15.0          # 1.5 cells per step along z
+    mconf = dict(dt=0.1, advectionMethod="maccormackOurs", maccormackStrength=0.6, buoyancyScale=1.0,
+                 gravityScale=0, vorticityConfinementAmp=0, simMethod="convnet")
+    sims = _slab_sims(_to_dev(b, dev), mconf, 2, S.default_3d_layers(seed=2))
+    with pytest.raises(tfluids.TfluidsError, match="reach"):
+        run_virtual_ranks(sims, 3)
+    for s in sims:
+        s.close()
+    # the same flow is fine for a slab that was laid out for reach 2 (5 halo planes)
+    sims = _slab_sims(_to_dev(b, dev), dict(mconf, buoyancyScale=0.0), 2, S.default_3d_layers(seed=2), reach=2)
+    run_virtual_ranks(sims, 1)
+    for s in sims:
+        s.close()
 
 
 @pytest.mark.parametrize("which", ["2d_convnet", "2d_jacobi", "3d_convnet"])
@@ -338,35 +385,6 @@ def test_conv_paths_agree_2d(oracle, monkeypatch):
         assert rp <= 2e-6 and rU <= 2e-6, (dims, rp, rU)
         p_ref, U_ref = S.model_forward(oracle, layers, sc["p"], sc["U"], sc["flags"])
         assert scenes.rel_l2(pm.cpu().numpy(), p_ref) <= TOL and scenes.rel_l2(Um.cpu().numpy(), U_ref) <= TOL
-
-
-def test_zslab_decomposition_fullsize_128():
-    """The same invariance at BASELINE's full 128^3 (where the CPU oracle takes minutes per step): splitting
-    the grid into two z-slabs must not change the owned planes. Scene = bench.py's config-4 scene."""
-    import torch
-    import bench
-    from fluidnet_amd import FluidNetModel
-    from fluidnet_amd.dist import SlabLayout, SlabSimulation, run_lockstep
-    from fluidnet_amd.simulate import simulate
-    dev = torch.device("cuda:0")
-    res = 128
-    ref, mconf = bench.build_scene(res, res, None, dev)
-    model = FluidNetModel.default_3d(seed=1)
-    lays = [SlabLayout(res, 2, r, 10) for r in range(2)]
-    sims = []
-    for lay in lays:
-        loc, _ = bench.build_scene(res, res, lay, dev)
-        sims.append(SlabSimulation(loc, mconf, FluidNetModel.default_3d(seed=1), lay, None, check_reach=True))
-    for _ in range(6):
-        simulate(None, mconf, ref, model)
-        run_lockstep([(s.step_gen(), s.lay) for s in sims])
-    assert float(ref["UDiv"].abs().max()) > 0 and bool(torch.isfinite(ref["UDiv"]).all())
-    for s in sims:
-        for k in ("pDiv", "UDiv", "density"):
-            got = s.lay.owned(s.batch[k])
-            want = ref[k][:, :, s.lay.z0:s.lay.z1]
-            rel = float((got - want).norm() / want.norm().clamp_min(1e-30))
-            assert rel <= 1e-6, (s.lay.rank, k, rel)
 
 
 def test_simulate_long_horizon_parity(oracle):
