@@ -124,6 +124,7 @@ SIGNATURES = {
     "tfl_applyBCs": (_c.c_int, [_c.c_void_p, _T, _T, _T, _c.c_int, _c.c_float, _c.c_float]),
     "tfl_set_z_window": (_c.c_int, [_c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.c_int]),
     "tfl_set_stages": (_c.c_int, [_c.c_void_p, _c.c_int]),
+    "tfl_set_z_origin": (_c.c_int, [_c.c_void_p, _c.c_int, _c.c_int]),
     "tfl_model_div": (_c.c_void_p, [_c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p]),
     "tfl_slab_halo": (_c.c_int32, [_c.c_int32]),
     "tfl_simulate_slab_workspace_floats": (_c.c_int64, [_c.c_void_p, _c.POINTER(tfl_sim_params), _c.POINTER(tfl_sim_state),

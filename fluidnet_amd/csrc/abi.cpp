@@ -43,6 +43,7 @@ static const int kMaxBatch = 1024;
 // ---- per-kernel event profiler (TFL_TIMED in the launchers) ---------------------------------------
 namespace tfl {
 thread_local ZWin g_zwin = {0, 0, 0, 0};
+thread_local ZOrigin g_zorigin = {0, 0};
 struct ProfRec { const char* name; hipEvent_t e0, e1; };
 struct Profiler { std::vector<ProfRec> recs; };
 static thread_local Profiler* g_prof = nullptr;
@@ -124,8 +125,8 @@ int check_scalar(tfl_ctx* ctx, const char* op, const char* name, const tfl_tenso
 // calling thread (tfl_host.hpp make_dom); it is cleared again on the way out so that every other operator -- and every
 // other context used from this thread -- sees the whole array.
 struct WindowScope {
-  explicit WindowScope(const tfl_ctx* c) { tfl::g_zwin = c->zwin; }
-  ~WindowScope() { tfl::g_zwin = tfl::ZWin{0, 0, 0, 0}; }
+  explicit WindowScope(const tfl_ctx* c) { tfl::g_zwin = c->zwin; tfl::g_zorigin = c->zorigin; }
+  ~WindowScope() { tfl::g_zwin = tfl::ZWin{0, 0, 0, 0}; tfl::g_zorigin = tfl::ZOrigin{0, 0}; }
 };
 int stages_of(const tfl_ctx* c) { return c->stages ? c->stages : 0xff; }
 
@@ -138,6 +139,7 @@ int parse_method(const char* m) {
 }
 
 float get_dx(const tfl_ctx* c, const tfl_tensor* f) {  // grid.cc:37-40
+  if (c && c->dx_dim > 0) return 1.0f / (float)c->dx_dim;
   if (c && c->dx_override > 0.0f) return c->dx_override;
   int m = f->X > f->Y ? f->X : f->Y;
   if (f->Z > m) m = f->Z;
@@ -198,6 +200,12 @@ int tfl_set_z_window(tfl_ctx* c, int a0, int a1, int b0, int b1) {
   if (a0 < 0 || a1 < a0 || b0 < 0 || b1 < b0 || (a1 > a0 && b1 > b0 && b0 < a1))
     return fail(c, TFL_EINVAL, "set_z_window: [%d,%d) [%d,%d) is not an ordered pair of plane runs", a0, a1, b0, b1);
   c->zwin = tfl::ZWin{a0, a1, b0, b1};
+  return TFL_OK;
+}
+
+int tfl_set_z_origin(tfl_ctx* c, int z_first, int z_total) {
+  if (!c || z_first < 0 || z_total < 0 || (z_total > 0 && z_first >= z_total)) return TFL_EINVAL;
+  c->zorigin = tfl::ZOrigin{z_total > 0 ? z_first : 0, z_total};
   return TFL_OK;
 }
 
@@ -743,6 +751,7 @@ int tfl_model_forward(tfl_ctx* c, tfl_model* m, const tfl_tensor* pDiv, const tf
 
 double tfl_getDx(tfl_ctx* c, const tfl_tensor* flags) {
   if (!flags) return 0.0;
+  if (c && c->dx_dim > 0) return 1.0 / (double)c->dx_dim;
   if (c && c->dx_override > 0.0f) return (double)c->dx_override;
   int m = flags->X > flags->Y ? flags->X : flags->Y;
   if (flags->Z > m) m = flags->Z;

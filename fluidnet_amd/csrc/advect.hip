@@ -47,7 +47,7 @@ __device__ __forceinline__ float sample_s(const Dom& d, const float* g, const fl
 // Manta SemiLagrange, tfluids.cc:209-218
 template <bool IS3D>
 __device__ __forceinline__ float sl_manta(const Dom& d, const float* U, const float* src, float dt, int i, int j, int k) {
-  const v3 c = cell_centre(i, j, k), u = get_centered<IS3D>(d, U, i, j, k);
+  const v3 c = cell_centre(d, i, j, k), u = get_centered<IS3D>(d, U, i, j, k);
   return interpol<IS3D>(d, src, mk3(c.x - u.x * dt, c.y - u.y * dt, c.z - u.z * dt));
 }
 
@@ -55,7 +55,7 @@ __device__ __forceinline__ float sl_manta(const Dom& d, const float* U, const fl
 template <bool IS3D>
 __device__ __forceinline__ float sl_euler_ours(const AdvArgs& a, const float* flags, const float* U, const float* src,
                                                float dt, int i, int j, int k, v3& back) {
-  const v3 c = cell_centre(i, j, k);
+  const v3 c = cell_centre(a.d, i, j, k);
   const v3 disp = scale3(get_centered<IS3D>(a.d, U, i, j, k), -dt);
   count_trace_error(line_trace(a.d, flags, c, disp, back), a.err);
   return sample_s<IS3D>(a.d, src, flags, back, a.outside);
@@ -64,7 +64,7 @@ __device__ __forceinline__ float sl_euler_ours(const AdvArgs& a, const float* fl
 // SemiLagrangeRK2Ours, tfluids.cc:23-77
 template <bool IS3D>
 __device__ float sl_rk2_ours(const AdvArgs& a, const float* flags, const float* U, const float* src, int i, int j, int k) {
-  const v3 c = cell_centre(i, j, k);
+  const v3 c = cell_centre(a.d, i, j, k);
   v3 half, back;
   int hit = line_trace(a.d, flags, c, scale3(get_centered<IS3D>(a.d, U, i, j, k), -a.dt * 0.5f), half);
   count_trace_error(hit, a.err);
@@ -76,7 +76,7 @@ __device__ float sl_rk2_ours(const AdvArgs& a, const float* flags, const float* 
 // SemiLagrangeRK3Ours, tfluids.cc:79-147 (CPU variant: a k3 hit samples at k3_pos)
 template <bool IS3D>
 __device__ float sl_rk3_ours(const AdvArgs& a, const float* flags, const float* U, const float* src, int i, int j, int k) {
-  const v3 c = cell_centre(i, j, k);
+  const v3 c = cell_centre(a.d, i, j, k);
   const float dt = a.dt;
   v3 p2, p3, back;
   const v3 k1 = get_centered<IS3D>(a.d, U, i, j, k);
@@ -117,13 +117,13 @@ __device__ __forceinline__ bool manta_clamp_bounds(const Dom& d, const float* __
     else { px = (int)(pos.x + vel.x); py = (int)(pos.y + vel.y); pz = (int)(pos.z + vel.z); }
     const int i0 = iclampi(px, 0, d.X - 2);
     const int j0 = iclampi(py, 0, d.Y - 2);
-    const int k0 = iclampi(pz, 0, IS3D ? (d.Z - 2) : 1);
+    const int k0 = iclampi(pz, 0, IS3D ? (d.Zg - 2) : 1);      // global plane (pos.z carries the slab's z origin)
     const int i1 = i0 + 1, j1 = j0 + 1, k1 = IS3D ? k0 + 1 : k0;
     // isInBounds(p, 0), grid.cc:42-52: in 2-D z must be exactly 0
-    if (IS3D) { if (k0 < 0 || k1 >= d.Z) return false; }
+    if (IS3D) { if (k0 < 0 || k1 >= d.Zg) return false; }
     else if (k0 != 0 || k1 != 0) return false;
     if (i0 < 0 || j0 < 0 || i1 >= d.X || j1 >= d.Y) return false;
-    const int a = TFL_AT(d, i0, j0, k0);
+    const int a = TFL_AT(d, i0, j0, k0 - d.zg);
 #ifdef TFL_EXACT_MINMAX
     minmax(lo, hi, g[a]);
     minmax(lo, hi, g[a + 1]);
@@ -166,38 +166,17 @@ __device__ __forceinline__ float manta_clamp_component(const Dom& d, float dst, 
 template <bool IS3D>
 __device__ float manta_clamp_scalar(const Dom& d, const float* flags, const float* U, float dval, const float* orig,
                                     float fwd, float dt, int i, int j, int k) {
-  const v3 ijk = mk3((float)i, (float)j, (float)k);
+  const v3 ijk = mk3((float)i, (float)j, (float)(k + d.zg));
   const v3 ud = scale3(get_centered<IS3D>(d, U, i, j, k), dt);
   dval = manta_clamp_component<IS3D>(d, dval, orig, fwd, ijk, ud);
   const int fx = (int)((ijk.x + 0.5f) - ud.x), fy = (int)((ijk.y + 0.5f) - ud.y), fz = (int)((ijk.z + 0.5f) - ud.z);
   const int bx = (int)((ijk.x + 0.5f) + ud.x), by = (int)((ijk.y + 0.5f) + ud.y), bz = (int)((ijk.z + 0.5f) + ud.z);
-  const int ux = d.X - 1, uy = d.Y - 1, uz = d.Z - 1;
+  const int ux = d.X - 1, uy = d.Y - 1, uz = d.Zg - 1;
   if (fx < 0 || fy < 0 || fz < 0 || bx < 0 || by < 0 || bz < 0 || fx > ux || fy > uy || (fz > uz && IS3D) ||
       bx > ux || by > uy || (bz > uz && IS3D))
     return fwd;
-  if ((flag_at(d, flags, fx, fy, fz) & kObstacle) || (flag_at(d, flags, bx, by, bz) & kObstacle)) return fwd;
+  if ((flag_at(d, flags, fx, fy, fz - d.zg) & kObstacle) || (flag_at(d, flags, bx, by, bz - d.zg) & kObstacle)) return fwd;
   return dval;
-}
-
-// getClampBounds, tfluids.cc:331-378: min/max of src over the (fluid) 3^dim neighbourhood of int(pos)
-template <bool IS3D>
-__device__ void ours_clamp_bounds(const Dom& d, const float* __restrict__ flags, const float* __restrict__ src,
-                                  v3 pos, int outside, float& lo, float& hi) {
-  lo = __builtin_inff(); hi = -__builtin_inff();
-  const int i0 = iclampi((int)pos.x, 0, d.X - 1), j0 = iclampi((int)pos.y, 0, d.Y - 1);
-  const int k0 = IS3D ? iclampi((int)pos.z, 0, d.Z - 1) : 0;
-  for (int c = (IS3D ? k0 - 1 : 0); c <= (IS3D ? k0 + 1 : 0); c++) {
-    if (c < 0 || c >= d.Z) continue;
-    for (int bb = j0 - 1; bb <= j0 + 1; bb++) {
-      if (bb < 0 || bb >= d.Y) continue;
-#pragma unroll
-      for (int aa = i0 - 1; aa <= i0 + 1; aa++) {
-        if (aa < 0 || aa >= d.X) continue;
-        const int o = TFL_AT(d, aa, bb, c);
-        if (outside || (((int)flags[o]) & kFluid)) minmax(lo, hi, src[o]);
-      }
-    }
-  }
 }
 
 // Precomputed clamp-bound grid: lo3/hi3[cell] = min/max of src over the (fluid) 3^dim neighbourhood of
@@ -329,7 +308,7 @@ __global__ __launch_bounds__(256) TFL_SCALAR_OCC void k_scalar_fwd(AdvArgs a, co
     v = sl_manta<IS3D>(d, U, s, a.dt, i, j, k);
   } else {
     const bool fl = fluid_at(d, flags, i, j, k);
-    v3 back = cell_centre(i, j, k);
+    v3 back = cell_centre(d, i, j, k);
     if (!fl) v = s[o];
     else if (METHOD == kRK2Ours) v = sl_rk2_ours<IS3D>(a, flags, U, s, i, j, k);
     else if (METHOD == kRK3Ours) v = sl_rk3_ours<IS3D>(a, flags, U, s, i, j, k);
@@ -337,7 +316,7 @@ __global__ __launch_bounds__(256) TFL_SCALAR_OCC void k_scalar_fwd(AdvArgs a, co
     if (METHOD == kMacCormackOurs) {
       // clamp bounds of the forward position = the precomputed 3^dim min/max of the cell it falls in
       const int i0 = iclampi((int)back.x, 0, d.X - 1), j0 = iclampi((int)back.y, 0, d.Y - 1);
-      const int k0 = IS3D ? iclampi((int)back.z, 0, d.Z - 1) : 0;
+      const int k0 = IS3D ? iclampi((int)back.z, 0, d.Zg - 1) - d.zg : 0;
       const long long g = b * cells + TFL_AT(d, i0, j0, k0);
       bounds += b * cells * C;
       bounds[o] = lo3[g];
@@ -386,7 +365,7 @@ __global__ __launch_bounds__(256) TFL_SCALAR_OCC void k_scalar_bwd(AdvArgs a, co
 template <bool IS3D, bool OURS, int AXIS>
 __device__ __forceinline__ float sl_mac_from_u(const AdvArgs& a, const float* flags, const float* src, v3 u, float dt,
                                                int i, int j, int k) {
-  const v3 ctr = cell_centre(i, j, k);
+  const v3 ctr = cell_centre(a.d, i, j, k);
   v3 p;
   if (OURS) count_trace_error(line_trace(a.d, flags, ctr, scale3(u, -dt), p), a.err);
   else p = mk3(ctr.x - u.x * dt, ctr.y - u.y * dt, ctr.z - u.z * dt);
@@ -443,7 +422,7 @@ __global__ __launch_bounds__(256) void k_vel_bwd(AdvArgs a, const float* __restr
     u[0] = get_at_mac<IS3D, 0>(d, U, i, j, k);
     u[1] = get_at_mac<IS3D, 1>(d, U, i, j, k);
     u[2] = IS3D ? get_at_mac<IS3D, 2>(d, U, i, j, k) : mk3(0.0f, 0.0f, 0.0f);
-    const v3 ijk = mk3((float)i, (float)j, (float)k);
+    const v3 ijk = mk3((float)i, (float)j, (float)(k + d.zg));
     // MacCormackClampMAC bounds, tfluids.cc:748-774
 #pragma unroll
     for (int c = 0; c < C; c++) ok[c] = manta_clamp_bounds<IS3D>(d, U + c * d.sc, ijk, scale3(u[c], a.dt), lo[c], hi[c]);

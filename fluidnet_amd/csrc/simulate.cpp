@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 
@@ -231,11 +232,11 @@ int tfl_simulate_step(tfl_ctx* c, const tfl_sim_params* prm, const tfl_sim_state
 // end the slab simply ends there). With R = back-trace reach in cells (max|u_z|*dt < R) the per-phase z-dependencies are
 //   3^3 min/max grid of rho  +-1      pass A of MacCormack  rho +-(R+1) incl. the min/max lookup, U +-(R+1)
 //   pass B                   fwd +-R, U +-(R+1)             buoyancy  rho -1         curl  U -1..+2
-//   confinement              curl -1, |curl| -2..+1         divergence  U_bc +1 (flags +2)
+//   confinement              curl -1, |curl| -2..+1         divergence  U +1 (flags +2)
 //   3 conv layers            +-1 each                       velocity update  p -1
 // so, working backwards from "owned planes exact":
 //   project (0,0) <- conv3 (1,0) <- conv2 (2,1) <- conv1 (3,2) <- {p, div} (4,3)            [T1: p, T3: div]
-//   confine (0,0) <- curl (2,1) <- buoyancy/gravity (3,3) <- {U_adv (3,3), rho (4,3)}        [T2]
+//   divergence (0,0) <- confine (0,1) <- curl (2,2) <- buoyancy/gravity (3,4) <- {U_adv (3,4), rho (4,4)}   [T2]
 //   pass B (0,0) <- pass A (R,R) <- min/max (2R,2R) <- {rho (2R+1,2R+1), U (R+1,R+1)}        [T0: U; rho is still
 //                                                                                             valid from T2]
 // Local array ends are treated by the kernels as the domain's border shell (zeros); with halo >= max(4, 2R+1) no window
@@ -334,8 +335,8 @@ void slab_messages(const SlabGeom& g, const tfl_sim_state* s, const tfl_tensor* 
   const int rr = 2 * g.R + 1;
   m[0].tag = 0; m[0].n = 1; m[0].f[0] = Halo{s->U, g.R + 1, g.R + 1};
   m[1].tag = 1; m[1].n = 1; m[1].f[0] = Halo{s->p, 4, 3};
-  m[2].tag = 2; m[2].n = s->n_density > 0 ? 2 : 1; m[2].f[0] = Halo{Uadv, 3, 3};
-  if (s->n_density > 0) m[2].f[1] = Halo{s->density[0], rr > 4 ? rr : 4, rr > 3 ? rr : 3};
+  m[2].tag = 2; m[2].n = s->n_density > 0 ? 2 : 1; m[2].f[0] = Halo{Uadv, 3, 4};
+  if (s->n_density > 0) m[2].f[1] = Halo{s->density[0], rr > 4 ? rr : 4, rr > 4 ? rr : 4};
   m[3].tag = 3; m[3].n = 1; m[3].f[0] = Halo{div, 4, 3};
 }
 
@@ -359,7 +360,9 @@ long long slab_ws(const SlabGeom& g, const tfl_sim_state* s, float* ws, SlabWs* 
 
 struct Win { int a, b; };
 Win ext(const SlabGeom& g, int below, int above) {
-  Win w; w.a = g.o0 - below < 0 ? 0 : g.o0 - below; w.b = g.o1 + above > g.Zl ? g.Zl : g.o1 + above; return w;
+  Win w;
+  static const int widen = getenv("TFL_SLAB_WIDEN") ? atoi(getenv("TFL_SLAB_WIDEN")) : 0;   // development aid
+  below += widen; above += widen; w.a = g.o0 - below < 0 ? 0 : g.o0 - below; w.b = g.o1 + above > g.Zl ? g.Zl : g.o1 + above; return w;
 }
 int set_win(tfl_ctx* c, Win w) { return tfl_set_z_window(c, w.a, w.b, 0, 0); }
 #define WIN(call) do { int wrc_ = (call); if (wrc_) return wrc_; } while (0)
@@ -379,7 +382,7 @@ Split split_owned(const SlabGeom& g, int k) {
 struct StageGuard {          // whatever happens, leave the context with no window / stage mask / dx override
   tfl_ctx* c;
   explicit StageGuard(tfl_ctx* ctx) : c(ctx) {}
-  ~StageGuard() { (void)tfl_set_z_window(c, 0, 0, 0, 0); (void)tfl_set_stages(c, 0); (void)tfl_set_dx_override(c, 0.0f); }
+  ~StageGuard() { (void)tfl_set_z_window(c, 0, 0, 0, 0); (void)tfl_set_stages(c, 0); c->dx_dim = 0; (void)tfl_set_z_origin(c, 0, 0); }
 };
 
 }  // namespace
@@ -459,7 +462,8 @@ int tfl_simulate_step_slab(tfl_ctx* c, const tfl_sim_params* prm, const tfl_sim_
       tfl::absmax(c->stream, (long long)g.Zl * g.yx, s->U->data + (3ll * b + 2) * g.Zl * g.yx, c->d_reach, b == 0);
     (void)hipMemcpyAsync(c->h_reach, c->d_reach, sizeof(float), hipMemcpyDeviceToHost, c->stream);
   }
-  (void)tfl_set_dx_override(c, (float)(1.0 / (double)std::max(std::max(s->flags->X, s->flags->Y), sl->z_total)));
+  c->dx_dim = std::max(std::max(s->flags->X, s->flags->Y), sl->z_total);   // tfluids.getDx of the WHOLE grid
+  (void)tfl_set_z_origin(c, sl->z_first, sl->z_total);
   const bool buoyant = s->n_density > 0 && prm->buoyancyScale > 0.0;
   const tfl_tensor* rho = s->n_density > 0 ? s->density[0] : nullptr;
 
@@ -500,7 +504,7 @@ int tfl_simulate_step_slab(tfl_ctx* c, const tfl_sim_params* prm, const tfl_sim_
 
   // ---- forces --------------------------------------------------------------------------------------------------------
   const double dx = tfl_getDx(c, s->flags);
-  WIN(set_win(c, ext(g, 3, 3)));
+  WIN(set_win(c, ext(g, 3, 4)));
   if (buoyant) {
     const float sc = (float)(-(dx / 4.0) * prm->buoyancyScale);
     const float gv[3] = {prm->gravity[0] * sc, prm->gravity[1] * sc, prm->gravity[2] * sc};
@@ -513,9 +517,9 @@ int tfl_simulate_step_slab(tfl_ctx* c, const tfl_sim_params* prm, const tfl_sim_
   }
   if (prm->vorticityConfinementAmp > 0.0) {
     const float strength = (float)(dx * prm->vorticityConfinementAmp);
-    (void)tfl_set_stages(c, 2); WIN(set_win(c, ext(g, 2, 1)));
+    (void)tfl_set_stages(c, 2); WIN(set_win(c, ext(g, 2, 2)));
     rc = tfl_vorticityConfinement(c, s->U, s->flags, strength, &curl, &curl, &cnorm, &curl, is3D); if (rc) return rc;
-    (void)tfl_set_stages(c, 4); WIN(set_win(c, ext(g, 0, 0)));
+    (void)tfl_set_stages(c, 4); WIN(set_win(c, ext(g, 0, 1)));
     rc = tfl_vorticityConfinement(c, s->U, s->flags, strength, &curl, &curl, &cnorm, &curl, is3D); if (rc) return rc;
   }
   (void)tfl_set_stages(c, 0); (void)tfl_set_z_window(c, 0, 0, 0, 0);

@@ -15,7 +15,9 @@ struct tfl_ctx {
   double* d_resid = nullptr;                  // Jacobi residual accumulators [kMaxBatch]
   double* h_resid = nullptr;                  // pinned mirror
   float dx_override = 0.0f;                   // > 0: use instead of 1/max(X,Y,Z) (z-slab ranks: global dx)
+  int dx_dim = 0;                             // > 0: dx = 1/dx_dim formed exactly like getDx does (tfl_simulate_step_slab)
   tfl::ZWin zwin = {0, 0, 0, 0};              // tfl_set_z_window: planes the next operators compute (all zero = all)
+  tfl::ZOrigin zorigin = {0, 0};              // tfl_set_z_origin: where the arrays sit in the whole grid (z-slab ranks)
   int stages = 0;                             // tfl_set_stages: which passes of a multi-pass operator run (0 = all)
   float* d_reach = nullptr;                   // z-slab reach check: max|u_z| of the current step (device word)
   float* h_reach = nullptr;                   // pinned mirror, read by the NEXT tfl_simulate_step_slab call

@@ -37,6 +37,11 @@ struct Dom {
   // phase only on the planes whose inputs are valid (tfl_set_z_window, csrc/simulate.cpp), in at most two runs
   // (the two boundary strips of an interior/boundary split go out as ONE launch).
   int w0, n0, w1, nw;
+  // z-slab ranks: the array holds planes [zg, zg + Z) of a Zg-deep grid (tfl_set_z_origin; default zg = 0, Zg = Z).
+  // Back-trace positions are formed in GLOBAL z -- (k + zg) + 0.5 - u*dt rounds exactly as the unsplit grid's
+  // k_global + 0.5 - u*dt does, a position relative to the slab would round differently whenever the two indices
+  // fall into different binades -- and are turned into local plane indices only to address memory.
+  int zg, Zg;
 };
 
 // (batch item, z-plane) of a block: blockIdx.z enumerates the window's planes, batch item by batch item
@@ -141,7 +146,8 @@ __device__ __forceinline__ Lerp build_index(const Dom& d, v3 pos) {
   lerp_axis(pos.x - 0.5f, d.X, L.xi, L.s0, L.s1);
   lerp_axis(pos.y - 0.5f, d.Y, L.yi, L.t0, L.t1);
   if (IS3D) {
-    lerp_axis(pos.z - 0.5f, d.Z, L.zi, L.f0, L.f1);
+    lerp_axis(pos.z - 0.5f, d.Zg, L.zi, L.f0, L.f1);
+    L.zi -= d.zg;
   } else {
     // Z == 1: the 2-D samplers only ever touch plane 0 (weights as the reference computes them)
     const float pz = pos.z - 0.5f;
@@ -216,11 +222,11 @@ __device__ __forceinline__ v3 sample_vel(const Dom& d, const float* __restrict__
 
 __device__ __forceinline__ bool out_of_domain(const Dom& d, v3 p) {  // :43-51 (walls count as outside)
   return p.x <= 0.0f || p.x >= (float)d.X || p.y <= 0.0f || p.y >= (float)d.Y || p.z <= 0.0f ||
-         p.z >= (float)d.Z;
+         p.z >= (float)d.Zg;
 }
 // :86-91 + :53-62; -1 when the cell index falls outside the grid (the CPU reference raises)
 __device__ __forceinline__ int blocked_at(const Dom& d, const float* __restrict__ flags, v3 p) {
-  const int i = (int)p.x, j = (int)p.y, k = (int)p.z;
+  const int i = (int)p.x, j = (int)p.y, k = (int)p.z - d.zg;
   if (i < 0 || i >= d.X || j < 0 || j >= d.Y || k < 0 || k >= d.Z) return -1;
   return fluid_at(d, flags, i, j, k) ? 0 : 1;
 }
@@ -228,7 +234,7 @@ __device__ __forceinline__ int blocked_at(const Dom& d, const float* __restrict_
 // blocked_at for a position already known to be inside the domain (0 < p < N on every axis, so the truncated
 // cell index is in range and the reference's out-of-grid error cannot fire): skips the six range tests
 __device__ __forceinline__ int blocked_inside(const Dom& d, const float* __restrict__ flags, v3 p) {
-  return fluid_at(d, flags, (int)p.x, (int)p.y, (int)p.z) ? 0 : 1;
+  return fluid_at(d, flags, (int)p.x, (int)p.y, (int)p.z - d.zg) ? 0 : 1;
 }
 
 // Ray/box test, calc_line_trace.cc:101-171
@@ -268,7 +274,7 @@ __device__ inline bool ray_box(const float* lo, const float* hi, const float* or
 __device__ inline bool ray_border(const Dom& d, v3 pos, v3 next, v3& ipos) {
   float min_step = 3.402823466e+38f;
   const float p[3] = {pos.x, pos.y, pos.z}, n[3] = {next.x, next.y, next.z};
-  const float sz[3] = {(float)d.X, (float)d.Y, (float)d.Z};
+  const float sz[3] = {(float)d.X, (float)d.Y, (float)d.Zg};
 #pragma unroll
   for (int a = 0; a < 3; a++) {
     if (n[a] <= TFL_HIT_MARGIN) {
@@ -308,7 +314,7 @@ __device__ inline int line_trace(const Dom& d, const float* __restrict__ flags, 
       if (!ray_border(d, out, next, ip)) {
         ip.x = stdmin(stdmax(next.x, TFL_HIT_MARGIN), (float)d.X - TFL_HIT_MARGIN);
         ip.y = stdmin(stdmax(next.y, TFL_HIT_MARGIN), (float)d.Y - TFL_HIT_MARGIN);
-        ip.z = stdmin(stdmax(next.z, TFL_HIT_MARGIN), (float)d.Z - TFL_HIT_MARGIN);
+        ip.z = stdmin(stdmax(next.z, TFL_HIT_MARGIN), (float)d.Zg - TFL_HIT_MARGIN);
       }
       if (out_of_domain(d, ip)) return -3;
       if (!blocked_inside(d, flags, ip)) { out = ip; return 1; }
@@ -344,8 +350,8 @@ __device__ inline int line_trace(const Dom& d, const float* __restrict__ flags, 
   return 0;
 }
 
-__device__ __forceinline__ v3 cell_centre(int i, int j, int k) {
-  return mk3((float)i + 0.5f, (float)j + 0.5f, (float)k + 0.5f);
+__device__ __forceinline__ v3 cell_centre(const Dom& d, int i, int j, int k) {   // k: local plane; position: global z
+  return mk3((float)i + 0.5f, (float)j + 0.5f, (float)(k + d.zg) + 0.5f);
 }
 
 __device__ __forceinline__ void count_trace_error(int rc, unsigned long long* err) {

@@ -11,10 +11,15 @@ namespace tfl {
 // launch): planes [a0, a1) and [b0, b1) in array indices; all zero = the whole array.
 struct ZWin { int a0, a1, b0, b1; };
 extern thread_local ZWin g_zwin;
+// z origin of the array inside the whole grid (tfl_set_z_origin): {first global plane, planes of the whole grid}; {0, 0} = none
+struct ZOrigin { int first, total; };
+extern thread_local ZOrigin g_zorigin;
 
 inline Dom make_dom(int Z, int Y, int X) {
   Dom d; d.X = X; d.Y = Y; d.Z = Z; d.sy = X; d.sz = X * Y; d.sc = X * Y * Z; d.one = 1;
   d.w0 = 0; d.n0 = Z; d.w1 = 0; d.nw = Z;
+  d.zg = 0; d.Zg = Z;
+  if (g_zorigin.total > 0) { d.zg = g_zorigin.first; d.Zg = g_zorigin.total; }
   const ZWin w = g_zwin;
   if (w.a1 > w.a0 || w.b1 > w.b0) {
     auto clip = [Z](int v) { return v < 0 ? 0 : (v > Z ? Z : v); };

@@ -10,7 +10,7 @@ The step itself is native: tfl_simulate_step_slab (fluidnet_amd/csrc/simulate.cp
 the narrowest z-window that keeps the owned planes exact (a few redundant planes per phase instead of a fixed wide
 halo), packs the halo messages, and calls back into THIS module only to move them:
     U (R+1 planes) and p (4 / 3 planes)      leave at the end of a step, are consumed by the next one
-    advected U (3) + density (max(4, 2R+1))  after MacCormack pass B, overlapped with the interior of pass B
+    advected U (3 / 4) + density (max(4, 2R+1))  after MacCormack pass B, overlapped with the interior of pass B
     divergence (4 / 3)                        overlapped with the interior of the first conv layer
 plus one 2-double all-reduce for the ConvNet's global std(U) normaliser (lib/model.lua:93-117). xGMI is point-to-point:
 a slab only ever talks to ranks r-1 and r+1, each over its own link, so every exchange is one grouped send/recv pair

@@ -325,6 +325,12 @@ int tfl_packPlanes(tfl_ctx* ctx, int n, const tfl_tensor* const* fields, int zlo
  * can leave) and interior (computed while the message is in flight). */
 int tfl_set_z_window(tfl_ctx* ctx, int a0, int a1, int b0, int b1);
 
+/* Where the tensors of the next advectScalar / advectVel calls sit inside the whole grid: local plane 0 is global plane
+ * z_first of z_total. The back-traces then form their positions in GLOBAL z, so that a slab rounds every position
+ * exactly like the unsplit grid does (a slab-relative coordinate lands in another binade and rounds differently);
+ * the domain walls of the trace are those of the whole grid. (0, 0) = the tensors are the whole grid (default). */
+int tfl_set_z_origin(tfl_ctx* ctx, int z_first, int z_total);
+
 /* Pass selection for the multi-pass operators (0 = all passes, the default), so that each pass can get its own
  * window: advectScalar 1 = 3^dim min/max grid, 2 = pass A (forward), 4 = pass B (backward + correct + clamp);
  * advectVel 2 / 4 likewise; vorticityConfinement 2 = curl, 4 = confinement force; tfl_model_begin 2 = wall BCs +
@@ -382,7 +388,7 @@ int64_t tfl_simulate_slab_workspace_floats(tfl_ctx* ctx, const tfl_sim_params* p
  * at the end of one step are consumed by the next).
  * Per step: three neighbour exchanges + one 2*B-double all-reduce --
  *   U(R+1 planes) | p(4 below, 3 above)   started at the end of the previous step, consumed at the start / before conv 1
- *   advected U(3) + density(max(4, 2R+1)) after MacCormack pass B, overlapped with the interior of pass B
+ *   advected U(3 below, 4 above) + density(max(4, 2R+1)) after MacCormack pass B, overlapped with its interior
  *   divergence(4 below, 3 above)          overlapped with the interior of the first conv layer
  * and every phase runs under the narrowest z-window that keeps the owned planes exact, so the redundant compute is a
  * few planes per phase instead of a fixed wide halo. */

@@ -308,12 +308,16 @@ def test_zslab_decomposition_equals_single_gpu(world, overlap):
         for _ in range(2):
             simulate_native(None, mconf, ref, model)
         run_virtual_ranks(sims, 2)
-        _assert_slabs_equal(sims, ref, 0.0 if world == 1 else 1e-6)
+        # bit for bit: back-trace positions are formed in global z (tfl_set_z_origin) and dx comes from the whole grid; only
+        # the fp64 summation order of the std all-reduce differs, which the fp32 scale almost never sees
+        _assert_slabs_equal(sims, ref, 0.0 if world == 1 else 1e-7)
     assert float(ref["UDiv"].abs().max()) > 0
-    for s in sims:       # after drain() the halo planes are valid too
-        for k in ("pDiv", "UDiv"):
-            got, want = s.batch[k], ref[k][:, :, s.lay.lo:s.lay.hi]
-            assert float((got - want).norm() / want.norm().clamp_min(1e-30)) <= 1e-6, (s.lay.rank, k)
+    for s in sims:       # after drain() the halo planes the messages refresh are valid too: U (2, 2), p (4 below, 3 above)
+        lay = s.lay
+        for k, below, above in (("UDiv", 2, 2), ("pDiv", 4, 3)):
+            a = lay.c0 - (below if lay.has_lower else 0)
+            b = lay.c1 + (above if lay.has_upper else 0)
+            assert torch.equal(s.batch[k][:, :, a:b], ref[k][:, :, lay.lo + a:lay.lo + b]), (lay.rank, k)
         s.close()
 
 
