@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py -- simulate() throughput of the MI355X-native tfluids path.
 
-Workload (BASELINE.json metric: "simulate() steps/s + Mcells/s, 3D 128^3 ConvNet projection"):
+Workload (BASELINE.json metric: "simulate() steps/s + Mcells/s, 3D 128^3 ConvNet projection, 1/2/4/8 MI355X"):
 BASELINE config 4 -- the scene of torch/fluid_net_3d_sim.lua:62-87 at res 128: plume BCs
 (createPlumeBCs(batch, {1}, plumeScale=1, rad=0.15)), buoyancyScale 2, vorticityConfinementAmp 3,
 dt 0.1, maccormackOurs with strength 0.6, ConvNet projection (3-D `default` topology, seeded weights:
@@ -10,8 +10,11 @@ the reference ships no 3-D model), plus a procedural voxel obstacle standing in 
 
   python bench.py [--gpus N] [--steps K] [--warmup W]      (N>1: launched by torch.distributed.run)
 
-N > 1 is weak scaling: every rank owns a 128^3 z-slab of a 128 x 128 x (128 N) grid (8 ranks = the
-cell count of the north-star 256^3 grid) and exchanges halo planes with its z-neighbours over RCCL.
+N = 1: the whole 128^3 grid on one GPU through ONE C-ABI call per step (tfl_simulate_step).
+N > 1: STRONG scaling of the same 128^3 grid -- the metric's 1/2/4/8 series: z-slabs of 128/N planes (+4 halo planes per
+neighbour), one tfl_simulate_step_slab call per step and rank, halo messages over RCCL send/recv (fluidnet_amd/dist.py).
+Every run also reports BASELINE config 5 (3-D 256^3, no obstacle, no confinement; cut into N z-slabs) under
+"config5_256" -- the north-star's ">= 100 steps/s at 256^3 on 8 GPUs" figure -- measured after the timed region.
 Rank 0 prints ONE JSON line. Inputs are resident in HBM before the timed region.
 """
 import argparse
@@ -108,6 +111,39 @@ def cpu_baseline(batch, mconf, layers, max_seconds=25.0, max_steps=6):
                          "reference CPU sources -O3" if kind == "reference" else "C restatement")}
 
 
+# Planes a slab rank computes beyond its own, per kernel (below + above), from the z-windows of tfl_simulate_step_slab
+# (fluidnet_amd/csrc/simulate.cpp); kernels not listed run on the owned planes only.
+SLAB_EXTRA_PLANES = {"k_minmax3": 4, "k_scalar_fwd": 2, "k_vel_fwd": 2, "k_add_buoyancy": 7, "k_add_gravity": 7, "k_curl": 4,
+                     "k_confine": 1, "k_conv3_mfma_in": 5, "k_conv3_mfma": 3, "k_conv3_mfma_tail": 1}
+
+
+def config5_scene(res, layout, device):
+    """BASELINE config 5 / config 3's scene at `res`: plume only (no obstacle, no vorticity confinement)."""
+    batch, mconf = build_scene(res, res, layout, device)
+    lo, hi = (0, res) if layout is None else (layout.lo, layout.hi)
+    zz, yy, xx = torch.meshgrid(torch.arange(lo, hi), torch.arange(res), torch.arange(res), indexing="ij")
+    border = (xx == 0) | (xx == res - 1) | (yy == 0) | (yy == res - 1) | (zz == 0) | (zz == res - 1)
+    batch["flags"] = torch.where(border, 2.0, 1.0).to(torch.float32).view(1, 1, hi - lo, res, res).contiguous().to(device)
+    return batch, dict(mconf, vorticityConfinementAmp=0)
+
+
+def make_stepper(res, world, rank, dev, model, scene):
+    """(batch, mconf, step, slab simulation or None) for a res^3 grid on `world` ranks."""
+    from fluidnet_amd.simulate import simulate_native
+    if world > 1:
+        from fluidnet_amd.dist import DistComm, SlabLayout, SlabSimulation
+        layout = SlabLayout(res, world, rank)
+        batch, mconf = scene(res, layout, dev)
+        sim = SlabSimulation(batch, mconf, model, layout, DistComm(rank, world))
+        return batch, mconf, sim.step, sim
+    batch, mconf = scene(res, None, dev)
+
+    def step():
+        # the whole simulate() step through ONE C-ABI call (tfl_simulate_step, csrc/simulate.cpp)
+        simulate_native(None, mconf, batch, model)
+    return batch, mconf, step, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -116,6 +152,7 @@ def main():
     ap.add_argument("--res", type=int, default=128)
     ap.add_argument("--preroll", type=int, default=16, help="untimed steps that develop the plume before warm-up")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-config5", action="store_true", help="skip the extra 256^3 (BASELINE config 5) measurement")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -138,21 +175,9 @@ def main():
             dist.init_process_group(backend)
 
     from fluidnet_amd import FluidNetModel, tfluids
-    from fluidnet_amd.simulate import simulate_native
     model = FluidNetModel.default_3d(seed=1)
     res = args.res
-    if world > 1:
-        from fluidnet_amd.dist import DistComm, SlabLayout, SlabSimulation
-        layout = SlabLayout(res * world, world, rank)
-        batch, mconf = build_scene(res, res * world, layout, dev)
-        stepper = SlabSimulation(batch, mconf, model, layout, DistComm())
-        step = stepper.step
-    else:
-        batch, mconf = build_scene(res, res, None, dev)
-
-        def step():
-            # the whole simulate() step through ONE C-ABI call (tfl_simulate_step, csrc/simulate.cpp)
-            simulate_native(None, mconf, batch, model)
+    batch, mconf, step, sim = make_stepper(res, world, rank, dev, model, lambda r, lay, d: build_scene(r, r, lay, d))
 
     def barrier():
         torch.cuda.synchronize()
@@ -161,89 +186,131 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed(stepfn, n):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            stepfn()
+        barrier()
+        el = time.perf_counter() - t0
+        if world > 1:
+            import torch.distributed as dist
+            t = torch.tensor([el], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el
 
     for _ in range(args.preroll + args.warmup):
         step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        import torch.distributed as dist
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = timed(step, args.steps)
     assert bool(torch.isfinite(batch["UDiv"]).all()), "simulation blew up"
-    halo_planes = 0 if world == 1 else (batch["flags"].size(2) - res)
 
-    cells_per_gpu = res ** 3
-    total_cells = cells_per_gpu * world
+    total_cells = res ** 3
+    owned_planes = res // world
+    cells_per_gpu = owned_planes * res * res
     ms = elapsed / args.steps * 1e3
 
-    # ---- per-kernel HIP-event timing over further steps (outside the timed region) -----------------
+    # ---- per-kernel HIP-event timing over further steps (outside the timed region; rank 0's kernels) --------------
     nprof = max(3, min(10, args.steps))
     with tfluids.profile(batch["UDiv"]) as prof:
         for _ in range(nprof):
             step()
+    if sim is not None:
+        sim.drain()
     kernels = {}
     for name, rec in prof.kernels.items():
         kernels[name] = {"launches_per_step": rec["calls"] / nprof, "avg_ms": rec["ms"] / rec["calls"],
                          "ms_per_step": rec["ms"] / nprof}
     lf = [2.0 * w.shape[0] * w.shape[1] * w.shape[2] ** 3 for w, _ in model.layers]   # flop per voxel per layer
-    conv_flops_by_kernel = {"k_conv_direct": sum(lf) * cells_per_gpu, "k_conv3_mfma_in": lf[0] * cells_per_gpu,
-                            "k_conv3_mfma": lf[1] * cells_per_gpu, "k_conv3_mfma_tail": sum(lf[2:]) * cells_per_gpu}
+    conv_flops_per_voxel = {"k_conv_direct": sum(lf), "k_conv3_mfma_in": lf[0], "k_conv3_mfma": lf[1],
+                            "k_conv3_mfma_tail": sum(lf[2:])}
+
+    def cells_of(name):
+        """cells one rank's launches of this kernel cover per step: the owned planes plus the slab step's extra planes"""
+        extra = SLAB_EXTRA_PLANES.get(name, 0) if world > 1 else 0
+        return (owned_planes + extra) * res * res
+
     for name, k in kernels.items():
         if name in ALG_BYTES_PER_CELL:
-            per_launch = ALG_BYTES_PER_CELL[name] * cells_per_gpu
-            k["bound"], k["achieved"], k["unit"] = "hbm", per_launch / (k["avg_ms"] * 1e-3) / 1e9, "GB/s"
+            per_step = ALG_BYTES_PER_CELL[name] * cells_of(name)
+            k["bound"], k["achieved"], k["unit"] = "hbm", per_step / (k["ms_per_step"] * 1e-3) / 1e9, "GB/s"
             k["frac"] = k["achieved"] / HBM_PEAK_GBS
         elif name.startswith("k_conv"):
             # useful (algorithmic) conv flops of the layers this kernel name executes in one step
             k["bound"], k["unit"] = "mfma", "TFLOP/s"
-            k["achieved"] = conv_flops_by_kernel.get(name, 0.0) / (k["ms_per_step"] * 1e-3) / 1e12
+            k["achieved"] = conv_flops_per_voxel.get(name, 0.0) * cells_of(name) / (k["ms_per_step"] * 1e-3) / 1e12
             k["frac"] = k["achieved"] / FP32_PEAK_TFLOPS
-        elif name == "k_apply_bcs":
-            # x, bc, invMask -> x over U (3 ch) twice + density (1 ch) three times per step = 9 planes... per launch avg
-            per_step = (2 * 3 + 3 * 1) * 16 * cells_per_gpu
-            k["bound"], k["achieved"], k["unit"] = "hbm", per_step / (k["ms_per_step"] * 1e-3) / 1e9, "GB/s"
-            k["frac"] = k["achieved"] / HBM_PEAK_GBS
     dom = max(kernels, key=lambda n: kernels[n]["ms_per_step"])
     dk = kernels[dom]
-    traffic = None
+    traffic, traffic_source = None, None
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(tpath):
+    if world == 1 and res == 128 and os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get(dom)
+            tj = json.load(open(tpath))
+            traffic = tj.get(dom)
+            meta = tj.get("_meta", {})
+            traffic_source = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this bench at commit %s)" \
+                % meta.get("commit", "r01")
         except Exception:
             traffic = None
     roofline = {"kernel": dom, "bound": dk.get("bound"), "achieved": dk.get("achieved"),
                 "peak": HBM_PEAK_GBS if dk.get("bound") == "hbm" else FP32_PEAK_TFLOPS, "unit": dk.get("unit"),
-                "frac": dk.get("frac"), "traffic": traffic, "avg_launch_ms": dk["avg_ms"],
-                "launches_per_step": dk["launches_per_step"]}
+                "frac": dk.get("frac"), "traffic": traffic, "traffic_source": traffic_source,
+                "avg_launch_ms": dk["avg_ms"], "launches_per_step": dk["launches_per_step"],
+                "note": "sum of per-kernel averages reads ~3% above ms_per_step (dispatches overlap at their edges)"}
     headline = {}
     if "k_vel_fwd" in kernels and "k_vel_bwd" in kernels:   # the north-star's "advection kernel" figure
-        t = kernels["k_vel_fwd"]["avg_ms"] + kernels["k_vel_bwd"]["avg_ms"]
+        t = kernels["k_vel_fwd"]["ms_per_step"] + kernels["k_vel_bwd"]["ms_per_step"]
+        by = 28 * cells_of("k_vel_fwd") + 40 * cells_of("k_vel_bwd")
         headline = {"op": "advectVel (k_vel_fwd + k_vel_bwd)", "algorithmic_bytes_per_cell": 68, "ms": t,
-                    "achieved_GBps": 68 * cells_per_gpu / (t * 1e-3) / 1e9,
-                    "frac_of_hbm_peak": 68 * cells_per_gpu / (t * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                    "achieved_GBps": by / (t * 1e-3) / 1e9, "frac_of_hbm_peak": by / (t * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    redundancy = None
+    if world > 1:   # share of the kernel time spent on planes other ranks own (from this rank's measured kernel times)
+        tot = sum(k["ms_per_step"] for k in kernels.values())
+        red = sum(k["ms_per_step"] * SLAB_EXTRA_PLANES.get(n, 0) / (owned_planes + SLAB_EXTRA_PLANES.get(n, 0))
+                  for n, k in kernels.items())
+        redundancy = {"redundant_compute_frac": red / tot, "halo_planes_stored_per_neighbour": 4,
+                      "halo_planes_recomputed_per_rank": red / ((tot - red) / owned_planes),
+                      "messages_per_step": 3, "allreduces_per_step": 1}
+
+    # ---- BASELINE config 5: 256^3 cut into `world` z-slabs (after the timed region; its own short timing) -------------
+    config5 = None
+    if not args.no_config5 and res == 128 and 256 % world == 0:
+        del batch, step, sim
+        torch.cuda.empty_cache()
+        b5, m5, step5, sim5 = make_stepper(256, world, rank, dev, model, config5_scene)
+        for _ in range(6):
+            step5()
+        n5 = 20
+        el5 = timed(step5, n5)
+        if sim5 is not None:
+            sim5.drain()
+        assert bool(torch.isfinite(b5["UDiv"]).all())
+        config5 = {"workload": "BASELINE config 5: 3-D 256^3 plume, MacCormack + ConvNet projection, %s"
+                               % ("one GPU, un-sharded" if world == 1 else "%d z-slabs of %d planes, RCCL halo exchange" % (world, 256 // world)),
+                   "steps_per_s": n5 / el5, "ms_per_step": el5 / n5 * 1e3, "mcells_per_s": 256 ** 3 * n5 / el5 / 1e6,
+                   "steps": n5, "n_gpus": world}
 
     out = {
         "metric": "simulate_mcells_per_s", "value": total_cells * args.steps / elapsed / 1e6, "unit": "Mcells/s",
         "steps_per_s": args.steps / elapsed, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "ms_per_step": ms, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic",
-        "config": {"workload": "BASELINE config 4: 3-D %d^3 plume + voxel obstacle (procedural stand-in), "
-                               "MacCormack(Ours) advection, buoyancy, vorticity confinement, ConvNet projection "
-                               "(3-D default topology, seeded weights); per-GPU z-slab of %d^3 cells" % (res, res),
-                   "grid_zyx": [res * world, res, res], "per_gpu_grid_zyx": [res, res, res],
+        "config": {"workload": "BASELINE config 4 / the metric's 128^3 series: 3-D %d^3 plume + voxel obstacle (procedural "
+                               "stand-in), MacCormack(Ours) advection, buoyancy, vorticity confinement, ConvNet projection "
+                               "(3-D default topology, seeded weights); %s" % (res, "single GPU" if world == 1 else
+                               "strong scaling: %d z-slabs of %d planes" % (world, owned_planes)),
+                   "grid_zyx": [res, res, res], "per_gpu_grid_zyx": [owned_planes, res, res],
                    "decomposition": "single GPU" if world == 1 else "z-slabs, %d ranks, RCCL halo exchange" % world,
-                   "preroll_steps": args.preroll, "halo_planes_recomputed_per_rank": halo_planes},
-        "roofline": roofline, "advection_headline": headline, "kernels": kernels,
+                   "preroll_steps": args.preroll, "slab": redundancy},
+        "roofline": roofline, "advection_headline": headline, "config5_256": config5, "kernels": kernels,
     }
     if rank == 0 and not args.no_cpu_baseline and world == 1:
-        out["cpu_baseline"] = cpu_baseline(batch, mconf, model.layers)
+        b1, m1 = build_scene(res, res, None, dev)
+        for _ in range(args.preroll):
+            from fluidnet_amd.simulate import simulate_native
+            simulate_native(None, m1, b1, model)
+        out["cpu_baseline"] = cpu_baseline(b1, m1, model.layers)
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0:
