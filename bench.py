@@ -113,8 +113,9 @@ def cpu_baseline(batch, mconf, layers, max_seconds=25.0, max_steps=6):
 
 # Planes a slab rank computes beyond its own, per kernel (below + above), from the z-windows of tfl_simulate_step_slab
 # (fluidnet_amd/csrc/simulate.cpp); kernels not listed run on the owned planes only.
-SLAB_EXTRA_PLANES = {"k_minmax3": 4, "k_scalar_fwd": 2, "k_vel_fwd": 2, "k_add_buoyancy": 7, "k_add_gravity": 7, "k_curl": 4,
-                     "k_confine": 1, "k_conv3_mfma_in": 5, "k_conv3_mfma": 3, "k_conv3_mfma_tail": 1}
+SLAB_EXTRA_PLANES = {"k_minmax3": (2, 2), "k_scalar_fwd": (1, 1), "k_vel_fwd": (1, 1), "k_add_buoyancy": (3, 4),
+                     "k_add_gravity": (3, 4), "k_curl": (2, 2), "k_confine": (0, 1), "k_conv3_mfma_in": (3, 2),
+                     "k_conv3_mfma": (2, 1), "k_conv3_mfma_tail": (1, 0)}
 
 
 def config5_scene(res, layout, device):
@@ -227,8 +228,8 @@ def main():
 
     def cells_of(name):
         """cells one rank's launches of this kernel cover per step: the owned planes plus the slab step's extra planes"""
-        extra = SLAB_EXTRA_PLANES.get(name, 0) if world > 1 else 0
-        return (owned_planes + extra) * res * res
+        below, above = SLAB_EXTRA_PLANES.get(name, (0, 0)) if world > 1 else (0, 0)
+        return (owned_planes + (below if rank > 0 else 0) + (above if rank < world - 1 else 0)) * res * res
 
     for name, k in kernels.items():
         if name in ALG_BYTES_PER_CELL:
@@ -265,12 +266,14 @@ def main():
         headline = {"op": "advectVel (k_vel_fwd + k_vel_bwd)", "algorithmic_bytes_per_cell": 68, "ms": t,
                     "achieved_GBps": by / (t * 1e-3) / 1e9, "frac_of_hbm_peak": by / (t * 1e-3) / 1e9 / HBM_PEAK_GBS}
     redundancy = None
-    if world > 1:   # share of the kernel time spent on planes other ranks own (from this rank's measured kernel times)
-        tot = sum(k["ms_per_step"] for k in kernels.values())
-        red = sum(k["ms_per_step"] * SLAB_EXTRA_PLANES.get(n, 0) / (owned_planes + SLAB_EXTRA_PLANES.get(n, 0))
-                  for n, k in kernels.items())
-        redundancy = {"redundant_compute_frac": red / tot, "halo_planes_stored_per_neighbour": 4,
-                      "halo_planes_recomputed_per_rank": red / ((tot - red) / owned_planes),
+    if world > 1:
+        # Redundant compute of an INTERIOR rank (two neighbours), from this rank's measured time per plane of each kernel:
+        # planes it computes beyond its own, weighted by what a plane of that kernel costs.
+        per_plane = {n: k["ms_per_step"] / (cells_of(n) / (res * res)) for n, k in kernels.items()}
+        own = sum(per_plane[n] * owned_planes for n in kernels)
+        red = sum(per_plane[n] * sum(SLAB_EXTRA_PLANES.get(n, (0, 0))) for n in kernels)
+        redundancy = {"redundant_compute_frac": red / (own + red), "halo_planes_stored_per_neighbour": 4,
+                      "halo_planes_recomputed_per_rank": red / (own / owned_planes),
                       "messages_per_step": 3, "allreduces_per_step": 1}
 
     # ---- BASELINE config 5: 256^3 cut into `world` z-slabs (after the timed region; its own short timing) -------------
