@@ -19,12 +19,16 @@
 
 struct tfl_layer {
   int cin = 0, cout = 0, k = 0;
-  float* w = nullptr;  // device, [tap][cin][cout]
-  float* b = nullptr;  // device, [cout]
+  int pool = 1;        // 2: 2x average pooling after the non-linearity (model_utils.lua:184-208)
+  int up = 1;          // 2: {Spatial,Volumetric}ConvolutionUpsample -- up^dim sub-position convolutions, pixel-shuffled
+  float* w = nullptr;  // device, [sub][tap][cin][cout]
+  float* b = nullptr;  // device, [sub][cout]
 };
 struct tfl_model {
   bool is3d = false;
   int max_c = 0;
+  bool multires = false;   // some layer pools / upsamples (the `tog` topologies)
+  int max_down = 1;        // coarsest activation resolution = grid / max_down
   std::vector<tfl_layer> layers;
   // 3-D `default` topology (3->8 k3, 8->8 k3, 8->8 k3, 8->8 k1, 8->1 k1): MFMA path (conv_mfma.hip)
   bool mfma3d = false;
@@ -513,6 +517,12 @@ int tfl_solveLinearSystemJacobi(tfl_ctx* c, const tfl_tensor* p, const tfl_tenso
 
 tfl_model* tfl_model_create(tfl_ctx* c, int is3D, int nlayers, const int32_t* cin, const int32_t* cout,
                             const int32_t* ksize, const float* const* weights, const float* const* biases) {
+  return tfl_model_create_ex(c, is3D, nlayers, cin, cout, ksize, nullptr, nullptr, weights, biases);
+}
+
+tfl_model* tfl_model_create_ex(tfl_ctx* c, int is3D, int nlayers, const int32_t* cin, const int32_t* cout,
+                               const int32_t* ksize, const int32_t* pool, const int32_t* up,
+                               const float* const* weights, const float* const* biases) {
   if (!c) return nullptr;
   auto bad = [&](const char* m) -> tfl_model* { fail(c, TFL_EINVAL, "model_create: %s", m); return nullptr; };
   if (nlayers < 1 || !cin || !cout || !ksize || !weights || !biases) return bad("null or empty layer description");
@@ -522,44 +532,59 @@ tfl_model* tfl_model_create(tfl_ctx* c, int is3D, int nlayers, const int32_t* ci
   m->is3d = is3D != 0;
   auto cleanup = [&](const char* msg) -> tfl_model* { tfl_model_destroy(c, m); return bad(msg); };
   if (hipMalloc((void**)&m->d_stats, sizeof(double) * 2 * kMaxBatch) != hipSuccess) return cleanup("hipMalloc failed");
-  // The shape-generic kernels are instantiated for 1, 2, 4, 8, 16, 32 output channels. Any other width (the
+  // The shape-generic kernels are instantiated for 1, 2, 4, 8, 16, 32, 64 output channels. Any other width (the
   // `yang` topology of model.lua:188-205 has 6) is zero-padded to the next one: the extra channels carry
   // relu(0 + 0) = 0 into zero weights of the next layer, i.e. every sum gains exact `+ 0 * 0` terms only.
-  auto padded = [](int cch) { for (int w : {1, 2, 4, 8, 16, 32}) if (cch <= w) return w; return -1; };
+  auto padded = [](int cch) { for (int w : {1, 2, 4, 8, 16, 32, 64}) if (cch <= w) return w; return -1; };
   int prev_cout_padded = 3;
+  int res_num = 1, res_den = 1;   // resolution of the current activations relative to the grid = res_num / res_den
   for (int l = 0; l < nlayers; l++) {
     tfl_layer L;
     if (cin[l] < 1 || cout[l] < 1 || ksize[l] < 1 || (ksize[l] % 2) != 1) return cleanup("convolution size must be odd and positive");
     if (l > 0 && cin[l] != cout[l - 1]) return cleanup("layer channel counts do not chain");
+    L.pool = pool ? pool[l] : 1; L.up = up ? up[l] : 1;
+    if ((L.pool != 1 && L.pool != 2) || (L.up != 1 && L.up != 2)) return cleanup("pooling / upsampling factors must be 1 or 2");
+    if (L.pool > 1 && L.up > 1) return cleanup("Pooling and upsampling in the same layer!");               // model.lua:322-324
+    if (L.pool > 1 && l + 1 == nlayers) return cleanup("Pooling is not allowed in the last layer");        // model.lua:247
+    res_num *= L.up; res_den *= L.pool;
+    if (res_num > res_den) return cleanup("a layer upsamples beyond the grid resolution");
+    if (L.pool > 1 || L.up > 1 || res_num != res_den) m->multires = true;
+    if (res_den / res_num > m->max_down) m->max_down = res_den / res_num;
     const int cout_p = (l + 1 == nlayers) ? cout[l] : padded(cout[l]);
-    if (cout_p < 0) return cleanup("unsupported output channel count (at most 32)");
+    if (cout_p < 0) return cleanup("unsupported output channel count (at most 64)");
     const int cin_p = prev_cout_padded;
     L.cin = cin_p; L.cout = cout_p; L.k = ksize[l];
     prev_cout_padded = cout_p;
     const int taps = m->is3d ? L.k * L.k * L.k : L.k * L.k;
-    std::vector<float> relaid((size_t)taps * L.cin * L.cout, 0.0f);
-    for (int co = 0; co < cout[l]; co++)
-      for (int ci = 0; ci < cin[l]; ci++)
-        for (int t = 0; t < taps; t++)
-          relaid[((size_t)t * L.cin + ci) * L.cout + co] = weights[l][((size_t)co * cin[l] + ci) * taps + t];
-    std::vector<float> bias_p((size_t)L.cout, 0.0f);
-    for (int co = 0; co < cout[l]; co++) bias_p[co] = biases[l][co];
+    const int S = m->is3d ? L.up * L.up * L.up : L.up * L.up;
+    // cudnn weight [cout*S][cin][taps] (output channel index = o*S + sub) -> [sub][tap][cin_p][cout_p]
+    std::vector<float> relaid((size_t)S * taps * L.cin * L.cout, 0.0f);
+    for (int sub = 0; sub < S; sub++)
+      for (int co = 0; co < cout[l]; co++)
+        for (int ci = 0; ci < cin[l]; ci++)
+          for (int t = 0; t < taps; t++)
+            relaid[(((size_t)sub * taps + t) * L.cin + ci) * L.cout + co] =
+                weights[l][(((size_t)co * S + sub) * cin[l] + ci) * taps + t];
+    std::vector<float> bias_p((size_t)S * L.cout, 0.0f);
+    for (int sub = 0; sub < S; sub++)
+      for (int co = 0; co < cout[l]; co++) bias_p[(size_t)sub * L.cout + co] = biases[l][(size_t)co * S + sub];
     if (hipMalloc((void**)&L.w, relaid.size() * sizeof(float)) != hipSuccess ||
-        hipMalloc((void**)&L.b, L.cout * sizeof(float)) != hipSuccess ||
+        hipMalloc((void**)&L.b, bias_p.size() * sizeof(float)) != hipSuccess ||
         hipMemcpy(L.w, relaid.data(), relaid.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(L.b, bias_p.data(), L.cout * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+        hipMemcpy(L.b, bias_p.data(), bias_p.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
       m->layers.push_back(L);
       return cleanup("uploading weights failed");
     }
     m->layers.push_back(L);
     if (L.cout > m->max_c && l + 1 < nlayers) m->max_c = L.cout;
   }
+  if (res_num != res_den) return cleanup("the layers do not return to the grid resolution (pool / up factors)");
   if (m->max_c < 1) m->max_c = 1;
   // ---- MFMA path for the 3-D default topology (TFL_CONV_PATH=direct forces the generic kernels) ----
   const char* force = getenv("TFL_CONV_PATH");
   const bool want_mfma = !(force && strcmp(force, "direct") == 0);
   const int dflt[5][3] = {{3, 8, 3}, {8, 8, 3}, {8, 8, 3}, {8, 8, 1}, {8, 1, 1}};
-  bool match = m->is3d && nlayers == 5;
+  bool match = m->is3d && nlayers == 5 && !m->multires;
   for (int l = 0; match && l < 5; l++) match = cin[l] == dflt[l][0] && cout[l] == dflt[l][1] && ksize[l] == dflt[l][2];
   if (match && want_mfma) {
     for (int l = 0; l < 3; l++) {
@@ -586,7 +611,7 @@ tfl_model* tfl_model_create(tfl_ctx* c, int is3D, int nlayers, const int32_t* ci
     m->mfma3d = true;
   }
   const int dflt2[5][3] = {{3, 16, 3}, {16, 16, 3}, {16, 16, 3}, {16, 16, 3}, {16, 1, 1}};
-  bool match2 = !m->is3d && nlayers == 5;
+  bool match2 = !m->is3d && nlayers == 5 && !m->multires;
   for (int l = 0; match2 && l < 5; l++) match2 = cin[l] == dflt2[l][0] && cout[l] == dflt2[l][1] && ksize[l] == dflt2[l][2];
   if (match2 && want_mfma) {
     for (int l = 0; l < 4; l++) {
@@ -719,15 +744,31 @@ int tfl_model_finish(tfl_ctx* c, tfl_model* m, const tfl_tensor* pDiv, const tfl
     tfl::conv2_mfma_mid(st, B, Y, X, w.act[1], m->bfrag2[2], m->layers[2].b, w.act[0]);
     tfl::conv2_mfma_tail(st, B, Y, X, w.act[0], m->bfrag2[3], m->layers[3].b, m->tail_w5, m->layers[4].b, w.pPred);
   } else {
+    if (m->multires && ((m->is3d && Z % m->max_down) || Y % m->max_down || X % m->max_down))
+      return fail(c, TFL_EINVAL, "model_finish: grid %dx%dx%d is not divisible by the model's pooling factor %d", Z, Y, X, m->max_down);
     tfl::model_net_input(st, m->is3d, B, Z, Y, X, pDiv->data, w.div, flags->data, st_in, count, w.x3);
     const float* in = w.x3;
+    int Zc = Z, Yc = Y, Xc = X;     // resolution of `in`
     for (size_t l = 0; l < m->layers.size(); l++) {
       const tfl_layer& L = m->layers[l];
       const bool last = l + 1 == m->layers.size();
-      float* out = last ? w.pPred : w.act[l & 1];
-      if (!tfl::conv_direct(st, m->is3d, B, Z, Y, X, L.cin, L.cout, L.k, !last, in, L.w, L.b, out))
-        return fail(c, TFL_EUNSUPPORTED, "model_finish: no kernel for %d output channels", L.cout);
+      float* out = last ? w.pPred : (in == w.act[0] ? w.act[1] : w.act[0]);
+      const int taps = m->is3d ? L.k * L.k * L.k : L.k * L.k;
+      const int S = m->is3d ? L.up * L.up * L.up : L.up * L.up;
+      for (int sub = 0; sub < S; sub++)      // ConvolutionUpsample: one strided-store convolution per sub-position
+        if (!tfl::conv_direct(st, m->is3d, B, Zc, Yc, Xc, L.cin, L.cout, L.k, !last, in, L.w + (size_t)sub * taps * L.cin * L.cout,
+                              L.b + (size_t)sub * L.cout, out, L.up, sub))
+          return fail(c, TFL_EUNSUPPORTED, "model_finish: no kernel for %d output channels", L.cout);
+      if (m->is3d) Zc *= L.up;
+      Yc *= L.up; Xc *= L.up;
       in = out;
+      if (L.pool > 1) {
+        float* pooled = in == w.act[0] ? w.act[1] : w.act[0];
+        tfl::avg_pool2(st, m->is3d, B * L.cout, Zc, Yc, Xc, in, pooled);
+        if (m->is3d) Zc /= 2;
+        Yc /= 2; Xc /= 2;
+        in = pooled;
+      }
     }
   }
   if (stg & 8)

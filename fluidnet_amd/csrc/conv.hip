@@ -4,21 +4,33 @@
 // torch/lib/model_utils.lua:80-116: stride 1, zero padding (k-1)/2, cross-correlation, bias, with the
 // following nn.ReLU fused into the epilogue. Activations are channel-planar fp32 [B][C][Z][Y][X].
 //
-// k_conv_direct is the shape-generic path (any C_in, k; C_out in {1, 2, 4, 8, 16, 32}): one thread
+// k_conv_direct is the shape-generic path (any C_in, k; C_out in {1, 2, 4, 8, 16, 32, 64}): one thread
 // per voxel holding all C_out accumulators in registers; the weights are re-laid out on the host as
 // [tap][c_in][c_out] so every weight address is wave-uniform and travels through the scalar cache
 // (s_load), leaving the vector memory path to the activations. The fmaf chain is exact fp32.
+//
+// The `tog` topologies (lib/model.lua:163-178, 211-218) add two things, both here: 2x average pooling after a layer
+// (cudnn.{Spatial,Volumetric}AveragePooling(2,..,2), model_utils.lua:184-208) = k_avg_pool2, and
+// nn.{Spatial,Volumetric}ConvolutionUpsample (lib/modules/spatial_convolution_upsample.lua:24-93,
+// volumetric_convolution_upsample.lua): a convolution to up^dim * C_out channels whose result is pixel-shuffled,
+// out[b][o][z*u+a][y*u+b][x*u+c] = conv[b][((o*u + a)*u + b)*u + c][z][y][x]. The shuffle costs nothing here: the conv
+// is launched once per sub-position (a, b, c) with that sub-position's weight slice and a strided store (ConvUp).
 #include "tfl_device.hpp"
 #include "tfl_host.hpp"
 
 namespace tfl {
+
+struct ConvUp {      // output placement: voxel (i, j, k) of the conv grid goes to (i*u + a, j*u + b, k*uz + c) of `dout`
+  int u, uz, a, b, c;
+  int oX, oY, oZ;    // size of the output grid
+};
 
 // CPT = output channels per thread: COUT for large grids (each activation is loaded once), COUT/4 for small
 // ones where the grid would otherwise leave most CUs idle (2-D 128^2 = 64 blocks of 256 threads).
 template <bool IS3D, int COUT, int CPT, bool RELU>
 __global__ __launch_bounds__(256) void k_conv_direct(Dom d, int cin, int ksz, const float* __restrict__ in,
                                                      const float* __restrict__ w, const float* __restrict__ bias,
-                                                     float* __restrict__ out) {
+                                                     float* __restrict__ out, ConvUp up) {
   constexpr int G = COUT / CPT;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int j = blockIdx.y * blockDim.y + threadIdx.y;
@@ -26,7 +38,8 @@ __global__ __launch_bounds__(256) void k_conv_direct(Dom d, int cin, int ksz, co
   const int b = zg / d.Z, k = zg - b * d.Z;
   if (i >= d.X || j >= d.Y) return;
   const long long cells = d.sc;
-  in += b * cells * cin; out += b * cells * COUT;
+  const long long ocells = (long long)up.oX * up.oY * up.oZ;
+  in += b * cells * cin; out += b * ocells * COUT;
   float acc[CPT];
 #pragma unroll
   for (int c = 0; c < CPT; c++) acc[c] = bias[co0 + c];
@@ -60,14 +73,31 @@ __global__ __launch_bounds__(256) void k_conv_direct(Dom d, int cin, int ksz, co
       }
     }
   }
-  const int o = TFL_AT(d, i, j, k);
+  const long long o = (i * up.u + up.a) + (long long)up.oX * ((j * up.u + up.b) + (long long)up.oY * (k * up.uz + up.c));
 #pragma unroll
-  for (int c = 0; c < CPT; c++) out[o + (co0 + c) * d.sc] = RELU ? fmaxf(acc[c], 0.0f) : acc[c];
+  for (int c = 0; c < CPT; c++) out[o + (co0 + c) * ocells] = RELU ? fmaxf(acc[c], 0.0f) : acc[c];
+}
+
+// cudnn average pooling, window = stride = 2, no padding: out size floor(n / 2) per pooled axis (z only in 3-D)
+template <bool IS3D>
+__global__ __launch_bounds__(256) void k_avg_pool2(int rows, int Zo, int Yo, int Xo, int Z, int Y, int X,
+                                                   const float* __restrict__ in, float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = blockIdx.y * blockDim.y + threadIdx.y;
+  const int r = blockIdx.z / Zo, k = blockIdx.z - r * Zo;      // r = b*C + c
+  if (i >= Xo || j >= Yo) return;
+  const float* p = in + ((long long)r * Z + (IS3D ? 2 * k : 0)) * Y * X + (long long)(2 * j) * X + 2 * i;
+  float s = (p[0] + p[1]) + (p[X] + p[X + 1]);
+  if (IS3D) {
+    const float* q = p + (long long)Y * X;
+    s += (q[0] + q[1]) + (q[X] + q[X + 1]);
+  }
+  out[((long long)r * Zo + k) * Yo * Xo + (long long)j * Xo + i] = s * (IS3D ? 0.125f : 0.25f);
 }
 
 template <bool IS3D, int COUT>
 static void launch_direct(hipStream_t st, const Dom& d, int B, int cin, int ksz, bool relu, const float* in,
-                          const float* w, const float* bias, float* out) {
+                          const float* w, const float* bias, float* out, const ConvUp& up) {
   const dim3 blk(64, 4, 1);
   const unsigned nxy = ((d.X + 63) / 64) * ((d.Y + 3) / 4);
   constexpr int CPT_SMALL = COUT >= 4 ? COUT / 4 : COUT;
@@ -75,29 +105,42 @@ static void launch_direct(hipStream_t st, const Dom& d, int B, int cin, int ksz,
   TFL_TIMED("k_conv_direct", st);
   if (split) {
     const dim3 grd((d.X + 63) / 64, (d.Y + 3) / 4, (unsigned)(d.Z * B * (COUT / CPT_SMALL)));
-    if (relu) k_conv_direct<IS3D, COUT, CPT_SMALL, true><<<grd, blk, 0, st>>>(d, cin, ksz, in, w, bias, out);
-    else k_conv_direct<IS3D, COUT, CPT_SMALL, false><<<grd, blk, 0, st>>>(d, cin, ksz, in, w, bias, out);
+    if (relu) k_conv_direct<IS3D, COUT, CPT_SMALL, true><<<grd, blk, 0, st>>>(d, cin, ksz, in, w, bias, out, up);
+    else k_conv_direct<IS3D, COUT, CPT_SMALL, false><<<grd, blk, 0, st>>>(d, cin, ksz, in, w, bias, out, up);
   } else {
     const dim3 grd((d.X + 63) / 64, (d.Y + 3) / 4, (unsigned)(d.Z * B));
-    if (relu) k_conv_direct<IS3D, COUT, COUT, true><<<grd, blk, 0, st>>>(d, cin, ksz, in, w, bias, out);
-    else k_conv_direct<IS3D, COUT, COUT, false><<<grd, blk, 0, st>>>(d, cin, ksz, in, w, bias, out);
+    if (relu) k_conv_direct<IS3D, COUT, COUT, true><<<grd, blk, 0, st>>>(d, cin, ksz, in, w, bias, out, up);
+    else k_conv_direct<IS3D, COUT, COUT, false><<<grd, blk, 0, st>>>(d, cin, ksz, in, w, bias, out, up);
   }
 }
 
 // w: device, [tap][cin][cout]. Returns false when cout has no instantiation.
 bool conv_direct(hipStream_t st, bool is3d, int B, int Z, int Y, int X, int cin, int cout, int ksz, bool relu,
-                 const float* in, const float* w, const float* bias, float* out) {
-  const Dom d = make_dom(Z, Y, X);
+                 const float* in, const float* w, const float* bias, float* out, int upf, int sub) {
+  Dom d = make_dom(Z, Y, X);
+  d.w0 = 0; d.n0 = Z; d.w1 = 0; d.nw = Z;       // the shape-generic path always covers the whole grid
+  ConvUp up;
+  up.u = upf; up.uz = is3d ? upf : 1;
+  up.a = sub % upf; up.b = (sub / upf) % upf; up.c = is3d ? sub / (upf * upf) : 0;
+  up.oX = X * up.u; up.oY = Y * up.u; up.oZ = Z * up.uz;
 #define TFL_CASE(N)                                                                        \
   case N:                                                                                  \
-    if (is3d) launch_direct<true, N>(st, d, B, cin, ksz, relu, in, w, bias, out);          \
-    else launch_direct<false, N>(st, d, B, cin, ksz, relu, in, w, bias, out);              \
+    if (is3d) launch_direct<true, N>(st, d, B, cin, ksz, relu, in, w, bias, out, up);          \
+    else launch_direct<false, N>(st, d, B, cin, ksz, relu, in, w, bias, out, up);              \
     return true;
   switch (cout) {
-    TFL_CASE(1) TFL_CASE(2) TFL_CASE(4) TFL_CASE(8) TFL_CASE(16) TFL_CASE(32)
+    TFL_CASE(1) TFL_CASE(2) TFL_CASE(4) TFL_CASE(8) TFL_CASE(16) TFL_CASE(32) TFL_CASE(64)
     default: return false;
   }
 #undef TFL_CASE
+}
+
+void avg_pool2(hipStream_t st, bool is3d, int rows, int Z, int Y, int X, const float* in, float* out) {
+  const int Zo = is3d ? Z / 2 : Z, Yo = Y / 2, Xo = X / 2;
+  const dim3 blk(64, 4, 1), grd((Xo + 63) / 64, (Yo + 3) / 4, (unsigned)(rows * Zo));
+  TFL_TIMED("k_avg_pool2", st);
+  if (is3d) k_avg_pool2<true><<<grd, blk, 0, st>>>(rows, Zo, Yo, Xo, Z, Y, X, in, out);
+  else k_avg_pool2<false><<<grd, blk, 0, st>>>(rows, Zo, Yo, Xo, Z, Y, X, in, out);
 }
 
 }  // namespace tfl

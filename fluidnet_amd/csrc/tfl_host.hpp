@@ -127,8 +127,11 @@ long long pack_planes(hipStream_t st, int n, float* const* ptrs, const int* rows
                       long long zstride, long long yx, float* buf, int unpack);
 
 // conv.hip
+// upf > 1: the result goes to sub-position `sub` (= (c*upf + b)*upf + a) of an upf-times finer output grid (pixel shuffle)
 bool conv_direct(hipStream_t st, bool is3d, int B, int Z, int Y, int X, int cin, int cout, int ksz, bool relu,
-                 const float* in, const float* w, const float* bias, float* out);
+                 const float* in, const float* w, const float* bias, float* out, int upf = 1, int sub = 0);
+// 2x average pooling of `rows` = B*C planes-stacks [Z][Y][X] -> [Z/2 (3-D)][Y/2][X/2]
+void avg_pool2(hipStream_t st, bool is3d, int rows, int Z, int Y, int X, const float* in, float* out);
 
 // conv_mfma.hip (3-D default topology: k=3, 8 output channels; x-phase-packed fp32 MFMA)
 void conv3_mfma_first(hipStream_t st, int B, int Z, int Y, int X, const float* in_planar3, const float* bfrag,

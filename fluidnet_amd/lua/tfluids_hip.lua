@@ -94,6 +94,9 @@ typedef struct tfl_model tfl_model;
 tfl_model* tfl_model_create(tfl_ctx* ctx, int is3D, int nlayers, const int32_t* cin, const int32_t* cout,
                             const int32_t* ksize, const float* const* weights,
                             const float* const* biases);
+tfl_model* tfl_model_create_ex(tfl_ctx* ctx, int is3D, int nlayers, const int32_t* cin, const int32_t* cout,
+                               const int32_t* ksize, const int32_t* pool, const int32_t* up,
+                               const float* const* weights, const float* const* biases);
 void tfl_model_destroy(tfl_ctx* ctx, tfl_model* model);
 int64_t tfl_model_workspace_floats(const tfl_model* model, int B, int Z, int Y, int X);
 int tfl_model_forward(tfl_ctx* ctx, tfl_model* model, const tfl_tensor* pDiv, const tfl_tensor* UDiv,

@@ -17,12 +17,19 @@ from ._lib import TfluidsError
 
 
 class FluidNetModel:
-    def __init__(self, layers, is3D):
+    def __init__(self, layers, is3D, pool=None, up=None):
         """layers: [(weight[nOut, nIn, k(,k),k], bias[nOut])] in forward order (numpy float32),
-        weight layout as cudnn.{Spatial,Volumetric}Convolution.weight."""
+        weight layout as cudnn.{Spatial,Volumetric}Convolution.weight. pool / up: per-layer psize / usize of
+        lib/model.lua's layer tables (1 or 2; None = all 1): 2x average pooling after a layer, or the layer is an
+        nn.{Spatial,Volumetric}ConvolutionUpsample (its weight then has nOut * 2^dim output channels)."""
         self.is3D = bool(is3D)
         self.layers = [(np.ascontiguousarray(w, np.float32), np.ascontiguousarray(b, np.float32))
                        for w, b in layers]
+        n = len(self.layers)
+        self.pool = [1] * n if pool is None else [int(v) for v in pool]
+        self.up = [1] * n if up is None else [int(v) for v in up]
+        if len(self.pool) != n or len(self.up) != n:
+            raise TfluidsError("pool / up need one entry per layer")
         for w, _ in self.layers:
             if w.ndim != (5 if self.is3D else 4):
                 raise TfluidsError("weight rank does not match is3D")
@@ -58,19 +65,41 @@ class FluidNetModel:
             layers.append((w, b))
         return cls(layers, True)
 
+    @classmethod
+    def tog(cls, is3D, seed=1, scale=0.5):
+        """Seeded stand-in for a trained `tog` model (none is shipped), single bank: the layer tables of
+        lib/model.lua:163-178 (2-D) / :211-218 (3-D) -- pooling after the first layer(s), ConvolutionUpsample at the end."""
+        if is3D:
+            osize, ksize = [16, 16, 16, 16, 32, 32, 1], [3, 3, 3, 3, 1, 1, 3]
+            psize, usize = [2, 2, 1, 1, 1, 1, 1], [1, 1, 1, 1, 1, 2, 2]
+        else:
+            osize, ksize = [16, 32, 32, 64, 64, 32, 1], [5, 5, 5, 5, 1, 1, 3]
+            psize, usize = [2, 1, 1, 1, 1, 1, 1], [1, 1, 1, 1, 1, 1, 2]
+        dim = 3 if is3D else 2
+        rng = np.random.RandomState(seed)
+        layers, ci = [], 3
+        for co, k, u in zip(osize, ksize, usize):
+            fan = ci * k ** dim
+            w = (rng.randn(co * u ** dim, ci, *([k] * dim)) * scale * math.sqrt(2.0 / fan)).astype(np.float32)
+            b = (rng.randn(co * u ** dim) * 0.01).astype(np.float32)
+            layers.append((w, b))
+            ci = co
+        return cls(layers, is3D, pool=psize, up=usize)
+
     # -- device handle -----------------------------------------------------------------------
     def _handle(self, lib, ctx, dev):
         h = self._handles.get(dev)
         if h is None:
             n = len(self.layers)
             I32 = ctypes.c_int32 * n
+            dim = 3 if self.is3D else 2
             cin = I32(*[w.shape[1] for w, _ in self.layers])
-            cout = I32(*[w.shape[0] for w, _ in self.layers])
+            cout = I32(*[w.shape[0] // (u ** dim) for (w, _), u in zip(self.layers, self.up)])
             ks = I32(*[w.shape[-1] for w, _ in self.layers])
             FP = ctypes.POINTER(ctypes.c_float)
             ws = (FP * n)(*[w.ctypes.data_as(FP) for w, _ in self.layers])
             bs = (FP * n)(*[b.ctypes.data_as(FP) for _, b in self.layers])
-            h = lib.tfl_model_create(ctx, int(self.is3D), n, cin, cout, ks, ws, bs)
+            h = lib.tfl_model_create_ex(ctx, int(self.is3D), n, cin, cout, ks, I32(*self.pool), I32(*self.up), ws, bs)
             if not h:
                 raise TfluidsError(lib.tfl_last_error(ctx).decode())
             self._handles[dev] = h

@@ -197,13 +197,23 @@ typedef struct tfl_model tfl_model;
 
 /* Builds the `default` topology: nlayers convolutions (stride 1, zero pad (k-1)/2, cross-correlation,
  * lib/model_utils.lua:80-116), ReLU after all but the last; input channels {pDiv/scale, div/scale,
- * occupancy} (cin[0] must be 3), cout[nlayers-1] must be 1. weights[l] is HOST memory laid out like
+ * occupancy} (cin[0] must be 3), cout[nlayers-1] must be 1; at most 64 channels per layer. weights[l] is HOST memory laid out like
  * cudnn.{Spatial,Volumetric}Convolution.weight: [cout][cin][k(z)][k(y)][k(x)] (no z for 2-D);
  * biases[l] is [cout]. The model copies and re-lays-out the weights; the caller keeps ownership.
  * Returns NULL on error (see tfl_last_error). */
 tfl_model* tfl_model_create(tfl_ctx* ctx, int is3D, int nlayers, const int32_t* cin, const int32_t* cout,
                             const int32_t* ksize, const float* const* weights,
                             const float* const* biases);
+/* The same with the two extra per-layer knobs of lib/model.lua's layer tables (:163-178, :211-218): pool[l] = psize
+ * (2: cudnn 2x average pooling after the layer's ReLU, model_utils.lua:184-208) and up[l] = usize (2: the layer is an
+ * nn.{Spatial,Volumetric}ConvolutionUpsample, lib/modules/*_convolution_upsample.lua -- weights[l] then has
+ * cout[l] * 2^dim output channels, channel index = o * 2^dim + sub-position, and the result is pixel-shuffled to twice
+ * the resolution). NULL = all 1. This covers the `tog` model types (2-D: 16,32,32,64,64,32,1 with k 5,5,5,5,1,1,3;
+ * 3-D: 16,16,16,16,32,32,1 with k 3,3,3,3,1,1,3); such models run through the shape-generic kernels, and the grid
+ * must be divisible by the product of the pooling factors. */
+tfl_model* tfl_model_create_ex(tfl_ctx* ctx, int is3D, int nlayers, const int32_t* cin, const int32_t* cout,
+                               const int32_t* ksize, const int32_t* pool, const int32_t* up,
+                               const float* const* weights, const float* const* biases);
 void tfl_model_destroy(tfl_ctx* ctx, tfl_model* model);
 /* Scratch floats tfl_model_forward needs for a [B][.][Z][Y][X] grid. */
 int64_t tfl_model_workspace_floats(const tfl_model* model, int B, int Z, int Y, int X);

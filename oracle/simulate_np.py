@@ -89,8 +89,9 @@ def input_scale(U_bc):
     return np.sqrt(var).astype(np.float32)
 
 
-def conv_stack(x, layers, is3d, dtype="float32"):
-    """x: [B, 3, Z, Y, X] float32; layers: [(w[nOut, nIn, k..], b)], ReLU after all but the last."""
+def conv_stack(x, layers, is3d, dtype="float32", pool=None, up=None):
+    """x: [B, 3, Z, Y, X] float32; layers: [(w[nOut, nIn, k..], b)], ReLU after all but the last. pool / up: the
+    per-layer psize / usize of lib/model.lua's `tog` tables (:163-178, :211-218)."""
     import torch
     import torch.nn.functional as F
     td = getattr(torch, dtype)
@@ -101,14 +102,25 @@ def conv_stack(x, layers, is3d, dtype="float32"):
         wt, bt = torch.from_numpy(np.asarray(w)).to(td), torch.from_numpy(np.asarray(b)).to(td)
         pad = (w.shape[-1] - 1) // 2
         h = F.conv3d(h, wt, bt, padding=pad) if is3d else F.conv2d(h, wt, bt, padding=pad)
+        u = 1 if up is None else up[li]
+        if u > 1:   # nn.{Spatial,Volumetric}ConvolutionUpsample: view (b, nO, s.., dims..) -> interleave (pixel shuffle)
+            bsz = h.shape[0]
+            if is3d:
+                no, (t, hh, ww) = h.shape[1] // u ** 3, h.shape[2:]
+                h = h.view(bsz, no, u, u, u, t, hh, ww).permute(0, 1, 5, 2, 6, 3, 7, 4).reshape(bsz, no, t * u, hh * u, ww * u)
+            else:
+                no, (hh, ww) = h.shape[1] // u ** 2, h.shape[2:]
+                h = h.view(bsz, no, u, u, hh, ww).permute(0, 1, 4, 2, 5, 3).reshape(bsz, no, hh * u, ww * u)
         if li + 1 < len(layers):
             h = torch.relu(h)
+        if pool is not None and pool[li] > 1:   # cudnn average pooling, window = stride (model_utils.lua:184-208)
+            h = F.avg_pool3d(h, pool[li]) if is3d else F.avg_pool2d(h, pool[li])
     if not is3d:
         h = h.unsqueeze(2)
     return h.to(torch.float32).numpy()
 
 
-def model_forward(ops, layers, pDiv, UDiv, flags, conv_dtype="float32"):
+def model_forward(ops, layers, pDiv, UDiv, flags, conv_dtype="float32", pool=None, up=None):
     """`default` model FPROP; returns (p, U) and leaves the inputs untouched."""
     is3d = UDiv.shape[1] == 3
     U_bc = UDiv.copy()
@@ -120,7 +132,7 @@ def model_forward(ops, layers, pDiv, UDiv, flags, conv_dtype="float32"):
     occ = np.zeros_like(pDiv)
     ops.flagsToOccupancy(flags, occ)
     x = np.concatenate([pDiv / sc, div / sc, occ], axis=1)   # apply_scale.lua (CDivTable), JoinTable
-    p_pred = conv_stack(x, layers, is3d, conv_dtype)
+    p_pred = conv_stack(x, layers, is3d, conv_dtype, pool, up)
     U = (U_bc / sc).astype(np.float32)
     ops.velocityUpdateForward(U, flags, np.ascontiguousarray(p_pred))  # velocity_update.lua:29-39
     p = (p_pred * sc).astype(np.float32)                     # model.lua:383-387

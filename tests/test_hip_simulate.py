@@ -215,6 +215,31 @@ def test_other_topologies_through_the_generic_kernels(oracle, is3d, shapes):
     assert scenes.rel_l2(pm.cpu().numpy(), p_ref) <= TOL and scenes.rel_l2(Um.cpu().numpy(), U_ref) <= TOL
 
 
+@pytest.mark.parametrize("is3d,dims", [(False, (1, 64, 96)), (True, (16, 24, 32)), (False, (1, 35, 70))])
+def test_tog_topology_pooling_and_convolution_upsample(oracle, is3d, dims):
+    """modelType = 'tog' (lib/model.lua:163-178 2-D, :211-218 3-D): 2x average pooling after the first
+    layer(s), nn.{Spatial,Volumetric}ConvolutionUpsample (conv to 2^dim * nOut channels + pixel shuffle,
+    lib/modules/*_convolution_upsample.lua) at the end; up to 64 channels, 5x5 kernels. Seeded weights (no such model is
+    shipped) against PyTorch-CPU conv / avg_pool / the module's view-permute restated in oracle/simulate_np.py."""
+    import torch
+    from fluidnet_amd import FluidNetModel, TfluidsError
+    dev = torch.device("cuda:0")
+    model = FluidNetModel.tog(is3d, seed=9)
+    sc = scenes.make_scene(dims, seed=31, vel_cells=0.4, B=2)
+    tp, tU, tf = (torch.from_numpy(sc[k]).to(dev) for k in ("p", "U", "flags"))
+    if dims[2] % 2 or dims[1] % 2:      # 2-D tog pools once: odd sizes are refused, like cudnn's shape check would
+        with pytest.raises(TfluidsError):
+            model.forward([tp, tU, tf])
+        return
+    p, U = model.forward([tp, tU, tf])
+    p_ref, U_ref = S.model_forward(oracle, model.layers, sc["p"], sc["U"], sc["flags"], pool=model.pool, up=model.up)
+    rp, rU = scenes.rel_l2(p.cpu().numpy(), p_ref), scenes.rel_l2(U.cpu().numpy(), U_ref)
+    assert rp <= TOL and rU <= TOL, (rp, rU)
+    assert float(np.abs(p_ref).max()) > 0
+    p64, _ = S.model_forward(oracle, model.layers, sc["p"], sc["U"], sc["flags"], conv_dtype="float64", pool=model.pool, up=model.up)
+    assert scenes.rel_l2(p.cpu().numpy(), p64) <= 4 * scenes.rel_l2(p_ref, p64) + 1e-7
+
+
 @pytest.mark.parametrize("which", ["2d_jacobi", "2d_convnet_rgb", "3d_convnet_vort_obstacle", "3d_gravity_rk2", "2d_pcg"])
 def test_native_simulate_step_equals_python_orchestration(which):
     """tfl_simulate_step (csrc/simulate.cpp: lib/simulate.lua in native code behind one C-ABI call) against
