@@ -126,6 +126,7 @@ SIGNATURES = {
     "tfl_applyBCsIndexedMulti": (_c.c_int, [_c.c_void_p, _c.c_int, _c.POINTER(_T), _c.POINTER(_T), _c.POINTER(_T),
                                             _c.POINTER(_c.c_void_p), _c.POINTER(_c.c_int64)]),
     "tfl_applyBCs": (_c.c_int, [_c.c_void_p, _T, _T, _T, _c.c_int, _c.c_float, _c.c_float]),
+    "tfl_setWallBcsBackward": (_c.c_int, [_c.c_void_p, _T, _T, _c.c_int, _T]),
     "tfl_set_z_window": (_c.c_int, [_c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.c_int]),
     "tfl_set_stages": (_c.c_int, [_c.c_void_p, _c.c_int]),
     "tfl_set_z_origin": (_c.c_int, [_c.c_void_p, _c.c_int, _c.c_int]),

@@ -881,6 +881,17 @@ int tfl_packPlanes(tfl_ctx* c, int n, const tfl_tensor* const* fields, int zlo, 
   return check_launch(c, "packPlanes");
 }
 
+int tfl_setWallBcsBackward(tfl_ctx* c, const tfl_tensor* flags, const tfl_tensor* gradOutput, int is3D, const tfl_tensor* gradU) {
+  TRY(check_flags(c, "setWallBcsBackward", flags));
+  TRY(check_vel(c, "setWallBcsBackward", "gradOutput", gradOutput, flags, is3D));
+  TRY(check_vel(c, "setWallBcsBackward", "gradU", gradU, flags, is3D));
+  if (gradU->data != gradOutput->data)
+    HIP_TRY(c, hipMemcpyAsync(gradU->data, gradOutput->data, sizeof(float) * (size_t)flags->B * gradU->C * flags->Z * flags->Y * flags->X,
+                              hipMemcpyDeviceToDevice, c->stream));
+  tfl::set_wall_bcs(c->stream, is3D != 0, flags->B, flags->Z, flags->Y, flags->X, gradU->data, flags->data);
+  return check_launch(c, "setWallBcsBackward");
+}
+
 int tfl_velocityDivergenceBackward(tfl_ctx* c, const tfl_tensor* U, const tfl_tensor* flags, const tfl_tensor* gradOutput,
                                    int is3D, const tfl_tensor* gradU) {
   TRY(check_flags(c, "velocityDivergenceBackward", flags));

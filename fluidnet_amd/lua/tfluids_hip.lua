@@ -86,6 +86,8 @@ int tfl_velocityDivergenceBackward(tfl_ctx* ctx, const tfl_tensor* U, const tfl_
                                    const tfl_tensor* gradOutput, int is3D, const tfl_tensor* gradU);
 int tfl_velocityUpdateBackward(tfl_ctx* ctx, const tfl_tensor* U, const tfl_tensor* flags, const tfl_tensor* p,
                                const tfl_tensor* gradOutput, int is3D, const tfl_tensor* gradP);
+int tfl_setWallBcsBackward(tfl_ctx* ctx, const tfl_tensor* flags, const tfl_tensor* gradOutput, int is3D,
+                           const tfl_tensor* gradU);
 int tfl_volumetricUpSamplingNearestForward(tfl_ctx* ctx, int ratio, const tfl_tensor* input,
                                            const tfl_tensor* output);
 int tfl_volumetricUpSamplingNearestBackward(tfl_ctx* ctx, int ratio, const tfl_tensor* input,
@@ -254,6 +256,13 @@ function ops.velocityDivergenceBackward(U, flags, gradOutput, is3D, gradU)
 end
 function ops.velocityUpdateBackward(U, flags, p, gradOutput, is3D, gradP)
   check(lib.tfl_velocityUpdateBackward(ctx, T(U), T(flags), T(p), T(gradOutput), b2i(is3D), T(gradP)))
+end
+-- not a native entry of the reference (tfluids.SetWallBcs:updateGradInput does it with a mask tensor,
+-- set_wall_bcs.lua:50-66); exposed for a module override: gradInput[1] = hip.setWallBcsBackward(flags, gradOutput)
+function M.setWallBcsBackward(flags, gradOutput, gradU)
+  gradU = gradU or gradOutput.new():resizeAs(gradOutput)
+  check(lib.tfl_setWallBcsBackward(ctx, T(flags), T(gradOutput), b2i(gradOutput:size(2) == 3), T(gradU)))
+  return gradU
 end
 function ops.volumetricUpSamplingNearestForward(ratio, input, output)
   check(lib.tfl_volumetricUpSamplingNearestForward(ctx, ratio, T(input), T(output)))

@@ -180,6 +180,18 @@ def setWallBcsForward(U, flags):
     _call(lib, ctx, lib.tfl_setWallBcsForward(ctx, _tt(U), _tt(flags), int(is3D)))
 
 
+def setWallBcsBackward(flags, gradOutput, gradU=None):
+    """tfluids.SetWallBcs:updateGradInput (tfluids/set_wall_bcs.lua:50-66): gradient w.r.t. U of the wall-BC module
+    (= mask * gradOutput, the forward operator applied to the gradient); the gradient w.r.t. flags is zero."""
+    _, _, _, _, is3D = _dims(gradOutput, flags)
+    if gradU is None:
+        gradU = torch.empty_like(gradOutput)
+    _check(gradU.shape == gradOutput.shape and gradU.is_contiguous(), "Size mismatch")
+    lib, ctx = _context(gradOutput)
+    _call(lib, ctx, lib.tfl_setWallBcsBackward(ctx, _tt(flags), _tt(gradOutput), int(is3D), _tt(gradU)))
+    return gradU
+
+
 def velocityDivergenceForward(U, flags, UDiv):
     """init.lua:255-279."""
     _, _, _, _, is3D = _dims(U, flags)

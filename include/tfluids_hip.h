@@ -183,6 +183,12 @@ int tfl_velocityDivergenceBackward(tfl_ctx* ctx, const tfl_tensor* U, const tfl_
  * gathers its contributions in the reference's serial order (deterministic; the reference scatters atomically). */
 int tfl_velocityUpdateBackward(tfl_ctx* ctx, const tfl_tensor* U, const tfl_tensor* flags, const tfl_tensor* p,
                                const tfl_tensor* gradOutput, int is3D, const tfl_tensor* gradP);
+/* tfluids.SetWallBcs:updateGradInput (tfluids/set_wall_bcs.lua:50-66): gradU = mask * gradOutput with mask =
+ * setWallBcsForward(ones, flags), i.e. the forward operator applied to the incoming gradient (the module's own comment:
+ * "copy the gradOutput and treat it as an input velocity and call the forward function"); the gradient w.r.t. flags is
+ * zero. gradU may alias gradOutput. */
+int tfl_setWallBcsBackward(tfl_ctx* ctx, const tfl_tensor* flags, const tfl_tensor* gradOutput, int is3D,
+                           const tfl_tensor* gradU);
 /* init.lua:618-627 -> generic/tfluids.cc:509-633 | generic/tfluids.cu:516-686. */
 int tfl_volumetricUpSamplingNearestForward(tfl_ctx* ctx, int ratio, const tfl_tensor* input,
                                            const tfl_tensor* output);

@@ -435,3 +435,108 @@ def test_simulate_long_horizon_parity(oracle):
     for k in ("pDiv", "UDiv", "density"):
         r = scenes.rel_l2(batch[k].cpu().numpy(), nb[k])
         assert r <= TOL, (k, r)
+
+
+def test_batched_rollout_with_output_div(oracle):
+    """The training-side caller of simulate() (lib/run_epoch.lua:240-266): a batch of B = 4 DIFFERENT samples
+    (own obstacles, own flow speed, hence own std(U) input scale: lib/model.lua:93-117 normalises per batch item),
+    no plume BCs, stepped numFutureSteps = 4 times with outputDiv = true on the last step (advect + forces, no
+    projection). Native step vs the numpy/C restatement."""
+    import torch
+    from fluidnet_amd import FluidNetModel
+    from fluidnet_amd.simulate import simulate, simulate_native
+    dev = torch.device("cuda:0")
+    sc = scenes.make_scene((12, 20, 24), seed=77, vel_cells=0.6, B=4)
+    for bi, f in enumerate((1.0, 0.35, 2.0, 0.05)):
+        sc["U"][bi] *= f
+    layers = S.default_3d_layers(seed=6)
+    mconf = dict(dt=0.1, advectionMethod="maccormackOurs", maccormackStrength=0.6, buoyancyScale=1.0, gravityScale=0,
+                 vorticityConfinementAmp=1.5, simMethod="convnet")
+    nb = dict(pDiv=sc["p"].copy(), UDiv=sc["U"].copy(), flags=sc["flags"].copy(), density=sc["density"].copy())
+    ta, tb = _to_dev(nb, dev), _to_dev(nb, dev)
+    model = FluidNetModel(layers, True)
+    scales = []
+    for i in range(4):
+        last = i == 3
+        S.simulate(oracle, mconf, nb, layers, output_div=last)
+        simulate_native(None, mconf, ta, model, outputDiv=last)
+        simulate(None, mconf, tb, model, outputDiv=last)
+        scales.append([float(x) for x in ta["UDiv"].flatten(1).std(dim=1)])
+    assert max(scales[0]) / min(scales[0]) > 5            # the four samples really are normalised differently
+    for k in ("pDiv", "UDiv", "density"):
+        assert torch.equal(ta[k], tb[k]), k
+        for bi in range(4):
+            r = scenes.rel_l2(ta[k][bi].cpu().numpy(), nb[k][bi])
+            assert r <= TOL, (k, bi, r)
+    # the last step skipped the projection: the velocity is NOT divergence-free, p is the previous step's
+    from fluidnet_amd import tfluids
+    div = torch.empty_like(ta["pDiv"])
+    tfluids.velocityDivergenceForward(ta["UDiv"], ta["flags"], div)
+    assert float(div.abs().max()) > 1e-3
+
+
+@pytest.mark.parametrize("dims,stick", [((1, 33, 47), False), ((12, 18, 22), True)])
+def test_set_wall_bcs_module_backward(oracle, dims, stick):
+    """tfluids.SetWallBcs:updateGradInput (tfluids/set_wall_bcs.lua:50-66): gradInput[1] = mask * gradOutput with
+    mask = setWallBcsForward(ones, flags)."""
+    import torch
+    from fluidnet_amd import tfluids
+    dev = torch.device("cuda:0")
+    sc = scenes.make_scene(dims, seed=91, B=3, stick=stick, empty_cells=True)
+    rng = np.random.RandomState(5)
+    g = rng.randn(*sc["U"].shape).astype(np.float32)
+    mask = np.ones_like(sc["U"])
+    oracle.setWallBcsForward(mask, sc["flags"])
+    want = mask * g
+    assert 0 < int((mask == 0).sum()) < mask.size
+    tg, tf = torch.from_numpy(g).to(dev), torch.from_numpy(sc["flags"]).to(dev)
+    got = tfluids.setWallBcsBackward(tf, tg)
+    assert np.array_equal(got.cpu().numpy(), want) and torch.equal(tg.cpu(), torch.from_numpy(g))
+    tfluids.setWallBcsBackward(tf, tg, tg)             # in place
+    assert np.array_equal(tg.cpu().numpy(), want)
+
+
+def test_grid_limits_are_reported_not_crashed():
+    """the launch-grid limit (B*Z <= 65535: the batch is folded into gridDim.z) and the 32-bit
+    cell-offset guard (3*Z*Y*X < 2^31) must surface as TfluidsError; just inside the limits the operators work."""
+    import torch
+    from fluidnet_amd import tfluids
+    dev = torch.device("cuda:0")
+    U = torch.zeros(512, 3, 128, 4, 8, device=dev)
+    flags = torch.ones(512, 1, 128, 4, 8, device=dev)
+    with pytest.raises(tfluids.TfluidsError, match="launch grid"):
+        tfluids.setWallBcsForward(U, flags)
+    U, flags = U[:255, :, :].contiguous(), flags[:255].contiguous()        # 255 * 128 = 32640
+    flags[:, :, :, 0] = 2.0
+    U.fill_(1.0)
+    tfluids.setWallBcsForward(U, flags)
+    # y-faces above the wall zeroed in every sample; rows further up untouched
+    assert float(U[:, 1, :, 1].abs().max()) == 0.0 and float(U[:, :, :, 2:].min()) == 1.0
+    del U, flags
+    big = torch.empty(1, 1, 900, 900, 900, device=dev)                      # 729M cells: 3*N >= 2^31
+    bigU = torch.empty(1, 3, 900, 900, 900, device=dev)
+    with pytest.raises(tfluids.TfluidsError, match="32-bit"):
+        tfluids.setWallBcsForward(bigU, big)
+
+
+def test_512_cubed_step_runs():
+    """The reference driver's largest resolution (fluid_net_3d_sim.lua:62: res up to 512): two whole steps at 512^3
+    (134M cells, ~21 GB of state + workspace) stay finite, move the plume and hit no line-trace error path."""
+    import torch
+    from fluidnet_amd import FluidNetModel, tfluids
+    from fluidnet_amd.simulate import createPlumeBCs, simulate_native
+    dev = torch.device("cuda:0")
+    res = 512
+    flags = torch.empty(1, 1, res, res, res, device=dev)
+    tfluids.emptyDomain(flags, True)
+    batch = dict(pDiv=torch.zeros_like(flags), UDiv=torch.zeros(1, 3, res, res, res, device=dev), flags=flags,
+                 density=torch.zeros_like(flags))
+    createPlumeBCs(batch, [1.0], 4.0, 0.15)
+    mconf = dict(dt=0.1, advectionMethod="maccormackOurs", maccormackStrength=0.6, buoyancyScale=8.0, gravityScale=0,
+                 vorticityConfinementAmp=3.0, simMethod="convnet")
+    model = FluidNetModel.default_3d(seed=1)
+    for _ in range(2):
+        simulate_native(None, mconf, batch, model)
+    assert bool(torch.isfinite(batch["UDiv"]).all()) and bool(torch.isfinite(batch["pDiv"]).all())
+    assert float(batch["density"][0, 0, :, 4:].sum()) > 0 and float(batch["UDiv"].abs().max()) > 0.5
+    assert tfluids.traceErrors(batch["UDiv"]) == 0
