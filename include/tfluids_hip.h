@@ -302,7 +302,8 @@ typedef struct tfl_sim_params {      /* mconf of lib/simulate.lua (defaults of l
   double vorticityConfinementAmp;    /* 0 = off */
   const char* simMethod;             /* NULL | "convnet" | "jacobi" | "pcg" */
   int32_t maxIter;                   /* jacobi / pcg; <= 0 -> 100 */
-  const char* pcgPrecond;            /* NULL = "ic0" (simulate.lua:283) */
+  const char* pcgPrecond;            /* NULL = "none": the fast path here (simulate.lua:283 hard-codes "ic0", whose
+                                        wavefront sweeps are ~10x slower on this machine; pass "ic0" to get it) */
   int32_t outputDiv;                 /* 1: return before the projection (simulate.lua:241-245) */
 } tfl_sim_params;
 
