@@ -44,6 +44,7 @@ def per_kernel(path, counter):
 def main():
     fetch, write, tag = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.argv[2], "WRITE_SIZE"), sys.argv[3]
     cells = float(sys.argv[4]) if len(sys.argv) > 4 else 128.0 ** 3
+    commit = sys.argv[5] if len(sys.argv) > 5 else "unknown"
     rows, out = [], {}
     for k in sorted(fetch, key=lambda k: -(2 * fetch[k] + write.get(k, 0))):
         f, w = fetch[k], write.get(k, 0.0)
@@ -51,13 +52,15 @@ def main():
         out[k] = t
         rows.append("%-24s %11.1f %12.1f %14d %10.1f %10s" % (k, f, w, t, t / cells, ALG.get(k, "-")))
     hdr = ("# HBM-side traffic per launch from rocprofv3 PMC (separate passes: --pmc FETCH_SIZE / --pmc WRITE_SIZE), MI355X,\n"
-           "# bench.py workload (3-D 128^3 config 4). FETCH_SIZE/WRITE_SIZE are in KiB; per MI355X_MICROARCH.md (HBM section)\n"
+           "# bench.py workload (3-D config 4 scene, %d cells, code at commit %s). FETCH_SIZE/WRITE_SIZE are in KiB; per MI355X_MICROARCH.md (HBM section)\n" % (int(cells), commit) +
            "# FETCH_SIZE reports half of the bytes of a wide coalesced read on gfx950 -> doubled here.\n"
            "# traffic = 2*FETCH + WRITE (bytes per launch). NOTE: the 128^3 working set fits the 256 MiB Infinity Cache,\n"
            "# whose hits these fabric-side counters include.\n"
            "%-24s %11s %12s %14s %10s %10s\n" % ("kernel", "fetch_KiB", "write_KiB", "traffic_bytes", "B/cell", "alg B/cell"))
     open(os.path.join(ROOT, "profiles", tag + "_pmc_traffic.txt"), "w").write(hdr + "\n".join(rows) + "\n")
-    json.dump(out, open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1)
+    if int(cells) == 128 ** 3:     # the file bench.py reads for roofline.traffic (default workload only)
+        out["_meta"] = {"commit": commit, "cells": int(cells), "source": tag + "_pmc_traffic.txt"}
+        json.dump(out, open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1)
     sys.stdout.write(hdr + "\n".join(rows) + "\n")
 
 
