@@ -115,7 +115,8 @@ def cpu_baseline(batch, mconf, layers, max_seconds=25.0, max_steps=6):
 # (fluidnet_amd/csrc/simulate.cpp); kernels not listed run on the owned planes only.
 SLAB_EXTRA_PLANES = {"k_minmax3": (2, 2), "k_scalar_fwd": (1, 1), "k_vel_fwd": (1, 1), "k_add_buoyancy": (3, 4),
                      "k_add_gravity": (3, 4), "k_curl": (2, 2), "k_confine": (0, 1), "k_conv3_mfma_in": (3, 2),
-                     "k_conv3_mfma": (2, 1), "k_conv3_mfma_tail": (1, 0)}
+                     "k_conv3_mfma": (2, 1), "k_conv3_mfma_tail": (1, 0), "k_conv3_in": (3, 2), "k_conv3_mid": (2, 1),
+                     "k_conv3_tail": (1, 0)}
 
 
 def config5_scene(res, layout, device):
@@ -224,7 +225,7 @@ def main():
                          "ms_per_step": rec["ms"] / nprof}
     lf = [2.0 * w.shape[0] * w.shape[1] * w.shape[2] ** 3 for w, _ in model.layers]   # flop per voxel per layer
     conv_flops_per_voxel = {"k_conv_direct": sum(lf), "k_conv3_mfma_in": lf[0], "k_conv3_mfma": lf[1],
-                            "k_conv3_mfma_tail": sum(lf[2:])}
+                            "k_conv3_mfma_tail": sum(lf[2:]), "k_conv3_in": lf[0], "k_conv3_mid": lf[1], "k_conv3_tail": sum(lf[2:])}
 
     def cells_of(name):
         """cells one rank's launches of this kernel cover per step: the owned planes plus the slab step's extra planes"""

@@ -32,6 +32,7 @@ struct tfl_model {
   std::vector<tfl_layer> layers;
   // 3-D `default` topology (3->8 k3, 8->8 k3, 8->8 k3, 8->8 k1, 8->1 k1): MFMA path (conv_mfma.hip)
   bool mfma3d = false;
+  bool valu3d = false;                            // the same three layers as a direct VALU convolution (conv_valu.hip): the default
   float* bfrag[3] = {nullptr, nullptr, nullptr};  // per-lane B fragments of the three k=3 layers
   float* tail_w4 = nullptr;                       // [8][8] (out, in) of the 8->8 k1 layer
   float* tail_w5 = nullptr;                       // [8] of the 8->1 k1 layer
@@ -609,6 +610,9 @@ tfl_model* tfl_model_create_ex(tfl_ctx* c, int is3D, int nlayers, const int32_t*
         hipMemcpy(m->tail_w5, weights[4], 8 * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
       return cleanup("uploading tail weights failed");
     m->mfma3d = true;
+    // default: the direct VALU kernels (conv_valu.hip; faster than the fp32-MFMA form for 8 output channels, see there).
+    // TFL_CONV_PATH=mfma keeps the MFMA kernels.
+    m->valu3d = !(force && strcmp(force, "mfma") == 0);
   }
   const int dflt2[5][3] = {{3, 16, 3}, {16, 16, 3}, {16, 16, 3}, {16, 16, 3}, {16, 1, 1}};
   bool match2 = !m->is3d && nlayers == 5 && !m->multires;
@@ -728,7 +732,15 @@ int tfl_model_finish(tfl_ctx* c, tfl_model* m, const tfl_tensor* pDiv, const tfl
   // + the two 1x1x1 layers, 8 = velocity update / un-scale / wall BCs. Only the 3-D MFMA path is staged.
   const int stg = stages_of(c);
   if (c->stages && !m->mfma3d) return fail(c, TFL_EUNSUPPORTED, "model_finish: stage masks need the 3-D default topology");
-  if (m->mfma3d) {
+  if (m->mfma3d && m->valu3d) {
+    // the first layer builds {pDiv/scale, div/scale, occupancy} while staging its LDS tile
+    if (stg & 1)
+      tfl::conv3_valu_first_fused(st, B, Z, Y, X, pDiv->data, w.div, flags->data, st_in, count, m->layers[0].w, m->layers[0].b, w.act[0]);
+    if (stg & 2) tfl::conv3_valu_mid(st, B, Z, Y, X, w.act[0], m->layers[1].w, m->layers[1].b, w.act[1]);
+    if (stg & 4)
+      tfl::conv3_valu_tail(st, B, Z, Y, X, w.act[1], m->layers[2].w, m->layers[2].b, m->tail_w4, m->layers[3].b, m->tail_w5,
+                           m->layers[4].b, w.pPred);
+  } else if (m->mfma3d) {
     // the first MFMA layer builds {pDiv/scale, div/scale, occupancy} while staging its LDS tile
     if (stg & 1)
       tfl::conv3_mfma_first_fused(st, B, Z, Y, X, pDiv->data, w.div, flags->data, st_in, count, m->bfrag[0],

@@ -145,6 +145,14 @@ void conv3_mfma_tail(hipStream_t st, int B, int Z, int Y, int X, const float* in
                      const float* bias, const float* w4, const float* b4, const float* w5, const float* b5,
                      float* p_out);
 
+// conv_valu.hip: the same three layers as a direct convolution on the vector ALUs (w = tfl_layer::w, [tap][cin][8])
+void conv3_valu_first_fused(hipStream_t st, int B, int Z, int Y, int X, const float* pDiv, const float* div, const float* flags,
+                            const double* stats, double count, const float* w, const float* bias, float* out_cl8);
+void conv3_valu_mid(hipStream_t st, int B, int Z, int Y, int X, const float* in_cl8, const float* w, const float* bias,
+                    float* out_cl8);
+void conv3_valu_tail(hipStream_t st, int B, int Z, int Y, int X, const float* in_cl8, const float* w, const float* bias,
+                     const float* w4, const float* b4, const float* w5, const float* b5, float* p_out);
+
 // backward.hip
 void velocity_divergence_bwd(hipStream_t st, bool is3d, int B, int Z, int Y, int X, const float* flags,
                              const float* grad_out, float* grad_U);

@@ -169,9 +169,9 @@ def test_simulate_gravity_and_rgb_density(oracle):
 
 
 def test_conv_paths_agree_3d(oracle, monkeypatch):
-    """The fp32-MFMA implicit GEMM (conv_mfma.hip) and the shape-generic direct kernels (conv.hip)
-    are two exact-fp32 evaluations of the same sums in different orders: they must agree to rounding,
-    including on grids that are ragged against the 32x8x4 MFMA tile."""
+    """The direct VALU kernels (conv_valu.hip, the default), the fp32-MFMA implicit GEMM (conv_mfma.hip) and the
+    shape-generic direct kernels (conv.hip) are three exact-fp32 evaluations of the same sums in different orders: they
+    must agree to rounding, including on grids that are ragged against the 64x4x4 / 32x8x4 tiles."""
     import torch
     from fluidnet_amd import FluidNetModel
     layers = S.default_3d_layers(seed=5)
@@ -185,6 +185,10 @@ def test_conv_paths_agree_3d(oracle, monkeypatch):
         pm, Um = FluidNetModel(layers, True).forward([tp, tU, tf])
         rp, rU = scenes.rel_l2(pm.cpu().numpy(), pd.cpu().numpy()), scenes.rel_l2(Um.cpu().numpy(), Ud.cpu().numpy())
         assert rp <= 2e-6 and rU <= 2e-6, (dims, rp, rU)
+        monkeypatch.delenv("TFL_CONV_PATH")      # the default: direct VALU kernels (conv_valu.hip)
+        pv, Uv = FluidNetModel(layers, True).forward([tp, tU, tf])
+        rp, rU = scenes.rel_l2(pv.cpu().numpy(), pd.cpu().numpy()), scenes.rel_l2(Uv.cpu().numpy(), Ud.cpu().numpy())
+        assert rp <= 2e-6 and rU <= 2e-6, ("valu", dims, rp, rU)
         p_ref, U_ref = S.model_forward(oracle, layers, sc["p"], sc["U"], sc["flags"])
         assert scenes.rel_l2(pm.cpu().numpy(), p_ref) <= TOL and scenes.rel_l2(Um.cpu().numpy(), U_ref) <= TOL
 
