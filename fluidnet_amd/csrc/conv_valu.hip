@@ -33,12 +33,18 @@ namespace tfl {
 
 namespace {
 
-constexpr int kVX = 64, kVY = 4, kVZ = 4;                 // block tile (voxels)
+#ifndef TFL_VALU_VY
+#define TFL_VALU_VY 4
+#endif
+#ifndef TFL_VALU_LB
+#define TFL_VALU_LB 4
+#endif
+constexpr int kVX = 64, kVY = TFL_VALU_VY, kVZ = 4;       // block tile (voxels); A/B knobs: -DTFL_VALU_VY=.. -DTFL_VALU_LB=..
 constexpr int kPX = kVX + 4;                              // LDS row pitch (66 used)
 constexpr int kRowsP = kVY + 2;                           // halo rows per plane
 constexpr int kRowsT = (kVZ + 2) * kRowsP;                // halo rows per channel (36)
 constexpr int kPlaneF = kRowsT * kPX;                     // floats per staged channel
-constexpr int kPerWave = kRowsT / 4;                      // staged rows per wave (9)
+constexpr int kPerWave = (kRowsT + 3) / 4;                // staged rows per wave (9)
 
 struct VTail {          // fused 1x1x1 layers (device pointers): h4 = relu(W4 h + b4); p = w5 . h4 + b5
   const float* w4;      // [8][8]  (out, in)
@@ -60,7 +66,7 @@ struct VIn {            // fused network input (first layer): {pDiv/scale, div/s
 // TAIL: fuse the two 1x1x1 layers and write planar pressure instead of channel-last activations.
 // w: [tap = (dz*3+dy)*3+dx][CIN][8] (tfl_layer::w), so the 8 output-channel weights of a (tap, c) are one s_load_dwordx8.
 template <int CIN, bool TAIL>
-__global__ __launch_bounds__(256, 4) void k_conv3_valu(Dom d, int tiles_x, int tiles_y, int tiles_z, int n_tiles,
+__global__ __launch_bounds__(256, TFL_VALU_LB) void k_conv3_valu(Dom d, int tiles_x, int tiles_y, int tiles_z, int n_tiles,
                                                        const float* __restrict__ in, const float* __restrict__ w,
                                                        const float* __restrict__ bias, float* __restrict__ out, VTail tail,
                                                        VIn cin) {
@@ -82,7 +88,10 @@ __global__ __launch_bounds__(256, 4) void k_conv3_valu(Dom d, int tiles_x, int t
   const int z_end = tz < tz_a ? d.w0 + d.n0 : d.w1 + (d.nw - d.n0);
   const int x0 = tx * kVX, y0 = ty * kVY;
   const long long cells = d.sc;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // the wave index is uniform across a wave, but only readfirstlane tells the compiler: with it the row geometry of the
+  // staging (row -> z, y, clamps, in-grid tests, LDS row offsets) is scalar-ALU work instead of ~300 VALU instructions
+  // per tile taken out of the FMA budget
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 
   float in_scale = 1.0f;
   if (FIRST) {  // lib/modules/variance.lua:44-76 (n-1) + Sqrt, as model.hip scale_from_stats
@@ -117,7 +126,7 @@ __global__ __launch_bounds__(256, 4) void k_conv3_valu(Dom d, int tiles_x, int t
 #pragma unroll
       for (int tt = 0; tt <= kPerWave; tt++) {
         const bool edge = tt == kPerWave;
-        const int r = edge ? wave + 4 * (e_live ? eq : 0) : wave + 4 * tt;
+        const int r = min(edge ? wave + 4 * (e_live ? eq : 0) : wave + 4 * tt, kRowsT - 1);
         int gz, gy; row_zy(r, gz, gy);
         const long long o = TFL_AT(d, edge ? exc : gxc, min(max(gy, 0), d.Y - 1), min(max(gz, 0), d.Z - 1));
         if (FIRST) {
@@ -131,7 +140,7 @@ __global__ __launch_bounds__(256, 4) void k_conv3_valu(Dom d, int tiles_x, int t
 #pragma unroll
       for (int tt = 0; tt <= kPerWave; tt++) {
         const bool edge = tt == kPerWave;
-        const int r = edge ? wave + 4 * (e_live ? eq : 0) : wave + 4 * tt;
+        const int r = edge ? wave + 4 * (e_live ? eq : 0) : wave + 4 * tt;      // < kRowsT except in a ragged last pass
         int gz, gy; row_zy(r, gz, gy);
         const bool ok = (edge ? ex_ok : gx_ok) && gy >= 0 && gy < d.Y && gz >= 0 && gz < d.Z;
         float v[4];
@@ -145,7 +154,7 @@ __global__ __launch_bounds__(256, 4) void k_conv3_valu(Dom d, int tiles_x, int t
         } else {
           v[0] = ld[tt].x; v[1] = ld[tt].y; v[2] = ld[tt].z; v[3] = ld[tt].w;
         }
-        if (!edge || e_live) {
+        if ((!edge || e_live) && r < kRowsT) {
           const int col = edge ? 64 + ee : lane;
 #pragma unroll
           for (int c = 0; c < CG; c++) lds[c * kPlaneF + r * kPX + col] = ok ? v[c] : 0.0f;
