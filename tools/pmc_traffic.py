@@ -11,7 +11,7 @@ import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ALG = {"k_conv3_mfma": 64, "k_conv3_mfma_tail": 36, "k_conv3_mfma_in": 44, "k_vel_bwd": 40, "k_vel_fwd": 28,
+ALG = {"k_conv3_mfma": 64, "k_conv3_mfma_tail": 36, "k_conv3_mfma_in": 44, "k_conv3_mid": 64, "k_conv3_tail": 36, "k_conv3_in": 44, "k_vel_bwd": 40, "k_vel_fwd": 28,
        "k_scalar_fwd": 24, "k_scalar_bwd": 28, "k_confine": 44, "k_curl": 28, "k_bcs_div_stats": 32, "k_minmax3": 16,
        "k_project": 60, "k_add_buoyancy": 32}
 
@@ -24,6 +24,9 @@ def short(name):
     if k == "k_conv3_mfma":
         a = [t.strip() for t in targs.strip("<>").split(",")]
         return "k_conv3_mfma_in" if a[1] == "true" else ("k_conv3_mfma_tail" if a[2] == "true" else "k_conv3_mfma")
+    if k == "k_conv3_valu":          # profiler names of conv_valu.hip's launches
+        a = [t.strip() for t in targs.strip("<>").split(",")]
+        return "k_conv3_in" if a[0] == "3" else ("k_conv3_tail" if a[1] == "true" else "k_conv3_mid")
     if k == "k_apply_bcs_indexed_multi":
         return "k_apply_bcs_indexed"
     return k[:-3] if k.endswith("_v4") else k
