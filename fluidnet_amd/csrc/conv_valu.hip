@@ -15,10 +15,13 @@
 // FMAs), data from an LDS halo tile. tools/ubench/valu_conv.hip measured the inner loop at 112-119 useful TFLOP/s
 // against 77-81 for the MFMA kernel.
 //
-// Block = 256 threads = 4 waves, tile 64(x) x 4(y) x 4(z): wave w owns z-plane w; lane = x; each lane keeps 4 rows x 8
-// output channels = 32 accumulators (register blocking along y: the 6 halo rows of a (channel, dz) feed 3 dy x 4 rows).
-// Input channels are staged 4 at a time as channel-planar halo planes [4][6][6][66(+2)] = 39 KB of LDS -> 4 blocks per
-// CU; per (channel, dz) a lane issues 18 ds_read_b32 (conflict-free: lanes read consecutive words) for 288 FMAs.
+// Block = 256 threads = 4 waves, tile 64(x) x 2(y) x 4(z): wave w owns z-plane w; lane = x; each lane keeps 2 rows x 8
+// output channels = 16 accumulators (register blocking along y: the 4 halo rows of a (channel, dz) feed 3 dy x 2 rows).
+// Input channels are staged 4 at a time as channel-planar halo planes [4][6][4][66(+2)] = 26 KB of LDS -> 6 blocks per
+// CU; per (channel, dz) a lane issues 12 ds_read_b32 (conflict-free: lanes read consecutive words) for 144 FMAs.
+// Tile height: 4 rows per lane is 1% faster at 128^3 but 10-25% slower on small and slab-shaped grids (64^3, 24..40 x
+// 128^2: half as many tiles to fill 256 CUs x 4+ slots) -- the shapes every rank of a z-slab run works on; 6 and 8 rows
+// are slower everywhere (A/B in one session, -DTFL_VALU_VY / -DTFL_VALU_LB).
 // Staging loads of a stage are ALL issued before the first LDS write (written load->store per element, hipcc waits for
 // every load in turn -- the mistake that sank two LDS advection kernels, profiles/r02_advect_experiments.txt).
 // Activations between layers: channel-last [Z][Y][X][8] (a lane's epilogue is two 16-byte stores, a wave writes 2 KB
@@ -34,7 +37,7 @@ namespace tfl {
 namespace {
 
 #ifndef TFL_VALU_VY
-#define TFL_VALU_VY 4
+#define TFL_VALU_VY 2
 #endif
 #ifndef TFL_VALU_LB
 #define TFL_VALU_LB 4
