@@ -32,8 +32,9 @@ struct tfl_model {
   std::vector<tfl_layer> layers;
   // 3-D `default` topology (3->8 k3, 8->8 k3, 8->8 k3, 8->8 k1, 8->1 k1): MFMA path (conv_mfma.hip)
   bool mfma3d = false;
-  bool valu3d = false;                            // the same three layers as a direct VALU convolution (conv_valu.hip): the default
+  bool valu3d = false;                            // the same three layers on the vector ALUs (conv_valu.hip): the default
   float* bfrag[3] = {nullptr, nullptr, nullptr};  // per-lane B fragments of the three k=3 layers
+  float* wino[3] = {nullptr, nullptr, nullptr};   // F(2,3)-in-x transformed weights of the same layers, [dz][dy][cin][4][8]
   float* tail_w4 = nullptr;                       // [8][8] (out, in) of the 8->8 k1 layer
   float* tail_w5 = nullptr;                       // [8] of the 8->1 k1 layer
   // 2-D `default` topology (3->16, 16->16 x3 k3, 16->1 k1): MFMA path (conv2d_mfma.hip)
@@ -610,9 +611,27 @@ tfl_model* tfl_model_create_ex(tfl_ctx* c, int is3D, int nlayers, const int32_t*
         hipMemcpy(m->tail_w5, weights[4], 8 * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
       return cleanup("uploading tail weights failed");
     m->mfma3d = true;
-    // default: the direct VALU kernels (conv_valu.hip; faster than the fp32-MFMA form for 8 output channels, see there).
+    // default: the vector-ALU kernels (conv_valu.hip; faster than the fp32-MFMA form for 8 output channels, see there).
     // TFL_CONV_PATH=mfma keeps the MFMA kernels.
     m->valu3d = !(force && strcmp(force, "mfma") == 0);
+    // their weights, Winograd-transformed along x: U = (g0, (g0 + g1 + g2)/2, (g0 - g1 + g2)/2, g2) over the three x-taps
+    // of every (dz, dy, c_in, c_out)
+    if (m->valu3d) {
+      for (int l = 0; l < 3; l++) {
+        const int ci_n = cin[l];
+        std::vector<float> u((size_t)9 * 4 * ci_n * 8);
+        for (int co = 0; co < 8; co++)
+          for (int c = 0; c < ci_n; c++)
+            for (int zy = 0; zy < 9; zy++) {
+              const float* g = weights[l] + (((size_t)co * ci_n + c) * 9 + zy) * 3;
+              const float uu[4] = {g[0], 0.5f * ((g[0] + g[2]) + g[1]), 0.5f * ((g[0] + g[2]) - g[1]), g[2]};
+              for (int p = 0; p < 4; p++) u[(((size_t)zy * ci_n + c) * 4 + p) * 8 + co] = uu[p];
+            }
+        if (hipMalloc((void**)&m->wino[l], u.size() * sizeof(float)) != hipSuccess ||
+            hipMemcpy(m->wino[l], u.data(), u.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
+          return cleanup("uploading transformed weights failed");
+      }
+    }
   }
   const int dflt2[5][3] = {{3, 16, 3}, {16, 16, 3}, {16, 16, 3}, {16, 16, 3}, {16, 1, 1}};
   bool match2 = !m->is3d && nlayers == 5 && !m->multires;
@@ -645,6 +664,7 @@ void tfl_model_destroy(tfl_ctx* c, tfl_model* m) {
   if (!m) return;
   for (auto& L : m->layers) { if (L.w) (void)hipFree(L.w); if (L.b) (void)hipFree(L.b); }
   for (int l = 0; l < 3; l++) if (m->bfrag[l]) (void)hipFree(m->bfrag[l]);
+  for (int l = 0; l < 3; l++) if (m->wino[l]) (void)hipFree(m->wino[l]);
   for (int l = 0; l < 4; l++) if (m->bfrag2[l]) (void)hipFree(m->bfrag2[l]);
   if (m->tail_w4) (void)hipFree(m->tail_w4);
   if (m->tail_w5) (void)hipFree(m->tail_w5);
@@ -735,10 +755,10 @@ int tfl_model_finish(tfl_ctx* c, tfl_model* m, const tfl_tensor* pDiv, const tfl
   if (m->mfma3d && m->valu3d) {
     // the first layer builds {pDiv/scale, div/scale, occupancy} while staging its LDS tile
     if (stg & 1)
-      tfl::conv3_valu_first_fused(st, B, Z, Y, X, pDiv->data, w.div, flags->data, st_in, count, m->layers[0].w, m->layers[0].b, w.act[0]);
-    if (stg & 2) tfl::conv3_valu_mid(st, B, Z, Y, X, w.act[0], m->layers[1].w, m->layers[1].b, w.act[1]);
+      tfl::conv3_valu_first_fused(st, B, Z, Y, X, pDiv->data, w.div, flags->data, st_in, count, m->wino[0], m->layers[0].b, w.act[0]);
+    if (stg & 2) tfl::conv3_valu_mid(st, B, Z, Y, X, w.act[0], m->wino[1], m->layers[1].b, w.act[1]);
     if (stg & 4)
-      tfl::conv3_valu_tail(st, B, Z, Y, X, w.act[1], m->layers[2].w, m->layers[2].b, m->tail_w4, m->layers[3].b, m->tail_w5,
+      tfl::conv3_valu_tail(st, B, Z, Y, X, w.act[1], m->wino[2], m->layers[2].b, m->tail_w4, m->layers[3].b, m->tail_w5,
                            m->layers[4].b, w.pPred);
   } else if (m->mfma3d) {
     // the first MFMA layer builds {pDiv/scale, div/scale, occupancy} while staging its LDS tile

@@ -145,12 +145,13 @@ void conv3_mfma_tail(hipStream_t st, int B, int Z, int Y, int X, const float* in
                      const float* bias, const float* w4, const float* b4, const float* w5, const float* b5,
                      float* p_out);
 
-// conv_valu.hip: the same three layers as a direct convolution on the vector ALUs (w = tfl_layer::w, [tap][cin][8])
+// conv_valu.hip: the same three layers on the vector ALUs, x-taps as Winograd F(2,3) (wq = tfl_model::wino,
+// [dz][dy][cin][4][8]); activations between the layers are channel-planar [B][8][Z][Y][X]
 void conv3_valu_first_fused(hipStream_t st, int B, int Z, int Y, int X, const float* pDiv, const float* div, const float* flags,
-                            const double* stats, double count, const float* w, const float* bias, float* out_cl8);
-void conv3_valu_mid(hipStream_t st, int B, int Z, int Y, int X, const float* in_cl8, const float* w, const float* bias,
-                    float* out_cl8);
-void conv3_valu_tail(hipStream_t st, int B, int Z, int Y, int X, const float* in_cl8, const float* w, const float* bias,
+                            const double* stats, double count, const float* wq, const float* bias, float* out_p8);
+void conv3_valu_mid(hipStream_t st, int B, int Z, int Y, int X, const float* in_p8, const float* wq, const float* bias,
+                    float* out_p8);
+void conv3_valu_tail(hipStream_t st, int B, int Z, int Y, int X, const float* in_p8, const float* wq, const float* bias,
                      const float* w4, const float* b4, const float* w5, const float* b5, float* p_out);
 
 // backward.hip

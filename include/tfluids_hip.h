@@ -212,7 +212,7 @@ tfl_model* tfl_model_create(tfl_ctx* ctx, int is3D, int nlayers, const int32_t* 
                             const float* const* biases);
 /* The same with the two extra per-layer knobs of lib/model.lua's layer tables (:163-178, :211-218): pool[l] = psize
  * (2: cudnn 2x average pooling after the layer's ReLU, model_utils.lua:184-208) and up[l] = usize (2: the layer is an
- * nn.{Spatial,Volumetric}ConvolutionUpsample, lib/modules/*_convolution_upsample.lua -- weights[l] then has
+ * nn.{Spatial,Volumetric}ConvolutionUpsample, lib/modules/{spatial,volumetric}_convolution_upsample.lua -- weights[l] then has
  * cout[l] * 2^dim output channels, channel index = o * 2^dim + sub-position, and the result is pixel-shuffled to twice
  * the resolution). NULL = all 1. This covers the `tog` model types (2-D: 16,32,32,64,64,32,1 with k 5,5,5,5,1,1,3;
  * 3-D: 16,16,16,16,32,32,1 with k 3,3,3,3,1,1,3); such models run through the shape-generic kernels, and the grid

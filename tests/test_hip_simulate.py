@@ -169,14 +169,15 @@ def test_simulate_gravity_and_rgb_density(oracle):
 
 
 def test_conv_paths_agree_3d(oracle, monkeypatch):
-    """The direct VALU kernels (conv_valu.hip, the default), the fp32-MFMA implicit GEMM (conv_mfma.hip) and the
-    shape-generic direct kernels (conv.hip) are three exact-fp32 evaluations of the same sums in different orders: they
-    must agree to rounding, including on grids that are ragged against the 64x4x4 / 32x8x4 tiles."""
+    """The vector-ALU kernels of conv_valu.hip (Winograd F(2,3) along x; the default), the fp32-MFMA implicit GEMM
+    (conv_mfma.hip) and the shape-generic direct kernels (conv.hip) are three fp32 evaluations of the same sums: they must
+    agree to rounding, including on grids that are ragged (and odd in x: the Winograd lanes own x-pairs) against the
+    64x2x4 / 32x8x4 tiles."""
     import torch
     from fluidnet_amd import FluidNetModel
     layers = S.default_3d_layers(seed=5)
     dev = torch.device("cuda:0")
-    for dims, seed in [((32, 32, 32), 51), ((13, 21, 45), 52), ((5, 9, 33), 53)]:
+    for dims, seed in [((32, 32, 32), 51), ((13, 21, 45), 52), ((5, 9, 33), 53), ((6, 7, 130), 54)]:
         sc = scenes.make_scene(dims, seed=seed, vel_cells=0.4, B=2)
         tp, tU, tf = (torch.from_numpy(sc[k]).to(dev) for k in ("p", "U", "flags"))
         monkeypatch.setenv("TFL_CONV_PATH", "direct")
@@ -185,10 +186,10 @@ def test_conv_paths_agree_3d(oracle, monkeypatch):
         pm, Um = FluidNetModel(layers, True).forward([tp, tU, tf])
         rp, rU = scenes.rel_l2(pm.cpu().numpy(), pd.cpu().numpy()), scenes.rel_l2(Um.cpu().numpy(), Ud.cpu().numpy())
         assert rp <= 2e-6 and rU <= 2e-6, (dims, rp, rU)
-        monkeypatch.delenv("TFL_CONV_PATH")      # the default: direct VALU kernels (conv_valu.hip)
-        pv, Uv = FluidNetModel(layers, True).forward([tp, tU, tf])
-        rp, rU = scenes.rel_l2(pv.cpu().numpy(), pd.cpu().numpy()), scenes.rel_l2(Uv.cpu().numpy(), Ud.cpu().numpy())
-        assert rp <= 2e-6 and rU <= 2e-6, ("valu", dims, rp, rU)
+        monkeypatch.delenv("TFL_CONV_PATH")      # the default: conv_valu.hip, Winograd along x
+        pw, Uw = FluidNetModel(layers, True).forward([tp, tU, tf])
+        rp, rU = scenes.rel_l2(pw.cpu().numpy(), pd.cpu().numpy()), scenes.rel_l2(Uw.cpu().numpy(), Ud.cpu().numpy())
+        assert rp <= 2e-6 and rU <= 2e-6, ("wino", dims, rp, rU)
         p_ref, U_ref = S.model_forward(oracle, layers, sc["p"], sc["U"], sc["flags"])
         assert scenes.rel_l2(pm.cpu().numpy(), p_ref) <= TOL and scenes.rel_l2(Um.cpu().numpy(), U_ref) <= TOL
 
