@@ -37,6 +37,7 @@ struct tfl_model {
   float* wino[3] = {nullptr, nullptr, nullptr};   // F(2,3)-in-x transformed weights of the same layers, [dz][dy][cin][4][8]
   float* tail_w4 = nullptr;                       // [8][8] (out, in) of the 8->8 k1 layer
   float* tail_w5 = nullptr;                       // [8] of the 8->1 k1 layer
+  float* tail_pack = nullptr;                     // conv_valu.hip: {bias3[8], w4[8][8], b4[8], w5[8], b5[1]} in one buffer
   // 2-D `default` topology (3->16, 16->16 x3 k3, 16->1 k1): MFMA path (conv2d_mfma.hip)
   bool mfma2d = false;
   float* bfrag2[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -617,6 +618,14 @@ tfl_model* tfl_model_create_ex(tfl_ctx* c, int is3D, int nlayers, const int32_t*
     // their weights, Winograd-transformed along x: U = (g0, (g0 + g1 + g2)/2, (g0 - g1 + g2)/2, g2) over the three x-taps
     // of every (dz, dy, c_in, c_out)
     if (m->valu3d) {
+      std::vector<float> tp(8 + 64 + 8 + 8 + 1);
+      for (int i = 0; i < 8; i++) tp[i] = biases[2][i];
+      for (int i = 0; i < 64; i++) tp[8 + i] = weights[3][i];
+      for (int i = 0; i < 8; i++) { tp[72 + i] = biases[3][i]; tp[80 + i] = weights[4][i]; }
+      tp[88] = biases[4][0];
+      if (hipMalloc((void**)&m->tail_pack, tp.size() * sizeof(float)) != hipSuccess ||
+          hipMemcpy(m->tail_pack, tp.data(), tp.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
+        return cleanup("uploading tail weights failed");
       for (int l = 0; l < 3; l++) {
         const int ci_n = cin[l];
         std::vector<float> u((size_t)9 * 4 * ci_n * 8);
@@ -667,6 +676,7 @@ void tfl_model_destroy(tfl_ctx* c, tfl_model* m) {
   for (int l = 0; l < 3; l++) if (m->wino[l]) (void)hipFree(m->wino[l]);
   for (int l = 0; l < 4; l++) if (m->bfrag2[l]) (void)hipFree(m->bfrag2[l]);
   if (m->tail_w4) (void)hipFree(m->tail_w4);
+  if (m->tail_pack) (void)hipFree(m->tail_pack);
   if (m->tail_w5) (void)hipFree(m->tail_w5);
   if (m->d_stats) (void)hipFree(m->d_stats);
   delete m;
@@ -758,8 +768,7 @@ int tfl_model_finish(tfl_ctx* c, tfl_model* m, const tfl_tensor* pDiv, const tfl
       tfl::conv3_valu_first_fused(st, B, Z, Y, X, pDiv->data, w.div, flags->data, st_in, count, m->wino[0], m->layers[0].b, w.act[0]);
     if (stg & 2) tfl::conv3_valu_mid(st, B, Z, Y, X, w.act[0], m->wino[1], m->layers[1].b, w.act[1]);
     if (stg & 4)
-      tfl::conv3_valu_tail(st, B, Z, Y, X, w.act[1], m->wino[2], m->layers[2].b, m->tail_w4, m->layers[3].b, m->tail_w5,
-                           m->layers[4].b, w.pPred);
+      tfl::conv3_valu_tail(st, B, Z, Y, X, w.act[1], m->wino[2], m->tail_pack, w.pPred);
   } else if (m->mfma3d) {
     // the first MFMA layer builds {pDiv/scale, div/scale, occupancy} while staging its LDS tile
     if (stg & 1)

@@ -21,7 +21,7 @@
 // Block = 256 threads = 4 waves, tile 64(x) x 2(y) x 4(z): wave w owns z-plane w; lane = (pair 0..31, row 0..1); a lane
 // keeps 4 Winograd points x 8 output channels = 32 accumulators. Input channels are staged 4 at a time as channel-planar
 // halo planes [4][6][4][66(+2)] = 26 KB of LDS; per (channel, dz) a lane issues 3 ds_read2_b64 for 96 FMAs. 96 VGPRs ->
-// 5 blocks per CU (the TAIL variant needs 97 and gets 4; forcing it to 96 spills into the loop and costs 50%).
+// 5 blocks per CU.
 // Staging loads of a stage are ALL issued before the first LDS write (written load->store per element, hipcc waits for
 // every load in turn -- the mistake that sank two LDS advection kernels, profiles/r02_advect_experiments.txt).
 // Activations between layers are channel-PLANAR [8][Z][Y][X]: a wave's staging load of a (channel, row) is one
@@ -53,12 +53,10 @@ constexpr int kRowsT = (kVZ + 2) * kRowsP;                // halo rows per chann
 constexpr int kPlaneF = kRowsT * kPX;                     // floats per staged channel
 constexpr int kPerWave = (kRowsT + 3) / 4;                // staged rows per wave
 
-struct VTail {          // fused 1x1x1 layers (device pointers): h4 = relu(W4 h + b4); p = w5 . h4 + b5
-  const float* w4;      // [8][8]  (out, in)
-  const float* b4;      // [8]
-  const float* w5;      // [8]
-  const float* b5;      // [1]
-};
+// fused 1x1x1 layers of the TAIL variant: h4 = relu(W4 h + b4); p = w5 . h4 + b5, read through the `bias` pointer, which
+// then holds {bias[8], w4[8][8] (out, in), b4[8], w5[8], b5[1]} (one pointer instead of five: the four extra ones cost
+// the kernel its 97th VGPR through SGPR spills, and with it the fifth block per CU)
+constexpr int kTailW4 = 8, kTailB4 = 72, kTailW5 = 80, kTailB5 = 88;
 struct VIn {            // fused network input (first layer): {pDiv/scale, div/scale, occupancy(flags)}
   const float* pDiv;    // [B][1][Z][Y][X]
   const float* div;
@@ -75,8 +73,7 @@ struct VIn {            // fused network input (first layer): {pDiv/scale, div/s
 template <int CIN, bool TAIL>
 __global__ __launch_bounds__(256, TFL_VALU_LB) void k_conv3_wino(Dom d, int tiles_x, int tiles_y, int tiles_z, int n_tiles,
                                                                  const float* __restrict__ in, const float* __restrict__ wq,
-                                                                 const float* __restrict__ bias, float* __restrict__ out, VTail tail,
-                                                                 VIn cin) {
+                                                                 const float* __restrict__ bias, float* __restrict__ out, VIn cin) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr bool FIRST = CIN == 3;
   constexpr int CG = FIRST ? 3 : 4;                        // channels staged per pass
@@ -205,7 +202,7 @@ __global__ __launch_bounds__(256, TFL_VALU_LB) void k_conv3_wino(Dom d, int tile
   if (x >= d.X || z >= z_end) return;
   const bool pair_ok = x + 1 < d.X;
   const bool vec2 = (d.X & 1) == 0;          // x is even: an (x, x+1) pair is 8-byte aligned iff the row pitch is even
-  const float b5 = TAIL ? tail.b5[0] : 0.0f;
+  const float b5 = TAIL ? bias[kTailB5] : 0.0f;
   out += (long long)b * cells * (TAIL ? 1 : 8);
 #pragma unroll
   for (int v = 0; v < kVY; v++) {
@@ -232,10 +229,10 @@ __global__ __launch_bounds__(256, TFL_VALU_LB) void k_conv3_wino(Dom d, int tile
         p[e] = b5;
 #pragma unroll
         for (int j = 0; j < 8; j++) {        // 8 -> 8 (k = 1) + ReLU, then 8 -> 1
-          float q = tail.b4[j];
+          float q = bias[kTailB4 + j];
 #pragma unroll
-          for (int i = 0; i < 8; i++) q = __builtin_fmaf(tail.w4[j * 8 + i], h[e][i], q);
-          p[e] = __builtin_fmaf(tail.w5[j], fmaxf(q, 0.0f), p[e]);
+          for (int i = 0; i < 8; i++) q = __builtin_fmaf(bias[kTailW4 + j * 8 + i], h[e][i], q);
+          p[e] = __builtin_fmaf(bias[kTailW5 + j], fmaxf(q, 0.0f), p[e]);
         }
       }
       put(out + o, p[0], p[1]);
@@ -245,7 +242,7 @@ __global__ __launch_bounds__(256, TFL_VALU_LB) void k_conv3_wino(Dom d, int tile
 
 template <int CIN, bool TAIL>
 static void launch_wino(hipStream_t st, const Dom& d, int B, const float* in, const float* wq, const float* bias, float* out,
-                        VTail tail, VIn cin) {
+                        VIn cin) {
   const int tx = (d.X + kVX - 1) / kVX, ty = (d.Y + kTY - 1) / kTY;
   const int tz = (d.n0 + kVZ - 1) / kVZ + (d.nw - d.n0 + kVZ - 1) / kVZ;   // z-tiles of the compute window's two plane runs
   const int n_tiles = tx * ty * tz * B;
@@ -263,28 +260,25 @@ static void launch_wino(hipStream_t st, const Dom& d, int B, const float* in, co
   }
   // profiler names kept from the MFMA kernels they replace (bench.py's per-layer flop table is keyed by them)
   TFL_TIMED_EXT(TAIL ? "k_conv3_tail" : (CIN == 3 ? "k_conv3_in" : "k_conv3_mid"), st);
-  TFL_LAUNCH_EXT((k_conv3_wino<CIN, TAIL>), grid, 256, lds_bytes, st, d, tx, ty, tz, n_tiles, in, wq, bias, out, tail, cin);
+  TFL_LAUNCH_EXT((k_conv3_wino<CIN, TAIL>), grid, 256, lds_bytes, st, d, tx, ty, tz, n_tiles, in, wq, bias, out, cin);
 }
 
 // first layer: {pDiv/scale, div/scale, occupancy} built while staging; activations out: channel-planar [B][8][Z][Y][X]
 void conv3_valu_first_fused(hipStream_t st, int B, int Z, int Y, int X, const float* pDiv, const float* div, const float* flags,
                             const double* stats, double count, const float* wq, const float* bias, float* out_p8) {
-  VTail none = {nullptr, nullptr, nullptr, nullptr};
   VIn ci = {pDiv, div, flags, stats, count};
-  launch_wino<3, false>(st, make_dom(Z, Y, X), B, pDiv, wq, bias, out_p8, none, ci);
+  launch_wino<3, false>(st, make_dom(Z, Y, X), B, pDiv, wq, bias, out_p8, ci);
 }
 void conv3_valu_mid(hipStream_t st, int B, int Z, int Y, int X, const float* in_p8, const float* wq, const float* bias,
                     float* out_p8) {
-  VTail none = {nullptr, nullptr, nullptr, nullptr};
   VIn noin = {nullptr, nullptr, nullptr, nullptr, 0.0};
-  launch_wino<8, false>(st, make_dom(Z, Y, X), B, in_p8, wq, bias, out_p8, none, noin);
+  launch_wino<8, false>(st, make_dom(Z, Y, X), B, in_p8, wq, bias, out_p8, noin);
 }
 // 8 -> 8 k3 + ReLU, then 8 -> 8 k1 + ReLU, then 8 -> 1 k1; planar pressure out.
-void conv3_valu_tail(hipStream_t st, int B, int Z, int Y, int X, const float* in_p8, const float* wq, const float* bias,
-                     const float* w4, const float* b4, const float* w5, const float* b5, float* p_out) {
-  VTail tail = {w4, b4, w5, b5};
+void conv3_valu_tail(hipStream_t st, int B, int Z, int Y, int X, const float* in_p8, const float* wq, const float* tail_pack,
+                     float* p_out) {
   VIn noin = {nullptr, nullptr, nullptr, nullptr, 0.0};
-  launch_wino<8, true>(st, make_dom(Z, Y, X), B, in_p8, wq, bias, p_out, tail, noin);
+  launch_wino<8, true>(st, make_dom(Z, Y, X), B, in_p8, wq, tail_pack, p_out, noin);
 }
 
 }  // namespace tfl

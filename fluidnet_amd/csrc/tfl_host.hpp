@@ -151,8 +151,9 @@ void conv3_valu_first_fused(hipStream_t st, int B, int Z, int Y, int X, const fl
                             const double* stats, double count, const float* wq, const float* bias, float* out_p8);
 void conv3_valu_mid(hipStream_t st, int B, int Z, int Y, int X, const float* in_p8, const float* wq, const float* bias,
                     float* out_p8);
-void conv3_valu_tail(hipStream_t st, int B, int Z, int Y, int X, const float* in_p8, const float* wq, const float* bias,
-                     const float* w4, const float* b4, const float* w5, const float* b5, float* p_out);
+// tail_pack: {bias of the k3 layer [8], w4 [8][8] (out, in), b4 [8], w5 [8], b5 [1]} (tfl_model::tail_pack)
+void conv3_valu_tail(hipStream_t st, int B, int Z, int Y, int X, const float* in_p8, const float* wq, const float* tail_pack,
+                     float* p_out);
 
 // backward.hip
 void velocity_divergence_bwd(hipStream_t st, bool is3d, int B, int Z, int Y, int X, const float* flags,
