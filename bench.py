@@ -171,10 +171,14 @@ def main():
     dev = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
+        import datetime
+        # a rank whose neighbour never shows up must end the job, not hang it: the process-group timeout is what the
+        # RCCL watchdog (nccl) / DistComm.wait (gloo) enforce
+        pg_timeout = datetime.timedelta(seconds=300)
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, timeout=pg_timeout)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=pg_timeout)
 
     from fluidnet_amd import FluidNetModel, tfluids
     model = FluidNetModel.default_3d(seed=1)

@@ -99,13 +99,19 @@ class _CommBase:
 class DistComm(_CommBase):
     """Halo exchange + all-reduce over torch.distributed: nccl (= RCCL over xGMI) on GPU tensors; with the gloo
     backend messages are staged through the host (CPU tensors directly) -- that path only validates the multi-rank
-    control flow on a box with fewer GPUs than ranks (TFL_DIST_BACKEND=gloo), it is not a measured configuration."""
+    control flow on a box with fewer GPUs than ranks (TFL_DIST_BACKEND=gloo), it is not a measured configuration.
 
-    def __init__(self, rank, world, group=None):
+    A neighbour that never arrives: with gloo, `wait` gives up after `timeout_s` and raises TimeoutError naming the
+    exchange (the native step turns that into TFL_ECOMM, see _CommBase). With nccl the wait only orders streams and
+    cannot time out on the host; there the process group's own timeout applies (init_process_group(timeout=...); the
+    NCCL/RCCL watchdog aborts the job when a send/recv has not completed by then) -- bench.py sets it explicitly."""
+
+    def __init__(self, rank, world, group=None, timeout_s=300.0):
         super().__init__()
         import torch.distributed as dist
         self.dist, self.group, self.rank, self.world = dist, group, rank, world
         self.stage_host = dist.get_backend(group) == "gloo"
+        self.timeout_s = float(timeout_s)
         self._pending = {}
 
     def start(self, tag, send_lo, recv_lo, send_hi, recv_hi):
@@ -131,9 +137,16 @@ class DistComm(_CommBase):
         self._pending[tag] = (dist.batch_isend_irecv(ops) if ops else [], back)
 
     def wait(self, tag):
+        import datetime
         works, back = self._pending.pop(tag)
         for w in works:
-            w.wait()          # nccl: the current stream waits; gloo: the host does
+            try:
+                ok = w.wait(datetime.timedelta(seconds=self.timeout_s))   # nccl: the current stream waits; gloo: the host does
+            except RuntimeError as e:
+                raise TimeoutError("halo exchange %d of rank %d did not complete within %.0f s (%s)"
+                                   % (tag, self.rank, self.timeout_s, str(e).splitlines()[0])) from e
+            if ok is False:
+                raise TimeoutError("halo exchange %d of rank %d did not complete within %.0f s" % (tag, self.rank, self.timeout_s))
         for dev_t, h in back:
             dev_t.copy_(h)
 

@@ -95,6 +95,42 @@ def test_transport_callbacks_gloo(world):
     assert dict(out) == {r: True for r in range(world)}
 
 
+def _worker_absent_neighbour(rank, world, port, out):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        if rank == 0:
+            ws = torch.zeros(1024)
+            comm = DistComm(rank, world, timeout_s=1.5)
+            comm.bind(ws)
+            p = lambda off: ctypes.cast(ws.data_ptr() + 4 * off, ctypes.POINTER(ctypes.c_float))
+            # rank 0 posts a send/recv with rank 1, which never takes part
+            rc0 = comm.struct.exchange_start(None, 0, None, 0, None, 0, p(0), 8, p(8), 8)
+            rc1 = comm.struct.exchange_wait(None, 0)
+            out[0] = (rc0, rc1, type(comm.error).__name__)
+        else:
+            import time
+            time.sleep(4.0)
+            out[1] = "idle"
+    finally:
+        try:
+            dist.destroy_process_group()
+        except Exception:
+            pass
+
+
+def test_absent_neighbour_times_out_instead_of_hanging():
+    """a halo partner that never arrives must surface as an error. With gloo the wait gives up
+    after DistComm.timeout_s; the callback returns non-zero (the native step reports TFL_ECOMM) and keeps the exception."""
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker_absent_neighbour, args=(2, _free_port(), out), nprocs=2, join=True)
+    rc0, rc1, err = out[0]
+    assert rc0 == 0 and rc1 != 0 and err == "TimeoutError", out[0]
+
+
 def test_transport_callbacks_threads():
     """ThreadComm (virtual ranks of the single-GPU decomposition tests) obeys the same contract."""
     import threading

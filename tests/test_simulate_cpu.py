@@ -99,3 +99,44 @@ def test_plume_bcs_slab_construction_matches_global_slice():
         createPlumeBCs(l, [1.0], 2.0, 0.15, zOffset=lo, zTotal=Zt)
         for k in ("UBC", "UBCInvMask", "densityBC", "densityBCInvMask"):
             assert torch.equal(l[k], g[k][:, :, lo:hi]), (k, lo)
+
+
+def _direct_sum_conv(x, w, b, relu):
+    """Independent witness for the oracle's convolutions: cross-correlation, stride 1, zero padding (k-1)/2, written
+    as an explicit fp64 sum over taps with numpy slicing only (no torch, no FFT, no im2col)."""
+    x = np.asarray(x, np.float64); w = np.asarray(w, np.float64)
+    nd = w.ndim - 2
+    k = w.shape[-1]; r = (k - 1) // 2
+    xp = np.pad(x, [(0, 0), (0, 0)] + [(r, r)] * nd)
+    out = np.zeros((x.shape[0], w.shape[0]) + x.shape[2:], np.float64)
+    for tap in np.ndindex(*([k] * nd)):
+        sl = tuple(slice(t, t + n) for t, n in zip(tap, x.shape[2:]))
+        patch = xp[(slice(None), slice(None)) + sl]                       # [B, Cin, ...]
+        out += np.tensordot(w[(slice(None), slice(None)) + tap], patch, axes=([1], [1])).swapaxes(0, 1)
+    out += np.asarray(b, np.float64).reshape((1, -1) + (1,) * nd)
+    return np.maximum(out, 0.0) if relu else out
+
+
+@pytest.mark.parametrize("is3d", [False, True])
+def test_conv_stack_against_fp64_direct_sum(is3d):
+    """the ConvNet's arithmetic lives in cuDNN (absent), the oracle uses PyTorch-CPU convolutions;
+    a second, independent evaluation (explicit fp64 tap sums in numpy) pins what `conv_stack` computes -- padding,
+    cross-correlation orientation, bias, ReLU placement -- so PyTorch is not the only witness. 2-D: the SHIPPED model's
+    weights (tests/golden/myModel2D_weights.npz); 3-D: the seeded default topology."""
+    rng = np.random.RandomState(3)
+    if is3d:
+        layers = S.default_3d_layers(seed=5)
+        x = rng.randn(2, 3, 9, 12, 14).astype(np.float32)
+    else:
+        layers = _layers2d()
+        x = rng.randn(2, 3, 1, 21, 30).astype(np.float32)
+    got32 = S.conv_stack(x, layers, is3d)
+    got64 = S.conv_stack(x, layers, is3d, dtype="float64")
+    h = x[:, :, 0] if not is3d else x
+    for li, (w, b) in enumerate(layers):
+        h = _direct_sum_conv(h, w, b, relu=li + 1 < len(layers))
+    want = h[:, :, None] if not is3d else h
+    assert got64.shape == want.shape
+    # conv_stack returns float32 even for the fp64 run: one rounding of the final value
+    assert scenes.rel_l2(got64, want) <= 1e-7
+    assert scenes.rel_l2(got32, want) <= 2e-6
