@@ -24,7 +24,7 @@ def short(name):
     if k == "k_conv3_mfma":
         a = [t.strip() for t in targs.strip("<>").split(",")]
         return "k_conv3_mfma_in" if a[1] == "true" else ("k_conv3_mfma_tail" if a[2] == "true" else "k_conv3_mfma")
-    if k == "k_conv3_valu":          # profiler names of conv_valu.hip's launches
+    if k in ("k_conv3_valu", "k_conv3_wino"):          # profiler names of conv_valu.hip's launches
         a = [t.strip() for t in targs.strip("<>").split(",")]
         return "k_conv3_in" if a[0] == "3" else ("k_conv3_tail" if a[1] == "true" else "k_conv3_mid")
     if k == "k_apply_bcs_indexed_multi":
