@@ -61,6 +61,7 @@ def test_simulate_parity_at_baseline_size(request, res, config, preroll, steps):
     for k in ("pDiv", "UDiv", "density"):
         got = batch[k].cpu().numpy()
         r = scenes.rel_l2(got, nb[k])
+        print("parity %d^3 vs %s: %s rel-L2 %.2e" % (res, kind, k, r))
         assert np.isfinite(got).all() and r <= TOL, (res, kind, k, r)
 
 
