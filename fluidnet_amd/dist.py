@@ -140,8 +140,11 @@ class DistComm(_CommBase):
         import datetime
         works, back = self._pending.pop(tag)
         for w in works:
+            if not self.stage_host:
+                w.wait()      # nccl: only the current STREAM waits (an explicit timeout would block the host thread instead)
+                continue
             try:
-                ok = w.wait(datetime.timedelta(seconds=self.timeout_s))   # nccl: the current stream waits; gloo: the host does
+                ok = w.wait(datetime.timedelta(seconds=self.timeout_s))   # gloo: the host waits
             except RuntimeError as e:
                 raise TimeoutError("halo exchange %d of rank %d did not complete within %.0f s (%s)"
                                    % (tag, self.rank, self.timeout_s, str(e).splitlines()[0])) from e
