@@ -1,6 +1,6 @@
 #!/bin/bash
 # SQ counters of the conv kernels (two --pmc passes, kernel-trace only) -> gpurun_out/pmc_conv/*.csv + summary
-# usage: tools/pmc_conv.sh [env assignments for the bench, e.g. TFL_CONV_PATH=valu]
+# usage: tools/pmc_conv.sh [env assignments for the bench, e.g. TFL_CONV_PATH=mfma]
 REPO=$(cd "$(dirname "$0")/.." && pwd); export TMPDIR=/tmp
 O=$REPO/gpurun_out/pmc_conv; mkdir -p $O
 tag=${1:-default}; shift
