@@ -17,6 +17,12 @@ class TfluidsError(RuntimeError):
     """Raised where the reference raises luaL_error / THError (torch/tfluids/init.lua asserts)."""
 
 
+class tfl_model_opts(ctypes.Structure):
+    """include/tfluids_hip.h tfl_model_opts"""
+    _fields_ = [(n, ctypes.c_int32) for n in ("in_pDiv", "in_UDiv", "in_div", "normalize", "norm_chan", "norm_func",
+                                              "nonlin", "pressure_skip")]
+
+
 class tfl_tensor(ctypes.Structure):
     _fields_ = [("data", ctypes.c_void_p), ("B", ctypes.c_int32), ("C", ctypes.c_int32),
                 ("Z", ctypes.c_int32), ("Y", ctypes.c_int32), ("X", ctypes.c_int32)]
@@ -96,6 +102,10 @@ SIGNATURES = {
                                           _c.POINTER(_c.c_int32), _c.POINTER(_c.c_int32), _c.POINTER(_c.c_int32),
                                           _c.POINTER(_c.c_int32), _c.POINTER(_c.POINTER(_c.c_float)),
                                           _c.POINTER(_c.POINTER(_c.c_float))]),
+    "tfl_model_create_opts": (_c.c_void_p, [_c.c_void_p, _c.c_int, _c.c_int, _c.POINTER(_c.c_int32),
+                                            _c.POINTER(_c.c_int32), _c.POINTER(_c.c_int32), _c.POINTER(_c.c_int32),
+                                            _c.POINTER(_c.c_int32), _c.POINTER(_c.POINTER(_c.c_float)),
+                                            _c.POINTER(_c.POINTER(_c.c_float)), _c.c_void_p]),
     "tfl_model_destroy": (None, [_c.c_void_p, _c.c_void_p]),
     "tfl_model_workspace_floats": (_c.c_int64, [_c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.c_int]),
     "tfl_model_forward": (_c.c_int, [_c.c_void_p, _c.c_void_p, _T, _T, _T, _T, _T, _c.c_void_p,

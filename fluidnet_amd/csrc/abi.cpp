@@ -42,6 +42,10 @@ struct tfl_model {
   bool mfma2d = false;
   float* bfrag2[4] = {nullptr, nullptr, nullptr, nullptr};
   double* d_stats = nullptr;  // [2 * kMaxBatch]: sum(u), sum(u^2) per sample
+  // forward-graph switches (tfl_model_opts); `custom` = any of them differs from default_conf.lua -> generic kernels only
+  tfl_model_opts opts = {1, 0, 1, 1, TFL_NORM_UDIV, TFL_NORMFUNC_STD, TFL_NONLIN_RELU, 0};
+  bool custom = false;
+  int in_c = 3;               // net input channels
 };
 
 #include "tfl_ctx.hpp"
@@ -526,25 +530,50 @@ tfl_model* tfl_model_create(tfl_ctx* c, int is3D, int nlayers, const int32_t* ci
 tfl_model* tfl_model_create_ex(tfl_ctx* c, int is3D, int nlayers, const int32_t* cin, const int32_t* cout,
                                const int32_t* ksize, const int32_t* pool, const int32_t* up,
                                const float* const* weights, const float* const* biases) {
+  return tfl_model_create_opts(c, is3D, nlayers, cin, cout, ksize, pool, up, weights, biases, nullptr);
+}
+
+tfl_model* tfl_model_create_opts(tfl_ctx* c, int is3D, int nlayers, const int32_t* cin, const int32_t* cout,
+                                 const int32_t* ksize, const int32_t* pool, const int32_t* up,
+                                 const float* const* weights, const float* const* biases, const tfl_model_opts* opts) {
   if (!c) return nullptr;
   auto bad = [&](const char* m) -> tfl_model* { fail(c, TFL_EINVAL, "model_create: %s", m); return nullptr; };
   if (nlayers < 1 || !cin || !cout || !ksize || !weights || !biases) return bad("null or empty layer description");
-  if (cin[0] != 3) return bad("the default model takes 3 input channels {pDiv, div, occupancy}");
+  tfl_model_opts o = {1, 0, 1, 1, TFL_NORM_UDIV, TFL_NORMFUNC_STD, TFL_NONLIN_RELU, 0};
+  if (opts) {
+    o = *opts;
+    o.in_pDiv = o.in_pDiv != 0; o.in_UDiv = o.in_UDiv != 0; o.in_div = o.in_div != 0; o.normalize = o.normalize != 0;
+    o.pressure_skip = o.pressure_skip != 0;
+    if (!o.in_pDiv && !o.in_UDiv && !o.in_div) return bad("Are you sure you dont want any (U, div or p) fields?");   // model.lua:50-52
+    if (o.norm_chan < TFL_NORM_UDIV || o.norm_chan > TFL_NORM_DIV) return bad("Incorrect normalize input channel.");
+    if (o.norm_func != TFL_NORMFUNC_STD && o.norm_func != TFL_NORMFUNC_L2) return bad("Incorrect normalize input function");
+    if (o.nonlin < TFL_NONLIN_RELU || o.nonlin > TFL_NONLIN_SIGMOID) return bad("Bad mconf.nonlinType");
+    if (o.pressure_skip && nlayers < 2) return bad("addPressureSkip needs a hidden layer to join pDiv to");
+  }
+  const int in_c = o.in_pDiv + o.in_UDiv * (is3D ? 3 : 2) + o.in_div + 1;
+  if (cin[0] != in_c) {
+    fail(c, TFL_EINVAL, "model_create: the first layer must take %d input channels {pDiv, UDiv, div, occupancy as selected}", in_c);
+    return nullptr;
+  }
   if (cout[nlayers - 1] != 1) return bad("the last layer must output 1 channel (pressure)");
   tfl_model* m = new tfl_model();
   m->is3d = is3D != 0;
+  m->opts = o; m->in_c = in_c;
+  m->custom = !(o.in_pDiv && !o.in_UDiv && o.in_div && o.normalize && o.norm_chan == TFL_NORM_UDIV &&
+                o.norm_func == TFL_NORMFUNC_STD && o.nonlin == TFL_NONLIN_RELU && !o.pressure_skip);
   auto cleanup = [&](const char* msg) -> tfl_model* { tfl_model_destroy(c, m); return bad(msg); };
   if (hipMalloc((void**)&m->d_stats, sizeof(double) * 2 * kMaxBatch) != hipSuccess) return cleanup("hipMalloc failed");
   // The shape-generic kernels are instantiated for 1, 2, 4, 8, 16, 32, 64 output channels. Any other width (the
   // `yang` topology of model.lua:188-205 has 6) is zero-padded to the next one: the extra channels carry
   // relu(0 + 0) = 0 into zero weights of the next layer, i.e. every sum gains exact `+ 0 * 0` terms only.
   auto padded = [](int cch) { for (int w : {1, 2, 4, 8, 16, 32, 64}) if (cch <= w) return w; return -1; };
-  int prev_cout_padded = 3;
+  int prev_cout_padded = in_c;
   int res_num = 1, res_den = 1;   // resolution of the current activations relative to the grid = res_num / res_den
   for (int l = 0; l < nlayers; l++) {
     tfl_layer L;
     if (cin[l] < 1 || cout[l] < 1 || ksize[l] < 1 || (ksize[l] % 2) != 1) return cleanup("convolution size must be odd and positive");
-    if (l > 0 && cin[l] != cout[l - 1]) return cleanup("layer channel counts do not chain");
+    const bool skip_in = m->opts.pressure_skip && l + 1 == nlayers;     // this layer also reads pDiv/scale (last channel)
+    if (l > 0 && cin[l] != cout[l - 1] + (skip_in ? 1 : 0)) return cleanup("layer channel counts do not chain");
     L.pool = pool ? pool[l] : 1; L.up = up ? up[l] : 1;
     if ((L.pool != 1 && L.pool != 2) || (L.up != 1 && L.up != 2)) return cleanup("pooling / upsampling factors must be 1 or 2");
     if (L.pool > 1 && L.up > 1) return cleanup("Pooling and upsampling in the same layer!");               // model.lua:322-324
@@ -555,7 +584,7 @@ tfl_model* tfl_model_create_ex(tfl_ctx* c, int is3D, int nlayers, const int32_t*
     if (res_den / res_num > m->max_down) m->max_down = res_den / res_num;
     const int cout_p = (l + 1 == nlayers) ? cout[l] : padded(cout[l]);
     if (cout_p < 0) return cleanup("unsupported output channel count (at most 64)");
-    const int cin_p = prev_cout_padded;
+    const int cin_p = prev_cout_padded + (skip_in ? 1 : 0);     // the skip channel sits after the (padded) hidden channels
     L.cin = cin_p; L.cout = cout_p; L.k = ksize[l];
     prev_cout_padded = cout_p;
     const int taps = m->is3d ? L.k * L.k * L.k : L.k * L.k;
@@ -565,9 +594,11 @@ tfl_model* tfl_model_create_ex(tfl_ctx* c, int is3D, int nlayers, const int32_t*
     for (int sub = 0; sub < S; sub++)
       for (int co = 0; co < cout[l]; co++)
         for (int ci = 0; ci < cin[l]; ci++)
-          for (int t = 0; t < taps; t++)
-            relaid[(((size_t)sub * taps + t) * L.cin + ci) * L.cout + co] =
+          for (int t = 0; t < taps; t++) {
+            const int cid = (skip_in && ci == cin[l] - 1) ? L.cin - 1 : ci;
+            relaid[(((size_t)sub * taps + t) * L.cin + cid) * L.cout + co] =
                 weights[l][(((size_t)co * S + sub) * cin[l] + ci) * taps + t];
+          }
     std::vector<float> bias_p((size_t)S * L.cout, 0.0f);
     for (int sub = 0; sub < S; sub++)
       for (int co = 0; co < cout[l]; co++) bias_p[(size_t)sub * L.cout + co] = biases[l][(size_t)co * S + sub];
@@ -579,13 +610,13 @@ tfl_model* tfl_model_create_ex(tfl_ctx* c, int is3D, int nlayers, const int32_t*
       return cleanup("uploading weights failed");
     }
     m->layers.push_back(L);
-    if (L.cout > m->max_c && l + 1 < nlayers) m->max_c = L.cout;
+    if (L.cout + (m->opts.pressure_skip ? 1 : 0) > m->max_c && l + 1 < nlayers) m->max_c = L.cout + (m->opts.pressure_skip ? 1 : 0);
   }
   if (res_num != res_den) return cleanup("the layers do not return to the grid resolution (pool / up factors)");
   if (m->max_c < 1) m->max_c = 1;
   // ---- MFMA path for the 3-D default topology (TFL_CONV_PATH=direct forces the generic kernels) ----
   const char* force = getenv("TFL_CONV_PATH");
-  const bool want_mfma = !(force && strcmp(force, "direct") == 0);
+  const bool want_mfma = !(force && strcmp(force, "direct") == 0) && !m->custom;
   const int dflt[5][3] = {{3, 8, 3}, {8, 8, 3}, {8, 8, 3}, {8, 8, 1}, {8, 1, 1}};
   bool match = m->is3d && nlayers == 5 && !m->multires;
   for (int l = 0; match && l < 5; l++) match = cin[l] == dflt[l][0] && cout[l] == dflt[l][1] && ksize[l] == dflt[l][2];
@@ -686,8 +717,8 @@ int64_t tfl_model_workspace_floats(const tfl_model* m, int B, int Z, int Y, int 
   if (!m) return -1;
   const int64_t n = (int64_t)B * Z * Y * X;
   // per-block fp64 stat partials (2 doubles = 4 floats per block, kept first for 8-byte alignment)
-  // + div[1] + net input[3] + two ping-pong activation buffers[max_c] + pPred[1]
-  return 4 * tfl::model_stat_blocks(B, Z, Y, X) + n * (1 + 3 + 2 * (int64_t)m->max_c + 1);
+  // + div[1] + net input[in_c] + two ping-pong activation buffers[max_c] + pPred[1]
+  return 4 * tfl::model_stat_blocks(B, Z, Y, X) + n * (1 + (int64_t)m->in_c + 2 * (int64_t)m->max_c + 1);
 }
 
 namespace {
@@ -704,7 +735,7 @@ int model_ws(tfl_ctx* c, const tfl_model* m, const tfl_tensor* flags, float* wor
   w->partials = (double*)workspace;
   w->div = workspace + 4 * tfl::model_stat_blocks(B, Z, Y, X);
   w->x3 = w->div + n;
-  w->act[0] = w->x3 + 3 * n;
+  w->act[0] = w->x3 + (int64_t)m->in_c * n;
   w->act[1] = w->act[0] + (int64_t)m->max_c * n;
   w->pPred = w->act[1] + (int64_t)m->max_c * n;
   return TFL_OK;
@@ -757,6 +788,23 @@ int tfl_model_finish(tfl_ctx* c, tfl_model* m, const tfl_tensor* pDiv, const tfl
   const int B = flags->B, Z = flags->Z, Y = flags->Y, X = flags->X;
   const double* st_in = stats ? stats : m->d_stats;
   hipStream_t st = c->stream;
+  if (m->custom) {
+    // tfl_model_opts: the input scale comes from another field / function / not at all. All three reach the kernels
+    // through the (stats, count) pair scale_from_stats reads -- sqrt((n s2 - s1^2) / (n (n - 1))): the l2 norm is
+    // (s1, s2, n) = (0, sum x^2, 2), "no scaling" is (0, 1, 2).
+    if (stats || c->stages || c->zwin.a1 > c->zwin.a0 || c->zwin.b1 > c->zwin.b0)
+      return fail(c, TFL_EUNSUPPORTED, "model_finish: models with non-default tfl_model_opts run un-sharded only");
+    const tfl_model_opts& o = m->opts;
+    const long long cells = (long long)Z * Y * X;
+    const float* field = o.norm_chan == TFL_NORM_PDIV ? pDiv->data : (o.norm_chan == TFL_NORM_DIV ? w.div : UOut->data);
+    const long long nf = o.norm_chan == TFL_NORM_UDIV ? cells * (m->is3d ? 3 : 2) : cells;
+    if (!o.normalize) { tfl::model_field_stats(st, B, nf, field, 2, m->d_stats); count = 2.0; }
+    else if (o.norm_func == TFL_NORMFUNC_L2) { tfl::model_field_stats(st, B, nf, field, 1, m->d_stats); count = 2.0; }
+    else if (o.norm_chan != TFL_NORM_UDIV) {
+      if (nf < 2) return fail(c, TFL_EINVAL, "model_finish: Sample variance requires more than one sample.");
+      tfl::model_field_stats(st, B, nf, field, 0, m->d_stats); count = (double)nf;
+    }
+  }
   WindowScope win(c);
   // tfl_set_stages (z-slab ranks run each layer under its own z-window): 1 = first conv layer, 2 = second, 4 = third
   // + the two 1x1x1 layers, 8 = velocity update / un-scale / wall BCs. Only the 3-D MFMA path is staged.
@@ -787,19 +835,32 @@ int tfl_model_finish(tfl_ctx* c, tfl_model* m, const tfl_tensor* pDiv, const tfl
   } else {
     if (m->multires && ((m->is3d && Z % m->max_down) || Y % m->max_down || X % m->max_down))
       return fail(c, TFL_EINVAL, "model_finish: grid %dx%dx%d is not divisible by the model's pooling factor %d", Z, Y, X, m->max_down);
-    tfl::model_net_input(st, m->is3d, B, Z, Y, X, pDiv->data, w.div, flags->data, st_in, count, w.x3);
+    if (m->custom)
+      tfl::model_net_input_gen(st, m->is3d, B, Z, Y, X, m->opts.in_pDiv, m->opts.in_UDiv, m->opts.in_div, pDiv->data,
+                               UOut->data, w.div, flags->data, st_in, count, w.x3);
+    else
+      tfl::model_net_input(st, m->is3d, B, Z, Y, X, pDiv->data, w.div, flags->data, st_in, count, w.x3);
+    const int act = 1 + m->opts.nonlin;            // conv_direct: 1 ReLU, 2 ReLU6, 3 sigmoid
+    const size_t nl = m->layers.size();
+    if (m->opts.pressure_skip && (m->layers[nl - 1].pool > 1 || m->layers[nl - 1].up > 1 || m->layers[nl - 2].pool > 1 ||
+                                  m->layers[nl - 2].up > 1 || (nl > 2 && m->multires)))
+      return fail(c, TFL_EUNSUPPORTED, "model_finish: addPressureSkip with pooling / upsampling layers");
     const float* in = w.x3;
     int Zc = Z, Yc = Y, Xc = X;     // resolution of `in`
     for (size_t l = 0; l < m->layers.size(); l++) {
       const tfl_layer& L = m->layers[l];
       const bool last = l + 1 == m->layers.size();
+      const bool joins_skip = m->opts.pressure_skip && l + 2 == m->layers.size();
       float* out = last ? w.pPred : (in == w.act[0] ? w.act[1] : w.act[0]);
       const int taps = m->is3d ? L.k * L.k * L.k : L.k * L.k;
       const int S = m->is3d ? L.up * L.up * L.up : L.up * L.up;
       for (int sub = 0; sub < S; sub++)      // ConvolutionUpsample: one strided-store convolution per sub-position
-        if (!tfl::conv_direct(st, m->is3d, B, Zc, Yc, Xc, L.cin, L.cout, L.k, !last, in, L.w + (size_t)sub * taps * L.cin * L.cout,
-                              L.b + (size_t)sub * L.cout, out, L.up, sub))
+        if (!tfl::conv_direct(st, m->is3d, B, Zc, Yc, Xc, L.cin, L.cout, L.k, last ? 0 : act, in,
+                              L.w + (size_t)sub * taps * L.cin * L.cout, L.b + (size_t)sub * L.cout, out, L.up, sub,
+                              joins_skip ? L.cout + 1 : 0))
           return fail(c, TFL_EUNSUPPORTED, "model_finish: no kernel for %d output channels", L.cout);
+      // addPressureSkip: pDiv/scale becomes the last input channel of the last layer (model.lua:356-360)
+      if (joins_skip) tfl::model_skip_channel(st, B, (long long)Z * Y * X, pDiv->data, st_in, count, out, L.cout + 1, L.cout);
       if (m->is3d) Zc *= L.up;
       Yc *= L.up; Xc *= L.up;
       in = out;

@@ -23,11 +23,19 @@ namespace tfl {
 struct ConvUp {      // output placement: voxel (i, j, k) of the conv grid goes to (i*u + a, j*u + b, k*uz + c) of `dout`
   int u, uz, a, b, c;
   int oX, oY, oZ;    // size of the output grid
+  int act;           // epilogue: 0 none, 1 ReLU, 2 ReLU6, 3 sigmoid (model_utils.lua:20-34)
+  int och;           // channel planes per batch item of `out` (>= COUT: room for a joined skip channel)
 };
+__device__ __forceinline__ float conv_act(float v, int act) {
+  if (act == 1) return fmaxf(v, 0.0f);
+  if (act == 2) return fminf(fmaxf(v, 0.0f), 6.0f);
+  if (act == 3) return 1.0f / (1.0f + expf(-v));     // nn.Sigmoid (THNN: 1 / (1 + exp(-x)))
+  return v;
+}
 
 // CPT = output channels per thread: COUT for large grids (each activation is loaded once), COUT/4 for small
 // ones where the grid would otherwise leave most CUs idle (2-D 128^2 = 64 blocks of 256 threads).
-template <bool IS3D, int COUT, int CPT, bool RELU>
+template <bool IS3D, int COUT, int CPT>
 __global__ __launch_bounds__(256) void k_conv_direct(Dom d, int cin, int ksz, const float* __restrict__ in,
                                                      const float* __restrict__ w, const float* __restrict__ bias,
                                                      float* __restrict__ out, ConvUp up) {
@@ -39,7 +47,7 @@ __global__ __launch_bounds__(256) void k_conv_direct(Dom d, int cin, int ksz, co
   if (i >= d.X || j >= d.Y) return;
   const long long cells = d.sc;
   const long long ocells = (long long)up.oX * up.oY * up.oZ;
-  in += b * cells * cin; out += b * ocells * COUT;
+  in += b * cells * cin; out += b * ocells * up.och;
   float acc[CPT];
 #pragma unroll
   for (int c = 0; c < CPT; c++) acc[c] = bias[co0 + c];
@@ -75,7 +83,7 @@ __global__ __launch_bounds__(256) void k_conv_direct(Dom d, int cin, int ksz, co
   }
   const long long o = (i * up.u + up.a) + (long long)up.oX * ((j * up.u + up.b) + (long long)up.oY * (k * up.uz + up.c));
 #pragma unroll
-  for (int c = 0; c < CPT; c++) out[o + (co0 + c) * ocells] = RELU ? fmaxf(acc[c], 0.0f) : acc[c];
+  for (int c = 0; c < CPT; c++) out[o + (co0 + c) * ocells] = conv_act(acc[c], up.act);
 }
 
 // cudnn average pooling, window = stride = 2, no padding: out size floor(n / 2) per pooled axis (z only in 3-D)
@@ -96,7 +104,7 @@ __global__ __launch_bounds__(256) void k_avg_pool2(int rows, int Zo, int Yo, int
 }
 
 template <bool IS3D, int COUT>
-static void launch_direct(hipStream_t st, const Dom& d, int B, int cin, int ksz, bool relu, const float* in,
+static void launch_direct(hipStream_t st, const Dom& d, int B, int cin, int ksz, const float* in,
                           const float* w, const float* bias, float* out, const ConvUp& up) {
   const dim3 blk(64, 4, 1);
   const unsigned nxy = ((d.X + 63) / 64) * ((d.Y + 3) / 4);
@@ -105,28 +113,28 @@ static void launch_direct(hipStream_t st, const Dom& d, int B, int cin, int ksz,
   TFL_TIMED("k_conv_direct", st);
   if (split) {
     const dim3 grd((d.X + 63) / 64, (d.Y + 3) / 4, (unsigned)(d.Z * B * (COUT / CPT_SMALL)));
-    if (relu) k_conv_direct<IS3D, COUT, CPT_SMALL, true><<<grd, blk, 0, st>>>(d, cin, ksz, in, w, bias, out, up);
-    else k_conv_direct<IS3D, COUT, CPT_SMALL, false><<<grd, blk, 0, st>>>(d, cin, ksz, in, w, bias, out, up);
+    k_conv_direct<IS3D, COUT, CPT_SMALL><<<grd, blk, 0, st>>>(d, cin, ksz, in, w, bias, out, up);
   } else {
     const dim3 grd((d.X + 63) / 64, (d.Y + 3) / 4, (unsigned)(d.Z * B));
-    if (relu) k_conv_direct<IS3D, COUT, COUT, true><<<grd, blk, 0, st>>>(d, cin, ksz, in, w, bias, out, up);
-    else k_conv_direct<IS3D, COUT, COUT, false><<<grd, blk, 0, st>>>(d, cin, ksz, in, w, bias, out, up);
+    k_conv_direct<IS3D, COUT, COUT><<<grd, blk, 0, st>>>(d, cin, ksz, in, w, bias, out, up);
   }
 }
 
-// w: device, [tap][cin][cout]. Returns false when cout has no instantiation.
-bool conv_direct(hipStream_t st, bool is3d, int B, int Z, int Y, int X, int cin, int cout, int ksz, bool relu,
-                 const float* in, const float* w, const float* bias, float* out, int upf, int sub) {
+// w: device, [tap][cin][cout]. act: 0 none | 1 ReLU | 2 ReLU6 | 3 sigmoid. out_ch: channel planes per batch item of
+// `out` (0 = cout). Returns false when cout has no instantiation.
+bool conv_direct(hipStream_t st, bool is3d, int B, int Z, int Y, int X, int cin, int cout, int ksz, int act,
+                 const float* in, const float* w, const float* bias, float* out, int upf, int sub, int out_ch) {
   Dom d = make_dom(Z, Y, X);
   d.w0 = 0; d.n0 = Z; d.w1 = 0; d.nw = Z;       // the shape-generic path always covers the whole grid
   ConvUp up;
   up.u = upf; up.uz = is3d ? upf : 1;
   up.a = sub % upf; up.b = (sub / upf) % upf; up.c = is3d ? sub / (upf * upf) : 0;
   up.oX = X * up.u; up.oY = Y * up.u; up.oZ = Z * up.uz;
+  up.act = act; up.och = out_ch > 0 ? out_ch : cout;
 #define TFL_CASE(N)                                                                        \
   case N:                                                                                  \
-    if (is3d) launch_direct<true, N>(st, d, B, cin, ksz, relu, in, w, bias, out, up);          \
-    else launch_direct<false, N>(st, d, B, cin, ksz, relu, in, w, bias, out, up);              \
+    if (is3d) launch_direct<true, N>(st, d, B, cin, ksz, in, w, bias, out, up);          \
+    else launch_direct<false, N>(st, d, B, cin, ksz, in, w, bias, out, up);              \
     return true;
   switch (cout) {
     TFL_CASE(1) TFL_CASE(2) TFL_CASE(4) TFL_CASE(8) TFL_CASE(16) TFL_CASE(32) TFL_CASE(64)

@@ -268,6 +268,60 @@ __global__ __launch_bounds__(256) void k_net_input(Dom d, const float* __restric
   x3[o + 2 * d.sc] = (f == kFluid) ? 0.0f : ((f == kObstacle) ? 1.0f : -1.0f);
 }
 
+// The general net input (tfl_model_opts): model.lua:130-148's JoinTable of the selected fields.
+template <bool IS3D>
+__global__ __launch_bounds__(256) void k_net_input_gen(Dom d, int in_pDiv, int in_UDiv, int in_div, const float* __restrict__ pDiv,
+                                                       const float* __restrict__ Ubc, const float* __restrict__ div,
+                                                       const float* __restrict__ flags, const double* __restrict__ stats,
+                                                       double count, float* __restrict__ x) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = blockIdx.y * blockDim.y + threadIdx.y;
+  int b, k; dom_bk(d, b, k);
+  if (i >= d.X || j >= d.Y) return;
+  const long long cells = d.sc;
+  const int C = IS3D ? 3 : 2;
+  const float scale = scale_from_stats(stats, b, count);
+  const int o = TFL_AT(d, i, j, k);
+  const long long bo = b * cells;
+  x += bo * (in_pDiv + in_UDiv * C + in_div + 1);
+  int ch = 0;
+  if (in_pDiv) x[o + (ch++) * cells] = pDiv[bo + o] / scale;               // nn.ApplyScale(true) = CDivTable
+  if (in_UDiv)
+    for (int c = 0; c < C; c++) x[o + (ch++) * cells] = Ubc[bo * C + o + c * cells] / scale;
+  if (in_div) x[o + (ch++) * cells] = div[bo + o] / scale;
+  const int f = (int)flags[bo + o];           // tfluids.FlagsToOccupancy, generic/tfluids.cu:355-371
+  x[o + ch * cells] = (f == kFluid) ? 0.0f : ((f == kObstacle) ? 1.0f : -1.0f);
+}
+
+__global__ __launch_bounds__(1024) void k_field_stats(long long n, const float* __restrict__ field, int mode,
+                                                      double* __restrict__ stats) {
+  const int b = blockIdx.x;
+  const float* p = field + (long long)b * n;
+  double s1 = 0.0, s2 = 0.0;
+  if (mode != 2)
+    for (long long t = threadIdx.x; t < n; t += 1024) { const double v = (double)p[t]; s1 += v; s2 += v * v; }
+  __shared__ double sh1[1024], sh2[1024];
+  sh1[threadIdx.x] = s1; sh2[threadIdx.x] = s2;
+  __syncthreads();
+  for (int w = 512; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) { sh1[threadIdx.x] += sh1[threadIdx.x + w]; sh2[threadIdx.x] += sh2[threadIdx.x + w]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    stats[b * 2] = mode == 0 ? sh1[0] : 0.0;
+    stats[b * 2 + 1] = mode == 2 ? 1.0 : sh2[0];
+  }
+}
+
+__global__ __launch_bounds__(256) void k_skip_channel(long long cells, const float* __restrict__ pDiv,
+                                                      const double* __restrict__ stats, double count,
+                                                      float* __restrict__ dst, int och, int ch) {
+  const int b = blockIdx.y;
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= cells) return;
+  dst[((long long)b * och + ch) * cells + t] = pDiv[(long long)b * cells + t] / scale_from_stats(stats, b, count);
+}
+
 struct BcArgs {  // optional fused tail of simulate(): setConstVals + clamp, simulate.lua:321-326
   const float* UBC; const float* UInvMask;
   int enable_clamp; float lo, hi;
@@ -508,6 +562,27 @@ void model_net_input(hipStream_t st, bool is3d, int B, int Z, int Y, int X, cons
   const dim3 blk(64, 4, 1), grd = TFL_GRID3(d, B);
   if (is3d) { TFL_TIMED("k_net_input", st); k_net_input<true><<<grd, blk, 0, st>>>(d, pDiv, div, flags, stats, count, x3); }
   else { TFL_TIMED("k_net_input", st); k_net_input<false><<<grd, blk, 0, st>>>(d, pDiv, div, flags, stats, count, x3); }
+}
+
+void model_net_input_gen(hipStream_t st, bool is3d, int B, int Z, int Y, int X, int in_pDiv, int in_UDiv, int in_div,
+                         const float* pDiv, const float* Ubc, const float* div, const float* flags, const double* stats,
+                         double count, float* x) {
+  const Dom d = make_dom(Z, Y, X);
+  const dim3 blk(64, 4, 1), grd = TFL_GRID3(d, B);
+  TFL_TIMED("k_net_input", st);
+  if (is3d) k_net_input_gen<true><<<grd, blk, 0, st>>>(d, in_pDiv, in_UDiv, in_div, pDiv, Ubc, div, flags, stats, count, x);
+  else k_net_input_gen<false><<<grd, blk, 0, st>>>(d, in_pDiv, in_UDiv, in_div, pDiv, Ubc, div, flags, stats, count, x);
+}
+
+void model_field_stats(hipStream_t st, int B, long long n, const float* field, int mode, double* stats) {
+  TFL_TIMED("k_field_stats", st);
+  k_field_stats<<<B, 1024, 0, st>>>(n, field, mode, stats);
+}
+
+void model_skip_channel(hipStream_t st, int B, long long cells, const float* pDiv, const double* stats, double count,
+                        float* dst, int och, int ch) {
+  TFL_TIMED("k_skip_channel", st);
+  k_skip_channel<<<dim3((unsigned)((cells + 255) / 256), (unsigned)B), 256, 0, st>>>(cells, pDiv, stats, count, dst, och, ch);
 }
 
 void model_project(hipStream_t st, bool is3d, int B, int Z, int Y, int X, const float* pPred, const float* flags,

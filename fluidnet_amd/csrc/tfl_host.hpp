@@ -110,6 +110,17 @@ void model_pre(hipStream_t st, bool is3d, int B, int Z, int Y, int X, const floa
                float* div, double* partials, double* stats, int zlo, int zhi, int stages = 3);
 void model_net_input(hipStream_t st, bool is3d, int B, int Z, int Y, int X, const float* pDiv, const float* div,
                      const float* flags, const double* stats, double count, float* x3);
+// the general net input of lib/model.lua:130-148: channels {pDiv/scale?, SetWallBcs(U)/scale (C)?, div/scale?, occupancy} in
+// this order into x [B][in_c][Z][Y][X]; Ubc = the wall-BC'd velocity tfl_model_begin left in UOut
+void model_net_input_gen(hipStream_t st, bool is3d, int B, int Z, int Y, int X, int in_pDiv, int in_UDiv, int in_div,
+                         const float* pDiv, const float* Ubc, const float* div, const float* flags, const double* stats,
+                         double count, float* x);
+// stats[b] = {mode 0: sum x, sum x^2 | mode 1: 0, sum x^2 | mode 2: 0, 1} over the n floats of sample b of `field`
+// (the three ways tfl_model_opts sets the input scale through scale_from_stats: std, l2 norm with count = 2, none)
+void model_field_stats(hipStream_t st, int B, long long n, const float* field, int mode, double* stats);
+// dst[b][ch][cell] = pDiv[b][cell] / scale_b: the joined pressure-skip channel (model.lua:356-360); dst has `och` planes per item
+void model_skip_channel(hipStream_t st, int B, long long cells, const float* pDiv, const double* stats, double count,
+                        float* dst, int och, int ch);
 void model_project(hipStream_t st, bool is3d, int B, int Z, int Y, int X, const float* pPred, const float* flags,
                    const double* stats, double count, float* Uio, float* pOut, const float* UBC, const float* UInvMask,
                    int do_clamp, float lo, float hi);
@@ -128,8 +139,9 @@ long long pack_planes(hipStream_t st, int n, float* const* ptrs, const int* rows
 
 // conv.hip
 // upf > 1: the result goes to sub-position `sub` (= (c*upf + b)*upf + a) of an upf-times finer output grid (pixel shuffle)
-bool conv_direct(hipStream_t st, bool is3d, int B, int Z, int Y, int X, int cin, int cout, int ksz, bool relu,
-                 const float* in, const float* w, const float* bias, float* out, int upf = 1, int sub = 0);
+// act: 0 none | 1 ReLU | 2 ReLU6 | 3 sigmoid; out_ch: channel planes per batch item of `out` (0 = cout)
+bool conv_direct(hipStream_t st, bool is3d, int B, int Z, int Y, int X, int cin, int cout, int ksz, int act,
+                 const float* in, const float* w, const float* bias, float* out, int upf = 1, int sub = 0, int out_ch = 0);
 // 2x average pooling of `rows` = B*C planes-stacks [Z][Y][X] -> [Z/2 (3-D)][Y/2][X/2]
 void avg_pool2(hipStream_t st, bool is3d, int rows, int Z, int Y, int X, const float* in, float* out);
 

@@ -99,6 +99,20 @@ tfl_model* tfl_model_create(tfl_ctx* ctx, int is3D, int nlayers, const int32_t* 
 tfl_model* tfl_model_create_ex(tfl_ctx* ctx, int is3D, int nlayers, const int32_t* cin, const int32_t* cout,
                                const int32_t* ksize, const int32_t* pool, const int32_t* up,
                                const float* const* weights, const float* const* biases);
+enum { TFL_NORM_UDIV = 0, TFL_NORM_PDIV = 1, TFL_NORM_DIV = 2 };
+enum { TFL_NORMFUNC_STD = 0, TFL_NORMFUNC_L2 = 1 };
+enum { TFL_NONLIN_RELU = 0, TFL_NONLIN_RELU6 = 1, TFL_NONLIN_SIGMOID = 2 };
+typedef struct tfl_model_opts {
+  int32_t in_pDiv, in_UDiv, in_div;
+  int32_t normalize;
+  int32_t norm_chan;
+  int32_t norm_func;
+  int32_t nonlin;
+  int32_t pressure_skip;
+} tfl_model_opts;
+tfl_model* tfl_model_create_opts(tfl_ctx* ctx, int is3D, int nlayers, const int32_t* cin, const int32_t* cout,
+                                 const int32_t* ksize, const int32_t* pool, const int32_t* up,
+                                 const float* const* weights, const float* const* biases, const tfl_model_opts* opts);
 void tfl_model_destroy(tfl_ctx* ctx, tfl_model* model);
 int64_t tfl_model_workspace_floats(const tfl_model* model, int B, int Z, int Y, int X);
 int tfl_model_forward(tfl_ctx* ctx, tfl_model* model, const tfl_tensor* pDiv, const tfl_tensor* UDiv,
@@ -298,7 +312,9 @@ end
 local Model = {}
 Model.__index = Model
 
-function M.Model(gmodule)
+-- mconf (optional): the model's configuration table (torch.loadModel returns it next to the graph); its fields
+-- inputChannels / normalizeInput* / nonlinType / addPressureSkip select the forward graph as lib/model.lua:27-160 does.
+function M.Model(gmodule, mconf)
   local cin, cout, ks, ws, bs, keep = {}, {}, {}, {}, {}, {}
   local is3D = false
   for _, node in ipairs(gmodule.forwardnodes) do
@@ -315,9 +331,24 @@ function M.Model(gmodule)
   local n = #cin
   assert(n > 0, 'no convolution layers found in the model')
   local self = setmetatable({is3D = is3D}, Model)
-  self.handle = lib.tfl_model_create(ctx, b2i(is3D), n, ffi.new('int32_t[?]', n, cin), ffi.new('int32_t[?]', n, cout),
-                                     ffi.new('int32_t[?]', n, ks), ffi.new('const float*[?]', n, ws),
-                                     ffi.new('const float*[?]', n, bs))
+  local opts = nil
+  if mconf ~= nil then
+    local ic = mconf.inputChannels or {pDiv = true, UDiv = false, div = true, flags = true}
+    assert(ic.flags ~= false, 'Are you sure you dont want flags?')
+    local chan = ({UDiv = lib.TFL_NORM_UDIV, pDiv = lib.TFL_NORM_PDIV, div = lib.TFL_NORM_DIV})[mconf.normalizeInputChan or 'UDiv']
+    local func = ({std = lib.TFL_NORMFUNC_STD, norm = lib.TFL_NORMFUNC_L2})[mconf.normalizeInputFunc or 'std']
+    local nonlin = ({relu = lib.TFL_NONLIN_RELU, relu6 = lib.TFL_NONLIN_RELU6, sigmoid = lib.TFL_NONLIN_SIGMOID})[mconf.nonlinType or 'relu']
+    assert(chan and func and nonlin, 'bad normalizeInputChan / normalizeInputFunc / nonlinType')
+    opts = ffi.new('tfl_model_opts', {b2i(ic.pDiv), b2i(ic.UDiv), b2i(ic.div), b2i(mconf.normalizeInput ~= false), chan, func,
+                                      nonlin, b2i(mconf.addPressureSkip == true)})
+  end
+  local c_cin, c_cout, c_ks = ffi.new('int32_t[?]', n, cin), ffi.new('int32_t[?]', n, cout), ffi.new('int32_t[?]', n, ks)
+  local c_ws, c_bs = ffi.new('const float*[?]', n, ws), ffi.new('const float*[?]', n, bs)
+  if opts == nil then
+    self.handle = lib.tfl_model_create(ctx, b2i(is3D), n, c_cin, c_cout, c_ks, c_ws, c_bs)
+  else
+    self.handle = lib.tfl_model_create_opts(ctx, b2i(is3D), n, c_cin, c_cout, c_ks, nil, nil, c_ws, c_bs, opts)
+  end
   if self.handle == nil then error(ffi.string(lib.tfl_last_error(ctx)), 2) end
   ffi.gc(self.handle, function(h) lib.tfl_model_destroy(ctx, h) end)
   return self

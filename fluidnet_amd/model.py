@@ -16,12 +16,39 @@ from . import _lib, tfluids, torch7
 from ._lib import TfluidsError
 
 
+# the mconf switches that change the forward graph, with torch/lib/default_conf.lua:60-100's defaults
+DEFAULT_OPTS = dict(inputChannels=dict(pDiv=True, UDiv=False, div=True, flags=True), normalizeInput=True,
+                    normalizeInputChan="UDiv", normalizeInputFunc="std", nonlinType="relu", addPressureSkip=False)
+
+
+def _resolve_opts(opts):
+    o = {k: (dict(v) if isinstance(v, dict) else v) for k, v in DEFAULT_OPTS.items()}
+    for k, v in (opts or {}).items():
+        if k == "inputChannels":
+            o[k].update(v)
+        elif k in o:
+            o[k] = v
+        else:
+            raise TfluidsError("unknown model option %r" % (k,))
+    if not o["inputChannels"]["flags"]:
+        raise TfluidsError("Are you sure you dont want flags?")                       # lib/model.lua:81
+    for key, allowed in (("normalizeInputChan", ("UDiv", "pDiv", "div")), ("normalizeInputFunc", ("std", "norm")),
+                         ("nonlinType", ("relu", "relu6", "sigmoid"))):
+        if o[key] not in allowed:
+            raise TfluidsError("bad %s %r (one of %s)" % (key, o[key], ", ".join(allowed)))
+    return o
+
+
 class FluidNetModel:
-    def __init__(self, layers, is3D, pool=None, up=None):
+    def __init__(self, layers, is3D, pool=None, up=None, opts=None):
         """layers: [(weight[nOut, nIn, k(,k),k], bias[nOut])] in forward order (numpy float32),
         weight layout as cudnn.{Spatial,Volumetric}Convolution.weight. pool / up: per-layer psize / usize of
         lib/model.lua's layer tables (1 or 2; None = all 1): 2x average pooling after a layer, or the layer is an
-        nn.{Spatial,Volumetric}ConvolutionUpsample (its weight then has nOut * 2^dim output channels)."""
+        nn.{Spatial,Volumetric}ConvolutionUpsample (its weight then has nOut * 2^dim output channels).
+        opts: mconf fields that change the forward graph (lib/model.lua:27-160, 356-387), defaults as
+        default_conf.lua: inputChannels={pDiv,UDiv,div,flags}, normalizeInput, normalizeInputChan ('UDiv'|'pDiv'|'div'),
+        normalizeInputFunc ('std'|'norm'), nonlinType ('relu'|'relu6'|'sigmoid'), addPressureSkip."""
+        self.opts = _resolve_opts(opts)
         self.is3D = bool(is3D)
         self.layers = [(np.ascontiguousarray(w, np.float32), np.ascontiguousarray(b, np.float32))
                        for w, b in layers]
@@ -99,7 +126,13 @@ class FluidNetModel:
             FP = ctypes.POINTER(ctypes.c_float)
             ws = (FP * n)(*[w.ctypes.data_as(FP) for w, _ in self.layers])
             bs = (FP * n)(*[b.ctypes.data_as(FP) for _, b in self.layers])
-            h = lib.tfl_model_create_ex(ctx, int(self.is3D), n, cin, cout, ks, I32(*self.pool), I32(*self.up), ws, bs)
+            o, ic = self.opts, self.opts["inputChannels"]
+            copts = _lib.tfl_model_opts(int(ic["pDiv"]), int(ic["UDiv"]), int(ic["div"]), int(o["normalizeInput"]),
+                                        ("UDiv", "pDiv", "div").index(o["normalizeInputChan"]),
+                                        ("std", "norm").index(o["normalizeInputFunc"]),
+                                        ("relu", "relu6", "sigmoid").index(o["nonlinType"]), int(o["addPressureSkip"]))
+            h = lib.tfl_model_create_opts(ctx, int(self.is3D), n, cin, cout, ks, I32(*self.pool), I32(*self.up), ws, bs,
+                                          ctypes.byref(copts))
             if not h:
                 raise TfluidsError(lib.tfl_last_error(ctx).decode())
             self._handles[dev] = h

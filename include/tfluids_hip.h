@@ -203,7 +203,7 @@ typedef struct tfl_model tfl_model;
 
 /* Builds the `default` topology: nlayers convolutions (stride 1, zero pad (k-1)/2, cross-correlation,
  * lib/model_utils.lua:80-116), ReLU after all but the last; input channels {pDiv/scale, div/scale,
- * occupancy} (cin[0] must be 3), cout[nlayers-1] must be 1; at most 64 channels per layer. weights[l] is HOST memory laid out like
+ * occupancy} (cin[0] must be 3; other input sets: tfl_model_create_opts), cout[nlayers-1] must be 1; at most 64 channels per layer. weights[l] is HOST memory laid out like
  * cudnn.{Spatial,Volumetric}Convolution.weight: [cout][cin][k(z)][k(y)][k(x)] (no z for 2-D);
  * biases[l] is [cout]. The model copies and re-lays-out the weights; the caller keeps ownership.
  * Returns NULL on error (see tfl_last_error). */
@@ -220,6 +220,31 @@ tfl_model* tfl_model_create(tfl_ctx* ctx, int is3D, int nlayers, const int32_t* 
 tfl_model* tfl_model_create_ex(tfl_ctx* ctx, int is3D, int nlayers, const int32_t* cin, const int32_t* cout,
                                const int32_t* ksize, const int32_t* pool, const int32_t* up,
                                const float* const* weights, const float* const* biases);
+/* The mconf switches of lib/model.lua:27-160, 356-387 that change the FORWARD graph (fields of torch/lib/default_conf.lua:
+ * 60-100 with the same meaning; the defaults there are what tfl_model_create[_ex] builds and what NULL means here):
+ *   in_pDiv / in_UDiv / in_div  inputChannels (flags always feed the net, model.lua:81); the net input is the join, in this
+ *                               order, of pDiv/scale, SetWallBcs(UDiv)/scale (2 or 3 channels), div/scale, occupancy
+ *                               (model.lua:130-148), so cin[0] = in_pDiv + in_UDiv*(2|3) + in_div + 1
+ *   normalize, norm_chan, norm_func  normalizeInput / normalizeInputChan / normalizeInputFunc: scale = per-sample 'std'
+ *                               (n-1) or 'norm' (l2) of SetWallBcs(UDiv), pDiv or div; 0 = no scaling
+ *   nonlin                      nonlinType after every layer but the last (model_utils.lua:20-34)
+ *   pressure_skip               addPressureSkip: pDiv/scale joins the input of the LAST layer as its last channel
+ *                               (model.lua:356-360): cin[nlayers-1] = cout[nlayers-2] + 1
+ * Models with non-default options run through the shape-generic kernels and are not available to the z-slab step. */
+enum { TFL_NORM_UDIV = 0, TFL_NORM_PDIV = 1, TFL_NORM_DIV = 2 };
+enum { TFL_NORMFUNC_STD = 0, TFL_NORMFUNC_L2 = 1 };
+enum { TFL_NONLIN_RELU = 0, TFL_NONLIN_RELU6 = 1, TFL_NONLIN_SIGMOID = 2 };
+typedef struct tfl_model_opts {
+  int32_t in_pDiv, in_UDiv, in_div;
+  int32_t normalize;
+  int32_t norm_chan;
+  int32_t norm_func;
+  int32_t nonlin;
+  int32_t pressure_skip;
+} tfl_model_opts;
+tfl_model* tfl_model_create_opts(tfl_ctx* ctx, int is3D, int nlayers, const int32_t* cin, const int32_t* cout,
+                                 const int32_t* ksize, const int32_t* pool, const int32_t* up,
+                                 const float* const* weights, const float* const* biases, const tfl_model_opts* opts);
 void tfl_model_destroy(tfl_ctx* ctx, tfl_model* model);
 /* Scratch floats tfl_model_forward needs for a [B][.][Z][Y][X] grid. */
 int64_t tfl_model_workspace_floats(const tfl_model* model, int B, int Z, int Y, int X);

@@ -89,9 +89,11 @@ def input_scale(U_bc):
     return np.sqrt(var).astype(np.float32)
 
 
-def conv_stack(x, layers, is3d, dtype="float32", pool=None, up=None):
-    """x: [B, 3, Z, Y, X] float32; layers: [(w[nOut, nIn, k..], b)], ReLU after all but the last. pool / up: the
-    per-layer psize / usize of lib/model.lua's `tog` tables (:163-178, :211-218)."""
+def conv_stack(x, layers, is3d, dtype="float32", pool=None, up=None, nonlin="relu", skip=None):
+    """x: [B, C, Z, Y, X] float32; layers: [(w[nOut, nIn, k..], b)], the non-linearity (model_utils.lua:20-34: relu |
+    relu6 | sigmoid) after all but the last. pool / up: the per-layer psize / usize of lib/model.lua's `tog` tables
+    (:163-178, :211-218). skip: addPressureSkip (model.lua:356-360) -- a [B, 1, Z, Y, X] field joined to the input of
+    the LAST layer as its last channel."""
     import torch
     import torch.nn.functional as F
     td = getattr(torch, dtype)
@@ -100,6 +102,9 @@ def conv_stack(x, layers, is3d, dtype="float32", pool=None, up=None):
         h = h[:, :, 0]
     for li, (w, b) in enumerate(layers):
         wt, bt = torch.from_numpy(np.asarray(w)).to(td), torch.from_numpy(np.asarray(b)).to(td)
+        if skip is not None and li + 1 == len(layers):
+            sk = torch.from_numpy(np.ascontiguousarray(skip)).to(td)
+            h = torch.cat([h, sk if is3d else sk[:, :, 0]], dim=1)      # nn.JoinTable(2)({hl, pDiv})
         pad = (w.shape[-1] - 1) // 2
         h = F.conv3d(h, wt, bt, padding=pad) if is3d else F.conv2d(h, wt, bt, padding=pad)
         u = 1 if up is None else up[li]
@@ -112,7 +117,7 @@ def conv_stack(x, layers, is3d, dtype="float32", pool=None, up=None):
                 no, (hh, ww) = h.shape[1] // u ** 2, h.shape[2:]
                 h = h.view(bsz, no, u, u, hh, ww).permute(0, 1, 4, 2, 5, 3).reshape(bsz, no, hh * u, ww * u)
         if li + 1 < len(layers):
-            h = torch.relu(h)
+            h = {"relu": torch.relu, "relu6": lambda t: torch.clamp(t, 0.0, 6.0), "sigmoid": torch.sigmoid}[nonlin](h)
         if pool is not None and pool[li] > 1:   # cudnn average pooling, window = stride (model_utils.lua:184-208)
             h = F.avg_pool3d(h, pool[li]) if is3d else F.avg_pool2d(h, pool[li])
     if not is3d:
@@ -120,19 +125,60 @@ def conv_stack(x, layers, is3d, dtype="float32", pool=None, up=None):
     return h.to(torch.float32).numpy()
 
 
-def model_forward(ops, layers, pDiv, UDiv, flags, conv_dtype="float32", pool=None, up=None):
-    """`default` model FPROP; returns (p, U) and leaves the inputs untouched."""
+DEFAULT_MODEL_OPTS = dict(inputChannels=dict(pDiv=True, UDiv=False, div=True, flags=True), normalizeInput=True,
+                          normalizeInputChan="UDiv", normalizeInputFunc="std", nonlinType="relu", addPressureSkip=False)
+
+
+def model_opts(opts=None):
+    """default_conf.lua:60-100's forward-graph switches, overridden by `opts` (same field names)."""
+    o = {k: (dict(v) if isinstance(v, dict) else v) for k, v in DEFAULT_MODEL_OPTS.items()}
+    for k, v in (opts or {}).items():
+        if k == "inputChannels":
+            o[k].update(v)
+        elif k in o:
+            o[k] = v
+        else:
+            raise KeyError("unknown model option %r" % k)
+    return o
+
+
+def model_forward(ops, layers, pDiv, UDiv, flags, conv_dtype="float32", pool=None, up=None, opts=None):
+    """Model FPROP, lib/model.lua:27-160 + 356-390; returns (p, U) and leaves the inputs untouched. opts: the mconf
+    switches of model_opts()."""
+    o = model_opts(opts)
+    ic = o["inputChannels"]
+    assert ic["flags"], "Are you sure you dont want flags?"                      # model.lua:81
+    assert ic["div"] or ic["pDiv"] or ic["UDiv"], "Are you sure you dont want any (U, div or p) fields?"
     is3d = UDiv.shape[1] == 3
     U_bc = UDiv.copy()
     ops.setWallBcsForward(U_bc, flags)                       # tfluids/set_wall_bcs.lua:29-48
     div = np.zeros_like(pDiv)
     ops.velocityDivergenceForward(U_bc, flags, div)          # tfluids/velocity_divergence.lua:28-37
-    scale = input_scale(U_bc)                                # [B]
+    if o["normalizeInput"]:                                  # model.lua:93-128
+        src = {"UDiv": U_bc, "pDiv": pDiv, "div": div}[o["normalizeInputChan"]]
+        if o["normalizeInputFunc"] == "std":
+            scale = input_scale(src)                         # nn.StandardDeviation (n-1); the Clamp is a no-op (typo)
+        elif o["normalizeInputFunc"] == "norm":
+            x2 = src.reshape(src.shape[0], -1).astype(np.float64)
+            scale = np.sqrt((x2 * x2).sum(1)).astype(np.float32)     # Power(2) -> Sum -> Sqrt
+        else:
+            raise ValueError("Incorrect normalize input function")
+    else:
+        scale = np.ones(pDiv.shape[0], np.float32)
     sc = scale.reshape(-1, 1, 1, 1, 1)
     occ = np.zeros_like(pDiv)
     ops.flagsToOccupancy(flags, occ)
-    x = np.concatenate([pDiv / sc, div / sc, occ], axis=1)   # apply_scale.lua (CDivTable), JoinTable
-    p_pred = conv_stack(x, layers, is3d, conv_dtype, pool, up)
+    chans = []                                               # model.lua:130-148: pDiv, UDiv, div, occupancy
+    if ic["pDiv"]:
+        chans.append(pDiv / sc)
+    if ic["UDiv"]:
+        chans.append(U_bc / sc)
+    if ic["div"]:
+        chans.append(div / sc)
+    chans.append(occ)
+    x = np.concatenate(chans, axis=1).astype(np.float32)     # apply_scale.lua (CDivTable), JoinTable
+    skip = (pDiv / sc).astype(np.float32) if o["addPressureSkip"] else None
+    p_pred = conv_stack(x, layers, is3d, conv_dtype, pool, up, nonlin=o["nonlinType"], skip=skip)
     U = (U_bc / sc).astype(np.float32)
     ops.velocityUpdateForward(U, flags, np.ascontiguousarray(p_pred))  # velocity_update.lua:29-39
     p = (p_pred * sc).astype(np.float32)                     # model.lua:383-387

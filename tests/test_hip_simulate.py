@@ -194,6 +194,67 @@ def test_conv_paths_agree_3d(oracle, monkeypatch):
         assert scenes.rel_l2(pm.cpu().numpy(), p_ref) <= TOL and scenes.rel_l2(Um.cpu().numpy(), U_ref) <= TOL
 
 
+MODEL_OPTS = [
+    dict(inputChannels=dict(pDiv=True, UDiv=True, div=True)),                          # every field feeds the net
+    dict(inputChannels=dict(pDiv=False, UDiv=True, div=False), nonlinType="relu6"),
+    dict(inputChannels=dict(pDiv=False, UDiv=False, div=True), normalizeInputChan="div", nonlinType="sigmoid"),
+    dict(normalizeInputChan="pDiv", normalizeInputFunc="norm"),
+    dict(normalizeInputFunc="norm", addPressureSkip=True),
+    dict(normalizeInput=False, addPressureSkip=True, nonlinType="relu6"),
+]
+
+
+@pytest.mark.parametrize("is3d", [False, True])
+@pytest.mark.parametrize("oi", range(len(MODEL_OPTS)))
+def test_model_options_match_restatement(oracle, is3d, oi):
+    """The mconf switches of lib/model.lua:27-160, 356-387 that change the forward graph (tfl_model_opts): input channel
+    sets, the normaliser's channel / function / absence, relu6 / sigmoid, the pressure skip -- each against the oracle's
+    restatement of the same graph (PyTorch-CPU convolutions), seeded weights, hidden width 6 (zero-padded to 8) so that
+    the skip channel lands behind padding."""
+    import torch
+    from fluidnet_amd import FluidNetModel
+    opts = MODEL_OPTS[oi]
+    o = S.model_opts(opts)
+    ic = o["inputChannels"]
+    C = 3 if is3d else 2
+    in_c = int(ic["pDiv"]) + C * int(ic["UDiv"]) + int(ic["div"]) + 1
+    skip = 1 if o["addPressureSkip"] else 0
+    rng = np.random.RandomState(100 + oi)
+    shapes = [(6, in_c, 3), (6, 6, 3), (1, 6 + skip, 1)]
+    layers = []
+    for co, ci, k in shapes:
+        taps = k ** (3 if is3d else 2)
+        shape = (co, ci) + ((k, k, k) if is3d else (k, k))
+        layers.append(((rng.randn(*shape) * np.sqrt(2.0 / (ci * taps))).astype(np.float32), (rng.randn(co) * 0.05).astype(np.float32)))
+    dims = (9, 12, 20) if is3d else (1, 33, 41)
+    sc = scenes.make_scene(dims, seed=31 + oi, vel_cells=0.4, B=2)
+    dev = torch.device("cuda:0")
+    tp, tU, tf = (torch.from_numpy(sc[k]).to(dev) for k in ("p", "U", "flags"))
+    pm, Um = FluidNetModel(layers, is3d, opts=opts).forward([tp, tU, tf])
+    p_ref, U_ref = S.model_forward(oracle, layers, sc["p"], sc["U"], sc["flags"], opts=opts)
+    assert scenes.rel_l2(pm.cpu().numpy(), p_ref) <= TOL and scenes.rel_l2(Um.cpu().numpy(), U_ref) <= TOL
+
+
+def test_model_option_errors():
+    """Option combinations the reference rejects (model.lua:50-52, 81, 103, 121) or that do not chain."""
+    import torch
+    from fluidnet_amd import FluidNetModel, tfluids
+    dev = torch.device("cuda:0")
+    sc = scenes.make_scene((1, 16, 16), seed=3, B=1)
+    tp, tU, tf = (torch.from_numpy(sc[k]).to(dev) for k in ("p", "U", "flags"))
+    w = lambda co, ci, k: (np.zeros((co, ci, k, k), np.float32), np.zeros(co, np.float32))
+    with pytest.raises(tfluids.TfluidsError, match="flags"):
+        FluidNetModel([w(4, 3, 3), w(1, 4, 1)], False, opts=dict(inputChannels=dict(flags=False)))
+    with pytest.raises(tfluids.TfluidsError, match="normalizeInputFunc"):
+        FluidNetModel([w(4, 3, 3), w(1, 4, 1)], False, opts=dict(normalizeInputFunc="max"))
+    with pytest.raises(tfluids.TfluidsError, match="any"):
+        FluidNetModel([w(4, 1, 3), w(1, 4, 1)], False, opts=dict(inputChannels=dict(pDiv=False, div=False))).forward([tp, tU, tf])
+    with pytest.raises(tfluids.TfluidsError, match="input channels"):      # UDiv on: 2 more input channels than given
+        FluidNetModel([w(4, 3, 3), w(1, 4, 1)], False, opts=dict(inputChannels=dict(UDiv=True))).forward([tp, tU, tf])
+    with pytest.raises(tfluids.TfluidsError, match="chain"):               # the skip channel is missing from the last layer
+        FluidNetModel([w(4, 3, 3), w(1, 4, 1)], False, opts=dict(addPressureSkip=True)).forward([tp, tU, tf])
+
+
 @pytest.mark.parametrize("is3d,shapes", [(False, [(6, 3, 3), (6, 6, 1), (6, 6, 1), (1, 6, 1)]),       # `yang`, model.lua:188-205
                                          (True, [(6, 3, 3), (6, 6, 1), (6, 6, 1), (1, 6, 1)]),
                                          (True, [(5, 3, 3), (12, 5, 3), (1, 12, 1)]),
