@@ -91,6 +91,8 @@ SIGNATURES = {
     "tfl_addGravity": (_c.c_int, [_c.c_void_p, _T, _T, _F3, _c.c_float, _c.c_int, _c.c_void_p]),
     "tfl_emptyDomain": (_c.c_int, [_c.c_void_p, _T, _c.c_int, _c.c_int]),
     "tfl_flagsToOccupancy": (_c.c_int, [_c.c_void_p, _T, _T]),
+    "tfl_rectangularBlur": (_c.c_int, [_c.c_void_p, _T, _c.c_int, _c.c_int, _T, _T]),
+    "tfl_signedDistanceField": (_c.c_int, [_c.c_void_p, _T, _c.c_int, _c.c_int, _T]),
     "tfl_solveLinearSystemJacobi": (_c.c_int, [_c.c_void_p, _T, _T, _T, _T, _T, _T, _c.c_int,
                                                _c.c_float, _c.c_int, _c.c_int,
                                                _c.POINTER(_c.c_float)]),

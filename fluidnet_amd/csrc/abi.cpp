@@ -430,6 +430,29 @@ int tfl_flagsToOccupancy(tfl_ctx* c, const tfl_tensor* flags, const tfl_tensor* 
   return check_launch(c, "flagsToOccupancy");
 }
 
+int tfl_rectangularBlur(tfl_ctx* c, const tfl_tensor* src, int blurRad, int is3D, const tfl_tensor* dst,
+                        const tfl_tensor* tmp) {
+  if (!c) return TFL_EINVAL;
+  if (!src || !dst || !tmp || !src->data || !dst->data || !tmp->data) return fail(c, TFL_EINVAL, "rectangularBlur: null tensor");
+  if (!same_dims(dst, src) || dst->C != src->C || !same_dims(tmp, src) || tmp->C != src->C)
+    return fail(c, TFL_EINVAL, "rectangularBlur: src, dst and tmp must have the same size");
+  if (blurRad <= 0) return fail(c, TFL_EINVAL, "rectangularBlur: blurRad must be a positive, non-zero integer");   // init.lua:586-587
+  if (!is3D && src->Z != 1) return fail(c, TFL_EINVAL, "rectangularBlur: 2D field but zdepth > 1");
+  if (dst->data == src->data || tmp->data == src->data || tmp->data == dst->data)
+    return fail(c, TFL_EINVAL, "rectangularBlur: src, dst and tmp must not alias");
+  tfl::rectangular_blur(c->stream, is3D != 0, src->B, src->C, src->Z, src->Y, src->X, blurRad, src->data, dst->data, tmp->data);
+  return check_launch(c, "rectangularBlur");
+}
+
+int tfl_signedDistanceField(tfl_ctx* c, const tfl_tensor* flags, int searchRad, int is3D, const tfl_tensor* dst) {
+  TRY(check_flags(c, "signedDistanceField", flags));
+  TRY(check_scalar(c, "signedDistanceField", "dst", dst, flags));
+  if (searchRad <= 0) return fail(c, TFL_EINVAL, "signedDistanceField: searchRad must be a positive, non-zero integer");
+  if (!is3D && flags->Z != 1) return fail(c, TFL_EINVAL, "signedDistanceField: 2D domain but zdepth > 1");
+  tfl::signed_distance_field(c->stream, flags->B, flags->Z, flags->Y, flags->X, searchRad, flags->data, dst->data);
+  return check_launch(c, "signedDistanceField");
+}
+
 int64_t tfl_pcg_workspace_floats(int32_t Z, int32_t Y, int32_t X) { return tfl::pcg_workspace_floats(Z, Y, X); }
 
 int tfl_solveLinearSystemPCG(tfl_ctx* c, const tfl_tensor* p, const tfl_tensor* flags, const tfl_tensor* div, int is3D,

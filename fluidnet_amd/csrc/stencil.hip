@@ -254,6 +254,72 @@ void add_gravity(hipStream_t st, bool is3d, int B, int Z, int Y, int X, float* U
                  float fy, float fz) {
   TFL_LAUNCH(k_add_gravity, U, flags, fx, fy, fz);
 }
+// ---- rectangularBlur / signedDistanceField (generic/tfluids.cc:642-821): criterion-side helpers, not on the step ----------
+// One thread per line; the running sum is sequential along the line in the reference's order (bit-exact). Lines of a pass:
+// base(line) = (line / n_inner) * outer + (line % n_inner); z pass n_inner = Y*X, y pass n_inner = X (threads walk
+// neighbouring lines: coalesced), x pass n_inner = 1 (a thread owns a row).
+__global__ __launch_bounds__(256) void k_blur_axis(const float* __restrict__ src, float* __restrict__ dst, long long lines,
+                                                   long long n_inner, long long outer, int size, long long stride, int rad) {
+  const long long line = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (line >= lines) return;
+  const long long base = (line / n_inner) * outer + (line % n_inner);
+  const float* s = src + base;
+  float* o = dst + base;
+  float val = s[0] * (float)(rad + 1);
+  for (int i = 0; i < size && i < rad; i++) val += s[i * stride];
+  const float mul_const = 1.0f / (float)(rad * 2 + 1);
+  for (int i = 0; i < size; i++) {
+    const int iminus = max(0, i - rad - 1), iplus = min(size - 1, i + rad);
+    val -= s[iminus * stride];
+    val += s[iplus * stride];
+    o[i * stride] = val * mul_const;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_signed_distance(int rad, int Z, int Y, int X, const float* __restrict__ flags,
+                                                         float* __restrict__ dst) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blockIdx.y * blockDim.y + threadIdx.y;
+  const int b = blockIdx.z / Z, z = blockIdx.z - b * Z;
+  if (x >= X || y >= Y) return;
+  const long long N = (long long)Z * Y * X;
+  const float* f = flags + b * N;
+  const long long o = (long long)z * Y * X + (long long)y * X + x;
+  if ((int)f[o] & kObstacle) { dst[b * N + o] = 0.0f; return; }
+  float dist_sq = (float)(rad * rad);
+  for (int zs = max(0, z - rad); zs <= min(Z - 1, z + rad); zs++)
+    for (int ys = max(0, y - rad); ys <= min(Y - 1, y + rad); ys++)
+      for (int xs = max(0, x - rad); xs <= min(X - 1, x + rad); xs++)
+        if ((int)f[(long long)zs * Y * X + (long long)ys * X + xs] & kObstacle) {
+          const float cur = (float)((z - zs) * (z - zs) + (y - ys) * (y - ys) + (x - xs) * (x - xs));
+          if (dist_sq > cur) dist_sq = cur;
+        }
+  dst[b * N + o] = sqrtf(dist_sq);
+}
+
+void rectangular_blur(hipStream_t st, bool is3d, int B, int C, int Z, int Y, int X, int rad, const float* src, float* dst,
+                      float* tmp) {
+  const long long F = (long long)B * C, sy = X, sz = (long long)Y * X, sf = (long long)Z * Y * X;
+  auto pass = [&](const float* in, float* out, long long lines, long long n_inner, long long outer, int size, long long stride) {
+    TFL_TIMED("k_blur_axis", st);
+    k_blur_axis<<<(unsigned)((lines + 255) / 256), 256, 0, st>>>(in, out, lines, n_inner, outer, size, stride, rad);
+  };
+  const float* cur_src = src;
+  float* cur_dst = is3d ? dst : tmp;
+  if (is3d) {
+    pass(cur_src, cur_dst, F * Y * X, (long long)Y * X, sf, Z, sz);
+    cur_src = dst; cur_dst = tmp;
+  }
+  pass(cur_src, cur_dst, F * Z * X, X, sz, Y, sy);
+  pass(tmp, dst, F * Z * Y, 1, X, X, 1);
+}
+
+void signed_distance_field(hipStream_t st, int B, int Z, int Y, int X, int rad, const float* flags, float* dst) {
+  const dim3 blk(64, 4, 1), grd((X + 63) / 64, (Y + 3) / 4, (unsigned)(Z * B));
+  TFL_TIMED("k_signed_distance", st);
+  k_signed_distance<<<grd, blk, 0, st>>>(rad, Z, Y, X, flags, dst);
+}
+
 void empty_domain(hipStream_t st, bool is3d, int bnd, int B, int Z, int Y, int X, float* flags) {
   TFL_LAUNCH(k_empty_domain, bnd, flags);
 }

@@ -83,6 +83,9 @@ void add_gravity(hipStream_t st, bool is3d, int B, int Z, int Y, int X, float* U
                  float fy, float fz);
 void empty_domain(hipStream_t st, bool is3d, int bnd, int B, int Z, int Y, int X, float* flags);
 void flags_to_occupancy(hipStream_t st, long long numel, const float* flags, float* occ);
+void rectangular_blur(hipStream_t st, bool is3d, int B, int C, int Z, int Y, int X, int rad, const float* src, float* dst,
+                      float* tmp);
+void signed_distance_field(hipStream_t st, int B, int Z, int Y, int X, int rad, const float* flags, float* dst);
 void absmax(hipStream_t st, long long n, const float* x, float* out, bool reset);   // *out = max(*out, max |x|)
 
 // vorticity.hip

@@ -71,6 +71,9 @@ int tfl_addGravity(tfl_ctx* ctx, const tfl_tensor* U, const tfl_tensor* flags,
                    const float gravity[3], float dt, int is3D, float* forceTmp);
 int tfl_emptyDomain(tfl_ctx* ctx, const tfl_tensor* flags, int is3D, int bnd);
 int tfl_flagsToOccupancy(tfl_ctx* ctx, const tfl_tensor* flags, const tfl_tensor* occupancy);
+int tfl_rectangularBlur(tfl_ctx* ctx, const tfl_tensor* src, int blurRad, int is3D, const tfl_tensor* dst,
+                        const tfl_tensor* tmp);
+int tfl_signedDistanceField(tfl_ctx* ctx, const tfl_tensor* flags, int searchRad, int is3D, const tfl_tensor* dst);
 int64_t tfl_pcg_workspace_floats(int32_t Z, int32_t Y, int32_t X);
 int tfl_solveLinearSystemPCG(tfl_ctx* ctx, const tfl_tensor* p, const tfl_tensor* flags, const tfl_tensor* div,
                              int is3D, const char* precondType, float tol, int maxIter, int verbose,
@@ -264,6 +267,12 @@ function ops.emptyDomain(flags, is3D, bnd)
 end
 function ops.flagsToOccupancy(flags, occupancy)
   check(lib.tfl_flagsToOccupancy(ctx, T(flags), T(occupancy)))
+end
+function ops.rectangularBlur(src, blurRad, is3D, dst, tmp)
+  check(lib.tfl_rectangularBlur(ctx, T(src), blurRad, b2i(is3D), T(dst), T(tmp)))
+end
+function ops.signedDistanceField(flags, searchRad, is3D, dst)
+  check(lib.tfl_signedDistanceField(ctx, T(flags), searchRad, b2i(is3D), T(dst)))
 end
 function ops.velocityDivergenceBackward(U, flags, gradOutput, is3D, gradU)
   check(lib.tfl_velocityDivergenceBackward(ctx, T(U), T(flags), T(gradOutput), b2i(is3D), T(gradU)))

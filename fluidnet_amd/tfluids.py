@@ -341,6 +341,28 @@ def flagsToOccupancy(flags, occupancy):
     _call(lib, ctx, lib.tfl_flagsToOccupancy(ctx, _tt(flags), _tt(occupancy)))
 
 
+def rectangularBlur(src, blurRad, is3D, dst):
+    """init.lua:578-595: O(n) box blur of radius blurRad with clamped edges (per line a running sum)."""
+    _check(src.dim() == 5 and dst.dim() == 5, "Dimension mismatch")
+    _check(src.shape == dst.shape, "Size mismatch")
+    _check(blurRad > 0 and int(blurRad) == blurRad, "blurRad must be a positive, non-zero integer")
+    _check(src.is_contiguous() and dst.is_contiguous(), "Input is not contiguous")
+    tmp = getTempStorage(src, [tuple(src.shape)])[0]
+    lib, ctx = _context(src)
+    _call(lib, ctx, lib.tfl_rectangularBlur(ctx, _tt(src), int(blurRad), int(bool(is3D)), _tt(dst), _tt(tmp)))
+
+
+def signedDistanceField(flags, searchRad, is3D, dst):
+    """init.lua:597-613: distance to the nearest obstacle within searchRad (clamped there), O(pix * searchRad^dim)."""
+    _check(flags.dim() == 5 and dst.dim() == 5, "Dimension mismatch")
+    _check(flags.shape == dst.shape, "Size mismatch")
+    _check(flags.is_contiguous() and dst.is_contiguous(), "Input is not contiguous")
+    _check(flags.size(1) == 1, "flags must be scalar")
+    _check(searchRad > 0 and int(searchRad) == searchRad, "searchRad must be a positive, non-zero integer")
+    lib, ctx = _context(flags)
+    _call(lib, ctx, lib.tfl_signedDistanceField(ctx, _tt(flags), int(searchRad), int(bool(is3D)), _tt(dst)))
+
+
 def solveLinearSystemPCG(p, flags, div, is3D, tol=None, maxIter=None, precondType=None, verbose=None):
     """init.lua:645-677: the baseline (P)CG pressure solve, A p = div per connected fluid component.
     precondType 'none' | 'ilu0' | 'ic0' (default 'ic0'), tol default 1e-6, maxIter default 1000.

@@ -140,6 +140,16 @@ int tfl_emptyDomain(tfl_ctx* ctx, const tfl_tensor* flags, int is3D, int bnd);
  * exactly Fluid nor Obstacle become -1 (the CUDA behaviour); the CPU reference raises there. */
 int tfl_flagsToOccupancy(tfl_ctx* ctx, const tfl_tensor* flags, const tfl_tensor* occupancy);
 
+/* init.lua:583-595 `tfluids.rectangularBlur(src, blurRad, is3D, dst)` -> generic/tfluids.cc:642-760 (CPU only in the
+ * reference): separable box blur of radius blurRad with clamped edges over every [B][C] field, each line a running sum
+ * in the reference's order (bit-exact). tmp: scratch of src's size (the Lua wrapper's getTempStorage). */
+int tfl_rectangularBlur(tfl_ctx* ctx, const tfl_tensor* src, int blurRad, int is3D, const tfl_tensor* dst,
+                        const tfl_tensor* tmp);
+/* init.lua:603-613 `tfluids.signedDistanceField(flags, searchRad, is3D, dst)` -> generic/tfluids.cc:766-821 |
+ * generic/tfluids.cu:690-747: distance to the nearest obstacle cell within a (2 searchRad + 1)^dim window, clamped to
+ * searchRad, 0 inside obstacles (the loss weighting of lib/modules/fluid_criterion.lua:149). */
+int tfl_signedDistanceField(tfl_ctx* ctx, const tfl_tensor* flags, int searchRad, int is3D, const tfl_tensor* dst);
+
 /* init.lua:645-677 `tfluids.solveLinearSystemPCG(p, flags, div, is3D, tol, maxIter, precondType, verbose)` ->
  * tfluids_CudaMain_solveLinearSystemPCG, generic/tfluids.cu:1257-1759 (CUDA only in the reference; the baseline
  * "exact" pressure solver and the accuracy yard-stick of the paper). p is zeroed, then every connected fluid

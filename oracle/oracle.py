@@ -123,6 +123,16 @@ class OracleTfluids:
         if rc != 0:
             raise OracleError("ERROR: unsupported flag cell found!")
 
+    def rectangularBlur(self, src, blurRad, is3D, dst):
+        """init.lua:583-595 (the temp buffer is the wrapper's)."""
+        tmp = np.empty_like(src)
+        B, C, Z, Y, X = src.shape
+        self.lib.ora_rectangularBlur(_p(src), int(blurRad), int(bool(is3D)), _p(dst), _p(tmp), B, C, Z, Y, X)
+
+    def signedDistanceField(self, flags, searchRad, is3D, dst):
+        b, d, h, w = self._dims(flags)
+        self.lib.ora_signedDistanceField(_p(flags), int(searchRad), _p(dst), b, d, h, w)
+
     @staticmethod
     def getDx(flags):
         return 1.0 / max(flags.shape[2], flags.shape[3], flags.shape[4])

@@ -187,6 +187,14 @@ class RefTfluids:
     def flagsToOccupancy(self, flags, occupancy):
         self.call("flagsToOccupancy", flags, occupancy)
 
+    def rectangularBlur(self, src, blurRad, is3D, dst):
+        """init.lua:583-595: the wrapper supplies the temp buffer (contents undefined on entry)."""
+        tmp = self._tmp(src.shape)[0]
+        self.call("rectangularBlur", src, int(blurRad), bool(is3D), dst, tmp)
+
+    def signedDistanceField(self, flags, searchRad, is3D, dst):
+        self.call("signedDistanceField", flags, int(searchRad), bool(is3D), dst)
+
     def solveLinearSystemJacobi(self, p, flags, div, is3D, pTol=1e-5, maxIter=1000, verbose=False):
         """init.lua:693-735. CUDA only in the reference: runs the reference's own kernel and host loop
         (generic/tfluids.cu:1765-1927) compiled for the host (oracle/ref_jacobi.cc, `make ref_jacobi`)."""

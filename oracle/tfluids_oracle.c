@@ -1059,6 +1059,74 @@ int ora_flagsToOccupancy(const float* flags, float* occ, long numel) {
 }
 
 /* ------------------------------------------------------------------------------------------
+ * rectangularBlur, generic/tfluids.cc:642-760: separable box blur of radius `rad` with clamped edges,
+ * evaluated per line as a running sum (the arithmetic ORDER is the reference's: that is what makes
+ * the restatement bit-exact). 3-D: z pass src -> dst, y pass dst -> tmp, x pass tmp -> dst;
+ * 2-D: y pass src -> tmp, x pass tmp -> dst. Fields are [B][C][Z][Y][X].
+ * ---------------------------------------------------------------------------------------- */
+static void blur_axis(const float* src, int size, long stride, int rad, float* dst) {
+  float val = src[0] * (float)(rad + 1);
+  int i;
+  for (i = 0; i < size && i < rad; i++) val += src[i * stride];
+  const float mul_const = 1.0f / (float)(rad * 2 + 1);
+  for (i = 0; i < size; i++) {
+    const int iminus = i - rad - 1 > 0 ? i - rad - 1 : 0;
+    const int iplus = i + rad < size - 1 ? i + rad : size - 1;
+    val -= src[iminus * stride];
+    val += src[iplus * stride];
+    dst[i * stride] = val * mul_const;
+  }
+}
+
+void ora_rectangularBlur(const float* src, int rad, int is3d, float* dst, float* tmp, int B, int C, int Z, int Y, int X) {
+  const long sy = X, sz = (long)Y * X, sf = (long)Z * Y * X;
+  const float* cur_src = src;
+  float* cur_dst = is3d ? dst : tmp;
+  long f; int z, y, x;
+  if (is3d) {
+    for (f = 0; f < (long)B * C; f++)
+      for (y = 0; y < Y; y++)
+        for (x = 0; x < X; x++) blur_axis(cur_src + f * sf + y * sy + x, Z, sz, rad, cur_dst + f * sf + y * sy + x);
+    cur_src = dst; cur_dst = tmp;
+  }
+  for (f = 0; f < (long)B * C; f++)
+    for (z = 0; z < Z; z++)
+      for (x = 0; x < X; x++) blur_axis(cur_src + f * sf + z * sz + x, Y, sy, rad, cur_dst + f * sf + z * sz + x);
+  cur_src = tmp; cur_dst = dst;
+  for (f = 0; f < (long)B * C; f++)
+    for (z = 0; z < Z; z++)
+      for (y = 0; y < Y; y++) blur_axis(cur_src + f * sf + z * sz + y * sy, X, 1, rad, cur_dst + f * sf + z * sz + y * sy);
+}
+
+/* signedDistanceField, generic/tfluids.cc:766-821: distance to the nearest obstacle cell inside a
+ * (2 rad + 1)^dim window, clamped to rad; 0 in obstacle cells. flags, dst: [B][1][Z][Y][X]. */
+void ora_signedDistanceField(const float* flags, int rad, float* dst, int B, int Z, int Y, int X) {
+  const long N = (long)Z * Y * X;
+  int b, z, y, x;
+  for (b = 0; b < B; b++)
+    for (z = 0; z < Z; z++)
+      for (y = 0; y < Y; y++)
+        for (x = 0; x < X; x++) {
+          const float* f = flags + b * N;
+          const long o = b * N + (long)z * Y * X + (long)y * X + x;
+          if ((int)f[(long)z * Y * X + (long)y * X + x] & F_OBSTACLE) { dst[o] = 0.0f; continue; }
+          float dist_sq = (float)(rad * rad);
+          const int z0 = z - rad > 0 ? z - rad : 0, z1 = z + rad < Z - 1 ? z + rad : Z - 1;
+          const int y0 = y - rad > 0 ? y - rad : 0, y1 = y + rad < Y - 1 ? y + rad : Y - 1;
+          const int x0 = x - rad > 0 ? x - rad : 0, x1 = x + rad < X - 1 ? x + rad : X - 1;
+          int zs, ys, xs;
+          for (zs = z0; zs <= z1; zs++)
+            for (ys = y0; ys <= y1; ys++)
+              for (xs = x0; xs <= x1; xs++)
+                if ((int)f[(long)zs * Y * X + (long)ys * X + xs] & F_OBSTACLE) {
+                  const float cur = (float)((z - zs) * (z - zs) + (y - ys) * (y - ys) + (x - xs) * (x - xs));
+                  if (dist_sq > cur) dist_sq = cur;
+                }
+          dst[o] = sqrtf(dist_sq);
+        }
+}
+
+/* ------------------------------------------------------------------------------------------
  * solveLinearSystemJacobi -- restates the CUDA path generic/tfluids.cu:1765-1921 (no CPU version
  * exists in the reference: generic/tfluids.cc:836-839). PARITY UNPINNED beyond analytic checks.
  * p_prev is scratch [B][1][Z][Y][X]. Returns the last residual max_b ||p - p_prev||_2.

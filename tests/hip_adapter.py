@@ -94,6 +94,16 @@ class HipTfluids:
         tfluids.flagsToOccupancy(self._up(flags), to)
         occupancy[...] = to.cpu().numpy()
 
+    def rectangularBlur(self, src, blurRad, is3D, dst):
+        td = self._up(dst)
+        tfluids.rectangularBlur(self._up(src), blurRad, is3D, td)
+        dst[...] = td.cpu().numpy()
+
+    def signedDistanceField(self, flags, searchRad, is3D, dst):
+        td = self._up(dst)
+        tfluids.signedDistanceField(self._up(flags), searchRad, is3D, td)
+        dst[...] = td.cpu().numpy()
+
     def solveLinearSystemJacobi(self, p, flags, div, is3D, pTol=1e-5, maxIter=1000, verbose=False):
         tp = self._up(p)
         r = tfluids.solveLinearSystemJacobi(tp, self._up(flags), self._up(div), is3D, pTol, maxIter,

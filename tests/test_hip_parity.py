@@ -83,6 +83,29 @@ def test_hip_empty_domain_and_occupancy(hip, is3d):
     assert np.array_equal(occ, (sc["flags"] == 2).astype(np.float32))
 
 
+@pytest.mark.parametrize("is3d", [False, True])
+def test_hip_blur_and_signed_distance_match_oracle_bitwise(hip, oracle, is3d):
+    """tfluids.rectangularBlur / signedDistanceField (generic/tfluids.cc:642-821; the criterion-side helpers of
+    init.lua:578-613): same arithmetic in the same order, so bit-exact; odd sizes, several radii, B = 2, C = 3."""
+    rng = np.random.RandomState(8)
+    shape = (2, 3, 13, 19, 70) if is3d else (2, 3, 1, 37, 131)
+    src = rng.uniform(-1, 1, shape).astype(np.float32)
+    for rad in (1, 2, 5):
+        d_h = rng.rand(*shape).astype(np.float32)
+        d_o = np.empty_like(src)
+        hip.rectangularBlur(src, rad, is3d, d_h)
+        oracle.rectangularBlur(src, rad, is3d, d_o)
+        assert np.array_equal(d_h, d_o), rad
+    flags = np.ones((2, 1) + shape[2:], np.float32)
+    flags[rng.rand(*flags.shape) < 0.02] = 2.0
+    for rad in (1, 3):
+        s_h = rng.rand(*flags.shape).astype(np.float32)
+        s_o = np.empty_like(s_h)
+        hip.signedDistanceField(flags, rad, is3d, s_h)
+        oracle.signedDistanceField(flags, rad, is3d, s_o)
+        assert np.array_equal(s_h, s_o), rad
+
+
 @pytest.mark.parametrize("dims", [(1, 64, 64), (24, 20, 28)])
 def test_hip_jacobi_matches_oracle(hip, oracle, dims):
     sc = scenes.make_scene(dims, seed=9, vel_cells=1.0, B=2)

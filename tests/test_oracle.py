@@ -295,3 +295,56 @@ def test_jacobi_restatement_equals_compiled_reference_kernel(oracle, ref, dims, 
     assert np.array_equal(pa, pb) and ra < tol and rb < tol
     with pytest.raises(Exception):
         ref.solveLinearSystemJacobi(pb, f, div, sc["is3d"], 0.0, 0)
+
+
+@pytest.mark.parametrize("is3d", [False, True])
+@pytest.mark.parametrize("rad", [1, 3, 4])
+def test_rectangular_blur(tracer, oracle, ref, is3d, rad):
+    """test_tfluids.lua:1072-1133 without nn: the blur equals a box filter of width 2 rad + 1 over the edge-clamped
+    field (the reference checks that against a convolution at 1e-6); and the C restatement is the compiled reference
+    bit for bit (the running sum is evaluated in the reference's order)."""
+    rng = np.random.RandomState(11 + rad)
+    shape = (2, 3, 17, 21, 22) if is3d else (2, 3, 1, 35, 36)
+    src = rng.uniform(0, 1, shape).astype(np.float32)
+    dst = rng.uniform(0, 1, shape).astype(np.float32)          # filled with noise, as the reference test does
+    tracer.rectangularBlur(src, rad, is3d, dst)
+    pads = [(0, 0), (0, 0)] + [((rad, rad) if (is3d or ax > 0) else (0, 0)) for ax in range(3)]
+    padded = np.pad(src.astype(np.float64), pads, mode="edge")
+    want = np.zeros(shape, np.float64)
+    k = 2 * rad + 1
+    for dz in range(k if is3d else 1):
+        for dy in range(k):
+            for dx in range(k):
+                want += padded[:, :, dz:dz + shape[2], dy:dy + shape[3], dx:dx + shape[4]]
+    want /= float(k ** (3 if is3d else 2))
+    assert np.abs(dst - want).max() < 1e-5
+    d_o, d_r = np.empty_like(src), np.empty_like(src)
+    oracle.rectangularBlur(src, rad, is3d, d_o)
+    ref.rectangularBlur(src, rad, is3d, d_r)
+    assert np.array_equal(d_o, d_r)
+
+
+@pytest.mark.parametrize("is3d", [False, True])
+def test_signed_distance_field(tracer, oracle, ref, is3d):
+    """test_tfluids.lua:1135-1240: against a brute-force search over ALL obstacle cells, clamped to the search radius;
+    restatement == compiled reference bit for bit."""
+    rng = np.random.RandomState(5)
+    dims = (9, 12, 14) if is3d else (1, 20, 23)
+    rad = 3
+    flags = np.ones((2, 1) + dims, np.float32)
+    flags[rng.rand(*flags.shape) < 0.03] = 2.0
+    dist = rng.rand(*flags.shape).astype(np.float32)
+    tracer.signedDistanceField(flags, rad, is3d, dist)
+    zz, yy, xx = np.meshgrid(*[np.arange(n) for n in dims], indexing="ij")
+    for b in range(2):
+        obs = np.argwhere(flags[b, 0] == 2.0)
+        d2 = np.full(dims, float(rad * rad))
+        for (oz, oy, ox) in obs:
+            d2 = np.minimum(d2, (zz - oz) ** 2 + (yy - oy) ** 2 + (xx - ox) ** 2)
+        want = np.sqrt(d2)
+        # the search window is a CUBE of half-width rad: an obstacle at (rad, rad) offset lies outside the radius anyway
+        assert np.abs(dist[b, 0] - want).max() < 1e-6
+    d_o, d_r = np.empty_like(dist), np.empty_like(dist)
+    oracle.signedDistanceField(flags, rad, is3d, d_o)
+    ref.signedDistanceField(flags, rad, is3d, d_r)
+    assert np.array_equal(d_o, d_r)
