@@ -9,4 +9,5 @@
 from . import tfluids  # noqa: F401
 from . import simulate  # noqa: F401  (module: simulate.simulate, .createPlumeBCs, .setConstVals)
 from .model import FluidNetModel  # noqa: F401
+from . import modules  # noqa: F401  (the tfluids nn.Modules as torch.nn.Modules with autograd)
 from ._lib import TfluidsError  # noqa: F401

@@ -606,3 +606,61 @@ def test_512_cubed_step_runs():
     assert bool(torch.isfinite(batch["UDiv"]).all()) and bool(torch.isfinite(batch["pDiv"]).all())
     assert float(batch["density"][0, 0, :, 4:].sum()) > 0 and float(batch["UDiv"].abs().max()) > 0.5
     assert tfluids.traceErrors(batch["UDiv"]) == 0
+
+
+@pytest.mark.parametrize("dims", [(1, 20, 24), (7, 10, 12)])
+def test_nn_modules_forward_and_autograd(oracle, dims):
+    """fluidnet_amd.modules = tfluids/{velocity_divergence,velocity_update,set_wall_bcs,flags_to_occupancy,
+    volumetric_up_sampling_nearest}.lua as torch.nn.Modules: forward == the operator, autograd gradients == the oracle's
+    backward operators fed the same gradOutput (bit-exact: the HIP backward ops are), gradU of VelocityUpdate is zero and
+    flags get no gradient, as in the reference modules. (The reference checks its modules with nn.Jacobian,
+    test_tfluids.lua:428-432, 483-488, 536-542; the adjoint property itself is in test_oracle.py.)"""
+    import torch
+    from fluidnet_amd import modules as M
+    dev = torch.device("cuda:0")
+    sc = scenes.make_scene(dims, seed=77, vel_cells=1.0, B=2, empty_cells=True)
+    rng = np.random.RandomState(78)
+    f, U, p = sc["flags"], sc["U"], sc["p"]
+    tf = torch.from_numpy(f).to(dev)
+    # VelocityDivergence
+    tU = torch.from_numpy(U).to(dev).requires_grad_(True)
+    div = M.VelocityDivergence()([tU, tf])
+    want = np.zeros_like(p); oracle.velocityDivergenceForward(U, f, want)
+    assert np.array_equal(div.detach().cpu().numpy(), want)
+    go = rng.randn(*p.shape).astype(np.float32)
+    div.backward(torch.from_numpy(go).to(dev))
+    gU = np.zeros_like(U); oracle.velocityDivergenceBackward(U, f, go, gU)
+    assert np.array_equal(tU.grad.cpu().numpy(), gU)
+    # VelocityUpdate
+    tU = torch.from_numpy(U).to(dev).requires_grad_(True)
+    tp = torch.from_numpy(p).to(dev).requires_grad_(True)
+    Un = M.VelocityUpdate()([tp, tU, tf])
+    want = U.copy(); oracle.velocityUpdateForward(want, f, p)
+    assert np.array_equal(Un.detach().cpu().numpy(), want)
+    goU = rng.randn(*U.shape).astype(np.float32)
+    Un.backward(torch.from_numpy(goU).to(dev))
+    gP = np.zeros_like(p); oracle.velocityUpdateBackward(U, f, p, goU, gP)
+    assert np.array_equal(tp.grad.cpu().numpy(), gP)
+    assert float(tU.grad.abs().max()) == 0.0                      # velocity_update.lua:47
+    # SetWallBcs: gradient = mask * gradOutput
+    tU = torch.from_numpy(U).to(dev).requires_grad_(True)
+    Ub = M.SetWallBcs()([tU, tf])
+    want = U.copy(); oracle.setWallBcsForward(want, f)
+    assert np.array_equal(Ub.detach().cpu().numpy(), want)
+    Ub.backward(torch.from_numpy(goU).to(dev))
+    mask = np.ones_like(U); oracle.setWallBcsForward(mask, f)
+    assert np.array_equal(tU.grad.cpu().numpy(), mask * goU)
+    # FlagsToOccupancy (no gradient) and VolumetricUpSamplingNearest
+    f2 = scenes.make_scene(dims, seed=79, B=2)["flags"]            # fluid / obstacle only: the CPU reference raises otherwise
+    occ = M.FlagsToOccupancy()(torch.from_numpy(f2).to(dev))
+    want = np.zeros_like(f2); oracle.flagsToOccupancy(f2, want)
+    assert np.array_equal(occ.cpu().numpy(), want) and not occ.requires_grad
+    tx = torch.from_numpy(U).to(dev).requires_grad_(True)
+    up = M.VolumetricUpSamplingNearest(2)(tx)
+    B, C, Z, Y, X = U.shape
+    want = np.zeros((B, C, 2 * Z, 2 * Y, 2 * X), np.float32); oracle.volumetricUpSamplingNearestForward(2, U, want)
+    assert np.array_equal(up.detach().cpu().numpy(), want)
+    g = rng.randn(*want.shape).astype(np.float32)
+    up.backward(torch.from_numpy(g).to(dev))
+    gi = np.zeros_like(U); oracle.volumetricUpSamplingNearestBackward(2, U, g, gi)
+    assert np.array_equal(tx.grad.cpu().numpy(), gi)
