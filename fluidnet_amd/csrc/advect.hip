@@ -123,7 +123,7 @@ __device__ __forceinline__ bool manta_clamp_bounds(const Dom& d, const float* __
     if (IS3D) { if (k0 < 0 || k1 >= d.Zg) return false; }
     else if (k0 != 0 || k1 != 0) return false;
     if (i0 < 0 || j0 < 0 || i1 >= d.X || j1 >= d.Y) return false;
-    const int a = TFL_AT(d, i0, j0, k0 - d.zg);
+    const int a = TFL_AT(d, i0, j0, IS3D ? slab_plane(d, k0, d.Z - 2) : k0);
 #ifdef TFL_EXACT_MINMAX
     minmax(lo, hi, g[a]);
     minmax(lo, hi, g[a + 1]);
@@ -175,7 +175,7 @@ __device__ float manta_clamp_scalar(const Dom& d, const float* flags, const floa
   if (fx < 0 || fy < 0 || fz < 0 || bx < 0 || by < 0 || bz < 0 || fx > ux || fy > uy || (fz > uz && IS3D) ||
       bx > ux || by > uy || (bz > uz && IS3D))
     return fwd;
-  if ((flag_at(d, flags, fx, fy, fz - d.zg) & kObstacle) || (flag_at(d, flags, bx, by, bz - d.zg) & kObstacle)) return fwd;
+  if ((flag_at(d, flags, fx, fy, slab_plane(d, fz, d.Z - 1)) & kObstacle) || (flag_at(d, flags, bx, by, slab_plane(d, bz, d.Z - 1)) & kObstacle)) return fwd;
   return dval;
 }
 
@@ -316,7 +316,7 @@ __global__ __launch_bounds__(256) TFL_SCALAR_OCC void k_scalar_fwd(AdvArgs a, co
     if (METHOD == kMacCormackOurs) {
       // clamp bounds of the forward position = the precomputed 3^dim min/max of the cell it falls in
       const int i0 = iclampi((int)back.x, 0, d.X - 1), j0 = iclampi((int)back.y, 0, d.Y - 1);
-      const int k0 = IS3D ? iclampi((int)back.z, 0, d.Zg - 1) - d.zg : 0;
+      const int k0 = IS3D ? slab_plane(d, iclampi((int)back.z, 0, d.Zg - 1), d.Z - 1) : 0;
       const long long g = b * cells + TFL_AT(d, i0, j0, k0);
       bounds += b * cells * C;
       bounds[o] = lo3[g];

@@ -59,6 +59,12 @@ __device__ __forceinline__ void dom_bk(const Dom& d, int& b, int& k) {
 // cell-aligned MAC taps (get_at_mac) stay merged: there the wide load wins.
 #define TFL_P1(d) ((d).one)
 
+// global plane -> plane of the local array, held inside it. On the whole grid (zg = 0, Zg = Z) the clamp never acts. On
+// a z-slab it acts only when a back-trace left the halo (|u_z| dt above the layout's reach): that step's owned planes
+// are wrong either way and the reach check fails the NEXT call (csrc/simulate.cpp) -- but the read must stay inside the
+// array, a GPU memory fault would take the process down before the error can be reported.
+__device__ __forceinline__ int slab_plane(const Dom& d, int k_global, int hi) { return min(max(k_global - d.zg, 0), hi); }
+
 template <bool IS3D>
 __device__ __forceinline__ bool on_border(const Dom& d, int i, int j, int k) {
   // bnd = 1 is hard-coded in every op (third_party/tfluids.cc:467)
@@ -147,7 +153,7 @@ __device__ __forceinline__ Lerp build_index(const Dom& d, v3 pos) {
   lerp_axis(pos.y - 0.5f, d.Y, L.yi, L.t0, L.t1);
   if (IS3D) {
     lerp_axis(pos.z - 0.5f, d.Zg, L.zi, L.f0, L.f1);
-    L.zi -= d.zg;
+    L.zi = slab_plane(d, L.zi, d.Z - 2);
   } else {
     // Z == 1: the 2-D samplers only ever touch plane 0 (weights as the reference computes them)
     const float pz = pos.z - 0.5f;
@@ -234,7 +240,7 @@ __device__ __forceinline__ int blocked_at(const Dom& d, const float* __restrict_
 // blocked_at for a position already known to be inside the domain (0 < p < N on every axis, so the truncated
 // cell index is in range and the reference's out-of-grid error cannot fire): skips the six range tests
 __device__ __forceinline__ int blocked_inside(const Dom& d, const float* __restrict__ flags, v3 p) {
-  return fluid_at(d, flags, (int)p.x, (int)p.y, (int)p.z - d.zg) ? 0 : 1;
+  return fluid_at(d, flags, (int)p.x, (int)p.y, slab_plane(d, (int)p.z, d.Z - 1)) ? 0 : 1;
 }
 
 // Ray/box test, calc_line_trace.cc:101-171

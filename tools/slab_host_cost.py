@@ -1,0 +1,49 @@
+"""Host cost of one z-slab rank-step: rank 0 of a W-rank layout with a transport that does NOTHING (results are wrong,
+the enqueue path is the real one). With a 16-plane slab the GPU work is ~0.07 ms, so wall time per step ~ host time of
+the native step + its four transport callbacks (without the transport's own cost). usage: slab_host_cost.py [res] [world]"""
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+from fluidnet_amd import FluidNetModel  # noqa: E402
+from fluidnet_amd.dist import SlabLayout, SlabSimulation, _CommBase  # noqa: E402
+
+
+class NullComm(_CommBase):
+    def start(self, tag, send_lo, recv_lo, send_hi, recv_hi):
+        pass
+
+    def wait(self, tag):
+        pass
+
+    def allreduce(self, stats):
+        pass
+
+
+res = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+world = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+dev = torch.device("cuda:0")
+model = FluidNetModel.default_3d(seed=1)
+for rank in (0, world // 2):
+    lay = SlabLayout(res, world, rank)
+    batch, mconf = bench.build_scene(res, res, lay, dev)
+    mconf = dict(mconf, buoyancyScale=0.0)          # keep the (wrong) state tame: nothing rises into the missing halos
+    sim = SlabSimulation(batch, mconf, model, lay, NullComm(), check_reach=False)
+    for _ in range(5):
+        sim.step()
+    torch.cuda.synchronize()
+    for n in (50,):
+        t0 = time.time()
+        for _ in range(n):
+            sim.step()
+        t_host = (time.time() - t0) / n
+        torch.cuda.synchronize()
+        t_all = (time.time() - t0) / n
+    print("res %d, rank %d of %d (%d planes): enqueue %.3f ms per step, with GPU drain %.3f ms per step"
+          % (res, rank, world, lay.hi - lay.lo, t_host * 1e3, t_all * 1e3))
+    sim.close()
