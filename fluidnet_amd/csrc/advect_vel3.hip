@@ -1,0 +1,316 @@
+// advect_vel3.hip -- advectVel on a 3-D MAC grid, trace-based methods (eulerOurs, maccormackOurs): the
+// north-star's "advection kernel" (third_party/tfluids.cc:594-632 SemiLagrangeEulerOursMAC, :660-699
+// MacCormackCorrectMAC, :748-774 MacCormackClampMAC; generic/calc_line_trace.cc:313-503).
+//
+// The gather kernels of advect.hip spend their time in two places (profiles/r02_pmc_sq.txt): the
+// vector ALU (650 instructions per wave: three IEEE divisions and a full-range sqrt per trace, branchy
+// out-of-domain / obstacle handling whose phi copies are 17 % of the stream, clamped index arithmetic, 64-bit
+// addresses) and the texture addresser (123 gather instructions per wave). Here:
+//
+//  * FAST PATH / SLOW PATH. A cell whose three back-traces are "ordinary" -- fluid cell that is not a border cell, displacement shorter than 0.99 cell, end point in a fluid cell -- needs none of the reference's
+//    special cases: ONE trace step, no wall clipping, no ray/box test, no index clamps, every tap inside the 3^3
+//    neighbourhood of the cell. That path is straight-line code with the reference's operation order; the
+//    division by the trace length uses one refined reciprocal for the three components and the norm a one-step
+//    corrected v_sqrt, both proven bit-equal to `/` and sqrtf() on the operand range (tfl_fastmath.hpp,
+//    tools/ubench/exact_math.hip). Every other lane (walls, obstacles' neighbours, fast flow) runs the generic
+//    functions of tfl_device.hpp / tfl_advect.hpp afterwards, from scratch: same result as before by construction.
+//  * LDS TILE. Per 64x4x1-cell block the 66x6x3 halo tile of U (3 components) and flags is staged once with
+//    coalesced row loads; the 18 MAC taps, the trace's flag look-ups, the forward pass's 24 interpolation taps
+//    and the backward pass's 48 clamp corners are ds_reads with immediate offsets from one address VGPR. Only the
+//    backward pass's 24 interpolation taps of the forward field remain global gathers.
+//
+// Algorithmic HBM bytes per cell are unchanged: pass A 28 B (U3, flags -> fwd3), pass B 40 B (fwd3, U3, flags -> dst3).
+#include "tfl_advect.hpp"
+#include "tfl_fastmath.hpp"
+
+#include <cstdlib>
+
+namespace tfl {
+namespace {
+
+constexpr int TX = 64, TY = 4;                                       // cells per block: one wave per grid row
+constexpr int LX = TX + 2, LY = TY + 2, LP = LX * LY, LN = 3 * LP;   // 66, 6, 396 (plane), 1188 (field)
+constexpr int FL = 3 * LN;                                           // tile offset of the flags field
+constexpr float kFastLen = 0.99f;                                    // longest displacement the fast path takes
+
+__device__ __forceinline__ float ldg(const float* __restrict__ base, unsigned byte_off) {   // uniform base + 32-bit lane offset
+  return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+
+// Wave w stages field w: 18 rows of 64 (one coalesced 256-B load each) + the two halo columns (36 lanes).
+// Rows / columns outside the grid are loaded from the nearest inside one: fast lanes never read them.
+__device__ __forceinline__ void stage_tile(float* __restrict__ tile, const float* __restrict__ g, const Dom& d, int x0,
+                                           int y0, int k, int lane) {
+  const unsigned xl4 = (unsigned)min(x0 + lane, d.X - 1) * 4u;
+  float v[18];
+#pragma unroll
+  for (int r = 0; r < 18; r++) {
+    const int z = min(max(k - 1 + r / 6, 0), d.Z - 1), y = min(max(y0 - 1 + r % 6, 0), d.Y - 1);   // wave-uniform
+    v[r] = ldg(g + ((long long)z * d.sz + (long long)y * d.sy), xl4);
+  }
+  const int hr = min(lane >> 1, 17), hz = hr / 6, hy = hr - hz * 6;
+  const int gz = min(max(k - 1 + hz, 0), d.Z - 1), gy = min(max(y0 - 1 + hy, 0), d.Y - 1);
+  const int gx = (lane & 1) ? min(x0 + TX, d.X - 1) : max(x0 - 1, 0);
+  const float h = g[(long long)gz * d.sz + (long long)gy * d.sy + gx];
+#pragma unroll
+  for (int r = 0; r < 18; r++) tile[(r / 6) * LP + (r % 6) * LX + 1 + lane] = v[r];
+  if (lane < 36) tile[hz * LP + hy * LX + ((lane & 1) ? LX - 1 : 0)] = h;
+}
+
+// tile index of global cell (x, y, zg) = x + y*LX + zg*LP + cbias  (cbias: per lane, see the kernels)
+__device__ __forceinline__ int tidx(int x, int y, int zg, int cbias) {
+  return __mul24(zg, LP) + (__mul24(y, LX) + x) + cbias;
+}
+
+// get_at_mac (third_party/grid.cc:379-417) of the three faces of the cell at tile index c, from the tile
+__device__ __forceinline__ void mac_from_tile(const float* __restrict__ t, int c, v3& u0, v3& u1, v3& u2) {
+  const float* ux = t + c;
+  const float* uy = t + LN + c;
+  const float* uz = t + 2 * LN + c;
+  u0.x = ux[0];
+  u0.y = 0.25f * (uy[0] + uy[-1] + uy[LX] + uy[-1 + LX]);
+  u0.z = 0.25f * (uz[0] + uz[-1] + uz[LP] + uz[-1 + LP]);
+  u1.x = 0.25f * (ux[0] + ux[-LX] + ux[1] + ux[1 - LX]);
+  u1.y = uy[0];
+  u1.z = 0.25f * (uz[0] + uz[-LX] + uz[LP] + uz[-LX + LP]);
+  u2.x = 0.25f * (ux[0] + ux[-LP] + ux[1] + ux[1 - LP]);
+  u2.y = 0.25f * (uy[0] + uy[-LP] + uy[LX] + uy[LX - LP]);
+  u2.z = uz[0];
+}
+
+// One ordinary back-trace (calcLineTrace with length <= kFastLen: a single step, calc_line_trace.cc:313-503).
+// Returns false when the lane needs the generic trace (long displacement, NaN, end point not in a fluid cell).
+// `p` is the traced position (global z); valid only when true is returned.
+__device__ __forceinline__ bool trace_fast(const float* __restrict__ tile, int cbias, v3 ctr, v3 u, float ndt, v3& p) {
+  const float dx = u.x * ndt, dy = u.y * ndt, dz = u.z * ndt;     // scale3(u, -dt)
+  const float l2 = dx * dx + dy * dy + dz * dz;                   // vec3::norm, vec3.h:119-127
+  const bool nz = l2 > 1e-6f;
+  const float len = nz ? sqrt_exact(l2) : 0.0f;
+  const float r = nz ? rcp_refined(len) : 0.0f;                   // len == 0: direction 0, p = ctr (the reference returns pos)
+  const float qx = div_by<1>(dx, len, r), qy = div_by<1>(dy, len, r), qz = div_by<1>(dz, len, r);
+  p.x = ctr.x + qx * len;                                         // next = pos + dt * step, step = min(length - 0, 1) = length
+  p.y = ctr.y + qy * len;
+  p.z = ctr.z + qz * len;
+  const int f = (int)tile[FL + tidx((int)p.x, (int)p.y, (int)p.z, cbias)];
+  return (len <= kFastLen) & ((f & kFluid) != 0);
+}
+
+// interpol (grid.cc:182-202) of one tile field at p, for a position the fast trace produced: p - 0.5 lies in
+// [i - 1, i + 1) on every axis, so buildIndex's clamps cannot act; pc - float(int(pc)) == fract(pc) for pc >= 0.
+struct FastLerp { int x, y, z; float s0, s1, t0, t1, f0, f1; };
+__device__ __forceinline__ FastLerp lerp_fast(v3 p) {
+  FastLerp L;
+  const float px = p.x - 0.5f, py = p.y - 0.5f, pz = p.z - 0.5f;
+  L.x = (int)px; L.y = (int)py; L.z = (int)pz;
+  L.s1 = __builtin_amdgcn_fractf(px); L.t1 = __builtin_amdgcn_fractf(py); L.f1 = __builtin_amdgcn_fractf(pz);
+  L.s0 = 1.0f - L.s1; L.t0 = 1.0f - L.t1; L.f0 = 1.0f - L.f1;
+  return L;
+}
+__device__ __forceinline__ float lerp8(const FastLerp& L, float g000, float g010, float g100, float g110, float g001,
+                                       float g011, float g101, float g111) {   // g[x][y][z]
+  const float lo = (g000 * L.t0 + g010 * L.t1) * L.s0 + (g100 * L.t0 + g110 * L.t1) * L.s1;
+  const float hi = (g001 * L.t0 + g011 * L.t1) * L.s0 + (g101 * L.t0 + g111 * L.t1) * L.s1;
+  return lo * L.f0 + hi * L.f1;
+}
+__device__ __forceinline__ float sample_tile(const float* __restrict__ g, int cbias, v3 p) {
+  const FastLerp L = lerp_fast(p);
+  const float* q = g + tidx(L.x, L.y, L.z, cbias);
+  return lerp8(L, q[0], q[LX], q[1], q[1 + LX], q[LP], q[LP + LX], q[LP + 1], q[LP + 1 + LX]);
+}
+
+// min/max of the 2^3 corner box at tile index b, accumulated as manta_clamp_bounds does (tfl_advect.hpp)
+__device__ __forceinline__ void box_minmax(const float* __restrict__ q, float& lo, float& hi) {
+  lo = __builtin_fminf(__builtin_fminf(lo, q[0]), q[1]);
+  hi = __builtin_fmaxf(__builtin_fmaxf(hi, q[0]), q[1]);
+  lo = __builtin_fminf(__builtin_fminf(lo, q[LX]), q[1 + LX]);
+  hi = __builtin_fmaxf(__builtin_fmaxf(hi, q[LX]), q[1 + LX]);
+  lo = __builtin_fminf(__builtin_fminf(lo, q[LP]), q[LP + 1]);
+  hi = __builtin_fmaxf(__builtin_fmaxf(hi, q[LP]), q[LP + 1]);
+  lo = __builtin_fminf(__builtin_fminf(lo, q[LP + LX]), q[LP + 1 + LX]);
+  hi = __builtin_fmaxf(__builtin_fmaxf(hi, q[LP + LX]), q[LP + 1 + LX]);
+}
+// MacCormackClampMAC bounds (tfluids.cc:701-746) of one component for |vel| < 1 at a cell >= 2 inside the domain:
+// int(pos -+ vel) lies in [i - 1, i] on every axis, the index clamps and isInBounds cannot act.
+__device__ __forceinline__ void clamp_bounds_tile(const float* __restrict__ g, int cbias, v3 ijk, v3 vel, float& lo, float& hi) {
+  lo = 3.402823466e+38f; hi = -3.402823466e+38f;
+  box_minmax(g + tidx((int)(ijk.x - vel.x), (int)(ijk.y - vel.y), (int)(ijk.z - vel.z), cbias), lo, hi);
+  box_minmax(g + tidx((int)(ijk.x + vel.x), (int)(ijk.y + vel.y), (int)(ijk.z + vel.z), cbias), lo, hi);
+}
+
+#ifdef TFL_EXP_NOSTAGE
+#define TFL_EXP_STAGE(x) if (a.dt == 123.0f) { x; }
+#else
+#define TFL_EXP_STAGE(x) x
+#endif
+#ifdef TFL_EXP_STAGEONLY
+#define TFL_EXP_AFTER_STAGE if (a.dt != 123.0f) { if (tile[lane + w] == 77.f) flags = nullptr; else return; }
+#else
+#define TFL_EXP_AFTER_STAGE
+#endif
+struct Geo { int i, j, k, lane, c0, cbias; bool in_grid, deep; v3 ctr; };
+
+// common prologue: block -> plane/batch item, tile staged, cell geometry. `deep` = not a border cell of the whole grid and
+// the 3^3 neighbourhood inside the local array. With a displacement <= 0.99 from the centre of such a cell the trace
+// cannot leave the domain (p > 0.51, p < N - 0.51), p - 0.5 lies in (i - 1, i + 1) so buildIndex's clamps and the clamp
+// boxes' index clamps cannot act, and every tap lies in [i - 1, i + 1]: inside the grid and inside the tile.
+#define TFL_VEL3_PROLOGUE()                                                                        \
+  __shared__ float tile[4 * LN];                                                                   \
+  const Dom& d = a.d;                                                                              \
+  int b, k; dom_bk(d, b, k);                                                                       \
+  const long long cells = (long long)d.sc;                                                         \
+  flags += b * cells; U += b * cells * 3;                                                          \
+  const int lane = threadIdx.x, w = __builtin_amdgcn_readfirstlane(threadIdx.y);                   \
+  const int x0 = blockIdx.x * TX, y0 = blockIdx.y * TY;                                            \
+  TFL_EXP_STAGE(stage_tile(tile + w * LN, w < 3 ? U + w * cells : flags, d, x0, y0, k, lane));     \
+  __syncthreads();                                                                                 \
+  const int i = x0 + lane, j = y0 + w;                                                             \
+  if (i >= d.X || j >= d.Y) return;                                                                \
+  TFL_EXP_AFTER_STAGE                                                                              \
+  const int kg = k + d.zg;                                                                         \
+  const int c0 = LP + (w + 1) * LX + lane + 1;                                                     \
+  const int cbias = c0 - (i + j * LX + kg * LP);                                                   \
+  const bool deep = i >= 1 && i <= d.X - 2 && j >= 1 && j <= d.Y - 2 && kg >= 1 && kg <= d.Zg - 2 && k >= 1 && k <= d.Z - 2; \
+  const v3 ctr = mk3((float)i + 0.5f, (float)j + 0.5f, (float)kg + 0.5f);                          \
+  const int o = TFL_AT(d, i, j, k)
+
+// ---- pass A / the single-pass method: SemiLagrangeEulerOursMAC ------------------------------------------------
+__global__ __launch_bounds__(256) void k_vel3_fwd(AdvArgs a, const float* __restrict__ U, const float* __restrict__ flags,
+                                                  float* __restrict__ out) {
+  TFL_VEL3_PROLOGUE();
+  out += b * cells * 3;
+  float v0 = 0.0f, v1 = 0.0f, v2 = 0.0f;
+  unsigned slow = 0;
+  const bool fl = deep ? (((int)tile[FL + c0]) & kFluid) != 0 : fluid_at(d, flags, i, j, k);
+  if (deep && fl) {
+    v3 u0, u1, u2, p0, p1, p2;
+    mac_from_tile(tile, c0, u0, u1, u2);
+    const bool k0 = trace_fast(tile, cbias, ctr, u0, -a.dt, p0);
+    const bool k1 = trace_fast(tile, cbias, ctr, u1, -a.dt, p1);
+    const bool k2 = trace_fast(tile, cbias, ctr, u2, -a.dt, p2);
+    v0 = sample_tile(tile, cbias, p0);
+    v1 = sample_tile(tile + LN, cbias, p1);
+    v2 = sample_tile(tile + 2 * LN, cbias, p2);
+    slow = (k0 ? 0u : 1u) | (k1 ? 0u : 2u) | (k2 ? 0u : 4u);
+  } else if (!on_border<true>(d, i, j, k)) {
+    if (!fl) { v0 = U[o]; v1 = U[o + d.sc]; v2 = U[o + 2 * d.sc]; }   // tfluids.cc:598-601
+    else slow = 7u;
+  }
+#ifdef TFL_EXP_NOSLOW
+  if (deep && fl) slow = 0;
+#endif
+#ifdef TFL_EXP_COUNT
+  { const unsigned long long m = __ballot(slow != 0); if (lane == 0) { atomicAdd(a.err + 1, 1ull); if (m) atomicAdd(a.err + 2, 1ull); atomicAdd(a.err + 3, (unsigned long long)__popcll(m)); } }
+#endif
+  if (slow) {   // rare lanes: the generic trace + sampler on global memory
+    if (slow & 1u) v0 = sl_mac_from_u<true, true, 0>(a, flags, U, get_at_mac<true, 0>(d, U, i, j, k), a.dt, i, j, k);
+    if (slow & 2u) v1 = sl_mac_from_u<true, true, 1>(a, flags, U, get_at_mac<true, 1>(d, U, i, j, k), a.dt, i, j, k);
+    if (slow & 4u) v2 = sl_mac_from_u<true, true, 2>(a, flags, U, get_at_mac<true, 2>(d, U, i, j, k), a.dt, i, j, k);
+  }
+  out[o] = v0; out[o + d.sc] = v1; out[o + 2 * d.sc] = v2;
+}
+
+// ---- pass B: backward trace on fwd + MacCormackCorrectMAC + MacCormackClampMAC --------------------------------
+// interpol of a global channel plane at a fast-trace position (the forward field is not in the tile)
+__device__ __forceinline__ float sample_global_fast(const float* __restrict__ g, const Dom& d, unsigned safe_off4, bool ok, v3 p) {
+  const FastLerp L = lerp_fast(p);
+  // local plane = global plane - zg; a lane whose trace failed reads its own cell (any valid address) and is redone later
+  unsigned o4 = (unsigned)(__mul24(L.z - d.zg, d.sz * 4) + (__mul24(L.y, d.sy * 4) + L.x * 4));
+  o4 = ok ? o4 : safe_off4;
+  const unsigned sy4 = (unsigned)d.sy * 4u, sz4 = (unsigned)d.sz * 4u, one4 = (unsigned)d.one * 4u;
+  const unsigned a00 = o4, a01 = o4 + sy4, a10 = o4 + sz4, a11 = o4 + sz4 + sy4;
+  return lerp8(L, ldg(g, a00), ldg(g, a01), ldg(g, a00 + one4), ldg(g, a01 + one4), ldg(g, a10), ldg(g, a11),
+               ldg(g, a10 + one4), ldg(g, a11 + one4));
+}
+
+__global__ __launch_bounds__(256) void k_vel3_bwd(AdvArgs a, double half_strength, const float* __restrict__ U,
+                                                  const float* __restrict__ flags, const float* __restrict__ fwd,
+                                                  float* __restrict__ dst) {
+  TFL_VEL3_PROLOGUE();
+  fwd += b * cells * 3; dst += b * cells * 3;
+  const float f0 = fwd[o], f1 = fwd[o + d.sc], f2 = fwd[o + 2 * d.sc];
+  float r0 = f0, r1 = f1, r2 = f2;
+  const bool fl = deep ? (((int)tile[FL + c0]) & kFluid) != 0 : fluid_at(d, flags, i, j, k);
+  unsigned slow = 7u;
+  if (deep && fl) {
+    // MacCormackCorrectMAC skips a face whose other cell is not fluid (tfluids.cc:672-690)
+    const bool s0 = (((int)tile[FL + c0 - 1]) & kFluid) == 0, s1 = (((int)tile[FL + c0 - LX]) & kFluid) == 0,
+               s2 = (((int)tile[FL + c0 - LP]) & kFluid) == 0;
+    v3 u0, u1, u2, p0, p1, p2;
+    mac_from_tile(tile, c0, u0, u1, u2);
+    const bool k0 = trace_fast(tile, cbias, ctr, u0, a.dt, p0);
+    const bool k1 = trace_fast(tile, cbias, ctr, u1, a.dt, p1);
+    const bool k2 = trace_fast(tile, cbias, ctr, u2, a.dt, p2);
+    const unsigned o4 = (unsigned)o * 4u;
+    const float* fz = fwd;   // plane zg of the whole grid sits at local plane 0: sample_global_fast subtracts zg itself
+    const float b0 = sample_global_fast(fz, d, o4, k0, p0);
+    const float b1 = sample_global_fast(fz + d.sc, d, o4, k1, p1);
+    const float b2 = sample_global_fast(fz + 2 * d.sc, d, o4, k2, p2);
+    const v3 ijk = mk3((float)i, (float)j, (float)kg);
+    float lo0, hi0, lo1, hi1, lo2, hi2;
+    clamp_bounds_tile(tile, cbias, ijk, scale3(u0, a.dt), lo0, hi0);
+    clamp_bounds_tile(tile + LN, cbias, ijk, scale3(u1, a.dt), lo1, hi1);
+    clamp_bounds_tile(tile + 2 * LN, cbias, ijk, scale3(u2, a.dt), lo2, hi2);
+    const float uo0 = tile[c0], uo1 = tile[LN + c0], uo2 = tile[2 * LN + c0];
+    // the reference evaluates f + strength * 0.5 * (orig - bwd) in double (unsuffixed 0.5, tfluids.cc:693)
+    if (!s0) r0 = (float)((double)f0 + half_strength * (double)(uo0 - b0));
+    if (!s1) r1 = (float)((double)f1 + half_strength * (double)(uo1 - b1));
+    if (!s2) r2 = (float)((double)f2 + half_strength * (double)(uo2 - b2));
+    r0 = fclampf(r0, lo0, hi0); r1 = fclampf(r1, lo1, hi1); r2 = fclampf(r2, lo2, hi2);
+    // a failed trace also invalidates the clamp corners (|vel| may exceed the tile): the whole component is redone
+    slow = (k0 ? 0u : 1u) | (k1 ? 0u : 2u) | (k2 ? 0u : 4u);
+  }
+#ifdef TFL_EXP_NOSLOW
+  if (deep && fl) slow = 0;
+#endif
+  if (slow) {
+    const bool border = on_border<true>(d, i, j, k);
+    const bool sk0 = !fl || (i > 0 && !fluid_at(d, flags, i - 1, j, k));
+    const bool sk1 = !fl || (j > 0 && !fluid_at(d, flags, i, j - 1, k));
+    const bool sk2 = !fl || (k > 0 && !fluid_at(d, flags, i, j, k - 1));
+    const v3 ijk = mk3((float)i, (float)j, (float)kg);
+#define TFL_VEL3_SLOW(C, BIT, F, SK, R)                                                                              \
+    if (slow & BIT) {                                                                                                \
+      float v = F;                                                                                                   \
+      if (!border) {                                                                                                 \
+        const v3 u = get_at_mac<true, C>(d, U, i, j, k);                                                             \
+        float lo, hi;                                                                                                \
+        const bool ok = manta_clamp_bounds<true>(d, U + C * d.sc, ijk, scale3(u, a.dt), lo, hi);                     \
+        const float bw = fl ? sl_mac_from_u<true, true, C>(a, flags, fwd, u, -a.dt, i, j, k) : F;                    \
+        if (!SK) v = (float)((double)F + half_strength * (double)(U[o + C * d.sc] - bw));                            \
+        v = ok ? fclampf(v, lo, hi) : F;                                                                             \
+      } else if (!SK) {                                                                                              \
+        v = (float)((double)F + half_strength * (double)(U[o + C * d.sc] - 0.0f));                                   \
+      }                                                                                                              \
+      R = v;                                                                                                         \
+    }
+    TFL_VEL3_SLOW(0, 1u, f0, sk0, r0)
+    TFL_VEL3_SLOW(1, 2u, f1, sk1, r1)
+    TFL_VEL3_SLOW(2, 4u, f2, sk2, r2)
+#undef TFL_VEL3_SLOW
+  }
+  dst[o] = r0; dst[o + d.sc] = r1; dst[o + 2 * d.sc] = r2;
+}
+
+}  // namespace
+
+bool advect_vel3(hipStream_t st, bool two_pass, const AdvArgs& a, int B, const float* U, const float* flags, float* fwd,
+                 float* dst, int stages) {
+  static const bool off = getenv("TFL_ADVECT_GATHER") != nullptr;   // A/B switch: the round-2 gather kernels
+  const Dom& d = a.d;
+  // 24-bit multiplies address the planes (4*X*Y < 2^24) and 32-bit byte offsets the cells of one channel (Z*Y*X < 2^30)
+  if (off || d.Z < 3 || (long long)d.X * d.Y * 4 >= (1 << 24) || (long long)d.sc >= (1ll << 30)) return false;
+  const dim3 blk(TX, TY, 1), grd = cell_grid(d, B, blk);
+  const bool pa = stages & 2, pb = stages & 4;
+  if (!two_pass) {
+    if (pa) { TFL_TIMED_EXT("k_vel_fwd", st); TFL_LAUNCH_EXT(k_vel3_fwd, grd, blk, 0, st, a, U, flags, dst); }
+    return true;
+  }
+  if (pa) { TFL_TIMED_EXT("k_vel_fwd", st); TFL_LAUNCH_EXT(k_vel3_fwd, grd, blk, 0, st, a, U, flags, fwd); }
+  if (pb) {
+    TFL_TIMED_EXT("k_vel_bwd", st);
+    TFL_LAUNCH_EXT(k_vel3_bwd, grd, blk, 0, st, a, (double)a.strength * 0.5, U, flags, (const float*)fwd, dst);
+  }
+  return true;
+}
+
+}  // namespace tfl

@@ -16,7 +16,7 @@
 
 enum Op { ADD_U32, MUL_LO_U32, MUL_U24, MAD_U24, LSHL_ADD_U64, CVT_I32_F32, CVT_F32_I32, MIN3_F32, MIN_I32, FMA_F32,
           PK_FMA_F32, MUL_F32, FMA_F64, MUL_F64, ADD_F64, CVT_F64_F32, CVT_F32_F64, RCP_F32, SQRT_F32, DIV_SCALE,
-          DIV_FMAS, DIV_FIXUP, CNDMASK, CMP_F32, ADD3_U32, ASHR, LSHL_ADD_U32, NOPS };
+          DIV_FMAS, DIV_FIXUP, CNDMASK, CMP_F32, ADD3_U32, ASHR, LSHL_ADD_U32, ADD_F32, ADD_F32_E64, PK_ADD_F32, PK_MUL_F32, MED3_F32, MAX_F32, FMAC_F32, TRUNC_F32, FLOOR_F32, RSQ_F32, MAD_U64_U32, CMP_F32_E64, CNDMASK_E64, SUB_F32_SGPR, MUL_F32_LIT, AND_B32, MAD_I32_I24, FMA_F32_SGPR2, NOPS };
 
 template <int OP>
 __global__ __launch_bounds__(256) void k(float* out, int iters, float fa, int ia) {
@@ -51,6 +51,24 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, float fa, int ia
   if (OP == ADD3_U32) CHAIN8(asm volatile("v_add3_u32 %0, %0, %1, %1" : "+v"(i[q]) : "v"(ia)))
   if (OP == ASHR) CHAIN8(asm volatile("v_ashrrev_i32 %0, 31, %0" : "+v"(i[q])))
   if (OP == LSHL_ADD_U32) CHAIN8(asm volatile("v_lshl_add_u32 %0, %0, 2, %1" : "+v"(i[q]) : "v"(ia)))
+  if (OP == ADD_F32) CHAIN8(asm volatile("v_add_f32_e32 %0, %0, %1" : "+v"(f[q]) : "v"(fa)))
+  if (OP == ADD_F32_E64) CHAIN8(asm volatile("v_add_f32_e64 %0, %0, %1" : "+v"(f[q]) : "v"(fa)))
+  if (OP == PK_ADD_F32) CHAIN8(asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(p[q]) : "v"(p[(q + 1) & 7])))
+  if (OP == PK_MUL_F32) CHAIN8(asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(p[q]) : "v"(p[(q + 1) & 7])))
+  if (OP == MED3_F32) CHAIN8(asm volatile("v_med3_f32 %0, %0, %1, %1" : "+v"(f[q]) : "v"(fa)))
+  if (OP == MAX_F32) CHAIN8(asm volatile("v_max_f32_e32 %0, %0, %1" : "+v"(f[q]) : "v"(fa)))
+  if (OP == FMAC_F32) CHAIN8(asm volatile("v_fmac_f32_e32 %0, %1, %1" : "+v"(f[q]) : "v"(fa)))
+  if (OP == TRUNC_F32) CHAIN8(asm volatile("v_trunc_f32_e32 %0, %0" : "+v"(f[q])))
+  if (OP == FLOOR_F32) CHAIN8(asm volatile("v_floor_f32_e32 %0, %0" : "+v"(f[q])))
+  if (OP == RSQ_F32) CHAIN8(asm volatile("v_rsq_f32_e32 %0, %0" : "+v"(f[q])))
+  if (OP == MAD_U64_U32) CHAIN8(asm volatile("v_mad_u64_u32 %0, vcc, %1, %1, %0" : "+v"(l[q]) : "v"(ia) : "vcc"))
+  if (OP == CMP_F32_E64) CHAIN8(asm volatile("v_cmp_lt_f32_e64 s[20:21], %0, %1" : : "v"(f[q]), "v"(fa) : "s20", "s21"))
+  if (OP == CNDMASK_E64) CHAIN8(asm volatile("v_cndmask_b32_e64 %0, %0, %1, s[20:21]" : "+v"(f[q]) : "v"(fa)))
+  if (OP == SUB_F32_SGPR) CHAIN8(asm volatile("v_sub_f32_e32 %0, %1, %0" : "+v"(f[q]) : "s"(fa)))
+  if (OP == MUL_F32_LIT) CHAIN8(asm volatile("v_mul_f32_e32 %0, 0x3e800000, %0" : "+v"(f[q])))
+  if (OP == AND_B32) CHAIN8(asm volatile("v_and_b32_e32 %0, %0, %1" : "+v"(i[q]) : "v"(ia)))
+  if (OP == MAD_I32_I24) CHAIN8(asm volatile("v_mad_i32_i24 %0, %0, %1, %1" : "+v"(i[q]) : "v"(ia)))
+  if (OP == FMA_F32_SGPR2) CHAIN8(asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(f[q]) : "s"(fa)))
   float s = 0;
   for (int q = 0; q < 8; q++) s += f[q] + i[q] + (float)dd[q] + (float)l[q] + p[q].x + p[q].y;
   out[blockIdx.x * 256 + threadIdx.x] = s;
@@ -79,5 +97,6 @@ int main() {
   R(ADD_U32) R(ADD_U32) R(MUL_LO_U32) R(MUL_U24) R(MAD_U24) R(LSHL_ADD_U64) R(LSHL_ADD_U32) R(ADD3_U32) R(ASHR) R(CVT_I32_F32) R(CVT_F32_I32)
   R(MIN3_F32) R(MIN_I32) R(MUL_F32) R(FMA_F32) R(PK_FMA_F32) R(FMA_F64) R(MUL_F64) R(ADD_F64) R(CVT_F64_F32) R(CVT_F32_F64)
   R(RCP_F32) R(SQRT_F32) R(DIV_SCALE) R(DIV_FMAS) R(DIV_FIXUP) R(CNDMASK) R(CMP_F32)
+  R(ADD_F32) R(ADD_F32_E64) R(PK_ADD_F32) R(PK_MUL_F32) R(MED3_F32) R(MAX_F32) R(FMAC_F32) R(TRUNC_F32) R(FLOOR_F32) R(RSQ_F32) R(MAD_U64_U32) R(CMP_F32_E64) R(CNDMASK_E64) R(SUB_F32_SGPR) R(MUL_F32_LIT) R(AND_B32) R(MAD_I32_I24) R(FMA_F32_SGPR2)
   return 0;
 }
