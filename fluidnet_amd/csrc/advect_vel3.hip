@@ -15,9 +15,15 @@
 //    tools/ubench/exact_math.hip). Every other lane (walls, obstacles' neighbours, fast flow) runs the generic
 //    functions of tfl_device.hpp / tfl_advect.hpp afterwards, from scratch: same result as before by construction.
 //  * LDS TILE. Per 64x4x1-cell block the 66x6x3 halo tile of U (3 components) and flags is staged once with
-//    coalesced row loads; the 18 MAC taps, the trace's flag look-ups, the forward pass's 24 interpolation taps
-//    and the backward pass's 48 clamp corners are ds_reads with immediate offsets from one address VGPR. Only the
-//    backward pass's 24 interpolation taps of the forward field remain global gathers.
+//    coalesced row loads (one field per wave; scalar row pointers, no per-lane address arithmetic); the 18 MAC taps,
+//    the trace's flag look-ups, the forward pass's 24 interpolation taps and the backward pass's 48 clamp corners
+//    are ds_reads with immediate offsets from one address VGPR. Only the backward pass's 24 interpolation taps of
+//    the forward field remain global gathers, issued for the three components together (one L2 round trip).
+//  * What bounds these kernels now (profiles/r03_pmc_adv.txt): instruction ISSUE -- a SIMD retires one
+//    instruction of any kind (VALU, SALU, LDS, VMEM) per ~2.7 clocks here, so the count of ALL instructions per
+//    wave is the budget; packed fp32 (v_pk_mul/add) issues at half rate and buys nothing (SLP vectorisation is off
+//    for this file). A z-marched variant (4-slot plane ring, 1.55x instead of 4.6x staging) issued 24 % fewer
+//    instructions per cell but lost more to block-count quantisation at 128^3 (2048 long blocks on 256 CUs).
 //
 // Algorithmic HBM bytes per cell are unchanged: pass A 28 B (U3, flags -> fwd3), pass B 40 B (fwd3, U3, flags -> dst3).
 #include "tfl_advect.hpp"
@@ -33,28 +39,50 @@ constexpr int LX = TX + 2, LY = TY + 2, LP = LX * LY, LN = 3 * LP;   // 66, 6, 3
 constexpr int FL = 3 * LN;                                           // tile offset of the flags field
 constexpr float kFastLen = 0.99f;                                    // longest displacement the fast path takes
 
+// "surely a plain fluid cell": the flag word is exactly TypeFluid. Any other word (obstacle, or fluid with further
+// bits set) sends the lane to the generic path, which decodes the bits as the reference does.
+__device__ __forceinline__ bool plain_fluid(float f) { return f == 1.0f; }
+
 __device__ __forceinline__ float ldg(const float* __restrict__ base, unsigned byte_off) {   // uniform base + 32-bit lane offset
   return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);
 }
 
 // Wave w stages field w: 18 rows of 64 (one coalesced 256-B load each) + the two halo columns (36 lanes).
-// Rows / columns outside the grid are loaded from the nearest inside one: fast lanes never read them.
+// EDGE = false (block whose halo rows and planes lie inside the array): row pointers advance by scalar adds.
+// EDGE = true: rows / columns outside the array are loaded from the nearest inside one (fast lanes never read them).
+template <bool EDGE>
 __device__ __forceinline__ void stage_tile(float* __restrict__ tile, const float* __restrict__ g, const Dom& d, int x0,
                                            int y0, int k, int lane) {
-  const unsigned xl4 = (unsigned)min(x0 + lane, d.X - 1) * 4u;
-  float v[18];
+  float v[18], h;
+  const int hr = min(lane >> 1, 17), hz = hr / 6, hy = hr - hz * 6, side = lane & 1;
+  if (EDGE) {
+    const unsigned xl4 = (unsigned)min(x0 + lane, d.X - 1) * 4u;
 #pragma unroll
-  for (int r = 0; r < 18; r++) {
-    const int z = min(max(k - 1 + r / 6, 0), d.Z - 1), y = min(max(y0 - 1 + r % 6, 0), d.Y - 1);   // wave-uniform
-    v[r] = ldg(g + ((long long)z * d.sz + (long long)y * d.sy), xl4);
+    for (int r = 0; r < 18; r++) {
+      const int z = min(max(k - 1 + r / 6, 0), d.Z - 1), y = min(max(y0 - 1 + r % 6, 0), d.Y - 1);   // wave-uniform
+      v[r] = ldg(g + ((long long)z * d.sz + (long long)y * d.sy), xl4);
+    }
+    const int gz = min(max(k - 1 + hz, 0), d.Z - 1), gy = min(max(y0 - 1 + hy, 0), d.Y - 1);
+    const int gx = side ? min(x0 + TX, d.X - 1) : max(x0 - 1, 0);
+    h = ldg(g, (unsigned)(gz * d.sz + gy * d.sy + gx) * 4u);
+  } else {
+    // rows and planes all inside the array; only the columns may stick out (x0 = 0, or the last block of a row)
+    const int sy4 = d.sy * 4, sz4 = d.sz * 4;
+    const char* row = reinterpret_cast<const char*>(g + ((long long)(k - 1) * d.sz + (long long)(y0 - 1) * d.sy));
+    const unsigned l4 = (unsigned)min(x0 + lane, d.X - 1) * 4u;
+    const int gx = side ? min(x0 + TX, d.X - 1) : max(x0 - 1, 0);
+    h = *reinterpret_cast<const float*>(row + (unsigned)(__mul24(hz, sz4) + __mul24(hy, sy4) + gx * 4));
+#pragma unroll
+    for (int z = 0; z < 3; z++) {
+      const char* rp = row;
+#pragma unroll
+      for (int y = 0; y < 6; y++) { v[z * 6 + y] = *reinterpret_cast<const float*>(rp + l4); rp += sy4; }
+      row += sz4;
+    }
   }
-  const int hr = min(lane >> 1, 17), hz = hr / 6, hy = hr - hz * 6;
-  const int gz = min(max(k - 1 + hz, 0), d.Z - 1), gy = min(max(y0 - 1 + hy, 0), d.Y - 1);
-  const int gx = (lane & 1) ? min(x0 + TX, d.X - 1) : max(x0 - 1, 0);
-  const float h = g[(long long)gz * d.sz + (long long)gy * d.sy + gx];
 #pragma unroll
   for (int r = 0; r < 18; r++) tile[(r / 6) * LP + (r % 6) * LX + 1 + lane] = v[r];
-  if (lane < 36) tile[hz * LP + hy * LX + ((lane & 1) ? LX - 1 : 0)] = h;
+  if (lane < 36) tile[hz * LP + hy * LX + (side ? LX - 1 : 0)] = h;
 }
 
 // tile index of global cell (x, y, zg) = x + y*LX + zg*LP + cbias  (cbias: per lane, see the kernels)
@@ -91,8 +119,7 @@ __device__ __forceinline__ bool trace_fast(const float* __restrict__ tile, int c
   p.x = ctr.x + qx * len;                                         // next = pos + dt * step, step = min(length - 0, 1) = length
   p.y = ctr.y + qy * len;
   p.z = ctr.z + qz * len;
-  const int f = (int)tile[FL + tidx((int)p.x, (int)p.y, (int)p.z, cbias)];
-  return (len <= kFastLen) & ((f & kFluid) != 0);
+  return (len <= kFastLen) & plain_fluid(tile[FL + tidx((int)p.x, (int)p.y, (int)p.z, cbias)]);
 }
 
 // interpol (grid.cc:182-202) of one tile field at p, for a position the fast trace produced: p - 0.5 lies in
@@ -137,41 +164,42 @@ __device__ __forceinline__ void clamp_bounds_tile(const float* __restrict__ g, i
   box_minmax(g + tidx((int)(ijk.x + vel.x), (int)(ijk.y + vel.y), (int)(ijk.z + vel.z), cbias), lo, hi);
 }
 
-#ifdef TFL_EXP_NOSTAGE
-#define TFL_EXP_STAGE(x) if (a.dt == 123.0f) { x; }
-#else
-#define TFL_EXP_STAGE(x) x
-#endif
-#ifdef TFL_EXP_STAGEONLY
-#define TFL_EXP_AFTER_STAGE if (a.dt != 123.0f) { if (tile[lane + w] == 77.f) flags = nullptr; else return; }
-#else
-#define TFL_EXP_AFTER_STAGE
-#endif
-struct Geo { int i, j, k, lane, c0, cbias; bool in_grid, deep; v3 ctr; };
-
 // common prologue: block -> plane/batch item, tile staged, cell geometry. `deep` = not a border cell of the whole grid and
 // the 3^3 neighbourhood inside the local array. With a displacement <= 0.99 from the centre of such a cell the trace
 // cannot leave the domain (p > 0.51, p < N - 0.51), p - 0.5 lies in (i - 1, i + 1) so buildIndex's clamps and the clamp
 // boxes' index clamps cannot act, and every tap lies in [i - 1, i + 1]: inside the grid and inside the tile.
+// (One batch item and the whole window in grid.z is the common launch: it skips dom_bk's integer division.)
 #define TFL_VEL3_PROLOGUE()                                                                        \
   __shared__ float tile[4 * LN];                                                                   \
   const Dom& d = a.d;                                                                              \
-  int b, k; dom_bk(d, b, k);                                                                       \
+  int b = 0, k = (int)blockIdx.z;                                                                  \
+  if ((int)gridDim.z != d.nw) { b = k / d.nw; k -= b * d.nw; }                                     \
+  k = k < d.n0 ? d.w0 + k : d.w1 + (k - d.n0);                                                     \
   const long long cells = (long long)d.sc;                                                         \
   flags += b * cells; U += b * cells * 3;                                                          \
   const int lane = threadIdx.x, w = __builtin_amdgcn_readfirstlane(threadIdx.y);                   \
   const int x0 = blockIdx.x * TX, y0 = blockIdx.y * TY;                                            \
-  TFL_EXP_STAGE(stage_tile(tile + w * LN, w < 3 ? U + w * cells : flags, d, x0, y0, k, lane));     \
+  const bool inner = y0 >= 1 && y0 + TY < d.Y && k >= 1 && k + 1 < d.Z;                            \
+  {                                                                                                \
+    const float* sf = w < 3 ? U + w * cells : flags;                                               \
+    if (inner) stage_tile<false>(tile + w * LN, sf, d, x0, y0, k, lane);                           \
+    else stage_tile<true>(tile + w * LN, sf, d, x0, y0, k, lane);                                  \
+  }                                                                                                \
   __syncthreads();                                                                                 \
   const int i = x0 + lane, j = y0 + w;                                                             \
   if (i >= d.X || j >= d.Y) return;                                                                \
-  TFL_EXP_AFTER_STAGE                                                                              \
   const int kg = k + d.zg;                                                                         \
   const int c0 = LP + (w + 1) * LX + lane + 1;                                                     \
   const int cbias = c0 - (i + j * LX + kg * LP);                                                   \
   const bool deep = i >= 1 && i <= d.X - 2 && j >= 1 && j <= d.Y - 2 && kg >= 1 && kg <= d.Zg - 2 && k >= 1 && k <= d.Z - 2; \
   const v3 ctr = mk3((float)i + 0.5f, (float)j + 0.5f, (float)kg + 0.5f);                          \
-  const int o = TFL_AT(d, i, j, k)
+  const int o = TFL_AT(d, i, j, k);                                                                \
+  const unsigned o4 = (unsigned)o * 4u, sc4 = (unsigned)d.sc * 4u
+
+// store through a uniform base + 32-bit lane offset
+__device__ __forceinline__ void stg(float* __restrict__ base, unsigned byte_off, float v) {
+  *reinterpret_cast<float*>(reinterpret_cast<char*>(base) + byte_off) = v;
+}
 
 // ---- pass A / the single-pass method: SemiLagrangeEulerOursMAC ------------------------------------------------
 __global__ __launch_bounds__(256) void k_vel3_fwd(AdvArgs a, const float* __restrict__ U, const float* __restrict__ flags,
@@ -180,8 +208,8 @@ __global__ __launch_bounds__(256) void k_vel3_fwd(AdvArgs a, const float* __rest
   out += b * cells * 3;
   float v0 = 0.0f, v1 = 0.0f, v2 = 0.0f;
   unsigned slow = 0;
-  const bool fl = deep ? (((int)tile[FL + c0]) & kFluid) != 0 : fluid_at(d, flags, i, j, k);
-  if (deep && fl) {
+  const float cf = tile[FL + c0];
+  if (deep && plain_fluid(cf)) {
     v3 u0, u1, u2, p0, p1, p2;
     mac_from_tile(tile, c0, u0, u1, u2);
     const bool k0 = trace_fast(tile, cbias, ctr, u0, -a.dt, p0);
@@ -192,34 +220,29 @@ __global__ __launch_bounds__(256) void k_vel3_fwd(AdvArgs a, const float* __rest
     v2 = sample_tile(tile + 2 * LN, cbias, p2);
     slow = (k0 ? 0u : 1u) | (k1 ? 0u : 2u) | (k2 ? 0u : 4u);
   } else if (!on_border<true>(d, i, j, k)) {
-    if (!fl) { v0 = U[o]; v1 = U[o + d.sc]; v2 = U[o + 2 * d.sc]; }   // tfluids.cc:598-601
+    if ((((int)cf) & kFluid) == 0) { v0 = tile[c0]; v1 = tile[LN + c0]; v2 = tile[2 * LN + c0]; }   // tfluids.cc:598-601
     else slow = 7u;
   }
-#ifdef TFL_EXP_NOSLOW
-  if (deep && fl) slow = 0;
-#endif
-#ifdef TFL_EXP_COUNT
-  { const unsigned long long m = __ballot(slow != 0); if (lane == 0) { atomicAdd(a.err + 1, 1ull); if (m) atomicAdd(a.err + 2, 1ull); atomicAdd(a.err + 3, (unsigned long long)__popcll(m)); } }
-#endif
   if (slow) {   // rare lanes: the generic trace + sampler on global memory
     if (slow & 1u) v0 = sl_mac_from_u<true, true, 0>(a, flags, U, get_at_mac<true, 0>(d, U, i, j, k), a.dt, i, j, k);
     if (slow & 2u) v1 = sl_mac_from_u<true, true, 1>(a, flags, U, get_at_mac<true, 1>(d, U, i, j, k), a.dt, i, j, k);
     if (slow & 4u) v2 = sl_mac_from_u<true, true, 2>(a, flags, U, get_at_mac<true, 2>(d, U, i, j, k), a.dt, i, j, k);
   }
-  out[o] = v0; out[o + d.sc] = v1; out[o + 2 * d.sc] = v2;
+  stg(out, o4, v0); stg(out, o4 + sc4, v1); stg(out, o4 + 2u * sc4, v2);
 }
 
 // ---- pass B: backward trace on fwd + MacCormackCorrectMAC + MacCormackClampMAC --------------------------------
-// interpol of a global channel plane at a fast-trace position (the forward field is not in the tile)
-__device__ __forceinline__ float sample_global_fast(const float* __restrict__ g, const Dom& d, unsigned safe_off4, bool ok, v3 p) {
-  const FastLerp L = lerp_fast(p);
+// the 8 interpolation corners of a global channel plane at a fast-trace position (the forward field is not in the
+// tile). Issued for all three components BEFORE anything consumes them: one L2 round trip instead of three.
+__device__ __forceinline__ void gather8_global(const float* __restrict__ g, const Dom& d, unsigned safe_off4, bool ok,
+                                               const FastLerp& L, float* __restrict__ c) {
   // local plane = global plane - zg; a lane whose trace failed reads its own cell (any valid address) and is redone later
-  unsigned o4 = (unsigned)(__mul24(L.z - d.zg, d.sz * 4) + (__mul24(L.y, d.sy * 4) + L.x * 4));
-  o4 = ok ? o4 : safe_off4;
+  unsigned q4 = (unsigned)(__mul24(L.z - d.zg, d.sz * 4) + (__mul24(L.y, d.sy * 4) + L.x * 4));
+  q4 = ok ? q4 : safe_off4;
   const unsigned sy4 = (unsigned)d.sy * 4u, sz4 = (unsigned)d.sz * 4u, one4 = (unsigned)d.one * 4u;
-  const unsigned a00 = o4, a01 = o4 + sy4, a10 = o4 + sz4, a11 = o4 + sz4 + sy4;
-  return lerp8(L, ldg(g, a00), ldg(g, a01), ldg(g, a00 + one4), ldg(g, a01 + one4), ldg(g, a10), ldg(g, a11),
-               ldg(g, a10 + one4), ldg(g, a11 + one4));
+  const unsigned a00 = q4, a01 = q4 + sy4, a10 = q4 + sz4, a11 = q4 + sz4 + sy4;
+  c[0] = ldg(g, a00); c[1] = ldg(g, a01); c[2] = ldg(g, a00 + one4); c[3] = ldg(g, a01 + one4);
+  c[4] = ldg(g, a10); c[5] = ldg(g, a11); c[6] = ldg(g, a10 + one4); c[7] = ldg(g, a11 + one4);
 }
 
 __global__ __launch_bounds__(256) void k_vel3_bwd(AdvArgs a, double half_strength, const float* __restrict__ U,
@@ -227,11 +250,11 @@ __global__ __launch_bounds__(256) void k_vel3_bwd(AdvArgs a, double half_strengt
                                                   float* __restrict__ dst) {
   TFL_VEL3_PROLOGUE();
   fwd += b * cells * 3; dst += b * cells * 3;
-  const float f0 = fwd[o], f1 = fwd[o + d.sc], f2 = fwd[o + 2 * d.sc];
+  const float f0 = ldg(fwd, o4), f1 = ldg(fwd, o4 + sc4), f2 = ldg(fwd, o4 + 2u * sc4);
   float r0 = f0, r1 = f1, r2 = f2;
-  const bool fl = deep ? (((int)tile[FL + c0]) & kFluid) != 0 : fluid_at(d, flags, i, j, k);
+  const float cf = tile[FL + c0];
   unsigned slow = 7u;
-  if (deep && fl) {
+  if (deep && plain_fluid(cf)) {
     // MacCormackCorrectMAC skips a face whose other cell is not fluid (tfluids.cc:672-690)
     const bool s0 = (((int)tile[FL + c0 - 1]) & kFluid) == 0, s1 = (((int)tile[FL + c0 - LX]) & kFluid) == 0,
                s2 = (((int)tile[FL + c0 - LP]) & kFluid) == 0;
@@ -240,29 +263,32 @@ __global__ __launch_bounds__(256) void k_vel3_bwd(AdvArgs a, double half_strengt
     const bool k0 = trace_fast(tile, cbias, ctr, u0, a.dt, p0);
     const bool k1 = trace_fast(tile, cbias, ctr, u1, a.dt, p1);
     const bool k2 = trace_fast(tile, cbias, ctr, u2, a.dt, p2);
-    const unsigned o4 = (unsigned)o * 4u;
-    const float* fz = fwd;   // plane zg of the whole grid sits at local plane 0: sample_global_fast subtracts zg itself
-    const float b0 = sample_global_fast(fz, d, o4, k0, p0);
-    const float b1 = sample_global_fast(fz + d.sc, d, o4, k1, p1);
-    const float b2 = sample_global_fast(fz + 2 * d.sc, d, o4, k2, p2);
+    const FastLerp L0 = lerp_fast(p0), L1 = lerp_fast(p1), L2 = lerp_fast(p2);
+    float g0[8], g1[8], g2[8];
+    gather8_global(fwd, d, o4, k0, L0, g0);
+    gather8_global(fwd + d.sc, d, o4, k1, L1, g1);
+    gather8_global(fwd + 2 * d.sc, d, o4, k2, L2, g2);
     const v3 ijk = mk3((float)i, (float)j, (float)kg);
     float lo0, hi0, lo1, hi1, lo2, hi2;
     clamp_bounds_tile(tile, cbias, ijk, scale3(u0, a.dt), lo0, hi0);
     clamp_bounds_tile(tile + LN, cbias, ijk, scale3(u1, a.dt), lo1, hi1);
     clamp_bounds_tile(tile + 2 * LN, cbias, ijk, scale3(u2, a.dt), lo2, hi2);
     const float uo0 = tile[c0], uo1 = tile[LN + c0], uo2 = tile[2 * LN + c0];
+    const float b0 = lerp8(L0, g0[0], g0[1], g0[2], g0[3], g0[4], g0[5], g0[6], g0[7]);
+    const float b1 = lerp8(L1, g1[0], g1[1], g1[2], g1[3], g1[4], g1[5], g1[6], g1[7]);
+    const float b2 = lerp8(L2, g2[0], g2[1], g2[2], g2[3], g2[4], g2[5], g2[6], g2[7]);
     // the reference evaluates f + strength * 0.5 * (orig - bwd) in double (unsuffixed 0.5, tfluids.cc:693)
     if (!s0) r0 = (float)((double)f0 + half_strength * (double)(uo0 - b0));
     if (!s1) r1 = (float)((double)f1 + half_strength * (double)(uo1 - b1));
     if (!s2) r2 = (float)((double)f2 + half_strength * (double)(uo2 - b2));
-    r0 = fclampf(r0, lo0, hi0); r1 = fclampf(r1, lo1, hi1); r2 = fclampf(r2, lo2, hi2);
+    // std::min(hi, std::max(lo, v)) with lo <= hi (extrema of one set): the median of the three
+    r0 = __builtin_amdgcn_fmed3f(r0, lo0, hi0); r1 = __builtin_amdgcn_fmed3f(r1, lo1, hi1);
+    r2 = __builtin_amdgcn_fmed3f(r2, lo2, hi2);
     // a failed trace also invalidates the clamp corners (|vel| may exceed the tile): the whole component is redone
     slow = (k0 ? 0u : 1u) | (k1 ? 0u : 2u) | (k2 ? 0u : 4u);
   }
-#ifdef TFL_EXP_NOSLOW
-  if (deep && fl) slow = 0;
-#endif
   if (slow) {
+    const bool fl = (((int)cf) & kFluid) != 0;
     const bool border = on_border<true>(d, i, j, k);
     const bool sk0 = !fl || (i > 0 && !fluid_at(d, flags, i - 1, j, k));
     const bool sk1 = !fl || (j > 0 && !fluid_at(d, flags, i, j - 1, k));
@@ -288,7 +314,7 @@ __global__ __launch_bounds__(256) void k_vel3_bwd(AdvArgs a, double half_strengt
     TFL_VEL3_SLOW(2, 4u, f2, sk2, r2)
 #undef TFL_VEL3_SLOW
   }
-  dst[o] = r0; dst[o + d.sc] = r1; dst[o + 2 * d.sc] = r2;
+  stg(dst, o4, r0); stg(dst, o4 + sc4, r1); stg(dst, o4 + 2u * sc4, r2);
 }
 
 }  // namespace

@@ -44,4 +44,17 @@ __device__ __forceinline__ float sqrt_exact(float x) {
   return __builtin_fmaf(d, h, s);
 }
 
+// len = sqrt(x) and r = 1 / len from ONE transcendental (v_rsq): s0 = x * rsq(x) is within 2 ulp of the root, its
+// residual x - s0^2 comes out of one FMA, half the rsq is the correction slope; the rsq is also the seed of the
+// reciprocal of len (one Newton step). 7 VALU for both (sqrt_exact + rcp_refined: 8 with three transcendentals).
+__device__ __forceinline__ void sqrt_rcp_exact(float x, float& len, float& r) {
+  const float y = __builtin_amdgcn_rsqf(x);
+  const float s0 = x * y;
+  const float h = 0.5f * y;
+  const float d = __builtin_fmaf(-s0, s0, x);
+  len = __builtin_fmaf(d, h, s0);
+  const float e = __builtin_fmaf(-len, y, 1.0f);
+  r = __builtin_fmaf(e, y, y);
+}
+
 }  // namespace tfl

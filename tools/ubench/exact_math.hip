@@ -22,22 +22,24 @@ __device__ __forceinline__ uint32_t hash32(uint32_t x) {
   x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16; return x;
 }
 
-struct Counts { unsigned long long n, bad1, bad2, badsqrt, ex_a, ex_b, zsign; };
+struct Counts { unsigned long long n, bad1, bad2, badsqrt, ex_a, ex_b, zsign, badsqrt2, bad3; };
 
 __global__ void k_sqrt(uint32_t lo, uint32_t hi, Counts* c) {
-  unsigned long long bad = 0, n = 0;
+  unsigned long long bad = 0, bad2 = 0, n = 0;
   for (uint64_t u = lo + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; u < hi; u += (uint64_t)gridDim.x * blockDim.x) {
     const float x = __builtin_bit_cast(float, (uint32_t)u);
     const float want = sqrtf(x), got = tfl::sqrt_exact(x);
     n++;
     if (__builtin_bit_cast(uint32_t, want) != __builtin_bit_cast(uint32_t, got)) { bad++; c->ex_a = (uint32_t)u; }
+    float l2, r2; tfl::sqrt_rcp_exact(x, l2, r2);
+    if (__builtin_bit_cast(uint32_t, want) != __builtin_bit_cast(uint32_t, l2)) { bad2++; c->ex_b = (uint32_t)u; }
   }
-  atomicAdd(&c->n, n); atomicAdd(&c->badsqrt, bad);
+  atomicAdd(&c->n, n); atomicAdd(&c->badsqrt, bad); atomicAdd(&c->badsqrt2, bad2);
 }
 
 // mode 0: hashed pairs; mode 1: every mantissa of b in [0.5, 1) x 256 hashed numerators, b scaled into [2^-10, 1)
 __global__ void k_div(int mode, uint64_t total, uint32_t seed, Counts* c) {
-  unsigned long long bad1 = 0, bad2 = 0, n = 0, zs = 0;
+  unsigned long long bad1 = 0, bad2 = 0, bad3 = 0, n = 0, zs = 0;
   for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (uint64_t)gridDim.x * blockDim.x) {
     const uint32_t h1 = hash32((uint32_t)t ^ seed), h2 = hash32((uint32_t)(t >> 32) * 0x9e3779b9U + h1 + 0x1234567U),
                    h3 = hash32(h2 ^ 0xdeadbeefU);
@@ -68,16 +70,21 @@ __global__ void k_div(int mode, uint64_t total, uint32_t seed, Counts* c) {
       mag = 0.0f;
     }
     a = (h3 & 1) ? -mag : mag;
+    // rsq-seeded reciprocal (sqrt_rcp_exact): b has to be the root of an x; take x = RN(b*b) and its root as b
+    float r3; { float b3; tfl::sqrt_rcp_exact(b * b, b3, r3); if (mode == 0) b = b3; else if (b3 != b) r3 = tfl::rcp_refined(b); }
+    if (mag > b) { mag = b; a = (h3 & 1) ? -mag : mag; }
     const float want = a / b;
+    const float q3 = tfl::div_by<1>(a, b, r3);
     const float r = tfl::rcp_refined(b);
     const float q1 = tfl::div_by<1>(a, b, r), q2 = tfl::div_by<2>(a, b, r);
     n++;
     // a = -0: the quotient is -0 and the refinement returns +0 ((+0) + (-0)); equal as numbers, counted apart
-    if (want == 0.0f && q1 == 0.0f && q2 == 0.0f) { zs += __builtin_bit_cast(uint32_t, want) != __builtin_bit_cast(uint32_t, q1); continue; }
+    if (want == 0.0f && q1 == 0.0f && q2 == 0.0f && q3 == 0.0f) { zs += __builtin_bit_cast(uint32_t, want) != __builtin_bit_cast(uint32_t, q1); continue; }
     if (__builtin_bit_cast(uint32_t, want) != __builtin_bit_cast(uint32_t, q1)) { bad1++; c->ex_a = __builtin_bit_cast(uint32_t, a); c->ex_b = __builtin_bit_cast(uint32_t, b); }
     if (__builtin_bit_cast(uint32_t, want) != __builtin_bit_cast(uint32_t, q2)) bad2++;
+    if (__builtin_bit_cast(uint32_t, want) != __builtin_bit_cast(uint32_t, q3)) bad3++;
   }
-  atomicAdd(&c->n, n); atomicAdd(&c->bad1, bad1); atomicAdd(&c->bad2, bad2); atomicAdd(&c->zsign, zs);
+  atomicAdd(&c->n, n); atomicAdd(&c->bad1, bad1); atomicAdd(&c->bad2, bad2); atomicAdd(&c->zsign, zs); atomicAdd(&c->bad3, bad3);
 }
 
 static uint32_t fbits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
@@ -90,22 +97,23 @@ int main() {
   reset();
   k_sqrt<<<4096, 256>>>(fbits(ldexpf(1.0f, -40)), fbits(ldexpf(1.0f, 40)), d);
   fetch();
-  printf("sqrt_exact vs sqrtf: %llu operands (every float in [2^-40, 2^40)), mismatches %llu%s\n", h.n, h.badsqrt,
-         h.badsqrt ? " (example bits in ex_a)" : "");
+  printf("sqrt_exact vs sqrtf: %llu operands (every float in [2^-40, 2^40)), mismatches %llu; sqrt_rcp_exact (rsq-seeded) mismatches %llu\n",
+         h.n, h.badsqrt, h.badsqrt2);
+  if (h.badsqrt2) printf("  example x bits 0x%08llx (rsq-seeded)\n", h.ex_b);
   if (h.badsqrt) printf("  example x bits 0x%08llx\n", h.ex_a);
-  int rc = h.badsqrt != 0;
+  int rc = h.badsqrt != 0 || h.badsqrt2 != 0;
   reset();
   k_div<<<8192, 256>>>(0, 1ull << 33, 0x1234u, d);
   fetch();
-  printf("div_by vs '/': hashed pairs %llu, mismatches 1-step %llu, 2-step %llu (+ %llu zero quotients of sign +0 for -0)\n", h.n, h.bad1, h.bad2, h.zsign);
+  printf("div_by vs '/': hashed pairs %llu, mismatches 1-step %llu, 2-step %llu (+ %llu zero quotients of sign +0 for -0); rsq-seeded reciprocal 1-step %llu\n", h.n, h.bad1, h.bad2, h.zsign, h.bad3);
   if (h.bad1) printf("  example a bits 0x%08llx b bits 0x%08llx\n", h.ex_a, h.ex_b);
-  rc |= h.bad2 != 0;
+  rc |= h.bad2 != 0 || h.bad3 != 0;
   const unsigned long long b1a = h.bad1;
   reset();
   k_div<<<8192, 256>>>(1, (1ull << 23) * 10 * 256, 0x777u, d);
   fetch();
-  printf("div_by vs '/': all mantissas of b x 10 binades x 256 numerators %llu, mismatches 1-step %llu, 2-step %llu (+ %llu zero-sign)\n", h.n,
-         h.bad1, h.bad2, h.zsign);
+  printf("div_by vs '/': all mantissas of b x 10 binades x 256 numerators %llu, mismatches 1-step %llu, 2-step %llu (+ %llu zero-sign); rsq-seeded (where b is a root) %llu\n", h.n,
+         h.bad1, h.bad2, h.zsign, h.bad3);
   if (h.bad1) printf("  example a bits 0x%08llx b bits 0x%08llx\n", h.ex_a, h.ex_b);
   rc |= h.bad2 != 0;
   printf("TFL_DIV_STEPS needed: %d\n", (b1a || h.bad1) ? 2 : 1);

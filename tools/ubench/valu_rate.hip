@@ -16,7 +16,7 @@
 
 enum Op { ADD_U32, MUL_LO_U32, MUL_U24, MAD_U24, LSHL_ADD_U64, CVT_I32_F32, CVT_F32_I32, MIN3_F32, MIN_I32, FMA_F32,
           PK_FMA_F32, MUL_F32, FMA_F64, MUL_F64, ADD_F64, CVT_F64_F32, CVT_F32_F64, RCP_F32, SQRT_F32, DIV_SCALE,
-          DIV_FMAS, DIV_FIXUP, CNDMASK, CMP_F32, ADD3_U32, ASHR, LSHL_ADD_U32, ADD_F32, ADD_F32_E64, PK_ADD_F32, PK_MUL_F32, MED3_F32, MAX_F32, FMAC_F32, TRUNC_F32, FLOOR_F32, RSQ_F32, MAD_U64_U32, CMP_F32_E64, CNDMASK_E64, SUB_F32_SGPR, MUL_F32_LIT, AND_B32, MAD_I32_I24, FMA_F32_SGPR2, NOPS };
+          DIV_FMAS, DIV_FIXUP, CNDMASK, CMP_F32, ADD3_U32, ASHR, LSHL_ADD_U32, ADD_F32, ADD_F32_E64, PK_ADD_F32, PK_MUL_F32, MED3_F32, MAX_F32, FMAC_F32, TRUNC_F32, FLOOR_F32, RSQ_F32, MAD_U64_U32, CMP_F32_E64, CNDMASK_E64, SUB_F32_SGPR, MUL_F32_LIT, AND_B32, MAD_I32_I24, FMA_F32_SGPR2, MIX_ADD_CVT, MIX_MUL_FMA, MIX_ADD_MUL_AND, MIX_PKMUL_CVT, MIX_4, MOV_B32, NOPS };
 
 template <int OP>
 __global__ __launch_bounds__(256) void k(float* out, int iters, float fa, int ia) {
@@ -69,6 +69,12 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, float fa, int ia
   if (OP == AND_B32) CHAIN8(asm volatile("v_and_b32_e32 %0, %0, %1" : "+v"(i[q]) : "v"(ia)))
   if (OP == MAD_I32_I24) CHAIN8(asm volatile("v_mad_i32_i24 %0, %0, %1, %1" : "+v"(i[q]) : "v"(ia)))
   if (OP == FMA_F32_SGPR2) CHAIN8(asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(f[q]) : "s"(fa)))
+  if (OP == MIX_ADD_CVT) CHAIN8(asm volatile("v_add_f32_e32 %0, %0, %2\n v_cvt_i32_f32_e32 %1, %0" : "+v"(f[q]), "=v"(i[q]) : "v"(fa)))
+  if (OP == MIX_MUL_FMA) CHAIN8(asm volatile("v_mul_f32_e32 %0, %0, %2\n v_fma_f32 %1, %1, %2, %2" : "+v"(f[q]), "+v"(p[q].x) : "v"(fa)))
+  if (OP == MIX_ADD_MUL_AND) CHAIN8(asm volatile("v_add_f32_e32 %0, %0, %2\n v_mul_f32_e32 %1, %1, %2\n v_and_b32_e32 %3, %3, %4" : "+v"(f[q]), "+v"(p[q].x), "+v"(fa), "+v"(i[q]) : "v"(ia)))
+  if (OP == MIX_PKMUL_CVT) CHAIN8(asm volatile("v_pk_mul_f32 %0, %0, %2\n v_cvt_i32_f32_e32 %1, %3" : "+v"(p[q]), "=v"(i[q]) : "v"(p[(q + 1) & 7]), "v"(f[q])))
+  if (OP == MIX_4) CHAIN8(asm volatile("v_add_f32_e32 %0, %0, %2\n v_cvt_i32_f32_e32 %1, %0\n v_mul_f32_e32 %3, %3, %2\n v_fma_f32 %4, %4, %2, %2" : "+v"(f[q]), "=v"(i[q]), "+v"(fa), "+v"(p[q].x), "+v"(p[q].y)))
+  if (OP == MOV_B32) CHAIN8(asm volatile("v_mov_b32_e32 %0, %1" : "=v"(f[q]) : "v"(p[q].x)))
   float s = 0;
   for (int q = 0; q < 8; q++) s += f[q] + i[q] + (float)dd[q] + (float)l[q] + p[q].x + p[q].y;
   out[blockIdx.x * 256 + threadIdx.x] = s;
@@ -98,5 +104,7 @@ int main() {
   R(MIN3_F32) R(MIN_I32) R(MUL_F32) R(FMA_F32) R(PK_FMA_F32) R(FMA_F64) R(MUL_F64) R(ADD_F64) R(CVT_F64_F32) R(CVT_F32_F64)
   R(RCP_F32) R(SQRT_F32) R(DIV_SCALE) R(DIV_FMAS) R(DIV_FIXUP) R(CNDMASK) R(CMP_F32)
   R(ADD_F32) R(ADD_F32_E64) R(PK_ADD_F32) R(PK_MUL_F32) R(MED3_F32) R(MAX_F32) R(FMAC_F32) R(TRUNC_F32) R(FLOOR_F32) R(RSQ_F32) R(MAD_U64_U32) R(CMP_F32_E64) R(CNDMASK_E64) R(SUB_F32_SGPR) R(MUL_F32_LIT) R(AND_B32) R(MAD_I32_I24) R(FMA_F32_SGPR2)
+  printf("mixes: cycles per GROUP (2, 2, 3, 2, 4 instructions)\n");
+  R(MIX_ADD_CVT) R(MIX_MUL_FMA) R(MIX_ADD_MUL_AND) R(MIX_PKMUL_CVT) R(MIX_4) R(MOV_B32)
   return 0;
 }
