@@ -12,7 +12,13 @@ the reference ships no 3-D model), plus a procedural voxel obstacle standing in 
 
 N = 1: the whole 128^3 grid on one GPU through ONE C-ABI call per step (tfl_simulate_step).
 N > 1: STRONG scaling of the same 128^3 grid -- the metric's 1/2/4/8 series: z-slabs of 128/N planes (+4 halo planes per
-neighbour), one tfl_simulate_step_slab call per step and rank, halo messages over RCCL send/recv (fluidnet_amd/dist.py).
+neighbour), one tfl_simulate_step_slab call per step and rank, halo messages through the library's own transport
+(ncclSend / ncclRecv issued natively, fluidnet_amd/csrc/comm_rccl.cpp; torch.distributed only hands out the unique id
+and provides the timing barrier). TFL_DIST_BACKEND=gloo swaps in a host-staged transport for control-flow checks on a
+box with fewer GPUs than ranks; the line names the transport that actually ran.
+After the timed region the run also measures BASELINE configs 1-3 (short, through HIP-graph replay where they are
+launch-bound) and a 1 GiB device copy (the HBM rate this box actually delivers) -- reported under "configs" and
+"hbm_measured_peak_GBps"; every roofline fraction is given against the 8 TB/s pin rate AND against that.
 Every run also reports BASELINE config 5 (3-D 256^3, no obstacle, no confinement; cut into N z-slabs) under
 "config5_256" -- the north-star's ">= 100 steps/s at 256^3 on 8 GPUs" figure -- measured after the timed region.
 Rank 0 prints ONE JSON line. Inputs are resident in HBM before the timed region.
@@ -129,14 +135,29 @@ def config5_scene(res, layout, device):
     return batch, dict(mconf, vorticityConfinementAmp=0)
 
 
+TRANSPORT = {"name": "none (single GPU)"}
+
+
 def make_stepper(res, world, rank, dev, model, scene):
     """(batch, mconf, step, slab simulation or None) for a res^3 grid on `world` ranks."""
     from fluidnet_amd.simulate import simulate_native
     if world > 1:
-        from fluidnet_amd.dist import DistComm, SlabLayout, SlabSimulation
+        import torch.distributed as dist
+        from fluidnet_amd import tfluids
+        from fluidnet_amd.dist import DistComm, RcclComm, SlabLayout, SlabSimulation
         layout = SlabLayout(res, world, rank)
         batch, mconf = scene(res, layout, dev)
-        sim = SlabSimulation(batch, mconf, model, layout, DistComm(rank, world))
+        if dist.get_backend() == "nccl":
+            # the library's own transport: rank 0's RCCL unique id travels over the process group, the halo traffic does not
+            lib, ctx = tfluids._context(batch["UDiv"])
+            box = [RcclComm.unique_id(ctx) if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            comm = RcclComm(ctx, box[0], rank, world)
+            TRANSPORT["name"] = "native RCCL send/recv (csrc/comm_rccl.cpp, %s)" % lib.tfl_rccl_comm_origin(ctx).decode()
+        else:
+            comm = DistComm(rank, world)
+            TRANSPORT["name"] = "torch.distributed %s, staged through the host (control-flow check, not a measurement)" % dist.get_backend()
+        sim = SlabSimulation(batch, mconf, model, layout, comm)
         return batch, mconf, sim.step, sim
     batch, mconf = scene(res, None, dev)
 
@@ -146,15 +167,97 @@ def make_stepper(res, world, rank, dev, model, scene):
     return batch, mconf, step, None
 
 
+def measured_hbm_GBps(dev, mib=1024, reps=10):
+    """read + write rate of a 1 GiB device copy: what this box's HBM delivers to a streaming kernel (tools/hbm_bw.py)"""
+    n = mib * (1 << 20) // 4
+    a = torch.empty(n, device=dev).normal_()
+    b = torch.empty_like(a)
+    for _ in range(2):
+        b.copy_(a)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        b.copy_(a)
+    torch.cuda.synchronize()
+    el = (time.perf_counter() - t0) / reps
+    del a, b
+    torch.cuda.empty_cache()
+    return 2.0 * n * 4 / el / 1e9
+
+
+def _plume_scene(dims, rad, uscale, dev):
+    """flags = a border of obstacle cells, zero fields, plume BCs (simulate.lua:47-123) on a [Z][Y][X] grid (Z = 1: 2-D)"""
+    from fluidnet_amd import simulate as sim
+    Z, Y, X = dims
+    C = 3 if Z > 1 else 2
+    zz, yy, xx = torch.meshgrid(torch.arange(Z), torch.arange(Y), torch.arange(X), indexing="ij")
+    border = (xx == 0) | (xx == X - 1) | (yy == 0) | (yy == Y - 1)
+    if Z > 1:
+        border |= (zz == 0) | (zz == Z - 1)
+    flags = torch.where(border, 2.0, 1.0).to(torch.float32).view(1, 1, Z, Y, X).contiguous()
+    full = dict(pDiv=torch.zeros(1, 1, Z, Y, X), UDiv=torch.zeros(1, C, Z, Y, X), flags=flags, density=torch.zeros(1, 1, Z, Y, X))
+    sim.createPlumeBCs(full, [1.0], uscale, rad)
+    return {k: (None if v is None else v.contiguous().to(dev)) for k, v in full.items()}
+
+
+def other_configs(dev):
+    """BASELINE configs 1-3 on this GPU, steps/s (after the timed region). Small grids are launch-bound:
+    they run as HIP-graph replays (GraphedSimulate), the way a host would drive them; config 3 eagerly through
+    tfl_simulate_step. Config 2 uses the reference's shipped 2-D model (data/models/myModel2D, parsed into
+    tests/golden/myModel2D_weights.npz: a data fixture, no checker code is imported)."""
+    from fluidnet_amd import FluidNetModel
+    from fluidnet_amd.simulate import GraphedSimulate, simulate_native
+    out = {}
+
+    def run(key, what, dims, mconf, model, rad, usc, graph, steps):
+        b = _plume_scene(dims, rad, usc, dev)
+        if graph:
+            g = GraphedSimulate(None, mconf, b, model)
+            stepfn = g.step
+        else:
+            stepfn = lambda: simulate_native(None, mconf, b, model)   # noqa: E731
+        for _ in range(20):
+            stepfn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            stepfn()
+        torch.cuda.synchronize()
+        el = (time.perf_counter() - t0) / steps
+        assert bool(torch.isfinite(b["UDiv"]).all())
+        out[key] = {"workload": what, "steps_per_s": 1.0 / el, "ms_per_step": el * 1e3,
+                    "mcells_per_s": dims[0] * dims[1] * dims[2] / el / 1e6, "steps": steps,
+                    "driver": "HIP-graph replay (GraphedSimulate)" if graph else "tfl_simulate_step"}
+
+    m2 = dict(dt=4 / 60, advectionMethod="maccormackOurs", maccormackStrength=0.75, buoyancyScale=1.0, gravityScale=0,
+              vorticityConfinementAmp=0)
+    run("config1", "2-D 64x64 smoke plume, Jacobi pressure (20 iterations)", (1, 64, 64), dict(m2, simMethod="jacobi", maxIter=20),
+        None, 0.05, 10.0, True, 300)
+    wpath = os.path.join(ROOT, "tests", "golden", "myModel2D_weights.npz")
+    if os.path.exists(wpath):
+        z = np.load(wpath)
+        model2, wsrc = FluidNetModel([(z["w%d" % i], z["b%d" % i]) for i in range(5)], False), "shipped myModel2D weights"
+        run("config2", "2-D 128x128 ConvNet pressure projection (2-D default topology, %s)" % wsrc, (1, 128, 128),
+            dict(m2, simMethod="convnet"), model2, 0.05, 10.0, True, 300)
+    else:
+        out["config2"] = {"skipped": "tests/golden/myModel2D_weights.npz (the reference's shipped 2-D model) did not travel"}
+    m3 = dict(dt=0.1, advectionMethod="maccormackOurs", maccormackStrength=0.6, gravityScale=0, simMethod="convnet",
+              buoyancyScale=1.0, vorticityConfinementAmp=0)
+    run("config3", "3-D 64^3 plume, MacCormack advection + ConvNet projection", (64, 64, 64), m3,
+        FluidNetModel.default_3d(seed=1), 0.15, 0.5, False, 200)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--res", type=int, default=128)
     ap.add_argument("--preroll", type=int, default=16, help="untimed steps that develop the plume before warm-up")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-config5", action="store_true", help="skip the extra 256^3 (BASELINE config 5) measurement")
+    ap.add_argument("--no-configs", action="store_true", help="skip BASELINE configs 1-3")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -228,6 +331,7 @@ def main():
         kernels[name] = {"launches_per_step": rec["calls"] / nprof, "avg_ms": rec["ms"] / rec["calls"],
                          "ms_per_step": rec["ms"] / nprof}
     lf = [2.0 * w.shape[0] * w.shape[1] * w.shape[2] ** 3 for w, _ in model.layers]   # flop per voxel per layer
+    conv_path = os.environ.get("TFL_CONV_PATH", "winograd")
     conv_flops_per_voxel = {"k_conv_direct": sum(lf), "k_conv3_mfma_in": lf[0], "k_conv3_mfma": lf[1],
                             "k_conv3_mfma_tail": sum(lf[2:]), "k_conv3_in": lf[0], "k_conv3_mid": lf[1], "k_conv3_tail": sum(lf[2:])}
 
@@ -242,10 +346,16 @@ def main():
             k["bound"], k["achieved"], k["unit"] = "hbm", per_step / (k["ms_per_step"] * 1e-3) / 1e9, "GB/s"
             k["frac"] = k["achieved"] / HBM_PEAK_GBS
         elif name.startswith("k_conv"):
-            # useful (algorithmic) conv flops of the layers this kernel name executes in one step
-            k["bound"], k["unit"] = "mfma", "TFLOP/s"
+            # useful (algorithmic) conv flops of the layers this kernel name executes in one step. What runs behind the
+            # name: the default 3-D path is Winograd F(2,3) along x on the VECTOR ALUs (conv_valu.hip; no MFMA issued;
+            # 2/3 of a k3 layer's algorithmic MACs are issued), TFL_CONV_PATH=mfma the fp32-MFMA implicit GEMM
+            wino = conv_path == "winograd" and name in ("k_conv3_in", "k_conv3_mid", "k_conv3_tail")
+            k["bound"], k["unit"] = ("fp32-valu-winograd" if wino else ("mfma" if "mfma" in name or conv_path == "mfma" else "fp32-valu")), "TFLOP/s"
             k["achieved"] = conv_flops_per_voxel.get(name, 0.0) * cells_of(name) / (k["ms_per_step"] * 1e-3) / 1e12
             k["frac"] = k["achieved"] / FP32_PEAK_TFLOPS
+            if wino:   # flops the kernel really issues: x-taps 4 multiplies per 2 outputs instead of 6; the 1x1x1 layers in full
+                issued = {"k_conv3_in": lf[0] * 2 / 3, "k_conv3_mid": lf[1] * 2 / 3, "k_conv3_tail": lf[2] * 2 / 3 + sum(lf[3:])}[name]
+                k["issued_frac"] = issued * cells_of(name) / (k["ms_per_step"] * 1e-3) / 1e12 / FP32_PEAK_TFLOPS
     dom = max(kernels, key=lambda n: kernels[n]["ms_per_step"])
     dk = kernels[dom]
     traffic, traffic_source = None, None
@@ -259,9 +369,12 @@ def main():
                 % meta.get("commit", "r01")
         except Exception:
             traffic = None
+    hbm_meas = measured_hbm_GBps(dev)
     roofline = {"kernel": dom, "bound": dk.get("bound"), "achieved": dk.get("achieved"),
                 "peak": HBM_PEAK_GBS if dk.get("bound") == "hbm" else FP32_PEAK_TFLOPS, "unit": dk.get("unit"),
-                "frac": dk.get("frac"), "traffic": traffic, "traffic_source": traffic_source,
+                "frac": dk.get("frac"), "issued_frac": dk.get("issued_frac"),
+                "frac_of_measured_hbm": (dk["achieved"] / hbm_meas if dk.get("bound") == "hbm" else None),
+                "traffic": traffic, "traffic_source": traffic_source,
                 "avg_launch_ms": dk["avg_ms"], "launches_per_step": dk["launches_per_step"],
                 "note": "sum of per-kernel averages reads ~3% above ms_per_step (dispatches overlap at their edges)"}
     headline = {}
@@ -269,7 +382,9 @@ def main():
         t = kernels["k_vel_fwd"]["ms_per_step"] + kernels["k_vel_bwd"]["ms_per_step"]
         by = 28 * cells_of("k_vel_fwd") + 40 * cells_of("k_vel_bwd")
         headline = {"op": "advectVel (k_vel_fwd + k_vel_bwd)", "algorithmic_bytes_per_cell": 68, "ms": t,
-                    "achieved_GBps": by / (t * 1e-3) / 1e9, "frac_of_hbm_peak": by / (t * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                    "achieved_GBps": by / (t * 1e-3) / 1e9, "frac_of_hbm_peak": by / (t * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "frac_of_measured_hbm": by / (t * 1e-3) / 1e9 / hbm_meas,
+                    "bound_in_practice": "instruction issue (DESIGN.md 7): ~2.7 clocks per instruction of any kind per SIMD"}
     redundancy = None
     if world > 1:
         # Redundant compute of an INTERIOR rank (two neighbours), from this rank's measured time per plane of each kernel:
@@ -295,7 +410,7 @@ def main():
             sim5.drain()
         assert bool(torch.isfinite(b5["UDiv"]).all())
         config5 = {"workload": "BASELINE config 5: 3-D 256^3 plume, MacCormack + ConvNet projection, %s"
-                               % ("one GPU, un-sharded" if world == 1 else "%d z-slabs of %d planes, RCCL halo exchange" % (world, 256 // world)),
+                               % ("one GPU, un-sharded" if world == 1 else "%d z-slabs of %d planes, transport: %s" % (world, 256 // world, TRANSPORT["name"])),
                    "steps_per_s": n5 / el5, "ms_per_step": el5 / n5 * 1e3, "mcells_per_s": 256 ** 3 * n5 / el5 / 1e6,
                    "steps": n5, "n_gpus": world}
 
@@ -309,9 +424,10 @@ def main():
                                "(3-D default topology, seeded weights); %s" % (res, "single GPU" if world == 1 else
                                "strong scaling: %d z-slabs of %d planes" % (world, owned_planes)),
                    "grid_zyx": [res, res, res], "per_gpu_grid_zyx": [owned_planes, res, res],
-                   "decomposition": "single GPU" if world == 1 else "z-slabs, %d ranks, RCCL halo exchange" % world,
+                   "decomposition": "single GPU" if world == 1 else "z-slabs, %d ranks, transport: %s" % (world, TRANSPORT["name"]),
                    "preroll_steps": args.preroll, "slab": redundancy},
-        "roofline": roofline, "advection_headline": headline, "config5_256": config5, "kernels": kernels,
+        "roofline": roofline, "advection_headline": headline, "hbm_measured_peak_GBps": hbm_meas,
+        "config5_256": config5, "configs": other_configs(dev) if (world == 1 and not (args.no_configs or args.no_config5)) else None, "kernels": kernels,
     }
     if rank == 0 and not args.no_cpu_baseline and world == 1:
         b1, m1 = build_scene(res, res, None, dev)

@@ -148,6 +148,13 @@ SIGNATURES = {
                                                         _c.POINTER(tfl_slab)]),
     "tfl_simulate_step_slab": (_c.c_int, [_c.c_void_p, _c.POINTER(tfl_sim_params), _c.POINTER(tfl_sim_state),
                                           _c.POINTER(tfl_slab), _c.POINTER(tfl_comm), _c.c_void_p, _c.c_int64]),
+    "tfl_rccl_available": (_c.c_int, [_c.c_void_p]),
+    "tfl_rccl_comm_origin": (_c.c_char_p, [_c.c_void_p]),
+    "tfl_rccl_get_unique_id": (_c.c_int, [_c.c_void_p, _c.c_void_p]),
+    "tfl_rccl_comm_create": (_c.c_void_p, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int]),
+    "tfl_rccl_comm_wrap": (_c.c_void_p, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int]),
+    "tfl_rccl_comm_callbacks": (_c.POINTER(tfl_comm), [_c.c_void_p]),
+    "tfl_rccl_comm_destroy": (None, [_c.c_void_p, _c.c_void_p]),
     "tfl_slab_drain": (_c.c_int, [_c.c_void_p, _c.POINTER(tfl_sim_state), _c.POINTER(tfl_slab), _c.POINTER(tfl_comm),
                                   _c.c_void_p, _c.c_int64]),
 }

@@ -174,7 +174,8 @@ tfl_ctx* tfl_create(int device) {
       hipMalloc((void**)&c->d_resid, sizeof(double) * kMaxBatch) != hipSuccess ||
       hipHostMalloc((void**)&c->h_resid, sizeof(double) * kMaxBatch, hipHostMallocDefault) != hipSuccess ||
       hipMalloc((void**)&c->d_reach, sizeof(float)) != hipSuccess ||
-      hipHostMalloc((void**)&c->h_reach, sizeof(float), hipHostMallocDefault) != hipSuccess) {
+      hipHostMalloc((void**)&c->h_reach, sizeof(float), hipHostMallocDefault) != hipSuccess ||
+      hipEventCreateWithFlags(&c->reach_ev, hipEventDisableTiming) != hipSuccess) {
     tfl_destroy(c);
     return nullptr;
   }
@@ -186,6 +187,7 @@ void tfl_destroy(tfl_ctx* c) {
   if (!c) return;
   if (c->d_reach) (void)hipFree(c->d_reach);
   if (c->h_reach) (void)hipHostFree(c->h_reach);
+  if (c->reach_ev) (void)hipEventDestroy(c->reach_ev);
   if (c->d_trace_err) (void)hipFree(c->d_trace_err);
   if (c->d_resid) (void)hipFree(c->d_resid);
   if (c->h_resid) (void)hipHostFree(c->h_resid);

@@ -241,7 +241,8 @@ int tfl_simulate_step(tfl_ctx* c, const tfl_sim_params* prm, const tfl_sim_state
 // so, working backwards from "owned planes exact":
 //   project (0,0) <- conv3 (1,0) <- conv2 (2,1) <- conv1 (3,2) <- {p, div} (4,3)            [T1: p, T3: div]
 //   divergence (0,0) <- confine (0,1) <- curl (2,2) <- buoyancy/gravity (3,4) <- {U_adv (3,4), rho (4,4)}   [T2]
-//   pass B (0,0) <- pass A (R,R) <- min/max (2R,2R) <- {rho (2R+1,2R+1), U (R+1,R+1)}        [T0: U; rho is still
+//   pass B (0,0) <- pass A (R,R) <- min/max (2R,2R) <- {rho (2R+1,2R+1), U (max(R+1,2R), same): trace velocity R+1,
+//                                                       advected field 2R}                    [T0: U; rho is still
 //                                                                                             valid from T2]
 // Local array ends are treated by the kernels as the domain's border shell (zeros); with halo >= max(4, 2R+1) no window
 // above ever evaluates a tap there except through data that is exchanged instead (div, p).
@@ -337,7 +338,11 @@ int msg_finish(tfl_ctx* c, const SlabGeom& g, const tfl_comm* comm, const Msg& q
 // the four messages of a step; `div` / `Uadv` may be null tensors when only the layout of T0 / T1 is wanted
 void slab_messages(const SlabGeom& g, const tfl_sim_state* s, const tfl_tensor* Uadv, const tfl_tensor* div, Msg m[4]) {
   const int rr = 2 * g.R + 1;
-  m[0].tag = 0; m[0].n = 1; m[0].f[0] = Halo{s->U, g.R + 1, g.R + 1};
+  // U feeds pass A twice: as the trace velocity (window (R,R) reads it out to +-(R+1)) and as the ADVECTED field of the
+  // velocity's self-advection, sampled at positions up to R cells away from the window: +-2R. The projection only
+  // rewrites the owned planes, so everything out to max(R+1, 2R) must be refreshed (R = 1: 2 planes either way).
+  const int ur = std::max(g.R + 1, 2 * g.R);
+  m[0].tag = 0; m[0].n = 1; m[0].f[0] = Halo{s->U, ur, ur};
   m[1].tag = 1; m[1].n = 1; m[1].f[0] = Halo{s->p, 4, 3};
   m[2].tag = 2; m[2].n = s->n_density > 0 ? 2 : 1; m[2].f[0] = Halo{Uadv, 3, 4};
   if (s->n_density > 0) m[2].f[1] = Halo{s->density[0], rr > 4 ? rr : 4, rr > 4 ? rr : 4};
@@ -453,10 +458,15 @@ int tfl_simulate_step_slab(tfl_ctx* c, const tfl_sim_params* prm, const tfl_sim_
 
   // ---- reach check of the PREVIOUS step's velocity (no host sync: the word was copied back behind that step) ---------
   if (sl->check_reach) {
+    if (c->reach_pending) { (void)hipEventSynchronize(c->reach_ev); c->reach_pending = false; }   // step n-1's reduction has landed
     if (c->h_reach[0] * prm->dt >= (float)g.R) {
       char buf[160];
       snprintf(buf, sizeof(buf), "simulate_step_slab: max|u_z|*dt = %.3f cells reached the slab's back-trace reach %d", c->h_reach[0] * prm->dt, g.R);
-      c->err = buf; c->h_reach[0] = 0.0f;
+      c->h_reach[0] = 0.0f;
+      // the neighbours' matching receives of the U / p messages are already posted: finish ours before giving up
+      for (int t = 0; t < 2; t++)
+        if (multi && (sl->in_flight & (1 << t))) { (void)msg_finish(c, g, comm, m[t]); sl->in_flight &= ~(1 << t); }
+      c->err = buf;
       return TFL_EINVAL;
     }
   }
@@ -465,6 +475,7 @@ int tfl_simulate_step_slab(tfl_ctx* c, const tfl_sim_params* prm, const tfl_sim_
     for (int b = 0; b < g.B; b++)                                                                            // u_z of every batch item
       tfl::absmax(c->stream, (long long)g.Zl * g.yx, s->U->data + (3ll * b + 2) * g.Zl * g.yx, c->d_reach, b == 0);
     (void)hipMemcpyAsync(c->h_reach, c->d_reach, sizeof(float), hipMemcpyDeviceToHost, c->stream);
+    c->reach_pending = hipEventRecord(c->reach_ev, c->stream) == hipSuccess;
   }
   c->dx_dim = std::max(std::max(s->flags->X, s->flags->Y), sl->z_total);   // tfluids.getDx of the WHOLE grid
   (void)tfl_set_z_origin(c, sl->z_first, sl->z_total);

@@ -21,4 +21,6 @@ struct tfl_ctx {
   int stages = 0;                             // tfl_set_stages: which passes of a multi-pass operator run (0 = all)
   float* d_reach = nullptr;                   // z-slab reach check: max|u_z| of the current step (device word)
   float* h_reach = nullptr;                   // pinned mirror, read by the NEXT tfl_simulate_step_slab call
+  hipEvent_t reach_ev = nullptr;              // recorded behind the copy into h_reach; the next call waits for it
+  bool reach_pending = false;
 };

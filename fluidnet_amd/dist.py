@@ -9,7 +9,7 @@ the flow moves more than a cell per step).
 The step itself is native: tfl_simulate_step_slab (fluidnet_amd/csrc/simulate.cpp) runs every phase of simulate() under
 the narrowest z-window that keeps the owned planes exact (a few redundant planes per phase instead of a fixed wide
 halo), packs the halo messages, and calls back into THIS module only to move them:
-    U (R+1 planes) and p (4 / 3 planes)      leave at the end of a step, are consumed by the next one
+    U (max(R+1, 2R) planes) and p (4 / 3 planes)  leave at the end of a step, are consumed by the next one
     advected U (3 / 4) + density (max(4, 2R+1))  after MacCormack pass B, overlapped with the interior of pass B
     divergence (4 / 3)                        overlapped with the interior of the first conv layer
 plus one 2-double all-reduce for the ConvNet's global std(U) normaliser (lib/model.lua:93-117). xGMI is point-to-point:
@@ -162,6 +162,42 @@ class DistComm(_CommBase):
         self.dist.all_reduce(stats, op=self.dist.ReduceOp.SUM, group=self.group)
 
 
+class RcclComm:
+    """The library's own transport (csrc/comm_rccl.cpp): ncclSend / ncclRecv / ncclAllReduce issued natively on a
+    communication stream of the communicator -- no Python in the step's data path, the same object a LuaJIT or C host
+    uses (include/tfluids_hip.h, "native transport"). `unique_id` = the 128 bytes rank 0 got from `unique_id()`,
+    handed to the other ranks by the caller (torch.distributed broadcast in bench.py; any channel works).
+    `ctx` = the tfl_ctx the slab steps run on (SlabSimulation passes its own)."""
+
+    ID_BYTES = 128
+
+    def __init__(self, ctx, unique_id, rank, world):
+        self.lib = _lib.load()
+        self.ctx, self.rank, self.world = ctx, rank, world
+        buf = (ctypes.c_char * self.ID_BYTES).from_buffer_copy(bytes(unique_id))
+        self.handle = self.lib.tfl_rccl_comm_create(ctx, buf, rank, world)
+        if not self.handle:
+            raise TfluidsError(self.lib.tfl_last_error(ctx).decode() or "tfl_rccl_comm_create failed")
+        self.struct = self.lib.tfl_rccl_comm_callbacks(self.handle).contents
+        self.error = None
+
+    @staticmethod
+    def unique_id(ctx):
+        lib = _lib.load()
+        buf = (ctypes.c_char * RcclComm.ID_BYTES)()
+        if lib.tfl_rccl_get_unique_id(ctx, buf) != 0:
+            raise TfluidsError(lib.tfl_last_error(ctx).decode() or "tfl_rccl_get_unique_id failed")
+        return bytes(buf)
+
+    def bind(self, ws):      # the native callbacks take device pointers as they are
+        pass
+
+    def close(self):
+        if self.handle:
+            self.lib.tfl_rccl_comm_destroy(self.ctx, self.handle)
+            self.handle = None
+
+
 class ThreadComm(_CommBase):
     """Transport between VIRTUAL ranks living in threads of one process on one GPU (tests, single-GPU verification
     of the decomposition): a shared mailbox and barriers. All ranks enqueue on the same HIP stream, so device-side
@@ -212,7 +248,7 @@ class SlabSimulation:
         if (mconf.get("simMethod") or "convnet") != "convnet":
             raise TfluidsError("the z-slab path implements the ConvNet projection")
         if layout.world > 1 and comm is None:
-            raise TfluidsError("a slab with neighbours needs a transport (DistComm / ThreadComm)")
+            raise TfluidsError("a slab with neighbours needs a transport (RcclComm / DistComm / ThreadComm)")
         self.lib = _lib.load()
         self._own_ctx = None
         if own_context:      # virtual ranks in threads: the context carries per-step state (window, stream, reach word)
@@ -230,7 +266,7 @@ class SlabSimulation:
         if n <= 0:
             raise TfluidsError(lib.tfl_last_error(ctx).decode() or "bad slab description")
         self.ws = torch.zeros(n, dtype=torch.float32, device=U.device)    # persistent: messages live here across steps
-        if comm is not None:
+        if comm is not None and hasattr(comm, "struct"):
             comm.bind(self.ws)
 
     def _context(self):
@@ -242,6 +278,11 @@ class SlabSimulation:
 
     def _call(self, fn, *args):
         lib, ctx = self._context()
+        if self.comm is not None and not hasattr(self.comm, "struct"):
+            # a factory: the transport needs this simulation's context and -- communicator creation being collective --
+            # the rank's own thread / process (RcclComm)
+            self.comm = self.comm(ctx)
+            self.comm.bind(self.ws)
         cptr = ctypes.byref(self.comm.struct) if self.comm is not None else None
         if self.comm is not None:
             self.comm.error = None
@@ -260,6 +301,8 @@ class SlabSimulation:
             self._call(self.lib.tfl_slab_drain, ctypes.byref(self.st))
 
     def close(self):
+        if isinstance(self.comm, RcclComm):
+            self.comm.close()
         if self._own_ctx is not None:
             self.lib.tfl_destroy(self._own_ctx)
             self._own_ctx = None

@@ -197,6 +197,14 @@ int tfl_simulate_step_slab(tfl_ctx* ctx, const tfl_sim_params* params, const tfl
                            const tfl_comm* comm, float* workspace, int64_t workspace_floats);
 int tfl_slab_drain(tfl_ctx* ctx, const tfl_sim_state* state, tfl_slab* slab, const tfl_comm* comm, float* workspace,
                    int64_t workspace_floats);
+typedef struct tfl_rccl_comm tfl_rccl_comm;
+int tfl_rccl_available(tfl_ctx* ctx);
+const char* tfl_rccl_comm_origin(tfl_ctx* ctx);
+int tfl_rccl_get_unique_id(tfl_ctx* ctx, void* id);
+tfl_rccl_comm* tfl_rccl_comm_create(tfl_ctx* ctx, const void* id, int rank, int world);
+tfl_rccl_comm* tfl_rccl_comm_wrap(tfl_ctx* ctx, void* nccl_comm, int rank, int world);
+const tfl_comm* tfl_rccl_comm_callbacks(tfl_rccl_comm* comm);
+void tfl_rccl_comm_destroy(tfl_ctx* ctx, tfl_rccl_comm* comm);
 ]]
 -- END generated cdef
 
@@ -397,7 +405,7 @@ function M.invalidateBCs() plans = setmetatable({}, {__mode = 'k'}) end
 
 -- `model` may be a hip.Model, or an nn.gModule (wrapped on first use), or nil for the Jacobi / PCG projections.
 local wrapped = setmetatable({}, {__mode = 'k'})
-function M.simulate(conf, mconf, batch, model, outputDiv)
+local function sim_args(mconf, batch, model, outputDiv)
   local keep = {}
   local function D(t) local d = T(t); keep[#keep + 1] = d; return d end
   local prm = ffi.new('tfl_sim_params')
@@ -433,8 +441,61 @@ function M.simulate(conf, mconf, batch, model, outputDiv)
     model = wrapped[model]
   end
   st.model = model and model.handle or nil
+  return prm, st, keep
+end
+
+function M.simulate(conf, mconf, batch, model, outputDiv)
+  local prm, st, keep = sim_args(mconf, batch, model, outputDiv)
   local ws, n = workspace(batch.UDiv, lib.tfl_simulate_workspace_floats(ctx, prm, st))
   check(lib.tfl_simulate_step(ctx, prm, st, ws, n))
+  return keep ~= nil
+end
+
+-- ---- z-slab ranks: one LuaJIT process per GPU, grid cut along z, halos over RCCL inside the library -----------------
+-- (no counterpart in the reference, which is single-GPU; BASELINE config 5). Rank 0 calls M.rcclUniqueId() and hands
+-- the 128-byte string to the other ranks (a file, the launcher's environment, a socket); every rank then builds
+--   local slab = M.Slab{zTotal = 256, zFirst = lo, ownLo = c0, ownHi = c1, id = idString, rank = r, world = n}
+-- on its LOCAL extended tensors (owned planes + tfl_slab_halo(reach) planes next to each neighbour) and steps with
+--   slab:simulate(conf, mconf, batch, model)       -- tfluids.simulate on the slab, bit-equal on the owned planes
+--   slab:drain()                                   -- before reading halo planes / at the end
+function M.rcclUniqueId()
+  local id = ffi.new('char[128]')
+  check(lib.tfl_rccl_get_unique_id(ctx, id))
+  return ffi.string(id, 128)
+end
+
+local Slab = {}
+Slab.__index = Slab
+function M.Slab(o)
+  local self = setmetatable({}, Slab)
+  self.desc = ffi.new('tfl_slab')
+  self.desc.z_total, self.desc.z_first = o.zTotal, o.zFirst
+  self.desc.own_lo, self.desc.own_hi = o.ownLo, o.ownHi
+  self.desc.reach, self.desc.overlap = o.reach or 1, b2i(o.overlap)
+  self.desc.check_reach, self.desc.in_flight = b2i(o.checkReach ~= false), 0
+  if (o.world or 1) > 1 then
+    assert(type(o.id) == 'string' and #o.id == 128, 'Slab: id = the 128 bytes of M.rcclUniqueId() of rank 0')
+    self.comm = lib.tfl_rccl_comm_create(ctx, o.id, o.rank, o.world)
+    if self.comm == nil then error('tfluids_hip: ' .. ffi.string(lib.tfl_last_error(ctx))) end
+    self.comm = ffi.gc(self.comm, function(c) lib.tfl_rccl_comm_destroy(ctx, c) end)
+    self.callbacks = lib.tfl_rccl_comm_callbacks(self.comm)
+  end
+  return self
+end
+function Slab:simulate(conf, mconf, batch, model)
+  local prm, st, keep = sim_args(mconf, batch, model, false)
+  if self.ws == nil then   -- the SAME buffer on every call: messages started by one step are consumed by the next
+    self.n = tonumber(lib.tfl_simulate_slab_workspace_floats(ctx, prm, st, self.desc))
+    self.buf = batch.UDiv.new():resize(self.n):zero()     -- private: the shared scratch may be re-allocated by other operators
+    self.ws = ffi.cast('float*', torch.data(self.buf))
+  end
+  self.st, self.keep = st, keep
+  check(lib.tfl_simulate_step_slab(ctx, prm, st, self.desc, self.callbacks, self.ws, self.n))
+end
+function Slab:drain()
+  if self.st ~= nil and self.desc.in_flight ~= 0 then
+    check(lib.tfl_slab_drain(ctx, self.st, self.desc, self.callbacks, self.ws, self.n))
+  end
 end
 
 --- Route torch.CudaTensor's `.tfluids` method table, tfluids.normalizePressureMean and tfluids.simulate to the MI355X

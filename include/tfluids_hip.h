@@ -42,7 +42,11 @@ typedef enum tfl_status {
   TFL_EUNSUPPORTED = -3  /* valid in the reference but not built here */
 } tfl_status;
 
-/* A contiguous fp32 5-D tensor resident in HBM: [B][C][Z][Y][X], x fastest. */
+/* A contiguous fp32 5-D tensor resident in HBM: [B][C][Z][Y][X], x fastest.
+ * Supported sizes: the elements of ONE batch item fit a signed 32-bit index, C*Z*Y*X < 2^31 (element strides are
+ * int32 inside the kernels; the batch offset is applied in 64 bits), e.g. a 3-channel velocity up to 894^3. Larger
+ * tensors are refused with TFL_EUNSUPPORTED, never computed wrongly. The LDS-tiled 3-D advection kernels further use
+ * 24-bit plane strides (4*X*Y < 2^24, i.e. X*Y <= 2047^2) and fall back to the gather kernels beyond that. */
 typedef struct tfl_tensor {
   float* data;
   int32_t B, C, Z, Y, X;
@@ -404,7 +408,9 @@ typedef struct tfl_slab {
   int32_t overlap;        /* 1: split the phases that feed a message into boundary strips + interior so that the
                              transfer overlaps compute (worth it when a slab holds >~ 1M cells); 0: one launch each */
   int32_t check_reach;    /* 1: every step reduces max|u_z| on the device; a violation found by step n is reported
-                             by the call for step n+1 (no host sync is added) */
+                             by the call for step n+1, which waits for step n's reduction to land (the host can run
+                             at most one step ahead of the device); messages in flight are drained before the error
+                             is returned, so neighbours do not hang */
   int32_t in_flight;      /* OUT/IN, initialise to 0: bit mask of halo messages started by the previous call and not
                              yet consumed (tfl_simulate_step_slab finishes them; tfl_slab_drain does so explicitly) */
 } tfl_slab;
@@ -439,7 +445,7 @@ int64_t tfl_simulate_slab_workspace_floats(tfl_ctx* ctx, const tfl_sim_params* p
  * out of a global initial state); `workspace` must be the SAME buffer on every call (halo messages of p and U started
  * at the end of one step are consumed by the next).
  * Per step: three neighbour exchanges + one 2*B-double all-reduce --
- *   U(R+1 planes) | p(4 below, 3 above)   started at the end of the previous step, consumed at the start / before conv 1
+ *   U(max(R+1, 2R) planes) | p(4 below, 3 above)   started at the end of the previous step, consumed at the start / before conv 1
  *   advected U(3 below, 4 above) + density(max(4, 2R+1)) after MacCormack pass B, overlapped with its interior
  *   divergence(4 below, 3 above)          overlapped with the interior of the first conv layer
  * and every phase runs under the narrowest z-window that keeps the owned planes exact, so the redundant compute is a
@@ -451,6 +457,29 @@ int tfl_simulate_step_slab(tfl_ctx* ctx, const tfl_sim_params* params, const tfl
  * valid too (call before reading halos on the host, or before freeing the workspace). */
 int tfl_slab_drain(tfl_ctx* ctx, const tfl_sim_state* state, tfl_slab* slab, const tfl_comm* comm, float* workspace,
                    int64_t workspace_floats);
+
+/* ---- native transport for the z-slab step: RCCL send/recv over xGMI inside the library (csrc/comm_rccl.cpp) ------------
+ * For hosts without a communication layer of their own (the LuaJIT loop, plain C): one process per GPU, ranks ordered
+ * along z (rank r's upper neighbour is r+1). Rank 0 obtains a unique id and hands the 128 bytes to the other ranks by
+ * any means it has (a file, a socket, MPI, the launcher's environment); every rank then creates its communicator and
+ * passes tfl_rccl_comm_callbacks() as the `comm` of tfl_simulate_step_slab / tfl_slab_drain. RCCL is dlopen'ed on first
+ * use ($TFL_RCCL_LIBRARY, else a copy already loaded in the process, else librccl.so.1): the library itself links
+ * only the HIP runtime. Transfers run on a communication stream of the communicator, ordered against the context's
+ * stream by events; no call blocks the host. The context must outlive the communicator and keep its device. */
+#define TFL_RCCL_UNIQUE_ID_BYTES 128
+typedef struct tfl_rccl_comm tfl_rccl_comm;
+/* 1 when an RCCL could be bound (the reason is in tfl_last_error otherwise). */
+int tfl_rccl_available(tfl_ctx* ctx);
+/* which library was bound ("librccl.so.1 (already loaded)", a path, ...) */
+const char* tfl_rccl_comm_origin(tfl_ctx* ctx);
+/* ncclGetUniqueId: fills id[0..128). */
+int tfl_rccl_get_unique_id(tfl_ctx* ctx, void* id);
+/* ncclCommInitRank on the context's device (collective: every rank of `world` must call it). NULL on failure. */
+tfl_rccl_comm* tfl_rccl_comm_create(tfl_ctx* ctx, const void* id, int rank, int world);
+/* The same around a communicator the host already has (an ncclComm_t); it is not destroyed by tfl_rccl_comm_destroy. */
+tfl_rccl_comm* tfl_rccl_comm_wrap(tfl_ctx* ctx, void* nccl_comm, int rank, int world);
+const tfl_comm* tfl_rccl_comm_callbacks(tfl_rccl_comm* comm);
+void tfl_rccl_comm_destroy(tfl_ctx* ctx, tfl_rccl_comm* comm);
 
 #ifdef __cplusplus
 }

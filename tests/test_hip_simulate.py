@@ -350,20 +350,25 @@ def test_native_simulate_step_equals_python_orchestration(which):
     assert float(ta["UDiv"].abs().max()) > 0.1
 
 
-def _slab_sims(ref, mconf, world, layers_seed, reach=1, overlap=None, check_reach=True):
-    """Cut the global state `ref` (dict of device tensors) into `world` virtual z-slab ranks (threads + ThreadComm)."""
+def _slab_sims(ref, mconf, world, layers_seed, reach=1, overlap=None, check_reach=True, transport="thread"):
+    """Cut the global state `ref` (dict of device tensors) into `world` virtual z-slab ranks (threads). transport:
+    "thread" = ThreadComm (Python callbacks), "native" = the library's RCCL transport (csrc/comm_rccl.cpp; needs an
+    RCCL that accepts several ranks per device, i.e. tests/stub_rccl.cpp through TFL_RCCL_LIBRARY)."""
     import torch
-    from fluidnet_amd import FluidNetModel
-    from fluidnet_amd.dist import SlabLayout, SlabSimulation, ThreadComm
+    from fluidnet_amd import FluidNetModel, tfluids
+    from fluidnet_amd.dist import RcclComm, SlabLayout, SlabSimulation, ThreadComm
     Zt = ref["flags"].size(2)
     hub = ThreadComm.Hub(world)
+    uid = RcclComm.unique_id(tfluids._context(ref["flags"])[1]) if transport == "native" and world > 1 else None
     sims = []
     for r in range(world):
         lay = SlabLayout(Zt, world, r, reach)
         loc = {k: (lay.extract(v) if torch.is_tensor(v) else v) for k, v in ref.items()}
         model = FluidNetModel(layers_seed, True) if isinstance(layers_seed, list) else FluidNetModel.default_3d(seed=layers_seed)
-        sims.append(SlabSimulation(loc, mconf, model, lay, ThreadComm(hub, r) if world > 1 else None,
-                                   check_reach=check_reach, overlap=overlap, own_context=True))
+        comm = None
+        if world > 1:
+            comm = ThreadComm(hub, r) if transport == "thread" else (lambda ctx, r=r: RcclComm(ctx, uid, r, world))
+        sims.append(SlabSimulation(loc, mconf, model, lay, comm, check_reach=check_reach, overlap=overlap, own_context=True))
     return sims
 
 
@@ -431,6 +436,34 @@ def test_zslab_reach_violation_is_reported():
     # the same flow is fine for a slab that was laid out for reach 2 (5 halo planes)
     sims = _slab_sims(_to_dev(b, dev), dict(mconf, buoyancyScale=0.0), 2, S.default_3d_layers(seed=2), reach=2)
     run_virtual_ranks(sims, 1)
+    for s in sims:
+        s.close()
+
+
+def test_zslab_reach2_equals_single_gpu():
+    """with reach R = 2 the velocity's self-advection samples U up to 2R planes from the owned range, so the
+    U message must refresh max(R+1, 2R) planes, not R+1. A flow with |u_z|*dt in (1, 2) across the slab boundaries,
+    several steps (the planes beyond R+1 go stale only from the second step on), against the unsplit step."""
+    import torch
+    from fluidnet_amd import FluidNetModel
+    from fluidnet_amd.dist import run_virtual_ranks
+    from fluidnet_amd.simulate import simulate_native
+    dev = torch.device("cuda:0")
+    world, Zt, Y, X = 3, 36, 20, 24
+    b = _plume_batch((Zt, Y, X), 0.15, 0.6)
+    b["UDiv"][:, 2, 2:34, 4:16, 4:20] = 14.0          # 1.4 cells per step along z, through both cuts (z = 12, 24)
+    b["UDiv"][:, 2, 8:28, 6:12, 6:14] = -12.0
+    mconf = dict(dt=0.1, advectionMethod="maccormackOurs", maccormackStrength=0.6, buoyancyScale=1.0,
+                 gravityScale=0, vorticityConfinementAmp=1.0, simMethod="convnet")
+    layers = S.default_3d_layers(seed=2)
+    ref = _to_dev(b, dev)
+    model = FluidNetModel(layers, True)
+    sims = _slab_sims(ref, mconf, world, layers, reach=2, overlap=False, check_reach=False)
+    for _ in range(4):
+        simulate_native(None, mconf, ref, model)
+        run_virtual_ranks(sims, 1)
+        _assert_slabs_equal(sims, ref, 1e-7)
+    assert float(ref["UDiv"][:, 2].abs().max()) * 0.1 > 1.0     # the flow really exceeds one cell per step
     for s in sims:
         s.close()
 
