@@ -574,6 +574,17 @@ tfl_model* tfl_model_create_opts(tfl_ctx* c, int is3D, int nlayers, const int32_
     if (o.norm_func != TFL_NORMFUNC_STD && o.norm_func != TFL_NORMFUNC_L2) return bad("Incorrect normalize input function");
     if (o.nonlin < TFL_NONLIN_RELU || o.nonlin > TFL_NONLIN_SIGMOID) return bad("Bad mconf.nonlinType");
     if (o.pressure_skip && nlayers < 2) return bad("addPressureSkip needs a hidden layer to join pDiv to");
+    if (o.pressure_skip && (pool || up)) {
+      // the skip joins pDiv at full resolution in front of the last layer: with the layer table in hand, refuse the
+      // combinations tfl_model_finish cannot run (it used to report them on every forward instead: ADVICE r02)
+      bool multires = false;
+      for (int l = 0; l < nlayers; l++) multires = multires || (pool && pool[l] > 1) || (up && up[l] > 1);
+      const bool tail = (pool && (pool[nlayers - 1] > 1 || pool[nlayers - 2] > 1)) || (up && (up[nlayers - 1] > 1 || up[nlayers - 2] > 1));
+      if (tail || (nlayers > 2 && multires)) {
+        fail(c, TFL_EUNSUPPORTED, "model_create: addPressureSkip with pooling / upsampling layers");
+        return nullptr;
+      }
+    }
   }
   const int in_c = o.in_pDiv + o.in_UDiv * (is3D ? 3 : 2) + o.in_div + 1;
   if (cin[0] != in_c) {

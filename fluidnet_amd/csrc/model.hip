@@ -512,12 +512,14 @@ __global__ __launch_bounds__(256) void k_bc_scan(long long n, const float* __res
 // differs per field). One launch per message instead of a dozen strided copies.
 struct PackArgs {
   float* ptr[8];
-  long long start[9];   // prefix sums of elements per field in the buffer
+  float* buf[8];        // where the field's elements live in the message (one message may have several buffers: the
+                        // lower and the upper neighbour's go out in ONE launch)
+  long long start[9];   // prefix sums of elements per field over the launch
   long long per_row[8]; // elements per (b, channel) row of the field in the buffer = its planes * Y * X
   long long zoff[8];    // element offset of the field's first plane inside a (b, channel) row of the array
   int n;
 };
-__global__ __launch_bounds__(256) void k_pack_planes(PackArgs a, long long zstride, float* __restrict__ buf, int unpack) {
+__global__ __launch_bounds__(256) void k_pack_planes(PackArgs a, long long zstride, int unpack) {
   const long long total = a.start[a.n];
   for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
     int f = 0;
@@ -526,8 +528,8 @@ __global__ __launch_bounds__(256) void k_pack_planes(PackArgs a, long long zstri
     const long long r = t - a.start[f];
     const long long row = r / a.per_row[f], within = r - row * a.per_row[f];   // row = b*C + c
     float* g = a.ptr[f] + row * zstride + a.zoff[f] + within;
-    if (unpack) *g = buf[t];
-    else buf[t] = *g;
+    if (unpack) *g = a.buf[f][r];
+    else a.buf[f][r] = *g;
   }
 }
 
@@ -612,12 +614,13 @@ void apply_bcs(hipStream_t st, long long n, float* x, const float* bcv, const fl
 }
 
 long long pack_planes(hipStream_t st, int n, float* const* ptrs, const int* rows, const int* zlo, const int* nplanes,
-                      long long zstride, long long yx, float* buf, int unpack) {
+                      long long zstride, long long yx, float* buf, int unpack, float* const* bufs) {
   PackArgs a;
   a.n = n;
   a.start[0] = 0;
   for (int i = 0; i < 8; i++) {
     a.ptr[i] = i < n ? ptrs[i] : nullptr;
+    a.buf[i] = i < n ? (bufs ? bufs[i] : buf + a.start[i]) : nullptr;   // bufs = NULL: one contiguous buffer, field after field
     a.per_row[i] = i < n ? (long long)nplanes[i] * yx : 1;
     a.zoff[i] = i < n ? (long long)zlo[i] * yx : 0;
     a.start[i + 1] = a.start[i] + (i < n ? (long long)rows[i] * a.per_row[i] : 0);
@@ -625,7 +628,7 @@ long long pack_planes(hipStream_t st, int n, float* const* ptrs, const int* rows
   long long blocks = (a.start[n] + 255) / 256;
   if (blocks > 2048) blocks = 2048;
   if (blocks < 1) return 0;
-  { TFL_TIMED(unpack ? "k_unpack_planes" : "k_pack_planes", st); k_pack_planes<<<(int)blocks, 256, 0, st>>>(a, zstride, buf, unpack); }
+  { TFL_TIMED(unpack ? "k_unpack_planes" : "k_pack_planes", st); k_pack_planes<<<(int)blocks, 256, 0, st>>>(a, zstride, unpack); }
   return a.start[n];
 }
 

@@ -307,43 +307,53 @@ long long msg_layout(const SlabGeom& g, Msg* m, int count, float* base) {
   return off;
 }
 
-void pack_side(tfl_ctx* c, const SlabGeom& g, const Msg& q, bool lower, bool unpack) {
-  float* ptrs[3]; int rows[3], zlo[3], np[3];
-  for (int i = 0; i < q.n; i++) {
-    const Halo& h = q.f[i];
-    ptrs[i] = h.t->data; rows[i] = h.t->B * h.t->C;
-    if (!unpack) { np[i] = lower ? h.above : h.below; zlo[i] = lower ? g.o0 : g.o1 - h.below; }     // owned planes out
-    else { np[i] = lower ? h.below : h.above; zlo[i] = lower ? g.o0 - h.below : g.o1; }              // halo planes in
+// the planes of one message that leave (unpack = false: owned planes -> send buffers) or arrive (unpack = true: receive
+// buffers -> halo planes), BOTH neighbours in one launch
+void pack_msg(tfl_ctx* c, const SlabGeom& g, const Msg& q, bool unpack) {
+  float* ptrs[8]; float* bufs[8]; int rows[8], zlo[8], np[8];
+  int n = 0;
+  for (int side = 0; side < 2; side++) {
+    const bool lower = side == 0;
+    if (lower ? !g.lower : !g.upper) continue;
+    float* buf = unpack ? (lower ? q.recv_lo : q.recv_hi) : (lower ? q.send_lo : q.send_hi);
+    for (int i = 0; i < q.n; i++) {
+      const Halo& h = q.f[i];
+      ptrs[n] = h.t->data; rows[n] = h.t->B * h.t->C;
+      if (!unpack) { np[n] = lower ? h.above : h.below; zlo[n] = lower ? g.o0 : g.o1 - h.below; }     // owned planes out
+      else { np[n] = lower ? h.below : h.above; zlo[n] = lower ? g.o0 - h.below : g.o1; }              // halo planes in
+      bufs[n] = buf;
+      buf += (long long)rows[n] * np[n] * g.yx;
+      n++;
+    }
   }
-  float* buf = unpack ? (lower ? q.recv_lo : q.recv_hi) : (lower ? q.send_lo : q.send_hi);
-  tfl::pack_planes(c->stream, q.n, ptrs, rows, zlo, np, g.yx * g.Zl, g.yx, buf, unpack ? 1 : 0);
+  if (n) tfl::pack_planes(c->stream, n, ptrs, rows, zlo, np, g.yx * g.Zl, g.yx, nullptr, unpack ? 1 : 0, bufs);
 }
 
 int msg_start(tfl_ctx* c, const SlabGeom& g, const tfl_comm* comm, const Msg& q) {
-  if (!g.lower && !g.upper) return TFL_OK;
-  if (g.lower) pack_side(c, g, q, true, false);
-  if (g.upper) pack_side(c, g, q, false, false);
+  if ((!g.lower && !g.upper) || q.n == 0) return TFL_OK;
+  pack_msg(c, g, q, false);
   if (comm->exchange_start(comm->user, q.tag, q.send_lo, q.n_send_lo, q.recv_lo, q.n_recv_lo, q.send_hi, q.n_send_hi,
                            q.recv_hi, q.n_recv_hi) != 0) { c->err = "simulate_step_slab: comm callback failed (exchange_start)"; return TFL_EINVAL; }
   return TFL_OK;
 }
 int msg_finish(tfl_ctx* c, const SlabGeom& g, const tfl_comm* comm, const Msg& q) {
-  if (!g.lower && !g.upper) return TFL_OK;
+  if ((!g.lower && !g.upper) || q.n == 0) return TFL_OK;
   if (comm->exchange_wait(comm->user, q.tag) != 0) { c->err = "simulate_step_slab: comm callback failed (exchange_wait)"; return TFL_EINVAL; }
-  if (g.lower) pack_side(c, g, q, true, true);
-  if (g.upper) pack_side(c, g, q, false, true);
+  pack_msg(c, g, q, true);
   return TFL_OK;
 }
 
-// the four messages of a step; `div` / `Uadv` may be null tensors when only the layout of T0 / T1 is wanted
+// the three messages of a step (slot 1 is empty); `div` / `Uadv` may be null tensors when only the layout of T0 is wanted
 void slab_messages(const SlabGeom& g, const tfl_sim_state* s, const tfl_tensor* Uadv, const tfl_tensor* div, Msg m[4]) {
   const int rr = 2 * g.R + 1;
   // U feeds pass A twice: as the trace velocity (window (R,R) reads it out to +-(R+1)) and as the ADVECTED field of the
   // velocity's self-advection, sampled at positions up to R cells away from the window: +-2R. The projection only
   // rewrites the owned planes, so everything out to max(R+1, 2R) must be refreshed (R = 1: 2 planes either way).
   const int ur = std::max(g.R + 1, 2 * g.R);
-  m[0].tag = 0; m[0].n = 1; m[0].f[0] = Halo{s->U, ur, ur};
-  m[1].tag = 1; m[1].n = 1; m[1].f[0] = Halo{s->p, 4, 3};
+  // U and p leave together at the end of a step (ONE message, one packing launch) and are consumed at the start of the
+  // next one: nothing writes either field's halo planes in between (p is only read by the first conv layer)
+  m[0].tag = 0; m[0].n = 2; m[0].f[0] = Halo{s->U, ur, ur}; m[0].f[1] = Halo{s->p, 4, 3};
+  m[1].tag = 1; m[1].n = 0;
   m[2].tag = 2; m[2].n = s->n_density > 0 ? 2 : 1; m[2].f[0] = Halo{Uadv, 3, 4};
   if (s->n_density > 0) m[2].f[1] = Halo{s->density[0], rr > 4 ? rr : 4, rr > 4 ? rr : 4};
   m[3].tag = 3; m[3].n = 1; m[3].f[0] = Halo{div, 4, 3};
@@ -470,7 +480,7 @@ int tfl_simulate_step_slab(tfl_ctx* c, const tfl_sim_params* prm, const tfl_sim_
       return TFL_EINVAL;
     }
   }
-  if (sl->in_flight & 1) { rc = msg_finish(c, g, comm, m[0]); if (rc) return rc; sl->in_flight &= ~1; }     // U halos
+  if (sl->in_flight & 1) { rc = msg_finish(c, g, comm, m[0]); if (rc) return rc; sl->in_flight &= ~1; }     // U and p halos
   if (sl->check_reach) {
     for (int b = 0; b < g.B; b++)                                                                            // u_z of every batch item
       tfl::absmax(c->stream, (long long)g.Zl * g.yx, s->U->data + (3ll * b + 2) * g.Zl * g.yx, c->d_reach, b == 0);
@@ -560,7 +570,6 @@ int tfl_simulate_step_slab(tfl_ctx* c, const tfl_sim_params* prm, const tfl_sim_
   (void)tfl_set_stages(c, 4);
   rc = tfl_model_begin(c, s->model, s->U, s->flags, s->U, cw, mws, g.o0, g.o1, W.stats); if (rc) return rc;
   if (multi && comm->allreduce_sum(comm->user, W.stats, 2ll * g.B) != 0) { c->err = "simulate_step_slab: comm callback failed (allreduce_sum)"; return TFL_EINVAL; }
-  if (sl->in_flight & 2) { rc = msg_finish(c, g, comm, m[1]); if (rc) return rc; sl->in_flight &= ~2; }     // p halos
   const double count = 3.0 * (double)sl->z_total * (double)g.yx;
   const bool late_ubc = s->UBC && s->UBC->sparse && s->UBC->idem;
   const tfl_tensor* ubc = (s->UBC && !late_ubc) ? &s->UBC->bc : nullptr;
@@ -589,8 +598,7 @@ int tfl_simulate_step_slab(tfl_ctx* c, const tfl_sim_params* prm, const tfl_sim_
   // the next step's U and p halos leave now; they are consumed at its start / before its first conv layer
   if (multi) {
     rc = msg_start(c, g, comm, m[0]); if (rc) return rc;
-    rc = msg_start(c, g, comm, m[1]); if (rc) return rc;
-    sl->in_flight |= 3;
+    sl->in_flight |= 1;
   }
   return TFL_OK;
 }

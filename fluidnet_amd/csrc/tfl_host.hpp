@@ -138,7 +138,7 @@ void apply_bcs_indexed(hipStream_t st, long long n, const int* idx, float* x, co
 // planes [zlo[i], zlo[i] + nplanes[i]) of field i (rows[i] = B*C rows of zstride floats each) <-> buf; returns the
 // number of floats moved
 long long pack_planes(hipStream_t st, int n, float* const* ptrs, const int* rows, const int* zlo, const int* nplanes,
-                      long long zstride, long long yx, float* buf, int unpack);
+                      long long zstride, long long yx, float* buf, int unpack, float* const* bufs = nullptr);
 
 // conv.hip
 // upf > 1: the result goes to sub-position `sub` (= (c*upf + b)*upf + a) of an upf-times finer output grid (pixel shuffle)

@@ -88,6 +88,36 @@ def loadVoxelData(filename, reference_quirks=True):
     return dict(dims=dims, translation=translation, scale=scale, data=np.ascontiguousarray(vox, np.float32))
 
 
+def saveVoxelData(filename, voxels, translation=(0.0, 0.0, 0.0), scale=1.0):
+    """binvox writer (the format of the voxelizer's output the reference loads): `voxels` = a {0,1} grid in the layout
+    loadVoxelData returns, shape (d0, d2, d1). Plain run-length pairs (value, count <= 255). The reference's reader
+    drops the pair that ends the file (see loadVoxelData), so a grid that is to survive it must end in two empty cells
+    (file order: the last two x of the last row) -- true of every model that does not touch the last corner of its
+    box; asserted here."""
+    v = np.ascontiguousarray(np.asarray(voxels).transpose(0, 2, 1) != 0).astype(np.uint8)
+    d0, d1, d2 = v.shape
+    flat = v.reshape(-1)
+    assert flat[-1] == 0 and flat[-2] == 0, "the last two cells (file order) must be empty: the reference's reader skips the final run"
+    change = np.flatnonzero(np.diff(flat)) + 1
+    starts = np.concatenate(([0], change))
+    lengths = np.diff(np.concatenate((starts, [flat.size])))
+    runs = [(int(flat[st]), int(ln)) for st, ln in zip(starts, lengths)]
+    # the reference's reader writes each run over count+1 cells and never applies the pair that ends the file: end with
+    # a run of its own holding the last empty cell, so that the spill of the run before it lands on an empty cell too
+    val, ln = runs[-1]
+    runs[-1:] = [(0, ln - 1), (0, 1)]
+    out = bytearray()
+    for val, ln in runs:
+        while ln > 0:
+            c = min(ln, 255)
+            out += bytes((val, c))
+            ln -= c
+    with open(filename, "wb") as f:
+        f.write(("#binvox 1\ndim %d %d %d\ntranslate %g %g %g\nscale %g\ndata\n"
+                 % (d0, d1, d2, translation[0], translation[1], translation[2], scale)).encode("latin-1"))
+        f.write(bytes(out))
+
+
 def calculateBoundingBox(voxels):
     """voxel_utils.lua:20-50: 1-based inclusive first/last non-zero index along each of the 3 dims."""
     assert voxels.ndim == 3 and voxels.sum() > 0

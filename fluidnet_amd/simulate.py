@@ -303,8 +303,11 @@ def _bc_plan(lib, ctx, bc, inv):
     place, destroyed (tfl_bc_plan_destroy) when either is freed or replaced."""
     if bc is None or inv is None:
         return None
+    # plans are context-independent (they hold device pointers and an index list; tfl_bc_plan_destroy ignores ctx):
+    # a second context on the same tensors (SlabSimulation(own_context=True)) shares the plan instead of evicting it
+    # from under a holder of the raw pointer (ADVICE r02)
     hit = _plan_cache.get(bc, inv)
-    if hit is not None and hit[1] == ctx:
+    if hit is not None:
         return hit[2]
     plan = lib.tfl_bc_plan_create(ctx, tfluids._tt5(bc), tfluids._tt5(inv))
     if not plan:

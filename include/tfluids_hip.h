@@ -445,7 +445,7 @@ int64_t tfl_simulate_slab_workspace_floats(tfl_ctx* ctx, const tfl_sim_params* p
  * out of a global initial state); `workspace` must be the SAME buffer on every call (halo messages of p and U started
  * at the end of one step are consumed by the next).
  * Per step: three neighbour exchanges + one 2*B-double all-reduce --
- *   U(max(R+1, 2R) planes) | p(4 below, 3 above)   started at the end of the previous step, consumed at the start / before conv 1
+ *   U(max(R+1, 2R) planes) + p(4 below, 3 above)   ONE message started at the end of the previous step, consumed at the start
  *   advected U(3 below, 4 above) + density(max(4, 2R+1)) after MacCormack pass B, overlapped with its interior
  *   divergence(4 below, 3 above)          overlapped with the interior of the first conv layer
  * and every phase runs under the narrowest z-window that keeps the owned planes exact, so the redundant compute is a

@@ -46,4 +46,14 @@ for rank in (0, world // 2):
         t_all = (time.time() - t0) / n
     print("res %d, rank %d of %d (%d planes): enqueue %.3f ms per step, with GPU drain %.3f ms per step"
           % (res, rank, world, lay.hi - lay.lo, t_host * 1e3, t_all * 1e3))
+    if rank == world // 2 and "--kernels" in sys.argv:
+        from fluidnet_amd import tfluids
+        with tfluids.profile(batch["UDiv"]) as prof:
+            for _ in range(10):
+                sim.step()
+        tot, cnt = 0.0, 0
+        for name, rec in sorted(prof.kernels.items(), key=lambda kv: -kv[1]["ms"]):
+            print("   %-26s %5.1f launches/step  %7.1f us/step  (%.1f us each)" % (name, rec["calls"] / 10, rec["ms"] * 100, rec["ms"] / rec["calls"] * 1e3))
+            tot += rec["ms"] * 100; cnt += rec["calls"] / 10
+        print("   sum %.1f us/step over %.0f launches" % (tot, cnt))
     sim.close()
