@@ -9,7 +9,7 @@
 // A numerator of -0 gives +0 instead of -0 (the refinement adds (+0) + (-0)); the quotient only ever enters
 // `pos + q * length`, which absorbs the sign. Those cases are counted separately.
 // The run covers much wider ranges: sqrt exhaustively over every float in [2^-40, 2^40]; division over 2^33
-// hashed pairs with b in [2^-12, 2^12] plus, for every one of the 2^23 mantissas of b in [0.5, 1), 256 numerators.
+// hashed pairs with b in [2^-12, 2^21] plus, for every one of the 2^23 mantissas of b in [0.5, 1), 256 numerators.
 // build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off exact_math.hip -o exact_math
 #include <hip/hip_runtime.h>
 #include <cstdint>
@@ -45,8 +45,8 @@ __global__ void k_div(int mode, uint64_t total, uint32_t seed, Counts* c) {
                    h3 = hash32(h2 ^ 0xdeadbeefU);
     float a, b;
     if (mode == 0) {
-      // b: random mantissa, exponent 2^-12 .. 2^12
-      const int eb = 127 - 12 + (int)(h2 % 25);
+      // b: random mantissa, exponent 2^-12 .. 2^21
+      const int eb = 127 - 12 + (int)(h2 % 34);   // 2^-12 .. 2^21 (the vorticity kernels normalise gradients up to 2^20)
       b = __builtin_bit_cast(float, ((uint32_t)eb << 23) | (h1 & 0x7fffffu));
     } else {
       const int eb = 126 - (int)((t >> 23) % 10);
