@@ -18,17 +18,20 @@
 //     outside the pattern): d(n) = a(n,n) - sum over lower fluid neighbours m of 1/d(m), in lexicographic order.
 //     ilu0: L = unit lower with l(n,m) = -1/d(m), U = upper part of A with d on the diagonal.
 //     ic0:  R upper with R(n,n) = sqrt(d(n)), R(n,q) = -1/R(n,n); M = R^T R.
-//     Cells of one hyperplane i+j+k = const are independent, so factorisation and the two triangular solves are
-//     wavefront sweeps, one launch per hyperplane (what cusparse's csrsv level analysis discovers at run time).
-//     On this hardware the unpreconditioned solve is the fast one (a sweep is ~X+Y+Z tiny launches); the
-//     preconditioned forms exist for API parity.
+//     Cells of one hyperplane i+j+k = const are independent (what cusparse's csrsv level analysis discovers at run
+//     time). The factorisation (once per solve) runs one launch per hyperplane; the two triangular solves of every CG
+//     iteration run as PIPELINED WAVEFRONTS on 3-D grids -- two launches instead of ~760 at 128^3 (k_wf_sweep below:
+//     354 -> 77 ms per solve; the unpreconditioned solve takes 27 ms in 3x the iterations). 2-D grids and grids with
+//     more than 240 sub-boxes keep the launch-per-hyperplane sweeps.
 // Dot products are two-stage fp64 reductions with a fixed order (bit-reproducible run to run).
 #include "tfl_device.hpp"
 #include "tfl_host.hpp"
+#include "tfl_vec4.hpp"
 
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <limits>
 #include <vector>
 
@@ -346,6 +349,217 @@ __global__ __launch_bounds__(256) void k_ilu_backward(const PcgState* __restrict
   else z[c.o] = (y[c.o] + acc) / dg[c.o];
 }
 
+// ---- the triangular solves as TWO launches: pipelined wavefronts (3-D) ------------------------------------------
+// A lexicographic IC(0) / ILU(0) solve is a 3-D recurrence: cell (i, j, k) needs (i-1, j, k), (i, j-1, k), (i, j, k-1).
+// One launch per hyperplane (above) is X+Y+Z-6 launches per solve, ~760 per CG iteration at 128^3: 2.7 ms of launch
+// latency around ~20 us of arithmetic. Here a sweep is ONE launch:
+//   * the interior is cut into sub-boxes of 64 rows (j) x 16 planes (k) x all of x; a 1024-thread block owns one:
+//     wave w <-> plane, lane l <-> row, and at iteration T the thread works on i = 1 + T - l - w -- the hyperplane
+//     T = (i-1) + l + w of its sub-box. Its three predecessors were computed ONE iteration earlier by itself (x), by the
+//     lane below (y: one DPP wave shift) and by the wave below (z: a 64-float LDS slot, double buffered): one
+//     __syncthreads per iteration, X + 78 iterations per sub-box;
+//   * sub-boxes depend on their lower j / k neighbours through global memory. They all run concurrently, each staying
+//     64 (rows) resp. 16 (planes) iterations + a margin behind its predecessors: a block publishes its iteration count
+//     every 8 iterations behind a release fence and polls its predecessors' (bounded spin, acquire fence) before each
+//     chunk of 8. The critical path is ~X + 64 (ns-1) + 24 (nb-1) + 78 iterations instead of X+Y+Z launches;
+//   * everything a sweep reads per cell sits in a SKEWED copy laid out [sub-box][plane][T][row], so that a wave's access
+//     at iteration T is one coalesced 256-B row: the diagonal scaling c (1/sqrt(d) for IC, 1/d for ILU; 0 outside the
+//     component, which also zeroes such cells' results), r, the forward result y and z. Two chip-wide kernels per
+//     solve copy r into, and z out of, that layout (k_wf_skew).
+// With q = y * c handed on instead of y:   IC: y = (((r + q_z) + q_y) + q_x) * c      ILU: y = ((r + q_z) + q_y) + q_x
+// backward, t = sum of the upper neighbours' z:   IC: z = (y + t * c) * c              ILU: z = (y + t) * c
+// (the reference divides by R(m,m) / d(m) where this multiplies by the reciprocal: inside the solver's tolerance).
+#ifndef TFL_WF_PLANES
+#define TFL_WF_PLANES 16
+#endif
+#ifndef TFL_WF_CHUNK
+#define TFL_WF_CHUNK 8
+#endif
+constexpr int kWfRows = 64, kWfPlanes = TFL_WF_PLANES, kWfChunk = TFL_WF_CHUNK, kWfMaxBlocks = 240;
+
+struct WfGeom {
+  int X, Y, Z, ns, nb, NT;     // strips, slabs, iterations per sub-box
+  long long sub;               // floats of one sub-box in the skewed arrays = kWfPlanes * NT * kWfRows
+};
+inline WfGeom wf_geom(int Z, int Y, int X) {
+  WfGeom g;
+  g.X = X; g.Y = Y; g.Z = Z;
+  g.ns = (Y - 2 + kWfRows - 1) / kWfRows; g.nb = (Z - 2 + kWfPlanes - 1) / kWfPlanes;
+  g.NT = (((X - 2) + (kWfRows - 1) + (kWfPlanes - 1)) + kWfChunk - 1) / kWfChunk * kWfChunk;
+  g.sub = (long long)kWfPlanes * g.NT * kWfRows;
+  return g;
+}
+inline bool wf_usable(bool is3d, int Z, int Y, int X) {
+  if (!is3d || X < 3 || Y < 3 || Z < 3) return false;
+  static const bool off = getenv("TFL_PCG_HYPERPLANES") != nullptr;     // A/B switch: the one-launch-per-hyperplane sweeps
+  const WfGeom g = wf_geom(Z, Y, X);
+  return !off && g.ns * g.nb <= kWfMaxBlocks;      // every block must be resident at once (they wait for each other)
+}
+inline long long wf_floats(int Z, int Y, int X) {
+  const WfGeom g = wf_geom(Z, Y, X);
+  return 4 * g.sub * g.ns * g.nb + 2 * kWfMaxBlocks + 64;      // c, r, y, z in the skewed layout
+}
+
+// c (skewed) from the factor's diagonal: one thread per interior cell
+template <bool IC>
+__global__ __launch_bounds__(256) void k_wf_build(WfGeom g, Dom d, const int* __restrict__ label, int root, const float* __restrict__ dg,
+                                                  float* __restrict__ cs) {
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int nx = g.X - 2, ny = g.Y - 2, nz = g.Z - 2;
+  if (t >= (long long)nx * ny * nz) return;
+  const int i = 1 + (int)(t % nx), j = 1 + (int)((t / nx) % ny), k = 1 + (int)(t / ((long long)nx * ny));
+  const int o = TFL_AT(d, i, j, k);
+  float c = 0.0f;
+  if (label[o] == root) c = IC ? 1.0f / sqrtf(dg[o]) : 1.0f / dg[o];
+  const int s = (j - 1) / kWfRows, l = (j - 1) % kWfRows, b = (k - 1) / kWfPlanes, w = (k - 1) % kWfPlanes;
+  cs[((long long)(s * g.nb + b) * kWfPlanes + w) * g.NT * kWfRows + (long long)((i - 1) + l + w) * kWfRows + l] = c;
+}
+
+// natural layout <-> skewed layout of a vector on the interior cells (chip-wide, one thread per cell: the sweeps
+// themselves must not gather / scatter -- a wave's 64 rows are 64 cache lines per instruction, measured 4.5 us per 8
+// iterations when the forward sweep read r and the backward sweep wrote z in the natural layout)
+template <bool TO_SKEWED>
+__global__ __launch_bounds__(256) void k_wf_skew(const PcgState* __restrict__ S, WfGeom g, Dom d, float* __restrict__ nat, float* __restrict__ skw) {
+  if (S->done) return;
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int nx = g.X - 2, ny = g.Y - 2, nz = g.Z - 2;
+  if (t >= (long long)nx * ny * nz) return;
+  const int i = 1 + (int)(t % nx), j = 1 + (int)((t / nx) % ny), k = 1 + (int)(t / ((long long)nx * ny));
+  const int o = TFL_AT(d, i, j, k);
+  const int s = (j - 1) / kWfRows, l = (j - 1) % kWfRows, b = (k - 1) / kWfPlanes, w = (k - 1) % kWfPlanes;
+  const long long a = ((long long)(s * g.nb + b) * kWfPlanes + w) * g.NT * kWfRows + (long long)((i - 1) + l + w) * kWfRows + l;
+  if (TO_SKEWED) skw[a] = nat[o];
+  else nat[o] = skw[a];
+}
+
+__device__ __forceinline__ int wf_poll(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// DIR = +1 forward (lower neighbours), -1 backward (upper neighbours, iterations run from the last to the first)
+template <bool IC, int DIR>
+__global__ __launch_bounds__(kWfPlanes * 64) void k_wf_sweep(const PcgState* __restrict__ S, WfGeom g, Dom d, const float* __restrict__ cs,
+                                                   const float* __restrict__ rin, float* __restrict__ ys, float* __restrict__ zout,
+                                                   int* __restrict__ prog, int base, int* __restrict__ err) {
+  if (S->done) return;
+  __shared__ float qz[2][kWfPlanes][kWfRows];
+  __shared__ int s_ok;
+  const int blk = blockIdx.x, sidx = blk / g.nb, bidx = blk - sidx * g.nb;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int NT = g.NT;
+  const long long mine = ((long long)blk * kWfPlanes + w) * NT * kWfRows + lane;
+  // predecessor sub-boxes in j and k (forward: the lower ones) and the cell of theirs this thread's edge cell needs:
+  // the strip predecessor's lane 63 (forward) / 0 (backward) of the same plane, the slab predecessor's plane 15 / 0
+  const int ps = DIR > 0 ? (sidx > 0 ? blk - g.nb : -1) : (sidx + 1 < g.ns ? blk + g.nb : -1);
+  const int pk = DIR > 0 ? (bidx > 0 ? blk - 1 : -1) : (bidx + 1 < g.nb ? blk + 1 : -1);
+  const int elane = DIR > 0 ? kWfRows - 1 : 0, ewave = DIR > 0 ? kWfPlanes - 1 : 0;
+  const long long from_s = ps >= 0 ? ((long long)ps * kWfPlanes + w) * NT * kWfRows + elane : 0;
+  const long long from_k = pk >= 0 ? ((long long)pk * kWfPlanes + ewave) * NT * kWfRows + lane : 0;
+  const bool edge_l = DIR > 0 ? lane == 0 : lane == kWfRows - 1;
+  const bool edge_w = DIR > 0 ? w == 0 : w == kWfPlanes - 1;
+  // the neighbour (i, j-+1, k) of an edge lane sits at the predecessor's iteration T +- (kWfRows - 1), the neighbour
+  // (i, j, k-+1) of an edge wave at T +- (kWfPlanes - 1)
+  float q_prev = 0.0f;      // forward: q = y * c of this thread's previous cell; backward: its z
+  qz[0][w][lane] = 0.0f; qz[1][w][lane] = 0.0f;
+  int seen_s = 0, seen_k = 0;     // thread 0: the predecessors' progress as last read
+
+  struct Operands { float cv[kWfChunk], rv[kWfChunk], es[kWfChunk], ek[kWfChunk]; };
+  // make sure the predecessors are far enough ahead for the chunk starting at iteration c0 (thread 0 polls only when its
+  // cached reading does not already say so), then issue every load of that chunk
+  auto wait_for = [&](int c0) -> bool {
+    if (threadIdx.x == 0) {
+      const int last = c0 + kWfChunk - 1;
+      const int need_s = base + min(last + kWfRows, NT), need_k = base + min(last + kWfPlanes, NT);
+      bool ok = true, polled = false;
+      if (ps >= 0 && seen_s < need_s) {
+        polled = true;
+        for (long long spin = 0; (seen_s = wf_poll(prog + ps)) < need_s; spin++) {
+          if (spin > (1ll << 24) || wf_poll(err)) { ok = false; atomicExch(err, 1); break; }   // never hang the GPU
+          __builtin_amdgcn_s_sleep(1);
+        }
+      }
+      if (ok && pk >= 0 && seen_k < need_k) {
+        polled = true;
+        for (long long spin = 0; (seen_k = wf_poll(prog + pk)) < need_k; spin++) {
+          if (spin > (1ll << 24) || wf_poll(err)) { ok = false; atomicExch(err, 1); break; }
+          __builtin_amdgcn_s_sleep(1);
+        }
+      }
+      if (polled) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      s_ok = ok ? 1 : 0;
+    }
+    __syncthreads();
+    return s_ok != 0;
+  };
+  auto load = [&](int c0, Operands& op) {
+#pragma unroll
+    for (int u = 0; u < kWfChunk; u++) {
+      const int it = c0 + u, T = DIR > 0 ? it : NT - 1 - it;
+      op.cv[u] = cs[mine + (long long)T * kWfRows];
+      // forward: r of the cell; backward: the forward result y (both skewed: one coalesced row per wave)
+      op.rv[u] = DIR > 0 ? rin[mine + (long long)T * kWfRows] : ys[mine + (long long)T * kWfRows];
+      op.es[u] = 0.0f; op.ek[u] = 0.0f;
+      // forward: (i, j-1, k) of lane 0 = the strip predecessor's lane 63 at its iteration T + 63, (i, j, k-1) of wave 0 = the
+      // slab predecessor's wave 15 at its iteration T + 15: q = y * c. Backward: mirrored (lane 0 / wave 0 of the upper
+      // predecessors at T - 63 / T - 15): z. All out of the predecessors' skewed arrays.
+      const int Ts = T + DIR * (kWfRows - 1), Tk = T + DIR * (kWfPlanes - 1);
+      if (edge_l && ps >= 0 && Ts >= 0 && Ts < NT) {
+        const long long a = from_s + (long long)Ts * kWfRows;
+        op.es[u] = DIR > 0 ? __builtin_nontemporal_load(ys + a) * cs[a] : __builtin_nontemporal_load(zout + a);
+      }
+      if (edge_w && pk >= 0 && Tk >= 0 && Tk < NT) {
+        const long long a = from_k + (long long)Tk * kWfRows;
+        op.ek[u] = DIR > 0 ? __builtin_nontemporal_load(ys + a) * cs[a] : __builtin_nontemporal_load(zout + a);
+      }
+    }
+  };
+  auto compute = [&](int c0, const Operands& op) {
+#pragma unroll
+    for (int u = 0; u < kWfChunk; u++) {
+      const int it = c0 + u, T = DIR > 0 ? it : NT - 1 - it;
+      // the wave shift must run with EVERY lane enabled (a disabled source lane reads as 0): keep it out of the select
+      float shifted = DIR > 0 ? from_lane_below(q_prev) : from_lane_above(q_prev);
+      asm volatile("" : "+v"(shifted));
+      const float nb_y = edge_l ? op.es[u] : shifted;
+      float below = qz[(it + 1) & 1][DIR > 0 ? max(w - 1, 0) : min(w + 1, kWfPlanes - 1)][lane];   // every lane reads (no exec juggling)
+      asm volatile("" : "+v"(below));
+      const float nb_z = edge_w ? op.ek[u] : below;
+      float out, hand;
+      if (DIR > 0) {
+        const float v = ((op.rv[u] + nb_z) + nb_y) + q_prev;
+        out = IC ? v * op.cv[u] : v;        // y
+        hand = out * op.cv[u];              // q = y * c
+        ys[mine + (long long)T * kWfRows] = out;
+      } else {
+        const float t = (q_prev + nb_y) + nb_z;
+        out = IC ? (op.rv[u] + t * op.cv[u]) * op.cv[u] : (op.rv[u] + t) * op.cv[u];     // z
+        hand = out;
+        zout[mine + (long long)T * kWfRows] = out;
+      }
+      q_prev = hand;
+      qz[it & 1][w][lane] = hand;
+      // workgroup barrier that waits for the LDS write only: __syncthreads() also drains vmcnt, i.e. every iteration would
+      // wait for the next chunk's operand loads and for its own y / z store (measured: 1.2 k clocks per iteration)
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    if (threadIdx.x == 0) {    // publish
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_store(prog + blk, base + c0 + kWfChunk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  };
+  // two chunks in flight: the operands of chunk n+1 are loaded while chunk n runs its eight barrier-separated iterations
+  Operands A, B;
+  if (!wait_for(0)) return;
+  load(0, A);
+  for (int c0 = 0; c0 < NT; c0 += 2 * kWfChunk) {
+    const bool more1 = c0 + kWfChunk < NT, more2 = c0 + 2 * kWfChunk < NT;
+    if (more1) { if (!wait_for(c0 + kWfChunk)) return; load(c0 + kWfChunk, B); }
+    compute(c0, A);
+    if (!more1) break;
+    if (more2) { if (!wait_for(c0 + 2 * kWfChunk)) return; load(c0 + 2 * kWfChunk, A); }
+    compute(c0 + kWfChunk, B);
+  }
+}
+
 // ---- normalizePressureMean (generic/tfluids.cc:845-925): p -= mean of p over the cell's fluid component ----
 __global__ __launch_bounds__(256) void k_npm_sum(Dom d, const int* __restrict__ label, const float* __restrict__ p,
                                                  double* __restrict__ sum_at) {
@@ -381,7 +595,7 @@ inline int cdiv(long long a, int b) { return (int)((a + b - 1) / b); }
 long long pcg_workspace_floats(int Z, int Y, int X) {
   const long long n = (long long)Z * Y * X;
   // label, size_at (int32) + x, r, z, s, w, dg, y (fp32) + roots + partials/state (fp64, kept 8-byte aligned first)
-  return 2 * (kRedBlocks + 64) + 9 * n + kMaxComponents + 64;
+  return 2 * (kRedBlocks + 64) + 9 * n + kMaxComponents + 64 + (wf_usable(Z > 1, Z, Y, X) ? wf_floats(Z, Y, X) : 0);
 }
 
 // Solves every component of every batch element. Returns 0, or a negative code with `msg` filled:
@@ -400,6 +614,19 @@ int pcg_solve(hipStream_t st, bool is3d, int B, int Z, int Y, int X, float* p, c
   float* w = base + 6 * n; float* dg = base + 7 * n; float* y = base + 8 * n;
   int* roots = reinterpret_cast<int*>(base + 9 * n);
   int* counters = roots + kMaxComponents;   // [0] changed, [1] count, [2] border fluid
+  // pipelined wavefront sweeps (3-D): skewed c and y, the blocks' progress words, an error word
+  const bool wf = wf_usable(is3d, Z, Y, X);
+  const WfGeom wg = wf_geom(Z > 2 ? Z : 3, Y > 2 ? Y : 3, X > 2 ? X : 3);
+  float* wfbase = base + 9 * n + kMaxComponents + 64;
+  float* cs = wfbase;
+  const long long wtot = wg.sub * wg.ns * wg.nb;
+  float* rsk = wf ? cs + wtot : nullptr;
+  float* ysk = wf ? cs + 2 * wtot : nullptr;
+  float* zsk = wf ? cs + 3 * wtot : nullptr;
+  int* prog = wf ? reinterpret_cast<int*>(cs + 4 * wtot) : nullptr;
+  int* wferr = wf ? prog + kWfMaxBlocks : nullptr;
+  int epoch = 0;
+  const int wf_stride = wg.NT + kWfChunk;       // progress values of launch e live in (e * stride, e * stride + NT]
   auto hip_ok = [&](hipError_t e, const char* what) {
     if (e == hipSuccess) return true;
     snprintf(msg, msg_len, "solveLinearSystemPCG: %s: %s", what, hipGetErrorString(e));
@@ -473,14 +700,37 @@ int pcg_solve(hipStream_t st, bool is3d, int B, int Z, int Y, int X, float* p, c
           if (is3d) k_ilu_factor<true><<<gwave, 256, 0, st>>>(d, h, fl, label, root, dg);
           else k_ilu_factor<false><<<gwave, 256, 0, st>>>(d, h, fl, label, root, dg);
         }
+        if (wf) {
+          const long long tot = wg.sub * wg.ns * wg.nb;
+          if (!hip_ok(hipMemsetAsync(cs, 0, sizeof(float) * (size_t)tot * 4, st), "memset skewed arrays")) return -4;
+          if (!hip_ok(hipMemsetAsync(prog, 0, sizeof(int) * (kWfMaxBlocks + 16), st), "memset progress")) return -4;
+          epoch = 0;
+          const int gb = cdiv((long long)(X - 2) * (Y - 2) * (Z - 2), 256);
+          if (pc == 2) k_wf_build<true><<<gb, 256, 0, st>>>(wg, d, label, root, dg, cs);
+          else k_wf_build<false><<<gb, 256, 0, st>>>(wg, d, label, root, dg, cs);
+        }
       }
       PcgState hs;
-      const int chunk = verbose ? 1 : (pc ? 4 : 32);
+      const int chunk = verbose ? 1 : (pc ? (wf ? 16 : 4) : 32);
       for (;;) {
         for (int it = 0; it < chunk; it++) {
           k_pcg_loop_top<<<1, 1, 0, st>>>(S);
           const float* dir_src = r;
-          if (pc) {
+          if (pc && wf) {
+            // M^-1 r as two launches (pipelined wavefronts)
+            const int nblk = wg.ns * wg.nb;
+            const int gb = cdiv((long long)(X - 2) * (Y - 2) * (Z - 2), 256);
+            { TFL_TIMED("k_pcg_precond", st);
+              k_wf_skew<true><<<gb, 256, 0, st>>>(S, wg, d, r, rsk);
+              epoch++;
+              if (pc == 2) k_wf_sweep<true, 1><<<nblk, kWfPlanes * 64, 0, st>>>(S, wg, d, cs, rsk, ysk, nullptr, prog, epoch * wf_stride, wferr);
+              else k_wf_sweep<false, 1><<<nblk, kWfPlanes * 64, 0, st>>>(S, wg, d, cs, rsk, ysk, nullptr, prog, epoch * wf_stride, wferr);
+              epoch++;
+              if (pc == 2) k_wf_sweep<true, -1><<<nblk, kWfPlanes * 64, 0, st>>>(S, wg, d, cs, nullptr, ysk, zsk, prog, epoch * wf_stride, wferr);
+              else k_wf_sweep<false, -1><<<nblk, kWfPlanes * 64, 0, st>>>(S, wg, d, cs, nullptr, ysk, zsk, prog, epoch * wf_stride, wferr);
+              k_wf_skew<false><<<gb, 256, 0, st>>>(S, wg, d, z, zsk); }
+            dir_src = z;
+          } else if (pc) {
             TFL_TIMED("k_pcg_precond", st);
             for (int h = hmin; h <= hmax; h++) {
               if (is3d) { if (pc == 2) k_ilu_forward<true, true><<<gwave, 256, 0, st>>>(S, d, h, fl, label, root, dg, r, y);
@@ -510,6 +760,11 @@ int pcg_solve(hipStream_t st, bool is3d, int B, int Z, int Y, int X, float* p, c
         if (!hip_ok(hipStreamSynchronize(st), "sync")) return -4;
         if (verbose && !hs.done)
           printf("PCG batch %d comp %d iter %d: residual %g (tol %g)\n", b + 1, cidx + 1, hs.iter, std::sqrt(hs.rr1), (double)tol);
+        if (wf && pc) {
+          int e = 0;
+          if (!hip_ok(hipMemcpy(&e, wferr, sizeof(int), hipMemcpyDeviceToHost), "memcpy")) return -4;
+          if (e) { snprintf(msg, msg_len, "solveLinearSystemPCG: a block of the pipelined triangular solve never saw its predecessor (set TFL_PCG_HYPERPLANES=1)"); return -4; }
+        }
         if (hs.bad) { snprintf(msg, msg_len, "solveLinearSystemPCG: ERROR: r_norm_sq1 is nan!"); return -2; }
         // the loop ends when the NEXT top-of-loop test fails
         if (hs.done || !((float)hs.rr1 > tol * tol) || hs.iter > max_iter) break;

@@ -211,11 +211,11 @@ int tfl_simulate_step(tfl_ctx* c, const tfl_sim_params* prm, const tfl_sim_state
   } else if (sm == "pcg") {
     float* pws = ws + ((z.N + 1) & ~1ll);    // 8-byte aligned
     float res = 0.0f;
-    // simulate.lua:283 hard-codes 'ic0'. IC(0)/ILU(0) in the reference's lexicographic order are X+Y+Z-6 dependent
-    // wavefronts per triangular solve -- ~760 tiny launches per CG iteration at 128^3 (profiles/r02_pcg.txt: 10x slower
-    // than no preconditioner on this machine) -- so the STEP defaults to the unpreconditioned solve; it converges to the
-    // same pressure within `tol`. pcgPrecond = "ic0" / "ilu0" selects the reference's preconditioners explicitly.
-    rc = tfl_solveLinearSystemPCG(c, s->p, s->flags, &div, is3D, prm->pcgPrecond && prm->pcgPrecond[0] ? prm->pcgPrecond : "none",
+    // simulate.lua:283 hard-codes 'ic0', and so does this step unless pcgPrecond says otherwise. The lexicographic
+    // IC(0) / ILU(0) solves run as pipelined wavefronts (pcg.hip, two launches per application); at 128^3 the
+    // preconditioned solve takes ~2.8x the time of the unpreconditioned one on this machine (fewer iterations, each
+    // with two latency-bound sweeps): pcgPrecond = "none" buys that back at the price of more iterations within maxIter.
+    rc = tfl_solveLinearSystemPCG(c, s->p, s->flags, &div, is3D, prm->pcgPrecond && prm->pcgPrecond[0] ? prm->pcgPrecond : "ic0",
                                   1e-4f, max_iter, 0, pws, ws_floats - (pws - ws), &res);
   } else {
     return TFL_EINVAL;   // mconf.simMethod is not a valid option

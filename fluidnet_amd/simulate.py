@@ -270,16 +270,16 @@ def simulate(conf, mconf, batch, model, outputDiv=False):
         tfluids.solveLinearSystemJacobi(p, flags, div, is3D, 0, mconf.get("maxIter") or 100, residual=False)
         tfluids.velocityUpdateForward(U, flags, p)
     elif simMethod == "pcg":
-        # simulate.lua:281-286: tol 1e-4, maxIter (default 100), 'ic0'. Here the step defaults to the unpreconditioned
-        # solve (same pressure within tol; ~10x faster on this hardware than the wavefront ic0/ilu0 sweeps, DESIGN.md
-        # section 8); mconf.pcgPrecond = 'ic0' | 'ilu0' selects the reference's preconditioners.
+        # simulate.lua:281-286: tol 1e-4, maxIter (default 100), 'ic0' -- the default here too (pipelined wavefront
+        # sweeps, pcg.hip); mconf.pcgPrecond = 'none' | 'ilu0' | 'ic0' overrides ('none' is ~2.8x faster per solve at
+        # 128^3 on this machine but needs ~3x the iterations, which matters under a small maxIter).
         div = batch.get("div")
         if div is None or div.shape != p.shape:
             div = torch.empty_like(p)
             batch["div"] = div
         tfluids.velocityDivergenceForward(U, flags, div)
         tfluids.solveLinearSystemPCG(p, flags, div, U.size(1) == 3, 1e-4, mconf.get("maxIter") or 100,
-                                     mconf.get("pcgPrecond") or "none")
+                                     mconf.get("pcgPrecond") or "ic0")
         tfluids.velocityUpdateForward(U, flags, p)
     else:
         raise TfluidsError("mconf.simMethod (%s) is not a valid option" % simMethod)

@@ -312,7 +312,9 @@ def test_vec4_kernels_and_their_fallbacks_match_the_oracle(no_vec4):
 # ---- solveLinearSystemPCG ---------------------------------------------------------------------
 @pytest.mark.parametrize("dims,seed,split,B,tol", [((1, 24, 28), 3, False, 1, 1e-5), ((9, 11, 13), 4, False, 2, 1e-5),
                                                   ((1, 30, 34), 5, True, 1, 1e-5), ((8, 10, 16), 6, True, 1, 1e-5),
-                                                  ((24, 20, 36), 8, False, 1, 1e-4), ((1, 96, 128), 9, True, 1, 1e-4)])
+                                                  ((24, 20, 36), 8, False, 1, 1e-4), ((1, 96, 128), 9, True, 1, 1e-4),
+                                                  # 3 strips x 3 slabs of the pipelined wavefront sweeps (64 rows x 16 planes each)
+                                                  ((36, 134, 22), 10, True, 1, 1e-4)])
 def test_hip_pcg_matches_the_oracle_and_the_reference_properties(hip, oracle, dims, seed, split, B, tol):
     """The matrix-free device PCG (pcg.hip) against the CSR restatement of the reference's cuSPARSE/cuBLAS solver:
     same converged pressure for all three preconditioners, plus what test_tfluids.lua:836-906 asserts (residual
@@ -327,7 +329,7 @@ def test_hip_pcg_matches_the_oracle_and_the_reference_properties(hip, oracle, di
         rb = oracle.solveLinearSystemPCG(pb, f, div, sc["is3d"], tol, 1000, pc)
         assert ra < 2 * tol and rb < 2 * tol and np.isfinite(pa).all(), (pc, ra, rb)
         scale = max(np.abs(pb).max(), 1e-6)
-        assert np.abs(pa - pb).max() < max(2e-4 * scale, 50 * tol), (pc, np.abs(pa - pb).max(), scale)
+        assert np.abs(pa - pb).max() < max(5e-5 * scale, 50 * tol), (pc, np.abs(pa - pb).max(), scale)
         assert np.all(pa[f != 1.0] == 0.0)
         Un = U.copy()
         hip.velocityUpdateForward(Un, f, pa)

@@ -33,4 +33,8 @@ for pc, tol in (("none", 1e-3), ("none", 1e-4), ("ic0", 1e-3), ("ilu0", 1e-3)):
     tfluids.velocityUpdateForward(Un, flags, p)
     d2 = torch.empty_like(div)
     tfluids.velocityDivergenceForward(Un, flags, d2)
+    with tfluids.profile(p) as prof:
+        tfluids.solveLinearSystemPCG(p, flags, div, True, tol, 3000, pc)
+    kk = "  ".join("%s %d x %.1f us" % (k, v["calls"], v["ms"] / v["calls"] * 1e3) for k, v in sorted(prof.kernels.items()))
+    print(f"   kernels: {kk}")
     print(f"{res}^3 precond {pc:5s} tol {tol:g}: {dt * 1e3:8.1f} ms  residual {r:.3e} (|rhs| {rhs:.2f})  max|div| {float(div.abs().max()):.3f} -> {float(d2.abs().max()):.2e}")
