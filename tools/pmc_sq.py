@@ -13,7 +13,7 @@ acc = collections.defaultdict(lambda: collections.defaultdict(float))
 cnt = collections.defaultdict(lambda: collections.defaultdict(int))
 order = []
 for r in csv.DictReader(open(src)):
-    m = re.search(r"tfl::(k_\w+(<[^>]*>)?)", r["Kernel_Name"])
+    m = re.search(r"::(k_\w+(<[^>]*>)?)", r["Kernel_Name"])
     if not m:
         continue
     k = m.group(1)

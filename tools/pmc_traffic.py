@@ -17,10 +17,11 @@ ALG = {"k_conv3_mfma": 64, "k_conv3_mfma_tail": 36, "k_conv3_mfma_in": 44, "k_co
 
 
 def short(name):
-    m = re.search(r"tfl::(k_\w+)(<[^>]*>)?", name)
+    m = re.search(r"::(k_\w+)(<[^>]*>)?", name)     # tfl::k_x<...> or tfl::(anonymous namespace)::k_x
     if not m:
         return None
     k, targs = m.group(1), m.group(2) or ""
+    k = {"k_vel3_fwd": "k_vel_fwd", "k_vel3_bwd": "k_vel_bwd"}.get(k, k)     # profiler names of advect_vel3.hip's launches
     if k == "k_conv3_mfma":
         a = [t.strip() for t in targs.strip("<>").split(",")]
         return "k_conv3_mfma_in" if a[1] == "true" else ("k_conv3_mfma_tail" if a[2] == "true" else "k_conv3_mfma")
