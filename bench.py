@@ -147,16 +147,31 @@ def make_stepper(res, world, rank, dev, model, scene):
         from fluidnet_amd.dist import DistComm, RcclComm, SlabLayout, SlabSimulation
         layout = SlabLayout(res, world, rank)
         batch, mconf = scene(res, layout, dev)
-        if dist.get_backend() == "nccl":
-            # the library's own transport: rank 0's RCCL unique id travels over the process group, the halo traffic does not
+        comm = None
+        if dist.get_backend() == "nccl" and not os.environ.get("TFL_BENCH_TORCH_TRANSPORT"):
+            # the library's own transport: rank 0's RCCL unique id travels over the process group, the halo traffic does not.
+            # Every rank must end up on the same transport: a failure anywhere sends all of them to torch.distributed.
             lib, ctx = tfluids._context(batch["UDiv"])
-            box = [RcclComm.unique_id(ctx) if rank == 0 else None]
-            dist.broadcast_object_list(box, src=0)
-            comm = RcclComm(ctx, box[0], rank, world)
-            TRANSPORT["name"] = "native RCCL send/recv (csrc/comm_rccl.cpp, %s)" % lib.tfl_rccl_comm_origin(ctx).decode()
-        else:
+            ok = 1
+            try:
+                box = [RcclComm.unique_id(ctx) if rank == 0 else None]
+                dist.broadcast_object_list(box, src=0)
+                comm = RcclComm(ctx, box[0], rank, world)
+            except Exception as e:      # noqa: BLE001
+                sys.stderr.write("rank %d: native RCCL transport unavailable (%s)\n" % (rank, e))
+                ok = 0
+            flag = torch.tensor([ok], device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 1:
+                TRANSPORT["name"] = "native RCCL send/recv (csrc/comm_rccl.cpp, %s)" % lib.tfl_rccl_comm_origin(ctx).decode()
+            else:
+                if comm is not None:
+                    comm.close()
+                comm = None
+        if comm is None:
             comm = DistComm(rank, world)
-            TRANSPORT["name"] = "torch.distributed %s, staged through the host (control-flow check, not a measurement)" % dist.get_backend()
+            TRANSPORT["name"] = ("torch.distributed nccl (RCCL) batch_isend_irecv" if dist.get_backend() == "nccl" else
+                                 "torch.distributed %s, staged through the host (control-flow check, not a measurement)" % dist.get_backend())
         sim = SlabSimulation(batch, mconf, model, layout, comm)
         return batch, mconf, sim.step, sim
     batch, mconf = scene(res, None, dev)
