@@ -276,7 +276,10 @@ int tfl_model_forward(tfl_ctx* ctx, tfl_model* model, const tfl_tensor* pDiv, co
  * wall BCs, computes the divergence and reduces sum(u), sum(u^2) of SetWallBcs(UDiv) over the owned
  * z-planes [zlo, zhi) into stats[2*B] (device doubles; NULL = the model's internal buffer); the caller
  * all-reduces stats across ranks; `finish` runs the rest with `count` = the GLOBAL number of velocity
- * samples per batch item (C*Z*Y*X of the whole grid). tfl_model_forward == begin(0, Z) + finish. */
+ * samples per batch item (C*Z*Y*X of the whole grid). tfl_model_forward == begin(0, Z) + finish.
+ * Models created with non-default tfl_model_opts (another normaliser channel / function, normalisation off) form their
+ * scale from statistics the model computes itself inside `finish`: pass stats = NULL there (a caller-supplied `stats`
+ * is refused with TFL_EUNSUPPORTED rather than silently ignored), and `count` is not used. */
 int tfl_model_begin(tfl_ctx* ctx, tfl_model* model, const tfl_tensor* UDiv, const tfl_tensor* flags,
                     const tfl_tensor* UOut, float* workspace, int64_t workspace_floats, int zlo, int zhi,
                     double* stats);
