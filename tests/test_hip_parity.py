@@ -164,6 +164,27 @@ def test_maccormack_large_displacements_and_ragged_grids(hip, oracle, dims, seed
     assert hip.traceErrors() == 0
 
 
+@pytest.mark.parametrize("dims,seed,vel,B", [((6, 20, 200), 71, 0.3, 1), ((5, 13, 129), 72, 0.9, 2), ((9, 22, 70), 73, 2.5, 1),
+                                             ((3, 9, 66), 74, 0.5, 1)])
+def test_advectvel_fast_path_tiles_and_flag_words(hip, oracle, dims, seed, vel, B):
+    """The LDS-tiled fast-path advectVel kernels (advect_vel3.hip) where their special cases live: grids with interior and
+    edge 64x4 tiles, displacements below / around / above the fast path's 0.99-cell limit, flag words that are fluid but
+    not the plain TypeFluid word (fluid | inflow = 9, fluid | open = 33: the fast path must hand those lanes to the generic
+    code), the thinnest grid the tile takes (Z = 3), B = 2; eulerOurs (single pass) and maccormackOurs: bit-exact."""
+    sc = scenes.make_scene(dims, seed=seed, vel_cells=vel, B=B)
+    f = sc["flags"]
+    rng = np.random.RandomState(seed)
+    fl = np.flatnonzero(f == 1.0)
+    pick = rng.choice(fl, size=max(1, fl.size // 40), replace=False)
+    f.reshape(-1)[pick] = rng.choice([9.0, 33.0], size=pick.size)
+    for m in ("maccormackOurs", "eulerOurs"):
+        a, b = sc["U"].copy(), sc["U"].copy()
+        hip.advectVel(sc["dt"], a, f, m)
+        oracle.advectVel(sc["dt"], b, f, m)
+        assert np.array_equal(a, b), (dims, m, int((a != b).sum()))
+    assert hip.traceErrors() == 0
+
+
 @pytest.mark.parametrize("dims,seed", [((1, 48, 40), 81), ((14, 18, 22), 82)])
 def test_hip_sample_outside_fluid_and_explicit_dst(hip, oracle, dims, seed):
     """Non-default wrapper arguments of init.lua:89-219: sampleOutsideFluid=true (temperature-like fields)

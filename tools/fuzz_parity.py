@@ -24,11 +24,17 @@ for t in range(n):
     Z = int(rng.randint(4, 12)) if is3d else 1
     if X > 100:
         Y, Z = min(Y, 9), (min(Z, 5) if is3d else 1)
+    if is3d and rng.rand() < 0.25:      # grids with interior 64x4 tiles for the LDS-tiled advectVel kernels
+        X, Y, Z = int(rng.choice([66, 70, 129, 200])), int(rng.randint(9, 22)), int(rng.randint(4, 9))
     seed = int(rng.randint(1 << 30))
     kw = dict(B=int(rng.randint(1, 3)), vel_cells=float(rng.choice([0.3, 1.0, 2.5, 4.0])), stick=bool(rng.rand() < 0.3),
               empty_cells=bool(rng.rand() < 0.3) and Y >= 10)
     sc = scenes.make_scene((Z, Y, X), seed=seed, **kw)
     f, dt = sc["flags"], sc["dt"]
+    if rng.rand() < 0.3:                # flag words that are fluid but not the plain TypeFluid word (fluid | inflow, fluid | open)
+        fl = np.flatnonzero(f == 1.0)
+        pick = rng.choice(fl, size=max(1, fl.size // 50), replace=False)
+        f.reshape(-1)[pick] = rng.choice([9.0, 33.0], size=pick.size)
     tag = ((Z, Y, X), seed, kw)
     try:
         for m in ("maccormackOurs", "eulerOurs", "rk2Ours", "rk3Ours", "euler", "maccormack"):
