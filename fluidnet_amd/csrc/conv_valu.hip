@@ -30,6 +30,7 @@
 // instruction in the texture addresser, and the store burst at the end of every block cost 12 us per layer at 128^3.
 // The first layer builds {pDiv/scale, div/scale, occupancy} on the fly while staging.
 #include "tfl_device.hpp"
+#include "tfl_fastmath.hpp"
 #include "tfl_host.hpp"
 
 #include <cstdio>
@@ -106,6 +107,8 @@ __global__ __launch_bounds__(256, TFL_VALU_LB) void k_conv3_wino(Dom d, int tile
     in += (long long)b * cells * CIN;
   }
 
+  const bool scale_in_range = FIRST && in_scale >= 0x1p-12f && in_scale <= 0x1p21f;     // wave-uniform
+  const float inv_scale = scale_in_range ? rcp_refined(in_scale) : 0.0f;
   float acc[kVY][4][8];
 #pragma unroll
   for (int v = 0; v < kVY; v++)
@@ -154,7 +157,11 @@ __global__ __launch_bounds__(256, TFL_VALU_LB) void k_conv3_wino(Dom d, int tile
         if (FIRST) {
           // the net input is built here: ApplyScale(true) = CDivTable (apply_scale.lua:24-30), FlagsToOccupancy
           // (generic/tfluids.cu:355-371)
-          v[0] = ld[tt][0] / in_scale; v[1] = ld[tt][1] / in_scale;
+          // x / scale with ONE refined reciprocal per thread and an exact-remainder step per quotient: bit-equal to `/`
+          // for a scale in [2^-12, 2^21] (tools/ubench/exact_math.hip, free-ratio run) at 3 instead of 11 instructions;
+          // 37 staged values per thread and layer made the two divisions a third of this kernel's vector instructions
+          if (scale_in_range) { v[0] = div_by<1>(ld[tt][0], in_scale, inv_scale); v[1] = div_by<1>(ld[tt][1], in_scale, inv_scale); }
+          else { v[0] = ld[tt][0] / in_scale; v[1] = ld[tt][1] / in_scale; }
           const int f = (int)ld[tt][2];
           v[2] = (f == kFluid) ? 0.0f : ((f == kObstacle) ? 1.0f : -1.0f);
         } else {

@@ -37,7 +37,8 @@ __global__ void k_sqrt(uint32_t lo, uint32_t hi, Counts* c) {
   atomicAdd(&c->n, n); atomicAdd(&c->badsqrt, bad); atomicAdd(&c->badsqrt2, bad2);
 }
 
-// mode 0: hashed pairs; mode 1: every mantissa of b in [0.5, 1) x 256 hashed numerators, b scaled into [2^-10, 1)
+// mode 0: hashed pairs; mode 1: every mantissa of b in [0.5, 1) x 256 hashed numerators, b scaled into [2^-10, 1);
+// mode 2: numerators of any magnitude against the same denominators (the ConvNet input's x / scale)
 __global__ void k_div(int mode, uint64_t total, uint32_t seed, Counts* c) {
   unsigned long long bad1 = 0, bad2 = 0, bad3 = 0, n = 0, zs = 0;
   for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (uint64_t)gridDim.x * blockDim.x) {
@@ -48,9 +49,13 @@ __global__ void k_div(int mode, uint64_t total, uint32_t seed, Counts* c) {
       // b: random mantissa, exponent 2^-12 .. 2^21
       const int eb = 127 - 12 + (int)(h2 % 34);   // 2^-12 .. 2^21 (the vorticity kernels normalise gradients up to 2^20)
       b = __builtin_bit_cast(float, ((uint32_t)eb << 23) | (h1 & 0x7fffffu));
-    } else {
+    } else if (mode == 1) {
       const int eb = 126 - (int)((t >> 23) % 10);
       b = __builtin_bit_cast(float, ((uint32_t)eb << 23) | ((uint32_t)t & 0x7fffffu));
+    } else {
+      // mode 2: x / scale of the ConvNet's input normalisation: b in [2^-12, 2^21], |a| anywhere in [2^-40, 2^40]
+      const int eb = 127 - 12 + (int)(h2 % 34);
+      b = __builtin_bit_cast(float, ((uint32_t)eb << 23) | (h1 & 0x7fffffu));
     }
     // a: |a| <= b * (1 + 2^-20) mostly near b's magnitude, sometimes tiny (down to 2^-100), random sign
     const uint32_t kind = h3 >> 28;
@@ -70,6 +75,14 @@ __global__ void k_div(int mode, uint64_t total, uint32_t seed, Counts* c) {
       mag = 0.0f;
     }
     a = (h3 & 1) ? -mag : mag;
+    if (mode == 2) {
+      const int ea = 127 - 40 + (int)((h3 >> 4) % 81);
+      a = __builtin_bit_cast(float, ((h3 & 1u) << 31) | ((uint32_t)ea << 23) | (h2 & 0x7fffffu));
+      const float want2 = a / b, r2 = tfl::rcp_refined(b), q2 = tfl::div_by<1>(a, b, r2);
+      n++;
+      if (__builtin_bit_cast(uint32_t, want2) != __builtin_bit_cast(uint32_t, q2)) { bad1++; c->ex_a = __builtin_bit_cast(uint32_t, a); c->ex_b = __builtin_bit_cast(uint32_t, b); }
+      continue;
+    }
     // rsq-seeded reciprocal (sqrt_rcp_exact): b has to be the root of an x; take x = RN(b*b) and its root as b
     float r3; { float b3; tfl::sqrt_rcp_exact(b * b, b3, r3); if (mode == 0) b = b3; else if (b3 != b) r3 = tfl::rcp_refined(b); }
     if (mag > b) { mag = b; a = (h3 & 1) ? -mag : mag; }
@@ -116,6 +129,13 @@ int main() {
          h.bad1, h.bad2, h.zsign, h.bad3);
   if (h.bad1) printf("  example a bits 0x%08llx b bits 0x%08llx\n", h.ex_a, h.ex_b);
   rc |= h.bad2 != 0;
-  printf("TFL_DIV_STEPS needed: %d\n", (b1a || h.bad1) ? 2 : 1);
+  const unsigned long long b1b = h.bad1;
+  reset();
+  k_div<<<8192, 256>>>(2, 1ull << 33, 0x4321u, d);
+  fetch();
+  printf("div_by vs '/': free ratio (|a| in [2^-40, 2^40], b in [2^-12, 2^21]) %llu pairs, mismatches 1-step %llu\n", h.n, h.bad1);
+  if (h.bad1) printf("  example a bits 0x%08llx b bits 0x%08llx\n", h.ex_a, h.ex_b);
+  rc |= h.bad1 != 0;
+  printf("TFL_DIV_STEPS needed: %d\n", (b1a || b1b) ? 2 : 1);
   return rc;
 }
