@@ -162,9 +162,15 @@ __global__ __launch_bounds__(256) void k_minmax3_v4(Dom d, int outside, const fl
   // first column (4 DPP moves per thread instead of 2 per row). v_min3 / v_max3 skip NaN operands like the
   // reference's comparisons do; against its compare-and-keep chain only the sign of a zero bound can differ
   // (see manta_clamp_bounds).
-  float clo[6], chi[6];
+  // v_min3_f32 / v_max3_f32 issued directly: through fminf / fmaxf hipcc first canonicalises every loaded operand
+  // (v_max_f32 x, x, x: 152 of this kernel's 677 vector instructions) because it cannot rule out signalling NaNs; the
+  // hardware instructions skip a NaN operand either way, which is all the masking needs. Rows are folded in pairs.
+  auto min3r = [](float a, float b, float c2) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c2)); return r; };
+  auto max3r = [](float a, float b, float c2) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c2)); return r; };
+  float clo[6], chi[6], pend[6];
 #pragma unroll
-  for (int q = 0; q < 6; q++) { clo[q] = __builtin_inff(); chi[q] = -__builtin_inff(); }
+  for (int q = 0; q < 6; q++) { clo[q] = __builtin_inff(); chi[q] = -__builtin_inff(); pend[q] = qnan; }
+  int nrow = 0;
 #pragma unroll
   for (int dz = (IS3D ? -1 : 0); dz <= (IS3D ? 1 : 0); dz++)
 #pragma unroll
@@ -172,19 +178,28 @@ __global__ __launch_bounds__(256) void k_minmax3_v4(Dom d, int outside, const fl
       const int jj = j + dy, kk = k + dz;
       const bool ok = live && jj >= 0 && jj < d.Y && kk >= 0 && kk < d.Z;
       const int o = TFL_AT(d, c.i0, jj, kk);
-      float sv[4], fv[4];
+      float sv[4], fv[4], m[6];
       v4_load(s, o, ok, qnan, sv);
       v4_load(flags, o, ok, 0.0f, fv);
 #pragma unroll
-      for (int q = 0; q < 4; q++) {
-        const float m = ok ? masked(sv[q], fv[q]) : qnan;
-        clo[q + 1] = __builtin_fminf(clo[q + 1], m);
-        chi[q + 1] = __builtin_fmaxf(chi[q + 1], m);
-      }
+      for (int q = 0; q < 4; q++) m[q + 1] = ok ? masked(sv[q], fv[q]) : qnan;
       // a segment's end lanes walk the outside columns themselves (only when the row continues: X > 128)
-      if (c.first && ok && c.has_l) { const float m = masked(s[o - 1], flags[o - 1]); clo[0] = __builtin_fminf(clo[0], m); chi[0] = __builtin_fmaxf(chi[0], m); }
-      if (c.last && ok && c.has_r) { const float m = masked(s[o + 4], flags[o + 4]); clo[5] = __builtin_fminf(clo[5], m); chi[5] = __builtin_fmaxf(chi[5], m); }
+      m[0] = qnan; m[5] = qnan;
+      if (c.first && ok && c.has_l) m[0] = masked(s[o - 1], flags[o - 1]);
+      if (c.last && ok && c.has_r) m[5] = masked(s[o + 4], flags[o + 4]);
+      if (nrow & 1) {
+#pragma unroll
+        for (int q = 0; q < 6; q++) { clo[q] = min3r(clo[q], pend[q], m[q]); chi[q] = max3r(chi[q], pend[q], m[q]); }
+      } else {
+#pragma unroll
+        for (int q = 0; q < 6; q++) pend[q] = m[q];
+      }
+      nrow++;
     }
+  if (nrow & 1) {
+#pragma unroll
+    for (int q = 0; q < 6; q++) { clo[q] = min3r(clo[q], pend[q], pend[q]); chi[q] = max3r(chi[q], pend[q], pend[q]); }
+  }
   {
     const float l0 = from_lane_below(clo[4]), h0 = from_lane_below(chi[4]);
     const float l5 = from_lane_above(clo[1]), h5 = from_lane_above(chi[1]);
@@ -194,8 +209,8 @@ __global__ __launch_bounds__(256) void k_minmax3_v4(Dom d, int outside, const fl
   float lo[4], hi[4];
 #pragma unroll
   for (int q = 0; q < 4; q++) {
-    lo[q] = __builtin_fminf(__builtin_fminf(clo[q], clo[q + 1]), clo[q + 2]);
-    hi[q] = __builtin_fmaxf(__builtin_fmaxf(chi[q], chi[q + 1]), chi[q + 2]);
+    lo[q] = min3r(clo[q], clo[q + 1], clo[q + 2]);
+    hi[q] = max3r(chi[q], chi[q + 1], chi[q + 2]);
   }
   if (live) {
     const int o = TFL_AT(d, c.i0, j, k);
