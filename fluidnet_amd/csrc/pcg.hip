@@ -20,8 +20,7 @@
 //     ic0:  R upper with R(n,n) = sqrt(d(n)), R(n,q) = -1/R(n,n); M = R^T R.
 //     Cells of one hyperplane i+j+k = const are independent (what cusparse's csrsv level analysis discovers at run
 //     time). The factorisation (once per solve) runs one launch per hyperplane; the two triangular solves of every CG
-//     iteration run as PIPELINED WAVEFRONTS on 3-D grids -- two launches instead of ~760 at 128^3 (k_wf_sweep below:
-//     354 -> 77 ms per solve; the unpreconditioned solve takes 27 ms in 3x the iterations). 2-D grids and grids with
+//     iteration run as PIPELINED WAVEFRONTS on 3-D grids -- two launches instead of ~760 at 128^3 (k_wf_sweep below). 2-D grids and grids with
 //     more than 240 sub-boxes keep the launch-per-hyperplane sweeps.
 // Dot products are two-stage fp64 reductions with a fixed order (bit-reproducible run to run).
 #include "tfl_device.hpp"
@@ -30,9 +29,11 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <limits>
+#include <type_traits>
 #include <vector>
 
 namespace tfl {
@@ -354,38 +355,43 @@ __global__ __launch_bounds__(256) void k_ilu_backward(const PcgState* __restrict
 // One launch per hyperplane (above) is X+Y+Z-6 launches per solve, ~760 per CG iteration at 128^3: 2.7 ms of launch
 // latency around ~20 us of arithmetic. Here a sweep is ONE launch:
 //   * the interior is cut into sub-boxes of 64 rows (j) x 16 planes (k) x all of x; a 1024-thread block owns one:
-//     wave w <-> plane, lane l <-> row, and at iteration T the thread works on i = 1 + T - l - w -- the hyperplane
-//     T = (i-1) + l + w of its sub-box. Its three predecessors were computed ONE iteration earlier by itself (x), by the
-//     lane below (y: one DPP wave shift) and by the wave below (z: a 64-float LDS slot, double buffered): one
-//     __syncthreads per iteration, X + 78 iterations per sub-box;
-//   * sub-boxes depend on their lower j / k neighbours through global memory. They all run concurrently, each staying
-//     64 (rows) resp. 16 (planes) iterations + a margin behind its predecessors: a block publishes its iteration count
-//     every 8 iterations behind a release fence and polls its predecessors' (bounded spin, acquire fence) before each
-//     chunk of 8. The critical path is ~X + 64 (ns-1) + 24 (nb-1) + 78 iterations instead of X+Y+Z launches;
-//   * everything a sweep reads per cell sits in a SKEWED copy laid out [sub-box][plane][T][row], so that a wave's access
-//     at iteration T is one coalesced 256-B row: the diagonal scaling c (1/sqrt(d) for IC, 1/d for ILU; 0 outside the
-//     component, which also zeroes such cells' results), r, the forward result y and z. Two chip-wide kernels per
-//     solve copy r into, and z out of, that layout (k_wf_skew).
-// With q = y * c handed on instead of y:   IC: y = (((r + q_z) + q_y) + q_x) * c      ILU: y = ((r + q_z) + q_y) + q_x
-// backward, t = sum of the upper neighbours' z:   IC: z = (y + t * c) * c              ILU: z = (y + t) * c
-// (the reference divides by R(m,m) / d(m) where this multiplies by the reciprocal: inside the solver's tolerance).
+//     wave w <-> plane, lane l <-> row, and at step t the thread works on the cell with (i-1) + l + 4 w = t. Its
+//     three predecessors were computed one step earlier by itself (x: a register), one step earlier by the lane below
+//     (y: one DPP wave shift) and FOUR steps earlier by the wave below (z). That lag of four lets the waves of a block
+//     exchange through LDS in groups of four steps: one 16-byte read, one 16-byte write and one barrier per group;
+//   * a block's steps are bound by its CU's vector-memory pipe (every operand and result of the sub-box passes
+//     through one CU: measured ~15 ns per wave and step with three accesses per step), so everything a sweep touches
+//     per cell sits in SKEWED arrays laid out [sub-box][plane][t / 4][row][t % 4]: per group of four steps a wave
+//     reads cc and r and writes its results with ONE 16-byte access each. Two chip-wide kernels per solve copy r
+//     into, and z out of, that layout (k_wf_skew);
+//   * sub-boxes depend on their lower j / k neighbours through global memory, with no flags and no fences: the edge
+//     plane and the edge lane of a block also store their results as 8-byte {value, tag} pairs (tag = the launch's
+//     sequence number) into hand-off arrays; the consumer prefetches them like any other operand and, if a tag is
+//     not this launch's yet, re-reads until it is (bounded; an error word ends the solve instead of hanging the
+//     GPU). A consumer therefore settles by itself at the smallest lag behind its predecessor that memory latency
+//     allows.
+// With c = 1/sqrt(d) (IC) or 1/d (ILU) and cc = c*c (IC) or c (ILU), both factorisations run the same recurrences:
+//   forward    q = (((r + q_z) + q_y) + q_x) * cc          (q = y * c of the reference's forward solve)
+//   backward   z = q + ((z_x + z_y) + z_z) * cc
+// (the reference divides by R(m,m) / d(m) where this multiplies by reciprocals: inside the solver's tolerance).
 #ifndef TFL_WF_PLANES
 #define TFL_WF_PLANES 16
 #endif
-#ifndef TFL_WF_CHUNK
-#define TFL_WF_CHUNK 8
+#ifndef TFL_WF_DEPTH
+#define TFL_WF_DEPTH 16
 #endif
-constexpr int kWfRows = 64, kWfPlanes = TFL_WF_PLANES, kWfChunk = TFL_WF_CHUNK, kWfMaxBlocks = 240;
+constexpr int kWfRows = 64, kWfPlanes = TFL_WF_PLANES, kWfLag = 4, kWfDepth = TFL_WF_DEPTH, kWfMaxBlocks = 240;
+static_assert(kWfDepth % 8 == 0 && kWfLag == 4, "groups of four steps, strip edges in groups of eight");
 
 struct WfGeom {
-  int X, Y, Z, ns, nb, NT;     // strips, slabs, iterations per sub-box
-  long long sub;               // floats of one sub-box in the skewed arrays = kWfPlanes * NT * kWfRows
+  int X, Y, Z, ns, nb, NT;     // strips, slabs, steps per sub-box (a multiple of kWfDepth)
+  long long sub;               // cells of one sub-box in the skewed arrays = kWfPlanes * NT * kWfRows
 };
 inline WfGeom wf_geom(int Z, int Y, int X) {
   WfGeom g;
   g.X = X; g.Y = Y; g.Z = Z;
   g.ns = (Y - 2 + kWfRows - 1) / kWfRows; g.nb = (Z - 2 + kWfPlanes - 1) / kWfPlanes;
-  g.NT = (((X - 2) + (kWfRows - 1) + (kWfPlanes - 1)) + kWfChunk - 1) / kWfChunk * kWfChunk;
+  g.NT = (((X - 2) + (kWfRows - 1) + kWfLag * (kWfPlanes - 1)) + kWfDepth - 1) / kWfDepth * kWfDepth;
   g.sub = (long long)kWfPlanes * g.NT * kWfRows;
   return g;
 }
@@ -395,12 +401,21 @@ inline bool wf_usable(bool is3d, int Z, int Y, int X) {
   const WfGeom g = wf_geom(Z, Y, X);
   return !off && g.ns * g.nb <= kWfMaxBlocks;      // every block must be resident at once (they wait for each other)
 }
+// floats of: cc, r, q, z (skewed) | the slab hand-off pairs [block][t / 4][row][t % 4] | the strip hand-off pairs
+// [block][plane][t] | the error word
+inline long long wf_handoff_k(const WfGeom& g) { return 2ll * g.ns * g.nb * g.NT * kWfRows; }
+inline long long wf_handoff_s(const WfGeom& g) { return 2ll * g.ns * g.nb * kWfPlanes * g.NT; }
 inline long long wf_floats(int Z, int Y, int X) {
   const WfGeom g = wf_geom(Z, Y, X);
-  return 4 * g.sub * g.ns * g.nb + 2 * kWfMaxBlocks + 64;      // c, r, y, z in the skewed layout
+  return 4 * g.sub * g.ns * g.nb + wf_handoff_k(g) + wf_handoff_s(g) + 64;
+}
+__device__ __forceinline__ long long wf_at(const WfGeom& g, int i, int j, int k) {
+  const int s = (j - 1) / kWfRows, l = (j - 1) % kWfRows, b = (k - 1) / kWfPlanes, w = (k - 1) % kWfPlanes;
+  const int t = (i - 1) + l + kWfLag * w;
+  return ((((long long)(s * g.nb + b) * kWfPlanes + w) * (g.NT / 4) + (t >> 2)) * kWfRows + l) * 4 + (t & 3);
 }
 
-// c (skewed) from the factor's diagonal: one thread per interior cell
+// cc (skewed) from the factor's diagonal: one thread per interior cell
 template <bool IC>
 __global__ __launch_bounds__(256) void k_wf_build(WfGeom g, Dom d, const int* __restrict__ label, int root, const float* __restrict__ dg,
                                                   float* __restrict__ cs) {
@@ -409,15 +424,16 @@ __global__ __launch_bounds__(256) void k_wf_build(WfGeom g, Dom d, const int* __
   if (t >= (long long)nx * ny * nz) return;
   const int i = 1 + (int)(t % nx), j = 1 + (int)((t / nx) % ny), k = 1 + (int)(t / ((long long)nx * ny));
   const int o = TFL_AT(d, i, j, k);
-  float c = 0.0f;
-  if (label[o] == root) c = IC ? 1.0f / sqrtf(dg[o]) : 1.0f / dg[o];
-  const int s = (j - 1) / kWfRows, l = (j - 1) % kWfRows, b = (k - 1) / kWfPlanes, w = (k - 1) % kWfPlanes;
-  cs[((long long)(s * g.nb + b) * kWfPlanes + w) * g.NT * kWfRows + (long long)((i - 1) + l + w) * kWfRows + l] = c;
+  float cc = 0.0f;
+  if (label[o] == root) {
+    if (IC) { const float c = 1.0f / sqrtf(dg[o]); cc = c * c; }
+    else cc = 1.0f / dg[o];
+  }
+  cs[wf_at(g, i, j, k)] = cc;
 }
 
 // natural layout <-> skewed layout of a vector on the interior cells (chip-wide, one thread per cell: the sweeps
-// themselves must not gather / scatter -- a wave's 64 rows are 64 cache lines per instruction, measured 4.5 us per 8
-// iterations when the forward sweep read r and the backward sweep wrote z in the natural layout)
+// themselves must not gather / scatter -- a wave's 64 rows are 64 cache lines per instruction)
 template <bool TO_SKEWED>
 __global__ __launch_bounds__(256) void k_wf_skew(const PcgState* __restrict__ S, WfGeom g, Dom d, float* __restrict__ nat, float* __restrict__ skw) {
   if (S->done) return;
@@ -426,138 +442,188 @@ __global__ __launch_bounds__(256) void k_wf_skew(const PcgState* __restrict__ S,
   if (t >= (long long)nx * ny * nz) return;
   const int i = 1 + (int)(t % nx), j = 1 + (int)((t / nx) % ny), k = 1 + (int)(t / ((long long)nx * ny));
   const int o = TFL_AT(d, i, j, k);
-  const int s = (j - 1) / kWfRows, l = (j - 1) % kWfRows, b = (k - 1) / kWfPlanes, w = (k - 1) % kWfPlanes;
-  const long long a = ((long long)(s * g.nb + b) * kWfPlanes + w) * g.NT * kWfRows + (long long)((i - 1) + l + w) * kWfRows + l;
+  const long long a = wf_at(g, i, j, k);
   if (TO_SKEWED) skw[a] = nat[o];
   else nat[o] = skw[a];
 }
 
-__device__ __forceinline__ int wf_poll(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// {value, tag} pairs: one 8-byte access, coherent across the chip (sc1), so a tag never arrives before its value
+__device__ __forceinline__ unsigned long long wf_load_pair(const float2* p) {
+  return __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// two pairs with one 16-byte store (each aligned 8-byte half is written whole)
+__device__ __forceinline__ void wf_store_pairs2(float2* p, float v0, float v1, int tag) {
+  typedef float vec4 __attribute__((ext_vector_type(4)));
+  const vec4 u = {v0, __int_as_float(tag), v1, __int_as_float(tag)};
+  // s_nop: a VALU write to the data registers of a store wider than 8 bytes needs one wait state after it, and the
+  // compiler's hazard pass does not see inside asm
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 0" : : "v"(p), "v"(u) : "memory");
+}
+// the same loads for the retry path, opaque to the compiler's wait-count bookkeeping (they complete before they return)
+__device__ __forceinline__ unsigned long long wf_reload_pair(const float2* p) {
+  unsigned long long v;
+  asm volatile("global_load_dwordx2 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p) : "memory");
+  return v;
+}
+__device__ __forceinline__ int wf_reload_word(const int* p) {
+  int v;
+  asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p) : "memory");
+  return v;
+}
+__device__ __forceinline__ float wf_value(unsigned long long u) { return __uint_as_float((unsigned)u); }
+__device__ __forceinline__ int wf_tag(unsigned long long u) { return (int)(u >> 32); }
 
-// DIR = +1 forward (lower neighbours), -1 backward (upper neighbours, iterations run from the last to the first)
-template <bool IC, int DIR>
-__global__ __launch_bounds__(kWfPlanes * 64) void k_wf_sweep(const PcgState* __restrict__ S, WfGeom g, Dom d, const float* __restrict__ cs,
-                                                   const float* __restrict__ rin, float* __restrict__ ys, float* __restrict__ zout,
-                                                   int* __restrict__ prog, int base, int* __restrict__ err) {
-  if (S->done) return;
-  __shared__ float qz[2][kWfPlanes][kWfRows];
-  __shared__ int s_ok;
+struct WfArrays {
+  const float* cs;      // cc
+  const float* in;      // forward: r; backward: q
+  float* out;           // forward: q; backward: z
+  float2* hk;           // slab hand-off pairs of this launch's results
+  float2* hs;           // strip hand-off pairs
+  int* err;
+};
+
+// One wave's share of a sweep. DIR = +1 forward (lower neighbours), -1 backward (upper neighbours, steps run from the
+// last to the first); EDGE: the wave whose z neighbour lives in the slab predecessor (plane 0 forward, 15 backward).
+// The loop is written so that hipcc's vmcnt bookkeeping stays exact -- no conditional loads (addresses are clamped
+// and the unwanted values dropped at USE time), the retry loop's loads hidden in asm, the prologue issuing in loop
+// order -- because a conservative vmcnt(0) would drain the operand prefetch at every group.
+template <int DIR, bool EDGE>
+__device__ __forceinline__ void wf_run(const WfGeom& g, const WfArrays& A, int tag, float4 (*ring)[2][kWfRows]) {
+  constexpr int D = kWfDepth, G = D / 4;
   const int blk = blockIdx.x, sidx = blk / g.nb, bidx = blk - sidx * g.nb;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int NT = g.NT;
-  const long long mine = ((long long)blk * kWfPlanes + w) * NT * kWfRows + lane;
-  // predecessor sub-boxes in j and k (forward: the lower ones) and the cell of theirs this thread's edge cell needs:
-  // the strip predecessor's lane 63 (forward) / 0 (backward) of the same plane, the slab predecessor's plane 15 / 0
+  const int NT = g.NT, NG = NT / 4;
+  // predecessor sub-boxes in j and k (forward: the lower ones) and the entries of theirs this thread's edge cells need:
+  // the strip predecessor's lane 63 (forward) / 0 (backward) of the same plane at step t +- 63, the slab predecessor's
+  // plane 15 / 0 at step t +- 4 * 15. Without a predecessor the pointers stay inside this block's own rows (never used).
   const int ps = DIR > 0 ? (sidx > 0 ? blk - g.nb : -1) : (sidx + 1 < g.ns ? blk + g.nb : -1);
   const int pk = DIR > 0 ? (bidx > 0 ? blk - 1 : -1) : (bidx + 1 < g.nb ? blk + 1 : -1);
-  const int elane = DIR > 0 ? kWfRows - 1 : 0, ewave = DIR > 0 ? kWfPlanes - 1 : 0;
-  const long long from_s = ps >= 0 ? ((long long)ps * kWfPlanes + w) * NT * kWfRows + elane : 0;
-  const long long from_k = pk >= 0 ? ((long long)pk * kWfPlanes + ewave) * NT * kWfRows + lane : 0;
-  const bool edge_l = DIR > 0 ? lane == 0 : lane == kWfRows - 1;
-  const bool edge_w = DIR > 0 ? w == 0 : w == kWfPlanes - 1;
-  // the neighbour (i, j-+1, k) of an edge lane sits at the predecessor's iteration T +- (kWfRows - 1), the neighbour
-  // (i, j, k-+1) of an edge wave at T +- (kWfPlanes - 1)
-  float q_prev = 0.0f;      // forward: q = y * c of this thread's previous cell; backward: its z
-  qz[0][w][lane] = 0.0f; qz[1][w][lane] = 0.0f;
-  int seen_s = 0, seen_k = 0;     // thread 0: the predecessors' progress as last read
+  const bool has_s = ps >= 0, has_k = pk >= 0;
+  const bool out_k = (DIR > 0 ? w == kWfPlanes - 1 : w == 0) && (DIR > 0 ? bidx + 1 < g.nb : bidx > 0);       // a slab successor reads this wave
+  const bool out_s = (DIR > 0 ? lane == kWfRows - 1 : lane == 0) && (DIR > 0 ? sidx + 1 < g.ns : sidx > 0);   // a strip successor reads this lane
+  const long long base4 = ((long long)blk * kWfPlanes + w) * NG * kWfRows + lane;       // in float4 units; + group * 64
+  const float4* c4 = reinterpret_cast<const float4*>(A.cs) + base4;
+  const float4* i4 = reinterpret_cast<const float4*>(A.in) + base4;
+  float4* o4 = reinterpret_cast<float4*>(A.out) + base4;
+  float2* hk_me = A.hk + ((long long)blk * NG * kWfRows + lane) * 4;                      // + group * 256 + t % 4
+  float2* hs_me = A.hs + ((long long)blk * kWfPlanes + w) * NT;                           // + t
+  const float2* from_k = A.hk + ((long long)(has_k ? pk : blk) * NG * kWfRows + lane) * 4;
+  const float2* from_s = A.hs + ((long long)(has_s ? ps : blk) * kWfPlanes + w) * NT;
+  const int nbw = DIR > 0 ? max(w - 1, 0) : min(w + 1, kWfPlanes - 1);
+  auto tau = [&](int it) { return DIR > 0 ? it : NT - 1 - it; };
+  auto grp = [&](int ig) { return DIR > 0 ? ig : NG - 1 - ig; };           // memory group of the ig-th group in time
+  constexpr int kOffS = DIR * (kWfRows - 1), kOffGK = DIR * (kWfLag * (kWfPlanes - 1) / 4);
+  static_assert(kWfLag * (kWfPlanes - 1) % 4 == 0, "the slab predecessor's groups line up with this block's");
 
-  struct Operands { float cv[kWfChunk], rv[kWfChunk], es[kWfChunk], ek[kWfChunk]; };
-  // make sure the predecessors are far enough ahead for the chunk starting at iteration c0 (thread 0 polls only when its
-  // cached reading does not already say so), then issue every load of that chunk
-  auto wait_for = [&](int c0) -> bool {
-    if (threadIdx.x == 0) {
-      const int last = c0 + kWfChunk - 1;
-      const int need_s = base + min(last + kWfRows, NT), need_k = base + min(last + kWfPlanes, NT);
-      bool ok = true, polled = false;
-      if (ps >= 0 && seen_s < need_s) {
-        polled = true;
-        for (long long spin = 0; (seen_s = wf_poll(prog + ps)) < need_s; spin++) {
-          if (spin > (1ll << 24) || wf_poll(err)) { ok = false; atomicExch(err, 1); break; }   // never hang the GPU
-          __builtin_amdgcn_s_sleep(1);
-        }
-      }
-      if (ok && pk >= 0 && seen_k < need_k) {
-        polled = true;
-        for (long long spin = 0; (seen_k = wf_poll(prog + pk)) < need_k; spin++) {
-          if (spin > (1ll << 24) || wf_poll(err)) { ok = false; atomicExch(err, 1); break; }
-          __builtin_amdgcn_s_sleep(1);
-        }
-      }
-      if (polled) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      s_ok = ok ? 1 : 0;
-    }
-    __syncthreads();
-    return s_ok != 0;
-  };
-  auto load = [&](int c0, Operands& op) {
+  // operands, prefetched G groups ahead into rotating registers (slot = group mod G; the loop below is unrolled by G)
+  float4 cv[G], rv[G];
+  unsigned long long ekv[G][4];   // EDGE: the slab predecessor's pairs of the group
+  unsigned long long esv[G / 2];  // lane l: the strip predecessor's edge-lane pair of step (8-group start + l % 8)
+  bool dead = false;              // a predecessor never delivered: stop waiting (the host sees the error word)
+  auto issue = [&](int ig, int slot) {
+    const int gm = grp(ig);
+    cv[slot] = c4[(long long)gm * kWfRows];
+    rv[slot] = i4[(long long)gm * kWfRows];
+    if (EDGE) {
+      const int gk = min(max(gm + kOffGK, 0), NG - 1);
 #pragma unroll
-    for (int u = 0; u < kWfChunk; u++) {
-      const int it = c0 + u, T = DIR > 0 ? it : NT - 1 - it;
-      op.cv[u] = cs[mine + (long long)T * kWfRows];
-      // forward: r of the cell; backward: the forward result y (both skewed: one coalesced row per wave)
-      op.rv[u] = DIR > 0 ? rin[mine + (long long)T * kWfRows] : ys[mine + (long long)T * kWfRows];
-      op.es[u] = 0.0f; op.ek[u] = 0.0f;
-      // forward: (i, j-1, k) of lane 0 = the strip predecessor's lane 63 at its iteration T + 63, (i, j, k-1) of wave 0 = the
-      // slab predecessor's wave 15 at its iteration T + 15: q = y * c. Backward: mirrored (lane 0 / wave 0 of the upper
-      // predecessors at T - 63 / T - 15): z. All out of the predecessors' skewed arrays.
-      const int Ts = T + DIR * (kWfRows - 1), Tk = T + DIR * (kWfPlanes - 1);
-      if (edge_l && ps >= 0 && Ts >= 0 && Ts < NT) {
-        const long long a = from_s + (long long)Ts * kWfRows;
-        op.es[u] = DIR > 0 ? __builtin_nontemporal_load(ys + a) * cs[a] : __builtin_nontemporal_load(zout + a);
-      }
-      if (edge_w && pk >= 0 && Tk >= 0 && Tk < NT) {
-        const long long a = from_k + (long long)Tk * kWfRows;
-        op.ek[u] = DIR > 0 ? __builtin_nontemporal_load(ys + a) * cs[a] : __builtin_nontemporal_load(zout + a);
-      }
+      for (int j = 0; j < 4; j++) ekv[slot][j] = wf_load_pair(from_k + (long long)gk * (4 * kWfRows) + j);
     }
   };
-  auto compute = [&](int c0, const Operands& op) {
+  auto issue_s = [&](int it0, int slot) { esv[slot] = wf_load_pair(from_s + min(max(tau(it0 + (lane & 7)) + kOffS, 0), NT - 1)); };
+  // re-read until every wanted pair carries this launch's tag (normally the prefetched one already does). The re-reads
+  // are issued AND waited for inside one asm statement, invisible to the compiler's wait counting
+  auto settle = [&](unsigned long long& v, const float2* src, bool want) {
+    if (dead || __ballot(want && wf_tag(v) != tag) == 0ull) return;
+    for (int spin = 0;; spin++) {
+      if (want && wf_tag(v) != tag) v = wf_reload_pair(src);
+      if (__ballot(want && wf_tag(v) != tag) == 0ull) return;
+      if (spin > (1 << 20) || wf_reload_word(A.err)) { atomicExch(A.err, 1); dead = true; return; }   // never hang the GPU
+      __builtin_amdgcn_s_sleep(2);
+    }
+  };
+
+  float q_prev = 0.0f;      // this thread's previous result (forward: q, backward: z)
+  auto body = [&](int t0, auto more) {
 #pragma unroll
-    for (int u = 0; u < kWfChunk; u++) {
-      const int it = c0 + u, T = DIR > 0 ? it : NT - 1 - it;
-      // the wave shift must run with EVERY lane enabled (a disabled source lane reads as 0): keep it out of the select
-      float shifted = DIR > 0 ? from_lane_below(q_prev) : from_lane_above(q_prev);
-      asm volatile("" : "+v"(shifted));
-      const float nb_y = edge_l ? op.es[u] : shifted;
-      float below = qz[(it + 1) & 1][DIR > 0 ? max(w - 1, 0) : min(w + 1, kWfPlanes - 1)][lane];   // every lane reads (no exec juggling)
-      asm volatile("" : "+v"(below));
-      const float nb_z = edge_w ? op.ek[u] : below;
-      float out, hand;
-      if (DIR > 0) {
-        const float v = ((op.rv[u] + nb_z) + nb_y) + q_prev;
-        out = IC ? v * op.cv[u] : v;        // y
-        hand = out * op.cv[u];              // q = y * c
-        ys[mine + (long long)T * kWfRows] = out;
-      } else {
-        const float t = (q_prev + nb_y) + nb_z;
-        out = IC ? (op.rv[u] + t * op.cv[u]) * op.cv[u] : (op.rv[u] + t) * op.cv[u];     // z
-        hand = out;
-        zout[mine + (long long)T * kWfRows] = out;
+    for (int c = 0; c < G; c++) {
+      const int ig = t0 / 4 + c, gm = grp(ig);
+      const float4 below4 = ring[nbw][(c & 1) ^ 1][lane];       // what the neighbour wave computed during the previous group
+      const float below[4] = {below4.x, below4.y, below4.z, below4.w};
+      // in memory the group is ordered by t; backward walks it from its last element
+      const float ccs[4] = {DIR > 0 ? cv[c].x : cv[c].w, DIR > 0 ? cv[c].y : cv[c].z, DIR > 0 ? cv[c].z : cv[c].y, DIR > 0 ? cv[c].w : cv[c].x};
+      const float ins[4] = {DIR > 0 ? rv[c].x : rv[c].w, DIR > 0 ? rv[c].y : rv[c].z, DIR > 0 ? rv[c].z : rv[c].y, DIR > 0 ? rv[c].w : rv[c].x};
+      float h4[4];
+#pragma unroll
+      for (int u4 = 0; u4 < 4; u4++) {
+        const int u = c * 4 + u4, it = t0 + u;
+        if ((u & 7) == 0) {
+          const int Ts = tau(it + (lane & 7)) + kOffS;
+          const bool want = has_s && Ts >= 0 && Ts < NT;
+          settle(esv[u >> 3], from_s + min(max(Ts, 0), NT - 1), want);
+          if (!want) esv[u >> 3] = 0ull;
+        }
+        // y neighbour: the lane below / above; the edge lane has no source lane and keeps `old` = the predecessor's value
+        const int es_bits = __builtin_amdgcn_readlane((int)(unsigned)esv[u >> 3], u & 7);
+        float nb_y = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(es_bits, __builtin_bit_cast(int, q_prev),
+                                                                             DIR > 0 ? 0x138 /*wave_shr:1*/ : 0x130 /*wave_shl:1*/, 0xf, 0xf, false));
+        asm volatile("" : "+v"(nb_y));
+        float nb_z = below[u4];
+        if (EDGE) {
+          const int gk = gm + kOffGK, j = DIR > 0 ? u4 : 3 - u4;
+          const bool want = has_k && gk >= 0 && gk < NG;        // wave-uniform
+          settle(ekv[c][j], from_k + (long long)min(max(gk, 0), NG - 1) * (4 * kWfRows) + j, want);
+          nb_z = want ? wf_value(ekv[c][j]) : 0.0f;
+        }
+        float res;
+        if (DIR > 0) res = (((ins[u4] + nb_z) + nb_y) + q_prev) * ccs[u4];
+        else res = __builtin_fmaf((q_prev + nb_y) + nb_z, ccs[u4], ins[u4]);
+        h4[u4] = res;
+        q_prev = res;
       }
-      q_prev = hand;
-      qz[it & 1][w][lane] = hand;
-      // workgroup barrier that waits for the LDS write only: __syncthreads() also drains vmcnt, i.e. every iteration would
-      // wait for the next chunk's operand loads and for its own y / z store (measured: 1.2 k clocks per iteration)
+      ring[w][c & 1][lane] = make_float4(h4[0], h4[1], h4[2], h4[3]);
+      // workgroup barrier that waits for the LDS write only (__syncthreads() would also drain the operand prefetch)
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    }
-    if (threadIdx.x == 0) {    // publish
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __hip_atomic_store(prog + blk, base + c0 + kWfChunk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const float m4[4] = {DIR > 0 ? h4[0] : h4[3], DIR > 0 ? h4[1] : h4[2], DIR > 0 ? h4[2] : h4[1], DIR > 0 ? h4[3] : h4[0]};   // by t
+      o4[(long long)gm * kWfRows] = make_float4(m4[0], m4[1], m4[2], m4[3]);
+      if (out_k) {        // wave-uniform
+        float2* dst = hk_me + (long long)gm * (4 * kWfRows);
+        wf_store_pairs2(dst, m4[0], m4[1], tag);
+        wf_store_pairs2(dst + 2, m4[2], m4[3], tag);
+      }
+      if (out_s) {        // one lane
+        float2* dst = hs_me + gm * 4;
+        wf_store_pairs2(dst, m4[0], m4[1], tag);
+        wf_store_pairs2(dst + 2, m4[2], m4[3], tag);
+      }
+      if constexpr (decltype(more)::value) {
+        issue(ig + G, c);
+        if ((c & 1) == 1) issue_s(t0 + D + (c - 1) * 4, c >> 1);
+      }
     }
   };
-  // two chunks in flight: the operands of chunk n+1 are loaded while chunk n runs its eight barrier-separated iterations
-  Operands A, B;
-  if (!wait_for(0)) return;
-  load(0, A);
-  for (int c0 = 0; c0 < NT; c0 += 2 * kWfChunk) {
-    const bool more1 = c0 + kWfChunk < NT, more2 = c0 + 2 * kWfChunk < NT;
-    if (more1) { if (!wait_for(c0 + kWfChunk)) return; load(c0 + kWfChunk, B); }
-    compute(c0, A);
-    if (!more1) break;
-    if (more2) { if (!wait_for(c0 + 2 * kWfChunk)) return; load(c0 + 2 * kWfChunk, A); }
-    compute(c0 + kWfChunk, B);
+  // the prologue issues its loads in the order the loop does (operands of two groups, then those eight steps' edge
+  // pairs): the loop's waits are sized for the worse of "entered from here" and "came round the back edge"
+#pragma unroll
+  for (int c = 0; c < G; c++) {
+    issue(c, c);
+    if ((c & 1) == 1) issue_s((c - 1) * 4, c >> 1);
   }
+  int t0 = 0;
+  for (; t0 + D < NT; t0 += D) body(t0, std::true_type{});
+  body(t0, std::false_type{});
+}
+
+template <int DIR>
+__global__ __launch_bounds__(kWfPlanes * 64) void k_wf_sweep(const PcgState* __restrict__ S, WfGeom g, WfArrays A, int tag) {
+  if (S->done) return;
+  __shared__ float4 ring[kWfPlanes][2][kWfRows];     // a wave's last two groups of four results, for the wave above / below
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  ring[w][0][lane] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  ring[w][1][lane] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  __syncthreads();
+  if (DIR > 0 ? w == 0 : w == kWfPlanes - 1) wf_run<DIR, true>(g, A, tag, ring);
+  else wf_run<DIR, false>(g, A, tag, ring);
 }
 
 // ---- normalizePressureMean (generic/tfluids.cc:845-925): p -= mean of p over the cell's fluid component ----
@@ -595,7 +661,7 @@ inline int cdiv(long long a, int b) { return (int)((a + b - 1) / b); }
 long long pcg_workspace_floats(int Z, int Y, int X) {
   const long long n = (long long)Z * Y * X;
   // label, size_at (int32) + x, r, z, s, w, dg, y (fp32) + roots + partials/state (fp64, kept 8-byte aligned first)
-  return 2 * (kRedBlocks + 64) + 9 * n + kMaxComponents + 64 + (wf_usable(Z > 1, Z, Y, X) ? wf_floats(Z, Y, X) : 0);
+  return 2 * (kRedBlocks + 64) + 9 * n + kMaxComponents + 64 + (wf_usable(Z > 1, Z, Y, X) ? wf_floats(Z, Y, X) + 4 : 0);
 }
 
 // Solves every component of every batch element. Returns 0, or a negative code with `msg` filled:
@@ -618,15 +684,16 @@ int pcg_solve(hipStream_t st, bool is3d, int B, int Z, int Y, int X, float* p, c
   const bool wf = wf_usable(is3d, Z, Y, X);
   const WfGeom wg = wf_geom(Z > 2 ? Z : 3, Y > 2 ? Y : 3, X > 2 ? X : 3);
   float* wfbase = base + 9 * n + kMaxComponents + 64;
+  wfbase += (4 - (((uintptr_t)wfbase >> 2) & 3)) & 3;                  // 16-byte aligned (float4 rows, {value, tag} pairs)
   float* cs = wfbase;
   const long long wtot = wg.sub * wg.ns * wg.nb;
   float* rsk = wf ? cs + wtot : nullptr;
-  float* ysk = wf ? cs + 2 * wtot : nullptr;
+  float* qsk = wf ? cs + 2 * wtot : nullptr;
   float* zsk = wf ? cs + 3 * wtot : nullptr;
-  int* prog = wf ? reinterpret_cast<int*>(cs + 4 * wtot) : nullptr;
-  int* wferr = wf ? prog + kWfMaxBlocks : nullptr;
-  int epoch = 0;
-  const int wf_stride = wg.NT + kWfChunk;       // progress values of launch e live in (e * stride, e * stride + NT]
+  float2* wf_hk = wf ? reinterpret_cast<float2*>(cs + 4 * wtot) : nullptr;       // 16-byte aligned: wtot is a multiple of 1024
+  float2* wf_hs = wf ? reinterpret_cast<float2*>(cs + 4 * wtot + wf_handoff_k(wg)) : nullptr;
+  int* wferr = wf ? reinterpret_cast<int*>(cs + 4 * wtot + wf_handoff_k(wg) + wf_handoff_s(wg)) : nullptr;
+  int epoch = 0;                                // tag of the next sweep launch; the skewed arrays are zeroed with it
   auto hip_ok = [&](hipError_t e, const char* what) {
     if (e == hipSuccess) return true;
     snprintf(msg, msg_len, "solveLinearSystemPCG: %s: %s", what, hipGetErrorString(e));
@@ -702,8 +769,7 @@ int pcg_solve(hipStream_t st, bool is3d, int B, int Z, int Y, int X, float* p, c
         }
         if (wf) {
           const long long tot = wg.sub * wg.ns * wg.nb;
-          if (!hip_ok(hipMemsetAsync(cs, 0, sizeof(float) * (size_t)tot * 4, st), "memset skewed arrays")) return -4;
-          if (!hip_ok(hipMemsetAsync(prog, 0, sizeof(int) * (kWfMaxBlocks + 16), st), "memset progress")) return -4;
+          if (!hip_ok(hipMemsetAsync(cs, 0, sizeof(float) * (size_t)(tot * 4 + wf_handoff_k(wg) + wf_handoff_s(wg) + 16), st), "memset skewed arrays")) return -4;
           epoch = 0;
           const int gb = cdiv((long long)(X - 2) * (Y - 2) * (Z - 2), 256);
           if (pc == 2) k_wf_build<true><<<gb, 256, 0, st>>>(wg, d, label, root, dg, cs);
@@ -722,12 +788,8 @@ int pcg_solve(hipStream_t st, bool is3d, int B, int Z, int Y, int X, float* p, c
             const int gb = cdiv((long long)(X - 2) * (Y - 2) * (Z - 2), 256);
             { TFL_TIMED("k_pcg_precond", st);
               k_wf_skew<true><<<gb, 256, 0, st>>>(S, wg, d, r, rsk);
-              epoch++;
-              if (pc == 2) k_wf_sweep<true, 1><<<nblk, kWfPlanes * 64, 0, st>>>(S, wg, d, cs, rsk, ysk, nullptr, prog, epoch * wf_stride, wferr);
-              else k_wf_sweep<false, 1><<<nblk, kWfPlanes * 64, 0, st>>>(S, wg, d, cs, rsk, ysk, nullptr, prog, epoch * wf_stride, wferr);
-              epoch++;
-              if (pc == 2) k_wf_sweep<true, -1><<<nblk, kWfPlanes * 64, 0, st>>>(S, wg, d, cs, nullptr, ysk, zsk, prog, epoch * wf_stride, wferr);
-              else k_wf_sweep<false, -1><<<nblk, kWfPlanes * 64, 0, st>>>(S, wg, d, cs, nullptr, ysk, zsk, prog, epoch * wf_stride, wferr);
+              k_wf_sweep<1><<<nblk, kWfPlanes * 64, 0, st>>>(S, wg, WfArrays{cs, rsk, qsk, wf_hk, wf_hs, wferr}, ++epoch);
+              k_wf_sweep<-1><<<nblk, kWfPlanes * 64, 0, st>>>(S, wg, WfArrays{cs, qsk, zsk, wf_hk, wf_hs, wferr}, ++epoch);
               k_wf_skew<false><<<gb, 256, 0, st>>>(S, wg, d, z, zsk); }
             dir_src = z;
           } else if (pc) {
