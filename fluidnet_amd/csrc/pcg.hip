@@ -375,12 +375,18 @@ __global__ __launch_bounds__(256) void k_ilu_backward(const PcgState* __restrict
 //   backward   z = q + ((z_x + z_y) + z_z) * cc
 // (the reference divides by R(m,m) / d(m) where this multiplies by reciprocals: inside the solver's tolerance).
 #ifndef TFL_WF_PLANES
-#define TFL_WF_PLANES 16
+#define TFL_WF_PLANES 8
 #endif
 #ifndef TFL_WF_DEPTH
 #define TFL_WF_DEPTH 16
 #endif
-constexpr int kWfRows = 64, kWfPlanes = TFL_WF_PLANES, kWfLag = 4, kWfDepth = TFL_WF_DEPTH, kWfMaxBlocks = 240;
+#ifndef TFL_WF_EDGE_GROUPS
+#define TFL_WF_EDGE_GROUPS 2
+#endif
+// kWfDepth: steps the operands are prefetched ahead; kWfEdgeGroups: groups of four steps the slab predecessor's pairs
+// are (a block can only run that far + the memory round trip behind its predecessor, so shorter is better here)
+constexpr int kWfRows = 64, kWfPlanes = TFL_WF_PLANES, kWfLag = 4, kWfDepth = TFL_WF_DEPTH, kWfEdgeGroups = TFL_WF_EDGE_GROUPS, kWfMaxBlocks = 240;
+static_assert(kWfEdgeGroups >= 1 && kWfEdgeGroups <= kWfDepth / 4, "edge prefetch within the operand window");
 static_assert(kWfDepth % 8 == 0 && kWfLag == 4, "groups of four steps, strip edges in groups of eight");
 
 struct WfGeom {
@@ -473,6 +479,17 @@ __device__ __forceinline__ int wf_reload_word(const int* p) {
 __device__ __forceinline__ float wf_value(unsigned long long u) { return __uint_as_float((unsigned)u); }
 __device__ __forceinline__ int wf_tag(unsigned long long u) { return (int)(u >> 32); }
 
+// lane i <- lane i + n (DIR > 0, row_shl:n) or lane i - n (row_shr:n) of its row of 16; n is a constant after unrolling
+template <int DIR>
+__device__ __forceinline__ int wf_row_shift(int v, int n) {
+#define TFL_WF_SHIFT(N) case N: return __builtin_amdgcn_update_dpp(0, v, (DIR > 0 ? 0x100 : 0x110) + N, 0xf, 0xf, true);
+  switch (n) {
+    TFL_WF_SHIFT(1) TFL_WF_SHIFT(2) TFL_WF_SHIFT(3) TFL_WF_SHIFT(4) TFL_WF_SHIFT(5) TFL_WF_SHIFT(6) TFL_WF_SHIFT(7)
+    default: return v;
+  }
+#undef TFL_WF_SHIFT
+}
+
 struct WfArrays {
   const float* cs;      // cc
   const float* in;      // forward: r; backward: q
@@ -524,11 +541,12 @@ __device__ __forceinline__ void wf_run(const WfGeom& g, const WfArrays& A, int t
     const int gm = grp(ig);
     cv[slot] = c4[(long long)gm * kWfRows];
     rv[slot] = i4[(long long)gm * kWfRows];
-    if (EDGE) {
-      const int gk = min(max(gm + kOffGK, 0), NG - 1);
+  };
+  auto issue_k = [&](int ig, int slot) {
+    if (!EDGE) return;
+    const int gk = min(max(grp(min(ig, NG - 1)) + kOffGK, 0), NG - 1);
 #pragma unroll
-      for (int j = 0; j < 4; j++) ekv[slot][j] = wf_load_pair(from_k + (long long)gk * (4 * kWfRows) + j);
-    }
+    for (int j = 0; j < 4; j++) ekv[slot][j] = wf_load_pair(from_k + (long long)gk * (4 * kWfRows) + j);
   };
   auto issue_s = [&](int it0, int slot) { esv[slot] = wf_load_pair(from_s + min(max(tau(it0 + (lane & 7)) + kOffS, 0), NT - 1)); };
   // re-read until every wanted pair carries this launch's tag (normally the prefetched one already does). The re-reads
@@ -538,8 +556,9 @@ __device__ __forceinline__ void wf_run(const WfGeom& g, const WfArrays& A, int t
     for (int spin = 0;; spin++) {
       if (want && wf_tag(v) != tag) v = wf_reload_pair(src);
       if (__ballot(want && wf_tag(v) != tag) == 0ull) return;
-      if (spin > (1 << 20) || wf_reload_word(A.err)) { atomicExch(A.err, 1); dead = true; return; }   // never hang the GPU
-      __builtin_amdgcn_s_sleep(2);
+      // never hang the GPU: give up after ~1 s, or when another wave already has (looked at every 64th retry only: the
+      // error word costs a memory round trip of its own)
+      if (spin > (1 << 20) || ((spin & 63) == 63 && wf_reload_word(A.err))) { atomicExch(A.err, 1); dead = true; return; }
     }
   };
 
@@ -563,9 +582,11 @@ __device__ __forceinline__ void wf_run(const WfGeom& g, const WfArrays& A, int t
           settle(esv[u >> 3], from_s + min(max(Ts, 0), NT - 1), want);
           if (!want) esv[u >> 3] = 0ull;
         }
-        // y neighbour: the lane below / above; the edge lane has no source lane and keeps `old` = the predecessor's value
-        const int es_bits = __builtin_amdgcn_readlane((int)(unsigned)esv[u >> 3], u & 7);
-        float nb_y = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(es_bits, __builtin_bit_cast(int, q_prev),
+        // y neighbour: the lane below / above. The edge lane (0 forward, 63 backward) has no source lane and keeps `old`,
+        // which a row shift has filled with the strip predecessor's value of this step (held by lane u % 8 of every
+        // group of eight lanes): two DPP moves, no scalar round trip
+        const int old = wf_row_shift<DIR>((int)(unsigned)esv[u >> 3], DIR > 0 ? (u & 7) : 7 - (u & 7));
+        float nb_y = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(old, __builtin_bit_cast(int, q_prev),
                                                                              DIR > 0 ? 0x138 /*wave_shr:1*/ : 0x130 /*wave_shl:1*/, 0xf, 0xf, false));
         asm volatile("" : "+v"(nb_y));
         float nb_z = below[u4];
@@ -600,6 +621,7 @@ __device__ __forceinline__ void wf_run(const WfGeom& g, const WfArrays& A, int t
         issue(ig + G, c);
         if ((c & 1) == 1) issue_s(t0 + D + (c - 1) * 4, c >> 1);
       }
+      issue_k(ig + kWfEdgeGroups, (c + kWfEdgeGroups) % G);     // (clamped past the end: those pairs are never looked at)
     }
   };
   // the prologue issues its loads in the order the loop does (operands of two groups, then those eight steps' edge
@@ -608,6 +630,7 @@ __device__ __forceinline__ void wf_run(const WfGeom& g, const WfArrays& A, int t
   for (int c = 0; c < G; c++) {
     issue(c, c);
     if ((c & 1) == 1) issue_s((c - 1) * 4, c >> 1);
+    if (c < kWfEdgeGroups) issue_k(c, c);
   }
   int t0 = 0;
   for (; t0 + D < NT; t0 += D) body(t0, std::true_type{});
