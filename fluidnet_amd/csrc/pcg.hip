@@ -51,6 +51,7 @@ struct PcgState {
   float alpha, beta;
   float tol2;
   int iter, max_iter, done, first, bad;   // bad: a NaN residual was seen
+  int pending;                            // an update's r.r partials have not been folded into rr1 yet
   double sum_x;
 };
 
@@ -160,14 +161,32 @@ __global__ __launch_bounds__(256) void k_pcg_begin(PcgState* __restrict__ S, con
   const double rr = reduce_partials(partials);
   if (threadIdx.x == 0) {
     S->rr1 = rr; S->rr0 = 0.0; S->num = 0.0; S->prev_num = 0.0; S->den = 0.0; S->alpha = 0.0f; S->beta = 0.0f;
-    S->tol2 = tol * tol; S->iter = 0; S->max_iter = max_iter; S->first = 1; S->sum_x = 0.0;
+    S->tol2 = tol * tol; S->iter = 0; S->max_iter = max_iter; S->first = 1; S->sum_x = 0.0; S->pending = 0;
     S->bad = (rr != rr) ? 1 : 0;
     S->done = (!((float)rr > S->tol2) || S->bad) ? 1 : 0;   // while (r_norm_sq1 > tol * tol && iter <= max_iter)
   }
 }
-// top of an iteration: the loop condition, then iter++
-__global__ void k_pcg_loop_top(PcgState* __restrict__ S) {
+// The scalar steps of an iteration (alpha, beta, the residual bookkeeping) ride at the head of the chip-wide kernel that
+// needs them: every block folds the 512 partial sums itself, in the same fixed order, and block 0 records the result
+// -- one launch per iteration for scalars (k_pcg_top) instead of four, which at 128^3 were a third of its time.
+// Each reduction has its own partials buffer (a block may still be reading the previous one).
+__device__ __forceinline__ void pcg_fold_residual(PcgState* __restrict__ S, double rr) {   // the end of an iteration
+  S->prev_num = S->num;
+  S->rr0 = S->rr1;
+  S->rr1 = rr;
+  S->first = 0;
+  S->pending = 0;
+  if (rr != rr) { S->bad = 1; S->done = 1; }
+}
+// end of the previous iteration (if one is pending), then the loop condition and iter++
+__global__ __launch_bounds__(256) void k_pcg_top(PcgState* __restrict__ S, const double* __restrict__ p_rr, int test) {
   if (S->done) return;
+  const int pending = S->pending;
+  double rr = 0.0;
+  if (pending) rr = reduce_partials(p_rr);
+  if (threadIdx.x != 0) return;
+  if (pending) pcg_fold_residual(S, rr);
+  if (S->done || !test) return;
   if (!((float)S->rr1 > S->tol2) || S->iter > S->max_iter) { S->done = 1; return; }
   S->iter++;
 }
@@ -179,27 +198,17 @@ __global__ __launch_bounds__(256) void k_pcg_dot(const PcgState* __restrict__ S,
   for (long long o = (long long)blockIdx.x * 256 + threadIdx.x; o < n; o += (long long)gridDim.x * 256) acc += (double)a[o] * b[o];
   block_partial(acc, partials);
 }
-// beta and the new search direction's scalar: num = r.z (preconditioned) from `partials`
-__global__ __launch_bounds__(256) void k_pcg_beta(PcgState* __restrict__ S, const double* __restrict__ partials, int precond) {
-  if (S->done) return;
-  double num = 0.0;
-  if (precond) num = reduce_partials(partials);
-  if (threadIdx.x != 0) return;
-  if (precond) {
-    // beta_k = r_{k-1}.z_{k-1} / (r_{k-2}.z_{k-2}); the second is last iteration's numerator
-    S->num = num;
-    S->beta = S->first ? 0.0f : (float)num / clamp_to_epsilon((float)S->prev_num);
-  } else {
-    S->num = S->rr1;
-    S->beta = S->first ? 0.0f : (float)S->rr1 / clamp_to_epsilon((float)S->rr0);
-  }
-}
-// s = z + beta * s   (iteration 1: s = z; the reference's scal-then-axpy order: (beta*s) + z)
-__global__ __launch_bounds__(256) void k_pcg_dir(const PcgState* __restrict__ S, long long n, const float* __restrict__ z,
-                                                 float* __restrict__ s) {
+// beta (num = r.z from `p_num` when preconditioned, else r.r), then s = z + beta * s
+// (iteration 1: s = z; the reference's scal-then-axpy order: (beta*s) + z)
+__global__ __launch_bounds__(256) void k_pcg_dir(PcgState* __restrict__ S, long long n, const double* __restrict__ p_num, int precond,
+                                                 const float* __restrict__ z, float* __restrict__ s) {
   if (S->done) return;
   const bool first = S->first != 0;
-  const float beta = S->beta;
+  double num = S->rr1;
+  if (precond) num = reduce_partials(p_num);
+  // beta_k = r_{k-1}.z_{k-1} / (r_{k-2}.z_{k-2}); the second is last iteration's numerator
+  const float beta = first ? 0.0f : (float)num / clamp_to_epsilon((float)(precond ? S->prev_num : S->rr0));
+  if (blockIdx.x == 0 && threadIdx.x == 0) { S->num = num; S->beta = beta; }
   for (long long o = (long long)blockIdx.x * 256 + threadIdx.x; o < n; o += (long long)gridDim.x * 256)
     s[o] = first ? z[o] : (beta * s[o] + 1.0f * z[o]);
 }
@@ -230,19 +239,15 @@ __global__ __launch_bounds__(256) void k_pcg_apply(const PcgState* __restrict__ 
   }
   block_partial(acc, partials);
 }
-__global__ __launch_bounds__(256) void k_pcg_alpha(PcgState* __restrict__ S, const double* __restrict__ partials) {
+// alpha = num / s.w (from `p_den`), then x += alpha s; r -= alpha w; partial r.r
+__global__ __launch_bounds__(256) void k_pcg_update(PcgState* __restrict__ S, long long n, const double* __restrict__ p_den,
+                                                    const float* __restrict__ s, const float* __restrict__ w, float* __restrict__ x,
+                                                    float* __restrict__ r, double* __restrict__ p_rr) {
   if (S->done) return;
-  const double den = reduce_partials(partials);
-  if (threadIdx.x != 0) return;
-  S->den = den;
-  S->alpha = (float)S->num / clamp_to_epsilon((float)den);
-}
-// x += alpha s; r -= alpha w; partial r.r
-__global__ __launch_bounds__(256) void k_pcg_update(const PcgState* __restrict__ S, long long n, const float* __restrict__ s,
-                                                    const float* __restrict__ w, float* __restrict__ x, float* __restrict__ r,
-                                                    double* __restrict__ partials) {
-  if (S->done) return;
-  const float alpha = S->alpha, nalpha = -alpha;
+  const double den = reduce_partials(p_den);
+  const float alpha = (float)S->num / clamp_to_epsilon((float)den), nalpha = -alpha;
+  if (blockIdx.x == 0 && threadIdx.x == 0) { S->den = den; S->alpha = alpha; S->pending = 1; }
+  __syncthreads();      // reduce_partials' shared scratch is reused by block_partial below
   double acc = 0.0;
   for (long long o = (long long)blockIdx.x * 256 + threadIdx.x; o < n; o += (long long)gridDim.x * 256) {
     x[o] = alpha * s[o] + x[o];
@@ -250,17 +255,7 @@ __global__ __launch_bounds__(256) void k_pcg_update(const PcgState* __restrict__
     r[o] = rv;
     acc += (double)rv * rv;
   }
-  block_partial(acc, partials);
-}
-__global__ __launch_bounds__(256) void k_pcg_end(PcgState* __restrict__ S, const double* __restrict__ partials) {
-  if (S->done) return;
-  const double rr = reduce_partials(partials);
-  if (threadIdx.x != 0) return;
-  S->prev_num = S->num;
-  S->rr0 = S->rr1;
-  S->rr1 = rr;
-  S->first = 0;
-  if (rr != rr) { S->bad = 1; S->done = 1; }
+  block_partial(acc, p_rr);
 }
 // sum of x over the component (for the mean), then p = x - mean on the component
 __global__ __launch_bounds__(256) void k_pcg_sum(long long n, const float* __restrict__ x, double* __restrict__ partials) {
@@ -684,7 +679,7 @@ inline int cdiv(long long a, int b) { return (int)((a + b - 1) / b); }
 long long pcg_workspace_floats(int Z, int Y, int X) {
   const long long n = (long long)Z * Y * X;
   // label, size_at (int32) + x, r, z, s, w, dg, y (fp32) + roots + partials/state (fp64, kept 8-byte aligned first)
-  return 2 * (kRedBlocks + 64) + 9 * n + kMaxComponents + 64 + (wf_usable(Z > 1, Z, Y, X) ? wf_floats(Z, Y, X) + 4 : 0);
+  return 2 * (3 * kRedBlocks + 64) + 9 * n + kMaxComponents + 64 + (wf_usable(Z > 1, Z, Y, X) ? wf_floats(Z, Y, X) + 4 : 0);
 }
 
 // Solves every component of every batch element. Returns 0, or a negative code with `msg` filled:
@@ -695,8 +690,10 @@ int pcg_solve(hipStream_t st, bool is3d, int B, int Z, int Y, int X, float* p, c
   const Dom d = make_dom(Z, Y, X);
   const long long n = d.sc;
   double* partials = reinterpret_cast<double*>(workspace);
-  PcgState* S = reinterpret_cast<PcgState*>(partials + kRedBlocks);
-  float* base = workspace + 2 * (kRedBlocks + 64);
+  double* p_den = partials + kRedBlocks;      // s.w
+  double* p_rr = partials + 2 * kRedBlocks;   // r.r of the update
+  PcgState* S = reinterpret_cast<PcgState*>(partials + 3 * kRedBlocks);
+  float* base = workspace + 2 * (3 * kRedBlocks + 64);
   int* label = reinterpret_cast<int*>(base);
   int* size_at = reinterpret_cast<int*>(base + n);
   float* x = base + 2 * n; float* r = base + 3 * n; float* z = base + 4 * n; float* s = base + 5 * n;
@@ -803,7 +800,7 @@ int pcg_solve(hipStream_t st, bool is3d, int B, int Z, int Y, int X, float* p, c
       const int chunk = verbose ? 1 : (pc ? (wf ? 16 : 4) : 32);
       for (;;) {
         for (int it = 0; it < chunk; it++) {
-          k_pcg_loop_top<<<1, 1, 0, st>>>(S);
+          k_pcg_top<<<1, 256, 0, st>>>(S, p_rr, 1);
           const float* dir_src = r;
           if (pc && wf) {
             // M^-1 r as two launches (pipelined wavefronts)
@@ -833,14 +830,12 @@ int pcg_solve(hipStream_t st, bool is3d, int B, int Z, int Y, int X, float* p, c
           }
           TFL_TIMED("k_pcg", st);
           if (pc) k_pcg_dot<<<kRedBlocks, 256, 0, st>>>(S, n, r, z, partials);
-          k_pcg_beta<<<1, 256, 0, st>>>(S, partials, pc ? 1 : 0);
-          k_pcg_dir<<<kRedBlocks, 256, 0, st>>>(S, n, dir_src, s);
-          if (is3d) k_pcg_apply<true><<<kRedBlocks, 256, 0, st>>>(S, d, fl, label, root, s, w, partials);
-          else k_pcg_apply<false><<<kRedBlocks, 256, 0, st>>>(S, d, fl, label, root, s, w, partials);
-          k_pcg_alpha<<<1, 256, 0, st>>>(S, partials);
-          k_pcg_update<<<kRedBlocks, 256, 0, st>>>(S, n, s, w, x, r, partials);
-          k_pcg_end<<<1, 256, 0, st>>>(S, partials);
+          k_pcg_dir<<<kRedBlocks, 256, 0, st>>>(S, n, partials, pc ? 1 : 0, dir_src, s);
+          if (is3d) k_pcg_apply<true><<<kRedBlocks, 256, 0, st>>>(S, d, fl, label, root, s, w, p_den);
+          else k_pcg_apply<false><<<kRedBlocks, 256, 0, st>>>(S, d, fl, label, root, s, w, p_den);
+          k_pcg_update<<<kRedBlocks, 256, 0, st>>>(S, n, p_den, s, w, x, r, p_rr);
         }
+        { TFL_TIMED("k_pcg", st); k_pcg_top<<<1, 256, 0, st>>>(S, p_rr, 0); }     // fold the last update's residual for the host
         if (!hip_ok(hipMemcpyAsync(&hs, S, sizeof(PcgState), hipMemcpyDeviceToHost, st), "memcpy state")) return -4;
         if (!hip_ok(hipStreamSynchronize(st), "sync")) return -4;
         if (verbose && !hs.done)
