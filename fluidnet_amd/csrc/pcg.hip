@@ -380,9 +380,12 @@ __global__ __launch_bounds__(256) void k_ilu_backward(const PcgState* __restrict
 #endif
 // kWfDepth: steps the operands are prefetched ahead; kWfEdgeGroups: groups of four steps the slab predecessor's pairs
 // are (a block can only run that far + the memory round trip behind its predecessor, so shorter is better here)
-constexpr int kWfRows = 64, kWfPlanes = TFL_WF_PLANES, kWfLag = 4, kWfDepth = TFL_WF_DEPTH, kWfEdgeGroups = TFL_WF_EDGE_GROUPS, kWfMaxBlocks = 240;
+#ifndef TFL_WF_LAG
+#define TFL_WF_LAG 2
+#endif
+constexpr int kWfRows = 64, kWfPlanes = TFL_WF_PLANES, kWfLag = TFL_WF_LAG, kWfDepth = TFL_WF_DEPTH, kWfEdgeGroups = TFL_WF_EDGE_GROUPS, kWfMaxBlocks = 240;
 static_assert(kWfEdgeGroups >= 1 && kWfEdgeGroups <= kWfDepth / 4, "edge prefetch within the operand window");
-static_assert(kWfDepth % 8 == 0 && kWfLag == 4, "groups of four steps, strip edges in groups of eight");
+static_assert(kWfDepth % 8 == 0 && (kWfLag == 1 || kWfLag == 2 || kWfLag == 4), "operands in groups of four steps, strip edges in groups of eight");
 
 struct WfGeom {
   int X, Y, Z, ns, nb, NT;     // strips, slabs, steps per sub-box (a multiple of kWfDepth)
@@ -485,6 +488,18 @@ __device__ __forceinline__ int wf_row_shift(int v, int n) {
 #undef TFL_WF_SHIFT
 }
 
+// kWfLag consecutive floats of one lane with one LDS access
+__device__ __forceinline__ void wf_lds_read(const float* p, float* v) {
+  if (kWfLag == 4) { const float4 t = *reinterpret_cast<const float4*>(p); v[0] = t.x; v[1] = t.y; v[2 % kWfLag] = t.z; v[3 % kWfLag] = t.w; }
+  else if (kWfLag == 2) { const float2 t = *reinterpret_cast<const float2*>(p); v[0] = t.x; v[1 % kWfLag] = t.y; }
+  else v[0] = *p;
+}
+__device__ __forceinline__ void wf_lds_write(float* p, const float* v) {
+  if (kWfLag == 4) *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1 % kWfLag], v[2 % kWfLag], v[3 % kWfLag]);
+  else if (kWfLag == 2) *reinterpret_cast<float2*>(p) = make_float2(v[0], v[1 % kWfLag]);
+  else *p = v[0];
+}
+
 struct WfArrays {
   const float* cs;      // cc
   const float* in;      // forward: r; backward: q
@@ -500,7 +515,7 @@ struct WfArrays {
 // and the unwanted values dropped at USE time), the retry loop's loads hidden in asm, the prologue issuing in loop
 // order -- because a conservative vmcnt(0) would drain the operand prefetch at every group.
 template <int DIR, bool EDGE>
-__device__ __forceinline__ void wf_run(const WfGeom& g, const WfArrays& A, int tag, float4 (*ring)[2][kWfRows]) {
+__device__ __forceinline__ void wf_run(const WfGeom& g, const WfArrays& A, int tag, float (*ring)[2][kWfRows][kWfLag]) {
   constexpr int D = kWfDepth, G = D / 4;
   const int blk = blockIdx.x, sidx = blk / g.nb, bidx = blk - sidx * g.nb;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -524,8 +539,9 @@ __device__ __forceinline__ void wf_run(const WfGeom& g, const WfArrays& A, int t
   const int nbw = DIR > 0 ? max(w - 1, 0) : min(w + 1, kWfPlanes - 1);
   auto tau = [&](int it) { return DIR > 0 ? it : NT - 1 - it; };
   auto grp = [&](int ig) { return DIR > 0 ? ig : NG - 1 - ig; };           // memory group of the ig-th group in time
-  constexpr int kOffS = DIR * (kWfRows - 1), kOffGK = DIR * (kWfLag * (kWfPlanes - 1) / 4);
-  static_assert(kWfLag * (kWfPlanes - 1) % 4 == 0, "the slab predecessor's groups line up with this block's");
+  constexpr int kOffS = DIR * (kWfRows - 1), kOffK = DIR * kWfLag * (kWfPlanes - 1);
+  // address of the slab predecessor's pair of step t (clamped into the array; unwanted pairs are dropped at use)
+  auto pair_k = [&](int t) { const int tc = min(max(t, 0), NT - 1); return from_k + (long long)(tc >> 2) * (4 * kWfRows) + (tc & 3); };
 
   // operands, prefetched G groups ahead into rotating registers (slot = group mod G; the loop below is unrolled by G)
   float4 cv[G], rv[G];
@@ -539,9 +555,9 @@ __device__ __forceinline__ void wf_run(const WfGeom& g, const WfArrays& A, int t
   };
   auto issue_k = [&](int ig, int slot) {
     if (!EDGE) return;
-    const int gk = min(max(grp(min(ig, NG - 1)) + kOffGK, 0), NG - 1);
+    const int tg = grp(min(ig, NG - 1)) * 4 + kOffK;     // the predecessor's step of this group's first pair in memory
 #pragma unroll
-    for (int j = 0; j < 4; j++) ekv[slot][j] = wf_load_pair(from_k + (long long)gk * (4 * kWfRows) + j);
+    for (int j = 0; j < 4; j++) ekv[slot][j] = wf_load_pair(pair_k(tg + j));
   };
   auto issue_s = [&](int it0, int slot) { esv[slot] = wf_load_pair(from_s + min(max(tau(it0 + (lane & 7)) + kOffS, 0), NT - 1)); };
   // re-read until every wanted pair carries this launch's tag (normally the prefetched one already does). The re-reads
@@ -562,44 +578,48 @@ __device__ __forceinline__ void wf_run(const WfGeom& g, const WfArrays& A, int t
 #pragma unroll
     for (int c = 0; c < G; c++) {
       const int ig = t0 / 4 + c, gm = grp(ig);
-      const float4 below4 = ring[nbw][(c & 1) ^ 1][lane];       // what the neighbour wave computed during the previous group
-      const float below[4] = {below4.x, below4.y, below4.z, below4.w};
       // in memory the group is ordered by t; backward walks it from its last element
       const float ccs[4] = {DIR > 0 ? cv[c].x : cv[c].w, DIR > 0 ? cv[c].y : cv[c].z, DIR > 0 ? cv[c].z : cv[c].y, DIR > 0 ? cv[c].w : cv[c].x};
       const float ins[4] = {DIR > 0 ? rv[c].x : rv[c].w, DIR > 0 ? rv[c].y : rv[c].z, DIR > 0 ? rv[c].z : rv[c].y, DIR > 0 ? rv[c].w : rv[c].x};
       float h4[4];
 #pragma unroll
-      for (int u4 = 0; u4 < 4; u4++) {
-        const int u = c * 4 + u4, it = t0 + u;
-        if ((u & 7) == 0) {
-          const int Ts = tau(it + (lane & 7)) + kOffS;
-          const bool want = has_s && Ts >= 0 && Ts < NT;
-          settle(esv[u >> 3], from_s + min(max(Ts, 0), NT - 1), want);
-          if (!want) esv[u >> 3] = 0ull;
+      for (int e = 0; e < 4 / kWfLag; e++) {       // LDS exchanges of this group: kWfLag steps each
+        const int par = (c * (4 / kWfLag) + e) & 1;
+        float below[kWfLag];       // what the neighbour wave computed during the previous exchange interval
+        wf_lds_read(&ring[nbw][par ^ 1][lane][0], below);
+#pragma unroll
+        for (int v = 0; v < kWfLag; v++) {
+          const int u4 = e * kWfLag + v, u = c * 4 + u4, it = t0 + u;
+          if ((u & 7) == 0) {
+            const int Ts = tau(it + (lane & 7)) + kOffS;
+            const bool want = has_s && Ts >= 0 && Ts < NT;
+            settle(esv[u >> 3], from_s + min(max(Ts, 0), NT - 1), want);
+            if (!want) esv[u >> 3] = 0ull;
+          }
+          // y neighbour: the lane below / above. The edge lane (0 forward, 63 backward) has no source lane and keeps `old`,
+          // which a row shift has filled with the strip predecessor's value of this step (held by lane u % 8 of every
+          // group of eight lanes): two DPP moves, no scalar round trip
+          const int old = wf_row_shift<DIR>((int)(unsigned)esv[u >> 3], DIR > 0 ? (u & 7) : 7 - (u & 7));
+          float nb_y = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(old, __builtin_bit_cast(int, q_prev),
+                                                                               DIR > 0 ? 0x138 /*wave_shr:1*/ : 0x130 /*wave_shl:1*/, 0xf, 0xf, false));
+          asm volatile("" : "+v"(nb_y));
+          float nb_z = below[v];
+          if (EDGE) {
+            const int tk = tau(it) + kOffK, j = DIR > 0 ? u4 : 3 - u4;
+            const bool want = has_k && tk >= 0 && tk < NT;        // wave-uniform
+            settle(ekv[c][j], pair_k(tk), want);
+            nb_z = want ? wf_value(ekv[c][j]) : 0.0f;
+          }
+          float res;
+          if (DIR > 0) res = (((ins[u4] + nb_z) + nb_y) + q_prev) * ccs[u4];
+          else res = __builtin_fmaf((q_prev + nb_y) + nb_z, ccs[u4], ins[u4]);
+          h4[u4] = res;
+          q_prev = res;
         }
-        // y neighbour: the lane below / above. The edge lane (0 forward, 63 backward) has no source lane and keeps `old`,
-        // which a row shift has filled with the strip predecessor's value of this step (held by lane u % 8 of every
-        // group of eight lanes): two DPP moves, no scalar round trip
-        const int old = wf_row_shift<DIR>((int)(unsigned)esv[u >> 3], DIR > 0 ? (u & 7) : 7 - (u & 7));
-        float nb_y = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(old, __builtin_bit_cast(int, q_prev),
-                                                                             DIR > 0 ? 0x138 /*wave_shr:1*/ : 0x130 /*wave_shl:1*/, 0xf, 0xf, false));
-        asm volatile("" : "+v"(nb_y));
-        float nb_z = below[u4];
-        if (EDGE) {
-          const int gk = gm + kOffGK, j = DIR > 0 ? u4 : 3 - u4;
-          const bool want = has_k && gk >= 0 && gk < NG;        // wave-uniform
-          settle(ekv[c][j], from_k + (long long)min(max(gk, 0), NG - 1) * (4 * kWfRows) + j, want);
-          nb_z = want ? wf_value(ekv[c][j]) : 0.0f;
-        }
-        float res;
-        if (DIR > 0) res = (((ins[u4] + nb_z) + nb_y) + q_prev) * ccs[u4];
-        else res = __builtin_fmaf((q_prev + nb_y) + nb_z, ccs[u4], ins[u4]);
-        h4[u4] = res;
-        q_prev = res;
+        wf_lds_write(&ring[w][par][lane][0], &h4[e * kWfLag]);
+        // workgroup barrier that waits for the LDS write only (__syncthreads() would also drain the operand prefetch)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
       }
-      ring[w][c & 1][lane] = make_float4(h4[0], h4[1], h4[2], h4[3]);
-      // workgroup barrier that waits for the LDS write only (__syncthreads() would also drain the operand prefetch)
-      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
       const float m4[4] = {DIR > 0 ? h4[0] : h4[3], DIR > 0 ? h4[1] : h4[2], DIR > 0 ? h4[2] : h4[1], DIR > 0 ? h4[3] : h4[0]};   // by t
       o4[(long long)gm * kWfRows] = make_float4(m4[0], m4[1], m4[2], m4[3]);
       if (out_k) {        // wave-uniform
@@ -635,10 +655,10 @@ __device__ __forceinline__ void wf_run(const WfGeom& g, const WfArrays& A, int t
 template <int DIR>
 __global__ __launch_bounds__(kWfPlanes * 64) void k_wf_sweep(const PcgState* __restrict__ S, WfGeom g, WfArrays A, int tag) {
   if (S->done) return;
-  __shared__ float4 ring[kWfPlanes][2][kWfRows];     // a wave's last two groups of four results, for the wave above / below
+  __shared__ __attribute__((aligned(16))) float ring[kWfPlanes][2][kWfRows][kWfLag];     // a wave's results of its last two exchange intervals
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  ring[w][0][lane] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-  ring[w][1][lane] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#pragma unroll
+  for (int v = 0; v < kWfLag; v++) ring[w][0][lane][v] = ring[w][1][lane][v] = 0.0f;
   __syncthreads();
   if (DIR > 0 ? w == 0 : w == kWfPlanes - 1) wf_run<DIR, true>(g, A, tag, ring);
   else wf_run<DIR, false>(g, A, tag, ring);
