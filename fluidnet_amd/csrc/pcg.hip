@@ -349,16 +349,16 @@ __global__ __launch_bounds__(256) void k_ilu_backward(const PcgState* __restrict
 // A lexicographic IC(0) / ILU(0) solve is a 3-D recurrence: cell (i, j, k) needs (i-1, j, k), (i, j-1, k), (i, j, k-1).
 // One launch per hyperplane (above) is X+Y+Z-6 launches per solve, ~760 per CG iteration at 128^3: 2.7 ms of launch
 // latency around ~20 us of arithmetic. Here a sweep is ONE launch:
-//   * the interior is cut into sub-boxes of 64 rows (j) x 16 planes (k) x all of x; a 1024-thread block owns one:
-//     wave w <-> plane, lane l <-> row, and at step t the thread works on the cell with (i-1) + l + 4 w = t. Its
-//     three predecessors were computed one step earlier by itself (x: a register), one step earlier by the lane below
-//     (y: one DPP wave shift) and FOUR steps earlier by the wave below (z). That lag of four lets the waves of a block
-//     exchange through LDS in groups of four steps: one 16-byte read, one 16-byte write and one barrier per group;
-//   * a block's steps are bound by its CU's vector-memory pipe (every operand and result of the sub-box passes
-//     through one CU: measured ~15 ns per wave and step with three accesses per step), so everything a sweep touches
-//     per cell sits in SKEWED arrays laid out [sub-box][plane][t / 4][row][t % 4]: per group of four steps a wave
-//     reads cc and r and writes its results with ONE 16-byte access each. Two chip-wide kernels per solve copy r
-//     into, and z out of, that layout (k_wf_skew);
+//   * the interior is cut into sub-boxes of 64 rows (j) x kWfPlanes (8) planes (k) x all of x; a 512-thread block owns
+//     one: wave w <-> plane, lane l <-> row, and at step t the thread works on the cell with (i-1) + l + kWfLag w = t.
+//     Its three predecessors were computed one step earlier by itself (x: a register), one step earlier by the lane
+//     below (y: one DPP wave shift) and kWfLag (2) steps earlier by the wave below (z). That lag lets the waves of a
+//     block exchange through LDS once per kWfLag steps: one 8-byte read, one 8-byte write and one barrier;
+//   * a block's steps are bound by its CU: four waves per SIMD take turns at ~12 instructions per step, and every
+//     operand and result of the sub-box passes through one CU's 64 B/clk vector-memory pipe. Hence two waves per SIMD
+//     (8 planes) and SKEWED arrays laid out [sub-box][plane][t / 4][row][t % 4]: per group of four steps a wave reads
+//     cc and r and writes its results with ONE 16-byte access each. Two chip-wide kernels per solve copy r into, and
+//     z out of, that layout (k_wf_skew);
 //   * sub-boxes depend on their lower j / k neighbours through global memory, with no flags and no fences: the edge
 //     plane and the edge lane of a block also store their results as 8-byte {value, tag} pairs (tag = the launch's
 //     sequence number) into hand-off arrays; the consumer prefetches them like any other operand and, if a tag is

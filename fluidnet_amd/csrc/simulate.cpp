@@ -212,9 +212,9 @@ int tfl_simulate_step(tfl_ctx* c, const tfl_sim_params* prm, const tfl_sim_state
     float* pws = ws + ((z.N + 1) & ~1ll);    // 8-byte aligned
     float res = 0.0f;
     // simulate.lua:283 hard-codes 'ic0', and so does this step unless pcgPrecond says otherwise. The lexicographic
-    // IC(0) / ILU(0) solves run as pipelined wavefronts (pcg.hip, two launches per application); at 128^3 the
-    // preconditioned solve takes ~2.8x the time of the unpreconditioned one on this machine (fewer iterations, each
-    // with two latency-bound sweeps): pcgPrecond = "none" buys that back at the price of more iterations within maxIter.
+    // IC(0) / ILU(0) solves run as pipelined wavefronts (pcg.hip, two launches per application); the preconditioned
+    // solve takes ~1.7x the time of the unpreconditioned one at 128^3 on this machine and 0.7x at 256^3 (a third of the
+    // iterations, each with two latency-bound sweeps): pcgPrecond = "none" trades that for more iterations within maxIter.
     rc = tfl_solveLinearSystemPCG(c, s->p, s->flags, &div, is3D, prm->pcgPrecond && prm->pcgPrecond[0] ? prm->pcgPrecond : "ic0",
                                   1e-4f, max_iter, 0, pws, ws_floats - (pws - ws), &res);
   } else {

@@ -271,7 +271,7 @@ def simulate(conf, mconf, batch, model, outputDiv=False):
         tfluids.velocityUpdateForward(U, flags, p)
     elif simMethod == "pcg":
         # simulate.lua:281-286: tol 1e-4, maxIter (default 100), 'ic0' -- the default here too (pipelined wavefront
-        # sweeps, pcg.hip); mconf.pcgPrecond = 'none' | 'ilu0' | 'ic0' overrides ('none' is ~2.8x faster per solve at
+        # sweeps, pcg.hip); mconf.pcgPrecond = 'none' | 'ilu0' | 'ic0' overrides ('none' is ~1.7x faster per solve at
         # 128^3 on this machine but needs ~3x the iterations, which matters under a small maxIter).
         div = batch.get("div")
         if div is None or div.shape != p.shape:

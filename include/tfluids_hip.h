@@ -345,7 +345,7 @@ typedef struct tfl_sim_params {      /* mconf of lib/simulate.lua (defaults of l
   const char* simMethod;             /* NULL | "convnet" | "jacobi" | "pcg" */
   int32_t maxIter;                   /* jacobi / pcg; <= 0 -> 100 */
   const char* pcgPrecond;            /* NULL = "ic0" like simulate.lua:283; "none" | "ilu0" | "ic0". The unpreconditioned
-                                        solve is ~2.8x faster per call at 128^3 here but takes ~3x the iterations */
+                                        solve is ~1.7x faster per call at 128^3 here (slower at 256^3) and takes ~3x the iterations */
   int32_t outputDiv;                 /* 1: return before the projection (simulate.lua:241-245) */
 } tfl_sim_params;
 
