@@ -349,22 +349,27 @@ __global__ __launch_bounds__(256) void k_ilu_backward(const PcgState* __restrict
 // A lexicographic IC(0) / ILU(0) solve is a 3-D recurrence: cell (i, j, k) needs (i-1, j, k), (i, j-1, k), (i, j, k-1).
 // One launch per hyperplane (above) is X+Y+Z-6 launches per solve, ~760 per CG iteration at 128^3: 2.7 ms of launch
 // latency around ~20 us of arithmetic. Here a sweep is ONE launch:
-//   * the interior is cut into sub-boxes of 64 rows (j) x kWfPlanes (8) planes (k) x all of x; a 512-thread block owns
-//     one: wave w <-> plane, lane l <-> row, and at step t the thread works on the cell with (i-1) + l + kWfLag w = t.
-//     Its three predecessors were computed one step earlier by itself (x: a register), one step earlier by the lane
-//     below (y: one DPP wave shift) and kWfLag (2) steps earlier by the wave below (z). That lag lets the waves of a
-//     block exchange through LDS once per kWfLag steps: one 8-byte read, one 8-byte write and one barrier;
-//   * a block's steps are bound by its CU: four waves per SIMD take turns at ~12 instructions per step, and every
+//   * the interior is cut into sub-boxes of 64 rows (j) x kWfPlanes (8) planes (k) x all of x; a block of 8 COMPUTE waves
+//     + 2 HELPER waves owns one: compute wave w <-> plane, lane l <-> row, and at step t the thread works on the cell
+//     with (i-1) + l + kWfLag w = t. Its three predecessors were computed one step earlier by itself (x: a register),
+//     one step earlier by the lane below (y: one DPP wave shift) and kWfLag (2) steps earlier by the wave below (z).
+//     That lag lets the waves of a block exchange through LDS once per kWfLag steps ("interval"): one 8-byte read, one
+//     8-byte write and one barrier. A step is a dependent chain of ~60 ns (tools/ubench/chain_latency.hip);
+//   * a block's steps are bound by its CU: four waves per SIMD would take turns at ~12 instructions per step, and every
 //     operand and result of the sub-box passes through one CU's 64 B/clk vector-memory pipe. Hence two waves per SIMD
 //     (8 planes) and SKEWED arrays laid out [sub-box][plane][t / 4][row][t % 4]: per group of four steps a wave reads
 //     cc and r and writes its results with ONE 16-byte access each. Two chip-wide kernels per solve copy r into, and
 //     z out of, that layout (k_wf_skew);
 //   * sub-boxes depend on their lower j / k neighbours through global memory, with no flags and no fences: the edge
-//     plane and the edge lane of a block also store their results as 8-byte {value, tag} pairs (tag = the launch's
-//     sequence number) into hand-off arrays; the consumer prefetches them like any other operand and, if a tag is
-//     not this launch's yet, re-reads until it is (bounded; an error word ends the solve instead of hanging the
-//     GPU). A consumer therefore settles by itself at the smallest lag behind its predecessor that memory latency
-//     allows.
+//     plane and the edge lanes of a block are also stored as 8-byte {value, tag} pairs (tag = the launch's sequence
+//     number) into hand-off arrays, and the consumer re-reads a pair until it carries this launch's tag (bounded; an
+//     error word ends the solve instead of hanging the GPU). All of that is the HELPER waves' job (one for the slab
+//     direction, one for the strips): they prefetch the predecessors' pairs a few intervals ahead, hand the values to
+//     the compute waves through the same LDS slots a neighbouring plane would use, and publish the block's own edge
+//     results out of those slots. The compute waves run a branch-free loop with nothing but their operand prefetch in
+//     flight -- a wave's loads complete in issue order, and with the short-fused pair loads in the same queue every
+//     operand prefetch had to arrive within their two groups (measured: memory latency / 8 per step, whatever the
+//     block's size). A consumer settles by itself at the smallest lag behind its predecessor that memory latency allows.
 // With c = 1/sqrt(d) (IC) or 1/d (ILU) and cc = c*c (IC) or c (ILU), both factorisations run the same recurrences:
 //   forward    q = (((r + q_z) + q_y) + q_x) * cc          (q = y * c of the reference's forward solve)
 //   backward   z = q + ((z_x + z_y) + z_z) * cc
@@ -375,17 +380,18 @@ __global__ __launch_bounds__(256) void k_ilu_backward(const PcgState* __restrict
 #ifndef TFL_WF_DEPTH
 #define TFL_WF_DEPTH 16
 #endif
-#ifndef TFL_WF_EDGE_GROUPS
-#define TFL_WF_EDGE_GROUPS 2
-#endif
-// kWfDepth: steps the operands are prefetched ahead; kWfEdgeGroups: groups of four steps the slab predecessor's pairs
-// are (a block can only run that far + the memory round trip behind its predecessor, so shorter is better here)
+// kWfDepth: steps the operands are prefetched ahead; kWfHelperAhead: exchange intervals the helper wave prefetches the
+// predecessors' pairs ahead (a block can only run that far + the memory round trip behind its predecessor)
 #ifndef TFL_WF_LAG
 #define TFL_WF_LAG 2
 #endif
-constexpr int kWfRows = 64, kWfPlanes = TFL_WF_PLANES, kWfLag = TFL_WF_LAG, kWfDepth = TFL_WF_DEPTH, kWfEdgeGroups = TFL_WF_EDGE_GROUPS, kWfMaxBlocks = 240;
-static_assert(kWfEdgeGroups >= 1 && kWfEdgeGroups <= kWfDepth / 4, "edge prefetch within the operand window");
-static_assert(kWfDepth % 8 == 0 && (kWfLag == 1 || kWfLag == 2 || kWfLag == 4), "operands in groups of four steps, strip edges in groups of eight");
+#ifndef TFL_WF_HELPER_AHEAD
+#define TFL_WF_HELPER_AHEAD 4
+#endif
+constexpr int kWfRows = 64, kWfPlanes = TFL_WF_PLANES, kWfLag = TFL_WF_LAG, kWfDepth = TFL_WF_DEPTH, kWfHelperAhead = TFL_WF_HELPER_AHEAD, kWfMaxBlocks = 240;
+static_assert(kWfDepth % 4 == 0 && (kWfLag == 1 || kWfLag == 2 || kWfLag == 4), "operands in groups of four steps");
+static_assert(kWfHelperAhead >= 1 && (kWfDepth / kWfLag) % kWfHelperAhead == 0, "the helper's rotating slots repeat with the unrolled loop");
+static_assert(kWfPlanes * kWfLag <= 64, "one helper lane per (plane, step of the interval)");
 
 struct WfGeom {
   int X, Y, Z, ns, nb, NT;     // strips, slabs, steps per sub-box (a multiple of kWfDepth)
@@ -407,8 +413,11 @@ inline bool wf_usable(bool is3d, int Z, int Y, int X) {
 }
 // floats of: cc, r, q, z (skewed) | the slab hand-off pairs [block][t / 4][row][t % 4] | the strip hand-off pairs
 // [block][plane][t] | the error word
-inline long long wf_handoff_k(const WfGeom& g) { return 2ll * g.ns * g.nb * g.NT * kWfRows; }
-inline long long wf_handoff_s(const WfGeom& g) { return 2ll * g.ns * g.nb * kWfPlanes * g.NT; }
+// (floats, including kWfGuard pairs of padding at either end: the helper wave reads up to kWfLag * (kWfPlanes - 1) resp. 63 steps
+// past a block's rows without clamping)
+constexpr long long kWfGuard = 4 * kWfRows * (kWfLag * (kWfPlanes - 1) / 4 + 2);        // pairs; >= 64 too
+inline long long wf_handoff_k(const WfGeom& g) { return 2ll * g.ns * g.nb * g.NT * kWfRows + 4 * kWfGuard; }
+inline long long wf_handoff_s(const WfGeom& g) { return 2ll * g.ns * g.nb * kWfPlanes * g.NT + 4 * kWfGuard; }
 inline long long wf_floats(int Z, int Y, int X) {
   const WfGeom g = wf_geom(Z, Y, X);
   return 4 * g.sub * g.ns * g.nb + wf_handoff_k(g) + wf_handoff_s(g) + 64;
@@ -455,13 +464,9 @@ __global__ __launch_bounds__(256) void k_wf_skew(const PcgState* __restrict__ S,
 __device__ __forceinline__ unsigned long long wf_load_pair(const float2* p) {
   return __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// two pairs with one 16-byte store (each aligned 8-byte half is written whole)
-__device__ __forceinline__ void wf_store_pairs2(float2* p, float v0, float v1, int tag) {
-  typedef float vec4 __attribute__((ext_vector_type(4)));
-  const vec4 u = {v0, __int_as_float(tag), v1, __int_as_float(tag)};
-  // s_nop: a VALU write to the data registers of a store wider than 8 bytes needs one wait state after it, and the
-  // compiler's hazard pass does not see inside asm
-  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 0" : : "v"(p), "v"(u) : "memory");
+__device__ __forceinline__ void wf_store_pair(float2* p, float v, int tag) {
+  const unsigned long long u = (unsigned long long)__float_as_uint(v) | ((unsigned long long)(unsigned)tag << 32);
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // the same loads for the retry path, opaque to the compiler's wait-count bookkeeping (they complete before they return)
 __device__ __forceinline__ unsigned long long wf_reload_pair(const float2* p) {
@@ -507,72 +512,36 @@ struct WfArrays {
   float2* hk;           // slab hand-off pairs of this launch's results
   float2* hs;           // strip hand-off pairs
   int* err;
+  long long* trace;     // TFL_WF_TRACE: [block][2] = wall clock (10 ns units) at a block's first and last step, else null
 };
 
-// One wave's share of a sweep. DIR = +1 forward (lower neighbours), -1 backward (upper neighbours, steps run from the
-// last to the first); EDGE: the wave whose z neighbour lives in the slab predecessor (plane 0 forward, 15 backward).
-// The loop is written so that hipcc's vmcnt bookkeeping stays exact -- no conditional loads (addresses are clamped
-// and the unwanted values dropped at USE time), the retry loop's loads hidden in asm, the prologue issuing in loop
-// order -- because a conservative vmcnt(0) would drain the operand prefetch at every group.
-template <int DIR, bool EDGE>
-__device__ __forceinline__ void wf_run(const WfGeom& g, const WfArrays& A, int tag, float (*ring)[2][kWfRows][kWfLag]) {
+// A COMPUTE wave's share of a sweep (wave w < kWfPlanes <-> plane). DIR = +1 forward (lower neighbours), -1 backward
+// (upper neighbours, steps run from the last to the first). It touches global memory only for its own operands and
+// results: what it needs from other sub-boxes arrives through LDS from the block's HELPER wave (below), in the same
+// slots and with the same lag as what it needs from the plane next door.
+template <int DIR>
+__device__ __forceinline__ void wf_compute(const WfGeom& g, const WfArrays& A, int tag, float (*ring)[2][kWfRows][kWfLag],
+                                           float (*edge_s)[kWfPlanes + 1][kWfLag]) {
   constexpr int D = kWfDepth, G = D / 4;
-  const int blk = blockIdx.x, sidx = blk / g.nb, bidx = blk - sidx * g.nb;
+  const int blk = blockIdx.x;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int NT = g.NT, NG = NT / 4;
-  // predecessor sub-boxes in j and k (forward: the lower ones) and the entries of theirs this thread's edge cells need:
-  // the strip predecessor's lane 63 (forward) / 0 (backward) of the same plane at step t +- 63, the slab predecessor's
-  // plane 15 / 0 at step t +- 4 * 15. Without a predecessor the pointers stay inside this block's own rows (never used).
-  const int ps = DIR > 0 ? (sidx > 0 ? blk - g.nb : -1) : (sidx + 1 < g.ns ? blk + g.nb : -1);
-  const int pk = DIR > 0 ? (bidx > 0 ? blk - 1 : -1) : (bidx + 1 < g.nb ? blk + 1 : -1);
-  const bool has_s = ps >= 0, has_k = pk >= 0;
-  const bool out_k = (DIR > 0 ? w == kWfPlanes - 1 : w == 0) && (DIR > 0 ? bidx + 1 < g.nb : bidx > 0);       // a slab successor reads this wave
-  const bool out_s = (DIR > 0 ? lane == kWfRows - 1 : lane == 0) && (DIR > 0 ? sidx + 1 < g.ns : sidx > 0);   // a strip successor reads this lane
   const long long base4 = ((long long)blk * kWfPlanes + w) * NG * kWfRows + lane;       // in float4 units; + group * 64
   const float4* c4 = reinterpret_cast<const float4*>(A.cs) + base4;
   const float4* i4 = reinterpret_cast<const float4*>(A.in) + base4;
   float4* o4 = reinterpret_cast<float4*>(A.out) + base4;
-  float2* hk_me = A.hk + ((long long)blk * NG * kWfRows + lane) * 4;                      // + group * 256 + t % 4
-  float2* hs_me = A.hs + ((long long)blk * kWfPlanes + w) * NT;                           // + t
-  const float2* from_k = A.hk + ((long long)(has_k ? pk : blk) * NG * kWfRows + lane) * 4;
-  const float2* from_s = A.hs + ((long long)(has_s ? ps : blk) * kWfPlanes + w) * NT;
-  const int nbw = DIR > 0 ? max(w - 1, 0) : min(w + 1, kWfPlanes - 1);
-  auto tau = [&](int it) { return DIR > 0 ? it : NT - 1 - it; };
+  // the wave whose results this one consumes with a lag: the plane below / above, or the helper (index kWfPlanes) for
+  // the plane that borders the slab predecessor
+  const int nbw = DIR > 0 ? (w > 0 ? w - 1 : kWfPlanes) : (w + 1 < kWfPlanes ? w + 1 : kWfPlanes);
   auto grp = [&](int ig) { return DIR > 0 ? ig : NG - 1 - ig; };           // memory group of the ig-th group in time
-  constexpr int kOffS = DIR * (kWfRows - 1), kOffK = DIR * kWfLag * (kWfPlanes - 1);
-  // address of the slab predecessor's pair of step t (clamped into the array; unwanted pairs are dropped at use)
-  auto pair_k = [&](int t) { const int tc = min(max(t, 0), NT - 1); return from_k + (long long)(tc >> 2) * (4 * kWfRows) + (tc & 3); };
 
   // operands, prefetched G groups ahead into rotating registers (slot = group mod G; the loop below is unrolled by G)
   float4 cv[G], rv[G];
-  unsigned long long ekv[G][4];   // EDGE: the slab predecessor's pairs of the group
-  unsigned long long esv[G / 2];  // lane l: the strip predecessor's edge-lane pair of step (8-group start + l % 8)
-  bool dead = false;              // a predecessor never delivered: stop waiting (the host sees the error word)
   auto issue = [&](int ig, int slot) {
     const int gm = grp(ig);
     cv[slot] = c4[(long long)gm * kWfRows];
     rv[slot] = i4[(long long)gm * kWfRows];
   };
-  auto issue_k = [&](int ig, int slot) {
-    if (!EDGE) return;
-    const int tg = grp(min(ig, NG - 1)) * 4 + kOffK;     // the predecessor's step of this group's first pair in memory
-#pragma unroll
-    for (int j = 0; j < 4; j++) ekv[slot][j] = wf_load_pair(pair_k(tg + j));
-  };
-  auto issue_s = [&](int it0, int slot) { esv[slot] = wf_load_pair(from_s + min(max(tau(it0 + (lane & 7)) + kOffS, 0), NT - 1)); };
-  // re-read until every wanted pair carries this launch's tag (normally the prefetched one already does). The re-reads
-  // are issued AND waited for inside one asm statement, invisible to the compiler's wait counting
-  auto settle = [&](unsigned long long& v, const float2* src, bool want) {
-    if (dead || __ballot(want && wf_tag(v) != tag) == 0ull) return;
-    for (int spin = 0;; spin++) {
-      if (want && wf_tag(v) != tag) v = wf_reload_pair(src);
-      if (__ballot(want && wf_tag(v) != tag) == 0ull) return;
-      // never hang the GPU: give up after ~1 s, or when another wave already has (looked at every 64th retry only: the
-      // error word costs a memory round trip of its own)
-      if (spin > (1 << 20) || ((spin & 63) == 63 && wf_reload_word(A.err))) { atomicExch(A.err, 1); dead = true; return; }
-    }
-  };
-
   float q_prev = 0.0f;      // this thread's previous result (forward: q, backward: z)
   auto body = [&](int t0, auto more) {
 #pragma unroll
@@ -585,34 +554,19 @@ __device__ __forceinline__ void wf_run(const WfGeom& g, const WfArrays& A, int t
 #pragma unroll
       for (int e = 0; e < 4 / kWfLag; e++) {       // LDS exchanges of this group: kWfLag steps each
         const int par = (c * (4 / kWfLag) + e) & 1;
-        float below[kWfLag];       // what the neighbour wave computed during the previous exchange interval
-        wf_lds_read(&ring[nbw][par ^ 1][lane][0], below);
+        float below[kWfLag], edge[kWfLag];
+        wf_lds_read(&ring[nbw][par ^ 1][lane][0], below);      // what the neighbour wave computed during the previous interval
+        wf_lds_read(&edge_s[par ^ 1][w][0], edge);             // the strip predecessor's values for the edge lane (every lane reads them)
 #pragma unroll
         for (int v = 0; v < kWfLag; v++) {
-          const int u4 = e * kWfLag + v, u = c * 4 + u4, it = t0 + u;
-          if ((u & 7) == 0) {
-            const int Ts = tau(it + (lane & 7)) + kOffS;
-            const bool want = has_s && Ts >= 0 && Ts < NT;
-            settle(esv[u >> 3], from_s + min(max(Ts, 0), NT - 1), want);
-            if (!want) esv[u >> 3] = 0ull;
-          }
-          // y neighbour: the lane below / above. The edge lane (0 forward, 63 backward) has no source lane and keeps `old`,
-          // which a row shift has filled with the strip predecessor's value of this step (held by lane u % 8 of every
-          // group of eight lanes): two DPP moves, no scalar round trip
-          const int old = wf_row_shift<DIR>((int)(unsigned)esv[u >> 3], DIR > 0 ? (u & 7) : 7 - (u & 7));
-          float nb_y = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(old, __builtin_bit_cast(int, q_prev),
+          const int u4 = e * kWfLag + v;
+          // y neighbour: the lane below / above; the edge lane (0 forward, 63 backward) has no source lane and keeps `old`
+          float nb_y = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, edge[v]), __builtin_bit_cast(int, q_prev),
                                                                                DIR > 0 ? 0x138 /*wave_shr:1*/ : 0x130 /*wave_shl:1*/, 0xf, 0xf, false));
           asm volatile("" : "+v"(nb_y));
-          float nb_z = below[v];
-          if (EDGE) {
-            const int tk = tau(it) + kOffK, j = DIR > 0 ? u4 : 3 - u4;
-            const bool want = has_k && tk >= 0 && tk < NT;        // wave-uniform
-            settle(ekv[c][j], pair_k(tk), want);
-            nb_z = want ? wf_value(ekv[c][j]) : 0.0f;
-          }
           float res;
-          if (DIR > 0) res = (((ins[u4] + nb_z) + nb_y) + q_prev) * ccs[u4];
-          else res = __builtin_fmaf((q_prev + nb_y) + nb_z, ccs[u4], ins[u4]);
+          if (DIR > 0) res = (((ins[u4] + below[v]) + nb_y) + q_prev) * ccs[u4];
+          else res = __builtin_fmaf((q_prev + nb_y) + below[v], ccs[u4], ins[u4]);
           h4[u4] = res;
           q_prev = res;
         }
@@ -622,46 +576,152 @@ __device__ __forceinline__ void wf_run(const WfGeom& g, const WfArrays& A, int t
       }
       const float m4[4] = {DIR > 0 ? h4[0] : h4[3], DIR > 0 ? h4[1] : h4[2], DIR > 0 ? h4[2] : h4[1], DIR > 0 ? h4[3] : h4[0]};   // by t
       o4[(long long)gm * kWfRows] = make_float4(m4[0], m4[1], m4[2], m4[3]);
-      if (out_k) {        // wave-uniform
-        float2* dst = hk_me + (long long)gm * (4 * kWfRows);
-        wf_store_pairs2(dst, m4[0], m4[1], tag);
-        wf_store_pairs2(dst + 2, m4[2], m4[3], tag);
-      }
-      if (out_s) {        // one lane
-        float2* dst = hs_me + gm * 4;
-        wf_store_pairs2(dst, m4[0], m4[1], tag);
-        wf_store_pairs2(dst + 2, m4[2], m4[3], tag);
-      }
-      if constexpr (decltype(more)::value) {
-        issue(ig + G, c);
-        if ((c & 1) == 1) issue_s(t0 + D + (c - 1) * 4, c >> 1);
-      }
-      issue_k(ig + kWfEdgeGroups, (c + kWfEdgeGroups) % G);     // (clamped past the end: those pairs are never looked at)
+      if constexpr (decltype(more)::value) issue(ig + G, c);
     }
   };
-  // the prologue issues its loads in the order the loop does (operands of two groups, then those eight steps' edge
-  // pairs): the loop's waits are sized for the worse of "entered from here" and "came round the back edge"
 #pragma unroll
-  for (int c = 0; c < G; c++) {
-    issue(c, c);
-    if ((c & 1) == 1) issue_s((c - 1) * 4, c >> 1);
-    if (c < kWfEdgeGroups) issue_k(c, c);
-  }
+  for (int c = 0; c < G; c++) issue(c, c);
+  if (A.trace && threadIdx.x == 0) A.trace[blk * 2] = wall_clock64();
+  // the helper has to deliver the first interval's edge values before anyone starts (it is the "+1" of this barrier)
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   int t0 = 0;
   for (; t0 + D < NT; t0 += D) body(t0, std::true_type{});
   body(t0, std::false_type{});
+  if (A.trace && threadIdx.x == 0) A.trace[blk * 2 + 1] = wall_clock64();
+}
+
+// The HELPER wave of a block (wave index kWfPlanes): it alone reads what other sub-boxes hand over, and passes it on
+// through LDS one exchange interval ahead of its use, in step with the block's barriers:
+//   ring[kWfPlanes][.][lane][.]  the slab predecessor's edge-plane values  -> read by the bordering plane as its "plane next door"
+//   edge_s[.][w][.]              the strip predecessor's edge-lane values of plane w -> the DPP `old` of every compute wave
+// Its loads are the only ones in the block with a short fuse (the pairs exist only a few steps before they are needed),
+// and a wave's loads complete in issue order: in a compute wave they made every operand prefetch issued before them
+// wait in line (measured: each step of every block then cost memory latency / 8, whatever the block's size). Here they
+// have a wave -- and a vmcnt -- of their own. Pairs are prefetched kWfHelperAhead intervals ahead, checked against this
+// launch's tag and re-read until they carry it (bounded; an error word ends the solve instead of hanging the GPU).
+template <int DIR, int ROLE>
+__device__ __forceinline__ void wf_helper(const WfGeom& g, const WfArrays& A, int tag, float (*ring)[2][kWfRows][kWfLag],
+                                          float (*edge_s)[kWfPlanes + 1][kWfLag]) {
+  constexpr int P = kWfHelperAhead, NI = kWfDepth / kWfLag;     // the loop is unrolled by NI intervals (one compute body); NI % P == 0
+  constexpr bool SLAB = ROLE == 0;
+  const int blk = blockIdx.x, sidx = blk / g.nb, bidx = blk - sidx * g.nb;
+  const int lane = threadIdx.x & 63;
+  const int NT = g.NT, NG = NT / 4;
+  const int ps = DIR > 0 ? (sidx > 0 ? blk - g.nb : -1) : (sidx + 1 < g.ns ? blk + g.nb : -1);
+  const int pk = DIR > 0 ? (bidx > 0 ? blk - 1 : -1) : (bidx + 1 < g.nb ? blk + 1 : -1);
+  const bool has_pred = SLAB ? pk >= 0 : ps >= 0;
+  const bool has_succ = SLAB ? (DIR > 0 ? bidx + 1 < g.nb : bidx > 0) : (DIR > 0 ? sidx + 1 < g.ns : sidx > 0);     // someone reads what this block publishes
+  // SLAB: lane <-> row of the edge plane, kWfLag pairs per interval. STRIP: lane = w * kWfLag + v <-> (plane w, step v in
+  // memory order of the interval) of the edge lane; the lanes beyond that work on a spare row / the guard padding
+  const int sw = min(lane / kWfLag, kWfPlanes), sv = lane % kWfLag;
+  const bool live = SLAB || lane < kWfPlanes * kWfLag;
+  const float2* from = SLAB ? A.hk + ((long long)(has_pred ? pk : blk) * NG * kWfRows + lane) * 4
+                            : A.hs + ((long long)(has_pred ? ps : blk) * kWfPlanes + min(sw, kWfPlanes - 1)) * NT;
+  float2* mine = SLAB ? A.hk + ((long long)blk * NG * kWfRows + lane) * 4 : A.hs + ((long long)blk * kWfPlanes + min(sw, kWfPlanes - 1)) * NT;
+  constexpr int kOff = SLAB ? DIR * kWfLag * (kWfPlanes - 1) : DIR * (kWfRows - 1);
+  constexpr int NV = SLAB ? kWfLag : 1;       // pairs per lane and interval
+  // the first step IN MEMORY ORDER of interval iv (an interval's kWfLag steps are consecutive in t, and so are their pairs
+  // in both hand-off arrays: kOff of the slab is a multiple of kWfLag and a group of four steps never splits an interval)
+  auto t_lo = [&](int iv) { return DIR > 0 ? iv * kWfLag : NT - (iv + 1) * kWfLag; };
+  // addresses are NOT clamped: both arrays carry kWfGuard pairs of padding at either end (wf_floats), a pair outside
+  // [0, NT) is loaded from a neighbouring block's rows or the padding and never looked at
+  auto at = [&](const float2* base, int t) { return SLAB ? base + (long long)(t >> 2) * (4 * kWfRows) + (t & 3) : base + (t + sv); };
+
+  unsigned long long pv[P][NV];      // rotating: the pairs of interval (index mod P)
+  bool dead = false;
+  auto issue = [&](int iv, int slot) {
+    const float2* src = at(from, t_lo(iv) + kOff);
+#pragma unroll
+    for (int v = 0; v < NV; v++) pv[slot][v] = wf_load_pair(src + v);
+  };
+  // deliver interval iv's values into the slots the compute waves read during interval iv (parity of iv, inverted). A
+  // helper is one wave running a serial instruction stream in step with eight that do ~25 instructions per interval: its
+  // fast path is straight-line (one test and branch for all the interval's pairs); re-reading is the rare path
+  auto deliver = [&](int iv, int slot) {
+    const int par = iv & 1;
+    const int tp = t_lo(iv) + kOff + (SLAB ? 0 : sv);
+    const bool want = has_pred && live && tp >= 0 && tp < NT;       // SLAB: wave-uniform, the same for the interval's steps
+    bool stale = false;
+#pragma unroll
+    for (int v = 0; v < NV; v++) stale |= want && wf_tag(pv[slot][v]) != tag;
+    if (__builtin_expect(__ballot(stale) != 0ull, 0) && !dead) {
+      for (int spin = 0;; spin++) {
+        bool again = false;
+#pragma unroll
+        for (int v = 0; v < NV; v++) {
+          if (want && wf_tag(pv[slot][v]) != tag) pv[slot][v] = wf_reload_pair(at(from, t_lo(iv) + kOff) + v);
+          again |= want && wf_tag(pv[slot][v]) != tag;
+        }
+        if (__ballot(again) == 0ull) break;
+        // never hang the GPU: give up after ~1 s, or when another block already has (looked at every 64th retry only)
+        if (spin > (1 << 20) || ((spin & 63) == 63 && wf_reload_word(A.err))) { atomicExch(A.err, 1); dead = true; break; }
+      }
+    }
+    if (SLAB) {
+      float kval[kWfLag];     // in TIME order of the interval's steps, like a compute wave's results
+#pragma unroll
+      for (int v = 0; v < kWfLag; v++) kval[v] = want ? wf_value(pv[slot][DIR > 0 ? v : kWfLag - 1 - v]) : 0.0f;
+      wf_lds_write(&ring[kWfPlanes][par ^ 1][lane][0], kval);
+    } else {
+      edge_s[par ^ 1][sw][DIR > 0 ? sv : kWfLag - 1 - sv] = want ? wf_value(pv[slot][0]) : 0.0f;
+    }
+  };
+  // publish interval iv's results of the block's edge plane (-> the slab successor) resp. of every plane's edge lane (->
+  // the strip successor) as {value, tag} pairs, out of the LDS slots the compute waves wrote them to during interval iv
+  // (stable until the barrier that ends interval iv + 1): the compute waves carry no hand-off code at all
+  auto publish = [&](int iv, int ptag) {
+    if (!has_succ) return;        // block-uniform
+    const int par = iv & 1;
+    float res[kWfLag];            // time order
+    wf_lds_read(SLAB ? &ring[DIR > 0 ? kWfPlanes - 1 : 0][par][lane][0] : &ring[min(sw, kWfPlanes - 1)][par][DIR > 0 ? kWfRows - 1 : 0][0], res);
+    float2* dst = live ? const_cast<float2*>(at(mine, t_lo(iv))) : A.hs - 1 - lane;       // idle lanes: into the guard padding
+    if (SLAB) {
+#pragma unroll
+      for (int v = 0; v < kWfLag; v++) wf_store_pair(dst + v, res[DIR > 0 ? v : kWfLag - 1 - v], ptag);
+    } else {
+      float one = res[0];
+#pragma unroll
+      for (int v = 1; v < kWfLag; v++) one = (DIR > 0 ? sv : kWfLag - 1 - sv) == v ? res[v] : one;
+      wf_store_pair(dst, one, live ? ptag : 0);
+    }
+  };
+  const int n_iv = NT / kWfLag;
+#pragma unroll
+  for (int i = 0; i < P; i++) issue(i, i);
+  deliver(0, 0);
+  issue(P, 0);
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // the compute waves' start barrier
+  // during interval iv a helper publishes interval iv - 1, delivers interval iv + 1 and prefetches interval iv + 1 + P
+  for (int iv0 = 0; iv0 < n_iv; iv0 += NI) {
+#pragma unroll
+    for (int i = 0; i < NI; i++) {
+      // no branch around the loads (hipcc sizes the loop's vmcnt waits for the path that issues fewest): past the end the
+      // last interval is delivered again, into slots nobody reads any more
+      const int iv = iv0 + i;
+      publish(max(iv - 1, 0), iv > 0 ? tag : 0);          // (interval 0 has nothing behind it: a pair nobody will accept)
+      deliver(min(iv + 1, n_iv - 1), (i + 1) % P);
+      issue(min(iv + 1 + P, n_iv - 1), (i + 1) % P);
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+  }
+  publish(n_iv - 1, tag);
 }
 
 template <int DIR>
-__global__ __launch_bounds__(kWfPlanes * 64) void k_wf_sweep(const PcgState* __restrict__ S, WfGeom g, WfArrays A, int tag) {
+__global__ __launch_bounds__((kWfPlanes + 2) * 64) void k_wf_sweep(const PcgState* __restrict__ S, WfGeom g, WfArrays A, int tag) {
   if (S->done) return;
-  __shared__ __attribute__((aligned(16))) float ring[kWfPlanes][2][kWfRows][kWfLag];     // a wave's results of its last two exchange intervals
+  __shared__ __attribute__((aligned(16))) float ring[kWfPlanes + 1][2][kWfRows][kWfLag];   // results of a wave's last two exchange intervals
+  __shared__ __attribute__((aligned(16))) float edge_s[2][kWfPlanes + 1][kWfLag];     // [.][kWfPlanes]: spare row for the helper's idle lanes
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (w <= kWfPlanes) {
 #pragma unroll
-  for (int v = 0; v < kWfLag; v++) ring[w][0][lane][v] = ring[w][1][lane][v] = 0.0f;
+    for (int v = 0; v < kWfLag; v++) ring[w][0][lane][v] = ring[w][1][lane][v] = 0.0f;
+  }
+  if (threadIdx.x < 2 * (kWfPlanes + 1) * kWfLag) (&edge_s[0][0][0])[threadIdx.x] = 0.0f;
   __syncthreads();
-  if (DIR > 0 ? w == 0 : w == kWfPlanes - 1) wf_run<DIR, true>(g, A, tag, ring);
-  else wf_run<DIR, false>(g, A, tag, ring);
+  if (w < kWfPlanes) wf_compute<DIR>(g, A, tag, ring, edge_s);
+  else if (w == kWfPlanes) wf_helper<DIR, 0>(g, A, tag, ring, edge_s);
+  else wf_helper<DIR, 1>(g, A, tag, ring, edge_s);
 }
 
 // ---- normalizePressureMean (generic/tfluids.cc:845-925): p -= mean of p over the cell's fluid component ----
@@ -730,10 +790,14 @@ int pcg_solve(hipStream_t st, bool is3d, int B, int Z, int Y, int X, float* p, c
   float* rsk = wf ? cs + wtot : nullptr;
   float* qsk = wf ? cs + 2 * wtot : nullptr;
   float* zsk = wf ? cs + 3 * wtot : nullptr;
-  float2* wf_hk = wf ? reinterpret_cast<float2*>(cs + 4 * wtot) : nullptr;       // 16-byte aligned: wtot is a multiple of 1024
-  float2* wf_hs = wf ? reinterpret_cast<float2*>(cs + 4 * wtot + wf_handoff_k(wg)) : nullptr;
+  float2* wf_hk = wf ? reinterpret_cast<float2*>(cs + 4 * wtot) + kWfGuard : nullptr;       // 16-byte aligned: wtot is a multiple of 1024
+  float2* wf_hs = wf ? reinterpret_cast<float2*>(cs + 4 * wtot + wf_handoff_k(wg)) + kWfGuard : nullptr;
   int* wferr = wf ? reinterpret_cast<int*>(cs + 4 * wtot + wf_handoff_k(wg) + wf_handoff_s(wg)) : nullptr;
   int epoch = 0;                                // tag of the next sweep launch; the skewed arrays are zeroed with it
+  // development aid: TFL_WF_TRACE=1 prints when every sub-box of the last forward / backward sweep started and finished
+  static const bool wf_trace_on = getenv("TFL_WF_TRACE") != nullptr;
+  long long* wf_trace = nullptr;
+  if (wf && wf_trace_on && precond && hipMalloc(&wf_trace, sizeof(long long) * 4 * kWfMaxBlocks) != hipSuccess) wf_trace = nullptr;
   auto hip_ok = [&](hipError_t e, const char* what) {
     if (e == hipSuccess) return true;
     snprintf(msg, msg_len, "solveLinearSystemPCG: %s: %s", what, hipGetErrorString(e));
@@ -828,8 +892,8 @@ int pcg_solve(hipStream_t st, bool is3d, int B, int Z, int Y, int X, float* p, c
             const int gb = cdiv((long long)(X - 2) * (Y - 2) * (Z - 2), 256);
             { TFL_TIMED("k_pcg_precond", st);
               k_wf_skew<true><<<gb, 256, 0, st>>>(S, wg, d, r, rsk);
-              k_wf_sweep<1><<<nblk, kWfPlanes * 64, 0, st>>>(S, wg, WfArrays{cs, rsk, qsk, wf_hk, wf_hs, wferr}, ++epoch);
-              k_wf_sweep<-1><<<nblk, kWfPlanes * 64, 0, st>>>(S, wg, WfArrays{cs, qsk, zsk, wf_hk, wf_hs, wferr}, ++epoch);
+              k_wf_sweep<1><<<nblk, (kWfPlanes + 2) * 64, 0, st>>>(S, wg, WfArrays{cs, rsk, qsk, wf_hk, wf_hs, wferr, wf_trace}, ++epoch);
+              k_wf_sweep<-1><<<nblk, (kWfPlanes + 2) * 64, 0, st>>>(S, wg, WfArrays{cs, qsk, zsk, wf_hk, wf_hs, wferr, wf_trace ? wf_trace + 2 * nblk : nullptr}, ++epoch);
               k_wf_skew<false><<<gb, 256, 0, st>>>(S, wg, d, z, zsk); }
             dir_src = z;
           } else if (pc) {
@@ -875,6 +939,19 @@ int pcg_solve(hipStream_t st, bool is3d, int B, int Z, int Y, int X, float* p, c
         k_pcg_sum_end<<<1, 256, 0, st>>>(S, partials);
         k_pcg_write<<<kRedBlocks, 256, 0, st>>>(S, n, label, root, size, x, pb); }
     }
+  }
+  if (wf_trace) {
+    const int nblk = wg.ns * wg.nb;
+    std::vector<long long> t(4 * nblk);
+    if (hipMemcpy(t.data(), wf_trace, sizeof(long long) * 4 * nblk, hipMemcpyDeviceToHost) == hipSuccess) {
+      long long t0 = t[0];
+      for (int i = 0; i < 4 * nblk; i++) if (t[i] && t[i] < t0) t0 = t[i];
+      for (int dir = 0; dir < 2; dir++)
+        for (int b2 = 0; b2 < nblk; b2++)
+          fprintf(stderr, "[tfl] wf %s strip %d slab %2d: start %8.2f us  end %8.2f us\n", dir ? "bwd" : "fwd", b2 / wg.nb, b2 % wg.nb,
+                  (t[dir * 2 * nblk + 2 * b2] - t0) * 0.01, (t[dir * 2 * nblk + 2 * b2 + 1] - t0) * 0.01);
+    }
+    (void)hipFree(wf_trace);
   }
   if (residual) *residual = max_res;
   return 0;
