@@ -446,6 +446,8 @@ class GraphedSimulate:
         self.graph.replay()
 
     def __del__(self):
-        tfluids._tmp.pop((self.batch["UDiv"].device.index, ("graph", id(self))), None)
+        tmp = getattr(tfluids, "_tmp", None) if tfluids is not None else None      # both are None during interpreter shutdown
+        if tmp is not None:
+            tmp.pop((self.batch["UDiv"].device.index, ("graph", id(self))), None)
 
     __call__ = step
