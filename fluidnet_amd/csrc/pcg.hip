@@ -482,17 +482,6 @@ __device__ __forceinline__ int wf_reload_word(const int* p) {
 __device__ __forceinline__ float wf_value(unsigned long long u) { return __uint_as_float((unsigned)u); }
 __device__ __forceinline__ int wf_tag(unsigned long long u) { return (int)(u >> 32); }
 
-// lane i <- lane i + n (DIR > 0, row_shl:n) or lane i - n (row_shr:n) of its row of 16; n is a constant after unrolling
-template <int DIR>
-__device__ __forceinline__ int wf_row_shift(int v, int n) {
-#define TFL_WF_SHIFT(N) case N: return __builtin_amdgcn_update_dpp(0, v, (DIR > 0 ? 0x100 : 0x110) + N, 0xf, 0xf, true);
-  switch (n) {
-    TFL_WF_SHIFT(1) TFL_WF_SHIFT(2) TFL_WF_SHIFT(3) TFL_WF_SHIFT(4) TFL_WF_SHIFT(5) TFL_WF_SHIFT(6) TFL_WF_SHIFT(7)
-    default: return v;
-  }
-#undef TFL_WF_SHIFT
-}
-
 // kWfLag consecutive floats of one lane with one LDS access
 __device__ __forceinline__ void wf_lds_read(const float* p, float* v) {
   if (kWfLag == 4) { const float4 t = *reinterpret_cast<const float4*>(p); v[0] = t.x; v[1] = t.y; v[2 % kWfLag] = t.z; v[3 % kWfLag] = t.w; }
