@@ -334,7 +334,7 @@ def test_vec4_kernels_and_their_fallbacks_match_the_oracle(no_vec4):
 @pytest.mark.parametrize("dims,seed,split,B,tol", [((1, 24, 28), 3, False, 1, 1e-5), ((9, 11, 13), 4, False, 2, 1e-5),
                                                   ((1, 30, 34), 5, True, 1, 1e-5), ((8, 10, 16), 6, True, 1, 1e-5),
                                                   ((24, 20, 36), 8, False, 1, 1e-4), ((1, 96, 128), 9, True, 1, 1e-4),
-                                                  # 3 strips x 3 slabs of the pipelined wavefront sweeps (64 rows x 16 planes each)
+                                                  # 3 strips x 5 slabs of the pipelined wavefront sweeps (64 rows x 8 planes each)
                                                   ((36, 134, 22), 10, True, 1, 1e-4)])
 def test_hip_pcg_matches_the_oracle_and_the_reference_properties(hip, oracle, dims, seed, split, B, tol):
     """The matrix-free device PCG (pcg.hip) against the CSR restatement of the reference's cuSPARSE/cuBLAS solver:
@@ -357,6 +357,41 @@ def test_hip_pcg_matches_the_oracle_and_the_reference_properties(hip, oracle, di
         d2 = np.zeros_like(div)
         hip.velocityDivergenceForward(Un, f, d2)
         assert np.abs(d2).max() < max(3e-5 * max(1.0, np.abs(div).max()), 2 * tol), (pc, np.abs(d2).max())
+
+
+_PCG_FALLBACK = """
+import sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import numpy as np
+import scenes
+from hip_adapter import HipTfluids
+from oracle.oracle import OracleTfluids
+hip, ora = HipTfluids(), OracleTfluids()
+for dims, seed, split in (((12, 20, 24), 11, False), ((36, 134, 22), 10, True)):
+    sc, f, U, div = scenes.pcg_problem(ora, dims, seed, split=split, B=1, vel_cells=0.3)
+    for pc in ("ilu0", "ic0"):
+        pa = np.zeros_like(div); pb = np.zeros_like(div)
+        ra = hip.solveLinearSystemPCG(pa, f, div, True, 1e-4, 1000, pc)
+        rb = ora.solveLinearSystemPCG(pb, f, div, True, 1e-4, 1000, pc)
+        scale = max(np.abs(pb).max(), 1e-6)
+        assert ra < 2e-4 and np.abs(pa - pb).max() < max(5e-5 * scale, 5e-3), (dims, pc, ra, np.abs(pa - pb).max())
+print("PCG_PATH_OK")
+"""
+
+
+@pytest.mark.parametrize("hyperplanes", [True, False])
+def test_pcg_triangular_solves_both_schedules(hyperplanes):
+    """IC(0) / ILU(0) on 3-D grids: the pipelined-wavefront sweeps (default) and, with TFL_PCG_HYPERPLANES=1, the
+    one-launch-per-hyperplane sweeps they replace (still the path of grids with more than 240 sub-boxes), both against
+    the oracle. Child processes: the switch is read from the environment once."""
+    import subprocess, sys
+    code = _PCG_FALLBACK % (os.path.dirname(HERE), HERE)
+    env = dict(os.environ)
+    env.pop("TFL_PCG_HYPERPLANES", None)
+    if hyperplanes:
+        env["TFL_PCG_HYPERPLANES"] = "1"
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "PCG_PATH_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
 
 
 def test_hip_pcg_errors_and_defaults(hip, oracle):
