@@ -101,7 +101,7 @@ void jacobi_iteration(hipStream_t st, bool is3d, int B, int Z, int Y, int X, con
 // pcg.hip
 long long pcg_workspace_floats(int Z, int Y, int X);
 int pcg_solve(hipStream_t st, bool is3d, int B, int Z, int Y, int X, float* p, const float* flags, const float* div,
-              int precond, float tol, int max_iter, int verbose, float* workspace, float* residual, char* msg, size_t msg_len);
+              int precond, float tol, int max_iter, int verbose, float* workspace, float* residual, char* msg, size_t msg_len, bool allow_wavefronts = true);
 
 long long npm_workspace_floats(int Z, int Y, int X);
 int normalize_pressure_mean(hipStream_t st, bool is3d, int B, int Z, int Y, int X, float* p, const float* flags,

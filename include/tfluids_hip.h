@@ -164,7 +164,10 @@ int tfl_signedDistanceField(tfl_ctx* ctx, const tfl_tensor* flags, int searchRad
  * 1000); *residual = max over the solves of the final ||r|| (-inf if there was nothing to solve).
  * The reference keeps its temporaries in the tfluids._tmpPCG table; here the caller passes a workspace of
  * tfl_pcg_workspace_floats(Z, Y, X) floats (8-byte aligned). Synchronises the stream (as the reference does after
- * every dot product). Returns TFL_EINVAL for a fluid cell on the domain border (the reference raises). */
+ * every dot product). On 3-D grids the IC(0) / ILU(0) triangular solves run as pipelined wavefronts whose sub-boxes wait
+ * for each other (all of them must be resident on the GPU at once); if one times out (~1 s: something else holds part of
+ * the GPU) the solve is repeated with one launch per hyperplane. TFL_PCG_HYPERPLANES=1 in the environment selects that
+ * schedule from the start. Returns TFL_EINVAL for a fluid cell on the domain border (the reference raises). */
 int64_t tfl_pcg_workspace_floats(int32_t Z, int32_t Y, int32_t X);
 int tfl_solveLinearSystemPCG(tfl_ctx* ctx, const tfl_tensor* p, const tfl_tensor* flags, const tfl_tensor* div,
                              int is3D, const char* precondType, float tol, int maxIter, int verbose,
