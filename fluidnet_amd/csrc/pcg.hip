@@ -770,7 +770,7 @@ int pcg_solve(hipStream_t st, bool is3d, int B, int Z, int Y, int X, float* p, c
   float* w = base + 6 * n; float* dg = base + 7 * n; float* y = base + 8 * n;
   int* roots = reinterpret_cast<int*>(base + 9 * n);
   int* counters = roots + kMaxComponents;   // [0] changed, [1] count, [2] border fluid
-  // pipelined wavefront sweeps (3-D): skewed c and y, the blocks' progress words, an error word
+  // pipelined wavefront sweeps (3-D): the skewed arrays (cc, r, q, z), the two hand-off arrays of {value, tag} pairs, an error word
   const bool wf = allow_wavefronts && wf_usable(is3d, Z, Y, X);
   const WfGeom wg = wf_geom(Z > 2 ? Z : 3, Y > 2 ? Y : 3, X > 2 ? X : 3);
   float* wfbase = base + 9 * n + kMaxComponents + 64;
