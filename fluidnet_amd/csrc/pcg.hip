@@ -20,8 +20,8 @@
 //     ic0:  R upper with R(n,n) = sqrt(d(n)), R(n,q) = -1/R(n,n); M = R^T R.
 //     Cells of one hyperplane i+j+k = const are independent (what cusparse's csrsv level analysis discovers at run
 //     time). The factorisation (once per solve) runs one launch per hyperplane; the two triangular solves of every CG
-//     iteration run as PIPELINED WAVEFRONTS on 3-D grids -- two launches instead of ~760 at 128^3 (k_wf_sweep below). 2-D grids and grids with
-//     more than 240 sub-boxes keep the launch-per-hyperplane sweeps.
+//     iteration run as PIPELINED WAVEFRONTS on 3-D grids -- two launches instead of ~760 at 128^3 (k_wf_sweep below). 2-D grids keep the
+//     launch-per-hyperplane sweeps; 3-D grids with more than 240 sub-boxes run the wavefronts one range of slabs per launch.
 // Dot products are two-stage fp64 reductions with a fixed order (bit-reproducible run to run).
 #include "tfl_device.hpp"
 #include "tfl_host.hpp"
@@ -396,20 +396,28 @@ static_assert(kWfPlanes * kWfLag <= 64, "one helper lane per (plane, step of the
 struct WfGeom {
   int X, Y, Z, ns, nb, NT;     // strips, slabs, steps per sub-box (a multiple of kWfDepth)
   long long sub;               // cells of one sub-box in the skewed arrays = kWfPlanes * NT * kWfRows
+  int b_lo, b_cnt;             // the slabs [b_lo, b_lo + b_cnt) this launch works on (all strips of them)
 };
+// the sub-box of a workgroup: blocks of one launch are numbered strip-major over the launch's slabs
+__device__ __forceinline__ int wf_block(const WfGeom& g, int& sidx, int& bidx) {
+  sidx = (int)blockIdx.x / g.b_cnt;
+  bidx = g.b_lo + ((int)blockIdx.x - sidx * g.b_cnt);
+  return sidx * g.nb + bidx;
+}
 inline WfGeom wf_geom(int Z, int Y, int X) {
   WfGeom g;
   g.X = X; g.Y = Y; g.Z = Z;
   g.ns = (Y - 2 + kWfRows - 1) / kWfRows; g.nb = (Z - 2 + kWfPlanes - 1) / kWfPlanes;
   g.NT = (((X - 2) + (kWfRows - 1) + kWfLag * (kWfPlanes - 1)) + kWfDepth - 1) / kWfDepth * kWfDepth;
   g.sub = (long long)kWfPlanes * g.NT * kWfRows;
+  g.b_lo = 0; g.b_cnt = g.nb;
   return g;
 }
 inline bool wf_usable(bool is3d, int Z, int Y, int X) {
   if (!is3d || X < 3 || Y < 3 || Z < 3) return false;
   static const bool off = getenv("TFL_PCG_HYPERPLANES") != nullptr;     // A/B switch: the one-launch-per-hyperplane sweeps
   const WfGeom g = wf_geom(Z, Y, X);
-  return !off && g.ns * g.nb <= kWfMaxBlocks;      // every block must be resident at once (they wait for each other)
+  return !off && g.ns <= kWfMaxBlocks;      // (grids with more sub-boxes than fit the GPU at once run slab range by slab range)
 }
 // floats of: cc, r, q, z (skewed) | the slab hand-off pairs [block][t / 4][row][t % 4] | the strip hand-off pairs
 // [block][plane][t] | the error word
@@ -512,7 +520,8 @@ template <int DIR>
 __device__ __forceinline__ void wf_compute(const WfGeom& g, const WfArrays& A, int tag, float (*ring)[2][kWfRows][kWfLag],
                                            float (*edge_s)[kWfPlanes + 1][kWfLag]) {
   constexpr int D = kWfDepth, G = D / 4;
-  const int blk = blockIdx.x;
+  int sidx, bidx;
+  const int blk = wf_block(g, sidx, bidx);
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int NT = g.NT, NG = NT / 4;
   const long long base4 = ((long long)blk * kWfPlanes + w) * NG * kWfRows + lane;       // in float4 units; + group * 64
@@ -593,7 +602,8 @@ __device__ __forceinline__ void wf_helper(const WfGeom& g, const WfArrays& A, in
                                           float (*edge_s)[kWfPlanes + 1][kWfLag]) {
   constexpr int P = kWfHelperAhead, NI = kWfDepth / kWfLag;     // the loop is unrolled by NI intervals (one compute body); NI % P == 0
   constexpr bool SLAB = ROLE == 0;
-  const int blk = blockIdx.x, sidx = blk / g.nb, bidx = blk - sidx * g.nb;
+  int sidx, bidx;
+  const int blk = wf_block(g, sidx, bidx);
   const int lane = threadIdx.x & 63;
   const int NT = g.NT, NG = NT / 4;
   const int ps = DIR > 0 ? (sidx > 0 ? blk - g.nb : -1) : (sidx + 1 < g.ns ? blk + g.nb : -1);
@@ -783,11 +793,13 @@ int pcg_solve(hipStream_t st, bool is3d, int B, int Z, int Y, int X, float* p, c
   float2* wf_hk = wf ? reinterpret_cast<float2*>(cs + 4 * wtot) + kWfGuard : nullptr;       // 16-byte aligned: wtot is a multiple of 1024
   float2* wf_hs = wf ? reinterpret_cast<float2*>(cs + 4 * wtot + wf_handoff_k(wg)) + kWfGuard : nullptr;
   int* wferr = wf ? reinterpret_cast<int*>(cs + 4 * wtot + wf_handoff_k(wg) + wf_handoff_s(wg)) : nullptr;
-  int epoch = 0;                                // tag of the next sweep launch; the skewed arrays are zeroed with it
+  int epoch = 0;                                // tag of the next sweep; the skewed arrays are zeroed with it
+  static const int wf_cap = getenv("TFL_WF_MAX_BLOCKS") ? std::max(1, atoi(getenv("TFL_WF_MAX_BLOCKS"))) : kWfMaxBlocks;     // (tests: small launches)
+  const int wf_slabs = std::max(1, std::min(wf_cap, kWfMaxBlocks) / std::max(wg.ns, 1));      // slabs per launch
   // development aid: TFL_WF_TRACE=1 prints when every sub-box of the last forward / backward sweep started and finished
   static const bool wf_trace_on = getenv("TFL_WF_TRACE") != nullptr;
   long long* wf_trace = nullptr;
-  if (wf && wf_trace_on && precond && hipMalloc(&wf_trace, sizeof(long long) * 4 * kWfMaxBlocks) != hipSuccess) wf_trace = nullptr;
+  if (wf && wf_trace_on && precond && hipMalloc(&wf_trace, sizeof(long long) * 4 * wg.ns * wg.nb) != hipSuccess) wf_trace = nullptr;
   auto hip_ok = [&](hipError_t e, const char* what) {
     if (e == hipSuccess) return true;
     snprintf(msg, msg_len, "solveLinearSystemPCG: %s: %s", what, hipGetErrorString(e));
@@ -882,8 +894,19 @@ int pcg_solve(hipStream_t st, bool is3d, int B, int Z, int Y, int X, float* p, c
             const int gb = cdiv((long long)(X - 2) * (Y - 2) * (Z - 2), 256);
             { TFL_TIMED("k_pcg_precond", st);
               k_wf_skew<true><<<gb, 256, 0, st>>>(S, wg, d, r, rsk);
-              k_wf_sweep<1><<<nblk, (kWfPlanes + 2) * 64, 0, st>>>(S, wg, WfArrays{cs, rsk, qsk, wf_hk, wf_hs, wferr, wf_trace}, ++epoch);
-              k_wf_sweep<-1><<<nblk, (kWfPlanes + 2) * 64, 0, st>>>(S, wg, WfArrays{cs, qsk, zsk, wf_hk, wf_hs, wferr, wf_trace ? wf_trace + 2 * nblk : nullptr}, ++epoch);
+              // every sub-box of a launch must be resident (they wait for each other): at most wf_cap of them per launch,
+              // all strips of a range of slabs, the ranges in sweep order -- a later launch finds its predecessors' pairs
+              // waiting under the same tag
+              ++epoch;
+              for (int b0 = 0; b0 < wg.nb; b0 += wf_slabs) {
+                WfGeom c = wg; c.b_lo = b0; c.b_cnt = std::min(wf_slabs, wg.nb - b0);
+                k_wf_sweep<1><<<wg.ns * c.b_cnt, (kWfPlanes + 2) * 64, 0, st>>>(S, c, WfArrays{cs, rsk, qsk, wf_hk, wf_hs, wferr, wf_trace}, epoch);
+              }
+              ++epoch;
+              for (int b1 = wg.nb; b1 > 0; b1 -= wf_slabs) {
+                WfGeom c = wg; c.b_lo = std::max(b1 - wf_slabs, 0); c.b_cnt = b1 - c.b_lo;
+                k_wf_sweep<-1><<<wg.ns * c.b_cnt, (kWfPlanes + 2) * 64, 0, st>>>(S, c, WfArrays{cs, qsk, zsk, wf_hk, wf_hs, wferr, wf_trace ? wf_trace + 2 * nblk : nullptr}, epoch);
+              }
               k_wf_skew<false><<<gb, 256, 0, st>>>(S, wg, d, z, zsk); }
             dir_src = z;
           } else if (pc) {

@@ -379,13 +379,14 @@ print("PCG_PATH_OK")
 """
 
 
-@pytest.mark.parametrize("mode", ["wavefronts", "hyperplanes", "timeout"])
+@pytest.mark.parametrize("mode", ["wavefronts", "hyperplanes", "timeout", "chunks"])
 def test_pcg_triangular_solves_both_schedules(mode):
     """IC(0) / ILU(0) on 3-D grids: the pipelined-wavefront sweeps (default) and, with TFL_PCG_HYPERPLANES=1, the
-    one-launch-per-hyperplane sweeps they replace (still the path of grids with more than 240 sub-boxes), both against
+    one-launch-per-hyperplane sweeps they replace (still the path of 2-D grids and the fallback), both against
     the oracle; "timeout": the wavefront sweeps report that a sub-box never saw its predecessor (pretended:
-    TFL_WF_TEST_TIMEOUT) and the solve must come out right through the automatic repeat with hyperplane sweeps.
-    Child processes: the switches are read from the environment once."""
+    TFL_WF_TEST_TIMEOUT) and the solve must come out right through the automatic repeat with hyperplane sweeps;
+    "chunks": at most 4 sub-boxes per launch (TFL_WF_MAX_BLOCKS), the way grids with more sub-boxes than fit the GPU
+    at once run, one range of slabs per launch. Child processes: the switches are read from the environment once."""
     import subprocess, sys
     code = _PCG_FALLBACK % (os.path.dirname(HERE), HERE)
     env = dict(os.environ)
@@ -393,8 +394,11 @@ def test_pcg_triangular_solves_both_schedules(mode):
     env.pop("TFL_WF_TEST_TIMEOUT", None)
     if mode == "hyperplanes":
         env["TFL_PCG_HYPERPLANES"] = "1"
+    env.pop("TFL_WF_MAX_BLOCKS", None)
     if mode == "timeout":
         env["TFL_WF_TEST_TIMEOUT"] = "1"
+    if mode == "chunks":
+        env["TFL_WF_MAX_BLOCKS"] = "4"
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and "PCG_PATH_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
 
