@@ -1,5 +1,11 @@
-import os, sys, torch
-sys.path.insert(0, "/root/repo")
+"""Run a few IC(0)-preconditioned CG iterations on a box domain; with TFL_WF_TRACE=1 the library prints when every sub-box of
+the last forward / backward triangular sweep started and finished (pcg.hip). usage: TFL_WF_TRACE=1 python tools/wf_trace.py"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from fluidnet_amd import tfluids
 dev = torch.device("cuda", 0)
 Z, Y, X = 130, 130, 128
