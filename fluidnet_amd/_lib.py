@@ -60,10 +60,19 @@ COMM_WAIT = _c.CFUNCTYPE(_c.c_int, _c.c_void_p, _c.c_int)
 COMM_ALLREDUCE = _c.CFUNCTYPE(_c.c_int, _c.c_void_p, _c.c_void_p, _c.c_int64)
 
 
+class tfl_comm_chunk(_c.Structure):
+    _fields_ = [("ptr", _c.c_void_p), ("n", _c.c_int64)]
+
+
+COMM_START_V = _c.CFUNCTYPE(_c.c_int, _c.c_void_p, _c.c_int, _c.c_int, _c.POINTER(tfl_comm_chunk), _c.POINTER(tfl_comm_chunk),
+                            _c.c_int, _c.POINTER(tfl_comm_chunk), _c.POINTER(tfl_comm_chunk))
+
+
 class tfl_comm(_c.Structure):
-    """include/tfluids_hip.h tfl_comm: the transport callbacks of the z-slab step."""
+    """include/tfluids_hip.h tfl_comm: the transport callbacks of the z-slab step (exchange_start_v: optional, NULL here
+    unless a transport sets it -- the Python transports move one staged buffer per neighbour)."""
     _fields_ = [("user", _c.c_void_p), ("exchange_start", COMM_START), ("exchange_wait", COMM_WAIT),
-                ("allreduce_sum", COMM_ALLREDUCE)]
+                ("allreduce_sum", COMM_ALLREDUCE), ("exchange_start_v", COMM_START_V)]
 
 
 SIGNATURES = {

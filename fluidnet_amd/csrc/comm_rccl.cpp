@@ -139,6 +139,31 @@ int cb_exchange_start(void* user, int tag, const float* send_lo, int64_t n_send_
   return 0;
 }
 
+// the same exchange on the planes where they lie: several sends / receives per neighbour in ONE group (RCCL matches the
+// pieces of a pair of ranks in issue order)
+int cb_exchange_start_v(void* user, int tag, int n_lo, const tfl_comm_chunk* send_lo, const tfl_comm_chunk* recv_lo, int n_hi,
+                        const tfl_comm_chunk* send_hi, const tfl_comm_chunk* recv_hi) {
+  tfl_rccl_comm* q = (tfl_rccl_comm*)user;
+  if (tag < 0 || tag >= kTags) { q->last_error = "tag out of range"; return 1; }
+  const RcclApi* a = q->api;
+  HCHK(hipEventRecord(q->ready, q->ctx->stream), "hipEventRecord");
+  HCHK(hipStreamWaitEvent(q->stream, q->ready, 0), "hipStreamWaitEvent");
+  RCHK(a->GroupStart(), "ncclGroupStart");
+  if (q->rank > 0)
+    for (int i = 0; i < n_lo; i++) {
+      if (send_lo[i].n > 0) RCHK(a->Send(send_lo[i].ptr, (size_t)send_lo[i].n, kNcclFloat, q->rank - 1, q->comm, q->stream), "ncclSend(lower)");
+      if (recv_lo[i].n > 0) RCHK(a->Recv(recv_lo[i].ptr, (size_t)recv_lo[i].n, kNcclFloat, q->rank - 1, q->comm, q->stream), "ncclRecv(lower)");
+    }
+  if (q->rank + 1 < q->world)
+    for (int i = 0; i < n_hi; i++) {
+      if (send_hi[i].n > 0) RCHK(a->Send(send_hi[i].ptr, (size_t)send_hi[i].n, kNcclFloat, q->rank + 1, q->comm, q->stream), "ncclSend(upper)");
+      if (recv_hi[i].n > 0) RCHK(a->Recv(recv_hi[i].ptr, (size_t)recv_hi[i].n, kNcclFloat, q->rank + 1, q->comm, q->stream), "ncclRecv(upper)");
+    }
+  RCHK(a->GroupEnd(), "ncclGroupEnd");
+  HCHK(hipEventRecord(q->done[tag], q->stream), "hipEventRecord");
+  return 0;
+}
+
 int cb_exchange_wait(void* user, int tag) {
   tfl_rccl_comm* q = (tfl_rccl_comm*)user;
   if (tag < 0 || tag >= kTags) { q->last_error = "tag out of range"; return 1; }
@@ -170,6 +195,8 @@ tfl_rccl_comm* make(tfl_ctx* c, const RcclApi* a, NcclComm comm, bool owns, int 
   q->callbacks.exchange_start = cb_exchange_start;
   q->callbacks.exchange_wait = cb_exchange_wait;
   q->callbacks.allreduce_sum = cb_allreduce_sum;
+  // TFL_RCCL_PACKED=1: staged messages (one send + one receive per neighbour, pack / unpack kernels) for comparison
+  q->callbacks.exchange_start_v = getenv("TFL_RCCL_PACKED") ? nullptr : cb_exchange_start_v;
   return q;
 }
 

@@ -329,8 +329,38 @@ void pack_msg(tfl_ctx* c, const SlabGeom& g, const Msg& q, bool unpack) {
   if (n) tfl::pack_planes(c->stream, n, ptrs, rows, zlo, np, g.yx * g.Zl, g.yx, nullptr, unpack ? 1 : 0, bufs);
 }
 
+// the same planes as contiguous runs of the fields themselves, one per (batch item, channel): what exchange_start_v moves
+int msg_chunks(const SlabGeom& g, const Msg& q, bool lower, bool send, tfl_comm_chunk* out) {
+  if (lower ? !g.lower : !g.upper) return 0;
+  int n = 0;
+  for (int i = 0; i < q.n; i++) {
+    const Halo& h = q.f[i];
+    int np, zlo;
+    if (send) { np = lower ? h.above : h.below; zlo = lower ? g.o0 : g.o1 - h.below; }      // owned planes out
+    else { np = lower ? h.below : h.above; zlo = lower ? g.o0 - h.below : g.o1; }           // halo planes in
+    for (int row = 0; row < h.t->B * h.t->C; row++) {
+      out[n].ptr = h.t->data + ((long long)row * g.Zl + zlo) * g.yx;
+      out[n].n = (long long)np * g.yx;
+      n++;
+    }
+  }
+  return n;
+}
+constexpr int kMaxChunks = 64;     // per neighbour and message: (B * C) of every field of the message
+
 int msg_start(tfl_ctx* c, const SlabGeom& g, const tfl_comm* comm, const Msg& q) {
   if ((!g.lower && !g.upper) || q.n == 0) return TFL_OK;
+  if (comm->exchange_start_v) {
+    int rows = 0;
+    for (int i = 0; i < q.n; i++) rows += q.f[i].t->B * q.f[i].t->C;
+    if (q.n > 0 && rows <= kMaxChunks) {
+      tfl_comm_chunk slo[kMaxChunks], rlo[kMaxChunks], shi[kMaxChunks], rhi[kMaxChunks];
+      const int n_lo = msg_chunks(g, q, true, true, slo), n_hi = msg_chunks(g, q, false, true, shi);
+      msg_chunks(g, q, true, false, rlo); msg_chunks(g, q, false, false, rhi);
+      if (comm->exchange_start_v(comm->user, q.tag, n_lo, slo, rlo, n_hi, shi, rhi) != 0) { c->err = "simulate_step_slab: comm callback failed (exchange_start_v)"; return TFL_EINVAL; }
+      return TFL_OK;
+    }
+  }
   pack_msg(c, g, q, false);
   if (comm->exchange_start(comm->user, q.tag, q.send_lo, q.n_send_lo, q.recv_lo, q.n_recv_lo, q.send_hi, q.n_send_hi,
                            q.recv_hi, q.n_recv_hi) != 0) { c->err = "simulate_step_slab: comm callback failed (exchange_start)"; return TFL_EINVAL; }
@@ -339,6 +369,9 @@ int msg_start(tfl_ctx* c, const SlabGeom& g, const tfl_comm* comm, const Msg& q)
 int msg_finish(tfl_ctx* c, const SlabGeom& g, const tfl_comm* comm, const Msg& q) {
   if ((!g.lower && !g.upper) || q.n == 0) return TFL_OK;
   if (comm->exchange_wait(comm->user, q.tag) != 0) { c->err = "simulate_step_slab: comm callback failed (exchange_wait)"; return TFL_EINVAL; }
+  int rows = 0;
+  for (int i = 0; i < q.n; i++) rows += q.f[i].t->B * q.f[i].t->C;
+  if (comm->exchange_start_v && q.n > 0 && rows <= kMaxChunks) return TFL_OK;      // delivered in place
   pack_msg(c, g, q, true);
   return TFL_OK;
 }

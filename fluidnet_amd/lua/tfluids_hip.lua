@@ -183,12 +183,18 @@ typedef struct tfl_slab {
   int32_t check_reach;
   int32_t in_flight;
 } tfl_slab;
+typedef struct tfl_comm_chunk {
+  float* ptr;
+  int64_t n;
+} tfl_comm_chunk;
 typedef struct tfl_comm {
   void* user;
   int (*exchange_start)(void* user, int tag, const float* send_lo, int64_t n_send_lo, float* recv_lo, int64_t n_recv_lo,
                         const float* send_hi, int64_t n_send_hi, float* recv_hi, int64_t n_recv_hi);
   int (*exchange_wait)(void* user, int tag);
   int (*allreduce_sum)(void* user, double* dev, int64_t n);
+  int (*exchange_start_v)(void* user, int tag, int n_lo, const tfl_comm_chunk* send_lo, const tfl_comm_chunk* recv_lo,
+                          int n_hi, const tfl_comm_chunk* send_hi, const tfl_comm_chunk* recv_hi);
 } tfl_comm;
 int32_t tfl_slab_halo(int32_t reach);
 int64_t tfl_simulate_slab_workspace_floats(tfl_ctx* ctx, const tfl_sim_params* params, const tfl_sim_state* state,

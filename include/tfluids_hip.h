@@ -430,12 +430,26 @@ typedef struct tfl_slab {
  *   exchange_wait:  make the stream wait until the transfers of exchange_start(tag) have landed.
  *   allreduce_sum:  in-place sum of n device doubles over all ranks, ordered on the stream.
  * Return 0, or non-zero to abort the step (reported as TFL_EINVAL with "comm callback failed"). */
+typedef struct tfl_comm_chunk {   /* n contiguous floats of device memory */
+  float* ptr;
+  int64_t n;
+} tfl_comm_chunk;
+
 typedef struct tfl_comm {
   void* user;
   int (*exchange_start)(void* user, int tag, const float* send_lo, int64_t n_send_lo, float* recv_lo, int64_t n_recv_lo,
                         const float* send_hi, int64_t n_send_hi, float* recv_hi, int64_t n_recv_hi);
   int (*exchange_wait)(void* user, int tag);
   int (*allreduce_sum)(void* user, double* dev, int64_t n);
+  /* Optional (NULL: not offered). The same exchange WITHOUT staging buffers: the halo planes of a [C][Z][Y][X] field are
+   * one contiguous run per (batch item, channel), so a message is a short list of chunks that a transport able to move
+   * several pieces per neighbour (RCCL: several ncclSend / ncclRecv in one group) takes straight out of, and delivers
+   * straight into, the fields -- the step then launches no pack / unpack kernels (6 of a middle rank's 22 launches per
+   * step). Chunk i of send_hi pairs with chunk i of the upper neighbour's recv_lo (same order, same sizes); n_lo / n_hi = 0:
+   * no such neighbour. The received planes are written while the transfer runs, i.e. any time between this call and
+   * exchange_wait(tag); the step never reads them in that window. */
+  int (*exchange_start_v)(void* user, int tag, int n_lo, const tfl_comm_chunk* send_lo, const tfl_comm_chunk* recv_lo,
+                          int n_hi, const tfl_comm_chunk* send_hi, const tfl_comm_chunk* recv_hi);
 } tfl_comm;
 
 /* Halo depth a slab must store next to each neighbour for reach R (>= 4). */

@@ -15,6 +15,16 @@ from fluidnet_amd.dist import SlabLayout, SlabSimulation, _CommBase  # noqa: E40
 
 
 class NullComm(_CommBase):
+    """--packed: offers only the staged exchange (the library packs / unpacks, as for the Python transports); default: also
+    the in-place one (exchange_start_v, what the native RCCL transport offers), so that no pack / unpack kernels run."""
+
+    def __init__(self, in_place=True):
+        super().__init__()
+        if in_place:
+            from fluidnet_amd._lib import COMM_START_V
+            self._cbv = COMM_START_V(lambda *a: 0)
+            self.struct.exchange_start_v = self._cbv
+
     def start(self, tag, send_lo, recv_lo, send_hi, recv_hi):
         pass
 
@@ -25,15 +35,22 @@ class NullComm(_CommBase):
         pass
 
 
-res = int(sys.argv[1]) if len(sys.argv) > 1 else 128
-world = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+_pos = [a for a in sys.argv[1:] if not a.startswith("--")]
+res = int(_pos[0]) if len(_pos) > 0 else 128
+world = int(_pos[1]) if len(_pos) > 1 else 8
 dev = torch.device("cuda:0")
 model = FluidNetModel.default_3d(seed=1)
 for rank in (0, world // 2):
     lay = SlabLayout(res, world, rank)
     batch, mconf = bench.build_scene(res, res, lay, dev)
     mconf = dict(mconf, buoyancyScale=0.0)          # keep the (wrong) state tame: nothing rises into the missing halos
-    sim = SlabSimulation(batch, mconf, model, lay, NullComm(), check_reach=False)
+    if "--still" in sys.argv:
+        # dt = 0: nothing moves, so the halos the null transport never refreshes stay what the neighbours would have sent
+        # (except p, which only feeds the conv stack) and every kernel runs on the data it would see in a real run.
+        # Without it the in-place exchange leaves stale velocities in the halos and the advection kernels take their
+        # slow paths there, which is an artefact of the null transport, not of the step.
+        mconf = dict(mconf, dt=0.0)
+    sim = SlabSimulation(batch, mconf, model, lay, NullComm("--packed" not in sys.argv), check_reach=False)
     for _ in range(5):
         sim.step()
     torch.cuda.synchronize()
