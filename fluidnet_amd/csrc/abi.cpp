@@ -38,6 +38,11 @@ struct tfl_model {
   float* tail_w4 = nullptr;                       // [8][8] (out, in) of the 8->8 k1 layer
   float* tail_w5 = nullptr;                       // [8] of the 8->1 k1 layer
   float* tail_pack = nullptr;                     // conv_valu.hip: {bias3[8], w4[8][8], b4[8], w5[8], b5[1]} in one buffer
+  // conv_mfma16.hip: split-operand fp16 MFMA (TFL_CONV_PATH=mfma16)
+  bool m16 = false;
+  void* wfrag16[3] = {nullptr, nullptr, nullptr}; // A fragments of the three k=3 layers (conv3_m16_pack_weights)
+  float post16[3] = {0.0f, 0.0f, 0.0f};           // 2^-(11 + e) of each layer
+  unsigned long long* d_range_err = nullptr;      // blocks that clamped an activation at the fp16 range
   // 2-D `default` topology (3->16, 16->16 x3 k3, 16->1 k1): MFMA path (conv2d_mfma.hip)
   bool mfma2d = false;
   float* bfrag2[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -550,6 +555,10 @@ int tfl_solveLinearSystemJacobi(tfl_ctx* c, const tfl_tensor* p, const tfl_tenso
   return check_launch(c, "solveLinearSystemJacobi");
 }
 
+// TFL_CONV_PATH: "mfma16" = split-operand fp16 MFMA (conv_mfma16.hip), "winograd" / unset = fp32 Winograd on the vector
+// ALUs (conv_valu.hip), "mfma" = fp32-operand MFMA (conv_mfma.hip), "direct" = the shape-generic kernels
+static bool conv3d_default_is_m16(const char* force) { return force && strcmp(force, "mfma16") == 0; }
+
 tfl_model* tfl_model_create(tfl_ctx* c, int is3D, int nlayers, const int32_t* cin, const int32_t* cout,
                             const int32_t* ksize, const float* const* weights, const float* const* biases) {
   return tfl_model_create_ex(c, is3D, nlayers, cin, cout, ksize, nullptr, nullptr, weights, biases);
@@ -685,8 +694,21 @@ tfl_model* tfl_model_create_opts(tfl_ctx* c, int is3D, int nlayers, const int32_
     // default: the vector-ALU kernels (conv_valu.hip; faster than the fp32-MFMA form for 8 output channels, see there).
     // TFL_CONV_PATH=mfma keeps the MFMA kernels.
     m->valu3d = !(force && strcmp(force, "mfma") == 0);
+    m->m16 = conv3d_default_is_m16(force);
     // their weights, Winograd-transformed along x: U = (g0, (g0 + g1 + g2)/2, (g0 - g1 + g2)/2, g2) over the three x-taps
     // of every (dz, dy, c_in, c_out)
+    if (m->m16) {
+      for (int l = 0; l < 3; l++) {
+        std::vector<uint16_t> fr((size_t)9 * (cin[l] == 3 ? 1 : 2) * 64 * 8);
+        m->post16[l] = tfl::conv3_m16_pack_weights(weights[l], cin[l], fr.data());
+        if (hipMalloc(&m->wfrag16[l], fr.size() * sizeof(uint16_t)) != hipSuccess ||
+            hipMemcpy(m->wfrag16[l], fr.data(), fr.size() * sizeof(uint16_t), hipMemcpyHostToDevice) != hipSuccess)
+          return cleanup("uploading fp16 MFMA weight fragments failed");
+      }
+      if (hipMalloc((void**)&m->d_range_err, sizeof(unsigned long long)) != hipSuccess ||
+          hipMemset(m->d_range_err, 0, sizeof(unsigned long long)) != hipSuccess)
+        return cleanup("hipMalloc failed");
+    }
     if (m->valu3d) {
       std::vector<float> tp(8 + 64 + 8 + 8 + 1);
       for (int i = 0; i < 8; i++) tp[i] = biases[2][i];
@@ -744,6 +766,8 @@ void tfl_model_destroy(tfl_ctx* c, tfl_model* m) {
   for (auto& L : m->layers) { if (L.w) (void)hipFree(L.w); if (L.b) (void)hipFree(L.b); }
   for (int l = 0; l < 3; l++) if (m->bfrag[l]) (void)hipFree(m->bfrag[l]);
   for (int l = 0; l < 3; l++) if (m->wino[l]) (void)hipFree(m->wino[l]);
+  for (int l = 0; l < 3; l++) if (m->wfrag16[l]) (void)hipFree(m->wfrag16[l]);
+  if (m->d_range_err) (void)hipFree(m->d_range_err);
   for (int l = 0; l < 4; l++) if (m->bfrag2[l]) (void)hipFree(m->bfrag2[l]);
   if (m->tail_w4) (void)hipFree(m->tail_w4);
   if (m->tail_pack) (void)hipFree(m->tail_pack);
@@ -752,12 +776,23 @@ void tfl_model_destroy(tfl_ctx* c, tfl_model* m) {
   delete m;
 }
 
+int64_t tfl_model_range_errors(tfl_ctx* c, tfl_model* m) {
+  if (!c || !m) return -1;
+  if (!m->d_range_err) return 0;
+  unsigned long long v = 0;
+  if (hipMemcpyAsync(&v, m->d_range_err, sizeof(v), hipMemcpyDeviceToHost, c->stream) != hipSuccess) return -1;
+  if (hipMemsetAsync(m->d_range_err, 0, sizeof(v), c->stream) != hipSuccess) return -1;
+  if (hipStreamSynchronize(c->stream) != hipSuccess) return -1;
+  return (int64_t)v;
+}
+
 int64_t tfl_model_workspace_floats(const tfl_model* m, int B, int Z, int Y, int X) {
   if (!m) return -1;
   const int64_t n = (int64_t)B * Z * Y * X;
   // per-block fp64 stat partials (2 doubles = 4 floats per block, kept first for 8-byte alignment)
   // + div[1] + net input[in_c] + two ping-pong activation buffers[max_c] + pPred[1]
-  return 4 * tfl::model_stat_blocks(B, Z, Y, X) + n * (1 + (int64_t)m->in_c + 2 * (int64_t)m->max_c + 1);
+  // (+4: the fp16 MFMA path aligns its activation buffers to 16 bytes)
+  return 4 * tfl::model_stat_blocks(B, Z, Y, X) + n * (1 + (int64_t)m->in_c + 2 * (int64_t)m->max_c + 1) + (m->m16 ? 4 : 0);
 }
 
 namespace {
@@ -775,6 +810,7 @@ int model_ws(tfl_ctx* c, const tfl_model* m, const tfl_tensor* flags, float* wor
   w->div = workspace + 4 * tfl::model_stat_blocks(B, Z, Y, X);
   w->x3 = w->div + n;
   w->act[0] = w->x3 + (int64_t)m->in_c * n;
+  if (m->m16) w->act[0] = (float*)(((uintptr_t)w->act[0] + 15) & ~(uintptr_t)15);
   w->act[1] = w->act[0] + (int64_t)m->max_c * n;
   w->pPred = w->act[1] + (int64_t)m->max_c * n;
   return TFL_OK;
@@ -849,7 +885,16 @@ int tfl_model_finish(tfl_ctx* c, tfl_model* m, const tfl_tensor* pDiv, const tfl
   // + the two 1x1x1 layers, 8 = velocity update / un-scale / wall BCs. Only the 3-D MFMA path is staged.
   const int stg = stages_of(c);
   if (c->stages && !m->mfma3d) return fail(c, TFL_EUNSUPPORTED, "model_finish: stage masks need the 3-D default topology");
-  if (m->mfma3d && m->valu3d) {
+  if (m->mfma3d && m->m16) {
+    // split-operand fp16 MFMA (conv_mfma16.hip); the two activation buffers hold the "h2" form (32 B per voxel, as 8 fp32)
+    if (stg & 1)
+      tfl::conv3_m16_first_fused(st, B, Z, Y, X, pDiv->data, w.div, flags->data, st_in, count, m->wfrag16[0], m->layers[0].b,
+                                 m->post16[0], w.act[0], m->d_range_err);
+    if (stg & 2)
+      tfl::conv3_m16_mid(st, B, Z, Y, X, w.act[0], m->wfrag16[1], m->layers[1].b, m->post16[1], w.act[1], m->d_range_err);
+    if (stg & 4)
+      tfl::conv3_m16_tail(st, B, Z, Y, X, w.act[1], m->wfrag16[2], m->tail_pack, m->post16[2], w.pPred, m->d_range_err);
+  } else if (m->mfma3d && m->valu3d) {
     // the first layer builds {pDiv/scale, div/scale, occupancy} while staging its LDS tile
     if (stg & 1)
       tfl::conv3_valu_first_fused(st, B, Z, Y, X, pDiv->data, w.div, flags->data, st_in, count, m->wino[0], m->layers[0].b, w.act[0]);

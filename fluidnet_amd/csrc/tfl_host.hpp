@@ -170,6 +170,17 @@ void conv3_valu_mid(hipStream_t st, int B, int Z, int Y, int X, const float* in_
 void conv3_valu_tail(hipStream_t st, int B, int Z, int Y, int X, const float* in_p8, const float* wq, const float* tail_pack,
                      float* p_out);
 
+// conv_mfma16.hip: the same three layers as a split-operand fp16 MFMA implicit GEMM; activations between the layers are
+// "h2": per (b, z, y) two rows [x][8] of fp16 (hi, lo): 32 B per voxel. wfrag / post from conv3_m16_pack_weights.
+void conv3_m16_first_fused(hipStream_t st, int B, int Z, int Y, int X, const float* pDiv, const float* div, const float* flags,
+                           const double* stats, double count, const void* wfrag, const float* bias, float post, void* out_h2,
+                           unsigned long long* range_err);
+void conv3_m16_mid(hipStream_t st, int B, int Z, int Y, int X, const void* in_h2, const void* wfrag, const float* bias, float post,
+                   void* out_h2, unsigned long long* range_err);
+void conv3_m16_tail(hipStream_t st, int B, int Z, int Y, int X, const void* in_h2, const void* wfrag, const float* tail_pack,
+                    float post, float* p_out, unsigned long long* range_err);
+float conv3_m16_pack_weights(const float* w, int cin, uint16_t* out);
+
 // backward.hip
 void velocity_divergence_bwd(hipStream_t st, bool is3d, int B, int Z, int Y, int X, const float* flags,
                              const float* grad_out, float* grad_U);

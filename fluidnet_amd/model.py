@@ -170,6 +170,13 @@ class FluidNetModel:
 
     __call__ = forward
 
+    def range_errors(self, like):
+        """Thread blocks of the fp16-MFMA convolution path that clamped an activation at the fp16 range since the last
+        call (tfl_model_range_errors; synchronises). 0 for any working simulation; always 0 on the fp32 paths."""
+        lib, ctx = tfluids._context(like)
+        h = self._handles.get(like.device.index)
+        return 0 if h is None else int(lib.tfl_model_range_errors(ctx, h))
+
     # -- the same forward in two halves, for z-slab decomposition (fluidnet_amd.dist) --------------
     def _prep(self, flags):
         lib, ctx = tfluids._context(flags)

@@ -263,6 +263,12 @@ tfl_model* tfl_model_create_opts(tfl_ctx* ctx, int is3D, int nlayers, const int3
                                  const int32_t* ksize, const int32_t* pool, const int32_t* up,
                                  const float* const* weights, const float* const* biases, const tfl_model_opts* opts);
 void tfl_model_destroy(tfl_ctx* ctx, tfl_model* model);
+/* The 3-D default topology's convolution stack runs as a split-operand fp16 MFMA implicit GEMM (csrc/conv_mfma16.hip):
+ * every fp32 operand travels as two fp16 halves, which ends at |x| = 65504. An activation above that is clamped and the
+ * forward pass counts it; this returns the number of thread blocks that clamped since the last call and resets the
+ * count (synchronises the context's stream). 0 for every working simulation: the net's input is divided by the
+ * velocity's standard deviation. Always 0 on the fp32 paths (TFL_CONV_PATH=winograd|mfma|direct). -1 on error. */
+int64_t tfl_model_range_errors(tfl_ctx* ctx, tfl_model* model);
 /* Scratch floats tfl_model_forward needs for a [B][.][Z][Y][X] grid. */
 int64_t tfl_model_workspace_floats(const tfl_model* model, int B, int Z, int Y, int X);
 /* {pOut, UOut} = model:forward({pDiv, UDiv, flags}) (lib/model.lua:398, 421-450). Inputs are not
