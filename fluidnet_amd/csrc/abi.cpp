@@ -555,9 +555,9 @@ int tfl_solveLinearSystemJacobi(tfl_ctx* c, const tfl_tensor* p, const tfl_tenso
   return check_launch(c, "solveLinearSystemJacobi");
 }
 
-// TFL_CONV_PATH: "mfma16" = split-operand fp16 MFMA (conv_mfma16.hip), "winograd" / unset = fp32 Winograd on the vector
-// ALUs (conv_valu.hip), "mfma" = fp32-operand MFMA (conv_mfma.hip), "direct" = the shape-generic kernels
-static bool conv3d_default_is_m16(const char* force) { return force && strcmp(force, "mfma16") == 0; }
+// TFL_CONV_PATH: unset / "mfma16" = split-operand fp16 MFMA (conv_mfma16.hip: the default), "winograd" = fp32 Winograd on
+// the vector ALUs (conv_valu.hip), "mfma" = fp32-operand MFMA (conv_mfma.hip), "direct" = the shape-generic kernels
+static bool conv3d_default_is_m16(const char* force) { return !force || !*force || strcmp(force, "mfma16") == 0; }
 
 tfl_model* tfl_model_create(tfl_ctx* c, int is3D, int nlayers, const int32_t* cin, const int32_t* cout,
                             const int32_t* ksize, const float* const* weights, const float* const* biases) {
@@ -699,7 +699,7 @@ tfl_model* tfl_model_create_opts(tfl_ctx* c, int is3D, int nlayers, const int32_
     // of every (dz, dy, c_in, c_out)
     if (m->m16) {
       for (int l = 0; l < 3; l++) {
-        std::vector<uint16_t> fr((size_t)9 * (cin[l] == 3 ? 1 : 2) * 64 * 8);
+        std::vector<uint16_t> fr(((size_t)9 * (cin[l] == 3 ? 1 : 2) * 64 + 1) * 8);
         m->post16[l] = tfl::conv3_m16_pack_weights(weights[l], cin[l], fr.data());
         if (hipMalloc(&m->wfrag16[l], fr.size() * sizeof(uint16_t)) != hipSuccess ||
             hipMemcpy(m->wfrag16[l], fr.data(), fr.size() * sizeof(uint16_t), hipMemcpyHostToDevice) != hipSuccess)

@@ -42,6 +42,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 
 namespace tfl {
 
@@ -50,13 +51,24 @@ namespace {
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h2v __attribute__((ext_vector_type(2)));
 typedef float f4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void glb_void;
 
 constexpr int kTX = 32, kTY = 4, kTZ = 4;                 // block tile (voxels)
 constexpr int kNY = 4, kNZ = 2;                           // output rows of a wave: 16 x kNY x kNZ
 constexpr int kHX = kTX + 2, kHY = kTY + 2, kHZ = kTZ + 2;
+constexpr int kPlane2 = kHY * 2 * kHX;                    // 16-byte slots of one staged h2 plane (two row-terms per row)
+constexpr int kDma = (kPlane2 + 63) / 64;                 // LDS-DMA instructions (64 slots each) per plane
 constexpr float kHalfMax = 65504.0f;
 
 enum { kModeIn = 0, kModeMid = 1, kModeTail = 2 };
+// timing ablations (tools/ab_build.sh): 1 = no staging loads, 2 = no MFMAs, 4 = no stores, 8 = no LDS fragment reads
+#ifndef TFL_M16_LB
+#define TFL_M16_LB 3
+#endif
+#ifndef TFL_M16_ABL
+#define TFL_M16_ABL 0
+#endif
 
 // tail pack (tfl_model::tail_pack): {bias3[8], w4[8][8] (out, in), b4[8], w5[8], b5[1]}
 constexpr int kTailW4 = 8, kTailB4 = 72, kTailW5 = 80, kTailB5 = 88;
@@ -77,11 +89,39 @@ __device__ __forceinline__ void split_h(float a, _Float16& hi, _Float16& lo) {
 
 }  // namespace
 
+// 4 x 4 transpose of dwords across the four 16-lane groups of a wave: in: R[r] of group g = T[r][g]; out: R[c] of group g =
+// T[g][c]. v_permlane32_swap exchanges the upper half of its first operand with the lower half of the second,
+// v_permlane16_swap the odd 16-lane rows of the first with the even rows of the second.
+__device__ __forceinline__ void transpose4(uint32_t (&R)[4]) {
+  auto s02 = __builtin_amdgcn_permlane32_swap(R[0], R[2], false, false);
+  auto s13 = __builtin_amdgcn_permlane32_swap(R[1], R[3], false, false);
+  auto t01 = __builtin_amdgcn_permlane16_swap(s02[0], s13[0], false, false);
+  auto t23 = __builtin_amdgcn_permlane16_swap(s02[1], s13[1], false, false);
+  R[0] = t01[0]; R[1] = t01[1]; R[2] = t23[0]; R[3] = t23[1];
+}
+
+// a + b after v_permlane32_swap / v_permlane16_swap of the pair: the sum over the two lane halves (32) or over the odd /
+// even 16-lane row pairs (16) of a in the lanes that keep their a, of b in the others (the tail's reduce-scatter).
+// (The results go through named scalars: clang 19 folds __builtin_bit_cast(float, r[1]) of the builtin's vector result
+// to element 0.)
+__device__ __forceinline__ float swap_sum32(float a, float b) {
+  auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(uint32_t, a), __builtin_bit_cast(uint32_t, b), false, false);
+  const uint32_t u0 = r[0], u1 = r[1];
+  return __builtin_bit_cast(float, u0) + __builtin_bit_cast(float, u1);
+}
+__device__ __forceinline__ float swap_sum16(float a, float b) {
+  auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(uint32_t, a), __builtin_bit_cast(uint32_t, b), false, false);
+  const uint32_t u0 = r[0], u1 = r[1];
+  return __builtin_bit_cast(float, u0) + __builtin_bit_cast(float, u1);
+}
+
 // MODE: kModeIn (inputs built from pDiv / div / flags, 1 row-term per input row), kModeMid (h2 in, h2 out),
 // kModeTail (h2 in, + the two 1x1x1 layers, planar fp32 pressure out).
 // wfrag: [9 (dz, dy)][RT][64 lanes] x 16 B -- the A fragments (weights), built by conv3_m16_pack_weights.
+// A block works through `nt` consecutive z-tiles of one (x, y) tile column: the weight fragments (18 KB per wave) are
+// fetched once per block instead of once per tile.
 template <int MODE>
-__global__ __launch_bounds__(256, 3) void k_conv3_m16(Dom d, int tiles_x, int tiles_y, int tiles_z, int n_tiles,
+__global__ __launch_bounds__(256, TFL_M16_LB) void k_conv3_m16(Dom d, int tiles_x, int tiles_y, int tiles_z, int nt, int n_chunks,
                                                       const uint4* __restrict__ in, const uint4* __restrict__ wfrag,
                                                       const float* __restrict__ bias, void* __restrict__ outv, float post,
                                                       MIn cin, unsigned long long* __restrict__ range_err) {
@@ -89,19 +129,17 @@ __global__ __launch_bounds__(256, 3) void k_conv3_m16(Dom d, int tiles_x, int ti
   constexpr bool FIRST = MODE == kModeIn, TAIL = MODE == kModeTail;
   constexpr int RT = FIRST ? 1 : 2;                       // row-terms per input row
   constexpr int kRows = kHZ * kHY * RT, kItems = kRows * kHX;
-  // XCD-aware tile order: consecutive block ids go round-robin over the 8 XCDs; give each XCD a contiguous tile run
-  const int per_xcd = (n_tiles + 7) / 8;
-  const int tile = (int)(blockIdx.x % 8) * per_xcd + (int)(blockIdx.x / 8);
-  if (tile >= n_tiles) return;
-  int t = tile;
+  constexpr int kIter = (kItems + 255) / 256;
+  // XCD-aware order: consecutive block ids go round-robin over the 8 XCDs; give each XCD a contiguous run of chunks
+  const int per_xcd = (n_chunks + 7) / 8;
+  const int chunk = (int)(blockIdx.x % 8) * per_xcd + (int)(blockIdx.x / 8);
+  if (chunk >= n_chunks) return;
+  int t = chunk;
   const int tx = t % tiles_x; t /= tiles_x;
   const int ty = t % tiles_y; t /= tiles_y;
-  const int tz = t % tiles_z;
-  const int b = t / tiles_z;
-  // z-window (tfl_device.hpp Dom): the z-tiles cover the plane run [w0, w0 + n0) and then [w1, w1 + nw - n0)
-  const int tz_a = (d.n0 + kTZ - 1) / kTZ;
-  const int z0 = tz < tz_a ? d.w0 + tz * kTZ : d.w1 + (tz - tz_a) * kTZ;
-  const int z_end = tz < tz_a ? d.w0 + d.n0 : d.w1 + (d.nw - d.n0);
+  const int chunks_z = (tiles_z + nt - 1) / nt;
+  const int tzc = t % chunks_z;
+  const int b = t / chunks_z;
   const int x0 = tx * kTX, y0 = ty * kTY;
   const long long cells = d.sc;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -116,159 +154,435 @@ __global__ __launch_bounds__(256, 3) void k_conv3_m16(Dom d, int tiles_x, int ti
       const uint4 v = wfrag[(p * RT + r) * 64 + lane];
       W[p][r] = __builtin_bit_cast(h8, v);
     }
-
-  // ---- staging: halo tile [kHZ][kHY][RT][kHX] of 16-byte slots, zero outside the grid ------------------------------------
+  float in_scale = 1.0f, inv_scale = 0.0f;
+  bool scale_in_range = false;
   if (FIRST) {
     // lib/modules/variance.lua:44-76 (n-1) + Sqrt, as model.hip scale_from_stats
     const double s1 = cin.stats[b * 2], s2 = cin.stats[b * 2 + 1], n = cin.count;
-    const float in_scale = (float)sqrt(fmax(n * s2 - s1 * s1, 0.0) / (n * (n - 1.0)));
-    const bool scale_in_range = in_scale >= 0x1p-12f && in_scale <= 0x1p21f;     // wave-uniform
-    const float inv_scale = scale_in_range ? rcp_refined(in_scale) : 0.0f;
-    constexpr int kIter = (kItems + 255) / 256;
-    float ld[kIter][3];
-    bool okv[kIter];
-#pragma unroll
-    for (int i = 0; i < kIter; i++) {
-      const int item = min(tid + 256 * i, kItems - 1);
-      const int r = item / kHX, hx = item - r * kHX;
-      const int hz = r / kHY, hy = r - hz * kHY;
-      const int gx = x0 - 1 + hx, gy = y0 - 1 + hy, gz = z0 - 1 + hz;
-      okv[i] = gx >= 0 && gx < d.X && gy >= 0 && gy < d.Y && gz >= 0 && gz < d.Z;
-      const long long o = (long long)b * cells + TFL_AT(d, min(max(gx, 0), d.X - 1), min(max(gy, 0), d.Y - 1), min(max(gz, 0), d.Z - 1));
-      ld[i][0] = cin.pDiv[o]; ld[i][1] = cin.div[o]; ld[i][2] = cin.flags[o];
-    }
-#pragma unroll
-    for (int i = 0; i < kIter; i++) {
-      const int item = tid + 256 * i;
-      // the net input is built here: ApplyScale(true) = CDivTable (apply_scale.lua:24-30), FlagsToOccupancy
-      // (generic/tfluids.cu:355-371); x / scale bit-equal to `/` as in conv_valu.hip
-      float v0, v1;
-      if (scale_in_range) { v0 = div_by<1>(ld[i][0], in_scale, inv_scale); v1 = div_by<1>(ld[i][1], in_scale, inv_scale); }
-      else { v0 = ld[i][0] / in_scale; v1 = ld[i][1] / in_scale; }
-      const int f = (int)ld[i][2];
-      const float occ = (f == kFluid) ? 0.0f : ((f == kObstacle) ? 1.0f : -1.0f);
-      const float c0 = __builtin_fminf(__builtin_fmaxf(v0, -kHalfMax), kHalfMax), c1 = __builtin_fminf(__builtin_fmaxf(v1, -kHalfMax), kHalfMax);
-      clipped = clipped || (okv[i] && (c0 != v0 || c1 != v1));
-      h8 s = {0, 0, 0, 0, 0, 0, 0, 0};
-      if (okv[i]) {
-        _Float16 ph, pl, dh, dl;
-        split_h(c0, ph, pl); split_h(c1, dh, dl);
-        s[0] = ph; s[1] = dh; s[2] = (_Float16)occ; s[3] = pl; s[4] = dl;
-      }
-      if (item < kItems) lds[item] = __builtin_bit_cast(uint4, s);
-    }
-  } else {
-    constexpr int kIter = (kItems + 255) / 256;
-    uint4 ld[kIter];
-    const uint4* src = in + (long long)b * cells * 2;
-#pragma unroll
-    for (int i = 0; i < kIter; i++) {
-      const int item = min(tid + 256 * i, kItems - 1);
-      const int r = item / kHX, hx = item - r * kHX;
-      const int rr = r >> 1, tm = r & 1;
-      const int hz = rr / kHY, hy = rr - hz * kHY;
-      const int gx = x0 - 1 + hx, gy = y0 - 1 + hy, gz = z0 - 1 + hz;
-      const bool ok = gx >= 0 && gx < d.X && gy >= 0 && gy < d.Y && gz >= 0 && gz < d.Z;
-      const long long o = ((long long)(min(max(gz, 0), d.Z - 1) * d.Y + min(max(gy, 0), d.Y - 1)) * 2 + tm) * d.X + min(max(gx, 0), d.X - 1);
-      ld[i] = src[o];
-      if (!ok) ld[i] = make_uint4(0u, 0u, 0u, 0u);
-    }
-#pragma unroll
-    for (int i = 0; i < kIter; i++) {
-      const int item = tid + 256 * i;
-      if (item < kItems) lds[item] = ld[i];
-    }
+    in_scale = (float)sqrt(fmax(n * s2 - s1 * s1, 0.0) / (n * (n - 1.0)));
+    scale_in_range = in_scale >= 0x1p-12f && in_scale <= 0x1p21f;     // wave-uniform
+    inv_scale = scale_in_range ? rcp_refined(in_scale) : 0.0f;
   }
-  __syncthreads();
-
-  // ---- main loop: wave = (x half, z pair); every (input row, term) fragment feeds up to 9 MFMAs ------------------------
   const int wx = wave & 1, wz = wave >> 1;
   const int nn = lane & 15, g = lane >> 4;
-  const uint4* fbase = lds + (wz * kNZ * kHY * RT) * kHX + wx * 16 + nn + (g < 3 ? g : 0);
-  f4 acc[kNZ][kNY];
-#pragma unroll
-  for (int a = 0; a < kNZ; a++)
-#pragma unroll
-    for (int c = 0; c < kNY; c++) acc[a][c] = (f4){0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-  for (int rz = 0; rz < kNZ + 2; rz++)
-#pragma unroll
-    for (int ry = 0; ry < kNY + 2; ry++)
-#pragma unroll
-      for (int tm = 0; tm < RT; tm++) {
-        const h8 f = __builtin_bit_cast(h8, fbase[((rz * kHY + ry) * RT + tm) * kHX]);
-#pragma unroll
-        for (int dz = 0; dz < 3; dz++)
-#pragma unroll
-          for (int dy = 0; dy < 3; dy++) {
-            const int oz = rz - dz, oy = ry - dy;
-            if (oz >= 0 && oz < kNZ && oy >= 0 && oy < kNY)
-              acc[oz][oy] = __builtin_amdgcn_mfma_f32_16x16x32_f16(W[dz * 3 + dy][tm], f, acc[oz][oy], 0, 0, 0);
-          }
-      }
-
-  // ---- epilogue: recombine, bias, ReLU; split again (h2 out) or run the 1x1x1 tail ------------------------------------
+  const int lane_slot = wx * 16 + nn + (g < 3 ? g : 0);
   const int x = x0 + wx * 16 + nn;
   const int c0 = 2 * g, c1 = 2 * g + 1;
   const float bias0 = bias[c0], bias1 = bias[c1];
-  float w4a[8], w4b[8], b4j[2], w5j[2], b5 = 0.0f;
-  // reduce-scatter of the 8 partial sums q_j over the four lane groups: after the exchange with lane ^ 32 a lane keeps
-  // j in {4 (g >> 1) .. +3}, after lane ^ 16 the two j = 4 (g >> 1) + 2 (g & 1) + {0, 1}
-  const int j0 = 4 * (g >> 1) + 2 * (g & 1);
-  if (TAIL) {
+  // z-window (tfl_device.hpp Dom): the z-tiles cover the plane run [w0, w0 + n0) and then [w1, w1 + nw - n0)
+  const int tz_a = (d.n0 + kTZ - 1) / kTZ;
+  const int tz_hi = min(tiles_z, (tzc + 1) * nt);
+  // staging geometry of a lane's kDma slots of a plane (the same for every tile of the block's column)
+  int st_off[kDma];
+  unsigned st_ok = 0;
+  if (!FIRST) {
 #pragma unroll
-    for (int j = 0; j < 8; j++) { w4a[j] = bias[kTailW4 + j * 8 + c0]; w4b[j] = bias[kTailW4 + j * 8 + c1]; }
-    b4j[0] = bias[kTailB4 + j0]; b4j[1] = bias[kTailB4 + j0 + 1];
-    w5j[0] = bias[kTailW5 + j0]; w5j[1] = bias[kTailW5 + j0 + 1];
-    b5 = bias[kTailB5];
+    for (int j = 0; j < kDma; j++) {
+      const int item = min(j * 64 + lane, kPlane2 - 1);
+      const int r = item / kHX, hx = item - r * kHX;
+      const int hy = r >> 1, tm = r & 1;
+      const int gx = x0 - 1 + hx, gy = y0 - 1 + hy;
+      st_off[j] = (min(max(gy, 0), d.Y - 1) * 2 + tm) * d.X + min(max(gx, 0), d.X - 1);
+      st_ok |= (gx >= 0 && gx < d.X && gy >= 0 && gy < d.Y) ? (1u << j) : 0u;
+    }
   }
+  int ring = 0, prev_z0 = -0x40000000;
+
+#pragma unroll 1
+  for (int tz = tzc * nt; tz < tz_hi; tz++) {
+    const int z0 = tz < tz_a ? d.w0 + tz * kTZ : d.w1 + (tz - tz_a) * kTZ;
+    const int z_end = tz < tz_a ? d.w0 + d.n0 : d.w1 + (d.nw - d.n0);
+    if (tz > tzc * nt) __syncthreads();       // every wave is done with the previous tile's fragments
+    // ---- staging: halo tile [kHZ][kHY][RT][kHX] of 16-byte slots, zero outside the grid ----------------------------------
+    if (FIRST) {
+      float ld[kIter][3];
+      bool okv[kIter];
 #pragma unroll
-  for (int oz = 0; oz < kNZ; oz++) {
-    const int z = z0 + wz * kNZ + oz;
+      for (int i = 0; i < kIter; i++) {
+        const int item = min(tid + 256 * i, kItems - 1);
+        const int r = item / kHX, hx = item - r * kHX;
+        const int hz = r / kHY, hy = r - hz * kHY;
+        const int gx = x0 - 1 + hx, gy = y0 - 1 + hy, gz = z0 - 1 + hz;
+        okv[i] = gx >= 0 && gx < d.X && gy >= 0 && gy < d.Y && gz >= 0 && gz < d.Z;
+        const long long o = (long long)b * cells + TFL_AT(d, min(max(gx, 0), d.X - 1), min(max(gy, 0), d.Y - 1), min(max(gz, 0), d.Z - 1));
+        ld[i][0] = cin.pDiv[o]; ld[i][1] = cin.div[o]; ld[i][2] = cin.flags[o];
+      }
 #pragma unroll
-    for (int oy = 0; oy < kNY; oy++) {
-      const int y = y0 + oy;
-      const bool live = x < d.X && y < d.Y && z < z_end;
-      const f4 a = acc[oz][oy];
-      float h0 = __builtin_fmaxf((a[0] + a[1] * 0x1p-11f) * post + bias0, 0.0f);
-      float h1 = __builtin_fmaxf((a[2] + a[3] * 0x1p-11f) * post + bias1, 0.0f);
+      for (int i = 0; i < kIter; i++) {
+        const int item = tid + 256 * i;
+        // the net input is built here: ApplyScale(true) = CDivTable (apply_scale.lua:24-30), FlagsToOccupancy
+        // (generic/tfluids.cu:355-371); x / scale bit-equal to `/` as in conv_valu.hip
+        float v0, v1;
+        if (scale_in_range) { v0 = div_by<1>(ld[i][0], in_scale, inv_scale); v1 = div_by<1>(ld[i][1], in_scale, inv_scale); }
+        else { v0 = ld[i][0] / in_scale; v1 = ld[i][1] / in_scale; }
+        const int f = (int)ld[i][2];
+        const float occ = (f == kFluid) ? 0.0f : ((f == kObstacle) ? 1.0f : -1.0f);
+        const float k0 = __builtin_fminf(__builtin_fmaxf(v0, -kHalfMax), kHalfMax), k1 = __builtin_fminf(__builtin_fmaxf(v1, -kHalfMax), kHalfMax);
+        clipped = clipped || (okv[i] && (k0 != v0 || k1 != v1));
+        h8 s = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (okv[i]) {
+          _Float16 ph, pl, dh, dl;
+          split_h(k0, ph, pl); split_h(k1, dh, dl);
+          s[0] = ph; s[1] = dh; s[2] = (_Float16)occ; s[3] = pl; s[4] = dl;
+        }
+        if (item < kItems) lds[item] = __builtin_bit_cast(uint4, s);
+      }
+    } else {
+      // LDS-DMA (global_load_lds_dwordx4: 64 consecutive slots per instruction, no staging registers): wave w brings in
+      // the new plane hz = 2 + w; planes 0 and 1 are the previous tile's planes 4 and 5 and stay where they are (ring
+      // of 6 plane slots) unless the tile does not continue the previous one
+      const bool fresh = z0 != prev_z0 + kTZ;
+      const uint4* src = in + (long long)b * cells * 2;
+      const uint4* zero = wfrag + 9 * RT * 64;             // 16 zero bytes behind the fragments
+#pragma unroll
+      for (int pass = 0; pass < 2; pass++) {
+        if (pass == 0 && !(fresh && wave < 2)) continue;   // wave-uniform
+        const int hz = pass == 0 ? wave : 2 + wave;
+        const int gz = z0 - 1 + hz;
+        const bool z_ok = gz >= 0 && gz < d.Z;
+        const uint4* psrc = src + (long long)min(max(gz, 0), d.Z - 1) * d.Y * 2 * d.X;
+        uint4* pdst = lds + ((ring + hz) % kHZ) * kPlane2;
+#pragma unroll
+        for (int j = 0; j < kDma; j++) {
+          const uint4* gp = (z_ok && ((st_ok >> j) & 1)) ? psrc + st_off[j] : zero;
+          if (j * 64 + lane < kPlane2)
+            __builtin_amdgcn_global_load_lds((glb_void*)gp, (lds_void*)(pdst + j * 64), 16, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+
+    // ---- main loop: wave = (x half, z pair); every (input row, term) fragment feeds up to 9 MFMAs ----------------------
+    const uint4* fb[kNZ + 2];                 // the wave's four input planes (ring slots)
+#pragma unroll
+    for (int rz = 0; rz < kNZ + 2; rz++)
+      fb[rz] = lds + (FIRST ? wz * kNZ + rz : (ring + wz * kNZ + rz) % kHZ) * (kHY * RT * kHX) + lane_slot;
+    f4 acc[kNZ][kNY];
+#pragma unroll
+    for (int a = 0; a < kNZ; a++)
+#pragma unroll
+      for (int c = 0; c < kNY; c++) acc[a][c] = (f4){0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int rz = 0; rz < kNZ + 2; rz++)
+#pragma unroll
+      for (int ry = 0; ry < kNY + 2; ry++)
+#pragma unroll
+        for (int tm = 0; tm < RT; tm++) {
+          const h8 f = (TFL_M16_ABL & 8) ? W[(rz + ry) % 9][tm] : __builtin_bit_cast(h8, fb[rz][(ry * RT + tm) * kHX]);
+#pragma unroll
+          for (int dz = 0; dz < 3; dz++)
+#pragma unroll
+            for (int dy = 0; dy < 3; dy++) {
+              const int oz = rz - dz, oy = ry - dy;
+              if (oz >= 0 && oz < kNZ && oy >= 0 && oy < kNY) {
+                if (TFL_M16_ABL & 2) { if (dz == 0 && dy == 0) acc[oz][oy] += __builtin_bit_cast(f4, f) + __builtin_bit_cast(f4, W[dz * 3 + dy][tm]); }
+                else acc[oz][oy] = __builtin_amdgcn_mfma_f32_16x16x32_f16(W[dz * 3 + dy][tm], f, acc[oz][oy], 0, 0, 0);
+              }
+            }
+        }
+
+    // ---- epilogue: recombine, bias, ReLU; split again (h2 out) or run the 1x1x1 tail; the four rows of a plane are
+    // transposed across the lane groups so that a lane stores the 16 bytes of one (row, voxel, term) -----------------------
+    static_assert(kNY == 4, "the epilogue transposes four rows across the four lane groups");
+#pragma unroll
+    for (int oz = 0; oz < kNZ; oz++) {
+      const int z = z0 + wz * kNZ + oz;
+      const int y = y0 + g;
+      const bool live = x < d.X && y < d.Y && z < z_end && (!(TFL_M16_ABL & 4) || post == 12345.0f);
+      float h0[kNY], h1[kNY];
+#pragma unroll
+      for (int oy = 0; oy < kNY; oy++) {
+        const f4 a = acc[oz][oy];
+        h0[oy] = __builtin_fmaxf((a[0] + a[1] * 0x1p-11f) * post + bias0, 0.0f);
+        h1[oy] = __builtin_fmaxf((a[2] + a[3] * 0x1p-11f) * post + bias1, 0.0f);
+      }
       if (!TAIL) {
-        const float k0 = __builtin_fminf(h0, kHalfMax), k1 = __builtin_fminf(h1, kHalfMax);
-        clipped = clipped || (live && (k0 != h0 || k1 != h1));
-        _Float16 hh0, hl0, hh1, hl1;
-        split_h(k0, hh0, hl0); split_h(k1, hh1, hl1);
-        if (live) {
-          uint32_t* orow = reinterpret_cast<uint32_t*>(outv) + ((((long long)b * d.Z + z) * d.Y + y) * 2 * d.X + x) * 4 + g;
+        uint32_t H[4], L[4];
+        bool over = false;
+#pragma unroll
+        for (int oy = 0; oy < kNY; oy++) {
+          const float k0 = __builtin_fminf(h0[oy], kHalfMax), k1 = __builtin_fminf(h1[oy], kHalfMax);
+          over = over || ((k0 != h0[oy] || k1 != h1[oy]) && x < d.X && y0 + oy < d.Y && z < z_end);
+          _Float16 hh0, hl0, hh1, hl1;
+          split_h(k0, hh0, hl0); split_h(k1, hh1, hl1);
           const h2v ph = {hh0, hh1}, pl = {hl0, hl1};
-          orow[0] = __builtin_bit_cast(uint32_t, ph);
-          orow[(long long)d.X * 4] = __builtin_bit_cast(uint32_t, pl);
+          H[oy] = __builtin_bit_cast(uint32_t, ph); L[oy] = __builtin_bit_cast(uint32_t, pl);
+        }
+        clipped = clipped || over;
+        transpose4(H); transpose4(L);
+        if (live) {
+          uint4* orow = reinterpret_cast<uint4*>(outv) + (((long long)b * d.Z + z) * d.Y + y) * 2 * d.X + x;
+          orow[0] = make_uint4(H[0], H[1], H[2], H[3]);
+          orow[d.X] = make_uint4(L[0], L[1], L[2], L[3]);
         }
       } else {
-        float q[8];
+        // tail pack (tfl_model::tail_pack): w4 [8][8] (out, in), b4, w5, b5 behind the k3 layer's bias
+        // reduce-scatter of the 8 partial sums q_j over the four lane groups: after the exchange with lane ^ 32 a lane
+        // keeps j in {4 (g >> 1) .. +3}, after lane ^ 16 the two j = 4 (g >> 1) + 2 (g & 1) + {0, 1}
+        const int j0 = 4 * (g >> 1) + 2 * (g & 1);
+        const float b4a = bias[kTailB4 + j0], b4b = bias[kTailB4 + j0 + 1], w5a = bias[kTailW5 + j0], w5b = bias[kTailW5 + j0 + 1];
+        float psel = 0.0f;
 #pragma unroll
-        for (int j = 0; j < 8; j++) q[j] = w4a[j] * h0 + w4b[j] * h1;
+        for (int oy = 0; oy < kNY; oy++) {
+          float q[8];
+#pragma unroll
+          for (int j = 0; j < 8; j++) q[j] = bias[kTailW4 + j * 8 + c0] * h0[oy] + bias[kTailW4 + j * 8 + c1] * h1[oy];
+          float r4[4];
+#pragma unroll
+          for (int j = 0; j < 4; j++) {       // lanes g >> 1 == 0 keep j 0..3 and send 4..7; the others the reverse
+            const float send = (g >> 1) ? q[j] : q[4 + j];
+            const float keep = (g >> 1) ? q[4 + j] : q[j];
+            r4[j] = keep + __shfl_xor(send, 32);
+          }
+          float r2[2];
+#pragma unroll
+          for (int j = 0; j < 2; j++) {
+            const float send = (g & 1) ? r4[j] : r4[2 + j];
+            const float keep = (g & 1) ? r4[2 + j] : r4[j];
+            r2[j] = keep + __shfl_xor(send, 16);
+          }
+          float pp = w5a * __builtin_fmaxf(r2[0] + b4a, 0.0f) + w5b * __builtin_fmaxf(r2[1] + b4b, 0.0f);
+          pp += __shfl_xor(pp, 16);
+          pp += __shfl_xor(pp, 32);
+          psel = g == oy ? pp : psel;         // lane group g stores row g
+        }
+        if (live) reinterpret_cast<float*>(outv)[(long long)b * cells + TFL_AT(d, x, y, z)] = psel + bias[kTailB5];
+      }
+    }
+    ring = (ring + kTZ) % kHZ; prev_z0 = z0;
+  }
+  if (clipped) atomicAdd(range_err, 1ull);
+}
+
+// =====================================================================================================================
+// z-MARCHED form of the 8 -> 8 layers (h2 in): a block owns a 32 x 8 column of the plane and walks a chunk of z. Input
+// planes stream through a ring of kMRing LDS slots by LDS-DMA issued kMAhead planes ahead (inline asm: hipcc drains
+// vmcnt(0) in front of every ds_read that follows a DMA it knows about, which would serialise the pipeline), each plane's
+// 12 fragments per wave are read ONCE and feed the three output planes in flight (dz = 0, 1, 2 -> accumulators A0, A1,
+// A2, rotated by register moves every step): 12 LDS reads per 72 MFMAs, half the tile kernel's, a third less staging
+// traffic (halo 1.33 x (cz + 2) / cz against 2.39), and no exposed staging latency.
+constexpr int kMX = 32, kMY = 8;                          // block column (voxels); wave = (x half, y half): 16 x 4 rows
+constexpr int kMHX = kMX + 2, kMHY = kMY + 2;
+constexpr int kMPlane = kMHY * 2 * kMHX;                  // 680 slots of a staged plane: [row][term][x]
+constexpr int kMDma = 3;                                  // DMA instructions per wave and plane: 4 x 3 x 64 = 768 slots
+constexpr int kMPitch = 4 * kMDma * 64;                   // ring pitch (the 88 slots behind the plane take the idle lanes)
+constexpr int kMRing = 4, kMAhead = 3;
+
+// one LDS-DMA instruction: 64 lanes x 16 bytes from per-lane global addresses to LDS bytes [lds_byte, lds_byte + 1024)
+__device__ __forceinline__ void dma16(const void* gsrc, uint32_t lds_byte) {
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_byte) : "memory");
+}
+
+#ifndef TFL_M16Z_LB
+#define TFL_M16Z_LB 2
+#endif
+template <bool TAIL>
+__global__ __launch_bounds__(256, TFL_M16Z_LB) void k_conv3_m16z(Dom d, int cols_x, int cols_y, int cz, int chunks_a, int chunks,
+                                                                int n_blocks, const uint4* __restrict__ in,
+                                                                const uint4* __restrict__ wfrag, const float* __restrict__ bias,
+                                                                void* __restrict__ outv, float post,
+                                                                unsigned long long* __restrict__ range_err) {
+  extern __shared__ __attribute__((aligned(16))) uint4 lds[];
+  const int per_xcd = (n_blocks + 7) / 8;
+  const int blk = (int)(blockIdx.x % 8) * per_xcd + (int)(blockIdx.x / 8);
+  if (blk >= n_blocks) return;
+  int t = blk;
+  const int cx = t % cols_x; t /= cols_x;
+  const int cy = t % cols_y; t /= cols_y;
+  const int ch = t % chunks;
+  const int b = t / chunks;
+  // z-window: chunks [0, chunks_a) tile the plane run [w0, w0 + n0), the others [w1, w1 + nw - n0)
+  const int zc0 = ch < chunks_a ? d.w0 + ch * cz : d.w1 + (ch - chunks_a) * cz;
+  const int z_end = ch < chunks_a ? d.w0 + d.n0 : d.w1 + (d.nw - d.n0);
+  const int nz = min(cz, z_end - zc0);                  // output planes of this block
+  const int nsteps = nz + 2;
+  const int x0 = cx * kMX, y0 = cy * kMY;
+  const long long cells = d.sc;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  bool clipped = false;
+
+  h8 W[9][2];
+#pragma unroll
+  for (int p = 0; p < 9; p++)
+#pragma unroll
+    for (int r = 0; r < 2; r++) W[p][r] = __builtin_bit_cast(h8, wfrag[(p * 2 + r) * 64 + lane]);
+
+  // staging geometry of the lane's kMDma slots of a plane
+  const uint4* src = in + (long long)b * cells * 2;
+  const uint4* zero = wfrag + 9 * 2 * 64;                // 16 zero bytes behind the fragments
+  int st_off[kMDma];
+  unsigned st_ok = 0;
+#pragma unroll
+  for (int j = 0; j < kMDma; j++) {
+    const int item = (wave * kMDma + j) * 64 + lane;
+    const int r = min(item, kMPlane - 1) / kMHX, hx = min(item, kMPlane - 1) - r * kMHX;
+    const int hy = r >> 1, tm = r & 1;
+    const int gx = x0 - 1 + hx, gy = y0 - 1 + hy;
+    st_off[j] = (min(max(gy, 0), d.Y - 1) * 2 + tm) * d.X + min(max(gx, 0), d.X - 1);
+    st_ok |= (item < kMPlane && gx >= 0 && gx < d.X && gy >= 0 && gy < d.Y) ? (1u << j) : 0u;
+  }
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void*)lds;
+  auto issue = [&](int q) {          // input plane q of the chunk (z = zc0 - 1 + q) -> ring slot q % kMRing
+    const int gz = zc0 - 1 + q;
+    const bool z_ok = q < nsteps && gz >= 0 && gz < d.Z;
+    const uint4* psrc = src + (long long)min(max(gz, 0), d.Z - 1) * d.Y * 2 * d.X;
+#pragma unroll
+    for (int j = 0; j < kMDma; j++) {
+      const uint4* gp = (z_ok && ((st_ok >> j) & 1)) ? psrc + st_off[j] : zero;
+      dma16(gp, __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)(((q % kMRing) * kMPitch + (wave * kMDma + j) * 64) * 16)));
+    }
+  };
+
+  const int wx = wave & 1, wy = wave >> 1;
+  const int nn = lane & 15, g = lane >> 4;
+  const int lane_slot = (wy * 4 * 2) * kMHX + wx * 16 + nn + (g < 3 ? g : 0);
+  const int x = x0 + wx * 16 + nn;
+  const int y = y0 + wy * 4 + g;                          // the row this lane group stores (after the transpose)
+  const int c0 = 2 * g, c1 = 2 * g + 1;
+  const float bias0 = bias[c0], bias1 = bias[c1];
+  const int j0 = 4 * (g >> 1) + 2 * (g & 1);              // TAIL: the two hidden channels this lane finishes
+  float b4a = 0.0f, b4b = 0.0f, w5a = 0.0f, w5b = 0.0f, b5 = 0.0f;
+  if (TAIL) {
+    b4a = bias[kTailB4 + j0]; b4b = bias[kTailB4 + j0 + 1]; w5a = bias[kTailW5 + j0]; w5b = bias[kTailW5 + j0 + 1];
+    b5 = bias[kTailB5];
+  }
+
+  f4 A0[4], A1[4], A2[4];
+#pragma unroll
+  for (int r = 0; r < 4; r++) A0[r] = A1[r] = A2[r] = (f4){0.0f, 0.0f, 0.0f, 0.0f};
+
+  // finish output plane z from A2: recombine, bias, ReLU, then split + transposed 16-byte stores, or the 1x1x1 tail
+  auto finish = [&](int z) {
+    const bool live = x < d.X && y < d.Y && (!(TFL_M16_ABL & 4) || post == 12345.0f);
+    float h0[4], h1[4];
+#pragma unroll
+    for (int oy = 0; oy < 4; oy++) {
+      h0[oy] = __builtin_fmaxf((A2[oy][0] + A2[oy][1] * 0x1p-11f) * post + bias0, 0.0f);
+      h1[oy] = __builtin_fmaxf((A2[oy][2] + A2[oy][3] * 0x1p-11f) * post + bias1, 0.0f);
+    }
+    if (!TAIL) {
+      uint32_t H[4], L[4];
+      bool over = false;
+#pragma unroll
+      for (int oy = 0; oy < 4; oy++) {
+        const float k0 = __builtin_fminf(h0[oy], kHalfMax), k1 = __builtin_fminf(h1[oy], kHalfMax);
+        over = over || ((k0 != h0[oy] || k1 != h1[oy]) && x < d.X && y0 + wy * 4 + oy < d.Y);
+        _Float16 hh0, hl0, hh1, hl1;
+        split_h(k0, hh0, hl0); split_h(k1, hh1, hl1);
+        const h2v ph = {hh0, hh1}, pl = {hl0, hl1};
+        H[oy] = __builtin_bit_cast(uint32_t, ph); L[oy] = __builtin_bit_cast(uint32_t, pl);
+      }
+      clipped = clipped || over;
+      transpose4(H); transpose4(L);
+      if (live) {
+        uint4* orow = reinterpret_cast<uint4*>(outv) + (((long long)b * d.Z + z) * d.Y + y) * 2 * d.X + x;
+        orow[0] = make_uint4(H[0], H[1], H[2], H[3]);
+        orow[d.X] = make_uint4(L[0], L[1], L[2], L[3]);
+      }
+    } else {
+      // 8 -> 8 (k = 1) + ReLU, 8 -> 1: a lane holds two of the eight channels of its voxel. Partial sums q_j over its two
+      // channels, then a reduce-scatter over the four lane groups by register swaps: v_permlane32_swap(a, b) exchanges
+      // a's upper half with b's lower half, so (q_j, q_{4+j}) -> new_a + new_b = the two-group sum of q_j in the lower
+      // lanes and of q_{4+j} in the upper ones; v_permlane16_swap does the same between odd and even 16-lane rows.
+      float psel = 0.0f;
+#pragma unroll
+      for (int oy = 0; oy < 4; oy++) {
         float r4[4];
 #pragma unroll
-        for (int j = 0; j < 4; j++) {       // lanes g >> 1 == 0 keep j 0..3 and send 4..7; the others the reverse
-          const float send = (g >> 1) ? q[j] : q[4 + j];
-          const float keep = (g >> 1) ? q[4 + j] : q[j];
-          r4[j] = keep + __shfl_xor(send, 32);
+        for (int j = 0; j < 4; j++) {
+          const float qa = bias[kTailW4 + j * 8 + c0] * h0[oy] + bias[kTailW4 + j * 8 + c1] * h1[oy];
+          const float qb = bias[kTailW4 + (4 + j) * 8 + c0] * h0[oy] + bias[kTailW4 + (4 + j) * 8 + c1] * h1[oy];
+          r4[j] = swap_sum32(qa, qb);
         }
         float r2[2];
 #pragma unroll
-        for (int j = 0; j < 2; j++) {
-          const float send = (g & 1) ? r4[j] : r4[2 + j];
-          const float keep = (g & 1) ? r4[2 + j] : r4[j];
-          r2[j] = keep + __shfl_xor(send, 16);
-        }
-        float pp = w5j[0] * __builtin_fmaxf(r2[0] + b4j[0], 0.0f) + w5j[1] * __builtin_fmaxf(r2[1] + b4j[1], 0.0f);
-        pp += __shfl_xor(pp, 16);
-        pp += __shfl_xor(pp, 32);
-        if (live && g == 0) reinterpret_cast<float*>(outv)[(long long)b * cells + TFL_AT(d, x, y, z)] = pp + b5;
+        for (int j = 0; j < 2; j++) r2[j] = swap_sum16(r4[j], r4[2 + j]);
+        float pp = w5a * __builtin_fmaxf(r2[0] + b4a, 0.0f) + w5b * __builtin_fmaxf(r2[1] + b4b, 0.0f);
+        pp = swap_sum16(pp, pp);
+        pp = swap_sum32(pp, pp);
+        psel = g == oy ? pp : psel;           // lane group g stores row g
       }
+      if (live) reinterpret_cast<float*>(outv)[(long long)b * cells + TFL_AT(d, x, y, z)] = psel + b5;
+    }
+  };
+
+  // one input plane: its 12 fragments against the weights of the output planes it reaches (MASK bit dz: plane q - dz)
+  auto plane = [&](auto mask_c, int q) {
+    constexpr int MASK = decltype(mask_c)::value;
+    const uint4* fb = lds + (q % kMRing) * kMPitch + lane_slot;
+#pragma unroll
+    for (int ry = 0; ry < 6; ry++)
+#pragma unroll
+      for (int tm = 0; tm < 2; tm++) {
+        const h8 f = (TFL_M16_ABL & 8) ? W[ry][tm] : __builtin_bit_cast(h8, fb[(ry * 2 + tm) * kMHX]);
+#pragma unroll
+        for (int dy = 0; dy < 3; dy++) {
+          const int oy = ry - dy;
+          if (oy < 0 || oy > 3) continue;
+          if (MASK & 1) A0[oy] = __builtin_amdgcn_mfma_f32_16x16x32_f16(W[0 * 3 + dy][tm], f, A0[oy], 0, 0, 0);
+          if (MASK & 2) A1[oy] = __builtin_amdgcn_mfma_f32_16x16x32_f16(W[1 * 3 + dy][tm], f, A1[oy], 0, 0, 0);
+          if (MASK & 4) A2[oy] = __builtin_amdgcn_mfma_f32_16x16x32_f16(W[2 * 3 + dy][tm], f, A2[oy], 0, 0, 0);
+        }
+      }
+  };
+
+#pragma unroll
+  for (int q = 0; q < kMAhead; q++) issue(q);
+#pragma unroll 1
+  for (int q = 0; q < nsteps; q++) {
+    // plane q has landed once at most the (kMAhead - 1) younger planes' DMAs are outstanding (loads retire in order; the
+    // epilogue's stores share the counter and only make the wait stricter)
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((kMAhead - 1) * kMDma) : "memory");
+    __syncthreads();                  // every wave's part of plane q is in LDS; every wave is done reading plane q - 1
+    issue(q + kMAhead);               // into the slot of plane q - 1 (past the chunk: the zero page, keeps the count uniform)
+#pragma unroll
+    for (int r = 0; r < 4; r++) { A2[r] = A1[r]; A1[r] = A0[r]; A0[r] = (f4){0.0f, 0.0f, 0.0f, 0.0f}; }
+    const int mask = (q < nz ? 1 : 0) | ((q >= 1 && q <= nz) ? 2 : 0) | (q >= 2 ? 4 : 0);
+    switch (mask) {
+      case 1: plane(std::integral_constant<int, 1>(), q); break;
+      case 2: plane(std::integral_constant<int, 2>(), q); break;
+      case 3: plane(std::integral_constant<int, 3>(), q); break;
+      case 4: plane(std::integral_constant<int, 4>(), q); break;
+      case 5: plane(std::integral_constant<int, 5>(), q); break;
+      case 6: plane(std::integral_constant<int, 6>(), q); break;
+      default: plane(std::integral_constant<int, 7>(), q); break;
+    }
+    if (q >= 2) finish(zc0 + q - 2);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the trailing zero-page DMAs must not outlive the block's LDS
+  if (clipped) atomicAdd(range_err, 1ull);
+}
+
+template <bool TAIL>
+static void launch_m16z(hipStream_t st, const Dom& d, int B, const void* in, const void* wfrag, const float* bias, void* out,
+                        float post, unsigned long long* range_err) {
+  const int cxn = (d.X + kMX - 1) / kMX, cyn = (d.Y + kMY - 1) / kMY;
+  const int na = d.n0, nb = d.nw - d.n0;
+  if (cxn * cyn * (na + nb) * B <= 0) return;
+  // chunk length: at least ~3 blocks per CU when the grid allows, chunks no shorter than 8 planes (z halo 1.25)
+  int cz = ((long long)cxn * cyn * B * (na + nb) + 767) / 768;
+  cz = cz < 8 ? 8 : (cz > 32 ? 32 : cz);
+  if (const char* e = getenv("TFL_M16_CZ")) cz = atoi(e) > 0 ? atoi(e) : cz;
+  const int chunks_a = (na + cz - 1) / cz, chunks = chunks_a + (nb + cz - 1) / cz;
+  const int n_blocks = cxn * cyn * chunks * B;
+  const int grid = ((n_blocks + 7) / 8) * 8;
+  const size_t lds_bytes = (size_t)16 * kMRing * kMPitch;
+  static int attr_dev = -1;
+  int dev = 0; (void)hipGetDevice(&dev);
+  if (attr_dev != dev) {
+    (void)hipFuncSetAttribute((const void*)k_conv3_m16z<TAIL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    attr_dev = dev;
+    if (getenv("TFL_DEBUG")) {
+      int nbk = -1;
+      (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nbk, (const void*)k_conv3_m16z<TAIL>, 256, lds_bytes);
+      fprintf(stderr, "[tfl] k_conv3_m16z<%d>: dynamic LDS %zu B, occupancy %d blocks/CU, grid %d, chunks of %d planes\n", (int)TAIL, lds_bytes, nbk, grid, cz);
     }
   }
-  if (clipped) atomicAdd(range_err, 1ull);
+  TFL_TIMED_EXT(TAIL ? "k_conv3_tail" : "k_conv3_mid", st);
+  TFL_LAUNCH_EXT((k_conv3_m16z<TAIL>), grid, 256, lds_bytes, st, d, cxn, cyn, cz, chunks_a, chunks, n_blocks, (const uint4*)in,
+                 (const uint4*)wfrag, bias, out, post, range_err);
 }
 
 template <int MODE>
@@ -276,9 +590,14 @@ static void launch_m16(hipStream_t st, const Dom& d, int B, const void* in, cons
                        float post, MIn cin, unsigned long long* range_err) {
   const int tx = (d.X + kTX - 1) / kTX, ty = (d.Y + kTY - 1) / kTY;
   const int tz = (d.n0 + kTZ - 1) / kTZ + (d.nw - d.n0 + kTZ - 1) / kTZ;   // z-tiles of the compute window's two plane runs
-  const int n_tiles = tx * ty * tz * B;
-  if (n_tiles <= 0) return;
-  const int grid = ((n_tiles + 7) / 8) * 8;
+  if (tx * ty * tz * B <= 0) return;
+  // z-tiles per block: enough blocks to fill 256 CUs x 4, as few weight fetches as that allows
+  int nt = (tx * ty * tz * B) / 1024;
+  nt = nt < 1 ? 1 : (nt > 8 ? 8 : nt);
+  if (const char* e = getenv("TFL_M16_NT")) nt = atoi(e) > 0 ? atoi(e) : nt;
+  if (nt > tz) nt = tz;
+  const int n_chunks = tx * ty * ((tz + nt - 1) / nt) * B;
+  const int grid = ((n_chunks + 7) / 8) * 8;
   const size_t lds_bytes = (size_t)16 * kHZ * kHY * (MODE == kModeIn ? 1 : 2) * kHX;
   static int attr_dev = -1;                    // the attribute is per device
   int dev = 0; (void)hipGetDevice(&dev);
@@ -288,11 +607,11 @@ static void launch_m16(hipStream_t st, const Dom& d, int B, const void* in, cons
     if (getenv("TFL_DEBUG")) {
       int nb = -1;
       (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)k_conv3_m16<MODE>, 256, lds_bytes);
-      fprintf(stderr, "[tfl] k_conv3_m16<%d>: dynamic LDS %zu B, occupancy %d blocks/CU, grid %d\n", MODE, lds_bytes, nb, grid);
+      fprintf(stderr, "[tfl] k_conv3_m16<%d>: dynamic LDS %zu B, occupancy %d blocks/CU, grid %d, %d z-tiles per block\n", MODE, lds_bytes, nb, grid, nt);
     }
   }
   TFL_TIMED_EXT(MODE == kModeTail ? "k_conv3_tail" : (MODE == kModeIn ? "k_conv3_in" : "k_conv3_mid"), st);
-  TFL_LAUNCH_EXT((k_conv3_m16<MODE>), grid, 256, lds_bytes, st, d, tx, ty, tz, n_tiles, (const uint4*)in, (const uint4*)wfrag,
+  TFL_LAUNCH_EXT((k_conv3_m16<MODE>), grid, 256, lds_bytes, st, d, tx, ty, tz, nt, n_chunks, (const uint4*)in, (const uint4*)wfrag,
                  bias, out, post, cin, range_err);
 }
 
@@ -304,11 +623,15 @@ void conv3_m16_first_fused(hipStream_t st, int B, int Z, int Y, int X, const flo
 }
 void conv3_m16_mid(hipStream_t st, int B, int Z, int Y, int X, const void* in_h2, const void* wfrag, const float* bias, float post,
                    void* out_h2, unsigned long long* range_err) {
+  const bool tiled = getenv("TFL_M16_TILED") && (atoi(getenv("TFL_M16_TILED")) & 1);      // the tile kernel, kept for comparison
+  if (!tiled) { launch_m16z<false>(st, make_dom(Z, Y, X), B, in_h2, wfrag, bias, out_h2, post, range_err); return; }
   MIn noin = {nullptr, nullptr, nullptr, nullptr, 0.0};
   launch_m16<kModeMid>(st, make_dom(Z, Y, X), B, in_h2, wfrag, bias, out_h2, post, noin, range_err);
 }
 void conv3_m16_tail(hipStream_t st, int B, int Z, int Y, int X, const void* in_h2, const void* wfrag, const float* tail_pack,
                     float post, float* p_out, unsigned long long* range_err) {
+  const bool tiled = getenv("TFL_M16_TILED") && (atoi(getenv("TFL_M16_TILED")) & 2);
+  if (!tiled) { launch_m16z<true>(st, make_dom(Z, Y, X), B, in_h2, wfrag, tail_pack, p_out, post, range_err); return; }
   MIn noin = {nullptr, nullptr, nullptr, nullptr, 0.0};
   launch_m16<kModeTail>(st, make_dom(Z, Y, X), B, in_h2, wfrag, tail_pack, p_out, post, noin, range_err);
 }
@@ -348,7 +671,8 @@ float h2f(uint16_t h) {
 }
 }  // namespace
 
-// out: 9 * RT * 64 * 8 halves (RT = 1 for cin == 3, 2 for cin == 8); returns the post-scale 2^-(11 + e)
+// out: (9 * RT * 64 + 1) * 8 halves (RT = 1 for cin == 3, 2 for cin == 8; the last 16 bytes are zero: the source of the
+// kernels' out-of-grid staging slots); returns the post-scale 2^-(11 + e)
 float conv3_m16_pack_weights(const float* w, int cin, uint16_t* out) {
   const int RT = cin == 3 ? 1 : 2;
   float mx = 0.0f;
@@ -375,6 +699,7 @@ float conv3_m16_pack_weights(const float* w, int cin, uint16_t* out) {
           }
           out[(((size_t)p * RT + r) * 64 + lane) * 8 + j] = f2h(v);
         }
+  for (int j = 0; j < 8; j++) out[(size_t)9 * RT * 64 * 8 + j] = 0;
   return ldexpf(1.0f, -(11 + e));
 }
 

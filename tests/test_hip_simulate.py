@@ -169,10 +169,11 @@ def test_simulate_gravity_and_rgb_density(oracle):
 
 
 def test_conv_paths_agree_3d(oracle, monkeypatch):
-    """The vector-ALU kernels of conv_valu.hip (Winograd F(2,3) along x; the default), the fp32-MFMA implicit GEMM
-    (conv_mfma.hip) and the shape-generic direct kernels (conv.hip) are three fp32 evaluations of the same sums: they must
-    agree to rounding, including on grids that are ragged (and odd in x: the Winograd lanes own x-pairs) against the
-    64x2x4 / 32x8x4 tiles."""
+    """The split-operand fp16 MFMA kernels of conv_mfma16.hip (the default: z-marched 32x8 columns, and the 32x4x4 tile
+    form kept beside them), the vector-ALU kernels of conv_valu.hip (Winograd F(2,3) along x), the fp32-MFMA implicit GEMM
+    (conv_mfma.hip) and the shape-generic direct kernels (conv.hip) are evaluations of the same sums: they must agree to
+    rounding, including on grids that are ragged (and odd in x: the Winograd lanes own x-pairs) against the tiles; the
+    fp16 path must not have clamped anything."""
     import torch
     from fluidnet_amd import FluidNetModel
     layers = S.default_3d_layers(seed=5)
@@ -186,10 +187,21 @@ def test_conv_paths_agree_3d(oracle, monkeypatch):
         pm, Um = FluidNetModel(layers, True).forward([tp, tU, tf])
         rp, rU = scenes.rel_l2(pm.cpu().numpy(), pd.cpu().numpy()), scenes.rel_l2(Um.cpu().numpy(), Ud.cpu().numpy())
         assert rp <= 2e-6 and rU <= 2e-6, (dims, rp, rU)
-        monkeypatch.delenv("TFL_CONV_PATH")      # the default: conv_valu.hip, Winograd along x
+        monkeypatch.setenv("TFL_CONV_PATH", "winograd")      # conv_valu.hip, Winograd along x
         pw, Uw = FluidNetModel(layers, True).forward([tp, tU, tf])
         rp, rU = scenes.rel_l2(pw.cpu().numpy(), pd.cpu().numpy()), scenes.rel_l2(Uw.cpu().numpy(), Ud.cpu().numpy())
         assert rp <= 2e-6 and rU <= 2e-6, ("wino", dims, rp, rU)
+        monkeypatch.delenv("TFL_CONV_PATH")      # the default: conv_mfma16.hip
+        for tiled in (None, "3"):
+            if tiled:
+                monkeypatch.setenv("TFL_M16_TILED", tiled)
+            m16 = FluidNetModel(layers, True)
+            ph, Uh = m16.forward([tp, tU, tf])
+            rp, rU = scenes.rel_l2(ph.cpu().numpy(), pd.cpu().numpy()), scenes.rel_l2(Uh.cpu().numpy(), Ud.cpu().numpy())
+            assert rp <= 2e-6 and rU <= 2e-6, ("mfma16", tiled, dims, rp, rU)
+            assert m16.range_errors(tp) == 0
+            if tiled:
+                monkeypatch.delenv("TFL_M16_TILED")
         p_ref, U_ref = S.model_forward(oracle, layers, sc["p"], sc["U"], sc["flags"])
         assert scenes.rel_l2(pm.cpu().numpy(), p_ref) <= TOL and scenes.rel_l2(Um.cpu().numpy(), U_ref) <= TOL
 
