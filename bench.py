@@ -42,12 +42,19 @@ import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP32_PEAK_TFLOPS = 157.3   # same guide: fp32 matrix (= vector) peak
+F16_MFMA_PEAK_TFLOPS = 2500.0   # same guide: bf16 / fp16 MFMA, dense
+# conv_mfma16.hip (the default 3-D conv path): MFMA flops ISSUED per voxel. One v_mfma_f32_16x16x32_f16 = 16384 flop; a
+# wave issues 72 of them per 64 output voxels in the 8->8 layers (9 (dz, dy) taps x 2 activation terms per output row of 16
+# voxels) and 72 per 128 in the first layer (one activation term): every fp32 product is four fp16 products (hi/lo of both
+# operands) and one K group of four is idle, 16/3 issued flops per algorithmic flop.
+M16_ISSUED_FLOP_PER_VOXEL = {"k_conv3_in": 72 * 16384 / 128.0, "k_conv3_mid": 72 * 16384 / 64.0, "k_conv3_tail": 72 * 16384 / 64.0}
 
 # Algorithmic HBM bytes per CELL per launch (fp32, 3-D; each distinct input read once, each output
 # written once) -- SURVEY.md 8d restated per kernel of the fused implementation.
 ALG_BYTES_PER_CELL = {
-    "k_scalar_fwd": 24,      # s, U3, flags -> fwd                      (advectScalar pass A)
-    "k_scalar_bwd": 28,      # fwd, s, U3, flags -> dst                 (advectScalar pass B)  A+B = 52
+    "k_scalar_fwd": 24,      # s, U3, flags -> fwd                      (advectScalar pass A; + 8 B of clamp bounds)
+    "k_scalar_bwd": 28,      # fwd, s, U3, flags -> dst                 (advectScalar pass B; + 8 B)  A+B = 52
+    "k_stream_copy": 8,      # the yard-stick: float4 copy
     "k_vel_fwd": 28,         # U3, flags -> fwd3                        (advectVel pass A)
     "k_vel_bwd": 40,         # fwd3, U3, flags -> dst3                  (advectVel pass B)     A+B = 68
     "k_add_buoyancy": 32,    # U3, flags, rho -> U3
@@ -183,21 +190,29 @@ def make_stepper(res, world, rank, dev, model, scene):
 
 
 def measured_hbm_GBps(dev, mib=1024, reps=10):
-    """read + write rate of a 1 GiB device copy: what this box's HBM delivers to a streaming kernel (tools/hbm_bw.py)"""
+    """read + write rate of a 1 GiB device copy by the library's own float4 kernel (k_stream_copy, stencil.hip), timed
+    per launch with the built-in HIP-event profiler: what this box's HBM delivers to a streaming kernel."""
+    import ctypes
+    from fluidnet_amd import tfluids
     n = mib * (1 << 20) // 4
     a = torch.empty(n, device=dev).normal_()
     b = torch.empty_like(a)
+    lib, ctx = tfluids._context(a)
+
+    def copy():
+        rc = lib.tfl_stream_copy(ctx, ctypes.c_void_p(b.data_ptr()), ctypes.c_void_p(a.data_ptr()), n)
+        assert rc == 0, lib.tfl_last_error(ctx)
     for _ in range(2):
-        b.copy_(a)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        b.copy_(a)
-    torch.cuda.synchronize()
-    el = (time.perf_counter() - t0) / reps
+        copy()
+    with tfluids.profile(a) as prof:
+        for _ in range(reps):
+            copy()
+    rec = prof.kernels["k_stream_copy"]
+    ok = bool(torch.equal(a[:4096], b[:4096]) and torch.equal(a[-4096:], b[-4096:]))
     del a, b
     torch.cuda.empty_cache()
-    return 2.0 * n * 4 / el / 1e9
+    assert ok, "k_stream_copy did not copy"
+    return 2.0 * n * 4 / (rec["ms"] / rec["calls"] * 1e-3) / 1e9
 
 
 def _plume_scene(dims, rad, uscale, dev):
@@ -270,6 +285,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--res", type=int, default=128)
     ap.add_argument("--preroll", type=int, default=16, help="untimed steps that develop the plume before warm-up")
+    ap.add_argument("--blocks", type=int, default=5, help="timed blocks of --steps steps each; ms_per_step = their median")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-config5", action="store_true", help="skip the extra 256^3 (BASELINE config 5) measurement")
     ap.add_argument("--no-configs", action="store_true", help="skip BASELINE configs 1-3")
@@ -326,7 +342,11 @@ def main():
 
     for _ in range(args.preroll + args.warmup):
         step()
-    elapsed = timed(step, args.steps)
+    # EXACTLY --steps steps per timed block, barrier + synchronize on both sides; --blocks blocks back to back. The line
+    # reports the MEDIAN block (box-to-box and run-to-run noise on this pool is +-5 %, a round's gains are of that order)
+    # with the fastest and slowest beside it.
+    block_s = sorted(timed(step, args.steps) for _ in range(max(1, args.blocks)))
+    elapsed = block_s[len(block_s) // 2] if len(block_s) % 2 else 0.5 * (block_s[len(block_s) // 2 - 1] + block_s[len(block_s) // 2])
     assert bool(torch.isfinite(batch["UDiv"]).all()), "simulation blew up"
 
     total_cells = res ** 3
@@ -346,7 +366,7 @@ def main():
         kernels[name] = {"launches_per_step": rec["calls"] / nprof, "avg_ms": rec["ms"] / rec["calls"],
                          "ms_per_step": rec["ms"] / nprof}
     lf = [2.0 * w.shape[0] * w.shape[1] * w.shape[2] ** 3 for w, _ in model.layers]   # flop per voxel per layer
-    conv_path = os.environ.get("TFL_CONV_PATH", "winograd")
+    conv_path = os.environ.get("TFL_CONV_PATH", "mfma16")
     conv_flops_per_voxel = {"k_conv_direct": sum(lf), "k_conv3_mfma_in": lf[0], "k_conv3_mfma": lf[1],
                             "k_conv3_mfma_tail": sum(lf[2:]), "k_conv3_in": lf[0], "k_conv3_mid": lf[1], "k_conv3_tail": sum(lf[2:])}
 
@@ -365,8 +385,24 @@ def main():
             # name: the default 3-D path is Winograd F(2,3) along x on the VECTOR ALUs (conv_valu.hip; no MFMA issued;
             # 2/3 of a k3 layer's algorithmic MACs are issued), TFL_CONV_PATH=mfma the fp32-MFMA implicit GEMM
             wino = conv_path == "winograd" and name in ("k_conv3_in", "k_conv3_mid", "k_conv3_tail")
-            k["bound"], k["unit"] = ("fp32-valu-winograd" if wino else ("mfma" if "mfma" in name or conv_path == "mfma" else "fp32-valu")), "TFLOP/s"
-            k["achieved"] = conv_flops_per_voxel.get(name, 0.0) * cells_of(name) / (k["ms_per_step"] * 1e-3) / 1e12
+            m16 = conv_path == "mfma16" and name in M16_ISSUED_FLOP_PER_VOXEL
+            k["unit"] = "TFLOP/s"
+            alg = conv_flops_per_voxel.get(name, 0.0) * cells_of(name) / (k["ms_per_step"] * 1e-3) / 1e12
+            if m16:
+                # the matrix pipe's own roofline: MFMA flops the kernel issues against the dense fp16 MFMA peak. The layer's
+                # ALGORITHMIC (fp32-equivalent) flops are reported beside it; they are 3/16 of the issued ones.
+                k["bound"] = "mfma"
+                k["operands"] = "fp32 values as fp16 hi/lo pairs (2 x 11 bit + round-to-nearest: 23+ bit), fp32 accumulate"
+                k["achieved"] = M16_ISSUED_FLOP_PER_VOXEL[name] * cells_of(name) / (k["ms_per_step"] * 1e-3) / 1e12
+                k["peak"] = F16_MFMA_PEAK_TFLOPS
+                k["frac"] = k["achieved"] / F16_MFMA_PEAK_TFLOPS
+                k["algorithmic_TFLOPs"] = alg
+                k["algorithmic_frac_of_fp32_peak"] = alg / FP32_PEAK_TFLOPS
+                k["algorithmic_frac_of_f16_mfma_peak"] = alg / F16_MFMA_PEAK_TFLOPS
+                continue
+            k["bound"] = "fp32-valu-winograd" if wino else ("mfma-f32" if "mfma" in name or conv_path == "mfma" else "fp32-valu")
+            k["achieved"] = alg
+            k["peak"] = FP32_PEAK_TFLOPS
             k["frac"] = k["achieved"] / FP32_PEAK_TFLOPS
             if wino:   # flops the kernel really issues: x-taps 4 multiplies per 2 outputs instead of 6; the 1x1x1 layers in full
                 issued = {"k_conv3_in": lf[0] * 2 / 3, "k_conv3_mid": lf[1] * 2 / 3, "k_conv3_tail": lf[2] * 2 / 3 + sum(lf[3:])}[name]
@@ -377,21 +413,38 @@ def main():
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if world == 1 and res == 128 and os.path.exists(tpath):
         try:
+            from fluidnet_amd import _kernels
             tj = json.load(open(tpath))
-            traffic = tj.get(dom)
             meta = tj.get("_meta", {})
-            traffic_source = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this bench at commit %s)" \
-                % meta.get("commit", "r01")
-        except Exception:
-            traffic = None
+            fname, sha_now = _kernels.source_sha(dom, conv_path)
+            rec = (meta.get("source_sha") or {}).get(dom)
+            if dom not in tj:
+                traffic_source = "null: %s is not in profiles/pmc_traffic.json" % dom
+            elif not rec or rec[1] is None or rec[1] != sha_now:
+                # a PMC figure describes the code it was measured on: refuse it when the kernel's source file has changed
+                traffic_source = ("null: profiles/pmc_traffic.json (commit %s) was measured on another version of %s "
+                                  "(git blob %s then, %s now); re-run tools/pmc_bench.sh" %
+                                  (meta.get("commit", "?"), fname, (rec or [None, None])[1], sha_now))
+            else:
+                traffic = tj[dom]
+                traffic_source = ("profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this bench at commit %s, "
+                                  "%s unchanged since (git blob %s)" % (meta.get("commit", "?"), fname, sha_now[:12]))
+        except Exception as e:      # noqa: BLE001
+            traffic, traffic_source = None, "null: %r" % (e,)
     hbm_meas = measured_hbm_GBps(dev)
+    sum_kernel_ms = sum(k["ms_per_step"] for k in kernels.values())
     roofline = {"kernel": dom, "bound": dk.get("bound"), "achieved": dk.get("achieved"),
-                "peak": HBM_PEAK_GBS if dk.get("bound") == "hbm" else FP32_PEAK_TFLOPS, "unit": dk.get("unit"),
+                "peak": HBM_PEAK_GBS if dk.get("bound") == "hbm" else dk.get("peak", FP32_PEAK_TFLOPS), "unit": dk.get("unit"),
                 "frac": dk.get("frac"), "issued_frac": dk.get("issued_frac"),
                 "frac_of_measured_hbm": (dk["achieved"] / hbm_meas if dk.get("bound") == "hbm" else None),
                 "traffic": traffic, "traffic_source": traffic_source,
-                "avg_launch_ms": dk["avg_ms"], "launches_per_step": dk["launches_per_step"],
-                "note": "sum of per-kernel averages reads ~3% above ms_per_step (dispatches overlap at their edges)"}
+                "avg_launch_ms": dk["avg_ms"], "launches_per_step": dk["launches_per_step"]}
+    for extra in ("operands", "algorithmic_TFLOPs", "algorithmic_frac_of_fp32_peak", "algorithmic_frac_of_f16_mfma_peak"):
+        if extra in dk:
+            roofline[extra] = dk[extra]
+    if dk.get("bound") == "mfma":
+        roofline["note"] = ("achieved / peak / frac = MFMA flops ISSUED against the dense fp16 MFMA peak (matrix-pipe utilisation); "
+                            "the layer's algorithmic fp32 flops are 3/16 of them (split operands: 4 products per fp32 product, 3 of 4 K groups used)")
     headline = {}
     if "k_vel_fwd" in kernels and "k_vel_bwd" in kernels:   # the north-star's "advection kernel" figure
         t = kernels["k_vel_fwd"]["ms_per_step"] + kernels["k_vel_bwd"]["ms_per_step"]
@@ -432,7 +485,11 @@ def main():
     out = {
         "metric": "simulate_mcells_per_s", "value": total_cells * args.steps / elapsed / 1e6, "unit": "Mcells/s",
         "steps_per_s": args.steps / elapsed, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": ms, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+        "ms_per_step": ms, "ms_per_step_min": block_s[0] / args.steps * 1e3, "ms_per_step_max": block_s[-1] / args.steps * 1e3,
+        "timed_blocks": len(block_s), "sum_kernel_ms": sum_kernel_ms, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+        "dtype_note": "every operator computes in fp32; the 3-D conv stack multiplies fp32 values held as fp16 hi/lo pairs on the "
+                      "matrix cores with fp32 accumulation (conv_mfma16.hip; error vs an fp64 convolution below PyTorch-fp32's)"
+                      if conv_path == "mfma16" else "fp32 throughout",
         "data": "synthetic",
         "config": {"workload": "BASELINE config 4 / the metric's 128^3 series: 3-D %d^3 plume + voxel obstacle (procedural "
                                "stand-in), MacCormack(Ours) advection, buoyancy, vorticity confinement, ConvNet projection "

@@ -1,0 +1,38 @@
+"""Which source file each profiled kernel name of the library lives in (the names the built-in profiler and
+tools/pmc_traffic.py report), and the git blob hash of a file: bench.py refuses a stored PMC traffic figure whose
+kernel source has changed since it was measured."""
+import hashlib
+import os
+
+CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+
+KERNEL_SOURCE = {
+    "k_conv3_in": "conv_mfma16.hip", "k_conv3_mid": "conv_mfma16.hip", "k_conv3_tail": "conv_mfma16.hip",
+    "k_vel_fwd": "advect_vel3.hip", "k_vel_bwd": "advect_vel3.hip",
+    "k_scalar_fwd": "advect_scalar3.hip", "k_scalar_bwd": "advect_scalar3.hip", "k_minmax3": "advect.hip",
+    "k_curl": "vorticity.hip", "k_confine": "vorticity.hip",
+    "k_add_buoyancy": "stencil.hip", "k_add_gravity": "stencil.hip",
+    "k_bcs_div_stats": "model.hip", "k_reduce_stats": "model.hip", "k_project": "model.hip", "k_net_input": "model.hip",
+    "k_apply_bcs_indexed": "model.hip", "k_bc_scan": "model.hip",
+}
+# the default conv path can be switched by TFL_CONV_PATH; these are the files behind the same profiler names then
+CONV_SOURCE = {"winograd": "conv_valu.hip", "mfma": "conv_mfma.hip", "direct": "conv.hip", "mfma16": "conv_mfma16.hip"}
+
+
+def blob_sha(path):
+    """`git hash-object <path>` without git"""
+    data = open(path, "rb").read()
+    return hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
+
+
+def source_of(kernel, conv_path="mfma16"):
+    f = KERNEL_SOURCE.get(kernel)
+    if f and kernel.startswith("k_conv3_"):
+        f = CONV_SOURCE.get(conv_path, f)
+    return f
+
+
+def source_sha(kernel, conv_path="mfma16"):
+    f = source_of(kernel, conv_path)
+    p = os.path.join(CSRC, f) if f else None
+    return (f, blob_sha(p)) if p and os.path.exists(p) else (f, None)

@@ -71,7 +71,7 @@ COMM_START_V = _c.CFUNCTYPE(_c.c_int, _c.c_void_p, _c.c_int, _c.c_int, _c.POINTE
 class tfl_comm(_c.Structure):
     """include/tfluids_hip.h tfl_comm: the transport callbacks of the z-slab step (exchange_start_v: optional, NULL here
     unless a transport sets it -- the Python transports move one staged buffer per neighbour)."""
-    _fields_ = [("user", _c.c_void_p), ("exchange_start", COMM_START), ("exchange_wait", COMM_WAIT),
+    _fields_ = [("size", _c.c_int32), ("user", _c.c_void_p), ("exchange_start", COMM_START), ("exchange_wait", COMM_WAIT),
                 ("allreduce_sum", COMM_ALLREDUCE), ("exchange_start_v", COMM_START_V)]
 
 
@@ -140,6 +140,7 @@ SIGNATURES = {
                                             _c.c_void_p, _c.c_int64, _c.c_void_p]),
     "tfl_getDx": (_c.c_double, [_c.c_void_p, _T]),
     "tfl_copy": (_c.c_int, [_c.c_void_p, _T, _T]),
+    "tfl_stream_copy": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int64]),
     "tfl_bc_plan_create": (_c.c_void_p, [_c.c_void_p, _T, _T]),
     "tfl_bc_plan_destroy": (None, [_c.c_void_p, _c.c_void_p]),
     "tfl_simulate_workspace_floats": (_c.c_int64, [_c.c_void_p, _c.POINTER(tfl_sim_params), _c.POINTER(tfl_sim_state)]),
@@ -151,6 +152,8 @@ SIGNATURES = {
     "tfl_setWallBcsBackward": (_c.c_int, [_c.c_void_p, _T, _T, _c.c_int, _T]),
     "tfl_set_z_window": (_c.c_int, [_c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.c_int]),
     "tfl_set_stages": (_c.c_int, [_c.c_void_p, _c.c_int]),
+    "tfl_set_advect_mode": (_c.c_int, [_c.c_void_p, _c.c_int]),
+    "tfl_get_advect_mode": (_c.c_int, [_c.c_void_p]),
     "tfl_set_z_origin": (_c.c_int, [_c.c_void_p, _c.c_int, _c.c_int]),
     "tfl_model_div": (_c.c_void_p, [_c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p]),
     "tfl_slab_halo": (_c.c_int32, [_c.c_int32]),

@@ -60,6 +60,7 @@ static const int kMaxBatch = 1024;
 namespace tfl {
 thread_local ZWin g_zwin = {0, 0, 0, 0};
 thread_local ZOrigin g_zorigin = {0, 0};
+thread_local int g_advect_fast = 0;
 struct ProfRec { const char* name; hipEvent_t e0, e1; };
 struct Profiler { std::vector<ProfRec> recs; };
 static thread_local Profiler* g_prof = nullptr;
@@ -141,8 +142,8 @@ int check_scalar(tfl_ctx* ctx, const char* op, const char* name, const tfl_tenso
 // calling thread (tfl_host.hpp make_dom); it is cleared again on the way out so that every other operator -- and every
 // other context used from this thread -- sees the whole array.
 struct WindowScope {
-  explicit WindowScope(const tfl_ctx* c) { tfl::g_zwin = c->zwin; tfl::g_zorigin = c->zorigin; }
-  ~WindowScope() { tfl::g_zwin = tfl::ZWin{0, 0, 0, 0}; tfl::g_zorigin = tfl::ZOrigin{0, 0}; }
+  explicit WindowScope(const tfl_ctx* c) { tfl::g_zwin = c->zwin; tfl::g_zorigin = c->zorigin; tfl::g_advect_fast = c->advect_fast; }
+  ~WindowScope() { tfl::g_zwin = tfl::ZWin{0, 0, 0, 0}; tfl::g_zorigin = tfl::ZOrigin{0, 0}; tfl::g_advect_fast = 0; }
 };
 int stages_of(const tfl_ctx* c) { return c->stages ? c->stages : 0xff; }
 
@@ -185,8 +186,17 @@ tfl_ctx* tfl_create(int device) {
     return nullptr;
   }
   c->h_reach[0] = 0.0f;
+  if (const char* m = getenv("TFL_ADVECT_MODE")) c->advect_fast = (strcmp(m, "fast") == 0 || strcmp(m, "1") == 0) ? 1 : 0;
   return c;
 }
+
+int tfl_set_advect_mode(tfl_ctx* c, int mode) {
+  if (!c) return TFL_EINVAL;
+  if (mode != TFL_ADVECT_EXACT && mode != TFL_ADVECT_FAST) return fail(c, TFL_EINVAL, "set_advect_mode: unknown mode %d", mode);
+  c->advect_fast = mode == TFL_ADVECT_FAST ? 1 : 0;
+  return TFL_OK;
+}
+int tfl_get_advect_mode(const tfl_ctx* c) { return c ? (c->advect_fast ? TFL_ADVECT_FAST : TFL_ADVECT_EXACT) : TFL_EINVAL; }
 
 void tfl_destroy(tfl_ctx* c) {
   if (!c) return;
@@ -992,6 +1002,14 @@ int tfl_copy(tfl_ctx* c, const tfl_tensor* dst, const tfl_tensor* src) {
   if (n != (long long)src->B * src->C * src->Z * src->Y * src->X) return fail(c, TFL_EINVAL, "copy: size mismatch");
   HIP_TRY(c, hipMemcpyAsync(dst->data, src->data, sizeof(float) * (size_t)n, hipMemcpyDeviceToDevice, c->stream));
   return TFL_OK;
+}
+
+int tfl_stream_copy(tfl_ctx* c, float* dst, const float* src, int64_t n) {
+  if (!c) return TFL_EINVAL;
+  if (!dst || !src || n < 0 || (n & 3) || (((uintptr_t)dst | (uintptr_t)src) & 15))
+    return fail(c, TFL_EINVAL, "stream_copy: needs 16-byte aligned pointers and a multiple of 4 floats");
+  tfl::stream_copy(c->stream, n / 4, src, dst);
+  return check_launch(c, "stream_copy");
 }
 
 int tfl_applyBCs(tfl_ctx* c, const tfl_tensor* x, const tfl_tensor* bc, const tfl_tensor* invMask, int doClamp,

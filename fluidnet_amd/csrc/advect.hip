@@ -21,26 +21,11 @@
 namespace tfl {
 
 
-template <bool IS3D>
-__device__ __forceinline__ float sample_s(const Dom& d, const float* g, const float* flags, v3 p, int outside) {
-  return outside ? interpol<IS3D>(d, g, p) : interpol_with_fluid<IS3D>(d, g, flags, p);
-}
-
 // Manta SemiLagrange, tfluids.cc:209-218
 template <bool IS3D>
 __device__ __forceinline__ float sl_manta(const Dom& d, const float* U, const float* src, float dt, int i, int j, int k) {
   const v3 c = cell_centre(d, i, j, k), u = get_centered<IS3D>(d, U, i, j, k);
   return interpol<IS3D>(d, src, mk3(c.x - u.x * dt, c.y - u.y * dt, c.z - u.z * dt));
-}
-
-// SemiLagrangeEulerOurs[SavePos], tfluids.cc:152-207 (fluid cells only; caller handles the rest)
-template <bool IS3D>
-__device__ __forceinline__ float sl_euler_ours(const AdvArgs& a, const float* flags, const float* U, const float* src,
-                                               float dt, int i, int j, int k, v3& back) {
-  const v3 c = cell_centre(a.d, i, j, k);
-  const v3 disp = scale3(get_centered<IS3D>(a.d, U, i, j, k), -dt);
-  count_trace_error(line_trace(a.d, flags, c, disp, back), a.err);
-  return sample_s<IS3D>(a.d, src, flags, back, a.outside);
 }
 
 // SemiLagrangeRK2Ours, tfluids.cc:23-77
@@ -372,6 +357,10 @@ static void launch_scalar(hipStream_t st, int method, const AdvArgs& a, int B, c
   // stages (tfl_set_stages): 1 = the 3^dim min/max grid, 2 = pass A, 4 = pass B; single-pass methods are "pass A"
   const bool pm = stages & 1, pa = stages & 2, pb = stages & 4;
   if (method != kMacCormack && method != kMacCormackOurs && !pa) return;
+  // the trace-based methods on a 3-D grid: LDS-tiled fast-path kernels without a min/max grid (advect_scalar3.hip)
+  if (IS3D && (method == kEulerOurs || method == kMacCormackOurs) &&
+      advect_scalar3(st, method == kMacCormackOurs, a, B, s, U, flags, fwd, bounds, dst, stages))
+    return;
   switch (method) {
     case kEuler: { TFL_TIMED("k_scalar_fwd", st); k_scalar_fwd<IS3D, kEuler><<<grd, blk, 0, st>>>(a, s, U, flags, dst, nullptr, nullptr, nullptr); break; }
     case kEulerOurs: { TFL_TIMED("k_scalar_fwd", st); k_scalar_fwd<IS3D, kEulerOurs><<<grd, blk, 0, st>>>(a, s, U, flags, dst, nullptr, nullptr, nullptr); break; }
@@ -408,7 +397,7 @@ void minmax3(hipStream_t st, bool is3d, int B, int Z, int Y, int X, int outside,
 void advect_scalar(hipStream_t st, bool is3d, int method, int B, int Z, int Y, int X, float dt, float strength,
                    int outside, unsigned long long* err, const float* s, const float* U, const float* flags,
                    float* fwd, float* bounds, float* mm, float* dst, int stages) {
-  AdvArgs a; a.d = make_dom(Z, Y, X); a.dt = dt; a.strength = strength; a.outside = outside; a.err = err;
+  AdvArgs a; a.d = make_dom(Z, Y, X); a.dt = dt; a.strength = strength; a.outside = outside; a.err = err; a.fast = g_advect_fast;
   if (is3d) launch_scalar<true>(st, method, a, B, s, U, flags, fwd, bounds, mm, dst, stages);
   else launch_scalar<false>(st, method, a, B, s, U, flags, fwd, bounds, mm, dst, stages);
 }
@@ -440,7 +429,7 @@ static void launch_vel(hipStream_t st, int method, const AdvArgs& a, int B, cons
 void advect_vel(hipStream_t st, bool is3d, int method, int B, int Z, int Y, int X, float dt, float strength,
                 unsigned long long* err, const float* U, const float* flags, float* fwd, float* dst, int stages) {
   if (method == kRK2Ours || method == kRK3Ours) method = kMacCormackOurs;  // tfluids.cc:799-802
-  AdvArgs a; a.d = make_dom(Z, Y, X); a.dt = dt; a.strength = strength; a.outside = 0; a.err = err;
+  AdvArgs a; a.d = make_dom(Z, Y, X); a.dt = dt; a.strength = strength; a.outside = 0; a.err = err; a.fast = g_advect_fast;
   if (is3d) launch_vel<true>(st, method, a, B, U, flags, fwd, dst, stages);
   else launch_vel<false>(st, method, a, B, U, flags, fwd, dst, stages);
 }

@@ -11,7 +11,7 @@
 //    special cases: ONE trace step, no wall clipping, no ray/box test, no index clamps, every tap inside the 3^3
 //    neighbourhood of the cell. That path is straight-line code with the reference's operation order; the
 //    division by the trace length uses one refined reciprocal for the three components and the norm a one-step
-//    corrected v_sqrt, both proven bit-equal to `/` and sqrtf() on the operand range (tfl_fastmath.hpp,
+//    corrected v_sqrt: the root checked exhaustively, the quotient SAMPLE-verified bit-equal to sqrtf() / `/` on the operand range (tfl_fastmath.hpp,
 //    tools/ubench/exact_math.hip). Every other lane (walls, obstacles' neighbours, fast flow) runs the generic
 //    functions of tfl_device.hpp / tfl_advect.hpp afterwards, from scratch: same result as before by construction.
 //  * LDS TILE. Per 64x4x1-cell block the 66x6x3 halo tile of U (3 components) and flags is staged once with
@@ -109,10 +109,18 @@ __device__ __forceinline__ void mac_from_tile(const float* __restrict__ t, int c
 // One ordinary back-trace (calcLineTrace with length <= kFastLen: a single step, calc_line_trace.cc:313-503).
 // Returns false when the lane needs the generic trace (long displacement, NaN, end point not in a fluid cell).
 // `p` is the traced position (global z); valid only when true is returned.
+// FAST (the tolerance mode, tfl_set_advect_mode): direction x length IS the displacement, so the end point is ctr + d --
+// no root, no reciprocal, no quotients (the reference's normalise-then-rescale differs from it by an ulp or two of the
+// position); the thresholds (|d|^2 > 1e-6, |d| <= 0.99) are applied to the squared length.
+template <bool FAST>
 __device__ __forceinline__ bool trace_fast(const float* __restrict__ tile, int cbias, v3 ctr, v3 u, float ndt, v3& p) {
   const float dx = u.x * ndt, dy = u.y * ndt, dz = u.z * ndt;     // scale3(u, -dt)
   const float l2 = dx * dx + dy * dy + dz * dz;                   // vec3::norm, vec3.h:119-127
   const bool nz = l2 > 1e-6f;
+  if (FAST) {
+    p.x = nz ? ctr.x + dx : ctr.x; p.y = nz ? ctr.y + dy : ctr.y; p.z = nz ? ctr.z + dz : ctr.z;
+    return (l2 <= kFastLen * kFastLen) & plain_fluid(tile[FL + tidx((int)p.x, (int)p.y, (int)p.z, cbias)]);
+  }
   const float len = nz ? sqrt_exact(l2) : 0.0f;
   const float r = nz ? rcp_refined(len) : 0.0f;                   // len == 0: direction 0, p = ctr (the reference returns pos)
   const float qx = div_by<1>(dx, len, r), qy = div_by<1>(dy, len, r), qz = div_by<1>(dz, len, r);
@@ -133,16 +141,24 @@ __device__ __forceinline__ FastLerp lerp_fast(v3 p) {
   L.s0 = 1.0f - L.s1; L.t0 = 1.0f - L.t1; L.f0 = 1.0f - L.f1;
   return L;
 }
+template <bool FAST>
 __device__ __forceinline__ float lerp8(const FastLerp& L, float g000, float g010, float g100, float g110, float g001,
                                        float g011, float g101, float g111) {   // g[x][y][z]
+  if (FAST) {   // a + t (b - a): 14 instead of 21 operations, contracted
+    const float a0 = __builtin_fmaf(L.t1, g010 - g000, g000), a1 = __builtin_fmaf(L.t1, g110 - g100, g100);
+    const float b0 = __builtin_fmaf(L.t1, g011 - g001, g001), b1 = __builtin_fmaf(L.t1, g111 - g101, g101);
+    const float lo = __builtin_fmaf(L.s1, a1 - a0, a0), hi = __builtin_fmaf(L.s1, b1 - b0, b0);
+    return __builtin_fmaf(L.f1, hi - lo, lo);
+  }
   const float lo = (g000 * L.t0 + g010 * L.t1) * L.s0 + (g100 * L.t0 + g110 * L.t1) * L.s1;
   const float hi = (g001 * L.t0 + g011 * L.t1) * L.s0 + (g101 * L.t0 + g111 * L.t1) * L.s1;
   return lo * L.f0 + hi * L.f1;
 }
+template <bool FAST>
 __device__ __forceinline__ float sample_tile(const float* __restrict__ g, int cbias, v3 p) {
   const FastLerp L = lerp_fast(p);
   const float* q = g + tidx(L.x, L.y, L.z, cbias);
-  return lerp8(L, q[0], q[LX], q[1], q[1 + LX], q[LP], q[LP + LX], q[LP + 1], q[LP + 1 + LX]);
+  return lerp8<FAST>(L, q[0], q[LX], q[1], q[1 + LX], q[LP], q[LP + LX], q[LP + 1], q[LP + 1 + LX]);
 }
 
 // min/max of the 2^3 corner box at tile index b, accumulated as manta_clamp_bounds does (tfl_advect.hpp)
@@ -202,6 +218,7 @@ __device__ __forceinline__ void stg(float* __restrict__ base, unsigned byte_off,
 }
 
 // ---- pass A / the single-pass method: SemiLagrangeEulerOursMAC ------------------------------------------------
+template <bool FAST>
 __global__ __launch_bounds__(256) void k_vel3_fwd(AdvArgs a, const float* __restrict__ U, const float* __restrict__ flags,
                                                   float* __restrict__ out) {
   TFL_VEL3_PROLOGUE();
@@ -212,12 +229,12 @@ __global__ __launch_bounds__(256) void k_vel3_fwd(AdvArgs a, const float* __rest
   if (deep && plain_fluid(cf)) {
     v3 u0, u1, u2, p0, p1, p2;
     mac_from_tile(tile, c0, u0, u1, u2);
-    const bool k0 = trace_fast(tile, cbias, ctr, u0, -a.dt, p0);
-    const bool k1 = trace_fast(tile, cbias, ctr, u1, -a.dt, p1);
-    const bool k2 = trace_fast(tile, cbias, ctr, u2, -a.dt, p2);
-    v0 = sample_tile(tile, cbias, p0);
-    v1 = sample_tile(tile + LN, cbias, p1);
-    v2 = sample_tile(tile + 2 * LN, cbias, p2);
+    const bool k0 = trace_fast<FAST>(tile, cbias, ctr, u0, -a.dt, p0);
+    const bool k1 = trace_fast<FAST>(tile, cbias, ctr, u1, -a.dt, p1);
+    const bool k2 = trace_fast<FAST>(tile, cbias, ctr, u2, -a.dt, p2);
+    v0 = sample_tile<FAST>(tile, cbias, p0);
+    v1 = sample_tile<FAST>(tile + LN, cbias, p1);
+    v2 = sample_tile<FAST>(tile + 2 * LN, cbias, p2);
     slow = (k0 ? 0u : 1u) | (k1 ? 0u : 2u) | (k2 ? 0u : 4u);
   } else if (!on_border<true>(d, i, j, k)) {
     if ((((int)cf) & kFluid) == 0) { v0 = tile[c0]; v1 = tile[LN + c0]; v2 = tile[2 * LN + c0]; }   // tfluids.cc:598-601
@@ -245,6 +262,7 @@ __device__ __forceinline__ void gather8_global(const float* __restrict__ g, cons
   c[4] = ldg(g, a10); c[5] = ldg(g, a11); c[6] = ldg(g, a10 + one4); c[7] = ldg(g, a11 + one4);
 }
 
+template <bool FAST>
 __global__ __launch_bounds__(256) void k_vel3_bwd(AdvArgs a, double half_strength, const float* __restrict__ U,
                                                   const float* __restrict__ flags, const float* __restrict__ fwd,
                                                   float* __restrict__ dst) {
@@ -260,9 +278,9 @@ __global__ __launch_bounds__(256) void k_vel3_bwd(AdvArgs a, double half_strengt
                s2 = (((int)tile[FL + c0 - LP]) & kFluid) == 0;
     v3 u0, u1, u2, p0, p1, p2;
     mac_from_tile(tile, c0, u0, u1, u2);
-    const bool k0 = trace_fast(tile, cbias, ctr, u0, a.dt, p0);
-    const bool k1 = trace_fast(tile, cbias, ctr, u1, a.dt, p1);
-    const bool k2 = trace_fast(tile, cbias, ctr, u2, a.dt, p2);
+    const bool k0 = trace_fast<FAST>(tile, cbias, ctr, u0, a.dt, p0);
+    const bool k1 = trace_fast<FAST>(tile, cbias, ctr, u1, a.dt, p1);
+    const bool k2 = trace_fast<FAST>(tile, cbias, ctr, u2, a.dt, p2);
     const FastLerp L0 = lerp_fast(p0), L1 = lerp_fast(p1), L2 = lerp_fast(p2);
     float g0[8], g1[8], g2[8];
     gather8_global(fwd, d, o4, k0, L0, g0);
@@ -274,13 +292,20 @@ __global__ __launch_bounds__(256) void k_vel3_bwd(AdvArgs a, double half_strengt
     clamp_bounds_tile(tile + LN, cbias, ijk, scale3(u1, a.dt), lo1, hi1);
     clamp_bounds_tile(tile + 2 * LN, cbias, ijk, scale3(u2, a.dt), lo2, hi2);
     const float uo0 = tile[c0], uo1 = tile[LN + c0], uo2 = tile[2 * LN + c0];
-    const float b0 = lerp8(L0, g0[0], g0[1], g0[2], g0[3], g0[4], g0[5], g0[6], g0[7]);
-    const float b1 = lerp8(L1, g1[0], g1[1], g1[2], g1[3], g1[4], g1[5], g1[6], g1[7]);
-    const float b2 = lerp8(L2, g2[0], g2[1], g2[2], g2[3], g2[4], g2[5], g2[6], g2[7]);
+    const float b0 = lerp8<FAST>(L0, g0[0], g0[1], g0[2], g0[3], g0[4], g0[5], g0[6], g0[7]);
+    const float b1 = lerp8<FAST>(L1, g1[0], g1[1], g1[2], g1[3], g1[4], g1[5], g1[6], g1[7]);
+    const float b2 = lerp8<FAST>(L2, g2[0], g2[1], g2[2], g2[3], g2[4], g2[5], g2[6], g2[7]);
     // the reference evaluates f + strength * 0.5 * (orig - bwd) in double (unsuffixed 0.5, tfluids.cc:693)
-    if (!s0) r0 = (float)((double)f0 + half_strength * (double)(uo0 - b0));
-    if (!s1) r1 = (float)((double)f1 + half_strength * (double)(uo1 - b1));
-    if (!s2) r2 = (float)((double)f2 + half_strength * (double)(uo2 - b2));
+    if (FAST) {   // the correction in fp32, contracted
+      const float hs = (float)half_strength;
+      if (!s0) r0 = __builtin_fmaf(hs, uo0 - b0, f0);
+      if (!s1) r1 = __builtin_fmaf(hs, uo1 - b1, f1);
+      if (!s2) r2 = __builtin_fmaf(hs, uo2 - b2, f2);
+    } else {
+      if (!s0) r0 = (float)((double)f0 + half_strength * (double)(uo0 - b0));
+      if (!s1) r1 = (float)((double)f1 + half_strength * (double)(uo1 - b1));
+      if (!s2) r2 = (float)((double)f2 + half_strength * (double)(uo2 - b2));
+    }
     // std::min(hi, std::max(lo, v)) with lo <= hi (extrema of one set): the median of the three
     r0 = __builtin_amdgcn_fmed3f(r0, lo0, hi0); r1 = __builtin_amdgcn_fmed3f(r1, lo1, hi1);
     r2 = __builtin_amdgcn_fmed3f(r2, lo2, hi2);
@@ -323,18 +348,21 @@ bool advect_vel3(hipStream_t st, bool two_pass, const AdvArgs& a, int B, const f
                  float* dst, int stages) {
   static const bool off = getenv("TFL_ADVECT_GATHER") != nullptr;   // A/B switch: the round-2 gather kernels
   const Dom& d = a.d;
-  // 24-bit multiplies address the planes (4*X*Y < 2^24) and 32-bit byte offsets the cells of one channel (Z*Y*X < 2^30)
-  if (off || d.Z < 3 || (long long)d.X * d.Y * 4 >= (1 << 24) || (long long)d.sc >= (1ll << 30)) return false;
+  // 24-bit multiplies address the planes (4*X*Y < 2^24); 32-bit BYTE offsets address the cells of all three channels
+  // (o4 + 2*sc4 in the loads / stores of U, fwd, dst): 12*Z*Y*X < 2^32. Larger grids take the gather kernels.
+  if (off || d.Z < 3 || (long long)d.X * d.Y * 4 >= (1 << 24) || 12ll * d.sc >= (1ll << 32)) return false;
   const dim3 blk(TX, TY, 1), grd = cell_grid(d, B, blk);
   const bool pa = stages & 2, pb = stages & 4;
-  if (!two_pass) {
-    if (pa) { TFL_TIMED_EXT("k_vel_fwd", st); TFL_LAUNCH_EXT(k_vel3_fwd, grd, blk, 0, st, a, U, flags, dst); }
-    return true;
+  float* outA = two_pass ? fwd : dst;
+  if (pa) {
+    TFL_TIMED_EXT("k_vel_fwd", st);
+    if (a.fast) TFL_LAUNCH_EXT(k_vel3_fwd<true>, grd, blk, 0, st, a, U, flags, outA);
+    else TFL_LAUNCH_EXT(k_vel3_fwd<false>, grd, blk, 0, st, a, U, flags, outA);
   }
-  if (pa) { TFL_TIMED_EXT("k_vel_fwd", st); TFL_LAUNCH_EXT(k_vel3_fwd, grd, blk, 0, st, a, U, flags, fwd); }
-  if (pb) {
+  if (two_pass && pb) {
     TFL_TIMED_EXT("k_vel_bwd", st);
-    TFL_LAUNCH_EXT(k_vel3_bwd, grd, blk, 0, st, a, (double)a.strength * 0.5, U, flags, (const float*)fwd, dst);
+    if (a.fast) TFL_LAUNCH_EXT(k_vel3_bwd<true>, grd, blk, 0, st, a, (double)a.strength * 0.5, U, flags, (const float*)fwd, dst);
+    else TFL_LAUNCH_EXT(k_vel3_bwd<false>, grd, blk, 0, st, a, (double)a.strength * 0.5, U, flags, (const float*)fwd, dst);
   }
   return true;
 }

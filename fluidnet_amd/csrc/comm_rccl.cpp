@@ -119,6 +119,8 @@ int hip_fail(tfl_rccl_comm* q, const char* what, hipError_t e) {
   return 1;
 }
 #define RCHK(call, what) do { int rc_ = (call); if (rc_ != kNcclSuccess) return fail(q, what, rc_); } while (0)
+// inside ncclGroupStart ... ncclGroupEnd: a failing call must still close the group on this thread before returning
+#define GCHK(call, what) do { int rc_ = (call); if (rc_ != kNcclSuccess) { (void)a->GroupEnd(); return fail(q, what, rc_); } } while (0)
 #define HCHK(call, what) do { hipError_t e_ = (call); if (e_ != hipSuccess) return hip_fail(q, what, e_); } while (0)
 
 int cb_exchange_start(void* user, int tag, const float* send_lo, int64_t n_send_lo, float* recv_lo, int64_t n_recv_lo,
@@ -130,10 +132,10 @@ int cb_exchange_start(void* user, int tag, const float* send_lo, int64_t n_send_
   HCHK(hipEventRecord(q->ready, q->ctx->stream), "hipEventRecord");
   HCHK(hipStreamWaitEvent(q->stream, q->ready, 0), "hipStreamWaitEvent");
   RCHK(a->GroupStart(), "ncclGroupStart");
-  if (n_send_lo > 0 && q->rank > 0) RCHK(a->Send(send_lo, (size_t)n_send_lo, kNcclFloat, q->rank - 1, q->comm, q->stream), "ncclSend(lower)");
-  if (n_recv_lo > 0 && q->rank > 0) RCHK(a->Recv(recv_lo, (size_t)n_recv_lo, kNcclFloat, q->rank - 1, q->comm, q->stream), "ncclRecv(lower)");
-  if (n_send_hi > 0 && q->rank + 1 < q->world) RCHK(a->Send(send_hi, (size_t)n_send_hi, kNcclFloat, q->rank + 1, q->comm, q->stream), "ncclSend(upper)");
-  if (n_recv_hi > 0 && q->rank + 1 < q->world) RCHK(a->Recv(recv_hi, (size_t)n_recv_hi, kNcclFloat, q->rank + 1, q->comm, q->stream), "ncclRecv(upper)");
+  if (n_send_lo > 0 && q->rank > 0) GCHK(a->Send(send_lo, (size_t)n_send_lo, kNcclFloat, q->rank - 1, q->comm, q->stream), "ncclSend(lower)");
+  if (n_recv_lo > 0 && q->rank > 0) GCHK(a->Recv(recv_lo, (size_t)n_recv_lo, kNcclFloat, q->rank - 1, q->comm, q->stream), "ncclRecv(lower)");
+  if (n_send_hi > 0 && q->rank + 1 < q->world) GCHK(a->Send(send_hi, (size_t)n_send_hi, kNcclFloat, q->rank + 1, q->comm, q->stream), "ncclSend(upper)");
+  if (n_recv_hi > 0 && q->rank + 1 < q->world) GCHK(a->Recv(recv_hi, (size_t)n_recv_hi, kNcclFloat, q->rank + 1, q->comm, q->stream), "ncclRecv(upper)");
   RCHK(a->GroupEnd(), "ncclGroupEnd");
   HCHK(hipEventRecord(q->done[tag], q->stream), "hipEventRecord");
   return 0;
@@ -151,13 +153,13 @@ int cb_exchange_start_v(void* user, int tag, int n_lo, const tfl_comm_chunk* sen
   RCHK(a->GroupStart(), "ncclGroupStart");
   if (q->rank > 0)
     for (int i = 0; i < n_lo; i++) {
-      if (send_lo[i].n > 0) RCHK(a->Send(send_lo[i].ptr, (size_t)send_lo[i].n, kNcclFloat, q->rank - 1, q->comm, q->stream), "ncclSend(lower)");
-      if (recv_lo[i].n > 0) RCHK(a->Recv(recv_lo[i].ptr, (size_t)recv_lo[i].n, kNcclFloat, q->rank - 1, q->comm, q->stream), "ncclRecv(lower)");
+      if (send_lo[i].n > 0) GCHK(a->Send(send_lo[i].ptr, (size_t)send_lo[i].n, kNcclFloat, q->rank - 1, q->comm, q->stream), "ncclSend(lower)");
+      if (recv_lo[i].n > 0) GCHK(a->Recv(recv_lo[i].ptr, (size_t)recv_lo[i].n, kNcclFloat, q->rank - 1, q->comm, q->stream), "ncclRecv(lower)");
     }
   if (q->rank + 1 < q->world)
     for (int i = 0; i < n_hi; i++) {
-      if (send_hi[i].n > 0) RCHK(a->Send(send_hi[i].ptr, (size_t)send_hi[i].n, kNcclFloat, q->rank + 1, q->comm, q->stream), "ncclSend(upper)");
-      if (recv_hi[i].n > 0) RCHK(a->Recv(recv_hi[i].ptr, (size_t)recv_hi[i].n, kNcclFloat, q->rank + 1, q->comm, q->stream), "ncclRecv(upper)");
+      if (send_hi[i].n > 0) GCHK(a->Send(send_hi[i].ptr, (size_t)send_hi[i].n, kNcclFloat, q->rank + 1, q->comm, q->stream), "ncclSend(upper)");
+      if (recv_hi[i].n > 0) GCHK(a->Recv(recv_hi[i].ptr, (size_t)recv_hi[i].n, kNcclFloat, q->rank + 1, q->comm, q->stream), "ncclRecv(upper)");
     }
   RCHK(a->GroupEnd(), "ncclGroupEnd");
   HCHK(hipEventRecord(q->done[tag], q->stream), "hipEventRecord");
@@ -190,7 +192,13 @@ tfl_rccl_comm* make(tfl_ctx* c, const RcclApi* a, NcclComm comm, bool owns, int 
             hipEventCreateWithFlags(&q->ready, hipEventDisableTiming) == hipSuccess &&
             hipEventCreateWithFlags(&q->reduced, hipEventDisableTiming) == hipSuccess;
   for (int t = 0; ok && t < kTags; t++) ok = hipEventCreateWithFlags(&q->done[t], hipEventDisableTiming) == hipSuccess;
-  if (!ok) { c->err = "rccl transport: could not create the communication stream / events"; tfl_rccl_comm_destroy(c, q); return nullptr; }
+  if (!ok) {
+    c->err = "rccl transport: could not create the communication stream / events";
+    q->owns_comm = false;      // the caller still owns `comm` on this path (tfl_rccl_comm_create destroys it once)
+    tfl_rccl_comm_destroy(c, q);
+    return nullptr;
+  }
+  q->callbacks.size = (int32_t)sizeof(tfl_comm);
   q->callbacks.user = q;
   q->callbacks.exchange_start = cb_exchange_start;
   q->callbacks.exchange_wait = cb_exchange_wait;

@@ -38,10 +38,12 @@
 #include "tfl_fastmath.hpp"
 #include "tfl_host.hpp"
 
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <type_traits>
 
 namespace tfl {
@@ -555,20 +557,59 @@ __global__ __launch_bounds__(256, TFL_M16Z_LB) void k_conv3_m16z(Dom d, int cols
   if (clipped) atomicAdd(range_err, 1ull);
 }
 
+// compute units of the current device (cached per device)
+static int device_cus() {
+  static std::atomic<int> cus[64];
+  int dev = 0; (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= 64) dev = 0;
+  int n = cus[dev].load();
+  if (!n) {
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    cus[dev].store(n);
+  }
+  return n;
+}
+
+// resident blocks per CU of a kernel with `lds` bytes of dynamic LDS (asked once per kernel; `fallback` if the runtime cannot say)
+static int blocks_per_cu(const void* fn, size_t lds, int fallback) {
+  struct Rec { const void* fn; int n; };
+  static Rec recs[16];
+  static int nrec = 0;
+  static std::mutex mu;                       // virtual ranks launch from several host threads
+  std::lock_guard<std::mutex> lock(mu);
+  for (int i = 0; i < nrec; i++) if (recs[i].fn == fn) return recs[i].n;
+  (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  int n = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, 256, lds) != hipSuccess || n <= 0) n = fallback;
+  if (nrec < 16) { recs[nrec].fn = fn; recs[nrec].n = n; nrec++; }
+  return n;
+}
+
 template <bool TAIL>
 static void launch_m16z(hipStream_t st, const Dom& d, int B, const void* in, const void* wfrag, const float* bias, void* out,
                         float post, unsigned long long* range_err) {
   const int cxn = (d.X + kMX - 1) / kMX, cyn = (d.Y + kMY - 1) / kMY;
   const int na = d.n0, nb = d.nw - d.n0;
   if (cxn * cyn * (na + nb) * B <= 0) return;
-  // chunk length: at least ~3 blocks per CU when the grid allows, chunks no shorter than 8 planes (z halo 1.25)
-  int cz = ((long long)cxn * cyn * B * (na + nb) + 767) / 768;
-  cz = cz < 8 ? 8 : (cz > 32 ? 32 : cz);
+  // chunk length: all blocks of a launch wait for each other's CU slots in ROUNDS of (CUs x blocks per CU); a block of cz
+  // output planes walks cz + 2 input planes (+ ~2 plane-times of weight fetch and pipeline fill). Take the cz in [8, 32]
+  // that minimises rounds x (cz + 4): at 128^3 that is 16 planes (512 blocks = ONE round on 256 CUs x 2) where "three
+  // blocks per CU" gave 768 blocks = two rounds of 13 planes.
+  const size_t lds_bytes = (size_t)16 * kMRing * kMPitch;
+  const int slots = device_cus() * blocks_per_cu((const void*)k_conv3_m16z<TAIL>, lds_bytes, TFL_M16Z_LB);
+  int cz = 8;
+  {
+    long long best = -1;
+    for (int c = 8; c <= 32; c++) {
+      const long long blocks = (long long)cxn * cyn * B * ((na + c - 1) / c + (nb + c - 1) / c);
+      const long long cost = ((blocks + slots - 1) / slots) * (c + 4);
+      if (best < 0 || cost < best) { best = cost; cz = c; }
+    }
+  }
   if (const char* e = getenv("TFL_M16_CZ")) cz = atoi(e) > 0 ? atoi(e) : cz;
   const int chunks_a = (na + cz - 1) / cz, chunks = chunks_a + (nb + cz - 1) / cz;
   const int n_blocks = cxn * cyn * chunks * B;
   const int grid = ((n_blocks + 7) / 8) * 8;
-  const size_t lds_bytes = (size_t)16 * kMRing * kMPitch;
   static int attr_dev = -1;
   int dev = 0; (void)hipGetDevice(&dev);
   if (attr_dev != dev) {
@@ -591,14 +632,23 @@ static void launch_m16(hipStream_t st, const Dom& d, int B, const void* in, cons
   const int tx = (d.X + kTX - 1) / kTX, ty = (d.Y + kTY - 1) / kTY;
   const int tz = (d.n0 + kTZ - 1) / kTZ + (d.nw - d.n0 + kTZ - 1) / kTZ;   // z-tiles of the compute window's two plane runs
   if (tx * ty * tz * B <= 0) return;
-  // z-tiles per block: enough blocks to fill 256 CUs x 4, as few weight fetches as that allows
-  int nt = (tx * ty * tz * B) / 1024;
-  nt = nt < 1 ? 1 : (nt > 8 ? 8 : nt);
+  // z-tiles per block (the weight fragments are fetched once per block): the nt in [1, 8] that minimises
+  // rounds x (nt + 1/2), rounds = blocks / (CUs x blocks per CU) rounded up -- 128^3: 6 (768 blocks, one round)
+  const size_t lds_bytes = (size_t)16 * kHZ * kHY * (MODE == kModeIn ? 1 : 2) * kHX;
+  const int slots = device_cus() * blocks_per_cu((const void*)k_conv3_m16<MODE>, lds_bytes, TFL_M16_LB);
+  int nt = 1;
+  {
+    long long best = -1;
+    for (int c = 1; c <= 8 && c <= (tz > 0 ? tz : 1); c++) {
+      const long long blocks = (long long)tx * ty * B * ((tz + c - 1) / c);
+      const long long cost = ((blocks + slots - 1) / slots) * (2 * c + 1);
+      if (best < 0 || cost < best) { best = cost; nt = c; }
+    }
+  }
   if (const char* e = getenv("TFL_M16_NT")) nt = atoi(e) > 0 ? atoi(e) : nt;
   if (nt > tz) nt = tz;
   const int n_chunks = tx * ty * ((tz + nt - 1) / nt) * B;
   const int grid = ((n_chunks + 7) / 8) * 8;
-  const size_t lds_bytes = (size_t)16 * kHZ * kHY * (MODE == kModeIn ? 1 : 2) * kHX;
   static int attr_dev = -1;                    // the attribute is per device
   int dev = 0; (void)hipGetDevice(&dev);
   if (attr_dev != dev) {

@@ -6,6 +6,7 @@
 #include "tfl_ctx.hpp"
 #include "tfl_host.hpp"
 
+#include <cstddef>
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -348,16 +349,21 @@ int msg_chunks(const SlabGeom& g, const Msg& q, bool lower, bool send, tfl_comm_
 }
 constexpr int kMaxChunks = 64;     // per neighbour and message: (B * C) of every field of the message
 
+// the optional in-place transport, read only when the host's struct is large enough to hold it (tfl_comm::size)
+static inline decltype(tfl_comm::exchange_start_v) start_v_of(const tfl_comm* comm) {
+  return comm->size >= (int32_t)(offsetof(tfl_comm, exchange_start_v) + sizeof(comm->exchange_start_v)) ? comm->exchange_start_v : nullptr;
+}
+
 int msg_start(tfl_ctx* c, const SlabGeom& g, const tfl_comm* comm, const Msg& q) {
   if ((!g.lower && !g.upper) || q.n == 0) return TFL_OK;
-  if (comm->exchange_start_v) {
+  if (auto start_v = start_v_of(comm)) {
     int rows = 0;
     for (int i = 0; i < q.n; i++) rows += q.f[i].t->B * q.f[i].t->C;
     if (q.n > 0 && rows <= kMaxChunks) {
       tfl_comm_chunk slo[kMaxChunks], rlo[kMaxChunks], shi[kMaxChunks], rhi[kMaxChunks];
       const int n_lo = msg_chunks(g, q, true, true, slo), n_hi = msg_chunks(g, q, false, true, shi);
       msg_chunks(g, q, true, false, rlo); msg_chunks(g, q, false, false, rhi);
-      if (comm->exchange_start_v(comm->user, q.tag, n_lo, slo, rlo, n_hi, shi, rhi) != 0) { c->err = "simulate_step_slab: comm callback failed (exchange_start_v)"; return TFL_EINVAL; }
+      if (start_v(comm->user, q.tag, n_lo, slo, rlo, n_hi, shi, rhi) != 0) { c->err = "simulate_step_slab: comm callback failed (exchange_start_v)"; return TFL_EINVAL; }
       return TFL_OK;
     }
   }
@@ -371,7 +377,7 @@ int msg_finish(tfl_ctx* c, const SlabGeom& g, const tfl_comm* comm, const Msg& q
   if (comm->exchange_wait(comm->user, q.tag) != 0) { c->err = "simulate_step_slab: comm callback failed (exchange_wait)"; return TFL_EINVAL; }
   int rows = 0;
   for (int i = 0; i < q.n; i++) rows += q.f[i].t->B * q.f[i].t->C;
-  if (comm->exchange_start_v && q.n > 0 && rows <= kMaxChunks) return TFL_OK;      // delivered in place
+  if (start_v_of(comm) && q.n > 0 && rows <= kMaxChunks) return TFL_OK;      // delivered in place
   pack_msg(c, g, q, true);
   return TFL_OK;
 }
@@ -474,7 +480,11 @@ int tfl_simulate_step_slab(tfl_ctx* c, const tfl_sim_params* prm, const tfl_sim_
   int rc = slab_geom(c, s, sl, &g);
   if (rc) return rc;
   const bool multi = g.lower || g.upper;
-  if (multi && (!comm || !comm->exchange_start || !comm->exchange_wait || !comm->allreduce_sum)) return TFL_EINVAL;
+  if (multi && (!comm || comm->size < (int32_t)(offsetof(tfl_comm, allreduce_sum) + sizeof(comm->allreduce_sum)) ||
+                !comm->exchange_start || !comm->exchange_wait || !comm->allreduce_sum)) {
+    c->err = "simulate_step_slab: tfl_comm is null, has no size (ABI 3: size = sizeof(tfl_comm)) or lacks a required callback";
+    return TFL_EINVAL;
+  }
   const Sizes z = sizes_of(s);
   if (!z.is3d) return bad("2-D grids have no z to cut (run replicas)");
   const char* method = (prm->advectionMethod && prm->advectionMethod[0]) ? prm->advectionMethod : "maccormackOurs";

@@ -211,6 +211,24 @@ void absmax(hipStream_t st, long long n, const float* x, float* out, bool reset)
   { TFL_TIMED("k_absmax", st); k_absmax<<<blocks > 0 ? blocks : 1, 256, 0, st>>>(n, x, out); }
 }
 
+// The yard-stick of every HBM fraction bench.py reports: a plain streaming copy, 16 bytes per lane and access, four
+// independent accesses per thread in flight (the guide's "float4 copy": ~6.3 of the 8 TB/s pin rate on this part).
+typedef float f4v __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void k_stream_copy(const f4v* __restrict__ src, f4v* __restrict__ dst, long long n4) {
+  const long long i0 = (long long)blockIdx.x * 1024 + threadIdx.x;
+  f4v v[4];
+#pragma unroll
+  for (int u = 0; u < 4; u++) { const long long i = i0 + u * 256; if (i < n4) v[u] = __builtin_nontemporal_load(src + i); }
+#pragma unroll
+  for (int u = 0; u < 4; u++) { const long long i = i0 + u * 256; if (i < n4) __builtin_nontemporal_store(v[u], dst + i); }
+}
+void stream_copy(hipStream_t st, long long n4, const float* src, float* dst) {
+  if (n4 <= 0) return;
+  TFL_TIMED_EXT("k_stream_copy", st);
+  TFL_LAUNCH_EXT(k_stream_copy, (unsigned)((n4 + 1023) / 1024), 256, 0, st, reinterpret_cast<const f4v*>(src),
+                 reinterpret_cast<f4v*>(dst), n4);
+}
+
 static inline dim3 cgrid(const Dom& d, int B, dim3 blk) {
   return dim3((d.X + blk.x - 1) / blk.x, (d.Y + blk.y - 1) / blk.y, (unsigned)(d.nw * B));
 }

@@ -11,6 +11,7 @@ struct AdvArgs {
   float dt;
   float strength;
   int outside;  // sampleOutsideFluid
+  int fast;     // tfl_set_advect_mode: 1 = the tolerance mode of the LDS-tiled 3-D kernels (advect_vel3.hip, advect_scalar3.hip)
   unsigned long long* err;
 };
 
@@ -100,6 +101,21 @@ __device__ __forceinline__ float sl_mac_from_u(const AdvArgs& a, const float* fl
   return interpol<IS3D>(a.d, src + AXIS * a.d.sc, p);
 }
 
+template <bool IS3D>
+__device__ __forceinline__ float sample_s(const Dom& d, const float* g, const float* flags, v3 p, int outside) {
+  return outside ? interpol<IS3D>(d, g, p) : interpol_with_fluid<IS3D>(d, g, flags, p);
+}
+
+// SemiLagrangeEulerOurs[SavePos], tfluids.cc:152-207 (fluid cells only; caller handles the rest)
+template <bool IS3D>
+__device__ __forceinline__ float sl_euler_ours(const AdvArgs& a, const float* flags, const float* U, const float* src,
+                                               float dt, int i, int j, int k, v3& back) {
+  const v3 c = cell_centre(a.d, i, j, k);
+  const v3 disp = scale3(get_centered<IS3D>(a.d, U, i, j, k), -dt);
+  count_trace_error(line_trace(a.d, flags, c, disp, back), a.err);
+  return sample_s<IS3D>(a.d, src, flags, back, a.outside);
+}
+
 static inline dim3 cell_grid(const Dom& d, int B, dim3 blk) {
   return dim3((d.X + blk.x - 1) / blk.x, (d.Y + blk.y - 1) / blk.y, (unsigned)(d.nw * B));
 }
@@ -108,5 +124,8 @@ static inline dim3 cell_grid(const Dom& d, int B, dim3 blk) {
 // advect_vel3.hip: advectVel of the trace-based methods on a 3-D grid; false = shape not supported (caller falls back)
 bool advect_vel3(hipStream_t st, bool two_pass, const AdvArgs& a, int B, const float* U, const float* flags, float* fwd,
                  float* dst, int stages);
+// advect_scalar3.hip: advectScalar of the trace-based methods on a 3-D grid (no min/max grid: `bounds` = two planes)
+bool advect_scalar3(hipStream_t st, bool two_pass, const AdvArgs& a, int B, const float* s, const float* U, const float* flags,
+                    float* fwd, float* bounds, float* dst, int stages);
 
 }  // namespace tfl

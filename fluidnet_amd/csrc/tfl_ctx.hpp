@@ -18,6 +18,7 @@ struct tfl_ctx {
   int dx_dim = 0;                             // > 0: dx = 1/dx_dim formed exactly like getDx does (tfl_simulate_step_slab)
   tfl::ZWin zwin = {0, 0, 0, 0};              // tfl_set_z_window: planes the next operators compute (all zero = all)
   tfl::ZOrigin zorigin = {0, 0};              // tfl_set_z_origin: where the arrays sit in the whole grid (z-slab ranks)
+  int advect_fast = 0;                        // tfl_set_advect_mode (initialised from TFL_ADVECT_MODE by tfl_create)
   int stages = 0;                             // tfl_set_stages: which passes of a multi-pass operator run (0 = all)
   float* d_reach = nullptr;                   // z-slab reach check: max|u_z| of the current step (device word)
   float* h_reach = nullptr;                   // pinned mirror, read by the NEXT tfl_simulate_step_slab call

@@ -7,9 +7,10 @@
 // In that range the scaling, the special-case fix-up and two of the three reciprocals are dead weight:
 //   r  = refined reciprocal of b (v_rcp + one Newton step)                     3 VALU, shared by the 3 quotients
 //   q0 = a * r; e = fma(-b, q0, a) (exact remainder); q = fma(e, r, q0)        3 VALU per quotient (+2 per extra step)
-// tools/ubench/exact_math.hip proves bit equality with `/` and sqrtf() on the GPU (2^33 hashed pairs + every
+// tools/ubench/exact_math.hip checks bit equality with `/` and sqrtf() on the GPU (the quotient on a SAMPLE: 2^33 hashed pairs + every
 // mantissa of b; every float in [2^-40, 2^40) for the root); its verdict is recorded in profiles/.
-// Outside the proven range (denormal quotients, b near the ends of the exponent range, inf/NaN) the results may
+// (the root exhaustively; for the quotient this is evidence, not a proof: a single Markstein step is only guaranteed
+// given a correctly rounded reciprocal -- TFL_DIV_STEPS=2 is the setting for strict parity). Outside the checked range (denormal quotients, b near the ends of the exponent range, inf/NaN) the results may
 // differ from `/`: callers use them only where DESIGN 3.2 shows the operands are inside it or the result is discarded.
 #pragma once
 #include <hip/hip_runtime.h>

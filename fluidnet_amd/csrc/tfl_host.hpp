@@ -14,6 +14,8 @@ extern thread_local ZWin g_zwin;
 // z origin of the array inside the whole grid (tfl_set_z_origin): {first global plane, planes of the whole grid}; {0, 0} = none
 struct ZOrigin { int first, total; };
 extern thread_local ZOrigin g_zorigin;
+// tfl_set_advect_mode of the calling thread's current operator: 1 = tolerance mode of the LDS-tiled 3-D advection kernels
+extern thread_local int g_advect_fast;
 
 inline Dom make_dom(int Z, int Y, int X) {
   Dom d; d.X = X; d.Y = Y; d.Z = Z; d.sy = X; d.sz = X * Y; d.sc = X * Y * Z; d.one = 1;
@@ -86,6 +88,7 @@ void flags_to_occupancy(hipStream_t st, long long numel, const float* flags, flo
 void rectangular_blur(hipStream_t st, bool is3d, int B, int C, int Z, int Y, int X, int rad, const float* src, float* dst,
                       float* tmp);
 void signed_distance_field(hipStream_t st, int B, int Z, int Y, int X, int rad, const float* flags, float* dst);
+void stream_copy(hipStream_t st, long long n4, const float* src, float* dst);   // n4 float4s, 16-byte aligned
 void absmax(hipStream_t st, long long n, const float* x, float* out, bool reset);   // *out = max(*out, max |x|)
 
 // vorticity.hip

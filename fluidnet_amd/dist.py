@@ -64,7 +64,7 @@ class _CommBase:
         self.ws = None
         self.error = None
         self._cb = (COMM_START(self._c_start), COMM_WAIT(self._c_wait), COMM_ALLREDUCE(self._c_allreduce))
-        self.struct = tfl_comm(None, *self._cb)
+        self.struct = tfl_comm(ctypes.sizeof(tfl_comm), None, *self._cb)
 
     def bind(self, ws):
         self.ws = ws

@@ -42,6 +42,9 @@ void tfl_destroy(tfl_ctx* ctx);
 int tfl_set_stream(tfl_ctx* ctx, void* hip_stream);
 const char* tfl_last_error(const tfl_ctx* ctx);
 int tfl_abi_version(void);
+enum { TFL_ADVECT_EXACT = 0, TFL_ADVECT_FAST = 1 };
+int tfl_set_advect_mode(tfl_ctx* ctx, int mode);
+int tfl_get_advect_mode(const tfl_ctx* ctx);
 int tfl_synchronize(tfl_ctx* ctx);
 int64_t tfl_trace_errors(tfl_ctx* ctx);
 int tfl_profile_begin(tfl_ctx* ctx);
@@ -139,6 +142,7 @@ int tfl_applyBCsIndexedMulti(tfl_ctx* ctx, int count, const tfl_tensor* const* x
                              const tfl_tensor* const* invMask, const int32_t* const* idx, const int64_t* n);
 double tfl_getDx(tfl_ctx* ctx, const tfl_tensor* flags);
 int tfl_copy(tfl_ctx* ctx, const tfl_tensor* dst, const tfl_tensor* src);
+int tfl_stream_copy(tfl_ctx* ctx, float* dst, const float* src, int64_t n);
 typedef struct tfl_bc_plan tfl_bc_plan;
 tfl_bc_plan* tfl_bc_plan_create(tfl_ctx* ctx, const tfl_tensor* bc, const tfl_tensor* invMask);
 void tfl_bc_plan_destroy(tfl_ctx* ctx, tfl_bc_plan* plan);
@@ -189,6 +193,7 @@ typedef struct tfl_comm_chunk {
   int64_t n;
 } tfl_comm_chunk;
 typedef struct tfl_comm {
+  int32_t size;
   void* user;
   int (*exchange_start)(void* user, int tag, const float* send_lo, int64_t n_send_lo, float* recv_lo, int64_t n_recv_lo,
                         const float* send_hi, int64_t n_send_hi, float* recv_hi, int64_t n_recv_hi);

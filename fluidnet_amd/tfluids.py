@@ -42,6 +42,23 @@ def _context(t):
     return lib, ctx
 
 
+ADVECT_EXACT, ADVECT_FAST = 0, 1
+
+
+def set_advect_mode(t, mode):
+    """Arithmetic of the LDS-tiled 3-D advection kernels on t's device (include/tfluids_hip.h tfl_set_advect_mode):
+    "exact" (default; bit-equal to the reference CPU path) or "fast" (the tolerance mode, rel-L2 <= 1e-5).
+    Returns the previous mode's name."""
+    lib, ctx = _context(t)
+    names = {"exact": ADVECT_EXACT, "fast": ADVECT_FAST, ADVECT_EXACT: ADVECT_EXACT, ADVECT_FAST: ADVECT_FAST}
+    _check(mode in names, "advect mode must be 'exact' or 'fast'")
+    prev = lib.tfl_get_advect_mode(ctx)
+    rc = lib.tfl_set_advect_mode(ctx, names[mode])
+    if rc != 0:
+        raise TfluidsError(lib.tfl_last_error(ctx).decode())
+    return "fast" if prev == ADVECT_FAST else "exact"
+
+
 def _tt(t):
     _check(t.dtype == torch.float32, "tensors must be float32")
     b, c, z, y, x = t.shape

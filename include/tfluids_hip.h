@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define TFL_ABI_VERSION 2
+#define TFL_ABI_VERSION 3   /* 3: tfl_comm starts with its own size; tfl_set_advect_mode, tfl_stream_copy */
 
 typedef enum tfl_status {
   TFL_OK = 0,
@@ -46,7 +46,8 @@ typedef enum tfl_status {
  * Supported sizes: the elements of ONE batch item fit a signed 32-bit index, C*Z*Y*X < 2^31 (element strides are
  * int32 inside the kernels; the batch offset is applied in 64 bits), e.g. a 3-channel velocity up to 894^3. Larger
  * tensors are refused with TFL_EUNSUPPORTED, never computed wrongly. The LDS-tiled 3-D advection kernels further use
- * 24-bit plane strides (4*X*Y < 2^24, i.e. X*Y <= 2047^2) and fall back to the gather kernels beyond that. */
+ * 24-bit plane strides (4*X*Y < 2^24, i.e. X*Y <= 2047^2) and 32-bit byte offsets over the three velocity channels
+ * (12*Z*Y*X < 2^32, i.e. up to ~710^3) and fall back to the gather kernels beyond that. */
 typedef struct tfl_tensor {
   float* data;
   int32_t B, C, Z, Y, X;
@@ -69,6 +70,18 @@ void tfl_destroy(tfl_ctx* ctx);
 int tfl_set_stream(tfl_ctx* ctx, void* hip_stream);
 const char* tfl_last_error(const tfl_ctx* ctx);
 int tfl_abi_version(void);
+/* Arithmetic of the LDS-tiled 3-D advection kernels (advectVel / advectScalar, methods eulerOurs and maccormackOurs):
+ *   TFL_ADVECT_EXACT (default)  every operation in the reference's order and rounding: results are bit-equal to the
+ *                               reference CPU path (third_party/tfluids.cc:152-234,594-774), which the golden tests pin;
+ *   TFL_ADVECT_FAST             the tolerance mode: trace end point = centre + displacement (no normalise / rescale round
+ *                               trip), trilinear samples as contracted a + t (b - a), MacCormack correction in fp32.
+ *                               Differs from the reference by a few ulp per cell; held to the north-star's rel-L2 <= 1e-5
+ *                               by tests/test_hip_fullsize.py. Lanes off the fast path (obstacle neighbours, fast flow)
+ *                               run the exact generic code in both modes.
+ * A context starts in the mode named by the environment variable TFL_ADVECT_MODE ("fast" | "exact"; unset = exact). */
+enum { TFL_ADVECT_EXACT = 0, TFL_ADVECT_FAST = 1 };
+int tfl_set_advect_mode(tfl_ctx* ctx, int mode);
+int tfl_get_advect_mode(const tfl_ctx* ctx);
 /* Blocks until the context's stream is idle (cutorch.synchronize(), simulate.lua:258). */
 int tfl_synchronize(tfl_ctx* ctx);
 /* Number of back-traces that hit one of calcLineTrace's invariant-violation paths since the last
@@ -327,6 +340,9 @@ double tfl_getDx(tfl_ctx* ctx, const tfl_tensor* flags);
 
 /* `dst:copy(src)` on the context's stream (same element count). */
 int tfl_copy(tfl_ctx* ctx, const tfl_tensor* dst, const tfl_tensor* src);
+/* A plain streaming copy of n floats (16-byte aligned, n % 4 == 0) by the library's own float4 kernel: the measured
+ * HBM yard-stick of bench.py (timed through tfl_profile_begin / _end as "k_stream_copy"). No reference counterpart. */
+int tfl_stream_copy(tfl_ctx* ctx, float* dst, const float* src, int64_t n);
 
 /* ---- the whole step as one call: lib/simulate.lua:175-327 in native code -------------------------------------
  * For hosts that are not Python (the LuaJIT binding): tfl_simulate_step runs tfluids.simulate() -- advectScalar
@@ -442,6 +458,8 @@ typedef struct tfl_comm_chunk {   /* n contiguous floats of device memory */
 } tfl_comm_chunk;
 
 typedef struct tfl_comm {
+  int32_t size;   /* sizeof(tfl_comm) as the HOST compiled it: the library reads no member that lies beyond it, so a host built
+                     against a header without the optional trailing callbacks keeps working (0 is refused) */
   void* user;
   int (*exchange_start)(void* user, int tag, const float* send_lo, int64_t n_send_lo, float* recv_lo, int64_t n_recv_lo,
                         const float* send_hi, int64_t n_send_hi, float* recv_hi, int64_t n_recv_hi);

@@ -41,8 +41,22 @@ def _scene(res, config):
     return batch, mconf
 
 
+@pytest.fixture
+def advect_mode(request):
+    """Runs the test body with the context in the named advection mode (tfl_set_advect_mode) and restores `exact`."""
+    import torch
+    from fluidnet_amd import tfluids
+    probe = torch.zeros(1, device="cuda:0")
+    tfluids.set_advect_mode(probe, request.param)
+    yield request.param
+    tfluids.set_advect_mode(probe, "exact")
+
+
+@pytest.mark.parametrize("advect_mode", ["exact", "fast"], indirect=True)
 @pytest.mark.parametrize("res,config,preroll,steps", [(64, 3, 12, 3), (128, 4, 12, 2), (256, 5, 8, 2)])
-def test_simulate_parity_at_baseline_size(request, res, config, preroll, steps):
+def test_simulate_parity_at_baseline_size(request, advect_mode, res, config, preroll, steps):
+    """Both advection modes against the compiled reference: `exact` (the default; its operators are bit-equal to the
+    reference, test_hip_parity.py) and `fast` (the tolerance mode of advect_vel3.hip / advect_scalar3.hip)."""
     import torch
     from fluidnet_amd import FluidNetModel
     from fluidnet_amd.simulate import simulate_native
@@ -61,7 +75,7 @@ def test_simulate_parity_at_baseline_size(request, res, config, preroll, steps):
     for k in ("pDiv", "UDiv", "density"):
         got = batch[k].cpu().numpy()
         r = scenes.rel_l2(got, nb[k])
-        print("parity %d^3 vs %s: %s rel-L2 %.2e" % (res, kind, k, r))
+        print("parity %d^3 (%s advection) vs %s: %s rel-L2 %.2e" % (res, advect_mode, kind, k, r))
         assert np.isfinite(got).all() and r <= TOL, (res, kind, k, r)
 
 
@@ -92,5 +106,9 @@ def test_zslab_decomposition_at_baseline_size(res, world, config):
         for k in ("pDiv", "UDiv", "density"):
             got, want = s.lay.owned(s.batch[k]), ref[k][:, :, s.lay.z0:s.lay.z1]
             rel = float((got - want).norm() / want.norm().clamp_min(1e-30))
-            assert rel <= 1e-6, (s.lay.rank, k, rel)
+            # every kernel of a slab rank computes its owned planes bit-identically to the unsplit step (positions in global
+            # z, dx of the whole grid); the one difference left is the ORDER of the fp64 sum behind std(U) (per-rank partial
+            # sums all-reduced vs one pass), which reaches the fp32 input scale only when the double lands on a rounding
+            # boundary: measured 0 on every box so far, held to one ulp-scale of the fields
+            assert rel <= 1e-7, (s.lay.rank, k, rel)
         s.close()

@@ -11,7 +11,9 @@ import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ALG = {"k_conv3_mfma": 64, "k_conv3_mfma_tail": 36, "k_conv3_mfma_in": 44, "k_conv3_mid": 64, "k_conv3_tail": 36, "k_conv3_in": 44, "k_vel_bwd": 40, "k_vel_fwd": 28,
+sys.path.insert(0, os.path.join(ROOT, "fluidnet_amd"))
+import _kernels  # noqa: E402  (fluidnet_amd/_kernels.py, without importing the package and torch)
+ALG = {"k_stream_copy": 8, "k_conv3_mfma": 64, "k_conv3_mfma_tail": 36, "k_conv3_mfma_in": 44, "k_conv3_mid": 64, "k_conv3_tail": 36, "k_conv3_in": 44, "k_vel_bwd": 40, "k_vel_fwd": 28,
        "k_scalar_fwd": 24, "k_scalar_bwd": 28, "k_confine": 44, "k_curl": 28, "k_bcs_div_stats": 32, "k_minmax3": 16,
        "k_project": 60, "k_add_buoyancy": 32}
 
@@ -66,7 +68,10 @@ def main():
            "%-24s %11s %12s %14s %10s %10s\n" % ("kernel", "fetch_KiB", "write_KiB", "traffic_bytes", "B/cell", "alg B/cell"))
     open(os.path.join(ROOT, "profiles", tag + "_pmc_traffic.txt"), "w").write(hdr + "\n".join(rows) + "\n")
     if int(cells) == 128 ** 3:     # the file bench.py reads for roofline.traffic (default workload only)
-        out["_meta"] = {"commit": commit, "cells": int(cells), "source": tag + "_pmc_traffic.txt"}
+        conv_path = os.environ.get("TFL_CONV_PATH", "mfma16")
+        out["_meta"] = {"commit": commit, "cells": int(cells), "source": tag + "_pmc_traffic.txt",
+                        # git blob hash of each kernel's source file at measurement time: bench.py refuses the figure when it differs
+                        "source_sha": {k: list(_kernels.source_sha(k, conv_path)) for k in out if not k.startswith("_")}}
         json.dump(out, open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1)
     sys.stdout.write(hdr + "\n".join(rows) + "\n")
 

@@ -1,0 +1,19 @@
+#!/bin/bash
+# round 4: advect_scalar3.hip second version (in-tile fluid-aware lerp) + the tolerance mode: parity, then A/B
+REPO=$(cd "$(dirname "$0")/.." && pwd); cd "$REPO"; export TMPDIR=/tmp
+O=$REPO/gpurun_out/r04scal3b; rm -rf $O; mkdir -p $O
+python -m pytest tests -m gpu -x -q -s -k "advect or parity_at_baseline or long_horizon or scalar or Scalar" 2>&1 | grep -E "passed|failed|rel-L2|Error|error|assert" | tail -40 | tee $O/pytest.txt
+run() { # label, env...
+  local label=$1; shift
+  for res in 128 256; do
+    echo "== $label res $res"
+    env "$@" python bench.py --no-cpu-baseline --no-config5 --no-configs --res $res --steps $((res == 128 ? 40 : 10)) 2>/dev/null | python tools/bench_kernels.py | grep -E "ms/step|k_scalar|k_minmax|k_vel"
+  done
+}
+for round in 1 2; do
+  run gather TFL_SCALAR_GATHER=1
+  run tz1 TFL_SCAL3_TZ=1
+  run tz2 TFL_SCAL3_TZ=2
+  run tz4 TFL_SCAL3_TZ=4
+  run tz2-fast TFL_SCAL3_TZ=2 TFL_ADVECT_MODE=fast
+done 2>&1 | tee $O/ab.txt
