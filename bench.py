@@ -464,6 +464,26 @@ def main():
                       "halo_planes_recomputed_per_rank": red / (own / owned_planes),
                       "messages_per_step": 3, "allreduces_per_step": 1}
 
+    # ---- N > 1: the same grid un-split on rank 0's GPU (after the timed region, the other ranks wait at the next barrier):
+    # speed-up and parallel efficiency of THIS run against a single-GPU step measured in the same job on the same box
+    single = None
+    if world > 1:
+        if rank == 0:
+            b1, m1, step1, _ = make_stepper(res, 1, 0, dev, model, lambda r, lay, d: build_scene(r, r, lay, d))
+            for _ in range(args.preroll + args.warmup):
+                step1()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                step1()
+            torch.cuda.synchronize()
+            t1 = (time.perf_counter() - t0) / args.steps
+            del b1, step1
+            single = {"ms_per_step_single_gpu": t1 * 1e3, "speedup": t1 / (elapsed / args.steps),
+                      "parallel_efficiency": t1 / (elapsed / args.steps) / world,
+                      "note": "single-GPU step of the same %d^3 grid timed on rank 0's GPU in this job (strong scaling)" % res}
+        barrier()
+
     # ---- BASELINE config 5: 256^3 cut into `world` z-slabs (after the timed region; its own short timing) -------------
     config5 = None
     if not args.no_config5 and res == 128 and 256 % world == 0:
@@ -497,7 +517,7 @@ def main():
                                "strong scaling: %d z-slabs of %d planes" % (world, owned_planes)),
                    "grid_zyx": [res, res, res], "per_gpu_grid_zyx": [owned_planes, res, res],
                    "decomposition": "single GPU" if world == 1 else "z-slabs, %d ranks, transport: %s" % (world, TRANSPORT["name"]),
-                   "preroll_steps": args.preroll, "slab": redundancy},
+                   "preroll_steps": args.preroll, "slab": redundancy, "strong_scaling": single},
         "roofline": roofline, "advection_headline": headline, "hbm_measured_peak_GBps": hbm_meas,
         "config5_256": config5, "configs": other_configs(dev) if (world == 1 and not (args.no_configs or args.no_config5)) else None, "kernels": kernels,
     }

@@ -64,7 +64,8 @@ constexpr int kDma = (kPlane2 + 63) / 64;                 // LDS-DMA instruction
 constexpr float kHalfMax = 65504.0f;
 
 enum { kModeIn = 0, kModeMid = 1, kModeTail = 2 };
-// timing ablations (tools/ab_build.sh): 1 = no staging loads, 2 = no MFMAs, 4 = no stores, 8 = no LDS fragment reads
+// timing ablations (tools/ab_build.sh): 1 = no staging loads, 2 = no MFMAs, 4 = no stores, 8 = no LDS fragment reads,
+// 32 = no epilogue arithmetic (z-marched kernels: zeros are stored), 64 = no per-plane barrier
 #ifndef TFL_M16_LB
 #define TFL_M16_LB 3
 #endif
@@ -432,6 +433,7 @@ __global__ __launch_bounds__(256, TFL_M16Z_LB) void k_conv3_m16z(Dom d, int cols
     const uint4* psrc = src + (long long)min(max(gz, 0), d.Z - 1) * d.Y * 2 * d.X;
 #pragma unroll
     for (int j = 0; j < kMDma; j++) {
+      if ((TFL_M16_ABL & 1) && q >= kMAhead) break;
       const uint4* gp = (z_ok && ((st_ok >> j) & 1)) ? psrc + st_off[j] : zero;
       dma16(gp, __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)(((q % kMRing) * kMPitch + (wave * kMDma + j) * 64) * 16)));
     }
@@ -458,6 +460,18 @@ __global__ __launch_bounds__(256, TFL_M16Z_LB) void k_conv3_m16z(Dom d, int cols
   // finish output plane z from A2: recombine, bias, ReLU, then split + transposed 16-byte stores, or the 1x1x1 tail
   auto finish = [&](int z) {
     const bool live = x < d.X && y < d.Y && (!(TFL_M16_ABL & 4) || post == 12345.0f);
+    if (TFL_M16_ABL & 32) {           // stores only (one accumulator word keeps the MFMAs alive)
+      if (live) {
+        const uint32_t w0 = __builtin_bit_cast(uint32_t, A2[0][0] + A2[1][1] + A2[2][2] + A2[3][3]);
+        if (!TAIL) {
+          uint4* orow = reinterpret_cast<uint4*>(outv) + (((long long)b * d.Z + z) * d.Y + y) * 2 * d.X + x;
+          orow[0] = make_uint4(w0, 0, 0, 0); orow[d.X] = make_uint4(w0, 0, 0, 0);
+        } else {
+          reinterpret_cast<float*>(outv)[(long long)b * cells + TFL_AT(d, x, y, z)] = __builtin_bit_cast(float, w0);
+        }
+      }
+      return;
+    }
     float h0[4], h1[4];
 #pragma unroll
     for (int oy = 0; oy < 4; oy++) {
@@ -523,6 +537,7 @@ __global__ __launch_bounds__(256, TFL_M16Z_LB) void k_conv3_m16z(Dom d, int cols
         for (int dy = 0; dy < 3; dy++) {
           const int oy = ry - dy;
           if (oy < 0 || oy > 3) continue;
+          if (TFL_M16_ABL & 2) { if (dy == 0) A0[oy] += __builtin_bit_cast(f4, f); continue; }
           if (MASK & 1) A0[oy] = __builtin_amdgcn_mfma_f32_16x16x32_f16(W[0 * 3 + dy][tm], f, A0[oy], 0, 0, 0);
           if (MASK & 2) A1[oy] = __builtin_amdgcn_mfma_f32_16x16x32_f16(W[1 * 3 + dy][tm], f, A1[oy], 0, 0, 0);
           if (MASK & 4) A2[oy] = __builtin_amdgcn_mfma_f32_16x16x32_f16(W[2 * 3 + dy][tm], f, A2[oy], 0, 0, 0);
@@ -536,8 +551,8 @@ __global__ __launch_bounds__(256, TFL_M16Z_LB) void k_conv3_m16z(Dom d, int cols
   for (int q = 0; q < nsteps; q++) {
     // plane q has landed once at most the (kMAhead - 1) younger planes' DMAs are outstanding (loads retire in order; the
     // epilogue's stores share the counter and only make the wait stricter)
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((kMAhead - 1) * kMDma) : "memory");
-    __syncthreads();                  // every wave's part of plane q is in LDS; every wave is done reading plane q - 1
+    if (!(TFL_M16_ABL & 1)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((kMAhead - 1) * kMDma) : "memory");
+    if (!(TFL_M16_ABL & 64)) __syncthreads();   // every wave's part of plane q is in LDS; every wave is done reading plane q - 1
     issue(q + kMAhead);               // into the slot of plane q - 1 (past the chunk: the zero page, keeps the count uniform)
 #pragma unroll
     for (int r = 0; r < 4; r++) { A2[r] = A1[r]; A1[r] = A0[r]; A0[r] = (f4){0.0f, 0.0f, 0.0f, 0.0f}; }

@@ -15,7 +15,7 @@ objs=()
 for f in $SRCS; do
   if [[ ",$files," == *",$f,"* ]]; then
     o="$REPO/ab/build_$name/${f%.*}.o"
-    extra=""; case $f in advect.hip|advect_vel3.hip) extra="-fno-slp-vectorize";; esac
+    extra=""; case $f in advect.hip|advect_vel3.hip|advect_scalar3.hip) extra="-fno-slp-vectorize";; esac
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -Wno-unused-function $extra -I"$REPO/include" "$@" -x hip -c -o "$o" "$f" &
   else
     o="build/${f%.*}.o"
