@@ -44,10 +44,12 @@ HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 T
 FP32_PEAK_TFLOPS = 157.3   # same guide: fp32 matrix (= vector) peak
 F16_MFMA_PEAK_TFLOPS = 2500.0   # same guide: bf16 / fp16 MFMA, dense
 # conv_mfma16.hip (the default 3-D conv path): MFMA flops ISSUED per voxel. One v_mfma_f32_16x16x32_f16 = 16384 flop; a
-# wave issues 72 of them per 64 output voxels in the 8->8 layers (9 (dz, dy) taps x 2 activation terms per output row of 16
-# voxels) and 72 per 128 in the first layer (one activation term): every fp32 product is four fp16 products (hi/lo of both
-# operands) and one K group of four is idle, 16/3 issued flops per algorithmic flop.
-M16_ISSUED_FLOP_PER_VOXEL = {"k_conv3_in": 72 * 16384 / 128.0, "k_conv3_mid": 72 * 16384 / 64.0, "k_conv3_tail": 72 * 16384 / 64.0}
+# wave issues 72 of them per 128 output voxels in the first layer (9 (dz, dy) taps per output row of 16 voxels, one
+# activation term): every fp32 product is four fp16 products (hi/lo of both operands) and one K group of four is idle.
+# The 8->8 layers run K-PACKED by default (k_conv3_m16p: the 27 taps in 7 groups of <= 4 K slices): 56 per 64 voxels;
+# TFL_M16_KPACK=0 brings back k_conv3_m16z (one (dz, dy) per MFMA, 72).
+_M16_MID = (56 if os.environ.get("TFL_M16_KPACK", "1") != "0" else 72) * 16384 / 64.0
+M16_ISSUED_FLOP_PER_VOXEL = {"k_conv3_in": 72 * 16384 / 128.0, "k_conv3_mid": _M16_MID, "k_conv3_tail": _M16_MID}
 
 # Algorithmic HBM bytes per CELL per launch (fp32, 3-D; each distinct input read once, each output
 # written once) -- SURVEY.md 8d restated per kernel of the fused implementation.
@@ -444,7 +446,7 @@ def main():
             roofline[extra] = dk[extra]
     if dk.get("bound") == "mfma":
         roofline["note"] = ("achieved / peak / frac = MFMA flops ISSUED against the dense fp16 MFMA peak (matrix-pipe utilisation); "
-                            "the layer's algorithmic fp32 flops are 3/16 of them (split operands: 4 products per fp32 product, 3 of 4 K groups used)")
+                            "the layer's algorithmic fp32 flops are 27/112 of them in the K-packed 8->8 layers (4 fp16 products per fp32 product, 27 of 28 K slices used), 3/16 in the first layer")
     headline = {}
     if "k_vel_fwd" in kernels and "k_vel_bwd" in kernels:   # the north-star's "advection kernel" figure
         t = kernels["k_vel_fwd"]["ms_per_step"] + kernels["k_vel_bwd"]["ms_per_step"]

@@ -709,7 +709,7 @@ tfl_model* tfl_model_create_opts(tfl_ctx* c, int is3D, int nlayers, const int32_
     // of every (dz, dy, c_in, c_out)
     if (m->m16) {
       for (int l = 0; l < 3; l++) {
-        std::vector<uint16_t> fr(((size_t)9 * (cin[l] == 3 ? 1 : 2) * 64 + 1) * 8);
+        std::vector<uint16_t> fr(tfl::conv3_m16_frag_halves(cin[l]));
         m->post16[l] = tfl::conv3_m16_pack_weights(weights[l], cin[l], fr.data());
         if (hipMalloc(&m->wfrag16[l], fr.size() * sizeof(uint16_t)) != hipSuccess ||
             hipMemcpy(m->wfrag16[l], fr.data(), fr.size() * sizeof(uint16_t), hipMemcpyHostToDevice) != hipSuccess)

@@ -572,6 +572,194 @@ __global__ __launch_bounds__(256, TFL_M16Z_LB) void k_conv3_m16z(Dom d, int cols
   if (clipped) atomicAdd(range_err, 1ull);
 }
 
+
+// =====================================================================================================================
+// z-marched, K-PACKED form of the 8 -> 8 layers: the round-4 default. In k_conv3_m16z one MFMA carries the three x-taps of
+// one (dz, dy) -- 24 of the 32 K elements -- and an output row costs 9 x 2 MFMAs. Here the 27 taps of an output voxel are
+// packed into SEVEN groups of at most four, whatever plane they come from:
+//   A(dy) = {(dz 0; dx 0, 1, 2), (dz 1; dx 0)}      B(dy) = {(dz 1; dx 1, 2), (dz 2; dx 0, 1)}      for dy = 0, 1, 2
+//   C     = {(dz 2, dx 2) of dy = 0, 1, 2}, one K group idle
+// i.e. 7 x 2 = 14 MFMAs per output row of 16 voxels instead of 18 (56 per wave and plane instead of 72). A fragment now
+// mixes planes: lane group g of the wave reads its 16-byte slot from the plane / row / x-offset its K group stands for (the
+// fragment of input row r still serves the three output rows r - dy). All terms of an output plane are issued in the step
+// its last input plane arrives: ONE accumulator set instead of three in flight (16 VGPRs instead of 48), 14 weight
+// fragments instead of 18, no partial-plane masks. Ring of four planes, the next one in flight during the step.
+constexpr int kPRing = 4;
+constexpr int kPFrags = 14;                               // weight fragments: A(dy) x 2 terms, B(dy) x 2 terms, C x 2 terms
+
+#ifndef TFL_M16P_LB
+#define TFL_M16P_LB 2
+#endif
+template <bool TAIL>
+__global__ __launch_bounds__(256, TFL_M16P_LB) void k_conv3_m16p(Dom d, int cols_x, int cols_y, int cz, int chunks_a, int chunks,
+                                                                int n_blocks, const uint4* __restrict__ in,
+                                                                const uint4* __restrict__ wfrag, const float* __restrict__ bias,
+                                                                void* __restrict__ outv, float post,
+                                                                unsigned long long* __restrict__ range_err) {
+  extern __shared__ __attribute__((aligned(16))) uint4 lds[];
+  const int per_xcd = (n_blocks + 7) / 8;
+  const int blk = (int)(blockIdx.x % 8) * per_xcd + (int)(blockIdx.x / 8);
+  if (blk >= n_blocks) return;
+  int t = blk;
+  const int cx = t % cols_x; t /= cols_x;
+  const int cy = t % cols_y; t /= cols_y;
+  const int ch = t % chunks;
+  const int b = t / chunks;
+  const int zc0 = ch < chunks_a ? d.w0 + ch * cz : d.w1 + (ch - chunks_a) * cz;
+  const int z_end = ch < chunks_a ? d.w0 + d.n0 : d.w1 + (d.nw - d.n0);
+  const int nz = min(cz, z_end - zc0);                  // output planes of this block
+  const int nsteps = nz + 2;                            // input planes zc0 - 1 .. zc0 + nz
+  const int x0 = cx * kMX, y0 = cy * kMY;
+  const long long cells = d.sc;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  bool clipped = false;
+
+  h8 W[kPFrags];
+#pragma unroll
+  for (int f = 0; f < kPFrags; f++) W[f] = __builtin_bit_cast(h8, wfrag[f * 64 + lane]);
+
+  // staging geometry of the lane's kMDma slots of a plane (as k_conv3_m16z)
+  const uint4* src = in + (long long)b * cells * 2;
+  const uint4* zero = wfrag + kPFrags * 64;             // 16 zero bytes behind the fragments
+  int st_off[kMDma];
+  unsigned st_ok = 0;
+#pragma unroll
+  for (int j = 0; j < kMDma; j++) {
+    const int item = (wave * kMDma + j) * 64 + lane;
+    const int r = min(item, kMPlane - 1) / kMHX, hx = min(item, kMPlane - 1) - r * kMHX;
+    const int hy = r >> 1, tm = r & 1;
+    const int gx = x0 - 1 + hx, gy = y0 - 1 + hy;
+    st_off[j] = (min(max(gy, 0), d.Y - 1) * 2 + tm) * d.X + min(max(gx, 0), d.X - 1);
+    st_ok |= (item < kMPlane && gx >= 0 && gx < d.X && gy >= 0 && gy < d.Y) ? (1u << j) : 0u;
+  }
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void*)lds;
+  auto issue = [&](int q) {          // input plane q of the chunk (z = zc0 - 1 + q) -> ring slot q % kPRing
+    const int gz = zc0 - 1 + q;
+    const bool z_ok = q < nsteps && gz >= 0 && gz < d.Z;
+    const uint4* psrc = src + (long long)min(max(gz, 0), d.Z - 1) * d.Y * 2 * d.X;
+#pragma unroll
+    for (int j = 0; j < kMDma; j++) {
+      const uint4* gp = (z_ok && ((st_ok >> j) & 1)) ? psrc + st_off[j] : zero;
+      dma16(gp, __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)(((q % kPRing) * kMPitch + (wave * kMDma + j) * 64) * 16)));
+    }
+  };
+
+  const int wx = wave & 1, wy = wave >> 1;
+  const int nn = lane & 15, g = lane >> 4;
+  // a lane's slot inside a plane for the three fragment kinds (input row 0 of the wave, term 0): K group g stands for
+  //   A: dx = g of the first plane (g = 3: dx 0 of the second)   B: dx 1, 2 of the second plane, dx 0, 1 of the third
+  //   C: dx 2 of the third plane, input rows +0, +1, +2 (g = 3: idle)
+  const int row0 = (wy * 4 * 2) * kMHX + wx * 16 + nn;
+  const int slotA = row0 + (g < 3 ? g : 0);
+  const int slotB = row0 + (g == 0 ? 1 : (g == 1 ? 2 : (g == 2 ? 0 : 1)));
+  const int slotC = row0 + 2 + (g < 3 ? g : 0) * 2 * kMHX;
+  const int x = x0 + wx * 16 + nn;
+  const int y = y0 + wy * 4 + g;                          // the row this lane group stores (after the transpose)
+  const int c0 = 2 * g, c1 = 2 * g + 1;
+  const float bias0 = bias[c0], bias1 = bias[c1];
+  const int j0 = 4 * (g >> 1) + 2 * (g & 1);              // TAIL: the two hidden channels this lane finishes
+  float b4a = 0.0f, b4b = 0.0f, w5a = 0.0f, w5b = 0.0f, b5 = 0.0f;
+  if (TAIL) {
+    b4a = bias[kTailB4 + j0]; b4b = bias[kTailB4 + j0 + 1]; w5a = bias[kTailW5 + j0]; w5b = bias[kTailW5 + j0 + 1];
+    b5 = bias[kTailB5];
+  }
+
+  // finish output plane z from its accumulators: recombine, bias, ReLU, then split + transposed 16-byte stores, or the tail
+  auto finish = [&](f4 (&A2)[4], int z) {
+    const bool live = x < d.X && y < d.Y;
+    float h0[4], h1[4];
+#pragma unroll
+    for (int oy = 0; oy < 4; oy++) {
+      h0[oy] = __builtin_fmaxf((A2[oy][0] + A2[oy][1] * 0x1p-11f) * post + bias0, 0.0f);
+      h1[oy] = __builtin_fmaxf((A2[oy][2] + A2[oy][3] * 0x1p-11f) * post + bias1, 0.0f);
+    }
+    if (!TAIL) {
+      uint32_t H[4], L[4];
+      bool over = false;
+#pragma unroll
+      for (int oy = 0; oy < 4; oy++) {
+        const float k0 = __builtin_fminf(h0[oy], kHalfMax), k1 = __builtin_fminf(h1[oy], kHalfMax);
+        over = over || ((k0 != h0[oy] || k1 != h1[oy]) && x < d.X && y0 + wy * 4 + oy < d.Y);
+        _Float16 hh0, hl0, hh1, hl1;
+        split_h(k0, hh0, hl0); split_h(k1, hh1, hl1);
+        const h2v ph = {hh0, hh1}, pl = {hl0, hl1};
+        H[oy] = __builtin_bit_cast(uint32_t, ph); L[oy] = __builtin_bit_cast(uint32_t, pl);
+      }
+      clipped = clipped || over;
+      transpose4(H); transpose4(L);
+      if (live) {
+        uint4* orow = reinterpret_cast<uint4*>(outv) + (((long long)b * d.Z + z) * d.Y + y) * 2 * d.X + x;
+        orow[0] = make_uint4(H[0], H[1], H[2], H[3]);
+        orow[d.X] = make_uint4(L[0], L[1], L[2], L[3]);
+      }
+    } else {
+      // 8 -> 8 (k = 1) + ReLU, 8 -> 1 on the vector ALUs (see k_conv3_m16z)
+      float psel = 0.0f;
+#pragma unroll
+      for (int oy = 0; oy < 4; oy++) {
+        float r4[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const float qa = bias[kTailW4 + j * 8 + c0] * h0[oy] + bias[kTailW4 + j * 8 + c1] * h1[oy];
+          const float qb = bias[kTailW4 + (4 + j) * 8 + c0] * h0[oy] + bias[kTailW4 + (4 + j) * 8 + c1] * h1[oy];
+          r4[j] = swap_sum32(qa, qb);
+        }
+        float r2[2];
+#pragma unroll
+        for (int j = 0; j < 2; j++) r2[j] = swap_sum16(r4[j], r4[2 + j]);
+        float pp = w5a * __builtin_fmaxf(r2[0] + b4a, 0.0f) + w5b * __builtin_fmaxf(r2[1] + b4b, 0.0f);
+        pp = swap_sum16(pp, pp);
+        pp = swap_sum32(pp, pp);
+        psel = g == oy ? pp : psel;           // lane group g stores row g
+      }
+      if (live) reinterpret_cast<float*>(outv)[(long long)b * cells + TFL_AT(d, x, y, z)] = psel + b5;
+    }
+  };
+
+#pragma unroll
+  for (int q = 0; q < 3; q++) issue(q);
+#pragma unroll 1
+  for (int q = 2; q < nsteps; q++) {
+    // planes q - 2, q - 1, q: everything issued so far has to have landed (plane q went out a whole step ago)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                  // every wave's part of plane q is in LDS; every wave is done reading plane q - 3
+    issue(q + 1);                     // into the slot of plane q - 3 (past the chunk: the zero page)
+    const int s0 = ((q - 2) % kPRing) * kMPitch, s1 = ((q - 1) % kPRing) * kMPitch, s2 = (q % kPRing) * kMPitch;
+    const uint4* fa = lds + ((g == 3 ? s1 : s0) + slotA);
+    const uint4* fb = lds + ((g < 2 ? s1 : s2) + slotB);
+    const uint4* fc = lds + (s2 + slotC);
+    f4 acc[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) acc[r] = (f4){0.0f, 0.0f, 0.0f, 0.0f};
+    // issue order: the A fragments of all rows, then the B fragments, then C -- two MFMAs on the same accumulator are at
+    // least two MFMAs apart almost everywhere (a dependent MFMA right behind its producer stalls the pipe)
+#pragma unroll
+    for (int kind = 0; kind < 2; kind++)
+#pragma unroll
+      for (int ry = 0; ry < 6; ry++)
+#pragma unroll
+        for (int tm = 0; tm < 2; tm++) {
+          const h8 v = __builtin_bit_cast(h8, (kind == 0 ? fa : fb)[(ry * 2 + tm) * kMHX]);
+#pragma unroll
+          for (int dy = 0; dy < 3; dy++) {
+            const int oy = ry - dy;
+            if (oy < 0 || oy > 3) continue;
+            acc[oy] = __builtin_amdgcn_mfma_f32_16x16x32_f16(W[kind * 6 + dy * 2 + tm], v, acc[oy], 0, 0, 0);
+          }
+        }
+#pragma unroll
+    for (int ry = 0; ry < 4; ry++)
+#pragma unroll
+      for (int tm = 0; tm < 2; tm++) {
+        const h8 vc = __builtin_bit_cast(h8, fc[(ry * 2 + tm) * kMHX]);
+        acc[ry] = __builtin_amdgcn_mfma_f32_16x16x32_f16(W[12 + tm], vc, acc[ry], 0, 0, 0);
+      }
+    finish(acc, zc0 + q - 2);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the trailing zero-page DMA must not outlive the block's LDS
+  if (clipped) atomicAdd(range_err, 1ull);
+}
+
 // compute units of the current device (cached per device)
 static int device_cus() {
   static std::atomic<int> cus[64];
@@ -641,6 +829,43 @@ static void launch_m16z(hipStream_t st, const Dom& d, int B, const void* in, con
                  (const uint4*)wfrag, bias, out, post, range_err);
 }
 
+
+template <bool TAIL>
+static void launch_m16p(hipStream_t st, const Dom& d, int B, const void* in, const void* wfrag, const float* bias, void* out,
+                        float post, unsigned long long* range_err) {
+  const int cxn = (d.X + kMX - 1) / kMX, cyn = (d.Y + kMY - 1) / kMY;
+  const int na = d.n0, nb = d.nw - d.n0;
+  if (cxn * cyn * (na + nb) * B <= 0) return;
+  const size_t lds_bytes = (size_t)16 * kPRing * kMPitch;
+  const int slots = device_cus() * blocks_per_cu((const void*)k_conv3_m16p<TAIL>, lds_bytes, TFL_M16P_LB);
+  // chunk length: rounds of resident blocks x (planes walked + pipeline fill), as launch_m16z
+  int cz = 8;
+  {
+    long long best = -1;
+    for (int c = 8; c <= 32; c++) {
+      const long long blocks = (long long)cxn * cyn * B * ((na + c - 1) / c + (nb + c - 1) / c);
+      const long long cost = ((blocks + slots - 1) / slots) * (c + 4);
+      if (best < 0 || cost < best) { best = cost; cz = c; }
+    }
+  }
+  if (const char* e = getenv("TFL_M16_CZ")) cz = atoi(e) > 0 ? atoi(e) : cz;
+  const int chunks_a = (na + cz - 1) / cz, chunks = chunks_a + (nb + cz - 1) / cz;
+  const int n_blocks = cxn * cyn * chunks * B;
+  const int grid = ((n_blocks + 7) / 8) * 8;
+  if (getenv("TFL_DEBUG")) {
+    static bool said[2] = {false, false};
+    if (!said[TAIL]) {
+      said[TAIL] = true;
+      fprintf(stderr, "[tfl] k_conv3_m16p<%d>: dynamic LDS %zu B, %d block slots, grid %d, chunks of %d planes\n", (int)TAIL, lds_bytes, slots, grid, cz);
+    }
+  }
+  // the fragments of this kernel lie behind those of k_conv3_m16z in the layer's buffer (conv3_m16_pack_weights)
+  const uint4* wp = (const uint4*)wfrag + (9 * 2 * 64 + 1);
+  TFL_TIMED_EXT(TAIL ? "k_conv3_tail" : "k_conv3_mid", st);
+  TFL_LAUNCH_EXT((k_conv3_m16p<TAIL>), grid, 256, lds_bytes, st, d, cxn, cyn, cz, chunks_a, chunks, n_blocks, (const uint4*)in,
+                 wp, bias, out, post, range_err);
+}
+
 template <int MODE>
 static void launch_m16(hipStream_t st, const Dom& d, int B, const void* in, const void* wfrag, const float* bias, void* out,
                        float post, MIn cin, unsigned long long* range_err) {
@@ -689,6 +914,8 @@ void conv3_m16_first_fused(hipStream_t st, int B, int Z, int Y, int X, const flo
 void conv3_m16_mid(hipStream_t st, int B, int Z, int Y, int X, const void* in_h2, const void* wfrag, const float* bias, float post,
                    void* out_h2, unsigned long long* range_err) {
   const bool tiled = getenv("TFL_M16_TILED") && (atoi(getenv("TFL_M16_TILED")) & 1);      // the tile kernel, kept for comparison
+  static const bool kpack = !(getenv("TFL_M16_KPACK") && atoi(getenv("TFL_M16_KPACK")) == 0);   // 0: k_conv3_m16z
+  if (!tiled && kpack) { launch_m16p<false>(st, make_dom(Z, Y, X), B, in_h2, wfrag, bias, out_h2, post, range_err); return; }
   if (!tiled) { launch_m16z<false>(st, make_dom(Z, Y, X), B, in_h2, wfrag, bias, out_h2, post, range_err); return; }
   MIn noin = {nullptr, nullptr, nullptr, nullptr, 0.0};
   launch_m16<kModeMid>(st, make_dom(Z, Y, X), B, in_h2, wfrag, bias, out_h2, post, noin, range_err);
@@ -696,6 +923,8 @@ void conv3_m16_mid(hipStream_t st, int B, int Z, int Y, int X, const void* in_h2
 void conv3_m16_tail(hipStream_t st, int B, int Z, int Y, int X, const void* in_h2, const void* wfrag, const float* tail_pack,
                     float post, float* p_out, unsigned long long* range_err) {
   const bool tiled = getenv("TFL_M16_TILED") && (atoi(getenv("TFL_M16_TILED")) & 2);
+  static const bool kpack = !(getenv("TFL_M16_KPACK") && atoi(getenv("TFL_M16_KPACK")) == 0);
+  if (!tiled && kpack) { launch_m16p<true>(st, make_dom(Z, Y, X), B, in_h2, wfrag, tail_pack, p_out, post, range_err); return; }
   if (!tiled) { launch_m16z<true>(st, make_dom(Z, Y, X), B, in_h2, wfrag, tail_pack, p_out, post, range_err); return; }
   MIn noin = {nullptr, nullptr, nullptr, nullptr, 0.0};
   launch_m16<kModeTail>(st, make_dom(Z, Y, X), B, in_h2, wfrag, tail_pack, p_out, post, noin, range_err);
@@ -736,8 +965,12 @@ float h2f(uint16_t h) {
 }
 }  // namespace
 
-// out: (9 * RT * 64 + 1) * 8 halves (RT = 1 for cin == 3, 2 for cin == 8; the last 16 bytes are zero: the source of the
-// kernels' out-of-grid staging slots); returns the post-scale 2^-(11 + e)
+// out: conv3_m16_frag_halves(cin) halves: (9 * RT * 64 + 1) * 8 (RT = 1 for cin == 3, 2 for cin == 8; the last 16 bytes
+// are zero: the source of the kernels' out-of-grid staging slots) and, for cin == 8, the K-packed fragments of
+// k_conv3_m16p behind them ((14 * 64 + 1) * 8); returns the post-scale 2^-(11 + e)
+size_t conv3_m16_frag_halves(int cin) {
+  return cin == 3 ? ((size_t)9 * 64 + 1) * 8 : ((size_t)9 * 2 * 64 + 1) * 8 + ((size_t)14 * 64 + 1) * 8;
+}
 float conv3_m16_pack_weights(const float* w, int cin, uint16_t* out) {
   const int RT = cin == 3 ? 1 : 2;
   float mx = 0.0f;
@@ -765,6 +998,32 @@ float conv3_m16_pack_weights(const float* w, int cin, uint16_t* out) {
           out[(((size_t)p * RT + r) * 64 + lane) * 8 + j] = f2h(v);
         }
   for (int j = 0; j < 8; j++) out[(size_t)9 * RT * 64 * 8 + j] = 0;
+  if (cin == 8) {
+    // the K-packed fragments of k_conv3_m16p behind them: A(dy) x term, B(dy) x term, C x term (f = 0..13), + 16 zero bytes.
+    // K group g of a fragment = one tap (kz, ky, kx) or none:
+    //   A(dy): (0, dy, 0) (0, dy, 1) (0, dy, 2) (1, dy, 0)    B(dy): (1, dy, 1) (1, dy, 2) (2, dy, 0) (2, dy, 1)
+    //   C:     (2, 0, 2) (2, 1, 2) (2, 2, 2) -
+    uint16_t* o2 = out + ((size_t)9 * RT * 64 + 1) * 8;
+    for (int f = 0; f < 14; f++)
+      for (int lane = 0; lane < 64; lane++)
+        for (int j = 0; j < 8; j++) {
+          const int m = lane & 15, g = lane >> 4, co = m >> 1, wt = m & 1;
+          const int kind = f < 6 ? 0 : (f < 12 ? 1 : 2), dy = kind == 2 ? 0 : ((f % 6) >> 1), tm = f & 1;
+          int kz = -1, ky = 0, kx = 0;
+          if (kind == 0) { kz = g == 3 ? 1 : 0; ky = dy; kx = g == 3 ? 0 : g; }
+          else if (kind == 1) { kz = g < 2 ? 1 : 2; ky = dy; kx = g == 0 ? 1 : (g == 1 ? 2 : (g == 2 ? 0 : 1)); }
+          else if (g < 3) { kz = 2; ky = g; kx = 2; }
+          float v = 0.0f;
+          if (kz >= 0) {
+            const float ws = ldexpf(w[(size_t)(co * cin + j) * 27 + kz * 9 + ky * 3 + kx], e);
+            const float wh = h2f(f2h(ws));
+            const float base = wt ? h2f(f2h((ws - wh) * 2048.0f)) : wh;
+            v = tm == 0 ? base * 2048.0f : base;       // term 0 multiplies the activations' high halves
+          }
+          o2[((size_t)f * 64 + lane) * 8 + j] = f2h(v);
+        }
+    for (int j = 0; j < 8; j++) o2[(size_t)14 * 64 * 8 + j] = 0;
+  }
   return ldexpf(1.0f, -(11 + e));
 }
 

@@ -182,6 +182,7 @@ void conv3_m16_mid(hipStream_t st, int B, int Z, int Y, int X, const void* in_h2
                    void* out_h2, unsigned long long* range_err);
 void conv3_m16_tail(hipStream_t st, int B, int Z, int Y, int X, const void* in_h2, const void* wfrag, const float* tail_pack,
                     float post, float* p_out, unsigned long long* range_err);
+size_t conv3_m16_frag_halves(int cin);
 float conv3_m16_pack_weights(const float* w, int cin, uint16_t* out);
 
 // backward.hip
