@@ -760,6 +760,170 @@ __global__ __launch_bounds__(256, TFL_M16P_LB) void k_conv3_m16p(Dom d, int cols
   if (clipped) atomicAdd(range_err, 1ull);
 }
 
+
+// The FIRST layer (3 -> 8) in the same z-marched, K-packed form: the net input {pDiv / scale, div / scale, occupancy} is
+// built plane by plane while the planes before it are multiplied -- each thread loads the raw words of its one or two
+// slots of plane q + 1 at the top of step q and converts / splits / writes them to the LDS ring behind the step's MFMAs.
+// One row-term per input row ({p_h, d_h, occ, p_l, d_l, 0, 0, 0}: 16 bytes per voxel), 7 fragments, 28 MFMAs per wave
+// and plane; against the tile kernel k_conv3_m16<kModeIn> 1.33 instead of 2.4 staged voxels per output voxel and 7
+// instead of 9 MFMAs per output row.
+constexpr int kIPlane = kMHY * kMHX;                     // 340 16-byte slots of a staged plane: [row][x]
+constexpr int kIRing = 4;
+constexpr int kIFrags = 7;                               // A(dy), B(dy), C
+
+#ifndef TFL_M16PI_LB
+#define TFL_M16PI_LB 4
+#endif
+__global__ __launch_bounds__(256, TFL_M16PI_LB) void k_conv3_m16p_in(Dom d, int cols_x, int cols_y, int cz, int chunks_a, int chunks,
+                                                                    int n_blocks, MIn cin, const uint4* __restrict__ wfrag,
+                                                                    const float* __restrict__ bias, void* __restrict__ outv,
+                                                                    float post, unsigned long long* __restrict__ range_err) {
+  __shared__ __attribute__((aligned(16))) uint4 lds[kIRing * kIPlane];
+  const int per_xcd = (n_blocks + 7) / 8;
+  const int blk = (int)(blockIdx.x % 8) * per_xcd + (int)(blockIdx.x / 8);
+  if (blk >= n_blocks) return;
+  int t = blk;
+  const int cx = t % cols_x; t /= cols_x;
+  const int cy = t % cols_y; t /= cols_y;
+  const int ch = t % chunks;
+  const int b = t / chunks;
+  const int zc0 = ch < chunks_a ? d.w0 + ch * cz : d.w1 + (ch - chunks_a) * cz;
+  const int z_end = ch < chunks_a ? d.w0 + d.n0 : d.w1 + (d.nw - d.n0);
+  const int nz = min(cz, z_end - zc0);
+  const int nsteps = nz + 2;
+  const int x0 = cx * kMX, y0 = cy * kMY;
+  const long long cells = d.sc;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  bool clipped = false;
+
+  h8 W[kIFrags];
+#pragma unroll
+  for (int f = 0; f < kIFrags; f++) W[f] = __builtin_bit_cast(h8, wfrag[f * 64 + lane]);
+
+  // lib/modules/variance.lua:44-76 (n-1) + Sqrt, as model.hip scale_from_stats
+  const double s1 = cin.stats[b * 2], s2 = cin.stats[b * 2 + 1], n = cin.count;
+  const float in_scale = (float)sqrt(fmax(n * s2 - s1 * s1, 0.0) / (n * (n - 1.0)));
+  const bool scale_in_range = in_scale >= 0x1p-12f && in_scale <= 0x1p21f;     // wave-uniform
+  const float inv_scale = scale_in_range ? rcp_refined(in_scale) : 0.0f;
+
+  // the thread's two slots of a plane (the second one only for tid < kIPlane - 256)
+  int st_off[2], st_slot[2];
+  bool st_in[2];
+#pragma unroll
+  for (int j = 0; j < 2; j++) {
+    const int item = min(tid + 256 * j, kIPlane - 1);
+    const int hy = item / kMHX, hx = item - hy * kMHX;
+    const int gx = x0 - 1 + hx, gy = y0 - 1 + hy;
+    st_off[j] = min(max(gy, 0), d.Y - 1) * d.sy + min(max(gx, 0), d.X - 1);
+    st_in[j] = gx >= 0 && gx < d.X && gy >= 0 && gy < d.Y && tid + 256 * j < kIPlane;
+    st_slot[j] = item;
+  }
+  const float* pP = cin.pDiv + (long long)b * cells;
+  const float* pD = cin.div + (long long)b * cells;
+  const float* pF = cin.flags + (long long)b * cells;
+  float raw[2][3];
+  auto load_plane = [&](int q) {      // raw words of input plane q of the chunk (z = zc0 - 1 + q)
+    const int gz = min(max(zc0 - 1 + q, 0), d.Z - 1);
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      if (j == 1 && tid >= kIPlane - 256) continue;
+      const int o = gz * d.sz + st_off[j];
+      raw[j][0] = pP[o]; raw[j][1] = pD[o]; raw[j][2] = pF[o];
+    }
+  };
+  auto write_plane = [&](int q) {     // -> ring slot q % kIRing; the net input is built here: ApplyScale(true) = CDivTable
+    const int gz = zc0 - 1 + q;       // (apply_scale.lua:24-30), FlagsToOccupancy (generic/tfluids.cu:355-371)
+    const bool z_ok = q < nsteps && gz >= 0 && gz < d.Z;
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      if (j == 1 && tid >= kIPlane - 256) continue;
+      float v0, v1;
+      if (scale_in_range) { v0 = div_by<1>(raw[j][0], in_scale, inv_scale); v1 = div_by<1>(raw[j][1], in_scale, inv_scale); }
+      else { v0 = raw[j][0] / in_scale; v1 = raw[j][1] / in_scale; }
+      const int f = (int)raw[j][2];
+      const float occ = (f == kFluid) ? 0.0f : ((f == kObstacle) ? 1.0f : -1.0f);
+      const float k0 = __builtin_fminf(__builtin_fmaxf(v0, -kHalfMax), kHalfMax), k1 = __builtin_fminf(__builtin_fmaxf(v1, -kHalfMax), kHalfMax);
+      const bool ok = z_ok && st_in[j];
+      clipped = clipped || (ok && (k0 != v0 || k1 != v1));
+      h8 sv = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (ok) {
+        _Float16 ph, pl, dh, dl;
+        split_h(k0, ph, pl); split_h(k1, dh, dl);
+        sv[0] = ph; sv[1] = dh; sv[2] = (_Float16)occ; sv[3] = pl; sv[4] = dl;
+      }
+      lds[(q % kIRing) * kIPlane + st_slot[j]] = __builtin_bit_cast(uint4, sv);
+    }
+  };
+
+  const int wx = wave & 1, wy = wave >> 1;
+  const int nn = lane & 15, g = lane >> 4;
+  const int row0 = (wy * 4) * kMHX + wx * 16 + nn;
+  const int slotA = row0 + (g < 3 ? g : 0);
+  const int slotB = row0 + (g == 0 ? 1 : (g == 1 ? 2 : (g == 2 ? 0 : 1)));
+  const int slotC = row0 + 2 + (g < 3 ? g : 0) * kMHX;
+  const int x = x0 + wx * 16 + nn;
+  const int y = y0 + wy * 4 + g;                          // the row this lane group stores (after the transpose)
+  const float bias0 = bias[2 * g], bias1 = bias[2 * g + 1];
+
+#pragma unroll 1
+  for (int q = 0; q < 3; q++) { load_plane(q); write_plane(q); }
+#pragma unroll 1
+  for (int q = 2; q < nsteps; q++) {
+    __syncthreads();                  // plane q is in LDS; every wave is done reading plane q - 3
+    load_plane(q + 1);                // in flight during the MFMAs
+    const int s0 = ((q - 2) % kIRing) * kIPlane, s1 = ((q - 1) % kIRing) * kIPlane, s2 = (q % kIRing) * kIPlane;
+    const uint4* fa = lds + ((g == 3 ? s1 : s0) + slotA);
+    const uint4* fb = lds + ((g < 2 ? s1 : s2) + slotB);
+    const uint4* fc = lds + (s2 + slotC);
+    f4 acc[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) acc[r] = (f4){0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int kind = 0; kind < 2; kind++)
+#pragma unroll
+      for (int ry = 0; ry < 6; ry++) {
+        const h8 v = __builtin_bit_cast(h8, (kind == 0 ? fa : fb)[ry * kMHX]);
+#pragma unroll
+        for (int dy = 0; dy < 3; dy++) {
+          const int oy = ry - dy;
+          if (oy < 0 || oy > 3) continue;
+          acc[oy] = __builtin_amdgcn_mfma_f32_16x16x32_f16(W[kind * 3 + dy], v, acc[oy], 0, 0, 0);
+        }
+      }
+#pragma unroll
+    for (int ry = 0; ry < 4; ry++) {
+      const h8 vc = __builtin_bit_cast(h8, fc[ry * kMHX]);
+      acc[ry] = __builtin_amdgcn_mfma_f32_16x16x32_f16(W[6], vc, acc[ry], 0, 0, 0);
+    }
+    // epilogue: recombine, bias, ReLU, split, transposed 16-byte stores (as the 8 -> 8 layers)
+    {
+      const int z = zc0 + q - 2;
+      uint32_t H[4], L[4];
+      bool over = false;
+#pragma unroll
+      for (int oy = 0; oy < 4; oy++) {
+        const float h0 = __builtin_fmaxf((acc[oy][0] + acc[oy][1] * 0x1p-11f) * post + bias0, 0.0f);
+        const float h1 = __builtin_fmaxf((acc[oy][2] + acc[oy][3] * 0x1p-11f) * post + bias1, 0.0f);
+        const float k0 = __builtin_fminf(h0, kHalfMax), k1 = __builtin_fminf(h1, kHalfMax);
+        over = over || ((k0 != h0 || k1 != h1) && x < d.X && y0 + wy * 4 + oy < d.Y);
+        _Float16 hh0, hl0, hh1, hl1;
+        split_h(k0, hh0, hl0); split_h(k1, hh1, hl1);
+        const h2v ph = {hh0, hh1}, pl = {hl0, hl1};
+        H[oy] = __builtin_bit_cast(uint32_t, ph); L[oy] = __builtin_bit_cast(uint32_t, pl);
+      }
+      clipped = clipped || over;
+      transpose4(H); transpose4(L);
+      if (x < d.X && y < d.Y) {
+        uint4* orow = reinterpret_cast<uint4*>(outv) + (((long long)b * d.Z + z) * d.Y + y) * 2 * d.X + x;
+        orow[0] = make_uint4(H[0], H[1], H[2], H[3]);
+        orow[d.X] = make_uint4(L[0], L[1], L[2], L[3]);
+      }
+    }
+    write_plane(q + 1);               // into the slot of plane q - 3 (every wave passed this step's barrier)
+  }
+  if (clipped) atomicAdd(range_err, 1ull);
+}
+
 // compute units of the current device (cached per device)
 static int device_cus() {
   static std::atomic<int> cus[64];
@@ -866,6 +1030,35 @@ static void launch_m16p(hipStream_t st, const Dom& d, int B, const void* in, con
                  wp, bias, out, post, range_err);
 }
 
+
+static void launch_m16p_in(hipStream_t st, const Dom& d, int B, MIn cin, const void* wfrag, const float* bias, void* out, float post,
+                           unsigned long long* range_err) {
+  const int cxn = (d.X + kMX - 1) / kMX, cyn = (d.Y + kMY - 1) / kMY;
+  const int na = d.n0, nb = d.nw - d.n0;
+  if (cxn * cyn * (na + nb) * B <= 0) return;
+  const int slots = device_cus() * blocks_per_cu((const void*)k_conv3_m16p_in, 0, TFL_M16PI_LB);
+  int cz = 8;
+  {
+    long long best = -1;
+    for (int c = 8; c <= 32; c++) {
+      const long long blocks = (long long)cxn * cyn * B * ((na + c - 1) / c + (nb + c - 1) / c);
+      const long long cost = ((blocks + slots - 1) / slots) * (c + 4);
+      if (best < 0 || cost < best) { best = cost; cz = c; }
+    }
+  }
+  if (const char* e = getenv("TFL_M16_CZ_IN")) cz = atoi(e) > 0 ? atoi(e) : cz;
+  const int chunks_a = (na + cz - 1) / cz, chunks = chunks_a + (nb + cz - 1) / cz;
+  const int n_blocks = cxn * cyn * chunks * B;
+  const int grid = ((n_blocks + 7) / 8) * 8;
+  if (getenv("TFL_DEBUG")) {
+    static bool said = false;
+    if (!said) { said = true; fprintf(stderr, "[tfl] k_conv3_m16p_in: %d block slots, grid %d, chunks of %d planes\n", slots, grid, cz); }
+  }
+  const uint4* wp = (const uint4*)wfrag + (9 * 64 + 1);     // behind the tile kernel's fragments (conv3_m16_pack_weights)
+  TFL_TIMED_EXT("k_conv3_in", st);
+  TFL_LAUNCH_EXT(k_conv3_m16p_in, grid, 256, 0, st, d, cxn, cyn, cz, chunks_a, chunks, n_blocks, cin, wp, bias, out, post, range_err);
+}
+
 template <int MODE>
 static void launch_m16(hipStream_t st, const Dom& d, int B, const void* in, const void* wfrag, const float* bias, void* out,
                        float post, MIn cin, unsigned long long* range_err) {
@@ -909,6 +1102,8 @@ void conv3_m16_first_fused(hipStream_t st, int B, int Z, int Y, int X, const flo
                            const double* stats, double count, const void* wfrag, const float* bias, float post, void* out_h2,
                            unsigned long long* range_err) {
   MIn ci = {pDiv, div, flags, stats, count};
+  static const bool kpack = !(getenv("TFL_M16_KPACK") && (atoi(getenv("TFL_M16_KPACK")) == 0 || atoi(getenv("TFL_M16_KPACK")) == 2));   // 0 / 2: the tile kernel
+  if (kpack) { launch_m16p_in(st, make_dom(Z, Y, X), B, ci, wfrag, bias, out_h2, post, range_err); return; }
   launch_m16<kModeIn>(st, make_dom(Z, Y, X), B, nullptr, wfrag, bias, out_h2, post, ci, range_err);
 }
 void conv3_m16_mid(hipStream_t st, int B, int Z, int Y, int X, const void* in_h2, const void* wfrag, const float* bias, float post,
@@ -969,7 +1164,7 @@ float h2f(uint16_t h) {
 // are zero: the source of the kernels' out-of-grid staging slots) and, for cin == 8, the K-packed fragments of
 // k_conv3_m16p behind them ((14 * 64 + 1) * 8); returns the post-scale 2^-(11 + e)
 size_t conv3_m16_frag_halves(int cin) {
-  return cin == 3 ? ((size_t)9 * 64 + 1) * 8 : ((size_t)9 * 2 * 64 + 1) * 8 + ((size_t)14 * 64 + 1) * 8;
+  return cin == 3 ? ((size_t)9 * 64 + 1) * 8 + ((size_t)7 * 64 + 1) * 8 : ((size_t)9 * 2 * 64 + 1) * 8 + ((size_t)14 * 64 + 1) * 8;
 }
 float conv3_m16_pack_weights(const float* w, int cin, uint16_t* out) {
   const int RT = cin == 3 ? 1 : 2;
@@ -998,6 +1193,32 @@ float conv3_m16_pack_weights(const float* w, int cin, uint16_t* out) {
           out[(((size_t)p * RT + r) * 64 + lane) * 8 + j] = f2h(v);
         }
   for (int j = 0; j < 8; j++) out[(size_t)9 * RT * 64 * 8 + j] = 0;
+  if (cin == 3) {
+    // the K-packed fragments of k_conv3_m16p_in behind them: A(dy), B(dy), C (f = 0..6), + 16 zero bytes; K group g of a
+    // fragment = one tap as below, its 8 elements = {p_h, d_h, occ, p_l, d_l, 0, 0, 0}
+    uint16_t* o2 = out + ((size_t)9 * RT * 64 + 1) * 8;
+    for (int f = 0; f < 7; f++)
+      for (int lane = 0; lane < 64; lane++)
+        for (int j = 0; j < 8; j++) {
+          const int m = lane & 15, g = lane >> 4, co = m >> 1, wt = m & 1;
+          const int kind = f < 3 ? 0 : (f < 6 ? 1 : 2), dy = kind == 2 ? 0 : f % 3;
+          int kz = -1, ky = 0, kx = 0;
+          if (kind == 0) { kz = g == 3 ? 1 : 0; ky = dy; kx = g == 3 ? 0 : g; }
+          else if (kind == 1) { kz = g < 2 ? 1 : 2; ky = dy; kx = g == 0 ? 1 : (g == 1 ? 2 : (g == 2 ? 0 : 1)); }
+          else if (g < 3) { kz = 2; ky = g; kx = 2; }
+          const int ci = j < 3 ? j : (j < 5 ? j - 3 : -1);
+          const bool act_hi = j < 3;
+          float v = 0.0f;
+          if (kz >= 0 && ci >= 0) {
+            const float ws = ldexpf(w[(size_t)(co * cin + ci) * 27 + kz * 9 + ky * 3 + kx], e);
+            const float wh = h2f(f2h(ws));
+            const float base = wt ? h2f(f2h((ws - wh) * 2048.0f)) : wh;
+            v = act_hi ? base * 2048.0f : base;
+          }
+          o2[((size_t)f * 64 + lane) * 8 + j] = f2h(v);
+        }
+    for (int j = 0; j < 8; j++) o2[(size_t)7 * 64 * 8 + j] = 0;
+  }
   if (cin == 8) {
     // the K-packed fragments of k_conv3_m16p behind them: A(dy) x term, B(dy) x term, C x term (f = 0..13), + 16 zero bytes.
     // K group g of a fragment = one tap (kz, ky, kx) or none:
