@@ -34,8 +34,16 @@
 namespace tfl {
 namespace {
 
-constexpr int TX = 64, TY = 4;                                       // cells per block: one wave per grid row
-constexpr int LX = TX + 2, LY = TY + 2, LP = LX * LY, LN = 3 * LP;   // 66, 6, 396 (plane), 1188 (field)
+// A block covers 64 x 4 x KZ cells: one wave per grid row, KZ consecutive planes one after the other on ONE staged tile
+// (66 x 6 x (KZ + 2) words per field). KZ = 1 (round 3) stages 4.6 words per cell and field, KZ = 2 3.1: what the four
+// fields' staging moves through L2 and LDS per cell was the larger part of these kernels' time (round 4).
+#ifndef TFL_VEL3_KZ
+#define TFL_VEL3_KZ 2
+#endif
+constexpr int KZ = TFL_VEL3_KZ, LZ = KZ + 2, NR = LZ * 6;            // planes of the tile; rows of one field of the tile
+static_assert(2 * NR <= 64, "the halo columns of a field are staged by one wave: 2 * 6 * (KZ + 2) lanes");
+constexpr int TX = 64, TY = 4;
+constexpr int LX = TX + 2, LY = TY + 2, LP = LX * LY, LN = LZ * LP;  // 66, 6, 396 (plane), field
 constexpr int FL = 3 * LN;                                           // tile offset of the flags field
 constexpr float kFastLen = 0.99f;                                    // longest displacement the fast path takes
 
@@ -47,18 +55,18 @@ __device__ __forceinline__ float ldg(const float* __restrict__ base, unsigned by
   return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);
 }
 
-// Wave w stages field w: 18 rows of 64 (one coalesced 256-B load each) + the two halo columns (36 lanes).
+// Wave w stages field w: NR rows of 64 (one coalesced 256-B load each) + the two halo columns (2 NR lanes).
 // EDGE = false (block whose halo rows and planes lie inside the array): row pointers advance by scalar adds.
 // EDGE = true: rows / columns outside the array are loaded from the nearest inside one (fast lanes never read them).
 template <bool EDGE>
 __device__ __forceinline__ void stage_tile(float* __restrict__ tile, const float* __restrict__ g, const Dom& d, int x0,
                                            int y0, int k, int lane) {
-  float v[18], h;
-  const int hr = min(lane >> 1, 17), hz = hr / 6, hy = hr - hz * 6, side = lane & 1;
+  float v[NR], h;
+  const int hr = min(lane >> 1, NR - 1), hz = hr / 6, hy = hr - hz * 6, side = lane & 1;
   if (EDGE) {
     const unsigned xl4 = (unsigned)min(x0 + lane, d.X - 1) * 4u;
 #pragma unroll
-    for (int r = 0; r < 18; r++) {
+    for (int r = 0; r < NR; r++) {
       const int z = min(max(k - 1 + r / 6, 0), d.Z - 1), y = min(max(y0 - 1 + r % 6, 0), d.Y - 1);   // wave-uniform
       v[r] = ldg(g + ((long long)z * d.sz + (long long)y * d.sy), xl4);
     }
@@ -73,7 +81,7 @@ __device__ __forceinline__ void stage_tile(float* __restrict__ tile, const float
     const int gx = side ? min(x0 + TX, d.X - 1) : max(x0 - 1, 0);
     h = *reinterpret_cast<const float*>(row + (unsigned)(__mul24(hz, sz4) + __mul24(hy, sy4) + gx * 4));
 #pragma unroll
-    for (int z = 0; z < 3; z++) {
+    for (int z = 0; z < LZ; z++) {
       const char* rp = row;
 #pragma unroll
       for (int y = 0; y < 6; y++) { v[z * 6 + y] = *reinterpret_cast<const float*>(rp + l4); rp += sy4; }
@@ -81,8 +89,8 @@ __device__ __forceinline__ void stage_tile(float* __restrict__ tile, const float
     }
   }
 #pragma unroll
-  for (int r = 0; r < 18; r++) tile[(r / 6) * LP + (r % 6) * LX + 1 + lane] = v[r];
-  if (lane < 36) tile[hz * LP + hy * LX + (side ? LX - 1 : 0)] = h;
+  for (int r = 0; r < NR; r++) tile[(r / 6) * LP + (r % 6) * LX + 1 + lane] = v[r];
+  if (lane < 2 * NR) tile[hz * LP + hy * LX + (side ? LX - 1 : 0)] = h;
 }
 
 // tile index of global cell (x, y, zg) = x + y*LX + zg*LP + cbias  (cbias: per lane, see the kernels)
@@ -185,27 +193,35 @@ __device__ __forceinline__ void clamp_bounds_tile(const float* __restrict__ g, i
 // cannot leave the domain (p > 0.51, p < N - 0.51), p - 0.5 lies in (i - 1, i + 1) so buildIndex's clamps and the clamp
 // boxes' index clamps cannot act, and every tap lies in [i - 1, i + 1]: inside the grid and inside the tile.
 // (One batch item and the whole window in grid.z is the common launch: it skips dom_bk's integer division.)
-#define TFL_VEL3_PROLOGUE()                                                                        \
+#define TFL_VEL3_STAGE()                                                                           \
   __shared__ float tile[4 * LN];                                                                   \
   const Dom& d = a.d;                                                                              \
-  int b = 0, k = (int)blockIdx.z;                                                                  \
-  if ((int)gridDim.z != d.nw) { b = k / d.nw; k -= b * d.nw; }                                     \
-  k = k < d.n0 ? d.w0 + k : d.w1 + (k - d.n0);                                                     \
+  /* groups of KZ planes tile the window's two plane runs */                                       \
+  const int ga_ = (d.n0 + KZ - 1) / KZ, gn_ = ga_ + (d.nw - d.n0 + KZ - 1) / KZ;                   \
+  int b = 0, g_ = (int)blockIdx.z;                                                                 \
+  if ((int)gridDim.z != gn_) { b = g_ / gn_; g_ -= b * gn_; }                                      \
+  const int k0 = g_ < ga_ ? d.w0 + g_ * KZ : d.w1 + (g_ - ga_) * KZ;                               \
+  const int kend = g_ < ga_ ? d.w0 + d.n0 : d.w1 + (d.nw - d.n0);                                  \
   const long long cells = (long long)d.sc;                                                         \
   flags += b * cells; U += b * cells * 3;                                                          \
   const int lane = threadIdx.x, w = __builtin_amdgcn_readfirstlane(threadIdx.y);                   \
   const int x0 = blockIdx.x * TX, y0 = blockIdx.y * TY;                                            \
-  const bool inner = y0 >= 1 && y0 + TY < d.Y && k >= 1 && k + 1 < d.Z;                            \
+  const bool inner = y0 >= 1 && y0 + TY < d.Y && k0 >= 1 && k0 + KZ < d.Z;                         \
   {                                                                                                \
     const float* sf = w < 3 ? U + w * cells : flags;                                               \
-    if (inner) stage_tile<false>(tile + w * LN, sf, d, x0, y0, k, lane);                           \
-    else stage_tile<true>(tile + w * LN, sf, d, x0, y0, k, lane);                                  \
+    if (inner) stage_tile<false>(tile + w * LN, sf, d, x0, y0, k0, lane);                          \
+    else stage_tile<true>(tile + w * LN, sf, d, x0, y0, k0, lane);                                 \
   }                                                                                                \
   __syncthreads();                                                                                 \
   const int i = x0 + lane, j = y0 + w;                                                             \
-  if (i >= d.X || j >= d.Y) return;                                                                \
+  if (i >= d.X || j >= d.Y) return
+
+// the cell of plane k0 + tz (inside the loop over the block's planes)
+#define TFL_VEL3_CELL(tz)                                                                          \
+  const int k = k0 + (tz);                                                                         \
+  if (k >= kend) break;                                                                            \
   const int kg = k + d.zg;                                                                         \
-  const int c0 = LP + (w + 1) * LX + lane + 1;                                                     \
+  const int c0 = ((tz) + 1) * LP + (w + 1) * LX + lane + 1;                                        \
   const int cbias = c0 - (i + j * LX + kg * LP);                                                   \
   const bool deep = i >= 1 && i <= d.X - 2 && j >= 1 && j <= d.Y - 2 && kg >= 1 && kg <= d.Zg - 2 && k >= 1 && k <= d.Z - 2; \
   const v3 ctr = mk3((float)i + 0.5f, (float)j + 0.5f, (float)kg + 0.5f);                          \
@@ -221,8 +237,11 @@ __device__ __forceinline__ void stg(float* __restrict__ base, unsigned byte_off,
 template <bool FAST>
 __global__ __launch_bounds__(256) void k_vel3_fwd(AdvArgs a, const float* __restrict__ U, const float* __restrict__ flags,
                                                   float* __restrict__ out) {
-  TFL_VEL3_PROLOGUE();
+  TFL_VEL3_STAGE();
   out += b * cells * 3;
+#pragma unroll 1
+  for (int tz = 0; tz < KZ; tz++) {
+  TFL_VEL3_CELL(tz);
   float v0 = 0.0f, v1 = 0.0f, v2 = 0.0f;
   unsigned slow = 0;
   const float cf = tile[FL + c0];
@@ -246,6 +265,7 @@ __global__ __launch_bounds__(256) void k_vel3_fwd(AdvArgs a, const float* __rest
     if (slow & 4u) v2 = sl_mac_from_u<true, true, 2>(a, flags, U, get_at_mac<true, 2>(d, U, i, j, k), a.dt, i, j, k);
   }
   stg(out, o4, v0); stg(out, o4 + sc4, v1); stg(out, o4 + 2u * sc4, v2);
+  }
 }
 
 // ---- pass B: backward trace on fwd + MacCormackCorrectMAC + MacCormackClampMAC --------------------------------
@@ -266,8 +286,11 @@ template <bool FAST>
 __global__ __launch_bounds__(256) void k_vel3_bwd(AdvArgs a, double half_strength, const float* __restrict__ U,
                                                   const float* __restrict__ flags, const float* __restrict__ fwd,
                                                   float* __restrict__ dst) {
-  TFL_VEL3_PROLOGUE();
+  TFL_VEL3_STAGE();
   fwd += b * cells * 3; dst += b * cells * 3;
+#pragma unroll 1
+  for (int tz = 0; tz < KZ; tz++) {
+  TFL_VEL3_CELL(tz);
   const float f0 = ldg(fwd, o4), f1 = ldg(fwd, o4 + sc4), f2 = ldg(fwd, o4 + 2u * sc4);
   float r0 = f0, r1 = f1, r2 = f2;
   const float cf = tile[FL + c0];
@@ -340,6 +363,7 @@ __global__ __launch_bounds__(256) void k_vel3_bwd(AdvArgs a, double half_strengt
 #undef TFL_VEL3_SLOW
   }
   stg(dst, o4, r0); stg(dst, o4 + sc4, r1); stg(dst, o4 + 2u * sc4, r2);
+  }
 }
 
 }  // namespace
@@ -351,7 +375,8 @@ bool advect_vel3(hipStream_t st, bool two_pass, const AdvArgs& a, int B, const f
   // 24-bit multiplies address the planes (4*X*Y < 2^24); 32-bit BYTE offsets address the cells of all three channels
   // (o4 + 2*sc4 in the loads / stores of U, fwd, dst): 12*Z*Y*X < 2^32. Larger grids take the gather kernels.
   if (off || d.Z < 3 || (long long)d.X * d.Y * 4 >= (1 << 24) || 12ll * d.sc >= (1ll << 32)) return false;
-  const dim3 blk(TX, TY, 1), grd = cell_grid(d, B, blk);
+  const int groups = (d.n0 + KZ - 1) / KZ + (d.nw - d.n0 + KZ - 1) / KZ;
+  const dim3 blk(TX, TY, 1), grd((d.X + TX - 1) / TX, (d.Y + TY - 1) / TY, (unsigned)(groups * B));
   const bool pa = stages & 2, pb = stages & 4;
   float* outA = two_pass ? fwd : dst;
   if (pa) {

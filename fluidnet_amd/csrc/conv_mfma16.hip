@@ -670,8 +670,8 @@ __global__ __launch_bounds__(256, TFL_M16P_LB) void k_conv3_m16p(Dom d, int cols
     float h0[4], h1[4];
 #pragma unroll
     for (int oy = 0; oy < 4; oy++) {
-      h0[oy] = __builtin_fmaxf((A2[oy][0] + A2[oy][1] * 0x1p-11f) * post + bias0, 0.0f);
-      h1[oy] = __builtin_fmaxf((A2[oy][2] + A2[oy][3] * 0x1p-11f) * post + bias1, 0.0f);
+      h0[oy] = __builtin_fmaxf(__builtin_fmaf(__builtin_fmaf(A2[oy][1], 0x1p-11f, A2[oy][0]), post, bias0), 0.0f);
+      h1[oy] = __builtin_fmaxf(__builtin_fmaf(__builtin_fmaf(A2[oy][3], 0x1p-11f, A2[oy][2]), post, bias1), 0.0f);
     }
     if (!TAIL) {
       uint32_t H[4], L[4];
@@ -700,14 +700,14 @@ __global__ __launch_bounds__(256, TFL_M16P_LB) void k_conv3_m16p(Dom d, int cols
         float r4[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-          const float qa = bias[kTailW4 + j * 8 + c0] * h0[oy] + bias[kTailW4 + j * 8 + c1] * h1[oy];
-          const float qb = bias[kTailW4 + (4 + j) * 8 + c0] * h0[oy] + bias[kTailW4 + (4 + j) * 8 + c1] * h1[oy];
+          const float qa = __builtin_fmaf(bias[kTailW4 + j * 8 + c0], h0[oy], bias[kTailW4 + j * 8 + c1] * h1[oy]);
+          const float qb = __builtin_fmaf(bias[kTailW4 + (4 + j) * 8 + c0], h0[oy], bias[kTailW4 + (4 + j) * 8 + c1] * h1[oy]);
           r4[j] = swap_sum32(qa, qb);
         }
         float r2[2];
 #pragma unroll
         for (int j = 0; j < 2; j++) r2[j] = swap_sum16(r4[j], r4[2 + j]);
-        float pp = w5a * __builtin_fmaxf(r2[0] + b4a, 0.0f) + w5b * __builtin_fmaxf(r2[1] + b4b, 0.0f);
+        float pp = __builtin_fmaf(w5a, __builtin_fmaxf(r2[0] + b4a, 0.0f), w5b * __builtin_fmaxf(r2[1] + b4b, 0.0f));
         pp = swap_sum16(pp, pp);
         pp = swap_sum32(pp, pp);
         psel = g == oy ? pp : psel;           // lane group g stores row g
@@ -902,8 +902,8 @@ __global__ __launch_bounds__(256, TFL_M16PI_LB) void k_conv3_m16p_in(Dom d, int 
       bool over = false;
 #pragma unroll
       for (int oy = 0; oy < 4; oy++) {
-        const float h0 = __builtin_fmaxf((acc[oy][0] + acc[oy][1] * 0x1p-11f) * post + bias0, 0.0f);
-        const float h1 = __builtin_fmaxf((acc[oy][2] + acc[oy][3] * 0x1p-11f) * post + bias1, 0.0f);
+        const float h0 = __builtin_fmaxf(__builtin_fmaf(__builtin_fmaf(acc[oy][1], 0x1p-11f, acc[oy][0]), post, bias0), 0.0f);
+        const float h1 = __builtin_fmaxf(__builtin_fmaf(__builtin_fmaf(acc[oy][3], 0x1p-11f, acc[oy][2]), post, bias1), 0.0f);
         const float k0 = __builtin_fminf(h0, kHalfMax), k1 = __builtin_fminf(h1, kHalfMax);
         over = over || ((k0 != h0 || k1 != h1) && x < d.X && y0 + wy * 4 + oy < d.Y);
         _Float16 hh0, hl0, hh1, hl1;

@@ -1,0 +1,13 @@
+#!/bin/bash
+# round 4: planes per block (one staged tile) of the LDS-tiled advectVel kernels
+REPO=$(cd "$(dirname "$0")/.." && pwd); cd "$REPO"; export TMPDIR=/tmp
+O=$REPO/gpurun_out/r04velkz; rm -rf $O; mkdir -p $O
+python -m pytest tests -m gpu -x -q 2>&1 | grep -E "passed|failed|Error|error|assert" | tail -8 | tee $O/pytest.txt
+for round in 1 2; do
+  for n in kz1 kz2 kz3; do
+    for res in 128 256; do
+      echo "== $n res $res"
+      TFL_LIBRARY=$PWD/ab/$n.so python bench.py --no-cpu-baseline --no-config5 --no-configs --blocks 3 --res $res --steps $((res == 128 ? 40 : 10)) 2>/dev/null | python tools/bench_kernels.py | grep -E "ms/step|k_vel|k_conv3"
+    done
+  done
+done 2>&1 | tee $O/ab.txt
