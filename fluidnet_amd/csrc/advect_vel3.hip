@@ -40,6 +40,12 @@ namespace {
 #ifndef TFL_VEL3_KZ
 #define TFL_VEL3_KZ 2
 #endif
+// timing ablations (tools/ab_build.sh -DTFL_VEL3_ABL=..): 1 = the tile is filled with constants instead of staged (no staging
+// loads; every lane on the fast path), 2 = pass B's 24 gathers of the forward field replaced by the cell's own value,
+// 4 = no stores
+#ifndef TFL_VEL3_ABL
+#define TFL_VEL3_ABL 0
+#endif
 constexpr int KZ = TFL_VEL3_KZ, LZ = KZ + 2, NR = LZ * 6;            // planes of the tile; rows of one field of the tile
 static_assert(2 * NR <= 64, "the halo columns of a field are staged by one wave: 2 * 6 * (KZ + 2) lanes");
 constexpr int TX = 64, TY = 4;
@@ -63,7 +69,11 @@ __device__ __forceinline__ void stage_tile(float* __restrict__ tile, const float
                                            int y0, int k, int lane) {
   float v[NR], h;
   const int hr = min(lane >> 1, NR - 1), hz = hr / 6, hy = hr - hz * 6, side = lane & 1;
-  if (EDGE) {
+  if (TFL_VEL3_ABL & 1) {                 // constants instead of loads: 1.0 = a fluid flag word, a velocity of 1 cell per unit time
+#pragma unroll
+    for (int r = 0; r < NR; r++) v[r] = 1.0f;
+    h = 1.0f;
+  } else if (EDGE) {
     const unsigned xl4 = (unsigned)min(x0 + lane, d.X - 1) * 4u;
 #pragma unroll
     for (int r = 0; r < NR; r++) {
@@ -264,7 +274,7 @@ __global__ __launch_bounds__(256) void k_vel3_fwd(AdvArgs a, const float* __rest
     if (slow & 2u) v1 = sl_mac_from_u<true, true, 1>(a, flags, U, get_at_mac<true, 1>(d, U, i, j, k), a.dt, i, j, k);
     if (slow & 4u) v2 = sl_mac_from_u<true, true, 2>(a, flags, U, get_at_mac<true, 2>(d, U, i, j, k), a.dt, i, j, k);
   }
-  stg(out, o4, v0); stg(out, o4 + sc4, v1); stg(out, o4 + 2u * sc4, v2);
+  if (!(TFL_VEL3_ABL & 4) || a.dt == 12345.0f) { stg(out, o4, v0); stg(out, o4 + sc4, v1); stg(out, o4 + 2u * sc4, v2); }
   }
 }
 
@@ -306,9 +316,14 @@ __global__ __launch_bounds__(256) void k_vel3_bwd(AdvArgs a, double half_strengt
     const bool k2 = trace_fast<FAST>(tile, cbias, ctr, u2, a.dt, p2);
     const FastLerp L0 = lerp_fast(p0), L1 = lerp_fast(p1), L2 = lerp_fast(p2);
     float g0[8], g1[8], g2[8];
-    gather8_global(fwd, d, o4, k0, L0, g0);
-    gather8_global(fwd + d.sc, d, o4, k1, L1, g1);
-    gather8_global(fwd + 2 * d.sc, d, o4, k2, L2, g2);
+    if (TFL_VEL3_ABL & 2) {
+#pragma unroll
+      for (int q = 0; q < 8; q++) { g0[q] = f0; g1[q] = f1; g2[q] = f2; }
+    } else {
+      gather8_global(fwd, d, o4, k0, L0, g0);
+      gather8_global(fwd + d.sc, d, o4, k1, L1, g1);
+      gather8_global(fwd + 2 * d.sc, d, o4, k2, L2, g2);
+    }
     const v3 ijk = mk3((float)i, (float)j, (float)kg);
     float lo0, hi0, lo1, hi1, lo2, hi2;
     clamp_bounds_tile(tile, cbias, ijk, scale3(u0, a.dt), lo0, hi0);
@@ -362,7 +377,7 @@ __global__ __launch_bounds__(256) void k_vel3_bwd(AdvArgs a, double half_strengt
     TFL_VEL3_SLOW(2, 4u, f2, sk2, r2)
 #undef TFL_VEL3_SLOW
   }
-  stg(dst, o4, r0); stg(dst, o4 + sc4, r1); stg(dst, o4 + 2u * sc4, r2);
+  if (!(TFL_VEL3_ABL & 4) || a.dt == 12345.0f) { stg(dst, o4, r0); stg(dst, o4 + sc4, r1); stg(dst, o4 + 2u * sc4, r2); }
   }
 }
 
