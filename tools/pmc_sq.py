@@ -26,13 +26,14 @@ for k in order:
     wc = a.get("SQ_WAVE_CYCLES", 0.0) or 1.0
     rows.append((a.get("SQ_BUSY_CYCLES", 0.0), k, cnt[k]["SQ_WAVES"], a.get("SQ_WAVES", 0), a.get("SQ_WAIT_ANY", 0) / wc,
                  a.get("SQ_WAIT_INST_ANY", 0) / wc, a.get("SQ_ACTIVE_INST_ANY", 0) / wc,
-                 a.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / (a.get("SQ_BUSY_CYCLES", 0) or 1.0),
+                 a.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / (a.get("SQ_BUSY_CYCLES", 0) or 1.0) / 32.0,
                  a.get("SQ_INSTS_VALU", 0) / (a.get("SQ_WAVES", 0) or 1.0), a.get("SQ_BUSY_CYCLES", 0) / 32.0))
 rows.sort(reverse=True)
 out = ["# rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU",
        "# (own pass, --kernel-trace only), bench.py 128^3, commit %s. per-launch averages; wait_any/wait_inst/active = fractions of" % commit,
-       "# SQ_WAVE_CYCLES; mfma/32 = SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES; valu/wave = SQ_INSTS_VALU / SQ_WAVES; clocks = SQ_BUSY_CYCLES / 32",
-       "%-46s %4s %9s %8s %8s %8s %9s %10s %9s" % ("kernel", "n", "waves", "wait_any", "wait_ins", "active", "mfma/32", "valu/wave", "clocks")]
+       "# SQ_WAVE_CYCLES; mfma_util = SQ_VALU_MFMA_BUSY_CYCLES (cycles, summed over the 1024 SIMDs) / (1024 x clocks): the busy fraction of",
+       "# the matrix pipes; valu/wave = SQ_INSTS_VALU / SQ_WAVES; clocks = SQ_BUSY_CYCLES / 32 (the counter is summed over 32 shader engines)",
+       "%-46s %4s %9s %8s %8s %8s %9s %10s %9s" % ("kernel", "n", "waves", "wait_any", "wait_ins", "active", "mfma_util", "valu/wave", "clocks")]
 for _, k, n, w, wa, wi, ac, mf, vw, clk in rows:
     out.append("%-46s %4d %9d %8.2f %8.2f %8.2f %9.2f %10.0f %9.0f" % (k[:46], n, w, wa, wi, ac, mf, vw, clk))
 open(os.path.join(ROOT, "profiles", tag + "_pmc_sq.txt"), "w").write("\n".join(out) + "\n")

@@ -30,7 +30,11 @@ def short(name):
     if k in ("k_conv3_valu", "k_conv3_wino"):          # profiler names of conv_valu.hip's launches
         a = [t.strip() for t in targs.strip("<>").split(",")]
         return "k_conv3_in" if a[0] == "3" else ("k_conv3_tail" if a[1] == "true" else "k_conv3_mid")
-    if k in ("k_conv3_m16", "k_conv3_m16z"):         # conv_mfma16.hip: <0|1|2> = in / mid / tail, z-marched <false|true> = mid / tail
+    if k == "k_conv3_m16p_in":
+        return "k_conv3_in"
+    if k in ("k_scal3_fwd", "k_scal3_bwd"):          # advect_scalar3.hip
+        return "k_scalar_fwd" if k.endswith("fwd") else "k_scalar_bwd"
+    if k in ("k_conv3_m16", "k_conv3_m16z", "k_conv3_m16p"):         # conv_mfma16.hip: <0|1|2> = in / mid / tail, z-marched <false|true> = mid / tail
         a = targs.strip("<>").strip()
         return {"0": "k_conv3_in", "1": "k_conv3_mid", "2": "k_conv3_tail", "false": "k_conv3_mid", "true": "k_conv3_tail"}.get(a, k)
     if k == "k_apply_bcs_indexed_multi":
