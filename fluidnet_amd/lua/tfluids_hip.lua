@@ -510,18 +510,26 @@ function Slab:drain()
   end
 end
 
+--- Arithmetic of the LDS-tiled 3-D advection kernels (include/tfluids_hip.h tfl_set_advect_mode): 'exact' (default; bit-equal
+--- to the reference CPU path) or 'fast' (the tolerance mode: rel-L2 ~2e-8 against the reference, bar 1e-5).
+function M.setAdvectMode(mode)
+  assert(mode == 'exact' or mode == 'fast', "advect mode must be 'exact' or 'fast'")
+  check(lib.tfl_set_advect_mode(ctx, mode == 'fast' and 1 or 0))
+end
+
 --- Route torch.CudaTensor's `.tfluids` method table, tfluids.normalizePressureMean and tfluids.simulate to the MI355X
 --- library.
 -- @param tfluids the table returned by require('tfluids')
--- @param opts {lib = path to libtfluids_hip.so, device = 0-based HIP device, stream = hipStream_t cdata,
+-- @param opts {lib = path to libtfluids_hip.so, device = 0-based HIP device, stream = hipStream_t cdata, advectMode = 'exact' | 'fast',
 --              keepLuaSimulate = true to leave lib/simulate.lua's tfluids.simulate in place}
 function M.install(tfluids, opts)
   opts = opts or {}
   lib = ffi.load(opts.lib or 'tfluids_hip')
-  assert(lib.tfl_abi_version() == 2, 'libtfluids_hip.so / tfluids_hip.lua ABI version mismatch')
+  assert(lib.tfl_abi_version() == 3, 'libtfluids_hip.so / tfluids_hip.lua ABI version mismatch')
   ctx = lib.tfl_create(opts.device or (cutorch.getDevice() - 1))
   assert(ctx ~= nil, 'tfl_create failed')
   if opts.stream then check(lib.tfl_set_stream(ctx, opts.stream)) end
+  if opts.advectMode then M.setAdvectMode(opts.advectMode) end
   local mt = getmetatable(torch.CudaTensor)  -- luaT_registeratname(L, tbl, "tfluids") put the table here
   mt.tfluids = mt.tfluids or {}
   for name, fn in pairs(ops) do mt.tfluids[name] = fn end
