@@ -94,6 +94,7 @@ SIGNATURES = {
     "tfl_velocityUpdateForward": (_c.c_int, [_c.c_void_p, _T, _T, _T, _c.c_int]),
     "tfl_vorticityConfinement": (_c.c_int, [_c.c_void_p, _T, _T, _c.c_float, _T, _T, _T, _T,
                                             _c.c_int]),
+    "tfl_vorticityConfinementFrom": (_c.c_int, [_c.c_void_p, _T, _T, _T, _c.c_float, _T, _T, _c.c_int]),
     "tfl_addBuoyancy": (_c.c_int, [_c.c_void_p, _T, _T, _T, _F3, _c.c_void_p, _c.c_float,
                                    _c.c_int]),
     "tfl_addBuoyancyFrom": (_c.c_int, [_c.c_void_p, _T, _T, _T, _T, _F3, _c.c_float, _c.c_int]),

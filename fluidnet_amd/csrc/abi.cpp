@@ -399,6 +399,36 @@ int tfl_vorticityConfinement(tfl_ctx* c, const tfl_tensor* U, const tfl_tensor* 
   return check_launch(c, "vorticityConfinement");
 }
 
+int tfl_vorticityConfinementFrom(tfl_ctx* c, const tfl_tensor* USrc, const tfl_tensor* U, const tfl_tensor* flags, float strength,
+                                 const tfl_tensor* curl, const tfl_tensor* curlNorm, int is3D) {
+  TRY(check_flags(c, "vorticityConfinementFrom", flags));
+  TRY(check_vel(c, "vorticityConfinementFrom", "U", U, flags, is3D));
+  TRY(check_vel(c, "vorticityConfinementFrom", "USrc", USrc, flags, is3D));
+  if (USrc->data == U->data) return fail(c, TFL_EINVAL, "vorticityConfinementFrom: U must not alias USrc (use vorticityConfinement)");
+  if (!curl || !curl->data || curl->C != 3 || !same_dims(curl, flags))
+    return fail(c, TFL_EINVAL, "vorticityConfinementFrom: curl must be a 3-channel grid of the flags size");
+  TRY(check_scalar(c, "vorticityConfinementFrom", "curlNorm", curlNorm, flags));
+  WindowScope win(c);
+  if (is3D && tfl::vorticity_confinement_fused(c->stream, flags->B, flags->Z, flags->Y, flags->X, USrc->data, U->data, flags->data,
+                                               strength))
+    return check_launch(c, "vorticityConfinementFrom");
+  // 2-D (or TFL_VORT_FUSED=0): the planes of the window are copied, then the two-launch form runs in place
+  {
+    const tfl::Dom d = tfl::make_dom(flags->Z, flags->Y, flags->X);
+    const size_t plane = sizeof(float) * (size_t)flags->Y * flags->X;
+    const int C = is3D ? 3 : 2;
+    for (int b = 0; b < flags->B; b++)
+      for (int ch = 0; ch < C; ch++) {
+        const size_t row = ((size_t)b * C + ch) * flags->Z;
+        if (d.n0 > 0) HIP_TRY(c, hipMemcpyAsync(U->data + (row + d.w0) * (plane / 4), USrc->data + (row + d.w0) * (plane / 4), plane * d.n0, hipMemcpyDeviceToDevice, c->stream));
+        if (d.nw > d.n0) HIP_TRY(c, hipMemcpyAsync(U->data + (row + d.w1) * (plane / 4), USrc->data + (row + d.w1) * (plane / 4), plane * (d.nw - d.n0), hipMemcpyDeviceToDevice, c->stream));
+      }
+  }
+  tfl::vorticity_confinement(c->stream, is3D != 0, flags->B, flags->Z, flags->Y, flags->X, U->data, flags->data, strength,
+                             curl->data, curlNorm->data, 3);
+  return check_launch(c, "vorticityConfinementFrom");
+}
+
 int tfl_addBuoyancyFrom(tfl_ctx* c, const tfl_tensor* USrc, const tfl_tensor* U, const tfl_tensor* flags,
                         const tfl_tensor* density, const float gravity[3], float dt, int is3D) {
   TRY(check_flags(c, "addBuoyancy", flags));

@@ -149,13 +149,23 @@ int tfl_simulate_step(tfl_ctx* c, const tfl_sim_params* prm, const tfl_sim_state
   tfl_tensor vfwd = view(ws, (int)z.C), vbwd = view(ws + z.C * z.N, (int)z.C), Uadv = view(ws + 2 * z.C * z.N, (int)z.C);
   rc = tfl_advectVel(c, prm->dt, s->U, s->flags, &vfwd, &vbwd, is3D, method, 1, prm->maccormackStrength, &Uadv);
   if (rc) return rc;
-  // U:copy(advected) (init.lua:216-218) is folded into addBuoyancy when buoyancy is on
+  // U:copy(advected) (init.lua:216-218) is folded into the first force that writes every cell of its output: addBuoyancy
+  // (tfl_addBuoyancyFrom) or, on a 3-D grid, the fused vorticity confinement (tfl_vorticityConfinementFrom, which cannot
+  // run in place: then buoyancy / gravity work on a scratch velocity and the confinement delivers into U)
   const bool buoyant = s->n_density > 0 && prm->buoyancyScale > 0.0;
-  if (!buoyant) {
+  const bool vort = prm->vorticityConfinementAmp > 0.0;
+  const bool vfused = vort && tfl::vorticity_confinement_fused_ok(is3D != 0, (int)z.Z);
+  // scratch of the vorticity operator (centered | curl[3] | cnorm | force): the velocity planes 3..5 are free here too
+  tfl_tensor centered = view(ws, (int)z.C), curl = view(ws + z.C * z.N, 3), cnorm = view(ws + (z.C + 3) * z.N, 1),
+             force = view(ws + (z.C + 4) * z.N, (int)z.C);
+  tfl_tensor Utmp = view(ws, (int)z.C);                    // = the advectVel `fwd` planes, dead after the advection
+  const tfl_tensor* cur = &Uadv;                           // where the velocity of the step currently lives
+  if (!buoyant && !vfused) {
     rc = tfl_copy(c, s->U, &Uadv);
     if (rc) return rc;
+    cur = s->U;
   }
-  rc = set_const_vals(c, s, buoyant ? &Uadv : s->U, true, Unchanged{false, false, false});
+  rc = set_const_vals(c, s, cur, true, Unchanged{false, false, false});
   if (rc) return rc;
 
   // ---- forces (simulate.lua:204-239) -------------------------------------------------------------------------
@@ -163,21 +173,23 @@ int tfl_simulate_step(tfl_ctx* c, const tfl_sim_params* prm, const tfl_sim_state
   if (buoyant) {
     const float sc = (float)(-(dx / 4.0) * prm->buoyancyScale);
     const float g[3] = {prm->gravity[0] * sc, prm->gravity[1] * sc, prm->gravity[2] * sc};
-    rc = tfl_addBuoyancyFrom(c, &Uadv, s->U, s->flags, s->density[0], g, prm->dt, is3D);
+    const tfl_tensor* dst = vfused ? &Utmp : s->U;
+    rc = tfl_addBuoyancyFrom(c, cur, dst, s->flags, s->density[0], g, prm->dt, is3D);
     if (rc) return rc;
+    cur = dst;
   }
   if (prm->gravityScale > 0.0) {
     const float sc = (float)((-dx / 4.0) * prm->gravityScale);
     const float g[3] = {prm->gravity[0] * sc, prm->gravity[1] * sc, prm->gravity[2] * sc};
-    rc = tfl_addGravity(c, s->U, s->flags, g, prm->dt, is3D, nullptr);
+    rc = tfl_addGravity(c, cur, s->flags, g, prm->dt, is3D, nullptr);
     if (rc) return rc;
   }
-  if (prm->vorticityConfinementAmp > 0.0) {
-    tfl_tensor centered = view(ws, (int)z.C), curl = view(ws + z.C * z.N, 3), cnorm = view(ws + (z.C + 3) * z.N, 1),
-               force = view(ws + (z.C + 4) * z.N, (int)z.C);
-    rc = tfl_vorticityConfinement(c, s->U, s->flags, (float)(dx * prm->vorticityConfinementAmp), &centered, &curl,
-                                  &cnorm, &force, is3D);
+  if (vort) {
+    const float strength = (float)(dx * prm->vorticityConfinementAmp);
+    if (vfused) rc = tfl_vorticityConfinementFrom(c, cur, s->U, s->flags, strength, &curl, &cnorm, is3D);
+    else rc = tfl_vorticityConfinement(c, s->U, s->flags, strength, &centered, &curl, &cnorm, &force, is3D);
     if (rc) return rc;
+    cur = s->U;
   }
   if (prm->outputDiv) return TFL_OK;
 
@@ -566,8 +578,13 @@ int tfl_simulate_step_slab(tfl_ctx* c, const tfl_sim_params* prm, const tfl_sim_
   }
   rc = msg_finish(c, g, comm, m[2]); if (rc) return rc;
   (void)tfl_set_stages(c, 0); (void)tfl_set_z_window(c, 0, 0, 0, 0);
-  if (!buoyant) { rc = tfl_copy(c, s->U, &Uadv); if (rc) return rc; }
-  rc = set_const_vals(c, s, buoyant ? &Uadv : s->U, true, Unchanged{false, false, false});
+  // as tfl_simulate_step: the fused vorticity confinement delivers into U, so buoyancy / gravity work on a scratch velocity
+  const bool vort = prm->vorticityConfinementAmp > 0.0;
+  const bool vfused = vort && tfl::vorticity_confinement_fused_ok(true, g.Zl);
+  tfl_tensor Utmp = view(cw + 4 * N, 3);                   // the scalar advection's bwdPos planes, dead by now
+  const tfl_tensor* cur = &Uadv;
+  if (!buoyant && !vfused) { rc = tfl_copy(c, s->U, &Uadv); if (rc) return rc; cur = s->U; }
+  rc = set_const_vals(c, s, cur, true, Unchanged{false, false, false});
   if (rc) return rc;
 
   // ---- forces --------------------------------------------------------------------------------------------------------
@@ -576,19 +593,27 @@ int tfl_simulate_step_slab(tfl_ctx* c, const tfl_sim_params* prm, const tfl_sim_
   if (buoyant) {
     const float sc = (float)(-(dx / 4.0) * prm->buoyancyScale);
     const float gv[3] = {prm->gravity[0] * sc, prm->gravity[1] * sc, prm->gravity[2] * sc};
-    rc = tfl_addBuoyancyFrom(c, &Uadv, s->U, s->flags, rho, gv, prm->dt, is3D); if (rc) return rc;
+    const tfl_tensor* dst = vfused ? &Utmp : s->U;
+    rc = tfl_addBuoyancyFrom(c, cur, dst, s->flags, rho, gv, prm->dt, is3D); if (rc) return rc;
+    cur = dst;
   }
   if (prm->gravityScale > 0.0) {
     const float sc = (float)((-dx / 4.0) * prm->gravityScale);
     const float gv[3] = {prm->gravity[0] * sc, prm->gravity[1] * sc, prm->gravity[2] * sc};
-    rc = tfl_addGravity(c, s->U, s->flags, gv, prm->dt, is3D, nullptr); if (rc) return rc;
+    rc = tfl_addGravity(c, cur, s->flags, gv, prm->dt, is3D, nullptr); if (rc) return rc;
   }
-  if (prm->vorticityConfinementAmp > 0.0) {
+  if (vort) {
     const float strength = (float)(dx * prm->vorticityConfinementAmp);
-    (void)tfl_set_stages(c, 2); WIN(set_win(c, ext(g, 2, 2)));
-    rc = tfl_vorticityConfinement(c, s->U, s->flags, strength, &curl, &curl, &cnorm, &curl, is3D); if (rc) return rc;
-    (void)tfl_set_stages(c, 4); WIN(set_win(c, ext(g, 0, 1)));
-    rc = tfl_vorticityConfinement(c, s->U, s->flags, strength, &curl, &curl, &cnorm, &curl, is3D); if (rc) return rc;
+    if (vfused) {
+      // one launch: curl (2,2) and |curl| live in LDS, the planes (0,1) of U are written (inputs: planes (3,3) of `cur`)
+      (void)tfl_set_stages(c, 0); WIN(set_win(c, ext(g, 0, 1)));
+      rc = tfl_vorticityConfinementFrom(c, cur, s->U, s->flags, strength, &curl, &cnorm, is3D); if (rc) return rc;
+    } else {
+      (void)tfl_set_stages(c, 2); WIN(set_win(c, ext(g, 2, 2)));
+      rc = tfl_vorticityConfinement(c, s->U, s->flags, strength, &curl, &curl, &cnorm, &curl, is3D); if (rc) return rc;
+      (void)tfl_set_stages(c, 4); WIN(set_win(c, ext(g, 0, 1)));
+      rc = tfl_vorticityConfinement(c, s->U, s->flags, strength, &curl, &curl, &cnorm, &curl, is3D); if (rc) return rc;
+    }
   }
   (void)tfl_set_stages(c, 0); (void)tfl_set_z_window(c, 0, 0, 0, 0);
   if (prm->outputDiv) return TFL_OK;

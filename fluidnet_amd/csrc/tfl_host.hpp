@@ -97,6 +97,11 @@ void absmax(hipStream_t st, long long n, const float* x, float* out, bool reset)
 void vorticity_confinement(hipStream_t st, bool is3d, int B, int Z, int Y, int X, float* U, const float* flags,
                            float strength, float* curl, float* curl_norm, int stages = 3);
 
+// U_out = U_in + confinement(U_in), 3-D, one fused launch without curl arrays (U_out != U_in); false = not supported here
+bool vorticity_confinement_fused_ok(bool is3d, int Z);   // would vorticity_confinement_fused take this grid
+bool vorticity_confinement_fused(hipStream_t st, int B, int Z, int Y, int X, const float* Uin, float* Uout, const float* flags,
+                                 float strength);
+
 // jacobi.hip
 void jacobi_iteration(hipStream_t st, bool is3d, int B, int Z, int Y, int X, const float* p_prev, const float* flags,
                       const float* div, float* p, double* resid_sq /* [B] or nullptr */);

@@ -12,6 +12,8 @@
 #include "tfl_host.hpp"
 #include "tfl_vec4.hpp"
 
+#include <cstdlib>
+
 namespace tfl {
 
 // centred velocity component AXIS of cell n, 0 on the border shell (tfluids.cc:1372-1386 + grid.cc:346-356)
@@ -275,6 +277,196 @@ __global__ __launch_bounds__(256) void k_confine_v4(Dom d, float* __restrict__ U
     for (int a = 0; a < 3; a++)
       if (a < C) v4_store(U, o + a * d.sc, u[a]);
   }
+}
+
+// =====================================================================================================================
+// Fused form (round 4): U_out = U_in + confinement(U_in) on a 3-D grid in ONE launch, no curl / |curl| arrays in HBM.
+// A block owns a 64 x 8 column of the plane and walks a chunk of z. Per step one plane of U_in (with a halo of 3 cells in x
+// and y) enters a ring of four planes in LDS; curl and |curl| of the plane two behind it are evaluated from the ring into
+// their own rings (|curl|: three planes, curl: two); the force of the plane three behind it comes from those, its x / y
+// face neighbours through a small exchange array, its z neighbour (the plane before) from the thread's own register; then
+// the plane's velocities are written. Per-cell arithmetic is that of k_curl / k_confine, operation for operation: the
+// results are bit-equal to the two-launch form (tests/test_hip_parity.py). HBM traffic: U (12 B/cell, ~3x with the halo
+// re-reads through L2) + flags in, U out -- against 72 B/cell for the two launches.
+// U_out must not alias U_in: neighbouring blocks read each other's input cells.
+namespace {
+constexpr int FBX = 64, FBY = 8;
+constexpr int FUX = FBX + 6, FUY = FBY + 6, FUN = FUX * FUY;      // U tile 70 x 14, origin (x0 - 3, y0 - 3)
+constexpr int FCX = FBX + 3, FCY = FBY + 3, FCN = FCX * FCY;      // curl tile 67 x 11, origin (x0 - 2, y0 - 2)
+constexpr int FEX = FBX + 1, FEY = FBY + 1;                       // force exchange, origin (x0 - 1, y0 - 1)
+constexpr int kFusedLds = (4 * 3 * FUN + 3 * FCN + 2 * 3 * FCN + 2 * FEY * FEX) * 4;   // 78 252 bytes: two blocks per CU
+}  // namespace
+
+__global__ __launch_bounds__(512) void k_vort_fused(Dom d, int cols_x, int cols_y, int cz, int chunks_a, int chunks, int n_blocks,
+                                                    const float* __restrict__ Uin, float* __restrict__ Uout,
+                                                    const float* __restrict__ flags, float strength) {
+  extern __shared__ float lds[];
+  float* Ut = lds;                    // [4][3][FUN]  planes t & 3
+  float* Cn = Ut + 4 * 3 * FUN;       // [3][FCN]     |curl|, planes z % 3
+  float* Cv = Cn + 3 * FCN;           // [2][3][FCN]  curl, planes z & 1
+  float* Fe = Cv + 2 * 3 * FCN;       // [2][FEY][FEX] force.x / force.y of the plane being finished
+  const int blk = (int)blockIdx.x;
+  if (blk >= n_blocks) return;
+  int tq = blk;
+  const int bx = tq % cols_x; tq /= cols_x;
+  const int by = tq % cols_y; tq /= cols_y;
+  const int ch = tq % chunks;
+  const int b = tq / chunks;
+  const int za = ch < chunks_a ? d.w0 + ch * cz : d.w1 + (ch - chunks_a) * cz;
+  const int z_end = ch < chunks_a ? d.w0 + d.n0 : d.w1 + (d.nw - d.n0);
+  const int zb = min(za + cz, z_end);
+  const int x0 = bx * FBX, y0 = by * FBY;
+  const long long cells = d.sc;
+  Uin += b * cells * 3; Uout += b * cells * 3; flags += b * cells;
+  const int tid = threadIdx.x, tx = tid & 63, ty = tid >> 6;
+  const int i = x0 + tx, j = y0 + ty;
+  auto mod3 = [](int z) { return (z + 6) % 3; };
+
+  // confinement force of the cell at curl-tile position (cx, cy) of plane zf (0 on the border shell), tfluids.cc:1410-1436
+  auto force = [&](int cx, int cy, int zf) -> v3 {
+    const int gx = x0 - 2 + cx, gy = y0 - 2 + cy;
+    if (gx >= d.X || gy >= d.Y || zf < 0 || zf >= d.Z || on_border<true>(d, gx, gy, zf)) return mk3(0.0f, 0.0f, 0.0f);
+    const int it = cy * FCX + cx;
+    const float* c0 = Cn + mod3(zf) * FCN + it;
+    v3 g = mk3(0.5f * (c0[1] - c0[-1]), 0.5f * (c0[FCX] - c0[-FCX]),
+               0.5f * (Cn[mod3(zf + 1) * FCN + it] - Cn[mod3(zf - 1) * FCN + it]));
+    g = normalize3(g);
+    const float* cv = Cv + (zf & 1) * 3 * FCN + it;
+    const v3 w = mk3(cv[0], cv[FCN], cv[2 * FCN]);
+    return mk3(((g.y * w.z) - (g.z * w.y)) * strength, ((g.z * w.x) - (g.x * w.z)) * strength,
+               ((g.x * w.y) - (g.y * w.x)) * strength);
+  };
+
+  float fz_prev = 0.0f;               // force.z of the thread's cell in the plane finished one step earlier
+#pragma unroll 1
+  for (int t = za - 3; t <= zb + 2; t++) {
+    // ---- U plane t -> ring (clamped addresses: cells outside the array are never used, the border shell counts as 0) ----
+    {
+      const int gz = min(max(t, 0), d.Z - 1);
+#pragma unroll
+      for (int r = 0; r < 2; r++) {
+        const int it = tid + 512 * r;
+        if (it < FUN) {
+          const int uy = it / FUX, ux = it - uy * FUX;
+          const int o = TFL_AT(d, min(max(x0 - 3 + ux, 0), d.X - 1), min(max(y0 - 3 + uy, 0), d.Y - 1), gz);
+          float* dst = Ut + (t & 3) * 3 * FUN + it;
+          dst[0] = Uin[o]; dst[FUN] = Uin[o + d.sc]; dst[2 * FUN] = Uin[o + 2 * d.sc];
+        }
+      }
+    }
+    __syncthreads();
+    // ---- curl, |curl| of plane zc = t - 2 (VecGrid::curl, grid.cc:497-515, centred velocities 0 on the border shell) ----
+    const int zc = t - 2;
+    if (zc >= za - 2 && zc <= zb) {
+#pragma unroll
+      for (int r = 0; r < 2; r++) {
+        const int it = tid + 512 * r;
+        if (it < FCN) {
+          const int cy = it / FCX, cx = it - cy * FCX;
+          const int gx = x0 - 2 + cx, gy = y0 - 2 + cy;
+          v3 w = mk3(0.0f, 0.0f, 0.0f);
+          float nrm = 0.0f;
+          if (gx >= 0 && gx < d.X && gy >= 0 && gy < d.Y && zc >= 0 && zc < d.Z && !on_border<true>(d, gx, gy, zc)) {
+            const int base = (cy + 1) * FUX + (cx + 1);
+            auto U = [&](int c, int dz, int off) { return Ut[(((zc + dz) & 3) * 3 + c) * FUN + base + off]; };
+            const bool xpb = gx + 1 == d.X - 1, xmb = gx - 1 == 0, ypb = gy + 1 == d.Y - 1, ymb = gy - 1 == 0,
+                       zpb = zc + 1 == d.Z - 1, zmb = zc - 1 == 0;
+            const float cy_xp = xpb ? 0.0f : 0.5f * (U(1, 0, 1) + U(1, 0, 1 + FUX));
+            const float cy_xm = xmb ? 0.0f : 0.5f * (U(1, 0, -1) + U(1, 0, -1 + FUX));
+            const float cx_yp = ypb ? 0.0f : 0.5f * (U(0, 0, FUX) + U(0, 0, FUX + 1));
+            const float cx_ym = ymb ? 0.0f : 0.5f * (U(0, 0, -FUX) + U(0, 0, -FUX + 1));
+            w.z = 0.5f * ((cy_xp - cy_xm) - (cx_yp - cx_ym));
+            const float cz_yp = ypb ? 0.0f : 0.5f * (U(2, 0, FUX) + U(2, 1, FUX));
+            const float cz_ym = ymb ? 0.0f : 0.5f * (U(2, 0, -FUX) + U(2, 1, -FUX));
+            const float cy_zp = zpb ? 0.0f : 0.5f * (U(1, 1, 0) + U(1, 1, FUX));
+            const float cy_zm = zmb ? 0.0f : 0.5f * (U(1, -1, 0) + U(1, -1, FUX));
+            w.x = 0.5f * ((cz_yp - cz_ym) - (cy_zp - cy_zm));
+            const float cx_zp = zpb ? 0.0f : 0.5f * (U(0, 1, 0) + U(0, 1, 1));
+            const float cx_zm = zmb ? 0.0f : 0.5f * (U(0, -1, 0) + U(0, -1, 1));
+            const float cz_xp = xpb ? 0.0f : 0.5f * (U(2, 0, 1) + U(2, 1, 1));
+            const float cz_xm = xmb ? 0.0f : 0.5f * (U(2, 0, -1) + U(2, 1, -1));
+            w.y = 0.5f * ((cx_zp - cx_zm) - (cz_xp - cz_xm));
+            nrm = norm3(w);
+          }
+          float* cv = Cv + (zc & 1) * 3 * FCN + it;
+          cv[0] = w.x; cv[FCN] = w.y; cv[2 * FCN] = w.z;
+          Cn[mod3(zc) * FCN + it] = nrm;
+        }
+      }
+    }
+    __syncthreads();
+    // ---- force of plane zf = t - 3: the thread's own cell, and the cells one column / one row before the block ----------
+    const int zf = t - 3;
+    v3 f0 = mk3(0.0f, 0.0f, 0.0f);
+    if (zf >= za - 1 && zf <= zb - 1) {
+      f0 = force(tx + 2, ty + 2, zf);
+      Fe[(ty + 1) * FEX + tx + 1] = f0.x;
+      Fe[(FEY + ty + 1) * FEX + tx + 1] = f0.y;
+      if (tid < FBY) Fe[(tid + 1) * FEX] = force(1, tid + 2, zf).x;                            // column x0 - 1
+      else if (tid >= 64 && tid < 64 + FBX) Fe[FEY * FEX + (tid - 64) + 1] = force(tid - 64 + 2, 1, zf).y;   // row y0 - 1
+    }
+    __syncthreads();
+    // ---- plane zf out: AddForceField (tfluids.cc:1312-1339); every cell of the plane is written (U_out is another array) ----
+    if (zf >= za && zf < zb && i < d.X && j < d.Y) {
+      const int o = TFL_AT(d, i, j, zf);
+      float u0 = Uin[o], u1 = Uin[o + d.sc], u2 = Uin[o + 2 * d.sc];
+      if (!on_border<true>(d, i, j, zf)) {
+        const int fc = (int)flags[o];
+        const bool cf = fc & kFluid, ce = fc & kEmpty;
+        if (cf || ce) {
+          const int nx = (int)flags[o - 1], ny = (int)flags[o - d.sy], nz = (int)flags[o - d.sz];
+          const bool ax = (nx & kFluid) || (cf && (nx & kEmpty));
+          const bool ay = (ny & kFluid) || (cf && (ny & kEmpty));
+          const bool az = (nz & kFluid) || (cf && (nz & kEmpty));
+          if (ax) u0 += (0.5f * (Fe[(ty + 1) * FEX + tx] + f0.x));
+          if (ay) u1 += (0.5f * (Fe[(FEY + ty) * FEX + tx + 1] + f0.y));
+          if (az) u2 += (0.5f * (fz_prev + f0.z));
+        }
+      }
+      Uout[o] = u0; Uout[o + d.sc] = u1; Uout[o + 2 * d.sc] = u2;
+    }
+    fz_prev = f0.z;
+  }
+}
+
+bool vorticity_confinement_fused_ok(bool is3d, int Z) {
+  static const bool off = getenv("TFL_VORT_FUSED") && atoi(getenv("TFL_VORT_FUSED")) == 0;
+  return is3d && !off && Z >= 3;
+}
+
+// false = shape not supported by the fused kernel (the caller copies and runs the two-launch form)
+bool vorticity_confinement_fused(hipStream_t st, int B, int Z, int Y, int X, const float* Uin, float* Uout, const float* flags,
+                                 float strength) {
+  if (!vorticity_confinement_fused_ok(true, Z) || Uin == Uout) return false;
+  const Dom d = make_dom(Z, Y, X);
+  const int cxn = (X + FBX - 1) / FBX, cyn = (Y + FBY - 1) / FBY;
+  const int na = d.n0, nb = d.nw - d.n0;
+  if ((long long)cxn * cyn * (na + nb) * B <= 0) return true;
+  static int slots = 0;
+  if (!slots) {
+    (void)hipFuncSetAttribute((const void*)k_vort_fused, hipFuncAttributeMaxDynamicSharedMemorySize, kFusedLds);
+    int cus = 256, dev = 0, per = 0;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, (const void*)k_vort_fused, 512, kFusedLds) != hipSuccess || per <= 0) per = 2;
+    slots = cus * per;
+  }
+  // chunk length: rounds of resident blocks x (planes written + 6 planes of pipeline fill)
+  int cz = 4;
+  {
+    long long best = -1;
+    for (int c = 4; c <= 32; c++) {
+      const long long blocks = (long long)cxn * cyn * B * ((na + c - 1) / c + (nb + c - 1) / c);
+      const long long cost = ((blocks + slots - 1) / slots) * (c + 6);
+      if (best < 0 || cost < best) { best = cost; cz = c; }
+    }
+  }
+  if (const char* e = getenv("TFL_VORT_CZ")) cz = atoi(e) > 0 ? atoi(e) : cz;
+  const int chunks_a = (na + cz - 1) / cz, chunks = chunks_a + (nb + cz - 1) / cz;
+  const int n_blocks = cxn * cyn * chunks * B;
+  TFL_TIMED_EXT("k_vort_fused", st);
+  TFL_LAUNCH_EXT(k_vort_fused, n_blocks, 512, kFusedLds, st, d, cxn, cyn, cz, chunks_a, chunks, n_blocks, Uin, Uout, flags, strength);
+  return true;
 }
 
 void vorticity_confinement(hipStream_t st, bool is3d, int B, int Z, int Y, int X, float* U, const float* flags,

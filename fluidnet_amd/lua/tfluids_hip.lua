@@ -65,6 +65,8 @@ int tfl_velocityUpdateForward(tfl_ctx* ctx, const tfl_tensor* U, const tfl_tenso
 int tfl_vorticityConfinement(tfl_ctx* ctx, const tfl_tensor* U, const tfl_tensor* flags,
                              float strength, const tfl_tensor* centered, const tfl_tensor* curl,
                              const tfl_tensor* curlNorm, const tfl_tensor* force, int is3D);
+int tfl_vorticityConfinementFrom(tfl_ctx* ctx, const tfl_tensor* USrc, const tfl_tensor* U, const tfl_tensor* flags,
+                                 float strength, const tfl_tensor* curl, const tfl_tensor* curlNorm, int is3D);
 int tfl_addBuoyancy(tfl_ctx* ctx, const tfl_tensor* U, const tfl_tensor* flags,
                     const tfl_tensor* density, const float gravity[3], float* strengthTmp,
                     float dt, int is3D);

@@ -268,11 +268,20 @@ def volumetricUpSamplingNearestBackward(ratio, input, gradOutput, gradInput):
                                                                 _tt(gradInput)))
 
 
-def vorticityConfinement(U, flags, strength):
-    """init.lua:394-430 (in place on U)."""
+def vorticityConfinement(U, flags, strength, USrc=None):
+    """init.lua:394-430 (in place on U).
+    USrc (extension): U = USrc + confinement(USrc), every cell of U written, one fused launch on a 3-D grid
+    (tfl_vorticityConfinementFrom); U must not alias USrc."""
     bsz, d, h, w, is3D = _dims(U, flags)
     _check(isinstance(strength, (int, float)), "strength must be a number")
     C = U.size(1)
+    if USrc is not None:
+        _check(USrc.shape == U.shape and USrc.is_contiguous(), "USrc must have U's shape")
+        curl, curlNorm = getTempStorage(U, [(bsz, 3, d, h, w), (bsz, 1, d, h, w)])
+        lib, ctx = _context(U)
+        _call(lib, ctx, lib.tfl_vorticityConfinementFrom(ctx, _tt(USrc), _tt(U), _tt(flags), float(strength), _tt(curl),
+                                                         _tt(curlNorm), int(is3D)))
+        return
     centered, curl, curlNorm, force = getTempStorage(
         U, [(bsz, C, d, h, w), (bsz, 3, d, h, w), (bsz, 1, d, h, w), (bsz, C, d, h, w)])
     lib, ctx = _context(U)

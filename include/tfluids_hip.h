@@ -131,6 +131,13 @@ int tfl_velocityUpdateForward(tfl_ctx* ctx, const tfl_tensor* U, const tfl_tenso
 int tfl_vorticityConfinement(tfl_ctx* ctx, const tfl_tensor* U, const tfl_tensor* flags,
                              float strength, const tfl_tensor* centered, const tfl_tensor* curl,
                              const tfl_tensor* curlNorm, const tfl_tensor* force, int is3D);
+/* The same operator out of place: U = USrc + confinement(USrc), every cell of U (of the z-window) written; U must not alias
+ * USrc. On a 3-D grid this is ONE fused launch that keeps curl and |curl| in LDS (vorticity.hip k_vort_fused: 72 -> ~30
+ * bytes per cell of HBM traffic), bit-equal to tfl_vorticityConfinement; 2-D grids copy and run the two-launch form, for
+ * which curl (3 channels) / curlNorm are the scratch. tfl_simulate_step uses it to fold simulate()'s `U:copy(advected)`
+ * and the confinement into one pass. No reference counterpart (the reference op is in place). */
+int tfl_vorticityConfinementFrom(tfl_ctx* ctx, const tfl_tensor* USrc, const tfl_tensor* U, const tfl_tensor* flags,
+                                 float strength, const tfl_tensor* curl, const tfl_tensor* curlNorm, int is3D);
 
 /* init.lua:469 -> third_party/tfluids.cc:1162-1233 | tfluids.cu:1201-1273 (in place on U).
  * gravity: 3 floats in HOST memory (the Lua wrapper passes a 3-element tensor, init.lua:455-458);

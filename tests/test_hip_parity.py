@@ -436,3 +436,28 @@ def test_hip_normalize_pressure_mean(hip, oracle, dims, seed, split):
     oracle.normalizePressureMean(b, f, sc["is3d"])
     assert np.abs(a - b).max() < 2e-6 * np.abs(p0).max()
     assert np.array_equal(a[f != 1.0], p0[f != 1.0])
+
+
+@pytest.mark.parametrize("dims,seed,B", [((20, 36, 68), 91, 1), ((5, 9, 70), 92, 2), ((33, 16, 64), 93, 1), ((3, 8, 8), 94, 1),
+                                          ((40, 70, 130), 95, 1)])
+def test_fused_vorticity_confinement_equals_the_two_launch_form(oracle, dims, seed, B):
+    """tfl_vorticityConfinementFrom on a 3-D grid = one z-marched launch with curl / |curl| in LDS (vorticity.hip
+    k_vort_fused): bit-equal to the in-place operator (itself bit-equal to the reference, test_hip_matches_golden) and to
+    the oracle, on ragged grids (partial 64 x 8 columns), more than one batch item, obstacles and empty cells; a 2-D grid
+    takes the copy + two-launch route of the same entry point."""
+    import torch
+    from fluidnet_amd import tfluids
+    dev = torch.device("cuda:0")
+    for is3d in (True, False):
+        d = dims if is3d else (1, dims[1], dims[2])
+        sc = scenes.make_scene(d, seed=seed, vel_cells=2.0, B=B, empty_cells=True)
+        U, fl = torch.from_numpy(sc["U"]).to(dev), torch.from_numpy(sc["flags"]).to(dev)
+        want = U.clone()
+        tfluids.vorticityConfinement(want, fl, 0.7)
+        got = torch.full_like(U, float("nan"))
+        tfluids.vorticityConfinement(got, fl, 0.7, USrc=U)
+        assert torch.equal(got, want), (d, int((got != want).sum()))
+        ref = sc["U"].copy()
+        oracle.vorticityConfinement(ref, sc["flags"], 0.7)
+        assert np.array_equal(got.cpu().numpy(), ref), d
+        assert torch.equal(U, torch.from_numpy(sc["U"]).to(dev))          # the source is left alone
