@@ -62,6 +62,7 @@ ALG_BYTES_PER_CELL = {
     "k_add_buoyancy": 32,    # U3, flags, rho -> U3
     "k_curl": 28,            # U3 -> curl3, |curl|                      (vorticity pass A)
     "k_confine": 44,         # curl3, |curl|, flags, U3 -> U3           (vorticity pass B)     A+B = 72
+    "k_vort_fused": 28,      # U3, flags -> U3                          (curl + confinement in one launch, curl in LDS)
     "k_bcs_div_stats": 32,   # U3, flags -> U3_bc, div (+ 2 scalars)
     "k_net_input": 24,       # pDiv, div, flags -> 3 input planes
     "k_project": 60,         # pPred, flags, U3, UBC3, mask3 -> U3, p

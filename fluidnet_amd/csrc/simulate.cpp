@@ -154,7 +154,7 @@ int tfl_simulate_step(tfl_ctx* c, const tfl_sim_params* prm, const tfl_sim_state
   // run in place: then buoyancy / gravity work on a scratch velocity and the confinement delivers into U)
   const bool buoyant = s->n_density > 0 && prm->buoyancyScale > 0.0;
   const bool vort = prm->vorticityConfinementAmp > 0.0;
-  const bool vfused = vort && tfl::vorticity_confinement_fused_ok(is3D != 0, (int)z.Z);
+  const bool vfused = vort && tfl::vorticity_confinement_fused_ok(is3D != 0, (int)z.Z, z.N / z.B);
   // scratch of the vorticity operator (centered | curl[3] | cnorm | force): the velocity planes 3..5 are free here too
   tfl_tensor centered = view(ws, (int)z.C), curl = view(ws + z.C * z.N, 3), cnorm = view(ws + (z.C + 3) * z.N, 1),
              force = view(ws + (z.C + 4) * z.N, (int)z.C);
@@ -580,7 +580,7 @@ int tfl_simulate_step_slab(tfl_ctx* c, const tfl_sim_params* prm, const tfl_sim_
   (void)tfl_set_stages(c, 0); (void)tfl_set_z_window(c, 0, 0, 0, 0);
   // as tfl_simulate_step: the fused vorticity confinement delivers into U, so buoyancy / gravity work on a scratch velocity
   const bool vort = prm->vorticityConfinementAmp > 0.0;
-  const bool vfused = vort && tfl::vorticity_confinement_fused_ok(true, g.Zl);
+  const bool vfused = vort && tfl::vorticity_confinement_fused_ok(true, g.Zl, (long long)g.Zl * g.yx);
   tfl_tensor Utmp = view(cw + 4 * N, 3);                   // the scalar advection's bwdPos planes, dead by now
   const tfl_tensor* cur = &Uadv;
   if (!buoyant && !vfused) { rc = tfl_copy(c, s->U, &Uadv); if (rc) return rc; cur = s->U; }

@@ -337,24 +337,48 @@ __global__ __launch_bounds__(512) void k_vort_fused(Dom d, int cols_x, int cols_
                ((g.x * w.y) - (g.y * w.x)) * strength);
   };
 
+  // the thread's one or two cells of a staged U plane: loaded one step ahead into registers (their latency hides behind the
+  // step's curl / force work), written to the ring at the top of the next step
+  int st_o[2];
+#pragma unroll
+  for (int r = 0; r < 2; r++) {
+    const int it = min(tid + 512 * r, FUN - 1);
+    const int uy = it / FUX, ux = it - uy * FUX;
+    st_o[r] = TFL_AT(d, min(max(x0 - 3 + ux, 0), d.X - 1), min(max(y0 - 3 + uy, 0), d.Y - 1), 0);
+  }
+  float nu[2][3];
+  auto load_plane = [&](int t) {      // clamped addresses: cells outside the array are never used, the border shell counts as 0
+    const int gz = min(max(t, 0), d.Z - 1);
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+      if (r == 1 && tid >= FUN - 512) continue;
+      const int o = st_o[r] + gz * d.sz;
+      nu[r][0] = Uin[o]; nu[r][1] = Uin[o + d.sc]; nu[r][2] = Uin[o + 2 * d.sc];
+    }
+  };
+  load_plane(za - 3);
   float fz_prev = 0.0f;               // force.z of the thread's cell in the plane finished one step earlier
 #pragma unroll 1
   for (int t = za - 3; t <= zb + 2; t++) {
-    // ---- U plane t -> ring (clamped addresses: cells outside the array are never used, the border shell counts as 0) ----
-    {
-      const int gz = min(max(t, 0), d.Z - 1);
+    // ---- U plane t (in registers since the previous step) -> ring ----
 #pragma unroll
-      for (int r = 0; r < 2; r++) {
-        const int it = tid + 512 * r;
-        if (it < FUN) {
-          const int uy = it / FUX, ux = it - uy * FUX;
-          const int o = TFL_AT(d, min(max(x0 - 3 + ux, 0), d.X - 1), min(max(y0 - 3 + uy, 0), d.Y - 1), gz);
-          float* dst = Ut + (t & 3) * 3 * FUN + it;
-          dst[0] = Uin[o]; dst[FUN] = Uin[o + d.sc]; dst[2 * FUN] = Uin[o + 2 * d.sc];
-        }
-      }
+    for (int r = 0; r < 2; r++) {
+      if (r == 1 && tid >= FUN - 512) continue;
+      float* dst = Ut + (t & 3) * 3 * FUN + tid + 512 * r;
+      dst[0] = nu[r][0]; dst[FUN] = nu[r][1]; dst[2 * FUN] = nu[r][2];
     }
     __syncthreads();
+    load_plane(t + 1);
+    // the inputs of the plane this step finishes (zf = t - 3), also asked for now
+    const int zo = t - 3;
+    const bool out_live = zo >= za && zo < zb && i < d.X && j < d.Y;
+    const bool out_inner = out_live && !on_border<true>(d, i, j, zo);
+    float pu0 = 0.0f, pu1 = 0.0f, pu2 = 0.0f, pfc = 0.0f, pnx = 0.0f, pny = 0.0f, pnz = 0.0f;
+    if (out_live) {
+      const int o = TFL_AT(d, i, j, zo);
+      pu0 = Uin[o]; pu1 = Uin[o + d.sc]; pu2 = Uin[o + 2 * d.sc];
+      if (out_inner) { pfc = flags[o]; pnx = flags[o - 1]; pny = flags[o - d.sy]; pnz = flags[o - d.sz]; }
+    }
     // ---- curl, |curl| of plane zc = t - 2 (VecGrid::curl, grid.cc:497-515, centred velocities 0 on the border shell) ----
     const int zc = t - 2;
     if (zc >= za - 2 && zc <= zb) {
@@ -407,14 +431,14 @@ __global__ __launch_bounds__(512) void k_vort_fused(Dom d, int cols_x, int cols_
     }
     __syncthreads();
     // ---- plane zf out: AddForceField (tfluids.cc:1312-1339); every cell of the plane is written (U_out is another array) ----
-    if (zf >= za && zf < zb && i < d.X && j < d.Y) {
+    if (out_live) {
       const int o = TFL_AT(d, i, j, zf);
-      float u0 = Uin[o], u1 = Uin[o + d.sc], u2 = Uin[o + 2 * d.sc];
-      if (!on_border<true>(d, i, j, zf)) {
-        const int fc = (int)flags[o];
+      float u0 = pu0, u1 = pu1, u2 = pu2;
+      if (out_inner) {
+        const int fc = (int)pfc;
         const bool cf = fc & kFluid, ce = fc & kEmpty;
         if (cf || ce) {
-          const int nx = (int)flags[o - 1], ny = (int)flags[o - d.sy], nz = (int)flags[o - d.sz];
+          const int nx = (int)pnx, ny = (int)pny, nz = (int)pnz;
           const bool ax = (nx & kFluid) || (cf && (nx & kEmpty));
           const bool ay = (ny & kFluid) || (cf && (ny & kEmpty));
           const bool az = (nz & kFluid) || (cf && (nz & kEmpty));
@@ -429,15 +453,18 @@ __global__ __launch_bounds__(512) void k_vort_fused(Dom d, int cols_x, int cols_
   }
 }
 
-bool vorticity_confinement_fused_ok(bool is3d, int Z) {
-  static const bool off = getenv("TFL_VORT_FUSED") && atoi(getenv("TFL_VORT_FUSED")) == 0;
-  return is3d && !off && Z >= 3;
+// does the native step route its confinement through the fused kernel (TFL_VORT_FUSED = 1 | 0; default: see the record in
+// profiles/r04_advect_experiments.txt)
+bool vorticity_confinement_fused_ok(bool is3d, int Z, long long cells) {
+  static const int mode = getenv("TFL_VORT_FUSED") ? atoi(getenv("TFL_VORT_FUSED")) : -1;
+  if (!is3d || Z < 3 || mode == 0) return false;
+  return mode == 1 || cells >= 6000000ll;
 }
 
 // false = shape not supported by the fused kernel (the caller copies and runs the two-launch form)
 bool vorticity_confinement_fused(hipStream_t st, int B, int Z, int Y, int X, const float* Uin, float* Uout, const float* flags,
                                  float strength) {
-  if (!vorticity_confinement_fused_ok(true, Z) || Uin == Uout) return false;
+  if (Z < 3 || Uin == Uout) return false;
   const Dom d = make_dom(Z, Y, X);
   const int cxn = (X + FBX - 1) / FBX, cyn = (Y + FBY - 1) / FBY;
   const int na = d.n0, nb = d.nw - d.n0;

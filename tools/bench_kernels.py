@@ -5,8 +5,9 @@ import sys
 src = open(sys.argv[1]) if len(sys.argv) > 1 else sys.stdin
 line = [l for l in src.read().splitlines() if l.startswith("{")][-1]
 d = json.loads(line)
-print(f"{d['ms_per_step']:.4f} ms/step  {d['value']:.1f} {d['unit']}  roofline {d['roofline']['kernel'] if 'kernel' in d['roofline'] else ''} "
-      f"{d['roofline']['achieved']:.1f}/{d['roofline']['peak']} {d['roofline']['unit']}")
+r = d["roofline"]
+print(f"{d['ms_per_step']:.4f} ms/step  {d['value']:.1f} {d['unit']}  roofline {r.get('kernel', '')} "
+      f"{(r.get('achieved') or 0.0):.1f}/{r.get('peak')} {r.get('unit')}")
 tot = 0.0
 for name, k in sorted(d.get("kernels", {}).items(), key=lambda kv: -kv[1]["ms_per_step"]):
     tot += k["ms_per_step"]
