@@ -2,9 +2,12 @@
 # round-4 evidence set -> gpurun_out/r04final/ (tools/r04_collect.sh copies what is kept into profiles/)
 REPO=$(cd "$(dirname "$0")/.." && pwd); cd "$REPO"; export TMPDIR=/tmp
 O=$REPO/gpurun_out/r04final; rm -rf $O; mkdir -p $O
-python bench.py 2> $O/bench.err | tail -1 > $O/bench.json; echo "bench rc=$?"
-TFL_ADVECT_MODE=fast python bench.py --no-cpu-baseline --no-config5 --no-configs 2>/dev/null | tail -1 > $O/bench_fast.json
-python tools/slab_host_cost.py 128 8 --kernels > $O/slab_128.txt 2>&1; python tools/slab_host_cost.py 256 8 >> $O/slab_128.txt 2>&1
+timeout 240 python bench.py 2> $O/bench.err | tail -1 > $O/bench.json; echo "bench rc=$?"
+TFL_ADVECT_MODE=fast timeout 120 python bench.py --no-cpu-baseline --no-config5 --no-configs 2>/dev/null | tail -1 > $O/bench_fast.json
+# --still (dt = 0): with a transport that moves nothing a moving scene diverges in the stale halos within a few steps (the
+# fp16-split conv clamps instead of overflowing to inf, velocities grow without bound and the reference's line trace walks
+# |u| dt cells): the first version of this script spent its whole time limit there
+timeout 120 python tools/slab_host_cost.py 128 8 --kernels --still > $O/slab_128.txt 2>&1; timeout 120 python tools/slab_host_cost.py 256 8 --still >> $O/slab_128.txt 2>&1
 cd /tmp
 for res in 128 256; do
   timeout -k 5 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats$res -o bench -- python $REPO/bench.py --no-cpu-baseline --no-config5 --no-configs --res $res --steps $((res==128?50:10)) --blocks 1 --preroll $((res==128?16:4)) > $O/stats$res.log 2>&1
