@@ -518,9 +518,12 @@ int tfl_solveLinearSystemPCG(tfl_ctx* c, const tfl_tensor* p, const tfl_tensor* 
     return fail(c, TFL_EINVAL, "solveLinearSystemPCG: workspace too small (tfl_pcg_workspace_floats)");
   if ((long long)flags->Z * flags->Y * flags->X >= (1ll << 31)) return fail(c, TFL_EINVAL, "solveLinearSystemPCG: grid too large for 32-bit cell indices");
   char msg[256] = {0};
+  // the pipelined sweeps need every sub-box resident at once: when something else holds part of the GPU they time out (~1 s)
+  // and the solve is repeated with one launch per hyperplane -- remembered per context, so that only the FIRST solve pays
   int rc = tfl::pcg_solve(c->stream, is3D != 0, flags->B, flags->Z, flags->Y, flags->X, p->data, flags->data, div->data,
-                          pc, tol, maxIter, verbose, workspace, residual, msg, sizeof(msg));
-  if (rc == -5)      // the pipelined sweeps need every sub-box resident at once; fall back to one launch per hyperplane
+                          pc, tol, maxIter, verbose, workspace, residual, msg, sizeof(msg), !c->wf_timed_out);
+  if (rc == -5) c->wf_timed_out = true;
+  if (rc == -5)
     rc = tfl::pcg_solve(c->stream, is3D != 0, flags->B, flags->Z, flags->Y, flags->X, p->data, flags->data, div->data,
                         pc, tol, maxIter, verbose, workspace, residual, msg, sizeof(msg), false);
   if (rc == -1 || rc == -3) return fail(c, TFL_EINVAL, "%s", msg);

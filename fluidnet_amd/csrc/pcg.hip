@@ -653,7 +653,7 @@ __device__ __forceinline__ void wf_helper(const WfGeom& g, const WfArrays& A, in
         }
         if (__ballot(again) == 0ull) break;
         // never hang the GPU: give up after ~1 s, or when another block already has (looked at every 64th retry only)
-        if (spin > (1 << 20) || ((spin & 63) == 63 && wf_reload_word(A.err))) { atomicExch(A.err, 1); dead = true; break; }
+        if (spin > (1 << 17) || ((spin & 63) == 63 && wf_reload_word(A.err))) { atomicExch(A.err, 1); dead = true; break; }
       }
     }
     if (SLAB) {
@@ -800,6 +800,7 @@ int pcg_solve(hipStream_t st, bool is3d, int B, int Z, int Y, int X, float* p, c
   static const bool wf_trace_on = getenv("TFL_WF_TRACE") != nullptr;
   long long* wf_trace = nullptr;
   if (wf && wf_trace_on && precond && hipMalloc(&wf_trace, sizeof(long long) * 4 * wg.ns * wg.nb) != hipSuccess) wf_trace = nullptr;
+  struct TraceGuard { long long*& p; ~TraceGuard() { if (p) { (void)hipFree(p); p = nullptr; } } } trace_guard{wf_trace};   // every exit frees it
   auto hip_ok = [&](hipError_t e, const char* what) {
     if (e == hipSuccess) return true;
     snprintf(msg, msg_len, "solveLinearSystemPCG: %s: %s", what, hipGetErrorString(e));
@@ -968,7 +969,6 @@ int pcg_solve(hipStream_t st, bool is3d, int B, int Z, int Y, int X, float* p, c
           fprintf(stderr, "[tfl] wf %s strip %d slab %2d: start %8.2f us  end %8.2f us\n", dir ? "bwd" : "fwd", b2 / wg.nb, b2 % wg.nb,
                   (t[dir * 2 * nblk + 2 * b2] - t0) * 0.01, (t[dir * 2 * nblk + 2 * b2 + 1] - t0) * 0.01);
     }
-    (void)hipFree(wf_trace);
   }
   if (residual) *residual = max_res;
   return 0;

@@ -24,4 +24,5 @@ struct tfl_ctx {
   float* h_reach = nullptr;                   // pinned mirror, read by the NEXT tfl_simulate_step_slab call
   hipEvent_t reach_ev = nullptr;              // recorded behind the copy into h_reach; the next call waits for it
   bool reach_pending = false;
+  bool wf_timed_out = false;                  // a pipelined PCG sweep timed out on this context once: later solves go straight to hyperplane sweeps
 };
