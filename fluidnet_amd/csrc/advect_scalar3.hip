@@ -20,8 +20,9 @@
 //    point in a fluid cell, every interpolation corner fluid. Everything else (obstacle neighbours, fast flow, NaNs)
 //    re-runs the generic functions of tfl_device.hpp afterwards from scratch: same result as the gather kernels by
 //    construction. Division and square root of the trace: tfl_fastmath.hpp.
-//  * A block covers 64 x 4 x TZ cells (TZ = 2): the halo-2 tile of pass A is 68 x 8 x 6 = 6.4 staged words per cell
-//    (10.6 for one plane), the halo-1 tile of pass B 3.1.
+//  * A block of 64 x 4 x TZ threads covers TZ x KZ planes (KZ planes per thread) on one staged tile: two planes make the
+//    halo-2 tile of pass A 68 x 8 x 6 = 6.4 staged words per cell (10.6 for one plane), the halo-1 tile of pass B 3.1;
+//    the shape is chosen per pass and grid size (launch()).
 //
 // Algorithmic HBM bytes per cell: pass A 24 (s, U3, flags -> fwd) + 8 (the clamp bounds of the forward position, two
 // planes of the fwdPos temp), pass B 28 (fwd, s, U3, flags -> dst) + 8. `sampleOutsideFluid`, 2-D grids and the Manta
@@ -34,6 +35,11 @@
 namespace tfl {
 namespace {
 
+// timing ablations (tools/ab_build.sh -DTFL_SCAL3_ABL=..): 1 = the tile is filled with a constant instead of staged, 2 = no 27-tap
+// bounds search (pass A), 4 = no stores, 8 = no trace / lerp (the cell's own value)
+#ifndef TFL_SCAL3_ABL
+#define TFL_SCAL3_ABL 0
+#endif
 constexpr int TX = 64, TY = 4;
 constexpr float kFastLen = 0.99f;
 // the "not a fluid cell" word of the masked tile: a quiet NaN with a payload no arithmetic produces (hardware NaNs are
@@ -72,11 +78,15 @@ __device__ __forceinline__ float mask_word(float v, float f, bool in) {
 // A wave stages whole rows (one coalesced 256-B load of g and of flags per row, the row's offset is scalar), a thread one
 // word of the 2H halo columns. EDGE = false: the block's halo rows and planes all lie inside the array and its 64 columns
 // inside the row (only the halo COLUMNS can stick out): no clamps, no row tests.
-template <int TZ, int H, bool EDGE>
+template <int TZ, int H, bool EDGE, int NW>       // TZ: planes of the tile; NW: waves of the block
 __device__ __forceinline__ void stage_masked(float* __restrict__ tile, const float* __restrict__ g,
                                              const float* __restrict__ flags, const Dom& d, int x0, int y0, int k0, int tid) {
   using T = Tile<TZ, H>;
-  constexpr int NW = TY * TZ, NT = 64 * NW, ROWS = T::LY * T::LZ;
+  constexpr int NT = 64 * NW, ROWS = T::LY * T::LZ;
+  if (TFL_SCAL3_ABL & 1) {
+    for (int it = tid; it < T::N; it += NT) tile[it] = 0.5f;
+    return;
+  }
   const int lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int gx = x0 + lane;
   const unsigned xc4 = (unsigned)(EDGE ? min(gx, d.X - 1) : gx) * 4u;
@@ -224,134 +234,209 @@ __device__ __forceinline__ void clamp_bounds_global(const Dom& d, const float* _
 __device__ __forceinline__ float min3r(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 __device__ __forceinline__ float max3r(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 
-// Common prologue: block -> plane group / batch item; tile staged (interior blocks without clamps); the cell's geometry.
-// `fl` comes from the tile (the mask word <=> not a fluid cell). All global accesses of the fast path are a uniform base +
-// a 32-bit byte offset (o4): no 64-bit address arithmetic per lane.
-#define TFL_SCAL3_PROLOGUE(H, SRC)                                                                 \
-  using T = Tile<TZ, H>;                                                                           \
+// Block part of a kernel: block -> plane group / batch item, tile staged (interior blocks without clamps). A block of
+// 64 x 4 x TZ threads covers PZ = TZ * KZ planes: thread (lane, ty, tz) owns the cells (i, j, k0 + tz + TZ q), q < KZ --
+// with KZ = 2 the same tile is staged by half the waves, twice as many blocks are resident and a launch needs half the
+// rounds of them (these kernels are bound by the latency of a block's life -- load, barrier, trace, store -- not by
+// throughput: profiles/r04_advect_experiments.txt 9). All global accesses of the fast path are a uniform base + a 32-bit
+// byte offset: no 64-bit address arithmetic per lane.
+#define TFL_SCAL3_BLOCK(H, SRC)                                                                    \
+  constexpr int PZ = TZ * KZ;                                                                      \
+  using T = Tile<PZ, H>;                                                                           \
   __shared__ float tile[T::N];                                                                     \
   const Dom& d = a.d;                                                                              \
-  int b, k0, kend; group_planes<TZ>(d, b, k0, kend);                                               \
+  int b, k0, kend; group_planes<PZ>(d, b, k0, kend);                                               \
   const long long cells = (long long)d.sc;                                                         \
   s += b * cells; flags += b * cells; U += b * cells * 3;                                          \
   const int lane = threadIdx.x, ty = threadIdx.y, tz = threadIdx.z;                                \
   const int tid = lane + 64 * (ty + TY * tz);                                                      \
   const int x0 = blockIdx.x * TX, y0 = blockIdx.y * TY;                                            \
-  const int i = x0 + lane, j = y0 + ty, k = k0 + tz;                                               \
-  const bool inner = y0 >= H && y0 + TY + H <= d.Y && k0 >= H && k0 + TZ + H <= d.Z && x0 + TX <= d.X;   \
-  if (inner) stage_masked<TZ, H, false>(tile, SRC, flags, d, x0, y0, k0, tid);                     \
-  else stage_masked<TZ, H, true>(tile, SRC, flags, d, x0, y0, k0, tid);                            \
-  const bool live = (i < d.X) & (j < d.Y) & (k < kend);                                            \
-  const unsigned o4 = (unsigned)(min(i, d.X - 1) + __mul24(min(j, d.Y - 1), d.sy) + __mul24(min(k, d.Z - 1), d.sz)) * 4u; \
+  const int i = x0 + lane, j = y0 + ty;                                                            \
+  const bool inner = y0 >= H && y0 + TY + H <= d.Y && k0 >= H && k0 + PZ + H <= d.Z && x0 + TX <= d.X;   \
+  if (inner) stage_masked<PZ, H, false, TY * TZ>(tile, SRC, flags, d, x0, y0, k0, tid);            \
+  else stage_masked<PZ, H, true, TY * TZ>(tile, SRC, flags, d, x0, y0, k0, tid);                   \
   const unsigned sc4 = (unsigned)d.sc * 4u;                                                        \
+  const unsigned oxy4 = (unsigned)(min(i, d.X - 1) + __mul24(min(j, d.Y - 1), d.sy)) * 4u;         \
   /* on_border (bnd = 1) without branches: c < 1 || c > N - 2  <=>  unsigned(c - 1) >= unsigned(N - 2) */ \
-  const bool border = ((unsigned)(i - 1) >= (unsigned)(d.X - 2)) | ((unsigned)(j - 1) >= (unsigned)(d.Y - 2)) |         \
-                      ((unsigned)(k - 1) >= (unsigned)(d.Z - 2));                                  \
+  const bool border_xy = ((unsigned)(i - 1) >= (unsigned)(d.X - 2)) | ((unsigned)(j - 1) >= (unsigned)(d.Y - 2))
+
+// Cell part (inside a loop over q): geometry of the thread's q-th cell
+#define TFL_SCAL3_CELL(H, q)                                                                       \
+  const int pz = tz + TZ * (q);                       /* plane of the tile's interior */           \
+  const int k = k0 + pz;                                                                           \
+  const bool live = (i < d.X) & (j < d.Y) & (k < kend);                                            \
+  const unsigned o4 = oxy4 + (unsigned)__mul24(min(k, d.Z - 1), d.sz) * 4u;                        \
+  const bool border = border_xy | ((unsigned)(k - 1) >= (unsigned)(d.Z - 2));                      \
   const int kg = k + d.zg;                                                                         \
   const bool deep = live & !border & ((unsigned)(kg - 1) < (unsigned)(d.Zg - 2));                  \
-  const int c0 = (tz + H) * T::LP + (ty + H) * T::LX + lane + H;                                   \
+  const int c0 = (pz + H) * T::LP + (ty + H) * T::LX + lane + H;                                   \
   const int cbias = c0 - (i + j * T::LX + kg * T::LP);                                             \
   const v3 ctr = mk3((float)i + 0.5f, (float)j + 0.5f, (float)kg + 0.5f)
 
 // ---- pass A / the single-pass method: SemiLagrangeEulerOurs[SavePos] + getClampBounds of the forward position ----------
-template <int TZ, bool BOUNDS, bool FAST>
+template <int TZ, int KZ, bool BOUNDS, bool FAST>
 __global__ __launch_bounds__(256 * TZ) void k_scal3_fwd(AdvArgs a, const float* __restrict__ s, const float* __restrict__ U,
                                                         const float* __restrict__ flags, float* __restrict__ out,
                                                         float* __restrict__ bounds) {
   constexpr int HH = BOUNDS ? 2 : 1;
-  TFL_SCAL3_PROLOGUE(HH, s);
+  TFL_SCAL3_BLOCK(HH, s);
   out += b * cells;
-  // loads that do not depend on the tile: the cell's own value and the six faces of its centred velocity
-  const float sv = ldg(s, o4);
-  v3 u = mk3(0.0f, 0.0f, 0.0f);
-  if (deep) u = centred(d, U, o4);
+  if (BOUNDS) bounds += b * cells * 3;
+  // loads that do not depend on the tile: the cells' own values and the six faces of their centred velocities
+  float svq[KZ];
+  v3 uq[KZ];
+#pragma unroll
+  for (int q = 0; q < KZ; q++) {
+    TFL_SCAL3_CELL(HH, q);
+    (void)c0; (void)cbias; (void)ctr;
+    svq[q] = ldg(s, o4);
+    uq[q] = mk3(0.0f, 0.0f, 0.0f);
+    if (deep) uq[q] = centred(d, U, o4);
+  }
   __syncthreads();
-  if (!live) return;
-  if (border) { stg(out, o4, 0.0f); return; }
-  const bool fl = !is_mask(tile[c0]);
-  float v = sv;
-  int e = c0;                       // cell of the forward position: the cell itself where nothing is advected (tfluids.cc:159-163)
-  bool slow = false;
-  if (fl) {
-    slow = true;
-    if (deep) {
-      v3 p;
-      const bool ok = trace_fast<FAST>(tile, T::LX, T::LP, cbias, ctr, u, -a.dt, p, e);
-      const float r = lerp_tile<FAST>(tile, T::LX, T::LP, cbias, ok ? p : ctr);
-      if (ok && !is_mask(r)) { v = r; slow = false; }
+#pragma unroll
+  for (int q = 0; q < KZ; q++) {
+    TFL_SCAL3_CELL(HH, q);
+    if (!live) continue;
+    if (border) { stg(out, o4, 0.0f); continue; }
+    const v3 u = uq[q];
+    const bool fl = !is_mask(tile[c0]);
+    float v = svq[q];
+    int e = c0;                     // cell of the forward position: the cell itself where nothing is advected (tfluids.cc:159-163)
+    bool slow = false;
+    if (fl) {
+      slow = true;
+      if (deep) {
+        if (TFL_SCAL3_ABL & 8) { v = tile[c0] + u.x; slow = false; }
+        else {
+          v3 p;
+          const bool ok = trace_fast<FAST>(tile, T::LX, T::LP, cbias, ctr, u, -a.dt, p, e);
+          const float r = lerp_tile<FAST>(tile, T::LX, T::LP, cbias, ok ? p : ctr);
+          if (ok && !is_mask(r)) { v = r; slow = false; }
+        }
+      }
     }
-  }
-  float lo = __builtin_inff(), hi = -__builtin_inff();
-  if (BOUNDS && !slow) {
-    const float* q = tile + (e - 1 - T::LX - T::LP);
-    float t[27];
+    float lo = __builtin_inff(), hi = -__builtin_inff();
+    if (BOUNDS && !slow && (TFL_SCAL3_ABL & 2)) { lo = tile[e]; hi = lo; }
+    if (BOUNDS && !slow && !(TFL_SCAL3_ABL & 2)) {
+      const float* qq = tile + (e - 1 - T::LX - T::LP);
+      float t[27];
 #pragma unroll
-    for (int n = 0; n < 27; n++) t[n] = q[(n / 9) * T::LP + ((n / 3) % 3) * T::LX + (n % 3)];
+      for (int n = 0; n < 27; n++) t[n] = qq[(n / 9) * T::LP + ((n / 3) % 3) * T::LX + (n % 3)];
 #pragma unroll
-    for (int n = 0; n < 26; n += 2) { lo = min3r(lo, t[n], t[n + 1]); hi = max3r(hi, t[n], t[n + 1]); }
-    lo = min3r(lo, t[26], t[26]); hi = max3r(hi, t[26], t[26]);
+      for (int n = 0; n < 26; n += 2) { lo = min3r(lo, t[n], t[n + 1]); hi = max3r(hi, t[n], t[n + 1]); }
+      lo = min3r(lo, t[26], t[26]); hi = max3r(hi, t[26], t[26]);
+    }
+    if (slow) {   // rare lanes: the generic trace + fluid-aware sampler on global memory
+      v3 back;
+      v = sl_euler_ours<true>(a, flags, U, s, a.dt, i, j, k, back);
+      if (BOUNDS) clamp_bounds_global(d, s, flags, back, lo, hi);
+    }
+    if ((TFL_SCAL3_ABL & 4) && a.dt != 12345.0f) continue;
+    stg(out, o4, v);
+    if (BOUNDS) { stg(bounds, o4, lo); stg(bounds, o4 + sc4, hi); }
   }
-  if (slow) {   // rare lanes: the generic trace + fluid-aware sampler on global memory
-    v3 back;
-    v = sl_euler_ours<true>(a, flags, U, s, a.dt, i, j, k, back);
-    if (BOUNDS) clamp_bounds_global(d, s, flags, back, lo, hi);
-  }
-  stg(out, o4, v);
-  if (BOUNDS) { bounds += b * cells * 3; stg(bounds, o4, lo); stg(bounds, o4 + sc4, hi); }
 }
 
 // ---- pass B: backward trace on fwd + MacCormackCorrect + MacCormackClampOurs ---------------------------------------------
-template <int TZ, bool FAST>
+template <int TZ, int KZ, bool FAST>
 __global__ __launch_bounds__(256 * TZ) void k_scal3_bwd(AdvArgs a, double half_strength, const float* __restrict__ s,
                                                         const float* __restrict__ U, const float* __restrict__ flags,
                                                         const float* __restrict__ fwd, const float* __restrict__ bounds,
                                                         float* __restrict__ dst) {
-  TFL_SCAL3_PROLOGUE(1, (fwd + b * cells));
+  TFL_SCAL3_BLOCK(1, (fwd + b * cells));
   fwd += b * cells; dst += b * cells; bounds += b * cells * 3;
-  const float sv = ldg(s, o4), f = ldg(fwd, o4);
-  const float blo = ldg(bounds, o4), bhi = ldg(bounds, o4 + sc4);
-  v3 u = mk3(0.0f, 0.0f, 0.0f);
-  if (deep) u = centred(d, U, o4);
-  __syncthreads();
-  if (!live) return;
-  // fluid cell <=> its word of the masked tile is not the mask word (a border cell of the array is never `deep`, and its
-  // flags are read directly: the correction below has no border test)
-  const bool fl = border ? ((((int)ldg(flags, o4)) & kFluid) != 0) : !is_mask(tile[c0]);
-  float bwd = border ? 0.0f : f;
-  if (fl && !border) {
-    bool slow = true;
-    if (deep) {
-      v3 p; int e;
-      const bool ok = trace_fast<FAST>(tile, T::LX, T::LP, cbias, ctr, u, a.dt, p, e);
-      const float r = lerp_tile<FAST>(tile, T::LX, T::LP, cbias, ok ? p : ctr);
-      if (ok && !is_mask(r)) { bwd = r; slow = false; }
-    }
-    if (slow) { v3 back; bwd = sl_euler_ours<true>(a, flags, U, fwd, -a.dt, i, j, k, back); }
+  float svq[KZ], fq[KZ], bloq[KZ], bhiq[KZ];
+  v3 uq[KZ];
+#pragma unroll
+  for (int q = 0; q < KZ; q++) {
+    TFL_SCAL3_CELL(1, q);
+    (void)c0; (void)cbias; (void)ctr;
+    svq[q] = ldg(s, o4); fq[q] = ldg(fwd, o4);
+    bloq[q] = ldg(bounds, o4); bhiq[q] = ldg(bounds, o4 + sc4);
+    uq[q] = mk3(0.0f, 0.0f, 0.0f);
+    if (deep) uq[q] = centred(d, U, o4);
   }
-  // MacCormackCorrect has no border test; the unsuffixed 0.5 makes the reference evaluate the correction in double and
-  // round once (tfluids.cc:231)
-  float v = f;
-  if (fl) v = FAST ? __builtin_fmaf((float)half_strength, sv - bwd, f) : (float)((double)f + half_strength * (double)(sv - bwd));
-  if (!border) v = (blo > bhi) ? f : fclampf(v, blo, bhi);
-  stg(dst, o4, v);
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < KZ; q++) {
+    TFL_SCAL3_CELL(1, q);
+    if (!live) continue;
+    const v3 u = uq[q];
+    const float sv = svq[q], f = fq[q], blo = bloq[q], bhi = bhiq[q];
+    // fluid cell <=> its word of the masked tile is not the mask word (a border cell of the array is never `deep`, and its
+    // flags are read directly: the correction below has no border test)
+    const bool fl = border ? ((((int)ldg(flags, o4)) & kFluid) != 0) : !is_mask(tile[c0]);
+    float bwd = border ? 0.0f : f;
+    if (fl && !border) {
+      bool slow = true;
+      if (deep) {
+        if (TFL_SCAL3_ABL & 8) { bwd = tile[c0] + u.x; slow = false; }
+        else {
+          v3 p; int e;
+          const bool ok = trace_fast<FAST>(tile, T::LX, T::LP, cbias, ctr, u, a.dt, p, e);
+          const float r = lerp_tile<FAST>(tile, T::LX, T::LP, cbias, ok ? p : ctr);
+          if (ok && !is_mask(r)) { bwd = r; slow = false; }
+        }
+      }
+      if (slow) { v3 back; bwd = sl_euler_ours<true>(a, flags, U, fwd, -a.dt, i, j, k, back); }
+    }
+    // MacCormackCorrect has no border test; the unsuffixed 0.5 makes the reference evaluate the correction in double and
+    // round once (tfluids.cc:231)
+    float v = f;
+    if (fl) v = FAST ? __builtin_fmaf((float)half_strength, sv - bwd, f) : (float)((double)f + half_strength * (double)(sv - bwd));
+    if (!border) v = (blo > bhi) ? f : fclampf(v, blo, bhi);
+    if ((TFL_SCAL3_ABL & 4) && a.dt != 12345.0f) continue;
+    stg(dst, o4, v);
+  }
 }
 
-template <int TZ, bool FAST>
-void launch(hipStream_t st, bool two_pass, const AdvArgs& a, int B, const float* s, const float* U, const float* flags,
-            float* fwd, float* bounds, float* dst, int stages) {
+// pass A (or the single-pass method) / pass B with a block of 64 x 4 x TZ threads and KZ planes per thread
+template <int TZ, int KZ, bool FAST>
+void launch_a(hipStream_t st, bool two_pass, const AdvArgs& a, int B, const float* s, const float* U, const float* flags, float* out,
+              float* bounds) {
   const Dom& d = a.d;
-  const int G = (d.n0 + TZ - 1) / TZ + (d.nw - d.n0 + TZ - 1) / TZ;
+  constexpr int PZ = TZ * KZ;
+  const int G = (d.n0 + PZ - 1) / PZ + (d.nw - d.n0 + PZ - 1) / PZ;
   const dim3 blk(TX, TY, TZ), grd((d.X + TX - 1) / TX, (d.Y + TY - 1) / TY, (unsigned)(G * B));
   if (grd.x * grd.y * grd.z == 0) return;
-  const bool pa = stages & 2, pb = stages & 4;
-  if (!two_pass) {
-    if (pa) { TFL_TIMED_EXT("k_scalar_fwd", st); TFL_LAUNCH_EXT((k_scal3_fwd<TZ, false, FAST>), grd, blk, 0, st, a, s, U, flags, dst, (float*)nullptr); }
-    return;
+  TFL_TIMED_EXT("k_scalar_fwd", st);
+  if (two_pass) TFL_LAUNCH_EXT((k_scal3_fwd<TZ, KZ, true, FAST>), grd, blk, 0, st, a, s, U, flags, out, bounds);
+  else TFL_LAUNCH_EXT((k_scal3_fwd<TZ, KZ, false, FAST>), grd, blk, 0, st, a, s, U, flags, out, (float*)nullptr);
+}
+template <int TZ, int KZ, bool FAST>
+void launch_b(hipStream_t st, const AdvArgs& a, int B, const float* s, const float* U, const float* flags, const float* fwd,
+              const float* bounds, float* dst) {
+  const Dom& d = a.d;
+  constexpr int PZ = TZ * KZ;
+  const int G = (d.n0 + PZ - 1) / PZ + (d.nw - d.n0 + PZ - 1) / PZ;
+  const dim3 blk(TX, TY, TZ), grd((d.X + TX - 1) / TX, (d.Y + TY - 1) / TY, (unsigned)(G * B));
+  if (grd.x * grd.y * grd.z == 0) return;
+  TFL_TIMED_EXT("k_scalar_bwd", st);
+  TFL_LAUNCH_EXT((k_scal3_bwd<TZ, KZ, FAST>), grd, blk, 0, st, a, (double)a.strength * 0.5, s, U, flags, fwd, bounds, dst);
+}
+
+template <bool FAST>
+void launch(hipStream_t st, int shape, bool two_pass, const AdvArgs& a, int B, const float* s, const float* U, const float* flags,
+            float* fwd, float* bounds, float* dst, int stages) {
+  const bool pa = stages & 2, pb = two_pass && (stages & 4);
+  float* outA = two_pass ? fwd : dst;
+  // Block shapes (threads in z x planes per thread), measured at 128^3 / 256^3 (profiles/r04_advect_experiments.txt 9):
+  // pass A 2 x 1: 26.3 / 209 us, 1 x 2: 28.3 / 220, 1 x 4: 28.0 / 185, 1 x 1: 29.6 / 244; pass B 2 x 1: 23.5 / 191,
+  // 1 x 2: 22.0 / 153, 1 x 4: 24.5 / 157. Default: pass A 2 x 1 below 6 M cells per item and 1 x 4 above, pass B 1 x 2.
+  const bool big = (long long)a.d.sc >= 6000000ll;
+  const int sa = shape ? shape : (big ? 14 : 2), sb = shape ? shape : 12;
+  if (pa) switch (sa) {
+    case 1:  launch_a<1, 1, FAST>(st, two_pass, a, B, s, U, flags, outA, bounds); break;
+    case 12: launch_a<1, 2, FAST>(st, two_pass, a, B, s, U, flags, outA, bounds); break;
+    case 14: launch_a<1, 4, FAST>(st, two_pass, a, B, s, U, flags, outA, bounds); break;
+    default: launch_a<2, 1, FAST>(st, two_pass, a, B, s, U, flags, outA, bounds); break;
   }
-  if (pa) { TFL_TIMED_EXT("k_scalar_fwd", st); TFL_LAUNCH_EXT((k_scal3_fwd<TZ, true, FAST>), grd, blk, 0, st, a, s, U, flags, fwd, bounds); }
-  if (pb) {
-    TFL_TIMED_EXT("k_scalar_bwd", st);
-    TFL_LAUNCH_EXT((k_scal3_bwd<TZ, FAST>), grd, blk, 0, st, a, (double)a.strength * 0.5, s, U, flags, (const float*)fwd, (const float*)bounds, dst);
+  if (pb) switch (sb) {
+    case 1:  launch_b<1, 1, FAST>(st, a, B, s, U, flags, fwd, bounds, dst); break;
+    case 2:  launch_b<2, 1, FAST>(st, a, B, s, U, flags, fwd, bounds, dst); break;
+    case 14: launch_b<1, 4, FAST>(st, a, B, s, U, flags, fwd, bounds, dst); break;
+    default: launch_b<1, 2, FAST>(st, a, B, s, U, flags, fwd, bounds, dst); break;
   }
 }
 
@@ -360,19 +445,12 @@ void launch(hipStream_t st, bool two_pass, const AdvArgs& a, int B, const float*
 bool advect_scalar3(hipStream_t st, bool two_pass, const AdvArgs& a, int B, const float* s, const float* U, const float* flags,
                     float* fwd, float* bounds, float* dst, int stages) {
   static const bool off = getenv("TFL_ADVECT_GATHER") != nullptr || getenv("TFL_SCALAR_GATHER") != nullptr;   // A/B switch: the round-2 gather kernels
-  static const int tzsel = getenv("TFL_SCAL3_TZ") ? atoi(getenv("TFL_SCAL3_TZ")) : 2;
+  static const int tzsel = getenv("TFL_SCAL3_TZ") ? atoi(getenv("TFL_SCAL3_TZ")) : 0;   // 0 = per pass and grid size (launch)
   const Dom& d = a.d;
   // 24-bit multiplies address the tile and the planes; 32-bit BYTE offsets the cells of the three velocity channels
   if (off || a.outside || d.Z < 3 || (long long)d.X * d.Y * 4 >= (1 << 24) || 12ll * d.sc >= (1ll << 32)) return false;
-  if (a.fast) {
-    if (tzsel == 1) launch<1, true>(st, two_pass, a, B, s, U, flags, fwd, bounds, dst, stages);
-    else if (tzsel == 4) launch<4, true>(st, two_pass, a, B, s, U, flags, fwd, bounds, dst, stages);
-    else launch<2, true>(st, two_pass, a, B, s, U, flags, fwd, bounds, dst, stages);
-  } else {
-    if (tzsel == 1) launch<1, false>(st, two_pass, a, B, s, U, flags, fwd, bounds, dst, stages);
-    else if (tzsel == 4) launch<4, false>(st, two_pass, a, B, s, U, flags, fwd, bounds, dst, stages);
-    else launch<2, false>(st, two_pass, a, B, s, U, flags, fwd, bounds, dst, stages);
-  }
+  if (a.fast) launch<true>(st, tzsel, two_pass, a, B, s, U, flags, fwd, bounds, dst, stages);
+  else launch<false>(st, tzsel, two_pass, a, B, s, U, flags, fwd, bounds, dst, stages);
   return true;
 }
 
