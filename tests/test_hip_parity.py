@@ -461,3 +461,44 @@ def test_fused_vorticity_confinement_equals_the_two_launch_form(oracle, dims, se
         oracle.vorticityConfinement(ref, sc["flags"], 0.7)
         assert np.array_equal(got.cpu().numpy(), ref), d
         assert torch.equal(U, torch.from_numpy(sc["U"]).to(dev))          # the source is left alone
+
+
+def test_round4_abi_additions(hip):
+    """tfl_set_advect_mode / tfl_get_advect_mode, tfl_stream_copy and the tfl_comm size check (ABI 3): argument errors
+    come back as codes, the copy copies, and a slab step refuses a transport struct that does not declare its size."""
+    import ctypes
+    import torch
+    from fluidnet_amd import _lib, tfluids, TfluidsError
+    dev = hip.dev
+    lib, ctx = tfluids._context(torch.zeros(1, device=dev))
+    assert lib.tfl_abi_version() == 3
+    assert lib.tfl_get_advect_mode(ctx) == 0
+    assert lib.tfl_set_advect_mode(ctx, 7) != 0 and b"unknown mode" in lib.tfl_last_error(ctx)
+    assert lib.tfl_set_advect_mode(ctx, 1) == 0 and lib.tfl_get_advect_mode(ctx) == 1
+    assert lib.tfl_set_advect_mode(ctx, 0) == 0 and lib.tfl_get_advect_mode(ctx) == 0
+    with pytest.raises(TfluidsError):
+        tfluids.set_advect_mode(torch.zeros(1, device=dev), "quick")
+    # stream copy: 16-byte aligned, a multiple of four floats
+    a = torch.randn(1 << 16, device=dev)
+    b = torch.zeros_like(a)
+    assert lib.tfl_stream_copy(ctx, ctypes.c_void_p(b.data_ptr()), ctypes.c_void_p(a.data_ptr()), a.numel()) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
+    assert lib.tfl_stream_copy(ctx, ctypes.c_void_p(b.data_ptr()), ctypes.c_void_p(a.data_ptr()), 6) != 0
+    assert lib.tfl_stream_copy(ctx, ctypes.c_void_p(b.data_ptr() + 4), ctypes.c_void_p(a.data_ptr()), 8) != 0
+    # vorticityConfinementFrom refuses an aliased destination
+    U = torch.zeros(1, 3, 6, 8, 8, device=dev)
+    with pytest.raises(TfluidsError):
+        tfluids.vorticityConfinement(U, torch.ones(1, 1, 6, 8, 8, device=dev), 0.5, USrc=U)
+    # a transport struct without its size is refused by the slab step instead of being read past its end
+    import bench
+    from fluidnet_amd import FluidNetModel
+    from fluidnet_amd.dist import SlabLayout, SlabSimulation, ThreadComm
+    lay = SlabLayout(16, 2, 0)
+    batch, mconf = bench.build_scene(16, 16, lay, dev)
+    comm = ThreadComm(ThreadComm.Hub(2), 0)
+    comm.struct.size = 0
+    sim = SlabSimulation(batch, mconf, FluidNetModel.default_3d(seed=1), lay, comm)
+    with pytest.raises(TfluidsError, match="size"):
+        sim.step()
+    sim.close()
