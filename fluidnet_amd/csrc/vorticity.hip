@@ -9,6 +9,7 @@
 //            evaluated in registers and face-averaged; no force grid is stored)
 // Algorithmic bytes per cell (3-D): A 7 words + B 11 words = 72 B. HBM-bound.
 #include "tfl_device.hpp"
+#include "tfl_fastmath.hpp"
 #include "tfl_host.hpp"
 #include "tfl_vec4.hpp"
 
@@ -297,6 +298,26 @@ constexpr int FEX = FBX + 1, FEY = FBY + 1;                       // force excha
 constexpr int kFusedLds = (4 * 3 * FUN + 3 * FCN + 2 * 3 * FCN + 2 * FEY * FEX) * 4;   // 78 252 bytes: two blocks per CU
 }  // namespace
 
+// vec3::norm / normalize (generic/vec3.h:119-141) with the same thresholds and the same correctly rounded root and quotients
+// as norm3 / normalize3 at a third of their instructions: sqrt_exact and ONE refined reciprocal for the three quotients
+// (tfl_fastmath.hpp: the root checked exhaustively on [2^-40, 2^40), the quotient on a sample; the numerators are components
+// of the vector whose norm divides them). Outside that range of the squared length, or for a NaN, the library forms.
+__device__ __forceinline__ float norm3_x(v3 a) {
+  const float l2 = a.x * a.x + a.y * a.y + a.z * a.z;
+  if (!(l2 < 0x1p40f)) return norm3(a);
+  return (l2 > 1e-6f) ? sqrt_exact(l2) : 0.0f;
+}
+__device__ __forceinline__ v3 normalize3_x(v3 a) {
+  const float l2 = a.x * a.x + a.y * a.y + a.z * a.z;
+  if (!(l2 < 0x1p40f)) return normalize3(a);
+  const float n = (l2 > 1e-6f) ? sqrt_exact(l2) : 0.0f;
+  if (n > 1e-6f) {
+    const float r = rcp_refined(n);
+    return mk3(div_by<1>(a.x, n, r), div_by<1>(a.y, n, r), div_by<1>(a.z, n, r));
+  }
+  return mk3(0.0f, 0.0f, 0.0f);
+}
+
 __global__ __launch_bounds__(512) void k_vort_fused(Dom d, int cols_x, int cols_y, int cz, int chunks_a, int chunks, int n_blocks,
                                                     const float* __restrict__ Uin, float* __restrict__ Uout,
                                                     const float* __restrict__ flags, float strength) {
@@ -320,25 +341,9 @@ __global__ __launch_bounds__(512) void k_vort_fused(Dom d, int cols_x, int cols_
   Uin += b * cells * 3; Uout += b * cells * 3; flags += b * cells;
   const int tid = threadIdx.x, tx = tid & 63, ty = tid >> 6;
   const int i = x0 + tx, j = y0 + ty;
-  auto mod3 = [](int z) { return (z + 6) % 3; };
 
-  // confinement force of the cell at curl-tile position (cx, cy) of plane zf (0 on the border shell), tfluids.cc:1410-1436
-  auto force = [&](int cx, int cy, int zf) -> v3 {
-    const int gx = x0 - 2 + cx, gy = y0 - 2 + cy;
-    if (gx >= d.X || gy >= d.Y || zf < 0 || zf >= d.Z || on_border<true>(d, gx, gy, zf)) return mk3(0.0f, 0.0f, 0.0f);
-    const int it = cy * FCX + cx;
-    const float* c0 = Cn + mod3(zf) * FCN + it;
-    v3 g = mk3(0.5f * (c0[1] - c0[-1]), 0.5f * (c0[FCX] - c0[-FCX]),
-               0.5f * (Cn[mod3(zf + 1) * FCN + it] - Cn[mod3(zf - 1) * FCN + it]));
-    g = normalize3(g);
-    const float* cv = Cv + (zf & 1) * 3 * FCN + it;
-    const v3 w = mk3(cv[0], cv[FCN], cv[2 * FCN]);
-    return mk3(((g.y * w.z) - (g.z * w.y)) * strength, ((g.z * w.x) - (g.x * w.z)) * strength,
-               ((g.x * w.y) - (g.y * w.x)) * strength);
-  };
-
-  // the thread's one or two cells of a staged U plane: loaded one step ahead into registers (their latency hides behind the
-  // step's curl / force work), written to the ring at the top of the next step
+  // ---- per-thread geometry, fixed for the whole march --------------------------------------------------------------------
+  // staging: the thread's one or two cells of a U plane (clamped: cells outside the array are never used, the border shell is 0)
   int st_o[2];
 #pragma unroll
   for (int r = 0; r < 2; r++) {
@@ -346,13 +351,48 @@ __global__ __launch_bounds__(512) void k_vort_fused(Dom d, int cols_x, int cols_
     const int uy = it / FUX, ux = it - uy * FUX;
     st_o[r] = TFL_AT(d, min(max(x0 - 3 + ux, 0), d.X - 1), min(max(y0 - 3 + uy, 0), d.Y - 1), 0);
   }
-  float nu[2][3];
-  auto load_plane = [&](int t) {      // clamped addresses: cells outside the array are never used, the border shell counts as 0
-    const int gz = min(max(t, 0), d.Z - 1);
+  // curl: the thread's one or two cells of the 67 x 11 curl tile; bits: 1 = in the grid and not on the x / y border shell,
+  // 2 / 4 = its +x / -x neighbour is on the shell, 8 / 16 = +y / -y
+  int c_it[2], c_base[2], c_bits[2];
+#pragma unroll
+  for (int r = 0; r < 2; r++) {
+    const int it = min(tid + 512 * r, FCN - 1);
+    const int cy = it / FCX, cx = it - cy * FCX;
+    const int gx = x0 - 2 + cx, gy = y0 - 2 + cy;
+    c_it[r] = it;
+    c_base[r] = (cy + 1) * FUX + (cx + 1);
+    const bool in = tid + 512 * r < FCN && gx >= 1 && gx <= d.X - 2 && gy >= 1 && gy <= d.Y - 2;
+    c_bits[r] = (in ? 1 : 0) | (gx + 1 == d.X - 1 ? 2 : 0) | (gx - 1 == 0 ? 4 : 0) | (gy + 1 == d.Y - 1 ? 8 : 0) | (gy - 1 == 0 ? 16 : 0);
+  }
+  // force: the thread's own cell, and (waves 0 and 1 only) one cell of the column / row before the block
+  const int f_it = (ty + 2) * FCX + tx + 2;
+  const bool f_in = i >= 1 && i <= d.X - 2 && j >= 1 && j <= d.Y - 2;
+  const bool e_col = tid < FBY, e_row = tid >= 64 && tid < 64 + FBX;
+  const int e_cx = e_col ? 1 : (tid - 64) + 2, e_cy = e_col ? tid + 2 : 1;
+  const int e_it = e_cy * FCX + e_cx;
+  const int e_gx = x0 - 2 + e_cx, e_gy = y0 - 2 + e_cy;
+  const bool e_in = (e_col || e_row) && e_gx >= 1 && e_gx <= d.X - 2 && e_gy >= 1 && e_gy <= d.Y - 2;
+  const int e_dst = e_col ? (tid + 1) * FEX : FEY * FEX + (tid - 64) + 1;
+  const bool out_xy = i < d.X && j < d.Y;
+  const int o_xy = TFL_AT(d, min(i, d.X - 1), min(j, d.Y - 1), 0);
+
+  // confinement force of the cell `it` of the curl tile in plane zf (tfluids.cc:1410-1436); n0 / np / nm: ring slots of |curl|
+  auto force = [&](int it, const float* cn0, const float* cnp, const float* cnm, const float* cv) -> v3 {
+    const float* c0 = cn0 + it;
+    v3 g = mk3(0.5f * (c0[1] - c0[-1]), 0.5f * (c0[FCX] - c0[-FCX]), 0.5f * (cnp[it] - cnm[it]));
+    g = normalize3_x(g);
+    const v3 w = mk3(cv[it], cv[FCN + it], cv[2 * FCN + it]);
+    return mk3(((g.y * w.z) - (g.z * w.y)) * strength, ((g.z * w.x) - (g.x * w.z)) * strength,
+               ((g.x * w.y) - (g.y * w.x)) * strength);
+  };
+
+  float nu[2][3];                     // the U plane loaded one step ahead
+  auto load_plane = [&](int t) {
+    const int gz = min(max(t, 0), d.Z - 1) * d.sz;
 #pragma unroll
     for (int r = 0; r < 2; r++) {
       if (r == 1 && tid >= FUN - 512) continue;
-      const int o = st_o[r] + gz * d.sz;
+      const int o = st_o[r] + gz;
       nu[r][0] = Uin[o]; nu[r][1] = Uin[o + d.sc]; nu[r][2] = Uin[o + 2 * d.sc];
     }
   };
@@ -361,78 +401,86 @@ __global__ __launch_bounds__(512) void k_vort_fused(Dom d, int cols_x, int cols_
 #pragma unroll 1
   for (int t = za - 3; t <= zb + 2; t++) {
     // ---- U plane t (in registers since the previous step) -> ring ----
-#pragma unroll
-    for (int r = 0; r < 2; r++) {
-      if (r == 1 && tid >= FUN - 512) continue;
-      float* dst = Ut + (t & 3) * 3 * FUN + tid + 512 * r;
-      dst[0] = nu[r][0]; dst[FUN] = nu[r][1]; dst[2 * FUN] = nu[r][2];
+    {
+      float* dst = Ut + (t & 3) * 3 * FUN + tid;
+      dst[0] = nu[0][0]; dst[FUN] = nu[0][1]; dst[2 * FUN] = nu[0][2];
+      if (tid < FUN - 512) { dst[512] = nu[1][0]; dst[FUN + 512] = nu[1][1]; dst[2 * FUN + 512] = nu[1][2]; }
     }
     __syncthreads();
     load_plane(t + 1);
-    // the inputs of the plane this step finishes (zf = t - 3), also asked for now
+    // the inputs of the plane this step finishes (zo = t - 3), also asked for now
     const int zo = t - 3;
-    const bool out_live = zo >= za && zo < zb && i < d.X && j < d.Y;
-    const bool out_inner = out_live && !on_border<true>(d, i, j, zo);
+    const bool out_live = out_xy && zo >= za && zo < zb;
+    const bool out_inner = out_live && f_in && zo >= 1 && zo <= d.Z - 2;
     float pu0 = 0.0f, pu1 = 0.0f, pu2 = 0.0f, pfc = 0.0f, pnx = 0.0f, pny = 0.0f, pnz = 0.0f;
     if (out_live) {
-      const int o = TFL_AT(d, i, j, zo);
+      const int o = o_xy + zo * d.sz;
       pu0 = Uin[o]; pu1 = Uin[o + d.sc]; pu2 = Uin[o + 2 * d.sc];
       if (out_inner) { pfc = flags[o]; pnx = flags[o - 1]; pny = flags[o - d.sy]; pnz = flags[o - d.sz]; }
     }
     // ---- curl, |curl| of plane zc = t - 2 (VecGrid::curl, grid.cc:497-515, centred velocities 0 on the border shell) ----
     const int zc = t - 2;
-    if (zc >= za - 2 && zc <= zb) {
+    if (zc >= za - 2 && zc <= zb) {       // block-uniform
+      const bool z_in = zc >= 1 && zc <= d.Z - 2, zpb = zc + 1 == d.Z - 1, zmb = zc - 1 == 0;
+      const float* P0 = Ut + (zc & 3) * 3 * FUN;          // planes zc, zc + 1, zc - 1 of the ring
+      const float* Pp = Ut + ((zc + 1) & 3) * 3 * FUN;
+      const float* Pm = Ut + ((zc - 1) & 3) * 3 * FUN;
+      float* cvw = Cv + (zc & 1) * 3 * FCN;
+      float* cnw = Cn + ((zc + 6) % 3) * FCN;
 #pragma unroll
       for (int r = 0; r < 2; r++) {
-        const int it = tid + 512 * r;
-        if (it < FCN) {
-          const int cy = it / FCX, cx = it - cy * FCX;
-          const int gx = x0 - 2 + cx, gy = y0 - 2 + cy;
-          v3 w = mk3(0.0f, 0.0f, 0.0f);
-          float nrm = 0.0f;
-          if (gx >= 0 && gx < d.X && gy >= 0 && gy < d.Y && zc >= 0 && zc < d.Z && !on_border<true>(d, gx, gy, zc)) {
-            const int base = (cy + 1) * FUX + (cx + 1);
-            auto U = [&](int c, int dz, int off) { return Ut[(((zc + dz) & 3) * 3 + c) * FUN + base + off]; };
-            const bool xpb = gx + 1 == d.X - 1, xmb = gx - 1 == 0, ypb = gy + 1 == d.Y - 1, ymb = gy - 1 == 0,
-                       zpb = zc + 1 == d.Z - 1, zmb = zc - 1 == 0;
-            const float cy_xp = xpb ? 0.0f : 0.5f * (U(1, 0, 1) + U(1, 0, 1 + FUX));
-            const float cy_xm = xmb ? 0.0f : 0.5f * (U(1, 0, -1) + U(1, 0, -1 + FUX));
-            const float cx_yp = ypb ? 0.0f : 0.5f * (U(0, 0, FUX) + U(0, 0, FUX + 1));
-            const float cx_ym = ymb ? 0.0f : 0.5f * (U(0, 0, -FUX) + U(0, 0, -FUX + 1));
-            w.z = 0.5f * ((cy_xp - cy_xm) - (cx_yp - cx_ym));
-            const float cz_yp = ypb ? 0.0f : 0.5f * (U(2, 0, FUX) + U(2, 1, FUX));
-            const float cz_ym = ymb ? 0.0f : 0.5f * (U(2, 0, -FUX) + U(2, 1, -FUX));
-            const float cy_zp = zpb ? 0.0f : 0.5f * (U(1, 1, 0) + U(1, 1, FUX));
-            const float cy_zm = zmb ? 0.0f : 0.5f * (U(1, -1, 0) + U(1, -1, FUX));
-            w.x = 0.5f * ((cz_yp - cz_ym) - (cy_zp - cy_zm));
-            const float cx_zp = zpb ? 0.0f : 0.5f * (U(0, 1, 0) + U(0, 1, 1));
-            const float cx_zm = zmb ? 0.0f : 0.5f * (U(0, -1, 0) + U(0, -1, 1));
-            const float cz_xp = xpb ? 0.0f : 0.5f * (U(2, 0, 1) + U(2, 1, 1));
-            const float cz_xm = xmb ? 0.0f : 0.5f * (U(2, 0, -1) + U(2, 1, -1));
-            w.y = 0.5f * ((cx_zp - cx_zm) - (cz_xp - cz_xm));
-            nrm = norm3(w);
-          }
-          float* cv = Cv + (zc & 1) * 3 * FCN + it;
-          cv[0] = w.x; cv[FCN] = w.y; cv[2 * FCN] = w.z;
-          Cn[mod3(zc) * FCN + it] = nrm;
+        if (r == 1 && tid >= FCN - 512) continue;
+        v3 w = mk3(0.0f, 0.0f, 0.0f);
+        float nrm = 0.0f;
+        if (z_in && (c_bits[r] & 1)) {
+          const bool xpb = c_bits[r] & 2, xmb = c_bits[r] & 4, ypb = c_bits[r] & 8, ymb = c_bits[r] & 16;
+          const float* ux0 = P0 + c_base[r];
+          const float* uy0 = ux0 + FUN;
+          const float* uz0 = ux0 + 2 * FUN;
+          const float* uzp = Pp + c_base[r] + 2 * FUN;
+          const float cy_xp = xpb ? 0.0f : 0.5f * (uy0[1] + uy0[1 + FUX]);
+          const float cy_xm = xmb ? 0.0f : 0.5f * (uy0[-1] + uy0[-1 + FUX]);
+          const float cx_yp = ypb ? 0.0f : 0.5f * (ux0[FUX] + ux0[FUX + 1]);
+          const float cx_ym = ymb ? 0.0f : 0.5f * (ux0[-FUX] + ux0[-FUX + 1]);
+          w.z = 0.5f * ((cy_xp - cy_xm) - (cx_yp - cx_ym));
+          const float cz_yp = ypb ? 0.0f : 0.5f * (uz0[FUX] + uzp[FUX]);
+          const float cz_ym = ymb ? 0.0f : 0.5f * (uz0[-FUX] + uzp[-FUX]);
+          const float cy_zp = zpb ? 0.0f : 0.5f * (Pp[c_base[r] + FUN] + Pp[c_base[r] + FUN + FUX]);
+          const float cy_zm = zmb ? 0.0f : 0.5f * (Pm[c_base[r] + FUN] + Pm[c_base[r] + FUN + FUX]);
+          w.x = 0.5f * ((cz_yp - cz_ym) - (cy_zp - cy_zm));
+          const float cx_zp = zpb ? 0.0f : 0.5f * (Pp[c_base[r]] + Pp[c_base[r] + 1]);
+          const float cx_zm = zmb ? 0.0f : 0.5f * (Pm[c_base[r]] + Pm[c_base[r] + 1]);
+          const float cz_xp = xpb ? 0.0f : 0.5f * (uz0[1] + uzp[1]);
+          const float cz_xm = xmb ? 0.0f : 0.5f * (uz0[-1] + uzp[-1]);
+          w.y = 0.5f * ((cx_zp - cx_zm) - (cz_xp - cz_xm));
+          nrm = norm3_x(w);
         }
+        cvw[c_it[r]] = w.x; cvw[FCN + c_it[r]] = w.y; cvw[2 * FCN + c_it[r]] = w.z;
+        cnw[c_it[r]] = nrm;
       }
     }
     __syncthreads();
     // ---- force of plane zf = t - 3: the thread's own cell, and the cells one column / one row before the block ----------
     const int zf = t - 3;
     v3 f0 = mk3(0.0f, 0.0f, 0.0f);
-    if (zf >= za - 1 && zf <= zb - 1) {
-      f0 = force(tx + 2, ty + 2, zf);
+    if (zf >= za - 1 && zf <= zb - 1) {   // block-uniform
+      const bool z_in = zf >= 1 && zf <= d.Z - 2;
+      const float* cn0 = Cn + ((zf + 6) % 3) * FCN;
+      const float* cnp = Cn + ((zf + 7) % 3) * FCN;
+      const float* cnm = Cn + ((zf + 5) % 3) * FCN;
+      const float* cv = Cv + (zf & 1) * 3 * FCN;
+      if (z_in && f_in) f0 = force(f_it, cn0, cnp, cnm, cv);
       Fe[(ty + 1) * FEX + tx + 1] = f0.x;
       Fe[(FEY + ty + 1) * FEX + tx + 1] = f0.y;
-      if (tid < FBY) Fe[(tid + 1) * FEX] = force(1, tid + 2, zf).x;                            // column x0 - 1
-      else if (tid >= 64 && tid < 64 + FBX) Fe[FEY * FEX + (tid - 64) + 1] = force(tid - 64 + 2, 1, zf).y;   // row y0 - 1
+      if (e_col || e_row) {
+        v3 fe = mk3(0.0f, 0.0f, 0.0f);
+        if (z_in && e_in) fe = force(e_it, cn0, cnp, cnm, cv);
+        Fe[e_dst] = e_col ? fe.x : fe.y;
+      }
     }
     __syncthreads();
     // ---- plane zf out: AddForceField (tfluids.cc:1312-1339); every cell of the plane is written (U_out is another array) ----
     if (out_live) {
-      const int o = TFL_AT(d, i, j, zf);
       float u0 = pu0, u1 = pu1, u2 = pu2;
       if (out_inner) {
         const int fc = (int)pfc;
@@ -447,6 +495,7 @@ __global__ __launch_bounds__(512) void k_vort_fused(Dom d, int cols_x, int cols_
           if (az) u2 += (0.5f * (fz_prev + f0.z));
         }
       }
+      const int o = o_xy + zf * d.sz;
       Uout[o] = u0; Uout[o + d.sc] = u1; Uout[o + 2 * d.sc] = u2;
     }
     fz_prev = f0.z;
