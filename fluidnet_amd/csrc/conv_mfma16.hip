@@ -675,17 +675,17 @@ __global__ __launch_bounds__(256, TFL_M16P_LB) void k_conv3_m16p(Dom d, int cols
     }
     if (!TAIL) {
       uint32_t H[4], L[4];
-      bool over = false;
-#pragma unroll
+      float hmax = 0.0f;              // the largest activation of the lane's eight (cells outside the grid see zero inputs:
+#pragma unroll                        // their activations are ReLU(bias)-sized and cannot fake a range error)
       for (int oy = 0; oy < 4; oy++) {
+        hmax = __builtin_fmaxf(__builtin_fmaxf(hmax, h0[oy]), h1[oy]);
         const float k0 = __builtin_fminf(h0[oy], kHalfMax), k1 = __builtin_fminf(h1[oy], kHalfMax);
-        over = over || ((k0 != h0[oy] || k1 != h1[oy]) && x < d.X && y0 + wy * 4 + oy < d.Y);
         _Float16 hh0, hl0, hh1, hl1;
         split_h(k0, hh0, hl0); split_h(k1, hh1, hl1);
         const h2v ph = {hh0, hh1}, pl = {hl0, hl1};
         H[oy] = __builtin_bit_cast(uint32_t, ph); L[oy] = __builtin_bit_cast(uint32_t, pl);
       }
-      clipped = clipped || over;
+      clipped = clipped || !(hmax <= kHalfMax);
       transpose4(H); transpose4(L);
       if (live) {
         uint4* orow = reinterpret_cast<uint4*>(outv) + (((long long)b * d.Z + z) * d.Y + y) * 2 * d.X + x;
@@ -911,7 +911,7 @@ __global__ __launch_bounds__(256, TFL_M16PI_LB) void k_conv3_m16p_in(Dom d, int 
         const h2v ph = {hh0, hh1}, pl = {hl0, hl1};
         H[oy] = __builtin_bit_cast(uint32_t, ph); L[oy] = __builtin_bit_cast(uint32_t, pl);
       }
-      clipped = clipped || over;
+      clipped = clipped || over;      // (one running maximum instead costs this kernel 13 VGPRs and its fifth wave per SIMD)
       transpose4(H); transpose4(L);
       if (x < d.X && y < d.Y) {
         uint4* orow = reinterpret_cast<uint4*>(outv) + (((long long)b * d.Z + z) * d.Y + y) * 2 * d.X + x;

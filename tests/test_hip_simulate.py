@@ -206,6 +206,24 @@ def test_conv_paths_agree_3d(oracle, monkeypatch):
         assert scenes.rel_l2(pm.cpu().numpy(), p_ref) <= TOL and scenes.rel_l2(Um.cpu().numpy(), U_ref) <= TOL
 
 
+def test_fp16_range_errors_are_counted(oracle):
+    """conv_mfma16.hip clamps activations at the fp16 range and COUNTS the blocks that did (tfl_model_range_errors): a net
+    input far outside it (pressure 1e9 times the velocity scale) must be reported, an ordinary one must not."""
+    import torch
+    from fluidnet_amd import FluidNetModel
+    dev = torch.device("cuda:0")
+    layers = S.default_3d_layers(seed=3)
+    sc = scenes.make_scene((12, 16, 40), seed=77, vel_cells=0.4)
+    tp, tU, tf = (torch.from_numpy(sc[k]).to(dev) for k in ("p", "U", "flags"))
+    m = FluidNetModel(layers, True)
+    m.forward([tp, tU, tf])
+    assert m.range_errors(tp) == 0
+    m.forward([tp * 1e9, tU, tf])
+    assert m.range_errors(tp) > 0
+    m.forward([tp, tU, tf])
+    assert m.range_errors(tp) == 0          # the counter is read-and-reset
+
+
 MODEL_OPTS = [
     dict(inputChannels=dict(pDiv=True, UDiv=True, div=True)),                          # every field feeds the net
     dict(inputChannels=dict(pDiv=False, UDiv=True, div=False), nonlinType="relu6"),
