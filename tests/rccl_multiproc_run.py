@@ -57,9 +57,17 @@ def main(rank, world, rdv):
         loc = {k: (lay.extract(v) if torch.is_tensor(v) else v) for k, v in ref.items()}
         sim = SlabSimulation(loc, mconf, FluidNetModel(layers, True), lay, lambda c: RcclComm(c, uid, rank, world), overlap=overlap)
         model = FluidNetModel(layers, True)
-        for _ in range(3):
+        for n in range(3):
             simulate_native(None, mconf, ref, model)
-            sim.step()
+            try:
+                sim.step()
+            except tfluids.TfluidsError as e:
+                # the communicator is made inside the first step (ncclCommInitRank is collective): an RCCL that cannot
+                # bootstrap in this environment (no usable network interface) is a reason to skip, not a failure of the path
+                if n == 0 and mode == "inplace" and ("ncclCommInitRank" in str(e) or "rccl transport" in str(e)):
+                    print("RCCL_INIT_FAILED: %s" % e)
+                    sys.exit(77)
+                raise
         sim.drain()
         torch.cuda.synchronize()
         for k in ("pDiv", "UDiv", "density"):

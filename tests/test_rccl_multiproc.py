@@ -37,6 +37,8 @@ def test_slab_steps_over_real_rccl(tmp_path, world):
         for p in procs:
             if p.poll() is None:
                 p.kill()
+    if any(p.returncode == 77 for p in procs):
+        pytest.skip("RCCL could not initialise between processes here: " + " | ".join(o.strip().splitlines()[-1] for o in outs if o.strip()))
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and ("rccl multiproc ok rank %d" % r) in o, "rank %d:\n%s" % (r, o[-4000:])
 
