@@ -266,11 +266,12 @@ static void launch_mfma(hipStream_t st, const Dom& d, int B, const float* in, co
   const int n_tiles = tx * ty * tz * B;
   const int grid = ((n_tiles + 7) / 8) * 8;
   const size_t lds_bytes = sizeof(float) * (CIN < 4 ? CIN : 4) * (kTZ + 2) * (kTY + 2) * kLX;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static int attr_dev = -1;                    // the attribute is a per-device setting
+  int cur_dev = 0; (void)hipGetDevice(&cur_dev);
+  if (attr_dev != cur_dev) {
     (void)hipFuncSetAttribute((const void*)k_conv3_mfma<CIN, IN_PLANAR, TAIL>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    attr_set = true;
+    attr_dev = cur_dev;
     if (getenv("TFL_DEBUG")) {
       int nb = -1;
       (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)k_conv3_mfma<CIN, IN_PLANAR, TAIL>, 256,

@@ -939,16 +939,17 @@ static int device_cus() {
 
 // resident blocks per CU of a kernel with `lds` bytes of dynamic LDS (asked once per kernel; `fallback` if the runtime cannot say)
 static int blocks_per_cu(const void* fn, size_t lds, int fallback) {
-  struct Rec { const void* fn; int n; };
-  static Rec recs[16];
+  struct Rec { const void* fn; int dev, n; };  // per kernel AND device: the dynamic-LDS attribute is a per-device setting
+  static Rec recs[64];
   static int nrec = 0;
   static std::mutex mu;                       // virtual ranks launch from several host threads
+  int dev = 0; (void)hipGetDevice(&dev);
   std::lock_guard<std::mutex> lock(mu);
-  for (int i = 0; i < nrec; i++) if (recs[i].fn == fn) return recs[i].n;
+  for (int i = 0; i < nrec; i++) if (recs[i].fn == fn && recs[i].dev == dev) return recs[i].n;
   (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   int n = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, 256, lds) != hipSuccess || n <= 0) n = fallback;
-  if (nrec < 16) { recs[nrec].fn = fn; recs[nrec].n = n; nrec++; }
+  if (nrec < 64) { recs[nrec].fn = fn; recs[nrec].dev = dev; recs[nrec].n = n; nrec++; }
   return n;
 }
 

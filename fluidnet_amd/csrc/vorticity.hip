@@ -13,6 +13,7 @@
 #include "tfl_host.hpp"
 #include "tfl_vec4.hpp"
 
+#include <atomic>
 #include <cstdlib>
 
 namespace tfl {
@@ -518,14 +519,19 @@ bool vorticity_confinement_fused(hipStream_t st, int B, int Z, int Y, int X, con
   const int cxn = (X + FBX - 1) / FBX, cyn = (Y + FBY - 1) / FBY;
   const int na = d.n0, nb = d.nw - d.n0;
   if ((long long)cxn * cyn * (na + nb) * B <= 0) return true;
-  static int slots = 0;
+  // block slots of the current device (the dynamic-LDS attribute is a per-device setting: asked once per device)
+  static std::atomic<int> slots_of[64];
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= 64) dev = 0;
+  int slots = slots_of[dev].load();
   if (!slots) {
     (void)hipFuncSetAttribute((const void*)k_vort_fused, hipFuncAttributeMaxDynamicSharedMemorySize, kFusedLds);
-    int cus = 256, dev = 0, per = 0;
-    (void)hipGetDevice(&dev);
+    int cus = 256, per = 0;
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, (const void*)k_vort_fused, 512, kFusedLds) != hipSuccess || per <= 0) per = 2;
     slots = cus * per;
+    slots_of[dev].store(slots);
   }
   // chunk length: rounds of resident blocks x (planes written + 6 planes of pipeline fill)
   int cz = 4;
