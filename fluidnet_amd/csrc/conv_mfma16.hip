@@ -953,6 +953,30 @@ static int blocks_per_cu(const void* fn, size_t lds, int fallback) {
   return n;
 }
 
+// Chunk length of the K-packed z-marched kernels (planes a block walks). A block of c output planes takes c + 4 plane steps
+// (two halo planes, ~two of weight fetch and pipeline fill); the blocks of a launch occupy the chip in rounds of `slots`
+// (= CUs x resident blocks per CU), and a plane step of a CU that holds n blocks costs L + W n: the n blocks hide each
+// other's latencies only in part. Fitted on tools/conv_cz_sweep.py (profiles/r04_conv_cz_sweep.txt; 128^2 and 256^2
+// columns, 24 .. 136 planes, chunks of 2 .. 64): 8 -> 8 layers L = 0.70, W = 0.35 us, first layer 0.95 / 0.24. On a full
+// 128^3 / 256^3 grid the choice is the one the round counting of launch_m16z makes (11 / 8 planes at 128^3); on the thin
+// windows of a z-slab rank it picks short chunks (24 planes of 128^2: 3 instead of 8, -4 us per layer).
+static int pick_chunk(long long cols, int na, int nb, int slots, int cus, float L, float W) {
+  int cz = 8;
+  float best = -1.0f;
+  for (int c = 2; c <= 32; c++) {
+    long long blocks = cols * ((na + c - 1) / c + (nb + c - 1) / c);
+    float per_step = 0.0f;
+    while (blocks > 0) {
+      const long long r = blocks < slots ? blocks : slots;
+      per_step += L + W * (float)((r + cus - 1) / cus);
+      blocks -= r;
+    }
+    const float cost = (float)(c + 4) * per_step;
+    if (best < 0.0f || cost < best) { best = cost; cz = c; }
+  }
+  return cz;
+}
+
 template <bool TAIL>
 static void launch_m16z(hipStream_t st, const Dom& d, int B, const void* in, const void* wfrag, const float* bias, void* out,
                         float post, unsigned long long* range_err) {
@@ -1003,16 +1027,7 @@ static void launch_m16p(hipStream_t st, const Dom& d, int B, const void* in, con
   if (cxn * cyn * (na + nb) * B <= 0) return;
   const size_t lds_bytes = (size_t)16 * kPRing * kMPitch;
   const int slots = device_cus() * blocks_per_cu((const void*)k_conv3_m16p<TAIL>, lds_bytes, TFL_M16P_LB);
-  // chunk length: rounds of resident blocks x (planes walked + pipeline fill), as launch_m16z
-  int cz = 8;
-  {
-    long long best = -1;
-    for (int c = 8; c <= 32; c++) {
-      const long long blocks = (long long)cxn * cyn * B * ((na + c - 1) / c + (nb + c - 1) / c);
-      const long long cost = ((blocks + slots - 1) / slots) * (c + 4);
-      if (best < 0 || cost < best) { best = cost; cz = c; }
-    }
-  }
+  int cz = pick_chunk((long long)cxn * cyn * B, na, nb, slots, device_cus(), 0.70f, 0.35f);
   if (const char* e = getenv("TFL_M16_CZ")) cz = atoi(e) > 0 ? atoi(e) : cz;
   const int chunks_a = (na + cz - 1) / cz, chunks = chunks_a + (nb + cz - 1) / cz;
   const int n_blocks = cxn * cyn * chunks * B;
@@ -1038,15 +1053,7 @@ static void launch_m16p_in(hipStream_t st, const Dom& d, int B, MIn cin, const v
   const int na = d.n0, nb = d.nw - d.n0;
   if (cxn * cyn * (na + nb) * B <= 0) return;
   const int slots = device_cus() * blocks_per_cu((const void*)k_conv3_m16p_in, 0, TFL_M16PI_LB);
-  int cz = 8;
-  {
-    long long best = -1;
-    for (int c = 8; c <= 32; c++) {
-      const long long blocks = (long long)cxn * cyn * B * ((na + c - 1) / c + (nb + c - 1) / c);
-      const long long cost = ((blocks + slots - 1) / slots) * (c + 4);
-      if (best < 0 || cost < best) { best = cost; cz = c; }
-    }
-  }
+  int cz = pick_chunk((long long)cxn * cyn * B, na, nb, slots, device_cus(), 0.95f, 0.24f);
   if (const char* e = getenv("TFL_M16_CZ_IN")) cz = atoi(e) > 0 ? atoi(e) : cz;
   const int chunks_a = (na + cz - 1) / cz, chunks = chunks_a + (nb + cz - 1) / cz;
   const int n_blocks = cxn * cyn * chunks * B;

@@ -51,13 +51,23 @@ for rank in (0, world // 2):
         # slow paths there, which is an artefact of the null transport, not of the step.
         mconf = dict(mconf, dt=0.0)
     sim = SlabSimulation(batch, mconf, model, lay, NullComm("--packed" not in sys.argv), check_reach=False)
-    for _ in range(5):
+    # --still also zeroes p before every step: with the null transport the net would otherwise iterate on its own output
+    # (stale p halos), leave the fp16 range within a few steps, and every block of the first conv layer would report a
+    # range error through one atomic counter -- 20 us of serialised atomics that no real run has
+    still = "--still" in sys.argv
+
+    def one_step():
+        if still:
+            batch["pDiv"].zero_()
         sim.step()
+
+    for _ in range(5):
+        one_step()
     torch.cuda.synchronize()
     for n in (50,):
         t0 = time.time()
         for _ in range(n):
-            sim.step()
+            one_step()
         t_host = (time.time() - t0) / n
         torch.cuda.synchronize()
         t_all = (time.time() - t0) / n
@@ -67,7 +77,8 @@ for rank in (0, world // 2):
         from fluidnet_amd import tfluids
         with tfluids.profile(batch["UDiv"]) as prof:
             for _ in range(10):
-                sim.step()
+                one_step()
+        print("   fp16 range errors reported by the conv stack: %d" % model.range_errors(batch["pDiv"]))
         tot, cnt = 0.0, 0
         for name, rec in sorted(prof.kernels.items(), key=lambda kv: -kv[1]["ms"]):
             print("   %-26s %5.1f launches/step  %7.1f us/step  (%.1f us each)" % (name, rec["calls"] / 10, rec["ms"] * 100, rec["ms"] / rec["calls"] * 1e3))
