@@ -44,6 +44,21 @@ def _jacobi_lib():
     return _JACOBI
 
 
+_PCG = None
+
+
+def pcg_available():
+    return os.path.exists(os.path.join(_HERE, "_ref", "libtfluids_ref_pcg.so"))
+
+
+def _pcg_lib():
+    global _PCG
+    if _PCG is None:
+        _PCG = ctypes.CDLL(os.path.join(_HERE, "_ref", "libtfluids_ref_pcg.so"))
+        _PCG.tfluids_ref_pcg.restype = ctypes.c_int
+    return _PCG
+
+
 def _path(fast):
     return os.path.join(_HERE, "_ref", "libtfluids_ref_fast.so" if fast else "libtfluids_ref.so")
 
@@ -208,6 +223,25 @@ class RefTfluids:
         vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
         rc = lib.tfluids_ref_jacobi(vp(p), vp(flags), vp(div), vp(pPrev), vp(pDelta), vp(norm), b, d, h, w,
                                     int(bool(is3D)), ctypes.c_float(pTol), int(maxIter), ctypes.byref(res), err, 512)
+        if rc != 0:
+            raise RefError(err.value.decode())
+        return float(res.value)
+
+    def solveLinearSystemPCG(self, p, flags, div, is3D, tol=1e-6, maxIter=1000, precondType="ic0", verbose=False):
+        """init.lua:637-691. CUDA + cuSPARSE / cuBLAS only in the reference: runs the reference's own host function
+        (generic/tfluids.cu:864-1759: components, reduced indices, setupLaplacian, the CG loop, the mean subtraction)
+        compiled for the host (oracle/ref_pcg.cc, `make ref_pcg`) over host restatements of the five cuSPARSE / cuBLAS
+        primitives it calls (oracle/ref_shim/cusparse_host.h). Returns the max residual over batches and components."""
+        assert self._dt == 0, "the reference's PCG solver is float only"
+        lib = _pcg_lib()
+        b, d, h, w = self._dims(flags)
+        res = ctypes.c_double(0.0)
+        err = ctypes.create_string_buffer(512)
+        for a in (p, flags, div):
+            assert a.dtype == np.float32 and a.flags["C_CONTIGUOUS"]
+        vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+        rc = lib.tfluids_ref_pcg(vp(p), vp(flags), vp(div), b, d, h, w, int(bool(is3D)), precondType.encode(),
+                                 ctypes.c_float(tol), int(maxIter), int(bool(verbose)), ctypes.byref(res), err, 512)
         if rc != 0:
             raise RefError(err.value.decode())
         return float(res.value)

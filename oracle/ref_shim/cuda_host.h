@@ -46,6 +46,12 @@ template <typename T> struct THCDeviceSubTensor<T, 1> {
   T* p; const long* stride;
   __host__ __device__ T& operator[](long i) const { return p[i * stride[0]]; }
 };
+// a fully indexed 1-D tensor (the PCG copy kernels' pressure_pcg[ind]): reads as a T, assigns through
+template <typename T> struct THCDeviceSubTensor<T, 0> {
+  T* p; const long* stride;
+  __host__ __device__ operator T&() const { return *p; }
+  __host__ __device__ T& operator=(T v) const { *p = v; return *p; }
+};
 template <typename T, int Dim> struct THCDeviceTensor {
   T* data_; long size_[Dim]; long stride_[Dim];
   __host__ __device__ long getSize(int i) const { return size_[i]; }

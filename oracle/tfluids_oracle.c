@@ -10,10 +10,13 @@
  * reference's own sources compiled in this container (oracle/_ref, recipe in oracle/Makefile),
  * against golden vectors generated from that build (tests/golden/, generator
  * tests/golden/make_golden.py) and against the portable known-answer cases of
- * generic/CalcLineTraceTest.m and test_tfluids.lua:675-753. The one exception is
- * ora_solveLinearSystemJacobi: the reference has no CPU Jacobi (generic/tfluids.cc:836-839
- * raises), so that function restates the CUDA kernel generic/tfluids.cu:1765-1921 and is
- * "parity unpinned" beyond analytic properties.
+ * generic/CalcLineTraceTest.m and test_tfluids.lua:675-753. The two solvers exist only as CUDA in
+ * the reference (generic/tfluids.cc:836-839 raises): ora_solveLinearSystemJacobi and
+ * ora_solveLinearSystemPCG restate generic/tfluids.cu:1765-1921 / :864-1759 and are pinned bit for
+ * bit to those very lines compiled for the host (oracle/ref_jacobi.cc, oracle/ref_pcg.cc). For PCG
+ * the five cuSPARSE / cuBLAS primitives the reference calls are not in its tree: their published
+ * algorithms are restated (oracle/ref_shim/cusparse_host.h); cuSPARSE's own summation order is
+ * the one thing left unpinned there.
  *
  * Layout: every field is a contiguous fp32 tensor [B][C][Z][Y][X], x fastest
  * (third_party/grid.h:68-78). MAC component c of cell (i,j,k) lives on the cell's negative
@@ -1128,7 +1131,8 @@ void ora_signedDistanceField(const float* flags, int rad, float* dst, int B, int
 
 /* ------------------------------------------------------------------------------------------
  * solveLinearSystemJacobi -- restates the CUDA path generic/tfluids.cu:1765-1921 (no CPU version
- * exists in the reference: generic/tfluids.cc:836-839). PARITY UNPINNED beyond analytic checks.
+ * exists in the reference: generic/tfluids.cc:836-839). Pinned bit for bit to the reference's kernel + host loop compiled
+ * for the host (oracle/ref_jacobi.cc; tests/test_oracle.py).
  * p_prev is scratch [B][1][Z][Y][X]. Returns the last residual max_b ||p - p_prev||_2.
  * ---------------------------------------------------------------------------------------- */
 float ora_solveLinearSystemJacobi(float* p, const float* flags, const float* div, float* p_prev,
@@ -1192,8 +1196,11 @@ float ora_solveLinearSystemJacobi(float* p, const float* flags, const float* div
  * system indices (:864-906), CSR Laplacian (setupLaplacian :908-1093), then PCG (Golub & Van Loan 10.3.1,
  * :1527-1714) with GENERIC CSR ILU(0) / IC(0) factorisations and triangular solves standing in for
  * cusparseScsrilu0 / cusparseScsric0 / cusparseScsrsv (cuSPARSE and cuBLAS are not in the tree: their
- * published algorithms are restated; summation orders inside them are unknown, so the iteration path is
- * "parity unpinned" and tests compare converged solutions + the properties test_tfluids.lua:836-906 checks).
+ * published algorithms are restated; summation orders inside them are unspecified). PINNED since round 4: bit-equal to the
+ * reference's own host function (:864-1759) compiled for the host by oracle/ref_pcg.cc over oracle/ref_shim/cusparse_host.h
+ * (tests/test_oracle.py::test_pcg_restatement_equals_compiled_reference_host_function); what stays outside any pin is
+ * cuSPARSE's internal summation order, so the device solver is compared on converged solutions (5e-5) + the properties
+ * test_tfluids.lua:836-906 checks.
  * precond: 0 none, 1 ilu0, 2 ic0. Returns 0, -1 (fluid cell on the border / non-fluid in a component), -2 NaN.
  * ---------------------------------------------------------------------------------------- */
 static float clamp_to_eps(float v) {   /* generic/tfluids.cu:1203-1214 */

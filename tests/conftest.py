@@ -53,3 +53,16 @@ def ref():
     if not refmod.available():
         pytest.skip("oracle/_ref/libtfluids_ref.so not built and /root/reference absent")
     return refmod.RefTfluids()
+
+
+@pytest.fixture(scope="session")
+def ref_pcg(ref):
+    """The reference's CUDA-only PCG host function (generic/tfluids.cu:864-1759) compiled for the host over the
+    cuSPARSE / cuBLAS stand-ins of oracle/ref_shim/cusparse_host.h (`make ref_pcg`); skipped like `ref`."""
+    import subprocess
+    from oracle import ref as refmod
+    if not refmod.pcg_available() and os.path.isdir("/root/reference/torch/tfluids"):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "ref_pcg"])
+    if not refmod.pcg_available():
+        pytest.skip("oracle/_ref/libtfluids_ref_pcg.so not built and /root/reference absent")
+    return ref

@@ -337,17 +337,25 @@ def test_vec4_kernels_and_their_fallbacks_match_the_oracle(no_vec4):
                                                   # 3 strips x 5 slabs of the pipelined wavefront sweeps (64 rows x 8 planes each)
                                                   ((36, 134, 22), 10, True, 1, 1e-4)])
 def test_hip_pcg_matches_the_oracle_and_the_reference_properties(hip, oracle, dims, seed, split, B, tol):
-    """The matrix-free device PCG (pcg.hip) against the CSR restatement of the reference's cuSPARSE/cuBLAS solver:
+    """The matrix-free device PCG (pcg.hip) against the reference's own PCG host function compiled for the host
+    (oracle/_ref/libtfluids_ref_pcg.so; cuSPARSE / cuBLAS primitives restated) and its bit-equal C restatement:
     same converged pressure for all three preconditioners, plus what test_tfluids.lua:836-906 asserts (residual
     below 2 tol, no NaN, velocityUpdate leaves no divergence) and the component rules (zero outside the fluid, a
     one-cell component untouched)."""
     # (fp32 CG stalls near 1e-6 |rhs|: the two larger grids get a smaller velocity and a looser tol)
+    from oracle import ref as refmod
     sc, f, U, div = scenes.pcg_problem(oracle, dims, seed, split=split, B=B, vel_cells=2.0 if tol < 5e-5 else 0.3)
     for pc in ("none", "ilu0", "ic0"):
         pa = np.random.RandomState(2).rand(*div.shape).astype(np.float32)
         pb = pa.copy()
         ra = hip.solveLinearSystemPCG(pa, f, div, sc["is3d"], tol, 1000, pc)
         rb = oracle.solveLinearSystemPCG(pb, f, div, sc["is3d"], tol, 1000, pc)
+        if refmod.pcg_available():
+            # the checker proper: the reference's own host function (generic/tfluids.cu:864-1759) compiled for the host
+            # (oracle/ref_pcg.cc); the restatement is bit-equal to it (tests/test_oracle.py), asserted here again
+            pr = np.random.RandomState(2).rand(*div.shape).astype(np.float32)
+            rr = refmod.RefTfluids().solveLinearSystemPCG(pr, f, div, sc["is3d"], tol, 1000, pc)
+            assert np.array_equal(pr, pb) and rr == rb, pc
         assert ra < 2 * tol and rb < 2 * tol and np.isfinite(pa).all(), (pc, ra, rb)
         scale = max(np.abs(pb).max(), 1e-6)
         assert np.abs(pa - pb).max() < max(5e-5 * scale, 50 * tol), (pc, np.abs(pa - pb).max(), scale)

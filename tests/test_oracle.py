@@ -243,6 +243,45 @@ def test_pcg_oracle_rejects_fluid_on_the_border(oracle):
         oracle.solveLinearSystemPCG(np.zeros_like(div), f, div, False, 1e-5, 100, "none")
 
 
+# ---- PCG pinned to the reference's own host function, compiled for the host ----------------------------------------
+@pytest.mark.parametrize("dims,seed,split,B,kw", [((1, 24, 28), 3, False, 1, {}), ((9, 11, 13), 4, False, 2, {}),
+                                                 ((1, 30, 34), 5, True, 1, {}), ((8, 10, 16), 6, True, 2, {}),
+                                                 ((16, 20, 24), 8, True, 1, {}), ((7, 12, 10), 13, False, 2, {"empty_cells": True}),
+                                                 ((1, 18, 22), 14, True, 1, {"empty_cells": True})])
+def test_pcg_restatement_equals_compiled_reference_host_function(oracle, ref_pcg, dims, seed, split, B, kw):
+    """generic/tfluids.cu:864-1759 -- findConnectedFluidComponents, createReducedSystemIndices, setupLaplacian, the CG
+    loop (Golub & Van Loan 10.3.1) with clampToEpsilon, its `while (r2 > tol^2 && iter <= maxIter)` rule, the
+    per-component mean subtraction and the copy kernels -- built by `make ref_pcg` from the file where it lies, over
+    host stand-ins for the five cuSPARSE / cuBLAS primitives it calls (oracle/ref_shim/cusparse_host.h), vs
+    oracle/tfluids_oracle.c: identical pressure and residual, BIT FOR BIT, for all three preconditioners, converged and
+    cut off after a few iterations, with several components, a one-cell component, empty cells and B = 2."""
+    sc, f, U, div = scenes.pcg_problem(oracle, dims, seed, split=split, B=B, **kw)
+    for pc in ("none", "ilu0", "ic0"):
+        for tol, max_iter in ((1e-5, 1000), (1e-12, 0), (1e-12, 1), (1e-12, 6), (1e3, 1000)):
+            pa = np.random.RandomState(1).rand(*div.shape).astype(np.float32)
+            pb = pa.copy()
+            ra = oracle.solveLinearSystemPCG(pa, f, div, sc["is3d"], tol, max_iter, pc)
+            rb = ref_pcg.solveLinearSystemPCG(pb, f, div, sc["is3d"], tol, max_iter, pc)
+            assert np.array_equal(pa, pb), (pc, tol, max_iter, np.abs(pa - pb).max())
+            assert ra == rb, (pc, tol, max_iter, ra, rb)
+    assert np.abs(pb).max() == 0 and np.abs(div).max() < 1e3     # tol above |rhs|: no iteration, p stays zero
+
+
+def test_pcg_compiled_reference_raises_like_the_restatement(oracle, ref_pcg):
+    """a fluid cell on the domain border: setupLaplacian raises (generic/tfluids.cu:1082-1090); an unknown preconditioner
+    name: StringToPrecondType raises (:1216-1228)"""
+    from oracle.oracle import OracleError
+    from oracle.ref import RefError
+    sc, f, U, div = scenes.pcg_problem(oracle, (1, 12, 12), 7)
+    with pytest.raises(RefError):
+        ref_pcg.solveLinearSystemPCG(np.zeros_like(div), f, div, False, 1e-5, 100, "cholesky")
+    f[0, 0, 0, 0, 5] = 1.0
+    with pytest.raises(RefError):
+        ref_pcg.solveLinearSystemPCG(np.zeros_like(div), f, div, False, 1e-5, 100, "none")
+    with pytest.raises(OracleError):
+        oracle.solveLinearSystemPCG(np.zeros_like(div), f, div, False, 1e-5, 100, "none")
+
+
 # ---- training-side operators + resampler (SURVEY.md 8f-4 / 8f-1) -------------------------------------------------
 from backward_cases import CASES as BWD_CASES, run_backward_ops  # noqa: E402
 
