@@ -411,6 +411,63 @@ def test_pcg_triangular_solves_both_schedules(mode):
     assert out.returncode == 0 and "PCG_PATH_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
 
 
+_ADV_VARIANTS = """
+import sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import numpy as np
+import scenes
+from hip_adapter import HipTfluids
+from oracle.oracle import OracleError, OracleTfluids
+hip, ora = HipTfluids(), OracleTfluids()
+rng = np.random.RandomState(%d)
+done = 0
+for dims in ((7, 13, 70), (9, 22, 129), (5, 9, 200), (8, 16, 64), (11, 10, 36), (6, 21, 133), (4, 12, 66), (13, 8, 20)):
+    for rep in range(2):
+        seed = int(rng.randint(1 << 30))
+        kw = dict(B=1 + rep, vel_cells=float(rng.choice([0.3, 1.0, 2.5, 4.0])), stick=bool(rep), empty_cells=bool(rep) and dims[1] >= 10)
+        sc = scenes.make_scene(dims, seed=seed, **kw)
+        f, dt = sc["flags"], sc["dt"]
+        if rep:           # fluid cells whose flag word is not the plain TypeFluid word: the generic path next to fast lanes
+            fl = np.flatnonzero(f == 1.0)
+            pick = rng.choice(fl, size=max(1, fl.size // 50), replace=False)
+            f.reshape(-1)[pick] = rng.choice([9.0, 33.0], size=pick.size)
+        try:
+            for m in ("maccormackOurs", "eulerOurs"):
+                a, b = sc["density"].copy(), sc["density"].copy()
+                hip.advectScalar(dt, a, sc["U"], f, m); ora.advectScalar(dt, b, sc["U"], f, m)
+                assert np.array_equal(a, b), ("advectScalar", m, dims, seed, int((a != b).sum()))
+                a, b = sc["U"].copy(), sc["U"].copy()
+                hip.advectVel(dt, a, f, m); ora.advectVel(dt, b, f, m)
+                assert np.array_equal(a, b), ("advectVel", m, dims, seed, int((a != b).sum()))
+            done += 1
+        except OracleError:
+            pass          # a back-trace ran into one of the reference's THError paths: not a comparable scene
+assert done >= 12, done
+print("ADV_VARIANTS_OK", done)
+"""
+
+
+@pytest.mark.parametrize("env", [{"TFL_VEL3_KZ": "2", "TFL_SCAL3_TZ": "14"}, {"TFL_VEL3_KZ": "2", "TFL_SCAL3_TZ": "12"},
+                                 {"TFL_VEL3_KZ": "1", "TFL_SCAL3_TZ": "1"}, {"TFL_ADVECT_GATHER": "1"}],
+                         ids=["big-grid-defaults", "kz2-scal-1x2", "kz1-scal-1x1", "gather-kernels"])
+def test_advection_kernel_variants_are_bit_exact(env):
+    """The advection kernels pick their block shape from the grid size: from 6 M cells per batch item on (256^3, BASELINE
+    config 5) advectVel runs two planes per block (advect_vel3.inc, kz2) and advectScalar's pass A four planes per thread
+    (advect_scalar3.hip <1, 4>). The golden / oracle tests above run small grids and would never see those kernels, so
+    the variants are FORCED here (TFL_VEL3_KZ, TFL_SCAL3_TZ; read once per process: child processes) onto small ragged
+    grids -- partial 64 x 4 tiles, odd plane counts against the 2- and 4-plane blocks, B = 2, obstacles, stick and empty
+    cells, exotic fluid words -- and held to the oracle bit for bit like the defaults. Also: the round-2 gather kernels
+    (the fallback of grids beyond the 32-bit offset guard), which no default-size test reaches any more either."""
+    import subprocess, sys
+    code = _ADV_VARIANTS % (os.path.dirname(HERE), HERE, 4242)
+    e = dict(os.environ)
+    for k in ("TFL_VEL3_KZ", "TFL_SCAL3_TZ", "TFL_ADVECT_GATHER", "TFL_ADVECT_MODE"):
+        e.pop(k, None)
+    e.update(env)
+    out = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "ADV_VARIANTS_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
 def test_hip_pcg_errors_and_defaults(hip, oracle):
     from fluidnet_amd import TfluidsError
     sc, f, U, div = scenes.pcg_problem(oracle, (1, 12, 12), 7)
