@@ -19,6 +19,14 @@
 #include <algorithm>
 #include <cstdlib>
 
+// minimum waves per SIMD the register allocator has to leave room for (tools/ab_build.sh -DTFL_LB_...=n for A/B runs)
+#ifndef TFL_LB_BCS
+#define TFL_LB_BCS 1
+#endif
+#ifndef TFL_LB_PROJECT
+#define TFL_LB_PROJECT 1
+#endif
+
 namespace tfl {
 
 // setWallBcs decision for the cell's own three face components, third_party/tfluids.cc:926-1002, as a pure
@@ -117,7 +125,7 @@ __global__ __launch_bounds__(256) void k_bcs_div_stats(Dom d, const float* __res
 // loaded for the cell's own mask plus four more rows (the stick test of the +y / +z neighbour looks two rows
 // away); U_bc.x of cell i0+4 comes from the next lane. ~26 vector loads per 4 cells instead of ~120 dword loads.
 template <bool IS3D>
-__global__ __launch_bounds__(256) void k_bcs_div_stats_v4(Dom d, const float* __restrict__ U, const float* __restrict__ flags,
+__global__ __launch_bounds__(256, TFL_LB_BCS) void k_bcs_div_stats_v4(Dom d, const float* __restrict__ U, const float* __restrict__ flags,
                                                           float* __restrict__ Ubc, float* __restrict__ div,
                                                           double* __restrict__ partials) {
   const V4Ctx c = v4_ctx(d);
@@ -378,7 +386,7 @@ __global__ __launch_bounds__(256) void k_project(Dom d, const float* __restrict_
 __device__ __forceinline__ void unpack4(const float4 v, float* o) { o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
 
 template <bool IS3D>
-__global__ __launch_bounds__(256) void k_project_v4(Dom d, const float* __restrict__ pPred, const float* __restrict__ flags,
+__global__ __launch_bounds__(256, TFL_LB_PROJECT) void k_project_v4(Dom d, const float* __restrict__ pPred, const float* __restrict__ flags,
                                                     const double* __restrict__ stats, double count,
                                                     float* __restrict__ Uio, float* __restrict__ pOut, BcArgs bc) {
   const int i0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;

@@ -16,6 +16,14 @@
 #include <atomic>
 #include <cstdlib>
 
+// minimum waves per SIMD the register allocator has to leave room for (tools/ab_build.sh -DTFL_LB_...=n for A/B runs)
+#ifndef TFL_LB_CURL
+#define TFL_LB_CURL 1
+#endif
+#ifndef TFL_LB_CONFINE
+#define TFL_LB_CONFINE 1
+#endif
+
 namespace tfl {
 
 // centred velocity component AXIS of cell n, 0 on the border shell (tfluids.cc:1372-1386 + grid.cc:346-356)
@@ -98,7 +106,7 @@ __global__ __launch_bounds__(256) void k_confine(Dom d, float* __restrict__ U, c
 // k_curl_v4: 16 row loads per 4 cells instead of 24 dword loads per cell. Tap (i+-1, j+-1, k+-1) of a
 // non-border cell is on the border shell iff its moved coordinate is 0 or N-1 -> contributes 0.
 template <bool IS3D>
-__global__ __launch_bounds__(256) void k_curl_v4(Dom d, const float* __restrict__ U, float* __restrict__ curl,
+__global__ __launch_bounds__(256, TFL_LB_CURL) void k_curl_v4(Dom d, const float* __restrict__ U, float* __restrict__ curl,
                                                  float* __restrict__ cnorm) {
   const V4Ctx c = v4_ctx(d);
   const int j = blockIdx.y * blockDim.y + threadIdx.y;
@@ -194,7 +202,7 @@ __device__ __forceinline__ void force_row(const Dom& d, float strength, int i0, 
 // down (z-1) are evaluated in registers from 10 |curl| rows + 7 curl rows; force.x of cell i0-1 comes from the
 // previous lane. U is rewritten in full rows (unchanged cells get their own value back).
 template <bool IS3D>
-__global__ __launch_bounds__(256) void k_confine_v4(Dom d, float* __restrict__ U, const float* __restrict__ flags,
+__global__ __launch_bounds__(256, TFL_LB_CONFINE) void k_confine_v4(Dom d, float* __restrict__ U, const float* __restrict__ flags,
                                                     const float* __restrict__ curl, const float* __restrict__ cn,
                                                     float strength) {
   const V4Ctx c = v4_ctx(d);
