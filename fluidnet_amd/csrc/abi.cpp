@@ -61,6 +61,8 @@ namespace tfl {
 thread_local ZWin g_zwin = {0, 0, 0, 0};
 thread_local ZOrigin g_zorigin = {0, 0};
 thread_local int g_advect_fast = 0;
+thread_local BcFoldArg g_fold = {nullptr, 0u, 0u};
+thread_local bool g_fold_done = false;
 struct ProfRec { const char* name; hipEvent_t e0, e1; };
 struct Profiler { std::vector<ProfRec> recs; };
 static thread_local Profiler* g_prof = nullptr;
@@ -141,9 +143,19 @@ int check_scalar(tfl_ctx* ctx, const char* op, const char* name, const tfl_tenso
 // Operators that honour tfl_set_z_window open one of these before launching: the launchers read the window from the
 // calling thread (tfl_host.hpp make_dom); it is cleared again on the way out so that every other operator -- and every
 // other context used from this thread -- sees the whole array.
+// The same scope carries tfl_simulate_step's setConstVals request (tfl_host.hpp BcFold) to the launchers and the
+// acknowledgement back into the context.
 struct WindowScope {
-  explicit WindowScope(const tfl_ctx* c) { tfl::g_zwin = c->zwin; tfl::g_zorigin = c->zorigin; tfl::g_advect_fast = c->advect_fast; }
-  ~WindowScope() { tfl::g_zwin = tfl::ZWin{0, 0, 0, 0}; tfl::g_zorigin = tfl::ZOrigin{0, 0}; tfl::g_advect_fast = 0; }
+  explicit WindowScope(tfl_ctx* c) : c_(c) {
+    tfl::g_zwin = c->zwin; tfl::g_zorigin = c->zorigin; tfl::g_advect_fast = c->advect_fast;
+    tfl::g_fold = c->fold; tfl::g_fold_done = false;
+  }
+  ~WindowScope() {
+    tfl::g_zwin = tfl::ZWin{0, 0, 0, 0}; tfl::g_zorigin = tfl::ZOrigin{0, 0}; tfl::g_advect_fast = 0;
+    c_->fold_done = c_->fold_done || tfl::g_fold_done;
+    tfl::g_fold = tfl::no_fold(); tfl::g_fold_done = false;
+  }
+  tfl_ctx* c_;
 };
 int stages_of(const tfl_ctx* c) { return c->stages ? c->stages : 0xff; }
 

@@ -343,9 +343,10 @@ template <int TZ, int KZ, bool FAST>
 __global__ __launch_bounds__(256 * TZ) void k_scal3_bwd(AdvArgs a, double half_strength, const float* __restrict__ s,
                                                         const float* __restrict__ U, const float* __restrict__ flags,
                                                         const float* __restrict__ fwd, const float* __restrict__ bounds,
-                                                        float* __restrict__ dst) {
+                                                        float* __restrict__ dst, BcFoldArg folda) {
   TFL_SCAL3_BLOCK(1, (fwd + b * cells));
   fwd += b * cells; dst += b * cells; bounds += b * cells * 3;
+  const bool fold_blk = fold_block(folda, y0, y0 + TY - 1, k0, kend - 1);
   float svq[KZ], fq[KZ], bloq[KZ], bhiq[KZ];
   v3 uq[KZ];
 #pragma unroll
@@ -387,6 +388,11 @@ __global__ __launch_bounds__(256 * TZ) void k_scal3_bwd(AdvArgs a, double half_s
     if (fl) v = FAST ? __builtin_fmaf((float)half_strength, sv - bwd, f) : (float)((double)f + half_strength * (double)(sv - bwd));
     if (!border) v = (blo > bhi) ? f : fclampf(v, blo, bhi);
     if ((TFL_SCAL3_ABL & 4) && a.dt != 12345.0f) continue;
+    // the setConstVals that follows the advection in simulate() (tfl_host.hpp BcFold): rows inside the pair's box only
+    if (fold_blk) {
+      const BcFold fold = *folda.dev;
+      if (fold_row(fold, j, k) && fold_col(fold, i)) v = v * ldg(fold.inv + b * cells, o4) + ldg(fold.bc + b * cells, o4);
+    }
     stg(dst, o4, v);
   }
 }
@@ -406,14 +412,14 @@ void launch_a(hipStream_t st, bool two_pass, const AdvArgs& a, int B, const floa
 }
 template <int TZ, int KZ, bool FAST>
 void launch_b(hipStream_t st, const AdvArgs& a, int B, const float* s, const float* U, const float* flags, const float* fwd,
-              const float* bounds, float* dst) {
+              const float* bounds, float* dst, const BcFoldArg& fold) {
   const Dom& d = a.d;
   constexpr int PZ = TZ * KZ;
   const int G = (d.n0 + PZ - 1) / PZ + (d.nw - d.n0 + PZ - 1) / PZ;
   const dim3 blk(TX, TY, TZ), grd((d.X + TX - 1) / TX, (d.Y + TY - 1) / TY, (unsigned)(G * B));
   if (grd.x * grd.y * grd.z == 0) return;
   TFL_TIMED_EXT("k_scalar_bwd", st);
-  TFL_LAUNCH_EXT((k_scal3_bwd<TZ, KZ, FAST>), grd, blk, 0, st, a, (double)a.strength * 0.5, s, U, flags, fwd, bounds, dst);
+  TFL_LAUNCH_EXT((k_scal3_bwd<TZ, KZ, FAST>), grd, blk, 0, st, a, (double)a.strength * 0.5, s, U, flags, fwd, bounds, dst, fold);
 }
 
 template <bool FAST>
@@ -432,11 +438,12 @@ void launch(hipStream_t st, int shape, bool two_pass, const AdvArgs& a, int B, c
     case 14: launch_a<1, 4, FAST>(st, two_pass, a, B, s, U, flags, outA, bounds); break;
     default: launch_a<2, 1, FAST>(st, two_pass, a, B, s, U, flags, outA, bounds); break;
   }
+  const BcFoldArg fold = pb ? take_fold() : no_fold();   // pass B writes the operator's result
   if (pb) switch (sb) {
-    case 1:  launch_b<1, 1, FAST>(st, a, B, s, U, flags, fwd, bounds, dst); break;
-    case 2:  launch_b<2, 1, FAST>(st, a, B, s, U, flags, fwd, bounds, dst); break;
-    case 14: launch_b<1, 4, FAST>(st, a, B, s, U, flags, fwd, bounds, dst); break;
-    default: launch_b<1, 2, FAST>(st, a, B, s, U, flags, fwd, bounds, dst); break;
+    case 1:  launch_b<1, 1, FAST>(st, a, B, s, U, flags, fwd, bounds, dst, fold); break;
+    case 2:  launch_b<2, 1, FAST>(st, a, B, s, U, flags, fwd, bounds, dst, fold); break;
+    case 14: launch_b<1, 4, FAST>(st, a, B, s, U, flags, fwd, bounds, dst, fold); break;
+    default: launch_b<1, 2, FAST>(st, a, B, s, U, flags, fwd, bounds, dst, fold); break;
   }
 }
 

@@ -175,17 +175,23 @@ __global__ __launch_bounds__(256, TFL_LB_BCS) void k_bcs_div_stats_v4(Dom d, con
   }
   // U_bc.x of cell i0+4: the next lane's first cell, or (segment end) rebuilt from memory
   ubx[4] = from_lane_above(ubx[0]);
-  if (c.last) {
-    float v = 0.0f;
-    if (live && c.has_r) {
-      const int oo = o + 4;
-      const int f = (int)fc[5];
-      bool zx, zy, zz;
-      wall_mask_from<IS3D>(f, (int)fc[4], 0, ym ? (int)flags[oo - d.sy] : 0, yp ? (int)flags[oo + d.sy] : 0,
-                           zm ? (int)flags[oo - d.sz] : 0, zp ? (int)flags[oo + d.sz] : 0, zx, zy, zz);
-      v = zx ? 0.0f : U[oo];
+  {
+    // (loads unconditional, tfl_vec4.hpp v4_load: every lane reads -- the lanes that need nothing, cell 0 of the field)
+    const bool need = c.last && live && c.has_r;
+    const int oo = o + 4;
+    const float gym = flags[need && ym ? oo - d.sy : 0], gyp = flags[need && yp ? oo + d.sy : 0];
+    const float gzm = flags[need && zm ? oo - d.sz : 0], gzp = flags[need && zp ? oo + d.sz : 0];
+    const float gu = U[need ? oo : 0];
+    if (c.last) {
+      float v = 0.0f;
+      if (need) {
+        const int f = (int)fc[5];
+        bool zx, zy, zz;
+        wall_mask_from<IS3D>(f, (int)fc[4], 0, ym ? (int)gym : 0, yp ? (int)gyp : 0, zm ? (int)gzm : 0, zp ? (int)gzp : 0, zx, zy, zz);
+        v = zx ? 0.0f : gu;
+      }
+      ubx[4] = v;
     }
-    ubx[4] = v;
   }
   float dv[4];
   const bool row_inner = live && j >= 1 && j <= d.Y - 2 && (!IS3D || (k >= 1 && k <= d.Z - 2));
@@ -331,7 +337,8 @@ __global__ __launch_bounds__(256) void k_skip_channel(long long cells, const flo
 }
 
 struct BcArgs {  // optional fused tail of simulate(): setConstVals + clamp, simulate.lua:321-326
-  const float* UBC; const float* UInvMask;
+  const float* UBC; const float* UInvMask;   // a dense pair: acts on every cell
+  BcFoldArg fold;                            // or tfl_simulate_step's sparse pair with its box (tfl_host.hpp)
   int enable_clamp; float lo, hi;
 };
 
@@ -372,9 +379,11 @@ __global__ __launch_bounds__(256) void k_project(Dom d, const float* __restrict_
 #pragma unroll
   for (int c = 0; c < C; c++) {
     float v = z[c] ? 0.0f : u[c] * scale;
-    if (bc.UBC) {
-      const long long g = b * cells * C + o + c * d.sc;
-      v = v * bc.UInvMask[g] + bc.UBC[g];
+    const long long g = b * cells * C + o + c * d.sc;
+    if (bc.UBC) v = v * bc.UInvMask[g] + bc.UBC[g];
+    else if (bc.fold.dev) {
+      const BcFold f = *bc.fold.dev;
+      if (fold_row(f, j, k) && fold_col(f, i)) v = v * f.inv[g] + f.bc[g];
     }
     if (bc.enable_clamp) v = fminf(fmaxf(v, bc.lo), bc.hi);
     Uio[o + c * d.sc] = v;
@@ -399,28 +408,43 @@ __global__ __launch_bounds__(256, TFL_LB_PROJECT) void k_project_v4(Dom d, const
   pPred += b * cells; flags += b * cells; pOut += b * cells; Uio += b * cells * C;
   const int o = TFL_AT(d, i0, j, k);
   const float4 z4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-  auto ld4 = [&](const float* p, bool ok) { return ok ? *reinterpret_cast<const float4*>(p) : z4; };
+  // every load is unconditional (tfl_vec4.hpp v4_load: a predicated load costs a drained load queue at its join -- 16 in a
+  // row here before round 4): a lane that must not read takes the thread's own vector / cell instead and drops it
+  auto ld4 = [&](const float* p, int off, bool ok) {
+    const float4 v = *reinterpret_cast<const float4*>(p + (ok ? off : o));
+    return ok ? v : z4;
+  };
   // flags: the row itself (+ one cell either side) and the four neighbouring rows
   float fc[4], fym[4], fyp[4], fzm[4], fzp[4], pc[4], pym[4], pzm[4];
-  unpack4(ld4(flags + o, true), fc);
-  unpack4(ld4(flags + o - d.sy, j > 0), fym);
-  unpack4(ld4(flags + o + d.sy, j < d.Y - 1), fyp);
-  unpack4(ld4(flags + o - d.sz, IS3D && k > 0), fzm);
-  unpack4(ld4(flags + o + d.sz, IS3D && k < d.Z - 1), fzp);
-  const float f_left = i0 > 0 ? flags[o - 1] : 0.0f, f_right = i0 + 4 < d.X ? flags[o + 4] : 0.0f;
-  unpack4(ld4(pPred + o, true), pc);
-  unpack4(ld4(pPred + o - d.sy, j > 0), pym);
-  unpack4(ld4(pPred + o - d.sz, IS3D && k > 0), pzm);
-  const float p_left = i0 > 0 ? pPred[o - 1] : 0.0f;
+  unpack4(ld4(flags, o, true), fc);
+  unpack4(ld4(flags, o - d.sy, j > 0), fym);
+  unpack4(ld4(flags, o + d.sy, j < d.Y - 1), fyp);
+  unpack4(ld4(flags, o - d.sz, IS3D && k > 0), fzm);
+  unpack4(ld4(flags, o + d.sz, IS3D && k < d.Z - 1), fzp);
+  const float f_left_v = flags[i0 > 0 ? o - 1 : o], f_right_v = flags[i0 + 4 < d.X ? o + 4 : o];
+  const float f_left = i0 > 0 ? f_left_v : 0.0f, f_right = i0 + 4 < d.X ? f_right_v : 0.0f;
+  unpack4(ld4(pPred, o, true), pc);
+  unpack4(ld4(pPred, o - d.sy, j > 0), pym);
+  unpack4(ld4(pPred, o - d.sz, IS3D && k > 0), pzm);
+  const float p_left_v = pPred[i0 > 0 ? o - 1 : o];
+  const float p_left = i0 > 0 ? p_left_v : 0.0f;
   float u[3][4];
 #pragma unroll
-  for (int c = 0; c < 3; c++) unpack4(ld4(Uio + o + c * d.sc, c < C), u[c]);
+  for (int c = 0; c < 3; c++) unpack4(ld4(Uio, o + c * d.sc, c < C), u[c]);
   float ubc[3][4], umk[3][4];
-  if (bc.UBC) {
+  bool bc_row = bc.UBC != nullptr;            // does a pair act on this thread's cells, and on which columns
+  const float *pb = bc.UBC, *pm = bc.UInvMask;
+  int bx0 = 0, bx1 = 0x7fffffff;
+  if (!bc_row && fold_block(bc.fold, (int)(blockIdx.y * blockDim.y), (int)(blockIdx.y * blockDim.y + blockDim.y - 1), k, k)) {
+    const BcFold f = *bc.fold.dev;
+    bc_row = fold_row(f, j, k) && i0 <= f.x1 && i0 + 3 >= f.x0;
+    pb = f.bc; pm = f.inv; bx0 = f.x0; bx1 = f.x1;
+  }
+  if (bc_row) {
 #pragma unroll
     for (int c = 0; c < 3; c++) {
-      unpack4(ld4(bc.UBC + b * cells * C + o + c * d.sc, c < C), ubc[c]);
-      unpack4(ld4(bc.UInvMask + b * cells * C + o + c * d.sc, c < C), umk[c]);
+      unpack4(ld4(pb + b * cells * C, o + c * d.sc, c < C), ubc[c]);
+      unpack4(ld4(pm + b * cells * C, o + c * d.sc, c < C), umk[c]);
     }
   }
   float po[4];
@@ -452,7 +476,7 @@ __global__ __launch_bounds__(256, TFL_LB_PROJECT) void k_project_v4(Dom d, const
 #pragma unroll
     for (int c = 0; c < C; c++) {
       float w = z[c] ? 0.0f : v[c] * scale;
-      if (bc.UBC) w = w * umk[c][q] + ubc[c][q];
+      if (bc_row && i >= bx0 && i <= bx1) w = w * umk[c][q] + ubc[c][q];
       if (bc.enable_clamp) w = fminf(fmaxf(w, bc.lo), bc.hi);
       u[c][q] = w;
     }
@@ -600,7 +624,9 @@ void model_project(hipStream_t st, bool is3d, int B, int Z, int Y, int X, const 
                    int do_clamp, float lo, float hi) {
   const Dom d = make_dom(Z, Y, X);
   const dim3 blk(64, 4, 1), grd = TFL_GRID3(d, B);
-  BcArgs bc; bc.UBC = UBC; bc.UInvMask = UInvMask; bc.enable_clamp = do_clamp; bc.lo = lo; bc.hi = hi;
+  // a dense pair acts everywhere; without one, tfl_simulate_step's sparse pair (if it asked: tfl_host.hpp BcFold) in its box
+  BcArgs bc; bc.enable_clamp = do_clamp; bc.lo = lo; bc.hi = hi;
+  bc.UBC = UBC; bc.UInvMask = UInvMask; bc.fold = UBC ? no_fold() : take_fold();
   const uintptr_t al = (uintptr_t)pPred | (uintptr_t)flags | (uintptr_t)Uio | (uintptr_t)pOut | (uintptr_t)UBC |
                        (uintptr_t)UInvMask;
   if (X % 4 == 0 && (al & 15) == 0 && !getenv("TFL_NO_VEC4")) {

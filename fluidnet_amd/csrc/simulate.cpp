@@ -8,6 +8,7 @@
 
 #include <cstddef>
 #include <algorithm>
+#include <vector>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -20,6 +21,9 @@ struct tfl_bc_plan {
   long long n_idx = 0, numel = 0;
   bool sparse = false;     // worth using the list (fewer than a quarter of the elements)
   bool idem = false;       // every listed element has invMask == 0 and |bc| <= 1e6
+  bool boxed = false;      // box[] = the listed elements' bounding box in (x, y, z), inclusive (any batch item / channel)
+  int box[6] = {0, 0, 0, 0, 0, 0};
+  tfl::BcFold* d_fold = nullptr;   // the device descriptor {bc, inv, box} a producing kernel reads (tfl_host.hpp BcFold)
 };
 
 namespace {
@@ -54,7 +58,8 @@ int apply_bcs(tfl_ctx* c, const Todo* todo, int n) {
 // whose pair is idempotent
 struct Unchanged { bool p, U, density; };
 
-int set_const_vals(tfl_ctx* c, const tfl_sim_state* s, const tfl_tensor* U_now, bool with_U, Unchanged un) {
+// density_done: bit i = the pair of density channel i has been applied already (by the kernel that produced the field)
+int set_const_vals(tfl_ctx* c, const tfl_sim_state* s, const tfl_tensor* U_now, bool with_U, Unchanged un, unsigned density_done = 0) {
   Todo todo[10];
   int n = 0;
   auto add = [&](const tfl_tensor* x, const tfl_bc_plan* p, bool unchanged) {
@@ -64,8 +69,25 @@ int set_const_vals(tfl_ctx* c, const tfl_sim_state* s, const tfl_tensor* U_now, 
   };
   add(s->p, s->pBC, un.p);
   if (with_U) add(U_now, s->UBC, un.U);
-  for (int i = 0; i < s->n_density; i++) add(s->density[i], s->densityBC[i], un.density);
+  for (int i = 0; i < s->n_density; i++)
+    if (!((density_done >> i) & 1u)) add(s->density[i], s->densityBC[i], un.density);
   return apply_bcs(c, todo, n);
+}
+
+// Folding a sparse pair into the kernel that produces the field (tfl_host.hpp BcFold): fold_ask before the operator, fold_took
+// after it. TFL_BC_FOLD=0 keeps every pair in its own launch (A/B switch).
+bool fold_ask(tfl_ctx* c, const tfl_bc_plan* p) {
+  static const bool off = getenv("TFL_BC_FOLD") && atoi(getenv("TFL_BC_FOLD")) == 0;
+  c->fold_done = false;
+  if (off || !p || !p->sparse || !p->boxed || !p->d_fold || p->n_idx == 0) { c->fold = tfl::no_fold(); return false; }
+  c->fold = tfl::BcFoldArg{p->d_fold, (unsigned)p->box[2] | ((unsigned)p->box[4] << 16), (unsigned)p->box[3] | ((unsigned)p->box[5] << 16)};
+  return true;
+}
+bool fold_took(tfl_ctx* c) {
+  const bool d = c->fold_done;
+  c->fold = tfl::no_fold();
+  c->fold_done = false;
+  return d;
 }
 
 struct Sizes { long long N, C; int B, Z, Y, X; bool is3d; };
@@ -101,6 +123,23 @@ tfl_bc_plan* tfl_bc_plan_create(tfl_ctx* c, const tfl_tensor* bc, const tfl_tens
     (void)hipMemset(d_cnt, 0, 2 * sizeof(int));
     tfl::bc_scan(nullptr, p->numel, bc->data, invMask->data, d_cnt, p->d_idx);
     (void)hipDeviceSynchronize();
+    // the listed elements' bounding box (one-time, on the host): what lets a producing kernel apply the pair itself
+    std::vector<int> h((size_t)p->n_idx);
+    if (hipMemcpy(h.data(), p->d_idx, sizeof(int) * h.size(), hipMemcpyDeviceToHost) == hipSuccess) {
+      int lo[3] = {bc->X, bc->Y, bc->Z}, hi[3] = {-1, -1, -1};
+      for (int e : h) {
+        const int x = e % bc->X, y = (e / bc->X) % bc->Y, z = (int)((e / ((long long)bc->X * bc->Y)) % bc->Z);
+        lo[0] = std::min(lo[0], x); hi[0] = std::max(hi[0], x);
+        lo[1] = std::min(lo[1], y); hi[1] = std::max(hi[1], y);
+        lo[2] = std::min(lo[2], z); hi[2] = std::max(hi[2], z);
+      }
+      for (int a = 0; a < 3; a++) { p->box[2 * a] = lo[a]; p->box[2 * a + 1] = hi[a]; }
+      p->boxed = true;
+      // the device descriptor (vector loads of the pair need 16-byte aligned tensors)
+      const tfl::BcFold hf = {bc->data, invMask->data, lo[0], hi[0], lo[1], hi[1], lo[2], hi[2]};
+      if ((((uintptr_t)bc->data | (uintptr_t)invMask->data) & 15) == 0 && bc->Y < 65536 && bc->Z < 65536 && hipMalloc((void**)&p->d_fold, sizeof(hf)) == hipSuccess &&
+          hipMemcpy(p->d_fold, &hf, sizeof(hf), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(p->d_fold); p->d_fold = nullptr; }
+    }
   }
   (void)hipFree(d_cnt);
   return p;
@@ -110,6 +149,7 @@ void tfl_bc_plan_destroy(tfl_ctx* c, tfl_bc_plan* p) {
   (void)c;
   if (!p) return;
   if (p->d_idx) (void)hipFree(p->d_idx);
+  if (p->d_fold) (void)hipFree(p->d_fold);
   delete p;
 }
 
@@ -137,17 +177,24 @@ int tfl_simulate_step(tfl_ctx* c, const tfl_sim_params* prm, const tfl_sim_state
   int rc;
 
   // ---- advection (simulate.lua:183-200): every density channel with the pre-advection U, then U ----------------
+  unsigned density_done = 0;
   for (int i = 0; i < s->n_density; i++) {
     tfl_tensor fwd = view(ws, 1), bwd = view(ws + z.N, 1), fwdPos = view(ws + 2 * z.N, (int)z.C),
                bwdPos = view(ws + (2 + z.C) * z.N, (int)z.C), out = view(ws + (2 + 2 * z.C) * z.N, 1);
     const tfl_tensor* dst = ours ? s->density[i] : &out;       // maccormackOurs runs in place (no copy back)
+    // the first setConstVals (below) follows the advection directly: the kernel that writes the advected field applies
+    // the field's pair itself where it can (fold_ask / fold_took; the sparse launch covers the rest)
+    fold_ask(c, s->densityBC[i]);
     rc = tfl_advectScalar(c, prm->dt, s->density[i], s->U, s->flags, &fwd, &bwd, is3D, method, &fwdPos, &bwdPos, 1, 0,
                           prm->maccormackStrength, dst);
+    if (fold_took(c)) density_done |= 1u << i;
     if (rc) return rc;
     if (!ours) { rc = tfl_copy(c, s->density[i], &out); if (rc) return rc; }
   }
   tfl_tensor vfwd = view(ws, (int)z.C), vbwd = view(ws + z.C * z.N, (int)z.C), Uadv = view(ws + 2 * z.C * z.N, (int)z.C);
+  fold_ask(c, s->UBC);
   rc = tfl_advectVel(c, prm->dt, s->U, s->flags, &vfwd, &vbwd, is3D, method, 1, prm->maccormackStrength, &Uadv);
+  const bool Uadv_done = fold_took(c);
   if (rc) return rc;
   // U:copy(advected) (init.lua:216-218) is folded into the first force that writes every cell of its output: addBuoyancy
   // (tfl_addBuoyancyFrom) or, on a 3-D grid, the fused vorticity confinement (tfl_vorticityConfinementFrom, which cannot
@@ -165,20 +212,29 @@ int tfl_simulate_step(tfl_ctx* c, const tfl_sim_params* prm, const tfl_sim_state
     if (rc) return rc;
     cur = s->U;
   }
-  rc = set_const_vals(c, s, cur, true, Unchanged{false, false, false});
+  rc = set_const_vals(c, s, cur, !Uadv_done, Unchanged{false, false, false}, density_done);
   if (rc) return rc;
 
   // ---- forces (simulate.lua:204-239) -------------------------------------------------------------------------
   const double dx = tfl_getDx(c, s->flags);
+  // The setConstVals that follows the forces (below) touches only U (nothing else has been written since the first one):
+  // with the ConvNet projection nothing comes between the last force and it, so the LAST force's kernel applies the U pair
+  // itself where it can (fold_ask / fold_took; the other projections run setWallBcs first, outputDiv skips the call).
+  const bool fold_forces = !prm->outputDiv && method_of(prm) == "convnet";
+  const bool gravity_on = prm->gravityScale > 0.0;
+  bool U_folded = false;
   if (buoyant) {
     const float sc = (float)(-(dx / 4.0) * prm->buoyancyScale);
     const float g[3] = {prm->gravity[0] * sc, prm->gravity[1] * sc, prm->gravity[2] * sc};
     const tfl_tensor* dst = vfused ? &Utmp : s->U;
+    const bool last = fold_forces && !gravity_on && !vort;
+    if (last) fold_ask(c, s->UBC);
     rc = tfl_addBuoyancyFrom(c, cur, dst, s->flags, s->density[0], g, prm->dt, is3D);
+    if (last) U_folded = fold_took(c);
     if (rc) return rc;
     cur = dst;
   }
-  if (prm->gravityScale > 0.0) {
+  if (gravity_on) {
     const float sc = (float)((-dx / 4.0) * prm->gravityScale);
     const float g[3] = {prm->gravity[0] * sc, prm->gravity[1] * sc, prm->gravity[2] * sc};
     rc = tfl_addGravity(c, cur, s->flags, g, prm->dt, is3D, nullptr);
@@ -186,8 +242,10 @@ int tfl_simulate_step(tfl_ctx* c, const tfl_sim_params* prm, const tfl_sim_state
   }
   if (vort) {
     const float strength = (float)(dx * prm->vorticityConfinementAmp);
+    if (fold_forces) fold_ask(c, s->UBC);
     if (vfused) rc = tfl_vorticityConfinementFrom(c, cur, s->U, s->flags, strength, &curl, &cnorm, is3D);
     else rc = tfl_vorticityConfinement(c, s->U, s->flags, strength, &centered, &curl, &cnorm, &force, is3D);
+    if (fold_forces) U_folded = fold_took(c);
     if (rc) return rc;
     cur = s->U;
   }
@@ -200,19 +258,22 @@ int tfl_simulate_step(tfl_ctx* c, const tfl_sim_params* prm, const tfl_sim_state
     if (rc) return rc;
   }
   // only U has been written since the first setConstVals
-  rc = set_const_vals(c, s, s->U, true, Unchanged{true, false, true});
+  rc = set_const_vals(c, s, s->U, !U_folded, Unchanged{true, false, true});
   if (rc) return rc;
   const int max_iter = prm->maxIter > 0 ? prm->maxIter : 100;
   if (sm == "convnet") {
     if (!s->model) return TFL_EINVAL;
     // sparse idempotent U BCs go after the projection by index list instead of as two dense fields inside it
+    // (round 4: the projection kernel applies them itself on the rows inside their box -- fold_ask -- and the launch goes too)
     const bool late_ubc = s->UBC && s->UBC->sparse && s->UBC->idem;
     const tfl_tensor* ubc = (s->UBC && !late_ubc) ? &s->UBC->bc : nullptr;
     const tfl_tensor* umask = (s->UBC && !late_ubc) ? &s->UBC->inv : nullptr;
+    if (late_ubc) fold_ask(c, s->UBC);
     rc = tfl_model_forward(c, s->model, s->p, s->U, s->flags, s->p, s->U, ws, ws_floats, ubc, umask, 1, -1e6f, 1e6f);
+    const bool folded = fold_took(c);
     if (rc) return rc;
     // p was rewritten by the model, density has not changed since the second setConstVals
-    return set_const_vals(c, s, s->U, late_ubc, Unchanged{false, false, true});
+    return set_const_vals(c, s, s->U, late_ubc && !folded, Unchanged{false, false, true});
   }
   tfl_tensor div = view(ws, 1);
   rc = tfl_velocityDivergenceForward(c, s->U, s->flags, &div, is3D);
@@ -551,6 +612,11 @@ int tfl_simulate_step_slab(tfl_ctx* c, const tfl_sim_params* prm, const tfl_sim_
   auto adv_scalar = [&]() { return tfl_advectScalar(c, prm->dt, rho, s->U, s->flags, &fwd, &fwd, is3D, method, &fwdPos, &bwdPos, 1, 0,
                                                     prm->maccormackStrength, rho); };
   auto adv_vel = [&]() { return tfl_advectVel(c, prm->dt, s->U, s->flags, &vfwd, &vfwd, is3D, method, 1, prm->maccormackStrength, &Uadv); };
+  // pass B (the launches that write the advected fields) applies the pairs of the setConstVals that follows on the planes
+  // it writes -- the owned ones, which is what message T2 carries to the neighbours' halos (fold_ask / fold_took)
+  bool rho_done = true, Uadv_done = true;
+  auto adv_scalar_b = [&]() { fold_ask(c, s->densityBC[0]); const int r = adv_scalar(); rho_done = fold_took(c) && rho_done; return r; };
+  auto adv_vel_b = [&]() { fold_ask(c, s->UBC); const int r = adv_vel(); Uadv_done = fold_took(c) && Uadv_done; return r; };
   if (rho) {
     (void)tfl_set_stages(c, 1); WIN(set_win(c, ext(g, 2 * g.R, 2 * g.R)));
     rc = adv_scalar(); if (rc) return rc;
@@ -564,16 +630,16 @@ int tfl_simulate_step_slab(tfl_ctx* c, const tfl_sim_params* prm, const tfl_sim_
   const bool ovl = sl->overlap && multi;
   if (ovl && spB.has_strips && spB.has_interior) {
     WIN(tfl_set_z_window(c, spB.a0, spB.a1, spB.b0, spB.b1));
-    if (rho) { rc = adv_scalar(); if (rc) return rc; }
-    rc = adv_vel(); if (rc) return rc;
+    if (rho) { rc = adv_scalar_b(); if (rc) return rc; }
+    rc = adv_vel_b(); if (rc) return rc;
     rc = msg_start(c, g, comm, m[2]); if (rc) return rc;
     WIN(tfl_set_z_window(c, spB.i0, spB.i1, 0, 0));
-    if (rho) { rc = adv_scalar(); if (rc) return rc; }
-    rc = adv_vel(); if (rc) return rc;
+    if (rho) { rc = adv_scalar_b(); if (rc) return rc; }
+    rc = adv_vel_b(); if (rc) return rc;
   } else {
     WIN(set_win(c, ext(g, 0, 0)));
-    if (rho) { rc = adv_scalar(); if (rc) return rc; }
-    rc = adv_vel(); if (rc) return rc;
+    if (rho) { rc = adv_scalar_b(); if (rc) return rc; }
+    rc = adv_vel_b(); if (rc) return rc;
     rc = msg_start(c, g, comm, m[2]); if (rc) return rc;
   }
   rc = msg_finish(c, g, comm, m[2]); if (rc) return rc;
@@ -584,20 +650,29 @@ int tfl_simulate_step_slab(tfl_ctx* c, const tfl_sim_params* prm, const tfl_sim_
   tfl_tensor Utmp = view(cw + 4 * N, 3);                   // the scalar advection's bwdPos planes, dead by now
   const tfl_tensor* cur = &Uadv;
   if (!buoyant && !vfused) { rc = tfl_copy(c, s->U, &Uadv); if (rc) return rc; cur = s->U; }
-  rc = set_const_vals(c, s, cur, true, Unchanged{false, false, false});
+  rc = set_const_vals(c, s, cur, !Uadv_done, Unchanged{false, false, false}, (rho && rho_done) ? 1u : 0u);
   if (rc) return rc;
 
   // ---- forces --------------------------------------------------------------------------------------------------------
   const double dx = tfl_getDx(c, s->flags);
   WIN(set_win(c, ext(g, 3, 4)));
+  // as tfl_simulate_step: the last force's kernel applies the U pair of the setConstVals that follows, on the planes it writes
+  // (they include every plane the projection reads: (0, 1)); the launch below then skips U
+  const bool fold_forces = !prm->outputDiv;
+  const bool gravity_on = prm->gravityScale > 0.0;
+  bool U_folded = false;
   if (buoyant) {
     const float sc = (float)(-(dx / 4.0) * prm->buoyancyScale);
     const float gv[3] = {prm->gravity[0] * sc, prm->gravity[1] * sc, prm->gravity[2] * sc};
     const tfl_tensor* dst = vfused ? &Utmp : s->U;
-    rc = tfl_addBuoyancyFrom(c, cur, dst, s->flags, rho, gv, prm->dt, is3D); if (rc) return rc;
+    const bool last = fold_forces && !gravity_on && !vort;
+    if (last) fold_ask(c, s->UBC);
+    rc = tfl_addBuoyancyFrom(c, cur, dst, s->flags, rho, gv, prm->dt, is3D);
+    if (last) U_folded = fold_took(c);
+    if (rc) return rc;
     cur = dst;
   }
-  if (prm->gravityScale > 0.0) {
+  if (gravity_on) {
     const float sc = (float)((-dx / 4.0) * prm->gravityScale);
     const float gv[3] = {prm->gravity[0] * sc, prm->gravity[1] * sc, prm->gravity[2] * sc};
     rc = tfl_addGravity(c, cur, s->flags, gv, prm->dt, is3D, nullptr); if (rc) return rc;
@@ -607,17 +682,23 @@ int tfl_simulate_step_slab(tfl_ctx* c, const tfl_sim_params* prm, const tfl_sim_
     if (vfused) {
       // one launch: curl (2,2) and |curl| live in LDS, the planes (0,1) of U are written (inputs: planes (3,3) of `cur`)
       (void)tfl_set_stages(c, 0); WIN(set_win(c, ext(g, 0, 1)));
-      rc = tfl_vorticityConfinementFrom(c, cur, s->U, s->flags, strength, &curl, &cnorm, is3D); if (rc) return rc;
+      if (fold_forces) fold_ask(c, s->UBC);
+      rc = tfl_vorticityConfinementFrom(c, cur, s->U, s->flags, strength, &curl, &cnorm, is3D);
+      if (fold_forces) U_folded = fold_took(c);
+      if (rc) return rc;
     } else {
       (void)tfl_set_stages(c, 2); WIN(set_win(c, ext(g, 2, 2)));
       rc = tfl_vorticityConfinement(c, s->U, s->flags, strength, &curl, &curl, &cnorm, &curl, is3D); if (rc) return rc;
       (void)tfl_set_stages(c, 4); WIN(set_win(c, ext(g, 0, 1)));
-      rc = tfl_vorticityConfinement(c, s->U, s->flags, strength, &curl, &curl, &cnorm, &curl, is3D); if (rc) return rc;
+      if (fold_forces) fold_ask(c, s->UBC);
+      rc = tfl_vorticityConfinement(c, s->U, s->flags, strength, &curl, &curl, &cnorm, &curl, is3D);
+      if (fold_forces) U_folded = fold_took(c);
+      if (rc) return rc;
     }
   }
   (void)tfl_set_stages(c, 0); (void)tfl_set_z_window(c, 0, 0, 0, 0);
   if (prm->outputDiv) return TFL_OK;
-  rc = set_const_vals(c, s, s->U, true, Unchanged{true, false, true});
+  rc = set_const_vals(c, s, s->U, !U_folded, Unchanged{true, false, true});
   if (rc) return rc;
 
   // ---- projection ----------------------------------------------------------------------------------------------------
@@ -659,9 +740,13 @@ int tfl_simulate_step_slab(tfl_ctx* c, const tfl_sim_params* prm, const tfl_sim_
   }
   (void)tfl_set_stages(c, 2); WIN(set_win(c, ext(g, 2, 1))); rc = finish(); if (rc) return rc;
   (void)tfl_set_stages(c, 4); WIN(set_win(c, ext(g, 1, 0))); rc = finish(); if (rc) return rc;
-  (void)tfl_set_stages(c, 8); WIN(set_win(c, ext(g, 0, 0))); rc = finish(); if (rc) return rc;
+  (void)tfl_set_stages(c, 8); WIN(set_win(c, ext(g, 0, 0)));
+  if (late_ubc) fold_ask(c, s->UBC);          // the projection kernel applies the sparse U pair itself (owned planes: what T0 sends)
+  rc = finish();
+  const bool U_late_folded = fold_took(c);
+  if (rc) return rc;
   (void)tfl_set_stages(c, 0); (void)tfl_set_z_window(c, 0, 0, 0, 0);
-  rc = set_const_vals(c, s, s->U, late_ubc, Unchanged{false, false, true});
+  rc = set_const_vals(c, s, s->U, late_ubc && !U_late_folded, Unchanged{false, false, true});
   if (rc) return rc;
   // the next step's U and p halos leave now; they are consumed at its start / before its first conv layer
   if (multi) {

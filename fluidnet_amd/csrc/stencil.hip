@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256) void k_add_buoyancy(Dom d, float* __restrict__
 template <bool IS3D>
 __global__ __launch_bounds__(256) void k_add_buoyancy_v4(Dom d, const float* __restrict__ Usrc, float* __restrict__ U,
                                                          const float* __restrict__ flags, const float* __restrict__ rho,
-                                                         float sx, float sy, float sz) {
+                                                         float sx, float sy, float sz, BcFoldArg folda) {
   // U = Usrc + buoyancy. Usrc == U: the reference's in-place op. Usrc != U (tfl_addBuoyancyFrom): every cell is
   // written, which folds the `U:copy(advected)` that precedes it in simulate() into this pass.
   const int i0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
@@ -153,6 +153,24 @@ __global__ __launch_bounds__(256) void k_add_buoyancy_v4(Dom d, const float* __r
     if (((int)fxm[q]) & kFluid) vx[q] += (0.5f * sx * (rc[q] + rxm[q]));
     if (((int)fym[q]) & kFluid) vy[q] += (0.5f * sy * (rc[q] + rym[q]));
     if (IS3D && (((int)fzm[q]) & kFluid)) vz[q] += (0.5f * sz * (rc[q] + rzm[q]));
+  }
+  // the setConstVals that follows the forces in simulate() (tfl_host.hpp BcFold; only asked for when Usrc != U: every cell written)
+  BcFold fold = {nullptr, nullptr, 0, -1, 0, -1, 0, -1};
+  const bool fold_blk = fold_block(folda, (int)(blockIdx.y * blockDim.y), (int)(blockIdx.y * blockDim.y + blockDim.y - 1), k, k);
+  if (fold_blk) fold = *folda.dev;
+  if (fold_blk && fold_row(fold, j, k) && i0 <= fold.x1 && i0 + 3 >= fold.x0) {
+    const float* fb = fold.bc + b * cells * C + o;
+    const float* fm = fold.inv + b * cells * C + o;
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      if (a >= C) continue;
+      const float4 b4 = *reinterpret_cast<const float4*>(fb + a * d.sc), m4 = *reinterpret_cast<const float4*>(fm + a * d.sc);
+      const float bb[4] = {b4.x, b4.y, b4.z, b4.w}, mm[4] = {m4.x, m4.y, m4.z, m4.w};
+      float* v = a == 0 ? vx : (a == 1 ? vy : vz);
+#pragma unroll
+      for (int q = 0; q < 4; q++)
+        if (fold_col(fold, i0 + q)) v[q] = v[q] * mm[q] + bb[q];
+    }
   }
   *reinterpret_cast<float4*>(U + o) = make_float4(vx[0], vx[1], vx[2], vx[3]);
   *reinterpret_cast<float4*>(U + o + d.sc) = make_float4(vy[0], vy[1], vy[2], vy[3]);
@@ -260,8 +278,9 @@ void add_buoyancy(hipStream_t st, bool is3d, int B, int Z, int Y, int X, const f
     const Dom d = make_dom(Z, Y, X);
     const dim3 blk(32, 8, 1), grd((X / 4 + 31) / 32, (Y + 7) / 8, (unsigned)(d.nw * B));
     TFL_TIMED_EXT("k_add_buoyancy", st);
-    if (is3d) TFL_LAUNCH_EXT((k_add_buoyancy_v4<true>), grd, blk, 0, st, d, Usrc, U, flags, density, sx, sy, sz);
-    else TFL_LAUNCH_EXT((k_add_buoyancy_v4<false>), grd, blk, 0, st, d, Usrc, U, flags, density, sx, sy, sz);
+    const BcFoldArg fold = Usrc != U ? take_fold() : no_fold();
+    if (is3d) TFL_LAUNCH_EXT((k_add_buoyancy_v4<true>), grd, blk, 0, st, d, Usrc, U, flags, density, sx, sy, sz, fold);
+    else TFL_LAUNCH_EXT((k_add_buoyancy_v4<false>), grd, blk, 0, st, d, Usrc, U, flags, density, sx, sy, sz, fold);
     return;
   }
   if (Usrc != U)   // the one-cell-per-thread kernel skips the cells it does not change

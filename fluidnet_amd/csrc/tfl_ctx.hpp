@@ -24,5 +24,7 @@ struct tfl_ctx {
   float* h_reach = nullptr;                   // pinned mirror, read by the NEXT tfl_simulate_step_slab call
   hipEvent_t reach_ev = nullptr;              // recorded behind the copy into h_reach; the next call waits for it
   bool reach_pending = false;
+  tfl::BcFoldArg fold = {nullptr, 0u, 0u};    // tfl_simulate_step: a setConstVals pair (device descriptor + gate) the next operator may apply to its output
+  bool fold_done = false;                     // ... and whether a launcher did (tfl_host.hpp BcFold)
   bool wf_timed_out = false;                  // a pipelined PCG sweep timed out on this context once: later solves go straight to hyperplane sweeps
 };

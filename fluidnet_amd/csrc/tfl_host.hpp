@@ -16,6 +16,36 @@ struct ZOrigin { int first, total; };
 extern thread_local ZOrigin g_zorigin;
 // tfl_set_advect_mode of the calling thread's current operator: 1 = tolerance mode of the LDS-tiled 3-D advection kernels
 extern thread_local int g_advect_fast;
+// A setConstVals pair (lib/simulate.lua:130-160: x = x * invMask + bc) that the calling thread's current operator MAY apply
+// to the field it writes (round 4): the pair is the identity outside the box [x0, x1] x [y0, y1] x [z0, z1] (inclusive, array
+// indices; the plume's pair covers four y rows), so a producing kernel compares its rows against the box and only the
+// threads inside it load bc / invMask ([B][C][Z][Y][X] like the field) -- nothing per cell elsewhere. The descriptor lives in
+// DEVICE memory (the plan owns it) and a kernel gets its address: one pointer argument, read with scalar loads at the store
+// -- ten scalars by value stayed live through the whole kernel and cost the advection kernels 30 SGPR spills each. A launcher
+// that hands the pointer to its kernel sets g_fold_done; tfl_simulate_step launches the sparse kernel (k_apply_bcs_indexed)
+// when nobody did.
+struct BcFold { const float* bc; const float* inv; int x0, x1, y0, y1, z0, z1; };
+// What a kernel is handed: the descriptor's device address and, by value, the box's y / z range packed into two words
+// (lo = y0 | z0 << 16, hi = y1 | z1 << 16): the block-uniform gate at the top of the kernel needs no memory access.
+struct BcFoldArg { const BcFold* dev; unsigned lo, hi; };     // dev == nullptr: no request
+extern thread_local BcFoldArg g_fold;
+extern thread_local bool g_fold_done;
+// the request for a kernel launch (and the acknowledgement), or an empty one
+inline BcFoldArg take_fold() { if (g_fold.dev) g_fold_done = true; return g_fold; }
+inline BcFoldArg no_fold() { return BcFoldArg{nullptr, 0u, 0u}; }
+
+// does row (j, k) / cell i of the field lie inside the pair's box
+__device__ __forceinline__ bool fold_row(const BcFold& f, int j, int k) {
+  return j >= f.y0 && j <= f.y1 && k >= f.z0 && k <= f.z1;
+}
+__device__ __forceinline__ bool fold_col(const BcFold& f, int i) { return i >= f.x0 && i <= f.x1; }
+// Block-uniform gate, evaluated once at the top of a kernel (two argument words, dead right after): can any cell of rows
+// [ya, yb] x planes [za, zb] lie in the pair's box?
+// Only the blocks that answer yes read the descriptor again at their stores -- for the plume's pair 1 block in 16-32.
+__device__ __forceinline__ bool fold_block(const BcFoldArg& a, int ya, int yb, int za, int zb) {
+  return (a.dev != nullptr) & (ya <= (int)(a.hi & 0xffffu)) & (yb >= (int)(a.lo & 0xffffu)) & (za <= (int)(a.hi >> 16)) &
+         (zb >= (int)(a.lo >> 16));
+}
 
 inline Dom make_dom(int Z, int Y, int X) {
   Dom d; d.X = X; d.Y = Y; d.Z = Z; d.sy = X; d.sz = X * Y; d.sc = X * Y * Z; d.one = 1;

@@ -46,11 +46,13 @@ __device__ __forceinline__ V4Ctx v4_ctx(const Dom& d) {
   return c;
 }
 
-// r[0..3] = p[o..o+3] (pad when !ok)
+// r[0..3] = p[o..o+3] (pad when !ok). The load itself is UNCONDITIONAL: a predicated load compiles to a branch, and hipcc
+// drains the whole load queue (s_waitcnt vmcnt(0)) at the join of every such branch -- k_confine_v4 had 20 of those between
+// its 30 loads, i.e. 20 memory round trips in a row per wave (round 4; profiles/r04_stream_loads.txt). A lane that must not
+// read takes the first vector of the array instead (p is a field's base pointer: valid, 16-byte aligned) and drops it.
 __device__ __forceinline__ void v4_load(const float* __restrict__ p, int o, bool ok, float pad, float* r) {
-  float4 v = make_float4(pad, pad, pad, pad);
-  if (ok) v = *reinterpret_cast<const float4*>(p + o);
-  r[0] = v.x; r[1] = v.y; r[2] = v.z; r[3] = v.w;
+  const float4 v = *reinterpret_cast<const float4*>(p + (ok ? o : 0));
+  r[0] = ok ? v.x : pad; r[1] = ok ? v.y : pad; r[2] = ok ? v.z : pad; r[3] = ok ? v.w : pad;
 }
 __device__ __forceinline__ void v4_store(float* __restrict__ p, int o, const float* r) {
   *reinterpret_cast<float4*>(p + o) = make_float4(r[0], r[1], r[2], r[3]);
@@ -59,13 +61,18 @@ __device__ __forceinline__ void v4_store(float* __restrict__ p, int o, const flo
 // EVERY lane of the wave must call this (DPP).
 template <bool LEFT, bool RIGHT>
 __device__ __forceinline__ void v4_edges(const V4Ctx& c, const float* __restrict__ p, int o, bool ok, float pad, float* e) {
+  // (the segment-end loads are unconditional too, see v4_load: every lane loads, the lanes that need no value read p[0])
   if (LEFT) {
+    const bool need = c.first && ok && c.has_l;
+    const float el = p[need ? o - 1 : 0];
     e[0] = from_lane_below(e[4]);
-    if (c.first) e[0] = (ok && c.has_l) ? p[o - 1] : pad;
+    if (c.first) e[0] = need ? el : pad;
   }
   if (RIGHT) {
+    const bool need = c.last && ok && c.has_r;
+    const float er = p[need ? o + 4 : 0];
     e[5] = from_lane_above(e[1]);
-    if (c.last) e[5] = (ok && c.has_r) ? p[o + 4] : pad;
+    if (c.last) e[5] = need ? er : pad;
   }
 }
 // e[0..5] = p[o-1 .. o+4]

@@ -21,7 +21,7 @@
 #define TFL_LB_CURL 1
 #endif
 #ifndef TFL_LB_CONFINE
-#define TFL_LB_CONFINE 1
+#define TFL_LB_CONFINE 4      // 128 VGPRs without spills (140 unconstrained: a wave less per SIMD)
 #endif
 
 namespace tfl {
@@ -204,10 +204,11 @@ __device__ __forceinline__ void force_row(const Dom& d, float strength, int i0, 
 template <bool IS3D>
 __global__ __launch_bounds__(256, TFL_LB_CONFINE) void k_confine_v4(Dom d, float* __restrict__ U, const float* __restrict__ flags,
                                                     const float* __restrict__ curl, const float* __restrict__ cn,
-                                                    float strength) {
+                                                    float strength, BcFoldArg folda) {
   const V4Ctx c = v4_ctx(d);
   const int j = blockIdx.y * blockDim.y + threadIdx.y;
   int b, k; dom_bk(d, b, k);
+  const bool fold_blk = fold_block(folda, (int)(blockIdx.y * blockDim.y), (int)(blockIdx.y * blockDim.y + blockDim.y - 1), k, k);
   const bool live = c.i0 < d.X && j < d.Y;
   const long long cells = d.sc;
   const int C = IS3D ? 3 : 2;
@@ -255,15 +256,22 @@ __global__ __launch_bounds__(256, TFL_LB_CONFINE) void k_confine_v4(Dom d, float
   if (IS3D) force_row<IS3D>(d, strength, c.i0, in_zm, n_zm, n_ymzm, n_ypzm, n_zm2, n_c + 1, wx_zm, wy_zm, wz_zm, fz);
   // force.x of cell i0-1: previous lane's last cell; at a segment start rebuilt from memory
   float fxl = from_lane_below(f0[3].x);
-  if (c.first) {
-    fxl = 0.0f;
+  {
+    // (loads unconditional, tfl_vec4.hpp v4_load: every lane reads -- the lanes that need nothing, cell 0 of the field)
     const int i = c.i0 - 1;
-    if (in && i >= 1) {   // i <= X-2 always
-      const int oo = o - 1;
-      v3 g = mk3(0.5f * (cn[oo + 1] - cn[oo - 1]), 0.5f * (cn[oo + d.sy] - cn[oo - d.sy]), 0.0f);
-      if (IS3D) g.z = 0.5f * (cn[oo + d.sz] - cn[oo - d.sz]);
-      g = normalize3(g);
-      fxl = ((g.y * curl[oo + 2 * d.sc]) - (g.z * curl[oo + d.sc])) * strength;
+    const bool need = c.first && in && i >= 1;   // i <= X-2 always
+    const int oo = need ? o - 1 : 0;
+    const float n_xm = cn[need ? oo - 1 : 0], n_ym1 = cn[need ? oo - d.sy : 0], n_yp1 = cn[need ? oo + d.sy : 0];
+    const float n_zm1 = cn[need && IS3D ? oo - d.sz : 0], n_zp1 = cn[need && IS3D ? oo + d.sz : 0];
+    const float w_y = curl[need ? oo + d.sc : 0], w_z = curl[need ? oo + 2 * d.sc : 0];
+    if (c.first) {
+      fxl = 0.0f;
+      if (need) {
+        v3 g = mk3(0.5f * (n_c[1] - n_xm), 0.5f * (n_yp1 - n_ym1), 0.0f);   // cn[oo + 1] is the thread's own first cell
+        if (IS3D) g.z = 0.5f * (n_zp1 - n_zm1);
+        g = normalize3(g);
+        fxl = ((g.y * w_z) - (g.z * w_y)) * strength;
+      }
     }
   }
 #pragma unroll
@@ -283,6 +291,21 @@ __global__ __launch_bounds__(256, TFL_LB_CONFINE) void k_confine_v4(Dom d, float
     if (az) u[2][q] += (0.5f * (fz[q].z + f0[q].z));
   }
   if (live) {
+    // the setConstVals that follows the forces in simulate() (tfl_host.hpp BcFold): only rows inside the pair's box load it
+    BcFold fold = {nullptr, nullptr, 0, -1, 0, -1, 0, -1};
+    if (fold_blk) fold = *folda.dev;
+    if (fold_blk && fold_row(fold, j, k) && c.i0 <= fold.x1 && c.i0 + 3 >= fold.x0) {
+#pragma unroll
+      for (int a = 0; a < 3; a++) {
+        if (a >= C) continue;
+        float fb[4], fm[4];
+        v4_load(fold.bc + b * cells * C, o + a * d.sc, true, 0.0f, fb);
+        v4_load(fold.inv + b * cells * C, o + a * d.sc, true, 1.0f, fm);
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+          if (fold_col(fold, c.i0 + q)) u[a][q] = u[a][q] * fm[q] + fb[q];
+      }
+    }
 #pragma unroll
     for (int a = 0; a < 3; a++)
       if (a < C) v4_store(U, o + a * d.sc, u[a]);
@@ -566,12 +589,13 @@ void vorticity_confinement(hipStream_t st, bool is3d, int B, int Z, int Y, int X
   const Vec4Launch v = vec4_launch(B, Z, Y, X, {U, flags, curl, curl_norm});
   const bool pa = stages & 1, pb = stages & 2;
   if (v.ok) {
+    const BcFoldArg fold = pb ? take_fold() : no_fold();   // pass B writes the operator's result
     if (is3d) {
       if (pa) { TFL_TIMED_EXT("k_curl", st); TFL_LAUNCH_EXT((k_curl_v4<true>), v.grd, v.blk, 0, st, d, (const float*)U, curl, curl_norm); }
-      if (pb) { TFL_TIMED_EXT("k_confine", st); TFL_LAUNCH_EXT((k_confine_v4<true>), v.grd, v.blk, 0, st, d, U, flags, (const float*)curl, (const float*)curl_norm, strength); }
+      if (pb) { TFL_TIMED_EXT("k_confine", st); TFL_LAUNCH_EXT((k_confine_v4<true>), v.grd, v.blk, 0, st, d, U, flags, (const float*)curl, (const float*)curl_norm, strength, fold); }
     } else {
       if (pa) { TFL_TIMED("k_curl", st); k_curl_v4<false><<<v.grd, v.blk, 0, st>>>(d, U, curl, curl_norm); }
-      if (pb) { TFL_TIMED("k_confine", st); k_confine_v4<false><<<v.grd, v.blk, 0, st>>>(d, U, flags, curl, curl_norm, strength); }
+      if (pb) { TFL_TIMED("k_confine", st); k_confine_v4<false><<<v.grd, v.blk, 0, st>>>(d, U, flags, curl, curl_norm, strength, fold); }
     }
     return;
   }
