@@ -156,6 +156,13 @@ __global__ __launch_bounds__(256, TFL_LB_BCS) void k_bcs_div_stats_v4(Dom d, con
   for (int a = 0; a < 3; a++) v4_load(U, o + a * d.sc, live && a < C, 0.0f, u[a]);
   v4_load(U, o + d.sc + d.sy, yp, 0.0f, uyp);
   v4_load(U, o + 2 * d.sc + d.sz, zp, 0.0f, uzp);
+  // what the last lane of a row segment needs of cell i0 + 4 (its wall-BC mask and U.x): issued here, with the row loads
+  // (loads unconditional, tfl_vec4.hpp v4_load: every lane reads -- the lanes that need nothing, cell 0 of the field)
+  const bool need = c.last && live && c.has_r;
+  const int oo = o + 4;
+  const float gym = flags[need && ym ? oo - d.sy : 0], gyp = flags[need && yp ? oo + d.sy : 0];
+  const float gzm = flags[need && zm ? oo - d.sz : 0], gzp = flags[need && zp ? oo + d.sz : 0];
+  const float gu = U[need ? oo : 0];
   // own cells
   double s1 = 0.0, s2 = 0.0;
   float ubx[5];
@@ -176,12 +183,6 @@ __global__ __launch_bounds__(256, TFL_LB_BCS) void k_bcs_div_stats_v4(Dom d, con
   // U_bc.x of cell i0+4: the next lane's first cell, or (segment end) rebuilt from memory
   ubx[4] = from_lane_above(ubx[0]);
   {
-    // (loads unconditional, tfl_vec4.hpp v4_load: every lane reads -- the lanes that need nothing, cell 0 of the field)
-    const bool need = c.last && live && c.has_r;
-    const int oo = o + 4;
-    const float gym = flags[need && ym ? oo - d.sy : 0], gyp = flags[need && yp ? oo + d.sy : 0];
-    const float gzm = flags[need && zm ? oo - d.sz : 0], gzp = flags[need && zp ? oo + d.sz : 0];
-    const float gu = U[need ? oo : 0];
     if (c.last) {
       float v = 0.0f;
       if (need) {

@@ -221,21 +221,32 @@ __global__ __launch_bounds__(256) void k_pcg_apply(const PcgState* __restrict__ 
   double acc = 0.0;
   for (long long o = (long long)blockIdx.x * 256 + threadIdx.x; o < d.sc; o += (long long)gridDim.x * 256) {
     float v = 0.0f;
-    if (label[o] == root) {
-      // setupLaplacian, generic/tfluids.cu:938-1075: the row of an interior fluid cell
-      const int nb[6] = {(int)o - d.sz, (int)o - d.sy, (int)o - 1, (int)o + 1, (int)o + d.sy, (int)o + d.sz};
+    // setupLaplacian, generic/tfluids.cu:938-1075: the row of an interior fluid cell. Every load is UNCONDITIONAL (round 4:
+    // `if (f & kFluid) off += s[nb]` made each neighbour a branch whose join drains the load queue -- 14 memory round trips in
+    // a row per cell); a cell outside the component reads its own index instead of its neighbours' and drops the values.
+    const bool in = label[o] == root;
+    const int nb[6] = {(int)o - d.sz, (int)o - d.sy, (int)o - 1, (int)o + 1, (int)o + d.sy, (int)o + d.sz};
+    float fn[6], sn[6];
+#pragma unroll
+    for (int q = 0; q < 6; q++) {
+      if (!IS3D && (q == 0 || q == 5)) { fn[q] = 0.0f; sn[q] = 0.0f; continue; }
+      const long long e = in ? (long long)nb[q] : o;
+      fn[q] = flags[e]; sn[q] = s[e];
+    }
+    const float so = s[o];
+    if (in) {
       float diag = 0.0f, off = 0.0f;
 #pragma unroll
       for (int q = 0; q < 6; q++) {
         if (!IS3D && (q == 0 || q == 5)) continue;
-        const int f = (int)flags[nb[q]];
+        const int f = (int)fn[q];
         if (!(f & kObstacle)) diag += 1.0f;
-        if (f & kFluid) off += s[nb[q]];
+        if (f & kFluid) off += sn[q];
       }
-      v = diag * s[o] - off;
+      v = diag * so - off;
     }
     w[o] = v;
-    acc += (double)s[o] * v;
+    acc += (double)so * v;
   }
   block_partial(acc, partials);
 }
