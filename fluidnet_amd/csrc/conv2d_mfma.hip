@@ -49,6 +49,12 @@ __global__ __launch_bounds__(256) void k_conv2_mfma(int B, int Y, int X, const f
     const double s1 = ci.stats[b * 2], s2 = ci.stats[b * 2 + 1], n = ci.count;
     in_scale = (float)sqrt(fmax(n * s2 - s1 * s1, 0.0) / (n * (n - 1.0)));
   }
+  // ---- B fragments (per-lane, host-arranged): [tap][c4 group]; asked for first, they travel with the tile's loads ------
+  constexpr int NB = 9 * (CIN4 / 4);
+  float bf[NB];
+#pragma unroll
+  for (int q = 0; q < NB; q++) bf[q] = bfrag[q * 64 + lane];
+  const float bv = bias[lane & 15];
   // ---- stage the halo tile (zero outside the image = the convolution's zero padding) -----------------
   constexpr int CREAL = FUSED ? 3 : CIN4;
   for (int idx = tid; idx < k2Rows * k2LW; idx += 256) {
@@ -68,18 +74,17 @@ __global__ __launch_bounds__(256) void k_conv2_mfma(int B, int Y, int X, const f
       lds[0 * k2Plane + idx] = v0; lds[1 * k2Plane + idx] = v1; lds[2 * k2Plane + idx] = v2;
       lds[3 * k2Plane + idx] = 0.0f;
     } else {
-      const float* ip = in + b * cells * CREAL;
+      // unconditional loads (a predicated load is a branch whose join drains the load queue: the 16 channels went two per
+      // memory round trip); a halo cell outside the image reads the image's first pixel and stores the padding zero
+      const float* ip = in + b * cells * CREAL + (ok ? o : 0);
+      float v[CIN4];
 #pragma unroll
-      for (int c = 0; c < CIN4; c++) lds[c * k2Plane + idx] = ok ? ip[c * cells + o] : 0.0f;
+      for (int c = 0; c < CIN4; c++) v[c] = ip[c * cells];
+#pragma unroll
+      for (int c = 0; c < CIN4; c++) lds[c * k2Plane + idx] = ok ? v[c] : 0.0f;
     }
   }
-  // ---- B fragments (per-lane, host-arranged): [tap][c4 group] -----------------------------------------
-  constexpr int NB = 9 * (CIN4 / 4);
-  float bf[NB];
-#pragma unroll
-  for (int q = 0; q < NB; q++) bf[q] = bfrag[q * 64 + lane];
   const int n = lane & 15, k4 = lane >> 4;
-  const float bv = bias[n];
   f32x4 acc[2] = {(f32x4){bv, bv, bv, bv}, (f32x4){bv, bv, bv, bv}};
   __syncthreads();
   // ---- implicit GEMM: one MFMA = one tap x four input channels ------------------------------------------

@@ -20,21 +20,27 @@ __global__ __launch_bounds__(256) void k_jacobi(Dom d, const float* __restrict__
     pp += b * cells; flags += b * cells; div += b * cells; p += b * cells;
     const int o = TFL_AT(d, i, j, k);
     float out = 0.0f;
+    // all loads in ONE round trip (round 4: flags[o] first and the rest behind its test were two; a border cell reads its
+    // own index instead of neighbours that do not exist -- 20 dependent launches per step make this a latency kernel)
+    const bool inner = !on_border<IS3D>(d, i, j, k);
+    const int sx = inner ? 1 : 0, sy = inner ? d.sy : 0, sz = (inner && IS3D) ? d.sz : 0;
     const int fc = (int)flags[o];
-    if (!on_border<IS3D>(d, i, j, k) && !(fc & kObstacle)) {
-      const float c = pp[o];
-      float p1 = pp[o - 1], p2 = pp[o + 1], p3 = pp[o - d.sy], p4 = pp[o + d.sy];
-      float p5 = IS3D ? pp[o - d.sz] : 0.0f, p6 = IS3D ? pp[o + d.sz] : 0.0f;
-      if (((int)flags[o - 1]) & kObstacle) p1 = c;
-      if (((int)flags[o + 1]) & kObstacle) p2 = c;
-      if (((int)flags[o - d.sy]) & kObstacle) p3 = c;
-      if (((int)flags[o + d.sy]) & kObstacle) p4 = c;
-      if (IS3D) {
-        if (((int)flags[o - d.sz]) & kObstacle) p5 = c;
-        if (((int)flags[o + d.sz]) & kObstacle) p6 = c;
-      }
-      out = (p1 + p2 + p3 + p4 + p5 + p6 + div[o]) / (IS3D ? 6.0f : 4.0f);
+    const float c = pp[o], dv = div[o];
+    float p1 = pp[o - sx], p2 = pp[o + sx], p3 = pp[o - sy], p4 = pp[o + sy];
+    float p5 = IS3D ? pp[o - sz] : 0.0f, p6 = IS3D ? pp[o + sz] : 0.0f;
+    const int f1 = (int)flags[o - sx], f2 = (int)flags[o + sx], f3 = (int)flags[o - sy], f4 = (int)flags[o + sy];
+    const int f5 = IS3D ? (int)flags[o - sz] : 0, f6 = IS3D ? (int)flags[o + sz] : 0;
+    // (the update itself is evaluated for every cell and selected at the end: behind a branch, hipcc sinks the loads into it)
+    p1 = (f1 & kObstacle) ? c : p1;
+    p2 = (f2 & kObstacle) ? c : p2;
+    p3 = (f3 & kObstacle) ? c : p3;
+    p4 = (f4 & kObstacle) ? c : p4;
+    if (IS3D) {
+      p5 = (f5 & kObstacle) ? c : p5;
+      p6 = (f6 & kObstacle) ? c : p6;
     }
+    const float upd = (p1 + p2 + p3 + p4 + p5 + p6 + dv) / (IS3D ? 6.0f : 4.0f);
+    out = (inner && !(fc & kObstacle)) ? upd : 0.0f;
     p[o] = out;
     if (RESID) { const double e = (double)out - (double)pp[o]; e2 = e * e; }
   }
