@@ -143,6 +143,17 @@ __device__ __forceinline__ v3 centred(const Dom& d, const float* __restrict__ U,
   return r;
 }
 
+// the same for a cell that may be a border cell: `deep` false -> all six loads read the cell itself (valid), the result is unused
+__device__ __forceinline__ v3 centred_if(const Dom& d, const float* __restrict__ U, unsigned o4, bool deep) {
+  const unsigned sc4 = (unsigned)d.sc * 4u;
+  const unsigned ex = deep ? 4u : 0u, ey = deep ? (unsigned)d.sy * 4u : 0u, ez = deep ? (unsigned)d.sz * 4u : 0u;
+  v3 r;
+  r.x = 0.5f * (ldg(U, o4) + ldg(U, o4 + ex));
+  r.y = 0.5f * (ldg(U, o4 + sc4) + ldg(U, o4 + sc4 + ey));
+  r.z = 0.5f * (ldg(U, o4 + 2u * sc4) + ldg(U, o4 + 2u * sc4 + ez));
+  return r;
+}
+
 // One ordinary back-trace (calcLineTrace with length <= kFastLen: a single step) from the centre of a cell that is not
 // a border cell; false = the lane needs the generic trace (long displacement, NaN, end point not in a fluid cell).
 // `mt` = the masked tile, `e` = tile index of the end point's cell.
@@ -240,7 +251,10 @@ __device__ __forceinline__ float max3r(float a, float b, float c) { float r; asm
 // rounds of them (these kernels are bound by the latency of a block's life -- load, barrier, trace, store -- not by
 // throughput: profiles/r04_advect_experiments.txt 9). All global accesses of the fast path are a uniform base + a 32-bit
 // byte offset: no 64-bit address arithmetic per lane.
-#define TFL_SCAL3_BLOCK(H, SRC)                                                                    \
+#define TFL_SCAL3_BLOCK(H, SRC) TFL_SCAL3_GEOM(H); TFL_SCAL3_STAGE(H, SRC)
+/* the geometry first: a kernel issues its own per-cell loads between GEOM and STAGE, so that they travel with the tile's */ \
+/* loads instead of costing a memory round trip of their own behind them (round 4) */
+#define TFL_SCAL3_GEOM(H)                                                                          \
   constexpr int PZ = TZ * KZ;                                                                      \
   using T = Tile<PZ, H>;                                                                           \
   __shared__ float tile[T::N];                                                                     \
@@ -253,12 +267,13 @@ __device__ __forceinline__ float max3r(float a, float b, float c) { float r; asm
   const int x0 = blockIdx.x * TX, y0 = blockIdx.y * TY;                                            \
   const int i = x0 + lane, j = y0 + ty;                                                            \
   const bool inner = y0 >= H && y0 + TY + H <= d.Y && k0 >= H && k0 + PZ + H <= d.Z && x0 + TX <= d.X;   \
-  if (inner) stage_masked<PZ, H, false, TY * TZ>(tile, SRC, flags, d, x0, y0, k0, tid);            \
-  else stage_masked<PZ, H, true, TY * TZ>(tile, SRC, flags, d, x0, y0, k0, tid);                   \
   const unsigned sc4 = (unsigned)d.sc * 4u;                                                        \
   const unsigned oxy4 = (unsigned)(min(i, d.X - 1) + __mul24(min(j, d.Y - 1), d.sy)) * 4u;         \
   /* on_border (bnd = 1) without branches: c < 1 || c > N - 2  <=>  unsigned(c - 1) >= unsigned(N - 2) */ \
   const bool border_xy = ((unsigned)(i - 1) >= (unsigned)(d.X - 2)) | ((unsigned)(j - 1) >= (unsigned)(d.Y - 2))
+#define TFL_SCAL3_STAGE(H, SRC)                                                                    \
+  if (inner) stage_masked<PZ, H, false, TY * TZ>(tile, SRC, flags, d, x0, y0, k0, tid);            \
+  else stage_masked<PZ, H, true, TY * TZ>(tile, SRC, flags, d, x0, y0, k0, tid)
 
 // Cell part (inside a loop over q): geometry of the thread's q-th cell
 #define TFL_SCAL3_CELL(H, q)                                                                       \
@@ -279,10 +294,11 @@ __global__ __launch_bounds__(256 * TZ) void k_scal3_fwd(AdvArgs a, const float* 
                                                         const float* __restrict__ flags, float* __restrict__ out,
                                                         float* __restrict__ bounds) {
   constexpr int HH = BOUNDS ? 2 : 1;
-  TFL_SCAL3_BLOCK(HH, s);
+  TFL_SCAL3_GEOM(HH);
   out += b * cells;
   if (BOUNDS) bounds += b * cells * 3;
-  // loads that do not depend on the tile: the cells' own values and the six faces of their centred velocities
+  // loads that do not depend on the tile -- the cells' own values and the six faces of their centred velocities -- are asked
+  // for BEFORE the tile's (unconditionally: a cell that is not `deep` reads itself)
   float svq[KZ];
   v3 uq[KZ];
 #pragma unroll
@@ -290,9 +306,9 @@ __global__ __launch_bounds__(256 * TZ) void k_scal3_fwd(AdvArgs a, const float* 
     TFL_SCAL3_CELL(HH, q);
     (void)c0; (void)cbias; (void)ctr;
     svq[q] = ldg(s, o4);
-    uq[q] = mk3(0.0f, 0.0f, 0.0f);
-    if (deep) uq[q] = centred(d, U, o4);
+    uq[q] = centred_if(d, U, o4, deep);
   }
+  TFL_SCAL3_STAGE(HH, s);
   __syncthreads();
 #pragma unroll
   for (int q = 0; q < KZ; q++) {
@@ -344,9 +360,10 @@ __global__ __launch_bounds__(256 * TZ) void k_scal3_bwd(AdvArgs a, double half_s
                                                         const float* __restrict__ U, const float* __restrict__ flags,
                                                         const float* __restrict__ fwd, const float* __restrict__ bounds,
                                                         float* __restrict__ dst, BcFoldArg folda) {
-  TFL_SCAL3_BLOCK(1, (fwd + b * cells));
+  TFL_SCAL3_GEOM(1);
   fwd += b * cells; dst += b * cells; bounds += b * cells * 3;
   const bool fold_blk = fold_block(folda, y0, y0 + TY - 1, k0, kend - 1);
+  // per-cell loads first (see k_scal3_fwd), then the tile of the forward field
   float svq[KZ], fq[KZ], bloq[KZ], bhiq[KZ];
   v3 uq[KZ];
 #pragma unroll
@@ -355,9 +372,9 @@ __global__ __launch_bounds__(256 * TZ) void k_scal3_bwd(AdvArgs a, double half_s
     (void)c0; (void)cbias; (void)ctr;
     svq[q] = ldg(s, o4); fq[q] = ldg(fwd, o4);
     bloq[q] = ldg(bounds, o4); bhiq[q] = ldg(bounds, o4 + sc4);
-    uq[q] = mk3(0.0f, 0.0f, 0.0f);
-    if (deep) uq[q] = centred(d, U, o4);
+    uq[q] = centred_if(d, U, o4, deep);
   }
+  TFL_SCAL3_STAGE(1, fwd);
   __syncthreads();
 #pragma unroll
   for (int q = 0; q < KZ; q++) {
