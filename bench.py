@@ -65,7 +65,8 @@ ALG_BYTES_PER_CELL = {
     "k_vort_fused": 28,      # U3, flags -> U3                          (curl + confinement in one launch, curl in LDS)
     "k_bcs_div_stats": 32,   # U3, flags -> U3_bc, div (+ 2 scalars)
     "k_net_input": 24,       # pDiv, div, flags -> 3 input planes
-    "k_project": 60,         # pPred, flags, U3, UBC3, mask3 -> U3, p
+    "k_project": 36,         # pPred, flags, U3 -> U3, p  (the plume's U pair is sparse: applied on its four rows, the dense
+                             # UBC3 / mask3 tensors -- 24 B/cell more -- are not read; round 3 counted them: 60)
     "k_set_wall_bcs": 28, "k_divergence": 20, "k_velocity_update": 32, "k_jacobi": 16,
 }
 
