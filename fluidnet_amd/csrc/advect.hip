@@ -155,23 +155,33 @@ __global__ __launch_bounds__(256) void k_minmax3_v4(Dom d, int outside, const fl
   float clo[6], chi[6], pend[6];
 #pragma unroll
   for (int q = 0; q < 6; q++) { clo[q] = __builtin_inff(); chi[q] = -__builtin_inff(); pend[q] = qnan; }
+  // all rows of the neighbourhood are asked for first (one memory round trip; round 4: a round trip per row before),
+  // then folded. A segment's end lanes walk the outside columns themselves (only when the row continues: X > 128); those
+  // loads are unconditional too (tfl_vec4.hpp v4_load: the lanes that need nothing read cell 0 of the field).
+  constexpr int NR = IS3D ? 9 : 3;
+  float svr[NR][4], fvr[NR][4], slr[NR], glr[NR], srr[NR], grr[NR];
+  bool okr[NR], nlr[NR], nrr[NR];
+#pragma unroll
+  for (int r = 0; r < NR; r++) {
+    const int dz = IS3D ? r / 3 - 1 : 0, dy = r % 3 - 1;
+    const int jj = j + dy, kk = k + dz;
+    const bool ok = live && jj >= 0 && jj < d.Y && kk >= 0 && kk < d.Z;
+    const int o = TFL_AT(d, c.i0, jj, kk);
+    v4_load(s, o, ok, qnan, svr[r]);
+    v4_load(flags, o, ok, 0.0f, fvr[r]);
+    const bool nl = c.first && ok && c.has_l, nr = c.last && ok && c.has_r;
+    slr[r] = s[nl ? o - 1 : 0]; glr[r] = flags[nl ? o - 1 : 0]; srr[r] = s[nr ? o + 4 : 0]; grr[r] = flags[nr ? o + 4 : 0];
+    okr[r] = ok; nlr[r] = nl; nrr[r] = nr;
+  }
   int nrow = 0;
 #pragma unroll
-  for (int dz = (IS3D ? -1 : 0); dz <= (IS3D ? 1 : 0); dz++)
+  for (int r = 0; r < NR; r++) {
+    {
+      const bool ok = okr[r];
+      float m[6];
 #pragma unroll
-    for (int dy = -1; dy <= 1; dy++) {
-      const int jj = j + dy, kk = k + dz;
-      const bool ok = live && jj >= 0 && jj < d.Y && kk >= 0 && kk < d.Z;
-      const int o = TFL_AT(d, c.i0, jj, kk);
-      float sv[4], fv[4], m[6];
-      v4_load(s, o, ok, qnan, sv);
-      v4_load(flags, o, ok, 0.0f, fv);
-#pragma unroll
-      for (int q = 0; q < 4; q++) m[q + 1] = ok ? masked(sv[q], fv[q]) : qnan;
-      // a segment's end lanes walk the outside columns themselves (only when the row continues: X > 128)
-      m[0] = qnan; m[5] = qnan;
-      if (c.first && ok && c.has_l) m[0] = masked(s[o - 1], flags[o - 1]);
-      if (c.last && ok && c.has_r) m[5] = masked(s[o + 4], flags[o + 4]);
+      for (int q = 0; q < 4; q++) m[q + 1] = ok ? masked(svr[r][q], fvr[r][q]) : qnan;
+      m[0] = nlr[r] ? masked(slr[r], glr[r]) : qnan; m[5] = nrr[r] ? masked(srr[r], grr[r]) : qnan;
       if (nrow & 1) {
 #pragma unroll
         for (int q = 0; q < 6; q++) { clo[q] = min3r(clo[q], pend[q], m[q]); chi[q] = max3r(chi[q], pend[q], m[q]); }
@@ -181,6 +191,7 @@ __global__ __launch_bounds__(256) void k_minmax3_v4(Dom d, int outside, const fl
       }
       nrow++;
     }
+  }
   if (nrow & 1) {
 #pragma unroll
     for (int q = 0; q < 6; q++) { clo[q] = min3r(clo[q], pend[q], pend[q]); chi[q] = max3r(chi[q], pend[q], pend[q]); }

@@ -27,26 +27,27 @@ template <bool IS3D>
 __global__ __launch_bounds__(256) void k_set_wall_bcs(Dom d, float* __restrict__ U, const float* __restrict__ flags) {
   TFL_STENCIL_INDEX();
   U += b * cells * C; flags += b * cells;
+  // the seven flag words in ONE memory round trip (round 4: each was a guarded load of its own, seven round trips in a row --
+  // DESIGN.md 3.6): a neighbour that does not exist reads the cell itself and counts as 0
   const int fc = (int)flags[o];
+  const float gxm = flags[i > 0 ? o - 1 : o], gym = flags[j > 0 ? o - d.sy : o], gzm = flags[(IS3D && k > 0) ? o - d.sz : o];
+  const float gxp = flags[i < d.X - 1 ? o + 1 : o], gyp = flags[j < d.Y - 1 ? o + d.sy : o];
+  const float gzp = flags[(IS3D && k < d.Z - 1) ? o + d.sz : o];
+  const int fxm = i > 0 ? (int)gxm : 0, fym = j > 0 ? (int)gym : 0, fzm = (IS3D && k > 0) ? (int)gzm : 0;
+  const int fxp = i < d.X - 1 ? (int)gxp : 0, fyp = j < d.Y - 1 ? (int)gyp : 0, fzp = (IS3D && k < d.Z - 1) ? (int)gzp : 0;
   const bool cf = fc & kFluid, co = fc & kObstacle;
-  if (!cf && !co) return;
-  const int fxm = i > 0 ? (int)flags[o - 1] : 0;
-  const int fym = j > 0 ? (int)flags[o - d.sy] : 0;
-  const int fzm = (IS3D && k > 0) ? (int)flags[o - d.sz] : 0;
   bool zx = (fxm & kObstacle) || (co && (fxm & kFluid));
   bool zy = (fym & kObstacle) || (co && (fym & kFluid));
   bool zz = IS3D && ((fzm & kObstacle) || (co && (fzm & kFluid)));
   if (cf) {
-    const int fxp = i < d.X - 1 ? (int)flags[o + 1] : 0;
-    const int fyp = j < d.Y - 1 ? (int)flags[o + d.sy] : 0;
-    const int fzp = (IS3D && k < d.Z - 1) ? (int)flags[o + d.sz] : 0;
     if ((fxm & kStick) || (fxp & kStick)) { zy = true; zz = IS3D; }
     if ((fym & kStick) || (fyp & kStick)) { zx = true; zz = zz || IS3D; }
     if (IS3D && ((fzm & kStick) || (fzp & kStick))) { zx = true; zy = true; }
   }
-  if (zx) U[o] = 0.0f;
-  if (zy) U[o + d.sc] = 0.0f;
-  if (IS3D && zz) U[o + 2 * d.sc] = 0.0f;
+  const bool act = cf || co;
+  if (act && zx) U[o] = 0.0f;
+  if (act && zy) U[o + d.sc] = 0.0f;
+  if (IS3D && act && zz) U[o + 2 * d.sc] = 0.0f;
 }
 
 // third_party/tfluids.cc:1008-1066 (negative divergence, Manta makeRhs convention)
@@ -70,26 +71,28 @@ __global__ __launch_bounds__(256) void k_velocity_update(Dom d, float* __restric
   TFL_STENCIL_INDEX();
   if (on_border<IS3D>(d, i, j, k)) return;
   U += b * cells * C; flags += b * cells; p += b * cells;
+  // every operand in ONE memory round trip (round 4, DESIGN.md 3.6: the pressure and velocity loads sat behind the flag tests)
   const int fc = (int)flags[o];
   const int fx = (int)flags[o - 1], fy = (int)flags[o - d.sy], fz = IS3D ? (int)flags[o - d.sz] : 0;
+  const float pc = p[o], pxm = p[o - 1], pym = p[o - d.sy], pzm = IS3D ? p[o - d.sz] : 0.0f;
+  const float ux0 = U[o], uy0 = U[o + d.sc], uz0 = IS3D ? U[o + 2 * d.sc] : 0.0f;
   if (fc & kFluid) {
-    const float pc = p[o];
-    float ux = U[o], uy = U[o + d.sc];
-    if (fx & kFluid) ux -= (pc - p[o - 1]);
-    if (fy & kFluid) uy -= (pc - p[o - d.sy]);
+    float ux = ux0, uy = uy0;
+    if (fx & kFluid) ux -= (pc - pxm);
+    if (fy & kFluid) uy -= (pc - pym);
     if (fx & kEmpty) ux -= pc;
     if (fy & kEmpty) uy -= pc;
     U[o] = ux; U[o + d.sc] = uy;
     if (IS3D) {
-      float uz = U[o + 2 * d.sc];
-      if (fz & kFluid) uz -= (pc - p[o - d.sz]);
+      float uz = uz0;
+      if (fz & kFluid) uz -= (pc - pzm);
       if (fz & kEmpty) uz -= pc;
       U[o + 2 * d.sc] = uz;
     }
   } else if ((fc & kEmpty) && !(fc & kOutflow)) {
-    U[o] = (fx & kFluid) ? U[o] + p[o - 1] : 0.0f;
-    U[o + d.sc] = (fy & kFluid) ? U[o + d.sc] + p[o - d.sy] : 0.0f;
-    if (IS3D) U[o + 2 * d.sc] = (fz & kFluid) ? U[o + 2 * d.sc] + p[o - d.sz] : 0.0f;
+    U[o] = (fx & kFluid) ? ux0 + pxm : 0.0f;
+    U[o + d.sc] = (fy & kFluid) ? uy0 + pym : 0.0f;
+    if (IS3D) U[o + 2 * d.sc] = (fz & kFluid) ? uz0 + pzm : 0.0f;
   }
 }
 
