@@ -659,9 +659,15 @@ __global__ __launch_bounds__(256, TFL_M16P_LB) void k_conv3_m16p(Dom d, int cols
   const float bias0 = bias[c0], bias1 = bias[c1];
   const int j0 = 4 * (g >> 1) + 2 * (g & 1);              // TAIL: the two hidden channels this lane finishes
   float b4a = 0.0f, b4b = 0.0f, w5a = 0.0f, w5b = 0.0f, b5 = 0.0f;
-  if (TAIL) {
+  float w4lo[4][2], w4hi[4][2];       // TAIL: the lane's 16 weights of the 8 -> 8 (k = 1) layer, fetched ONCE (round 4, late: they
+  if (TAIL) {                         // were re-read from memory in every plane step, 16 loads + their waits behind the MFMAs)
     b4a = bias[kTailB4 + j0]; b4b = bias[kTailB4 + j0 + 1]; w5a = bias[kTailW5 + j0]; w5b = bias[kTailW5 + j0 + 1];
     b5 = bias[kTailB5];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      w4lo[j][0] = bias[kTailW4 + j * 8 + c0]; w4lo[j][1] = bias[kTailW4 + j * 8 + c1];
+      w4hi[j][0] = bias[kTailW4 + (4 + j) * 8 + c0]; w4hi[j][1] = bias[kTailW4 + (4 + j) * 8 + c1];
+    }
   }
 
   // finish output plane z from its accumulators: recombine, bias, ReLU, then split + transposed 16-byte stores, or the tail
@@ -700,8 +706,8 @@ __global__ __launch_bounds__(256, TFL_M16P_LB) void k_conv3_m16p(Dom d, int cols
         float r4[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-          const float qa = __builtin_fmaf(bias[kTailW4 + j * 8 + c0], h0[oy], bias[kTailW4 + j * 8 + c1] * h1[oy]);
-          const float qb = __builtin_fmaf(bias[kTailW4 + (4 + j) * 8 + c0], h0[oy], bias[kTailW4 + (4 + j) * 8 + c1] * h1[oy]);
+          const float qa = __builtin_fmaf(w4lo[j][0], h0[oy], w4lo[j][1] * h1[oy]);
+          const float qb = __builtin_fmaf(w4hi[j][0], h0[oy], w4hi[j][1] * h1[oy]);
           r4[j] = swap_sum32(qa, qb);
         }
         float r2[2];
