@@ -575,6 +575,21 @@ int tfl_solveLinearSystemJacobi(tfl_ctx* c, const tfl_tensor* p, const tfl_tenso
   const int B = flags->B;
   if (B > kMaxBatch) return fail(c, TFL_EINVAL, "solveLinearSystemJacobi: batch size above %d", kMaxBatch);
   const size_t bytes = sizeof(float) * (size_t)B * flags->Z * flags->Y * flags->X;
+  // a small 2-D grid with a fixed iteration count (BASELINE config 1): one launch for the whole solve (jacobi.hip)
+  if (!is3D && flags->Z == 1 && !(pTol > 0.0f) && !verbose) {
+    const bool want = residual != nullptr;
+    if (tfl::jacobi_solve_lds(c->stream, B, flags->Y, flags->X, flags->data, div->data, p->data, pPrev->data, maxIter,
+                              want ? c->d_resid : nullptr)) {
+      if (want) {
+        HIP_TRY(c, hipMemcpyAsync(c->h_resid, c->d_resid, sizeof(double) * B, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        float res = 0.0f;
+        for (int b = 0; b < B; b++) res = std::max(res, (float)std::sqrt(c->h_resid[b]));
+        *residual = res;
+      }
+      return check_launch(c, "solveLinearSystemJacobi");
+    }
+  }
   // generic/tfluids.cu:1869-1872: both buffers start at zero
   HIP_TRY(c, hipMemsetAsync(p->data, 0, bytes, c->stream));
   HIP_TRY(c, hipMemsetAsync(pPrev->data, 0, bytes, c->stream));

@@ -136,6 +136,10 @@ bool vorticity_confinement_fused(hipStream_t st, int B, int Z, int Y, int X, con
 void jacobi_iteration(hipStream_t st, bool is3d, int B, int Z, int Y, int X, const float* p_prev, const float* flags,
                       const float* div, float* p, double* resid_sq /* [B] or nullptr */);
 
+// a 2-D grid of up to 16 K cells: the whole Jacobi solve in one launch, p ping-pongs in LDS (false = not taken)
+bool jacobi_solve_lds(hipStream_t st, int B, int Y, int X, const float* flags, const float* div, float* p, float* p_prev,
+                      int iters, double* resid_sq);
+
 // pcg.hip
 long long pcg_workspace_floats(int Z, int Y, int X);
 int pcg_solve(hipStream_t st, bool is3d, int B, int Z, int Y, int X, float* p, const float* flags, const float* div,
