@@ -106,7 +106,9 @@ def test_hip_blur_and_signed_distance_match_oracle_bitwise(hip, oracle, is3d):
         assert np.array_equal(s_h, s_o), rad
 
 
-@pytest.mark.parametrize("dims", [(1, 64, 64), (24, 20, 28)])
+# (2-D grids of up to 16 K cells with a fixed iteration count take the one-launch LDS solve of jacobi.hip: 1, 4 or 16 cells per
+# thread -- 24 x 33, 64 x 64, the ragged 100 x 90 --; 130 x 140 is past it and iterates launches like the 3-D grid)
+@pytest.mark.parametrize("dims", [(1, 64, 64), (24, 20, 28), (1, 24, 33), (1, 100, 90), (1, 130, 140)])
 def test_hip_jacobi_matches_oracle(hip, oracle, dims):
     sc = scenes.make_scene(dims, seed=9, vel_cells=1.0, B=2)
     f, U = sc["flags"], sc["U"].copy()
