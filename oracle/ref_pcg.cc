@@ -75,4 +75,23 @@ int tfluids_ref_pcg(float* p, float* flags, float* div, int B, int Z, int Y, int
   return rc;
 }
 
+// The five restated library primitives, exported so that tests can hold them to their DEFINING properties with an
+// independent implementation (numpy / scipy in tests/test_oracle.py): (L U)_ij = A_ij and (R^T R)_ij = A_ij on A's pattern,
+// op(T) x = alpha f, y = A x for a SYMMETRIC descriptor. what: 0 csrilu0 (val in place), 1 csric0 (upper storage, in place),
+// 2 csrsv_solve (descr: type 0 general / 3 triangular, fill 0 lower / 1 upper, diag 0 non-unit / 1 unit; op 0 N / 1 T; f -> x),
+// 3 csrmv (type 0 general / 1 symmetric; f -> x). Returns the primitive's status (0 = success).
+int tfluids_ref_cusparse_primitive(int what, int n, int nz, const int* row, const int* col, float* val, int type, int fill,
+                                   int diag, int op, const float* f, float* x) {
+  cusparseMatDescr d;
+  d.type = (cusparseMatrixType_t)type; d.fill = (cusparseFillMode_t)fill; d.diag = (cusparseDiagType_t)diag;
+  const float one = 1.0f, zero = 0.0f;
+  switch (what) {
+    case 0: return cusparseScsrilu0(0, CUSPARSE_OPERATION_NON_TRANSPOSE, n, &d, val, row, col, nullptr);
+    case 1: return cusparseScsric0(0, CUSPARSE_OPERATION_NON_TRANSPOSE, n, &d, val, row, col, nullptr);
+    case 2: return cusparseScsrsv_solve(0, (cusparseOperation_t)op, n, &one, &d, val, row, col, nullptr, f, x);
+    case 3: return cusparseScsrmv(0, CUSPARSE_OPERATION_NON_TRANSPOSE, n, n, nz, &one, &d, val, row, col, f, &zero, x);
+    default: return -1;
+  }
+}
+
 }  // extern "C"

@@ -267,6 +267,88 @@ def test_pcg_restatement_equals_compiled_reference_host_function(oracle, ref_pcg
     assert np.abs(pb).max() == 0 and np.abs(div).max() < 1e3     # tol above |rhs|: no iteration, p stays zero
 
 
+def _grid_laplacian(dims, seed):
+    """CSR of the reference's pressure matrix on a box with random obstacles (setupLaplacian's stencil: diagonal = number of
+    non-obstacle neighbours, -1 towards fluid neighbours), as scipy sparse float32 with sorted columns."""
+    import scipy.sparse as sp
+    rng = np.random.RandomState(seed)
+    fluid = np.ones(dims, bool)
+    fluid[rng.rand(*dims) < 0.15] = False
+    idx = -np.ones(dims, np.int64)
+    idx[fluid] = np.arange(fluid.sum())
+    rows, cols, vals = [], [], []
+    for c in np.argwhere(fluid):
+        diag = 0.0
+        for ax in range(len(dims)):
+            for s_ in (-1, 1):
+                nb = c.copy(); nb[ax] += s_
+                if nb[ax] < 0 or nb[ax] >= dims[ax]:
+                    continue                      # domain wall: an obstacle
+                diag += 1.0
+                if fluid[tuple(nb)]:
+                    rows.append(idx[tuple(c)]); cols.append(idx[tuple(nb)]); vals.append(-1.0)
+                else:
+                    diag -= 1.0
+        rows.append(idx[tuple(c)]); cols.append(idx[tuple(c)]); vals.append(max(diag, 1.0) + 0.25)   # + shift: SPD, well away from singular
+    A = sp.csr_matrix((np.array(vals, np.float32), (rows, cols)), shape=(int(fluid.sum()),) * 2)
+    A.sort_indices()
+    return A
+
+
+@pytest.mark.parametrize("dims,seed", [((9, 11), 1), ((5, 6, 7), 2)])
+def test_restated_cusparse_primitives_have_their_defining_properties(ref_pcg, dims, seed):
+    """oracle/ref_shim/cusparse_host.h restates the five cuSPARSE entry points the reference's PCG calls (the toolkit is not in
+    the tree). Independent witnesses, in numpy / scipy float64: csrilu0 -> (L U)_ij = A_ij on A's pattern (the definition of
+    ILU(0)); csric0 on the stored upper triangle -> (R^T R)_ij = A_ij on the pattern; csrsv_solve -> op(T) x = f for the
+    descriptor's triangle (unit / non-unit diagonal, N / T); csrmv with a SYMMETRIC descriptor and upper storage -> y = A x."""
+    import ctypes
+    import scipy.sparse as sp
+    from oracle import ref as refmod
+    lib = refmod._pcg_lib()
+    A = _grid_laplacian(dims, seed)
+    n = A.shape[0]
+    ip = lambda a: np.ascontiguousarray(a, np.int32).ctypes.data_as(ctypes.c_void_p)
+    fp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+
+    def call(what, M, val, type_=0, fill=0, diag=0, op=0, f=None, x=None):
+        rc = lib.tfluids_ref_cusparse_primitive(what, n, int(M.nnz), ip(M.indptr), ip(M.indices), fp(val), type_, fill, diag, op,
+                                                fp(f) if f is not None else None, fp(x) if x is not None else None)
+        assert rc == 0, (what, rc)
+
+    rng = np.random.RandomState(seed + 10)
+    f = rng.randn(n).astype(np.float32)
+    # ---- ILU(0) ----
+    val = A.data.copy()
+    call(0, A, val)
+    F = sp.csr_matrix((val.astype(np.float64), A.indices, A.indptr), shape=A.shape)
+    L = sp.tril(F, -1) + sp.identity(n)
+    U = sp.triu(F, 0)
+    LU = (L @ U).tocsr()
+    pat = A.copy(); pat.data[:] = 1.0
+    assert abs(LU.multiply(pat) - A.astype(np.float64)).max() < 2e-6 * abs(A).max()
+    # unit-lower then upper solve = (L U)^-1 f
+    y, z = np.zeros(n, np.float32), np.zeros(n, np.float32)
+    call(2, A, val, type_=0, fill=0, diag=1, op=0, f=f, x=y)
+    call(2, A, val, type_=0, fill=1, diag=0, op=0, f=y, x=z)
+    assert np.abs(LU @ z.astype(np.float64) - f).max() < 2e-5 * max(1.0, np.abs(f).max())
+    # ---- IC(0) on the stored upper triangle ----
+    Au = sp.triu(A, 0).tocsr(); Au.sort_indices()
+    valc = Au.data.copy()
+    call(1, Au, valc, type_=1, fill=1)
+    R = sp.csr_matrix((valc.astype(np.float64), Au.indices, Au.indptr), shape=A.shape)
+    RtR = (R.T @ R).tocsr()
+    assert abs(RtR.multiply(pat) - A.astype(np.float64)).max() < 2e-6 * abs(A).max()
+    call(2, Au, valc, type_=3, fill=1, diag=0, op=1, f=f, x=y)      # R^T y = f
+    call(2, Au, valc, type_=3, fill=1, diag=0, op=0, f=y, x=z)      # R z = y
+    assert np.abs(RtR @ z.astype(np.float64) - f).max() < 2e-5 * max(1.0, np.abs(f).max())
+    # ---- csrmv: general (full storage) and SYMMETRIC (upper storage) give the same y = A x ----
+    y1, y2 = np.zeros(n, np.float32), np.zeros(n, np.float32)
+    call(3, A, A.data.copy(), type_=0, f=f, x=y1)
+    call(3, Au, Au.data.copy(), type_=1, fill=1, f=f, x=y2)
+    want = A.astype(np.float64) @ f
+    assert np.abs(y1 - want).max() < 1e-5 * np.abs(want).max() and np.abs(y2 - want).max() < 1e-5 * np.abs(want).max()
+
+
 def test_pcg_compiled_reference_raises_like_the_restatement(oracle, ref_pcg):
     """a fluid cell on the domain border: setupLaplacian raises (generic/tfluids.cu:1082-1090); an unknown preconditioner
     name: StringToPrecondType raises (:1216-1228)"""
