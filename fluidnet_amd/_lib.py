@@ -120,6 +120,7 @@ SIGNATURES = {
                                             _c.POINTER(_c.POINTER(_c.c_float)), _c.c_void_p]),
     "tfl_model_destroy": (None, [_c.c_void_p, _c.c_void_p]),
     "tfl_model_range_errors": (_c.c_int64, [_c.c_void_p, _c.c_void_p]),
+    "tfl_model_range_flag": (_c.c_int64, [_c.c_void_p, _c.c_void_p]),
     "tfl_model_workspace_floats": (_c.c_int64, [_c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.c_int]),
     "tfl_model_forward": (_c.c_int, [_c.c_void_p, _c.c_void_p, _T, _T, _T, _T, _T, _c.c_void_p,
                                      _c.c_int64, _T, _T, _c.c_int, _c.c_float, _c.c_float]),

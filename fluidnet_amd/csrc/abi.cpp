@@ -42,7 +42,10 @@ struct tfl_model {
   bool m16 = false;
   void* wfrag16[3] = {nullptr, nullptr, nullptr}; // A fragments of the three k=3 layers (conv3_m16_pack_weights)
   float post16[3] = {0.0f, 0.0f, 0.0f};           // 2^-(11 + e) of each layer
+  float post16_tail = 0.0f;                       // the same for the tail's 8 -> 8 (k = 1) layer (conv3_m16_pack_tail)
   unsigned long long* d_range_err = nullptr;      // blocks that clamped an activation at the fp16 range
+  unsigned long long* h_range = nullptr;          // pinned, device-mapped: the projection kernel copies a non-zero count here, so the
+  unsigned long long* d_range_host = nullptr;     // NEXT call sees it without a stream sync (d_range_host = its device address)
   // 2-D `default` topology (3->16, 16->16 x3 k3, 16->1 k1): MFMA path (conv2d_mfma.hip)
   bool mfma2d = false;
   float* bfrag2[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -533,8 +536,15 @@ int tfl_solveLinearSystemPCG(tfl_ctx* c, const tfl_tensor* p, const tfl_tensor* 
   // the pipelined sweeps need every sub-box resident at once: when something else holds part of the GPU they time out (~1 s)
   // and the solve is repeated with one launch per hyperplane -- remembered per context, so that only the FIRST solve pays
   int rc = tfl::pcg_solve(c->stream, is3D != 0, flags->B, flags->Z, flags->Y, flags->X, p->data, flags->data, div->data,
-                          pc, tol, maxIter, verbose, workspace, residual, msg, sizeof(msg), !c->wf_timed_out);
-  if (rc == -5) c->wf_timed_out = true;
+                          pc, tol, maxIter, verbose, workspace, residual, msg, sizeof(msg), c->wf_skip == 0);
+  if (c->wf_skip > 0) c->wf_skip--;
+  if (rc == -5) {
+    // back off for 16, 32, ... 1024 solves, then try the pipelined sweeps again; say so once per latch
+    c->wf_timeouts++;
+    c->wf_skip = 16 << (c->wf_timeouts < 7 ? c->wf_timeouts - 1 : 6);
+    fprintf(stderr, "[tfl] solveLinearSystemPCG: a pipelined triangular sweep timed out (something else holds part of the GPU?); "
+                    "this solve and the next %d on this context use hyperplane sweeps (slower), then the pipelined form is retried\n", c->wf_skip);
+  }
   if (rc == -5)
     rc = tfl::pcg_solve(c->stream, is3D != 0, flags->B, flags->Z, flags->Y, flags->X, p->data, flags->data, div->data,
                         pc, tol, maxIter, verbose, workspace, residual, msg, sizeof(msg), false);
@@ -771,6 +781,7 @@ tfl_model* tfl_model_create_opts(tfl_ctx* c, int is3D, int nlayers, const int32_
       for (int l = 0; l < 3; l++) {
         std::vector<uint16_t> fr(tfl::conv3_m16_frag_halves(cin[l]));
         m->post16[l] = tfl::conv3_m16_pack_weights(weights[l], cin[l], fr.data());
+        if (l == 2) m->post16_tail = tfl::conv3_m16_pack_tail(weights[3], fr.data());     // the 8 -> 8 (k = 1) layer's A fragment
         if (hipMalloc(&m->wfrag16[l], fr.size() * sizeof(uint16_t)) != hipSuccess ||
             hipMemcpy(m->wfrag16[l], fr.data(), fr.size() * sizeof(uint16_t), hipMemcpyHostToDevice) != hipSuccess)
           return cleanup("uploading fp16 MFMA weight fragments failed");
@@ -778,13 +789,19 @@ tfl_model* tfl_model_create_opts(tfl_ctx* c, int is3D, int nlayers, const int32_
       if (hipMalloc((void**)&m->d_range_err, sizeof(unsigned long long)) != hipSuccess ||
           hipMemset(m->d_range_err, 0, sizeof(unsigned long long)) != hipSuccess)
         return cleanup("hipMalloc failed");
+      // the word a later call reads without a sync; failing to get mapped memory only loses the early warning
+      if (hipHostMalloc((void**)&m->h_range, sizeof(unsigned long long), hipHostMallocMapped) == hipSuccess) {
+        *m->h_range = 0;
+        if (hipHostGetDevicePointer((void**)&m->d_range_host, m->h_range, 0) != hipSuccess) { (void)hipHostFree(m->h_range); m->h_range = nullptr; m->d_range_host = nullptr; }
+      } else m->h_range = nullptr;
     }
     if (m->valu3d) {
-      std::vector<float> tp(8 + 64 + 8 + 8 + 1);
+      std::vector<float> tp(8 + 64 + 8 + 8 + 1 + 1);
       for (int i = 0; i < 8; i++) tp[i] = biases[2][i];
       for (int i = 0; i < 64; i++) tp[8 + i] = weights[3][i];
       for (int i = 0; i < 8; i++) { tp[72 + i] = biases[3][i]; tp[80 + i] = weights[4][i]; }
       tp[88] = biases[4][0];
+      tp[89] = m->post16_tail;        // conv_mfma16.hip kTailPost4 (0 on the fp32 paths, which do not read it)
       if (hipMalloc((void**)&m->tail_pack, tp.size() * sizeof(float)) != hipSuccess ||
           hipMemcpy(m->tail_pack, tp.data(), tp.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
         return cleanup("uploading tail weights failed");
@@ -838,6 +855,7 @@ void tfl_model_destroy(tfl_ctx* c, tfl_model* m) {
   for (int l = 0; l < 3; l++) if (m->wino[l]) (void)hipFree(m->wino[l]);
   for (int l = 0; l < 3; l++) if (m->wfrag16[l]) (void)hipFree(m->wfrag16[l]);
   if (m->d_range_err) (void)hipFree(m->d_range_err);
+  if (m->h_range) (void)hipHostFree(m->h_range);
   for (int l = 0; l < 4; l++) if (m->bfrag2[l]) (void)hipFree(m->bfrag2[l]);
   if (m->tail_w4) (void)hipFree(m->tail_w4);
   if (m->tail_pack) (void)hipFree(m->tail_pack);
@@ -853,7 +871,23 @@ int64_t tfl_model_range_errors(tfl_ctx* c, tfl_model* m) {
   if (hipMemcpyAsync(&v, m->d_range_err, sizeof(v), hipMemcpyDeviceToHost, c->stream) != hipSuccess) return -1;
   if (hipMemsetAsync(m->d_range_err, 0, sizeof(v), c->stream) != hipSuccess) return -1;
   if (hipStreamSynchronize(c->stream) != hipSuccess) return -1;
+  if (m->h_range) *(volatile unsigned long long*)m->h_range = 0;      // acknowledged: the next forward runs again
   return (int64_t)v;
+}
+
+int64_t tfl_model_range_flag(tfl_ctx* c, tfl_model* m) {
+  if (!c || !m) return -1;
+  return m->h_range ? (int64_t)*(volatile unsigned long long*)m->h_range : 0;
+}
+
+// A forward pass after one that clamped activations at the fp16 range would build on wrong values where the reference's
+// fp32 cuDNN carries on: refuse it until the host has acknowledged the count (tfl_model_range_errors).
+static int range_gate(tfl_ctx* c, tfl_model* m, const char* who) {
+  if (m && m->h_range && *(volatile unsigned long long*)m->h_range != 0)
+    return fail(c, TFL_ERANGE, "%s: an earlier forward pass of this model clamped activations at the fp16 range (|x| > 65504 after the "
+                               "std normalisation: a blown-up simulation); its pressure is not the reference's. Read and reset the count with "
+                               "tfl_model_range_errors, or create the model under TFL_CONV_PATH=winograd (strict fp32, no range limit)", who);
+  return TFL_OK;
 }
 
 int64_t tfl_model_workspace_floats(const tfl_model* m, int B, int Z, int Y, int X) {
@@ -896,6 +930,7 @@ int tfl_model_begin(tfl_ctx* c, tfl_model* m, const tfl_tensor* UDiv, const tfl_
                     float* workspace, int64_t workspace_floats, int zlo, int zhi, double* stats) {
   TRY(check_flags(c, "model_begin", flags));
   if (!m) return fail(c, TFL_EINVAL, "model_begin: null model");
+  TRY(range_gate(c, m, "model_begin"));
   const int is3D = m->is3d ? 1 : 0;
   TRY(check_vel(c, "model_begin", "UDiv", UDiv, flags, is3D));
   TRY(check_vel(c, "model_begin", "UOut", UOut, flags, is3D));
@@ -957,10 +992,15 @@ int tfl_model_finish(tfl_ctx* c, tfl_model* m, const tfl_tensor* pDiv, const tfl
   if (c->stages && !m->mfma3d) return fail(c, TFL_EUNSUPPORTED, "model_finish: stage masks need the 3-D default topology");
   if (m->mfma3d && m->m16) {
     // split-operand fp16 MFMA (conv_mfma16.hip); the two activation buffers hold the "h2" form (32 B per voxel, as 8 fp32)
-    if (stg & 1)
+    // layers 1 + 2 in one launch where the whole array is computed (round 5); a z-slab rank runs them under separate windows
+    const bool fused12 = (stg & 3) == 3 &&
+                         tfl::conv3_m16_first2_fused(st, B, Z, Y, X, pDiv->data, w.div, flags->data, st_in, count, m->wfrag16[0],
+                                                     m->layers[0].b, m->post16[0], m->wfrag16[1], m->layers[1].b, m->post16[1],
+                                                     w.act[1], m->d_range_err);
+    if ((stg & 1) && !fused12)
       tfl::conv3_m16_first_fused(st, B, Z, Y, X, pDiv->data, w.div, flags->data, st_in, count, m->wfrag16[0], m->layers[0].b,
                                  m->post16[0], w.act[0], m->d_range_err);
-    if (stg & 2)
+    if ((stg & 2) && !fused12)
       tfl::conv3_m16_mid(st, B, Z, Y, X, w.act[0], m->wfrag16[1], m->layers[1].b, m->post16[1], w.act[1], m->d_range_err);
     if (stg & 4)
       tfl::conv3_m16_tail(st, B, Z, Y, X, w.act[1], m->wfrag16[2], m->tail_pack, m->post16[2], w.pPred, m->d_range_err);
@@ -1029,7 +1069,8 @@ int tfl_model_finish(tfl_ctx* c, tfl_model* m, const tfl_tensor* pDiv, const tfl
   }
   if (stg & 8)
     tfl::model_project(st, m->is3d, B, Z, Y, X, w.pPred, flags->data, st_in, count, UOut->data, pOut->data,
-                       UBC ? UBC->data : nullptr, UBC ? UBCInvMask->data : nullptr, doClamp, lo, hi);
+                       UBC ? UBC->data : nullptr, UBC ? UBCInvMask->data : nullptr, doClamp, lo, hi,
+                       m->d_range_host ? m->d_range_err : nullptr, m->d_range_host);
   return check_launch(c, "model_finish");
 }
 

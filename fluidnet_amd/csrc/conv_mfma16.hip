@@ -52,6 +52,7 @@ namespace {
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+typedef _Float16 h4v __attribute__((ext_vector_type(4)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void glb_void;
@@ -74,7 +75,7 @@ enum { kModeIn = 0, kModeMid = 1, kModeTail = 2 };
 #endif
 
 // tail pack (tfl_model::tail_pack): {bias3[8], w4[8][8] (out, in), b4[8], w5[8], b5[1]}
-constexpr int kTailW4 = 8, kTailB4 = 72, kTailW5 = 80, kTailB5 = 88;
+constexpr int kTailW4 = 8, kTailB4 = 72, kTailW5 = 80, kTailB5 = 88, kTailPost4 = 89;   // + post4 (conv3_m16_pack_tail)
 
 struct MIn {            // fused network input (first layer): {pDiv/scale, div/scale, occupancy(flags)}
   const float* pDiv;    // [B][1][Z][Y][X]
@@ -90,6 +91,17 @@ __device__ __forceinline__ void split_h(float a, _Float16& hi, _Float16& lo) {
   lo = (_Float16)((a - (float)hi) * 2048.0f);
 }
 
+// (a, b) -> the packed hi halves and the packed lo halves of the split a = a_h + 2^-11 a_l (values in [0, 65504]). The lo half
+// is fp16(a 2^11 - a_h 2^11): both products and the difference are exact, so this is split_h's result in four instructions
+// per pair less (v_cvt_pk_f16_f32 + v_fma_mix instead of convert back / subtract / scale / convert)
+__device__ __forceinline__ void split_pair(float a, float b, uint32_t& H, uint32_t& L) {
+  const h2v ph = {(_Float16)a, (_Float16)b};
+  const float la = __builtin_fmaf((float)ph[0], -2048.0f, a * 2048.0f);
+  const float lb = __builtin_fmaf((float)ph[1], -2048.0f, b * 2048.0f);
+  const h2v pl = {(_Float16)la, (_Float16)lb};
+  H = __builtin_bit_cast(uint32_t, ph); L = __builtin_bit_cast(uint32_t, pl);
+}
+
 }  // namespace
 
 // 4 x 4 transpose of dwords across the four 16-lane groups of a wave: in: R[r] of group g = T[r][g]; out: R[c] of group g =
@@ -101,6 +113,24 @@ __device__ __forceinline__ void transpose4(uint32_t (&R)[4]) {
   auto t01 = __builtin_amdgcn_permlane16_swap(s02[0], s13[0], false, false);
   auto t23 = __builtin_amdgcn_permlane16_swap(s02[1], s13[1], false, false);
   R[0] = t01[0]; R[1] = t01[1]; R[2] = t23[0]; R[3] = t23[1];
+}
+
+// De-phase the blocks that share a CU (round 5). All blocks of a one-round launch start together and run the same sequence, so the
+// waves that share a SIMD -- one of each resident block -- reach their MFMA bursts, their epilogues and their waits TOGETHER: the
+// matrix pipe serialises the bursts and idles through everything else (SQ counters, profiles/r04_pmc_sq.txt: pipe busy 0.29 -
+// 0.52, waves 0.34 parked + 0.37 issue-stalled). A block delays its start by (hardware wave slot of its wave 0) x units x 64 clocks.
+__device__ __forceinline__ void stagger_start(int units, uint4* lds) {
+  if (units <= 0) return;             // uniform
+  volatile int* w = reinterpret_cast<volatile int*>(lds);
+  if (threadIdx.x == 0) w[0] = (int)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);   // HW_REG_HW_ID bits [3:0]: WAVE_ID
+  __syncthreads();
+  const int n = __builtin_amdgcn_readfirstlane(w[0]) * units;
+  __syncthreads();
+  for (int i = 0; i < n; i++) __builtin_amdgcn_s_sleep(1);
+}
+static int stagger_units(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
 }
 
 // a + b after v_permlane32_swap / v_permlane16_swap of the pair: the sum over the two lane halves (32) or over the odd /
@@ -590,16 +620,27 @@ constexpr int kPFrags = 14;                               // weight fragments: A
 #ifndef TFL_M16P_LB
 #define TFL_M16P_LB 2
 #endif
-template <bool TAIL>
+#ifndef TFL_M16P_DEFER
+#define TFL_M16P_DEFER 0
+#endif
+// timing ablations of k_conv3_m16p (tools/ab_build.sh; results are garbage): 1 = no staging DMA after the first planes,
+// 2 = no MFMAs, 4 = no stores, 8 = no LDS fragment reads, 16 = no per-plane barrier / DMA wait, 32 = no epilogue arithmetic
+#ifndef TFL_M16P_ABL
+#define TFL_M16P_ABL 0
+#endif
+// TMF (TAIL only, round 5): the 8 -> 8 (k = 1) layer of the tail as ONE v_mfma_f32_16x16x16_f16 per output row instead of
+// 16 multiply-adds and a six-swap reduce-scatter per row on the vector ALUs (see finish below)
+template <bool TAIL, bool TMF = false>
 __global__ __launch_bounds__(256, TFL_M16P_LB) void k_conv3_m16p(Dom d, int cols_x, int cols_y, int cz, int chunks_a, int chunks,
                                                                 int n_blocks, const uint4* __restrict__ in,
                                                                 const uint4* __restrict__ wfrag, const float* __restrict__ bias,
                                                                 void* __restrict__ outv, float post,
-                                                                unsigned long long* __restrict__ range_err) {
+                                                                unsigned long long* __restrict__ range_err, int stag) {
   extern __shared__ __attribute__((aligned(16))) uint4 lds[];
   const int per_xcd = (n_blocks + 7) / 8;
   const int blk = (int)(blockIdx.x % 8) * per_xcd + (int)(blockIdx.x / 8);
   if (blk >= n_blocks) return;
+  stagger_start(stag, lds);
   int t = blk;
   const int cx = t % cols_x; t /= cols_x;
   const int cy = t % cols_y; t /= cols_y;
@@ -660,17 +701,39 @@ __global__ __launch_bounds__(256, TFL_M16P_LB) void k_conv3_m16p(Dom d, int cols
   const int j0 = 4 * (g >> 1) + 2 * (g & 1);              // TAIL: the two hidden channels this lane finishes
   float b4a = 0.0f, b4b = 0.0f, w5a = 0.0f, w5b = 0.0f, b5 = 0.0f;
   float w4lo[4][2], w4hi[4][2];       // TAIL: the lane's 16 weights of the 8 -> 8 (k = 1) layer, fetched ONCE (round 4, late: they
+  h4v A4 = {0, 0, 0, 0};              // TMF: the lane's A fragment of that layer (conv3_m16_pack_tail) and its post-scale
+  float post4 = 0.0f;
   if (TAIL) {                         // were re-read from memory in every plane step, 16 loads + their waits behind the MFMAs)
     b4a = bias[kTailB4 + j0]; b4b = bias[kTailB4 + j0 + 1]; w5a = bias[kTailW5 + j0]; w5b = bias[kTailW5 + j0 + 1];
     b5 = bias[kTailB5];
+    if (TMF) {
+      A4 = __builtin_bit_cast(h4v, reinterpret_cast<const uint2*>(wfrag + (kPFrags * 64 + 1))[lane]);
+      post4 = bias[kTailPost4];
+    } else {
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-      w4lo[j][0] = bias[kTailW4 + j * 8 + c0]; w4lo[j][1] = bias[kTailW4 + j * 8 + c1];
-      w4hi[j][0] = bias[kTailW4 + (4 + j) * 8 + c0]; w4hi[j][1] = bias[kTailW4 + (4 + j) * 8 + c1];
+      for (int j = 0; j < 4; j++) {
+        w4lo[j][0] = bias[kTailW4 + j * 8 + c0]; w4lo[j][1] = bias[kTailW4 + j * 8 + c1];
+        w4hi[j][0] = bias[kTailW4 + (4 + j) * 8 + c0]; w4hi[j][1] = bias[kTailW4 + (4 + j) * 8 + c1];
+      }
     }
   }
 
   // finish output plane z from its accumulators: recombine, bias, ReLU, then split + transposed 16-byte stores, or the tail
+  float hmax = 0.0f;                  // TMF: the largest activation the lane split for the matrix cores (range check at the end)
+  // TFL_M16P_DEFER (A/B build): a plane's stores are issued behind the NEXT step's barrier instead of at the end of its own
+  // step, where the `s_waitcnt vmcnt(0)` that guards the DMA of the next plane would wait for their acknowledgement too
+  uint4 dH = make_uint4(0u, 0u, 0u, 0u), dL = dH;
+  float dP = 0.0f;
+  int dz = -1;
+  auto flush = [&]() {
+    if (dz < 0 || !(x < d.X && y < d.Y)) return;
+    if (!TAIL) {
+      uint4* orow = reinterpret_cast<uint4*>(outv) + (((long long)b * d.Z + dz) * d.Y + y) * 2 * d.X + x;
+      orow[0] = dH; orow[d.X] = dL;
+    } else {
+      reinterpret_cast<float*>(outv)[(long long)b * cells + TFL_AT(d, x, y, dz)] = dP;
+    }
+  };
   auto finish = [&](f4 (&A2)[4], int z) {
     const bool live = x < d.X && y < d.Y;
     float h0[4], h1[4];
@@ -681,23 +744,41 @@ __global__ __launch_bounds__(256, TFL_M16P_LB) void k_conv3_m16p(Dom d, int cols
     }
     if (!TAIL) {
       uint32_t H[4], L[4];
-      float hmax = 0.0f;              // the largest activation of the lane's eight (cells outside the grid see zero inputs:
-#pragma unroll                        // their activations are ReLU(bias)-sized and cannot fake a range error)
-      for (int oy = 0; oy < 4; oy++) {
+#pragma unroll                        // (hmax: cells outside the grid see zero inputs: their activations are ReLU(bias)-sized
+      for (int oy = 0; oy < 4; oy++) {   // and cannot fake a range error)
         hmax = __builtin_fmaxf(__builtin_fmaxf(hmax, h0[oy]), h1[oy]);
-        const float k0 = __builtin_fminf(h0[oy], kHalfMax), k1 = __builtin_fminf(h1[oy], kHalfMax);
-        _Float16 hh0, hl0, hh1, hl1;
-        split_h(k0, hh0, hl0); split_h(k1, hh1, hl1);
-        const h2v ph = {hh0, hh1}, pl = {hl0, hl1};
-        H[oy] = __builtin_bit_cast(uint32_t, ph); L[oy] = __builtin_bit_cast(uint32_t, pl);
+        split_pair(__builtin_fminf(h0[oy], kHalfMax), __builtin_fminf(h1[oy], kHalfMax), H[oy], L[oy]);
       }
-      clipped = clipped || !(hmax <= kHalfMax);
       transpose4(H); transpose4(L);
-      if (live) {
+      if (TFL_M16P_DEFER) { dH = make_uint4(H[0], H[1], H[2], H[3]); dL = make_uint4(L[0], L[1], L[2], L[3]); dz = z; }
+      else if ((TFL_M16P_ABL & 4) ? (post == 12345.0f) : live) {
         uint4* orow = reinterpret_cast<uint4*>(outv) + (((long long)b * d.Z + z) * d.Y + y) * 2 * d.X + x;
         orow[0] = make_uint4(H[0], H[1], H[2], H[3]);
         orow[d.X] = make_uint4(L[0], L[1], L[2], L[3]);
       }
+    } else if (TMF) {
+      // 8 -> 8 (k = 1) + ReLU on the matrix cores, the split riding on the recombination: after it the lane holds channels
+      // 2g, 2g + 1 of ONE voxel -- exactly K elements 4g .. 4g + 3 = {c_h, c'_h, c_l, c'_l} of column n of a 16 x 16 x 16
+      // B operand. A (conv3_m16_pack_tail): row 2 j + t = w4[j][.] 2^e4 as {w_h, w_l}, the columns of the hi terms times
+      // 2^11, so D[2 j] + 2^-11 D[2 j + 1] = 2^(11 + e4) sum_c w4[j][c] a_c as in the k = 3 layers; the lane gets rows
+      // 4g .. 4g + 3 = both halves of hidden channels 2g, 2g + 1 of its voxel. Then 8 -> 1: two products per lane and a
+      // reduce-scatter of the four rows over the four lane groups (3 swaps: group g ends up with row g, the row it stores).
+      float pp[4];
+#pragma unroll
+      for (int oy = 0; oy < 4; oy++) {
+        hmax = __builtin_fmaxf(__builtin_fmaxf(hmax, h0[oy]), h1[oy]);
+        uint32_t H, L;
+        split_pair(__builtin_fminf(h0[oy], kHalfMax), __builtin_fminf(h1[oy], kHalfMax), H, L);
+        const uint2 bq = make_uint2(H, L);
+        const f4 dq = __builtin_amdgcn_mfma_f32_16x16x16f16(A4, __builtin_bit_cast(h4v, bq), (f4){0.0f, 0.0f, 0.0f, 0.0f}, 0, 0, 0);
+        const float ha = __builtin_fmaxf(__builtin_fmaf(__builtin_fmaf(dq[1], 0x1p-11f, dq[0]), post4, b4a), 0.0f);
+        const float hb = __builtin_fmaxf(__builtin_fmaf(__builtin_fmaf(dq[3], 0x1p-11f, dq[2]), post4, b4b), 0.0f);
+        pp[oy] = __builtin_fmaf(w5a, ha, w5b * hb);
+      }
+      const float r02 = swap_sum32(pp[0], pp[2]), r13 = swap_sum32(pp[1], pp[3]);   // lower half: rows 0 / 1, upper: rows 2 / 3
+      const float psel = swap_sum16(r02, r13);                                       // group g: row g, summed over the groups
+      if (TFL_M16P_DEFER) { dP = psel + b5; dz = z; }
+      else if (live) reinterpret_cast<float*>(outv)[(long long)b * cells + TFL_AT(d, x, y, z)] = psel + b5;
     } else {
       // 8 -> 8 (k = 1) + ReLU, 8 -> 1 on the vector ALUs (see k_conv3_m16z)
       float psel = 0.0f;
@@ -727,9 +808,12 @@ __global__ __launch_bounds__(256, TFL_M16P_LB) void k_conv3_m16p(Dom d, int cols
 #pragma unroll 1
   for (int q = 2; q < nsteps; q++) {
     // planes q - 2, q - 1, q: everything issued so far has to have landed (plane q went out a whole step ago)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();                  // every wave's part of plane q is in LDS; every wave is done reading plane q - 3
-    issue(q + 1);                     // into the slot of plane q - 3 (past the chunk: the zero page)
+    if (!(TFL_M16P_ABL & 16)) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();                // every wave's part of plane q is in LDS; every wave is done reading plane q - 3
+    }
+    if (!(TFL_M16P_ABL & 1)) issue(q + 1);   // into the slot of plane q - 3 (past the chunk: the zero page)
+    if (TFL_M16P_DEFER) flush();      // the previous plane's stores: a whole step to complete before the next vmcnt(0)
     const int s0 = ((q - 2) % kPRing) * kMPitch, s1 = ((q - 1) % kPRing) * kMPitch, s2 = (q % kPRing) * kMPitch;
     const uint4* fa = lds + ((g == 3 ? s1 : s0) + slotA);
     const uint4* fb = lds + ((g < 2 ? s1 : s2) + slotB);
@@ -745,11 +829,12 @@ __global__ __launch_bounds__(256, TFL_M16P_LB) void k_conv3_m16p(Dom d, int cols
       for (int ry = 0; ry < 6; ry++)
 #pragma unroll
         for (int tm = 0; tm < 2; tm++) {
-          const h8 v = __builtin_bit_cast(h8, (kind == 0 ? fa : fb)[(ry * 2 + tm) * kMHX]);
+          const h8 v = (TFL_M16P_ABL & 8) ? W[(ry * 2 + tm + kind) % kPFrags] : __builtin_bit_cast(h8, (kind == 0 ? fa : fb)[(ry * 2 + tm) * kMHX]);
 #pragma unroll
           for (int dy = 0; dy < 3; dy++) {
             const int oy = ry - dy;
             if (oy < 0 || oy > 3) continue;
+            if (TFL_M16P_ABL & 2) { if (dy == 0) acc[oy] += __builtin_bit_cast(f4, v); continue; }
             acc[oy] = __builtin_amdgcn_mfma_f32_16x16x32_f16(W[kind * 6 + dy * 2 + tm], v, acc[oy], 0, 0, 0);
           }
         }
@@ -757,13 +842,20 @@ __global__ __launch_bounds__(256, TFL_M16P_LB) void k_conv3_m16p(Dom d, int cols
     for (int ry = 0; ry < 4; ry++)
 #pragma unroll
       for (int tm = 0; tm < 2; tm++) {
-        const h8 vc = __builtin_bit_cast(h8, fc[(ry * 2 + tm) * kMHX]);
+        const h8 vc = (TFL_M16P_ABL & 8) ? W[(ry + tm) % kPFrags] : __builtin_bit_cast(h8, fc[(ry * 2 + tm) * kMHX]);
+        if (TFL_M16P_ABL & 2) { acc[ry] += __builtin_bit_cast(f4, vc); continue; }
         acc[ry] = __builtin_amdgcn_mfma_f32_16x16x32_f16(W[12 + tm], vc, acc[ry], 0, 0, 0);
       }
-    finish(acc, zc0 + q - 2);
+    if (TFL_M16P_ABL & 32) {          // one word per lane keeps the accumulators alive
+      if ((TFL_M16P_ABL & 4) ? post == 12345.0f : (x < d.X && y < d.Y))
+        reinterpret_cast<float*>(outv)[((long long)b * cells + TFL_AT(d, x, y, zc0 + q - 2)) * (TAIL ? 1 : 8)] = acc[0][0] + acc[1][1] + acc[2][2] + acc[3][3];
+    } else {
+      finish(acc, zc0 + q - 2);
+    }
   }
+  if (TFL_M16P_DEFER) flush();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the trailing zero-page DMA must not outlive the block's LDS
-  if (clipped) atomicAdd(range_err, 1ull);
+  if (clipped || !(hmax <= kHalfMax)) atomicAdd(range_err, 1ull);
 }
 
 
@@ -783,11 +875,12 @@ constexpr int kIFrags = 7;                               // A(dy), B(dy), C
 __global__ __launch_bounds__(256, TFL_M16PI_LB) void k_conv3_m16p_in(Dom d, int cols_x, int cols_y, int cz, int chunks_a, int chunks,
                                                                     int n_blocks, MIn cin, const uint4* __restrict__ wfrag,
                                                                     const float* __restrict__ bias, void* __restrict__ outv,
-                                                                    float post, unsigned long long* __restrict__ range_err) {
+                                                                    float post, unsigned long long* __restrict__ range_err, int stag) {
   __shared__ __attribute__((aligned(16))) uint4 lds[kIRing * kIPlane];
   const int per_xcd = (n_blocks + 7) / 8;
   const int blk = (int)(blockIdx.x % 8) * per_xcd + (int)(blockIdx.x / 8);
   if (blk >= n_blocks) return;
+  stagger_start(stag, lds);
   int t = blk;
   const int cx = t % cols_x; t /= cols_x;
   const int cy = t % cols_y; t /= cols_y;
@@ -930,6 +1023,265 @@ __global__ __launch_bounds__(256, TFL_M16PI_LB) void k_conv3_m16p_in(Dom d, int 
   if (clipped) atomicAdd(range_err, 1ull);
 }
 
+// =====================================================================================================================
+// Layers 1 AND 2 in one z-marched launch (round 5). The split activations between the first two layers
+// -- 64 of the stack's 144 bytes per voxel, the traffic that bounds k_conv3_in / k_conv3_mid at 4.2-4.9 TB/s -- never reach
+// HBM: a block owns a 32 x 8 column, walks a chunk of z, and keeps TWO rings in LDS:
+//   R0  raw net input {p_h, d_h, occ, p_l, d_l, 0, 0, 0}, 36 x 12 voxels per plane (the column + 2), built plane by plane from
+//       pDiv / div / flags exactly as k_conv3_m16p_in builds it;
+//   R1  layer 1's output in the h2 form k_conv3_m16p stages ([row][term][x], 34 x 10 voxels = the column + 1).
+// Per step one raw plane arrives, ONE layer-1 plane (34 x 10 voxels: the x / y halo of layer 2's input is recomputed, 1.33 x
+// the layer's small MFMA work) is evaluated into R1 and ONE layer-2 plane leaves for HBM. Layer 1 runs on "free" tiles: an
+// MFMA's 16 columns are the 16 consecutive voxels v = 16 tile + n of the 340-voxel plane in row-major order, every lane
+// addresses its own voxel's taps (7 reads per 7 MFMAs instead of the row-shared 16 per 28; the layer is 7 MFMAs per tile),
+// and after the recombination a lane holds two channels of ONE voxel -- 4 bytes of the hi slot and 4 of the lo slot, stored
+// as two ds_write_b32 without the cross-lane transpose the 16-byte global stores need. Layer 2 is k_conv3_m16p's step on R1.
+// One barrier per step: layer 1 of step t writes the plane layer 2 reads from step t + 1 on (rings of four).
+//   step t:  raw plane t + 1 -> R0 (its words were loaded in step t - 1);  loads of raw plane t + 2 issued;
+//            layer 1 plane s = t - 2 from raw planes s, s + 1, s + 2;  layer 2 plane o = t - 5 from layer-1 planes o, o + 1, o + 2
+// Results are bit-identical to k_conv3_m16p_in + k_conv3_m16p<false> (the same MFMAs in the same order per voxel).
+constexpr int kF2RX = kMX + 4, kF2RY = kMY + 4;           // raw plane: 36 x 12 voxels, origin (x0 - 2, y0 - 2)
+constexpr int kF2RPlane = kF2RX * kF2RY;                  // 432 16-byte slots
+constexpr int kF2L1 = kMHX * kMHY;                        // 340 voxels of a layer-1 plane, origin (x0 - 1, y0 - 1)
+constexpr int kF2Tiles = (kF2L1 + 15) / 16;               // 22 tiles of 16 voxels: waves 0, 1 take six, waves 2, 3 five
+constexpr int kF2Ring = 4;
+constexpr int kF2Fill = 5;                                // steps of a chunk beyond its output planes
+constexpr size_t kF2Lds = (size_t)16 * kF2Ring * (kF2RPlane + kMPlane);    // 71 168 bytes: two blocks per CU
+
+#ifndef TFL_M16F2_LB
+#define TFL_M16F2_LB 2
+#endif
+__global__ __launch_bounds__(256, TFL_M16F2_LB) void k_conv3_m16p_f2(Dom d, int cols_x, int cols_y, int cz, int chunks_a, int chunks,
+                                                                    int n_blocks, MIn cin, const uint4* __restrict__ wf1,
+                                                                    const float* __restrict__ bias1, float post1,
+                                                                    const uint4* __restrict__ wf2, const float* __restrict__ bias2,
+                                                                    float post2, void* __restrict__ outv,
+                                                                    unsigned long long* __restrict__ range_err, int stag) {
+  extern __shared__ __attribute__((aligned(16))) uint4 lds[];
+  uint4* const R0 = lds;                                  // [kF2Ring][kF2RPlane]
+  uint4* const R1 = lds + kF2Ring * kF2RPlane;            // [kF2Ring][kMPlane]
+  const int per_xcd = (n_blocks + 7) / 8;
+  const int blk = (int)(blockIdx.x % 8) * per_xcd + (int)(blockIdx.x / 8);
+  if (blk >= n_blocks) return;
+  stagger_start(stag, lds);
+  int t0 = blk;
+  const int cx = t0 % cols_x; t0 /= cols_x;
+  const int cy = t0 % cols_y; t0 /= cols_y;
+  const int ch = t0 % chunks;
+  const int b = t0 / chunks;
+  const int zc0 = ch < chunks_a ? d.w0 + ch * cz : d.w1 + (ch - chunks_a) * cz;
+  const int z_end = ch < chunks_a ? d.w0 + d.n0 : d.w1 + (d.nw - d.n0);
+  const int nz = min(cz, z_end - zc0);                  // layer-2 planes this block writes
+  const int x0 = cx * kMX, y0 = cy * kMY;
+  const long long cells = d.sc;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  float hmax = 0.0f;                  // the largest activation this lane has produced (range check at the end)
+  bool clipped = false;
+
+  h8 W1[kIFrags], W2[kPFrags];
+#pragma unroll
+  for (int f = 0; f < kIFrags; f++) W1[f] = __builtin_bit_cast(h8, wf1[f * 64 + lane]);
+#pragma unroll
+  for (int f = 0; f < kPFrags; f++) W2[f] = __builtin_bit_cast(h8, wf2[f * 64 + lane]);
+
+  // lib/modules/variance.lua:44-76 (n-1) + Sqrt, as model.hip scale_from_stats
+  const double s1 = cin.stats[b * 2], s2 = cin.stats[b * 2 + 1], n = cin.count;
+  const float in_scale = (float)sqrt(fmax(n * s2 - s1 * s1, 0.0) / (n * (n - 1.0)));
+  const bool scale_in_range = in_scale >= 0x1p-12f && in_scale <= 0x1p21f;     // wave-uniform
+  const float inv_scale = scale_in_range ? rcp_refined(in_scale) : 0.0f;
+
+  // ---- raw planes: the thread's two slots (the second one only for tid < kF2RPlane - 256) ------------------------------
+  int st_off[2];
+  bool st_in[2];
+#pragma unroll
+  for (int j = 0; j < 2; j++) {
+    const int item = min(tid + 256 * j, kF2RPlane - 1);
+    const int hy = item / kF2RX, hx = item - hy * kF2RX;
+    const int gx = x0 - 2 + hx, gy = y0 - 2 + hy;
+    st_off[j] = min(max(gy, 0), d.Y - 1) * d.sy + min(max(gx, 0), d.X - 1);
+    st_in[j] = gx >= 0 && gx < d.X && gy >= 0 && gy < d.Y;
+  }
+  const float* pP = cin.pDiv + (long long)b * cells;
+  const float* pD = cin.div + (long long)b * cells;
+  const float* pF = cin.flags + (long long)b * cells;
+  float raw[2][3];
+  auto load_raw = [&](int r) {        // words of raw plane r of the chunk (z = zc0 - 2 + r)
+    const int gz = min(max(zc0 - 2 + r, 0), d.Z - 1);
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      if (j == 1 && tid >= kF2RPlane - 256) continue;
+      const int o = gz * d.sz + st_off[j];
+      raw[j][0] = pP[o]; raw[j][1] = pD[o]; raw[j][2] = pF[o];
+    }
+  };
+  auto write_raw = [&](int r) {       // -> R0 slot r & 3; the net input is built here (as k_conv3_m16p_in's write_plane)
+    const int gz = zc0 - 2 + r;
+    const bool z_ok = gz >= 0 && gz < d.Z;
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      if (j == 1 && tid >= kF2RPlane - 256) continue;
+      float v0, v1;
+      if (scale_in_range) { v0 = div_by<1>(raw[j][0], in_scale, inv_scale); v1 = div_by<1>(raw[j][1], in_scale, inv_scale); }
+      else { v0 = raw[j][0] / in_scale; v1 = raw[j][1] / in_scale; }
+      const int f = (int)raw[j][2];
+      const float occ = (f == kFluid) ? 0.0f : ((f == kObstacle) ? 1.0f : -1.0f);
+      const float k0 = __builtin_fminf(__builtin_fmaxf(v0, -kHalfMax), kHalfMax), k1 = __builtin_fminf(__builtin_fmaxf(v1, -kHalfMax), kHalfMax);
+      const bool ok = z_ok && st_in[j];
+      clipped = clipped || (ok && (k0 != v0 || k1 != v1));
+      h8 sv = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (ok) {
+        _Float16 ph, pl, dh, dl;
+        split_h(k0, ph, pl); split_h(k1, dh, dl);
+        sv[0] = ph; sv[1] = dh; sv[2] = (_Float16)occ; sv[3] = pl; sv[4] = dl;
+      }
+      R0[(r & 3) * kF2RPlane + tid + 256 * j] = __builtin_bit_cast(uint4, sv);
+    }
+  };
+
+  // ---- layer 1: the lane's voxel of each of the wave's tiles ----------------------------------------------------------------
+  const int nn = lane & 15, g = lane >> 4;
+  constexpr int kTPW = 6;
+  int l1_base[kTPW], l1_out[kTPW];    // slot of the voxel's first tap in a raw plane; byte offset of its 4 bytes in an R1 plane
+  unsigned l1_keep = 0, l1_live = 0;  // bit i: the voxel exists / lies inside the grid (outside: layer 2's zero padding)
+#pragma unroll
+  for (int i = 0; i < kTPW; i++) {
+    const int tl = wave + 4 * i, v = tl * 16 + nn;
+    const bool ok = tl < kF2Tiles && v < kF2L1;
+    const int vc = min(v, kF2L1 - 1);
+    const int ry = vc / kMHX, rx = vc - ry * kMHX;
+    l1_base[i] = ry * kF2RX + rx;
+    l1_out[i] = ((ry * 2) * kMHX + rx) * 16 + 4 * g;
+    const int gx = x0 - 1 + rx, gy = y0 - 1 + ry;
+    l1_keep |= ok ? (1u << i) : 0u;
+    l1_live |= (ok && gx >= 0 && gx < d.X && gy >= 0 && gy < d.Y) ? (1u << i) : 0u;
+  }
+  const bool six = wave < 2;          // 22 tiles: waves 0 and 1 own a sixth one
+  // K group g of the three fragment kinds (as k_conv3_m16p_in): A = {(dz 0; dx 0, 1, 2), (dz 1; dx 0)},
+  // B = {(dz 1; dx 1, 2), (dz 2; dx 0, 1)}, C = {(dz 2, dx 2) of dy = 0, 1, 2}
+  const int cA = g < 3 ? g : 0;
+  const int cB = g == 0 ? 1 : (g == 1 ? 2 : (g == 2 ? 0 : 1));
+  const int cC = 2 + (g < 3 ? g : 0) * kF2RX;
+  const float b1a = bias1[2 * g], b1b = bias1[2 * g + 1];
+
+  // ---- layer 2 (k_conv3_m16p's geometry on R1) ----------------------------------------------------------------------------
+  const int wx = wave & 1, wy = wave >> 1;
+  const int row0 = (wy * 4 * 2) * kMHX + wx * 16 + nn;
+  const int slotA = row0 + (g < 3 ? g : 0);
+  const int slotB = row0 + (g == 0 ? 1 : (g == 1 ? 2 : (g == 2 ? 0 : 1)));
+  const int slotC = row0 + 2 + (g < 3 ? g : 0) * 2 * kMHX;
+  const int x = x0 + wx * 16 + nn;
+  const int y = y0 + wy * 4 + g;                          // the row this lane group stores (after the transpose)
+  const float b2a = bias2[2 * g], b2b = bias2[2 * g + 1];
+
+  // tiles I0 .. I0 + N - 1 of the wave: 7 MFMAs each, interleaved over the tiles (a dependent MFMA right behind its producer
+  // stalls the pipe), then recombine / bias / ReLU / zero outside the grid / split / two 4-byte LDS stores
+  auto l1_tiles = [&](auto i0_c, auto n_c, const uint4* pA, const uint4* pB, const uint4* pC, char* r1p) {
+    constexpr int I0 = decltype(i0_c)::value, N = decltype(n_c)::value;
+    f4 a[N];
+#pragma unroll
+    for (int u = 0; u < N; u++) a[u] = (f4){0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int dy = 0; dy < 3; dy++)
+#pragma unroll
+      for (int u = 0; u < N; u++)
+        a[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(W1[dy], __builtin_bit_cast(h8, pA[l1_base[I0 + u] + dy * kF2RX]), a[u], 0, 0, 0);
+#pragma unroll
+    for (int dy = 0; dy < 3; dy++)
+#pragma unroll
+      for (int u = 0; u < N; u++)
+        a[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(W1[3 + dy], __builtin_bit_cast(h8, pB[l1_base[I0 + u] + dy * kF2RX]), a[u], 0, 0, 0);
+#pragma unroll
+    for (int u = 0; u < N; u++)
+      a[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(W1[6], __builtin_bit_cast(h8, pC[l1_base[I0 + u]]), a[u], 0, 0, 0);
+#pragma unroll
+    for (int u = 0; u < N; u++) {
+      const bool live = (l1_live >> (I0 + u)) & 1u;
+      float h0 = __builtin_fmaxf(__builtin_fmaf(__builtin_fmaf(a[u][1], 0x1p-11f, a[u][0]), post1, b1a), 0.0f);
+      float h1 = __builtin_fmaxf(__builtin_fmaf(__builtin_fmaf(a[u][3], 0x1p-11f, a[u][2]), post1, b1b), 0.0f);
+      h0 = live ? h0 : 0.0f; h1 = live ? h1 : 0.0f;
+      hmax = __builtin_fmaxf(__builtin_fmaxf(hmax, h0), h1);
+      uint32_t H, L;
+      split_pair(__builtin_fminf(h0, kHalfMax), __builtin_fminf(h1, kHalfMax), H, L);
+      if ((l1_keep >> (I0 + u)) & 1u) {
+        *reinterpret_cast<uint32_t*>(r1p + l1_out[I0 + u]) = H;
+        *reinterpret_cast<uint32_t*>(r1p + l1_out[I0 + u] + kMHX * 16) = L;
+      }
+    }
+  };
+
+  load_raw(0); write_raw(0); load_raw(1);
+#pragma unroll 1
+  for (int t = 0; t < nz + kF2Fill; t++) {
+    __syncthreads();                  // raw planes <= t and layer-1 planes <= t - 3 are in LDS; every wave is done with step t - 1
+    write_raw(t + 1);                 // slot of raw plane t - 3
+    load_raw(t + 2);                  // in flight for a whole step
+    const int o = t - 5, s = t - 2;
+    f4 acc[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) acc[r] = (f4){0.0f, 0.0f, 0.0f, 0.0f};
+    if (o >= 0) {                     // block-uniform: layer 2, plane o (as k_conv3_m16p)
+      const int q0 = (o & 3) * kMPlane, q1 = ((o + 1) & 3) * kMPlane, q2 = ((o + 2) & 3) * kMPlane;
+      const uint4* fa = R1 + ((g == 3 ? q1 : q0) + slotA);
+      const uint4* fb = R1 + ((g < 2 ? q1 : q2) + slotB);
+      const uint4* fc = R1 + (q2 + slotC);
+#pragma unroll
+      for (int kind = 0; kind < 2; kind++)
+#pragma unroll
+        for (int ry = 0; ry < 6; ry++)
+#pragma unroll
+          for (int tm = 0; tm < 2; tm++) {
+            const h8 v = __builtin_bit_cast(h8, (kind == 0 ? fa : fb)[(ry * 2 + tm) * kMHX]);
+#pragma unroll
+            for (int dy = 0; dy < 3; dy++) {
+              const int oy = ry - dy;
+              if (oy < 0 || oy > 3) continue;
+              acc[oy] = __builtin_amdgcn_mfma_f32_16x16x32_f16(W2[kind * 6 + dy * 2 + tm], v, acc[oy], 0, 0, 0);
+            }
+          }
+#pragma unroll
+      for (int ry = 0; ry < 4; ry++)
+#pragma unroll
+        for (int tm = 0; tm < 2; tm++) {
+          const h8 vc = __builtin_bit_cast(h8, fc[(ry * 2 + tm) * kMHX]);
+          acc[ry] = __builtin_amdgcn_mfma_f32_16x16x32_f16(W2[12 + tm], vc, acc[ry], 0, 0, 0);
+        }
+    }
+    if (s >= 0 && s <= nz + 1) {      // block-uniform: layer 1, plane s (z = zc0 - 1 + s)
+      const int z1 = zc0 - 1 + s;
+      char* r1p = reinterpret_cast<char*>(R1 + (s & 3) * kMPlane);
+      if (z1 >= 0 && z1 < d.Z) {
+        const int p0 = (s & 3) * kF2RPlane, p1 = ((s + 1) & 3) * kF2RPlane, p2 = ((s + 2) & 3) * kF2RPlane;
+        const uint4* pA = R0 + ((g == 3 ? p1 : p0) + cA);
+        const uint4* pB = R0 + ((g < 2 ? p1 : p2) + cB);
+        const uint4* pC = R0 + (p2 + cC);
+        l1_tiles(std::integral_constant<int, 0>(), std::integral_constant<int, 3>(), pA, pB, pC, r1p);
+        if (six) l1_tiles(std::integral_constant<int, 3>(), std::integral_constant<int, 3>(), pA, pB, pC, r1p);
+        else l1_tiles(std::integral_constant<int, 3>(), std::integral_constant<int, 2>(), pA, pB, pC, r1p);
+      } else {                        // a plane outside the grid is layer 2's zero padding, not conv(0) = ReLU(bias)
+        for (int it = tid; it < kMPlane; it += 256) reinterpret_cast<uint4*>(r1p)[it] = make_uint4(0u, 0u, 0u, 0u);
+      }
+    }
+    if (o >= 0) {                     // layer 2's epilogue: recombine, bias, ReLU, split, transposed 16-byte stores
+      const int z = zc0 + o;
+      uint32_t H[4], L[4];
+#pragma unroll
+      for (int oy = 0; oy < 4; oy++) {
+        const float h0 = __builtin_fmaxf(__builtin_fmaf(__builtin_fmaf(acc[oy][1], 0x1p-11f, acc[oy][0]), post2, b2a), 0.0f);
+        const float h1 = __builtin_fmaxf(__builtin_fmaf(__builtin_fmaf(acc[oy][3], 0x1p-11f, acc[oy][2]), post2, b2b), 0.0f);
+        hmax = __builtin_fmaxf(__builtin_fmaxf(hmax, h0), h1);
+        split_pair(__builtin_fminf(h0, kHalfMax), __builtin_fminf(h1, kHalfMax), H[oy], L[oy]);
+      }
+      transpose4(H); transpose4(L);
+      if (x < d.X && y < d.Y) {
+        uint4* orow = reinterpret_cast<uint4*>(outv) + (((long long)b * d.Z + z) * d.Y + y) * 2 * d.X + x;
+        orow[0] = make_uint4(H[0], H[1], H[2], H[3]);
+        orow[d.X] = make_uint4(L[0], L[1], L[2], L[3]);
+      }
+    }
+  }
+  if (clipped || !(hmax <= kHalfMax)) atomicAdd(range_err, 1ull);
+}
+
 // compute units of the current device (cached per device)
 static int device_cus() {
   static std::atomic<int> cus[64];
@@ -966,10 +1318,10 @@ static int blocks_per_cu(const void* fn, size_t lds, int fallback) {
 // columns, 24 .. 136 planes, chunks of 2 .. 64): 8 -> 8 layers L = 0.70, W = 0.35 us, first layer 0.95 / 0.24. On a full
 // 128^3 / 256^3 grid the choice is the one the round counting of launch_m16z makes (11 / 8 planes at 128^3); on the thin
 // windows of a z-slab rank it picks short chunks (24 planes of 128^2: 3 instead of 8, -4 us per layer).
-static int pick_chunk(long long cols, int na, int nb, int slots, int cus, float L, float W) {
+static int pick_chunk(long long cols, int na, int nb, int slots, int cus, float L, float W, int fill = 4, int cmax = 32) {
   int cz = 8;
   float best = -1.0f;
-  for (int c = 2; c <= 32; c++) {
+  for (int c = 2; c <= cmax; c++) {
     long long blocks = cols * ((na + c - 1) / c + (nb + c - 1) / c);
     float per_step = 0.0f;
     while (blocks > 0) {
@@ -977,7 +1329,7 @@ static int pick_chunk(long long cols, int na, int nb, int slots, int cus, float 
       per_step += L + W * (float)((r + cus - 1) / cus);
       blocks -= r;
     }
-    const float cost = (float)(c + 4) * per_step;
+    const float cost = (float)(c + fill) * per_step;
     if (best < 0.0f || cost < best) { best = cost; cz = c; }
   }
   return cz;
@@ -1048,8 +1400,47 @@ static void launch_m16p(hipStream_t st, const Dom& d, int B, const void* in, con
   // the fragments of this kernel lie behind those of k_conv3_m16z in the layer's buffer (conv3_m16_pack_weights)
   const uint4* wp = (const uint4*)wfrag + (9 * 2 * 64 + 1);
   TFL_TIMED_EXT(TAIL ? "k_conv3_tail" : "k_conv3_mid", st);
-  TFL_LAUNCH_EXT((k_conv3_m16p<TAIL>), grid, 256, lds_bytes, st, d, cxn, cyn, cz, chunks_a, chunks, n_blocks, (const uint4*)in,
-                 wp, bias, out, post, range_err);
+  // the tail's 1 x 1 x 1 layers: on the matrix cores (round 5) unless TFL_M16_TAIL_MFMA=0 (the vector-ALU epilogue, kept for A/B)
+  const char* etm = getenv("TFL_M16_TAIL_MFMA");       // (read per call: the tests switch it inside one process)
+  const bool tmf = !(etm && atoi(etm) == 0);
+  if (TAIL && tmf)
+    TFL_LAUNCH_EXT((k_conv3_m16p<TAIL, TAIL>), grid, 256, lds_bytes, st, d, cxn, cyn, cz, chunks_a, chunks, n_blocks, (const uint4*)in,
+                   wp, bias, out, post, range_err, stagger_units("TFL_M16_STAGGER", 0));
+  else
+    TFL_LAUNCH_EXT((k_conv3_m16p<TAIL, false>), grid, 256, lds_bytes, st, d, cxn, cyn, cz, chunks_a, chunks, n_blocks, (const uint4*)in,
+                   wp, bias, out, post, range_err, stagger_units("TFL_M16_STAGGER", 0));
+}
+
+// layers 1 + 2 in one launch (k_conv3_m16p_f2): false = not taken. OFF unless TFL_M16_FUSE12=1: measured SLOWER than the two
+// launches (profiles/r05_conv_experiments.txt: 72 us against 27 + 32.5 at 128^3, 532 against 200 + 263 at 256^3 -- these
+// kernels run at the SUM of their instruction streams, and the recomputed halo + the generic tiles make the fused stream
+// 15 % longer than the two it replaces; the 64 B/voxel it keeps out of HBM do not bind). Never taken under a z-window (the
+// slab step runs every layer under its own window; the fused kernel would recompute layer 1 where the window says it is
+// not valid).
+static bool launch_m16p_f2(hipStream_t st, const Dom& d, int B, MIn cin, const void* wfrag1, const float* bias1, float post1,
+                           const void* wfrag2, const float* bias2, float post2, void* out, unsigned long long* range_err) {
+  const char* ef = getenv("TFL_M16_FUSE12");           // (read per call: the tests switch it inside one process)
+  if (!(ef && atoi(ef) == 1) || d.nw != d.Z || d.n0 != d.Z) return false;
+  const int cxn = (d.X + kMX - 1) / kMX, cyn = (d.Y + kMY - 1) / kMY;
+  if ((long long)cxn * cyn * d.Z * B <= 0) return true;
+  const int slots = device_cus() * blocks_per_cu((const void*)k_conv3_m16p_f2, kF2Lds, TFL_M16F2_LB);
+  if (slots <= 0) return false;
+  // a step carries both layers (~1.7 x the 8 -> 8 layer's) and a chunk has five fill steps: longer chunks than k_conv3_m16p's
+  int cz = pick_chunk((long long)cxn * cyn * B, d.Z, 0, slots, device_cus(), 1.10f, 0.55f, kF2Fill + 2, 128);
+  if (const char* e = getenv("TFL_M16_CZ_F2")) cz = atoi(e) > 0 ? atoi(e) : cz;
+  const int chunks_a = (d.Z + cz - 1) / cz, chunks = chunks_a;
+  const int n_blocks = cxn * cyn * chunks * B;
+  const int grid = ((n_blocks + 7) / 8) * 8;
+  if (getenv("TFL_DEBUG")) {
+    static bool said = false;
+    if (!said) { said = true; fprintf(stderr, "[tfl] k_conv3_m16p_f2: dynamic LDS %zu B, %d block slots, grid %d, chunks of %d planes\n", kF2Lds, slots, grid, cz); }
+  }
+  const uint4* w1 = (const uint4*)wfrag1 + (9 * 64 + 1);          // the K-packed fragments (conv3_m16_pack_weights)
+  const uint4* w2 = (const uint4*)wfrag2 + (9 * 2 * 64 + 1);
+  TFL_TIMED_EXT("k_conv3_in_mid", st);
+  TFL_LAUNCH_EXT(k_conv3_m16p_f2, grid, 256, kF2Lds, st, d, cxn, cyn, cz, chunks_a, chunks, n_blocks, cin, w1, bias1, post1, w2, bias2,
+                 post2, out, range_err, stagger_units("TFL_M16_STAGGER_F2", 0));
+  return true;
 }
 
 
@@ -1070,7 +1461,8 @@ static void launch_m16p_in(hipStream_t st, const Dom& d, int B, MIn cin, const v
   }
   const uint4* wp = (const uint4*)wfrag + (9 * 64 + 1);     // behind the tile kernel's fragments (conv3_m16_pack_weights)
   TFL_TIMED_EXT("k_conv3_in", st);
-  TFL_LAUNCH_EXT(k_conv3_m16p_in, grid, 256, 0, st, d, cxn, cyn, cz, chunks_a, chunks, n_blocks, cin, wp, bias, out, post, range_err);
+  TFL_LAUNCH_EXT(k_conv3_m16p_in, grid, 256, 0, st, d, cxn, cyn, cz, chunks_a, chunks, n_blocks, cin, wp, bias, out, post, range_err,
+                 stagger_units("TFL_M16_STAGGER_IN", 0));
 }
 
 template <int MODE>
@@ -1119,6 +1511,14 @@ void conv3_m16_first_fused(hipStream_t st, int B, int Z, int Y, int X, const flo
   static const bool kpack = !(getenv("TFL_M16_KPACK") && (atoi(getenv("TFL_M16_KPACK")) == 0 || atoi(getenv("TFL_M16_KPACK")) == 2));   // 0 / 2: the tile kernel
   if (kpack) { launch_m16p_in(st, make_dom(Z, Y, X), B, ci, wfrag, bias, out_h2, post, range_err); return; }
   launch_m16<kModeIn>(st, make_dom(Z, Y, X), B, nullptr, wfrag, bias, out_h2, post, ci, range_err);
+}
+bool conv3_m16_first2_fused(hipStream_t st, int B, int Z, int Y, int X, const float* pDiv, const float* div, const float* flags,
+                            const double* stats, double count, const void* wfrag1, const float* bias1, float post1,
+                            const void* wfrag2, const float* bias2, float post2, void* out_h2, unsigned long long* range_err) {
+  static const bool kpack = !(getenv("TFL_M16_KPACK") && (atoi(getenv("TFL_M16_KPACK")) == 0 || atoi(getenv("TFL_M16_KPACK")) == 2));
+  if (!kpack || (getenv("TFL_M16_TILED") && atoi(getenv("TFL_M16_TILED")) != 0)) return false;
+  MIn ci = {pDiv, div, flags, stats, count};
+  return launch_m16p_f2(st, make_dom(Z, Y, X), B, ci, wfrag1, bias1, post1, wfrag2, bias2, post2, out_h2, range_err);
 }
 void conv3_m16_mid(hipStream_t st, int B, int Z, int Y, int X, const void* in_h2, const void* wfrag, const float* bias, float post,
                    void* out_h2, unsigned long long* range_err) {
@@ -1178,7 +1578,28 @@ float h2f(uint16_t h) {
 // are zero: the source of the kernels' out-of-grid staging slots) and, for cin == 8, the K-packed fragments of
 // k_conv3_m16p behind them ((14 * 64 + 1) * 8); returns the post-scale 2^-(11 + e)
 size_t conv3_m16_frag_halves(int cin) {
-  return cin == 3 ? ((size_t)9 * 64 + 1) * 8 + ((size_t)7 * 64 + 1) * 8 : ((size_t)9 * 2 * 64 + 1) * 8 + ((size_t)14 * 64 + 1) * 8;
+  return cin == 3 ? ((size_t)9 * 64 + 1) * 8 + ((size_t)7 * 64 + 1) * 8
+                  : ((size_t)9 * 2 * 64 + 1) * 8 + ((size_t)14 * 64 + 1) * 8 + (size_t)64 * 4;   // + the tail's 1 x 1 x 1 A fragment
+}
+// The A fragment of the tail's 8 -> 8 (k = 1) layer for v_mfma_f32_16x16x16_f16 (k_conv3_m16p<true, true>), written behind the
+// K-packed fragments of a cin == 8 layer buffer: lane (m = lane & 15, g = lane >> 4) holds A[m][4g .. 4g + 3]; row m = 2 j + t
+// = output channel j as {w_h, w_l} of w4[j][c] 2^e4; column 4g + i = input channel c = 2g + (i & 1), activation term i >> 1
+// (0: the high halves, their weights pre-multiplied by 2^11). Returns the post-scale 2^-(11 + e4).
+float conv3_m16_pack_tail(const float* w4, uint16_t* frag_buf) {
+  float mx = 0.0f;
+  for (int i = 0; i < 64; i++) mx = fmaxf(mx, fabsf(w4[i]));
+  int e = 0;
+  if (mx > 0.0f && std::isfinite(mx)) { int ex; (void)frexpf(mx, &ex); e = 4 - ex; }       // mx 2^e in [8, 16)
+  uint16_t* o = frag_buf + ((size_t)9 * 2 * 64 + 1) * 8 + ((size_t)14 * 64 + 1) * 8;
+  for (int lane = 0; lane < 64; lane++)
+    for (int i = 0; i < 4; i++) {
+      const int m = lane & 15, g = lane >> 4, j = m >> 1, wt = m & 1, c = 2 * g + (i & 1);
+      const float ws = ldexpf(w4[j * 8 + c], e);
+      const float wh = h2f(f2h(ws));
+      const float base = wt ? h2f(f2h((ws - wh) * 2048.0f)) : wh;
+      o[lane * 4 + i] = f2h((i >> 1) == 0 ? base * 2048.0f : base);
+    }
+  return ldexpf(1.0f, -(11 + e));
 }
 float conv3_m16_pack_weights(const float* w, int cin, uint16_t* out) {
   const int RT = cin == 3 ? 1 : 2;

@@ -341,7 +341,17 @@ struct BcArgs {  // optional fused tail of simulate(): setConstVals + clamp, sim
   const float* UBC; const float* UInvMask;   // a dense pair: acts on every cell
   BcFoldArg fold;                            // or tfl_simulate_step's sparse pair with its box (tfl_host.hpp)
   int enable_clamp; float lo, hi;
+  // the fp16 conv path's range-error count (device word, final once the conv kernels are done) and the pinned host word a
+  // non-zero count is copied to, so that the host sees it at its next call without a stream sync (abi.cpp range_gate)
+  const unsigned long long* range_src; unsigned long long* range_dst;
 };
+// one thread of the launch forwards a non-zero count (the host word is only written when something went wrong)
+__device__ __forceinline__ void forward_range_count(const BcArgs& bc, bool first_thread) {
+  if (bc.range_src && first_thread) {
+    const unsigned long long v = *bc.range_src;
+    if (v) *bc.range_dst = v;
+  }
+}
 
 template <bool IS3D>
 __global__ __launch_bounds__(256) void k_project(Dom d, const float* __restrict__ pPred, const float* __restrict__ flags,
@@ -350,6 +360,7 @@ __global__ __launch_bounds__(256) void k_project(Dom d, const float* __restrict_
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int j = blockIdx.y * blockDim.y + threadIdx.y;
   int b, k; dom_bk(d, b, k);
+  forward_range_count(bc, (blockIdx.x | blockIdx.y | blockIdx.z | threadIdx.x | threadIdx.y) == 0);
   if (i >= d.X || j >= d.Y) return;
   const long long cells = d.sc;
   const int C = IS3D ? 3 : 2;
@@ -402,6 +413,7 @@ __global__ __launch_bounds__(256, TFL_LB_PROJECT) void k_project_v4(Dom d, const
   const int i0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
   const int j = blockIdx.y * blockDim.y + threadIdx.y;
   int b, k; dom_bk(d, b, k);
+  forward_range_count(bc, (blockIdx.x | blockIdx.y | blockIdx.z | threadIdx.x | threadIdx.y) == 0);
   if (i0 >= d.X || j >= d.Y) return;
   const long long cells = d.sc;
   const int C = IS3D ? 3 : 2;
@@ -622,11 +634,12 @@ void model_skip_channel(hipStream_t st, int B, long long cells, const float* pDi
 
 void model_project(hipStream_t st, bool is3d, int B, int Z, int Y, int X, const float* pPred, const float* flags,
                    const double* stats, double count, float* Uio, float* pOut, const float* UBC, const float* UInvMask,
-                   int do_clamp, float lo, float hi) {
+                   int do_clamp, float lo, float hi, const unsigned long long* range_src, unsigned long long* range_dst) {
   const Dom d = make_dom(Z, Y, X);
   const dim3 blk(64, 4, 1), grd = TFL_GRID3(d, B);
   // a dense pair acts everywhere; without one, tfl_simulate_step's sparse pair (if it asked: tfl_host.hpp BcFold) in its box
   BcArgs bc; bc.enable_clamp = do_clamp; bc.lo = lo; bc.hi = hi;
+  bc.range_src = range_dst ? range_src : nullptr; bc.range_dst = range_dst;
   bc.UBC = UBC; bc.UInvMask = UInvMask; bc.fold = UBC ? no_fold() : take_fold();
   const uintptr_t al = (uintptr_t)pPred | (uintptr_t)flags | (uintptr_t)Uio | (uintptr_t)pOut | (uintptr_t)UBC |
                        (uintptr_t)UInvMask;

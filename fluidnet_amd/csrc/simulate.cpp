@@ -175,6 +175,13 @@ int tfl_simulate_step(tfl_ctx* c, const tfl_sim_params* prm, const tfl_sim_state
   const bool ours = std::strcmp(method, "maccormackOurs") == 0;
   auto view = [&](float* base, int C) { tfl_tensor t = *s->flags; t.data = base; t.C = C; return t; };
   int rc;
+  // an earlier step's projection left the fp16 range of the default 3-D conv path (no sync: the word the projection kernel
+  // wrote to pinned memory): refuse to step on from a clamped pressure, before anything of this step has been written
+  if (s->model && method_of(prm) == "convnet" && tfl_model_range_flag(c, s->model) > 0) {
+    c->err = "simulate_step: an earlier step's ConvNet projection clamped activations at the fp16 range (a blown-up simulation); "
+             "read the count with tfl_model_range_errors, or create the model under TFL_CONV_PATH=winograd (strict fp32)";
+    return TFL_ERANGE;
+  }
 
   // ---- advection (simulate.lua:183-200): every density channel with the pre-advection U, then U ----------------
   unsigned density_done = 0;
@@ -595,6 +602,13 @@ int tfl_simulate_step_slab(tfl_ctx* c, const tfl_sim_params* prm, const tfl_sim_
       c->err = buf;
       return TFL_EINVAL;
     }
+  }
+  if (s->model && tfl_model_range_flag(c, s->model) > 0) {      // as tfl_simulate_step; the neighbours' receives are finished first
+    for (int t = 0; t < 2; t++)
+      if (multi && (sl->in_flight & (1 << t))) { (void)msg_finish(c, g, comm, m[t]); sl->in_flight &= ~(1 << t); }
+    c->err = "simulate_step_slab: an earlier step's ConvNet projection clamped activations at the fp16 range (a blown-up simulation); "
+             "read the count with tfl_model_range_errors, or create the model under TFL_CONV_PATH=winograd (strict fp32)";
+    return TFL_ERANGE;
   }
   if (sl->in_flight & 1) { rc = msg_finish(c, g, comm, m[0]); if (rc) return rc; sl->in_flight &= ~1; }     // U and p halos
   if (sl->check_reach) {

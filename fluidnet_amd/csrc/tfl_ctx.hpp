@@ -26,5 +26,7 @@ struct tfl_ctx {
   bool reach_pending = false;
   tfl::BcFoldArg fold = {nullptr, 0u, 0u};    // tfl_simulate_step: a setConstVals pair (device descriptor + gate) the next operator may apply to its output
   bool fold_done = false;                     // ... and whether a launcher did (tfl_host.hpp BcFold)
-  bool wf_timed_out = false;                  // a pipelined PCG sweep timed out on this context once: later solves go straight to hyperplane sweeps
+  int wf_skip = 0;                            // > 0: a pipelined PCG sweep timed out on this context: the next wf_skip solves go straight to
+                                              // hyperplane sweeps, then the pipelined form is tried again (a transient stall must not latch for good)
+  int wf_timeouts = 0;                        // how often that happened (the back-off doubles, one warning per latch)
 };

@@ -168,7 +168,8 @@ void model_skip_channel(hipStream_t st, int B, long long cells, const float* pDi
                         float* dst, int och, int ch);
 void model_project(hipStream_t st, bool is3d, int B, int Z, int Y, int X, const float* pPred, const float* flags,
                    const double* stats, double count, float* Uio, float* pOut, const float* UBC, const float* UInvMask,
-                   int do_clamp, float lo, float hi);
+                   int do_clamp, float lo, float hi, const unsigned long long* range_src = nullptr,
+                   unsigned long long* range_dst = nullptr);
 void apply_bcs(hipStream_t st, long long n, float* x, const float* bcv, const float* inv, int do_clamp, float lo,
                float hi);
 
@@ -221,7 +222,13 @@ void conv3_m16_mid(hipStream_t st, int B, int Z, int Y, int X, const void* in_h2
                    void* out_h2, unsigned long long* range_err);
 void conv3_m16_tail(hipStream_t st, int B, int Z, int Y, int X, const void* in_h2, const void* wfrag, const float* tail_pack,
                     float post, float* p_out, unsigned long long* range_err);
+// layers 1 + 2 in ONE launch (round 5: the 64 B/voxel between them stay in LDS); false = not taken (z-window set, or switched
+// off): the caller runs conv3_m16_first_fused + conv3_m16_mid
+bool conv3_m16_first2_fused(hipStream_t st, int B, int Z, int Y, int X, const float* pDiv, const float* div, const float* flags,
+                            const double* stats, double count, const void* wfrag1, const float* bias1, float post1,
+                            const void* wfrag2, const float* bias2, float post2, void* out_h2, unsigned long long* range_err);
 size_t conv3_m16_frag_halves(int cin);
+float conv3_m16_pack_tail(const float* w4 /* [8][8] (out, in) */, uint16_t* frag_buf_of_a_cin8_layer);
 float conv3_m16_pack_weights(const float* w, int cin, uint16_t* out);
 
 // backward.hip

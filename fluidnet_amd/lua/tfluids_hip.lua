@@ -26,7 +26,8 @@ typedef enum tfl_status {
   TFL_OK = 0,
   TFL_EINVAL = -1,
   TFL_EHIP = -2,
-  TFL_EUNSUPPORTED = -3
+  TFL_EUNSUPPORTED = -3,
+  TFL_ERANGE = -4
 } tfl_status;
 typedef struct tfl_tensor {
   float* data;
@@ -123,6 +124,7 @@ tfl_model* tfl_model_create_opts(tfl_ctx* ctx, int is3D, int nlayers, const int3
                                  const float* const* weights, const float* const* biases, const tfl_model_opts* opts);
 void tfl_model_destroy(tfl_ctx* ctx, tfl_model* model);
 int64_t tfl_model_range_errors(tfl_ctx* ctx, tfl_model* model);
+int64_t tfl_model_range_flag(tfl_ctx* ctx, tfl_model* model);
 int64_t tfl_model_workspace_floats(const tfl_model* model, int B, int Z, int Y, int X);
 int tfl_model_forward(tfl_ctx* ctx, tfl_model* model, const tfl_tensor* pDiv, const tfl_tensor* UDiv,
                       const tfl_tensor* flags, const tfl_tensor* pOut, const tfl_tensor* UOut,

@@ -177,6 +177,15 @@ class FluidNetModel:
         h = self._handles.get(like.device.index)
         return 0 if h is None else int(lib.tfl_model_range_errors(ctx, h))
 
+    def range_flag(self, like):
+        """The same count as far as the device has reported it, WITHOUT a stream synchronisation and without resetting it
+        (tfl_model_range_flag): non-zero means a forward pass clamped activations at the fp16 range, and the next
+        forward / simulate step of this model is refused (TFL_ERANGE) until range_errors() has been called. The strict-fp32
+        stack without a range limit is TFL_CONV_PATH=winograd at model creation."""
+        lib, ctx = tfluids._context(like)
+        h = self._handles.get(like.device.index)
+        return 0 if h is None else int(lib.tfl_model_range_flag(ctx, h))
+
     # -- the same forward in two halves, for z-slab decomposition (fluidnet_amd.dist) --------------
     def _prep(self, flags):
         lib, ctx = tfluids._context(flags)

@@ -39,7 +39,9 @@ typedef enum tfl_status {
   TFL_OK = 0,
   TFL_EINVAL = -1,       /* bad argument (shape / channel / null pointer / unknown method) */
   TFL_EHIP = -2,         /* HIP runtime error (message carries hipGetErrorString) */
-  TFL_EUNSUPPORTED = -3  /* valid in the reference but not built here */
+  TFL_EUNSUPPORTED = -3, /* valid in the reference but not built here */
+  TFL_ERANGE = -4        /* an earlier forward pass of the model left the fp16 range of the default 3-D conv path (see
+                            tfl_model_range_errors): refused until that count has been read */
 } tfl_status;
 
 /* A contiguous fp32 5-D tensor resident in HBM: [B][C][Z][Y][X], x fastest.
@@ -289,6 +291,12 @@ void tfl_model_destroy(tfl_ctx* ctx, tfl_model* model);
  * count (synchronises the context's stream). 0 for every working simulation: the net's input is divided by the
  * velocity's standard deviation. Always 0 on the fp32 paths (TFL_CONV_PATH=winograd|mfma|direct). -1 on error. */
 int64_t tfl_model_range_errors(tfl_ctx* ctx, tfl_model* model);
+/* The same count WITHOUT a stream synchronisation, as far as the device has reported it: the projection kernel at the end of
+ * a forward pass copies a non-zero count into pinned host memory, and this reads that word (not reset; tfl_model_range_errors
+ * resets it). While it is non-zero, tfl_model_forward / tfl_model_begin / tfl_simulate_step[_slab] return TFL_ERANGE instead
+ * of stepping on from a clamped pressure -- the reference's fp32 cuDNN would have carried values up to 3e38; create the model
+ * under TFL_CONV_PATH=winograd for a strict-fp32 stack without a range limit. 0 on the fp32 paths. -1 on error. */
+int64_t tfl_model_range_flag(tfl_ctx* ctx, tfl_model* model);
 /* Scratch floats tfl_model_forward needs for a [B][.][Z][Y][X] grid. */
 int64_t tfl_model_workspace_floats(const tfl_model* model, int B, int Z, int Y, int X);
 /* {pOut, UOut} = model:forward({pDiv, UDiv, flags}) (lib/model.lua:398, 421-450). Inputs are not

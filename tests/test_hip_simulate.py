@@ -206,6 +206,50 @@ def test_conv_paths_agree_3d(oracle, monkeypatch):
         assert scenes.rel_l2(pm.cpu().numpy(), p_ref) <= TOL and scenes.rel_l2(Um.cpu().numpy(), U_ref) <= TOL
 
 
+def test_conv_fused_layers_and_mfma_tail(monkeypatch):
+    """Round 5: layers 1 + 2 of the 3-D default net in ONE launch (k_conv3_m16p_f2: layer 1's planes stay in an LDS ring, its
+    x / y halo is recomputed) issue the same MFMAs in the same order per voxel as k_conv3_m16p_in + k_conv3_m16p -- the
+    projection must be BIT-identical with the fusion on and off, on ragged grids, with several chunks per column
+    (TFL_M16_CZ_F2) and B = 2. The tail's 1x1x1 layers on the matrix cores (one 16x16x16 MFMA per row) sum in another order
+    than the vector-ALU epilogue: equal to rounding, and nothing clamped."""
+    import torch
+    from fluidnet_amd import FluidNetModel
+    layers = S.default_3d_layers(seed=7)
+    dev = torch.device("cuda:0")
+    for dims, seed, B in [((32, 32, 32), 61, 1), ((13, 21, 45), 62, 2), ((5, 9, 33), 63, 1), ((6, 7, 130), 64, 1),
+                          ((40, 24, 70), 65, 2), ((3, 8, 32), 66, 1), ((2, 6, 17), 67, 1)]:
+        sc = scenes.make_scene(dims, seed=seed, vel_cells=0.4, B=B)
+        tp, tU, tf = (torch.from_numpy(sc[k]).to(dev) for k in ("p", "U", "flags"))
+        monkeypatch.delenv("TFL_M16_FUSE12", raising=False)     # the default: one launch per layer
+        m0 = FluidNetModel(layers, True)
+        p0, U0 = m0.forward([tp, tU, tf])
+        assert m0.range_errors(tp) == 0
+        monkeypatch.setenv("TFL_M16_FUSE12", "1")
+        for cz in (None, "3", "1", "64"):
+            if cz:
+                monkeypatch.setenv("TFL_M16_CZ_F2", cz)
+            m1 = FluidNetModel(layers, True)
+            p1, U1 = m1.forward([tp, tU, tf])
+            assert torch.equal(p0, p1) and torch.equal(U0, U1), (dims, cz, scenes.rel_l2(p1.cpu().numpy(), p0.cpu().numpy()))
+            assert m1.range_errors(tp) == 0
+            if cz:
+                monkeypatch.delenv("TFL_M16_CZ_F2")
+        monkeypatch.delenv("TFL_M16_FUSE12")
+        monkeypatch.setenv("TFL_M16_TAIL_MFMA", "0")
+        m2 = FluidNetModel(layers, True)
+        p2, U2 = m2.forward([tp, tU, tf])
+        monkeypatch.delenv("TFL_M16_TAIL_MFMA")
+        rp, rU = scenes.rel_l2(p0.cpu().numpy(), p2.cpu().numpy()), scenes.rel_l2(U0.cpu().numpy(), U2.cpu().numpy())
+        assert rp <= 1e-6 and rU <= 1e-6, (dims, rp, rU)
+    # a blown-up input is still reported by the fused kernel (its own range check) and by the tail's split
+    sc = scenes.make_scene((12, 16, 40), seed=77, vel_cells=0.4)
+    tp, tU, tf = (torch.from_numpy(sc[k]).to(dev) for k in ("p", "U", "flags"))
+    monkeypatch.setenv("TFL_M16_FUSE12", "1")
+    m = FluidNetModel(layers, True)
+    m.forward([tp * 1e9, tU, tf])
+    assert m.range_errors(tp) > 0
+
+
 def test_fp16_range_errors_are_counted(oracle):
     """conv_mfma16.hip clamps activations at the fp16 range and COUNTS the blocks that did (tfl_model_range_errors): a net
     input far outside it (pressure 1e9 times the velocity scale) must be reported, an ordinary one must not."""
@@ -222,6 +266,18 @@ def test_fp16_range_errors_are_counted(oracle):
     assert m.range_errors(tp) > 0
     m.forward([tp, tU, tf])
     assert m.range_errors(tp) == 0          # the counter is read-and-reset
+    # an overflow nobody polled for must not stay silent -- the projection kernel copies the count to pinned
+    # host memory, and the next forward pass (no synchronisation needed to see it) is refused until it has been read
+    from fluidnet_amd import TfluidsError
+    m.forward([tp * 1e9, tU, tf])
+    torch.cuda.synchronize()
+    assert m.range_flag(tp) > 0
+    with pytest.raises(TfluidsError, match="fp16 range"):
+        m.forward([tp, tU, tf])
+    assert m.range_errors(tp) > 0           # acknowledged ...
+    assert m.range_flag(tp) == 0
+    m.forward([tp, tU, tf])                 # ... and the model runs again
+    assert m.range_errors(tp) == 0
 
 
 MODEL_OPTS = [
