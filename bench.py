@@ -96,7 +96,52 @@ def build_scene(res_xy, z_total, layout, device):
     return batch, mconf
 
 
-def cpu_baseline(batch, mconf, layers, max_seconds=25.0, max_steps=6):
+class _TimedOps:
+    """Wall time per tfluids operator of the CPU checker (per-op reference-CPU ms beside each number)."""
+
+    def __init__(self, ops):
+        self._ops, self.seconds, self.calls = ops, {}, {}
+
+    def __getattr__(self, name):
+        fn = getattr(self._ops, name)
+        if not callable(fn):
+            return fn
+
+        def timed(*a, **kw):
+            t0 = time.perf_counter()
+            try:
+                return fn(*a, **kw)
+            finally:
+                self.seconds[name] = self.seconds.get(name, 0.0) + time.perf_counter() - t0
+                self.calls[name] = self.calls.get(name, 0) + 1
+        return timed
+
+
+def conv_witness(ops, model, dev):
+    """How the `f32` label of the conv stack is earned: the projection of a developed 48^3 plume by the
+    HIP path (default: fp16 hi/lo pairs on the matrix cores) and by PyTorch-CPU fp32 convolutions, each against the SAME
+    graph with fp64 convolutions: ratio = our error / PyTorch-fp32's error (< 1: closer to the exact answer than an fp32
+    fmaf chain is). Checker work: runs inside the cpu_baseline leg, outside every timed region."""
+    from fluidnet_amd.simulate import simulate_native
+    from oracle import simulate_np as S
+    b, m = build_scene(48, 48, None, dev)
+    for _ in range(12):
+        simulate_native(None, m, b, model)
+    p, U, f = (b[k].cpu().numpy().copy() for k in ("pDiv", "UDiv", "flags"))
+    pg, Ug = model.forward([b["pDiv"], b["UDiv"], b["flags"]])
+    p32, U32 = S.model_forward(ops, model.layers, p, U, f)
+    p64, U64 = S.model_forward(ops, model.layers, p, U, f, conv_dtype="float64")
+
+    def rel(a, ref):
+        a, ref = np.asarray(a, np.float64), np.asarray(ref, np.float64)
+        return float(np.linalg.norm(a - ref) / max(np.linalg.norm(ref), 1e-300))
+    e_ours, e_torch = rel(pg.cpu().numpy(), p64), rel(p32, p64)
+    return {"grid": "48^3 developed plume + obstacle (12 steps)", "rel_l2_p_ours_vs_fp64_conv": e_ours,
+            "rel_l2_p_pytorch_fp32_vs_fp64_conv": e_torch, "ratio": e_ours / max(e_torch, 1e-300),
+            "rel_l2_U_ours_vs_fp64_conv": rel(Ug.cpu().numpy(), U64), "rel_l2_U_pytorch_fp32_vs_fp64_conv": rel(U32, U64)}
+
+
+def cpu_baseline(batch, mconf, layers, max_seconds=25.0, max_steps=6, model=None, dev=None):
     """The reference's own CPU tfluids code (oracle/_ref, -O3 build) -- or the C restatement if that
     library did not travel -- driving the same simulate() on the host cores, from the same state."""
     from oracle import simulate_np as S
@@ -114,18 +159,28 @@ def cpu_baseline(batch, mconf, layers, max_seconds=25.0, max_steps=6):
         ops, kind = OracleTfluids(), "port"
     nb = {k: (v.cpu().numpy().copy() if torch.is_tensor(v) else v) for k, v in batch.items()}
     cells = nb["flags"].size
+    tops = _TimedOps(ops)
     t0 = time.time()
     n = 0
     while n < max_steps and (n == 0 or time.time() - t0 < max_seconds):
-        S.simulate(ops, mconf, nb, layers)
+        S.simulate(tops, mconf, nb, layers)
         n += 1
     dt = time.time() - t0
-    return {"value": cells * n / dt / 1e6, "unit": "Mcells/s", "cores": os.cpu_count(), "kind": kind,
-            "steps_per_s": n / dt,
-            "sample": "%d full simulate() steps of the same %s grid from the post-warm-up state "
-                      "(tfluids ops: %s, OpenMP on all host cores; conv stack: PyTorch-CPU conv3d)"
-                      % (n, "x".join(str(s) for s in nb["flags"].shape[2:]),
-                         "reference CPU sources -O3" if kind == "reference" else "C restatement")}
+    per_op = {k: {"ms_per_step": v / n * 1e3, "calls_per_step": tops.calls[k] / n} for k, v in sorted(tops.seconds.items())}
+    per_op["conv_stack_and_numpy_glue"] = {"ms_per_step": (dt - sum(tops.seconds.values())) / n * 1e3, "calls_per_step": 1,
+                                           "what": "PyTorch-CPU conv3d x5 + the Lua-side arithmetic restated in numpy (setConstVals, scale, joins)"}
+    out = {"value": cells * n / dt / 1e6, "unit": "Mcells/s", "cores": os.cpu_count(), "kind": kind,
+           "steps_per_s": n / dt, "ms_per_step": dt / n * 1e3, "per_op_ms": per_op,
+           "sample": "%d full simulate() steps of the same %s grid from the post-warm-up state "
+                     "(tfluids ops: %s, OpenMP on all host cores; conv stack: PyTorch-CPU conv3d)"
+                     % (n, "x".join(str(s) for s in nb["flags"].shape[2:]),
+                        "reference CPU sources -O3" if kind == "reference" else "C restatement")}
+    if model is not None and dev is not None:
+        try:
+            out["conv_witness"] = conv_witness(ops, model, dev)
+        except Exception as e:      # noqa: BLE001 -- the baseline must not take the line down
+            out["conv_witness"] = {"error": repr(e)}
+    return out
 
 
 # Planes a slab rank computes beyond its own, per kernel (below + above), from the z-windows of tfl_simulate_step_slab
@@ -319,6 +374,7 @@ def main():
             dist.init_process_group(backend, timeout=pg_timeout)
 
     from fluidnet_amd import FluidNetModel, tfluids
+    from fluidnet_amd.simulate import simulate_native
     model = FluidNetModel.default_3d(seed=1)
     res = args.res
     batch, mconf, step, sim = make_stepper(res, world, rank, dev, model, lambda r, lay, d: build_scene(r, r, lay, d))
@@ -352,6 +408,13 @@ def main():
     block_s = sorted(timed(step, args.steps) for _ in range(max(1, args.blocks)))
     elapsed = block_s[len(block_s) // 2] if len(block_s) % 2 else 0.5 * (block_s[len(block_s) // 2 - 1] + block_s[len(block_s) // 2])
     assert bool(torch.isfinite(batch["UDiv"]).all()), "simulation blew up"
+    # the two silent-failure counters of the path, read AFTER the timed region (both synchronise): activations the fp16-split
+    # conv stack clamped at 65504 (a clamped run stays finite: the isfinite check above cannot see it) and back-traces that
+    # hit one of calcLineTrace's invariant paths. A line with either non-zero would be a measurement of wrong results.
+    range_errors = int(model.range_errors(batch["UDiv"]))
+    trace_errors = int(tfluids.traceErrors(batch["UDiv"]))
+    assert range_errors == 0, "fp16 range errors in the timed region: %d blocks clamped an activation" % range_errors
+    assert trace_errors == 0, "line-trace invariant errors in the timed region: %d" % trace_errors
 
     total_cells = res ** 3
     owned_planes = res // world
@@ -435,6 +498,36 @@ def main():
                                   "%s unchanged since (git blob %s)" % (meta.get("commit", "?"), fname, sha_now[:12]))
         except Exception as e:      # noqa: BLE001
             traffic, traffic_source = None, "null: %r" % (e,)
+    # ---- the roofline that binds an advection kernel in practice: VALU issue. From the committed SQ
+    # counter pass (profiles/pmc_sq.json, tools/pmc_sq.py; refused like the traffic figure when the kernel's source changed):
+    # VALU instructions per wave x waves per SIMD x CLK_PER_VALU / the launch's clocks. CLK_PER_VALU = 4: what a stream of
+    # fma-class wave64 instructions costs a SIMD (tools/ubench/valu_rate.hip, profiles/r03_ubench_valu_rate.txt; simple adds /
+    # moves issue in ~2.5, transcendentals in ~7) -- a fraction near 1 says the vector pipe, not HBM, is what the kernel runs on.
+    CLK_PER_VALU = 4.0
+    sq_issue, sq_source = {}, None
+    spath = os.path.join(ROOT, "profiles", "pmc_sq.json")
+    if world == 1 and res == 128 and os.path.exists(spath):
+        try:
+            from fluidnet_amd import _kernels
+            sj = json.load(open(spath))
+            smeta = sj.get("_meta", {})
+            for name, rec in sj.items():
+                if name.startswith("_") or name not in kernels:
+                    continue
+                _, sha_now = _kernels.source_sha(name, conv_path)
+                was = (smeta.get("source_sha") or {}).get(name)
+                if not was or was[1] != sha_now:
+                    continue
+                per_simd = rec["waves"] / float(smeta.get("simds", 1024))
+                sq_issue[name] = {"valu_per_wave": rec["valu_per_wave"], "waves_per_simd": per_simd,
+                                  "valu_issue_frac": rec["valu_per_wave"] * per_simd * CLK_PER_VALU / rec["clocks"],
+                                  "mfma_util": rec.get("mfma_util"), "wait_any": rec.get("wait_any")}
+                kernels[name]["valu_issue_frac"] = sq_issue[name]["valu_issue_frac"]
+                if rec.get("mfma_util"):
+                    kernels[name]["mfma_util_pmc"] = rec["mfma_util"]
+            sq_source = "profiles/pmc_sq.json: rocprofv3 --pmc SQ_* pass of this bench at commit %s (kernels whose source changed since are left out)" % smeta.get("commit", "?")
+        except Exception as e:      # noqa: BLE001
+            sq_source = "null: %r" % (e,)
     hbm_meas = measured_hbm_GBps(dev)
     sum_kernel_ms = sum(k["ms_per_step"] for k in kernels.values())
     roofline = {"kernel": dom, "bound": dk.get("bound"), "achieved": dk.get("achieved"),
@@ -446,6 +539,12 @@ def main():
     for extra in ("operands", "algorithmic_TFLOPs", "algorithmic_frac_of_fp32_peak", "algorithmic_frac_of_f16_mfma_peak"):
         if extra in dk:
             roofline[extra] = dk[extra]
+    roofline["valu_issue_frac"] = (sq_issue.get(dom) or {}).get("valu_issue_frac")
+    roofline["valu_issue_source"] = sq_source
+    if dk.get("bound") == "hbm" and roofline["valu_issue_frac"] is not None and roofline["valu_issue_frac"] > 0.7:
+        roofline["bound_in_practice"] = ("vector-ALU issue: %.2f of the SIMDs' issue slots are VALU instructions (%d per wave x %.0f waves per SIMD x %.0f clk); "
+                                         "`frac` is the HBM fraction the north-star asks for, this is the roofline the kernel actually runs on"
+                                         % (roofline["valu_issue_frac"], sq_issue[dom]["valu_per_wave"], sq_issue[dom]["waves_per_simd"], CLK_PER_VALU))
     if dk.get("bound") == "mfma":
         roofline["note"] = ("achieved / peak / frac = MFMA flops ISSUED against the dense fp16 MFMA peak (matrix-pipe utilisation); "
                             "the layer's algorithmic fp32 flops are 27/112 of them in the K-packed 8->8 layers (4 fp16 products per fp32 product, 27 of 28 K slices used), 3/16 in the first layer")
@@ -456,7 +555,8 @@ def main():
         headline = {"op": "advectVel (k_vel_fwd + k_vel_bwd)", "algorithmic_bytes_per_cell": 68, "ms": t,
                     "achieved_GBps": by / (t * 1e-3) / 1e9, "frac_of_hbm_peak": by / (t * 1e-3) / 1e9 / HBM_PEAK_GBS,
                     "frac_of_measured_hbm": by / (t * 1e-3) / 1e9 / hbm_meas,
-                    "bound_in_practice": "instruction issue (DESIGN.md 7): ~2.7 clocks per instruction of any kind per SIMD"}
+                    "bound_in_practice": "instruction issue (DESIGN.md 7): ~2.7 clocks per instruction of any kind per SIMD",
+                    "valu_issue_frac": {n: (sq_issue.get(n) or {}).get("valu_issue_frac") for n in ("k_vel_fwd", "k_vel_bwd")}}
     redundancy = None
     if world > 1:
         # Redundant compute of an INTERIOR rank (two neighbours), from this rank's measured time per plane of each kernel:
@@ -488,6 +588,27 @@ def main():
                       "note": "single-GPU step of the same %d^3 grid timed on rank 0's GPU in this job (strong scaling)" % res}
         barrier()
 
+    # ---- the same step with the strict-fp32 conv stack (TFL_CONV_PATH=winograd: fp32 Winograd F(2,3) on the vector ALUs, no
+    # fp16 anywhere), so that the `f32` label of the default line can be audited against an exact-fp32 figure ---------------
+    conv_exact = None
+    if world == 1 and conv_path == "mfma16":
+        prev = os.environ.get("TFL_CONV_PATH")
+        os.environ["TFL_CONV_PATH"] = "winograd"
+        try:
+            model_w = FluidNetModel.default_3d(seed=1)        # the path is chosen when the device handle is created
+            nw = max(10, args.steps // 2)
+            for _ in range(3):
+                simulate_native(None, mconf, batch, model_w)
+            elw = timed(lambda: simulate_native(None, mconf, batch, model_w), nw)
+            conv_exact = {"path": "winograd (conv_valu.hip: fp32 Winograd F(2,3) along x on the vector ALUs)", "ms_per_step": elw / nw * 1e3,
+                          "steps": nw, "mcells_per_s": total_cells * nw / elw / 1e6}
+            del model_w
+        finally:
+            if prev is None:
+                os.environ.pop("TFL_CONV_PATH", None)
+            else:
+                os.environ["TFL_CONV_PATH"] = prev
+
     # ---- BASELINE config 5: 256^3 cut into `world` z-slabs (after the timed region; its own short timing) -------------
     config5 = None
     if not args.no_config5 and res == 128 and 256 % world == 0:
@@ -512,8 +633,9 @@ def main():
         "ms_per_step": ms, "ms_per_step_min": block_s[0] / args.steps * 1e3, "ms_per_step_max": block_s[-1] / args.steps * 1e3,
         "timed_blocks": len(block_s), "sum_kernel_ms": sum_kernel_ms, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
         "dtype_note": "every operator computes in fp32; the 3-D conv stack multiplies fp32 values held as fp16 hi/lo pairs on the "
-                      "matrix cores with fp32 accumulation (conv_mfma16.hip; error vs an fp64 convolution below PyTorch-fp32's)"
-                      if conv_path == "mfma16" else "fp32 throughout",
+                      "matrix cores with fp32 accumulation (conv_mfma16.hip); evidence in this line: conv_witness_ratio (error vs an "
+                      "fp64 convolution / PyTorch-fp32's, cpu_baseline.conv_witness), range_errors = 0, and conv_exact_fp32 = the same "
+                      "step with the strict-fp32 stack" if conv_path == "mfma16" else "fp32 throughout",
         "data": "synthetic",
         "config": {"workload": "BASELINE config 4 / the metric's 128^3 series: 3-D %d^3 plume + voxel obstacle (procedural "
                                "stand-in), MacCormack(Ours) advection, buoyancy, vorticity confinement, ConvNet projection "
@@ -522,6 +644,7 @@ def main():
                    "grid_zyx": [res, res, res], "per_gpu_grid_zyx": [owned_planes, res, res],
                    "decomposition": "single GPU" if world == 1 else "z-slabs, %d ranks, transport: %s" % (world, TRANSPORT["name"]),
                    "preroll_steps": args.preroll, "slab": redundancy, "strong_scaling": single},
+        "range_errors": range_errors, "trace_errors": trace_errors, "conv_exact_fp32": conv_exact,
         "roofline": roofline, "advection_headline": headline, "hbm_measured_peak_GBps": hbm_meas,
         "config5_256": config5, "configs": other_configs(dev) if (world == 1 and not (args.no_configs or args.no_config5)) else None, "kernels": kernels,
     }
@@ -530,7 +653,8 @@ def main():
         for _ in range(args.preroll):
             from fluidnet_amd.simulate import simulate_native
             simulate_native(None, m1, b1, model)
-        out["cpu_baseline"] = cpu_baseline(b1, m1, model.layers)
+        out["cpu_baseline"] = cpu_baseline(b1, m1, model.layers, model=model, dev=dev)
+        out["conv_witness_ratio"] = (out["cpu_baseline"].get("conv_witness") or {}).get("ratio")
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0:

@@ -66,6 +66,8 @@ thread_local ZOrigin g_zorigin = {0, 0};
 thread_local int g_advect_fast = 0;
 thread_local BcFoldArg g_fold = {nullptr, 0u, 0u};
 thread_local bool g_fold_done = false;
+thread_local BuoyFold g_buoy = {nullptr, 0.0f, 0.0f, 0.0f};
+thread_local bool g_buoy_done = false;
 struct ProfRec { const char* name; hipEvent_t e0, e1; };
 struct Profiler { std::vector<ProfRec> recs; };
 static thread_local Profiler* g_prof = nullptr;
@@ -152,11 +154,14 @@ struct WindowScope {
   explicit WindowScope(tfl_ctx* c) : c_(c) {
     tfl::g_zwin = c->zwin; tfl::g_zorigin = c->zorigin; tfl::g_advect_fast = c->advect_fast;
     tfl::g_fold = c->fold; tfl::g_fold_done = false;
+    tfl::g_buoy = c->buoy; tfl::g_buoy_done = false;
   }
   ~WindowScope() {
     tfl::g_zwin = tfl::ZWin{0, 0, 0, 0}; tfl::g_zorigin = tfl::ZOrigin{0, 0}; tfl::g_advect_fast = 0;
     c_->fold_done = c_->fold_done || tfl::g_fold_done;
     tfl::g_fold = tfl::no_fold(); tfl::g_fold_done = false;
+    c_->buoy_done = c_->buoy_done || tfl::g_buoy_done;
+    tfl::g_buoy = tfl::no_buoy(); tfl::g_buoy_done = false;
   }
   tfl_ctx* c_;
 };
@@ -424,10 +429,15 @@ int tfl_vorticityConfinementFrom(tfl_ctx* c, const tfl_tensor* USrc, const tfl_t
     return fail(c, TFL_EINVAL, "vorticityConfinementFrom: curl must be a 3-channel grid of the flags size");
   TRY(check_scalar(c, "vorticityConfinementFrom", "curlNorm", curlNorm, flags));
   WindowScope win(c);
-  if (is3D && tfl::vorticity_confinement_fused(c->stream, flags->B, flags->Z, flags->Y, flags->X, USrc->data, U->data, flags->data,
-                                               strength))
+  if (is3D && !c->vort_from_two_launch &&
+      tfl::vorticity_confinement_fused(c->stream, flags->B, flags->Z, flags->Y, flags->X, USrc->data, U->data, flags->data, strength))
     return check_launch(c, "vorticityConfinementFrom");
-  // 2-D (or TFL_VORT_FUSED=0): the planes of the window are copied, then the two-launch form runs in place
+  // 2-D, a grid below the fused kernel's size, or TFL_VORT_FUSED=0: the two launches read USrc and write U (round 5) ...
+  if (tfl::vorticity_confinement(c->stream, is3D != 0, flags->B, flags->Z, flags->Y, flags->X, U->data, flags->data, strength,
+                                 curl->data, curlNorm->data, 3, USrc->data))
+    return check_launch(c, "vorticityConfinementFrom");
+  // ... or, where only the one-cell kernels apply (X % 4 != 0, misaligned views), the planes of the window are copied and the
+  // two-launch form runs in place
   {
     const tfl::Dom d = tfl::make_dom(flags->Z, flags->Y, flags->X);
     const size_t plane = sizeof(float) * (size_t)flags->Y * flags->X;

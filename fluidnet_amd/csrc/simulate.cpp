@@ -77,7 +77,8 @@ int set_const_vals(tfl_ctx* c, const tfl_sim_state* s, const tfl_tensor* U_now, 
 // Folding a sparse pair into the kernel that produces the field (tfl_host.hpp BcFold): fold_ask before the operator, fold_took
 // after it. TFL_BC_FOLD=0 keeps every pair in its own launch (A/B switch).
 bool fold_ask(tfl_ctx* c, const tfl_bc_plan* p) {
-  static const bool off = getenv("TFL_BC_FOLD") && atoi(getenv("TFL_BC_FOLD")) == 0;
+  const char* e = getenv("TFL_BC_FOLD");       // (read per call: the A/B parity test switches it inside one process)
+  const bool off = e && atoi(e) == 0;
   c->fold_done = false;
   if (off || !p || !p->sparse || !p->boxed || !p->d_fold || p->n_idx == 0) { c->fold = tfl::no_fold(); return false; }
   c->fold = tfl::BcFoldArg{p->d_fold, (unsigned)p->box[2] | ((unsigned)p->box[4] << 16), (unsigned)p->box[3] | ((unsigned)p->box[5] << 16)};
@@ -199,44 +200,65 @@ int tfl_simulate_step(tfl_ctx* c, const tfl_sim_params* prm, const tfl_sim_state
     if (!ours) { rc = tfl_copy(c, s->density[i], &out); if (rc) return rc; }
   }
   tfl_tensor vfwd = view(ws, (int)z.C), vbwd = view(ws + z.C * z.N, (int)z.C), Uadv = view(ws + 2 * z.C * z.N, (int)z.C);
-  fold_ask(c, s->UBC);
+  const bool buoyant = s->n_density > 0 && prm->buoyancyScale > 0.0;
+  const double dx = tfl_getDx(c, s->flags);
+  const float bsc = (float)(-(dx / 4.0) * prm->buoyancyScale);
+  const float bg[3] = {prm->gravity[0] * bsc, prm->gravity[1] * bsc, prm->gravity[2] * bsc};
+  const bool U_pair_asked = fold_ask(c, s->UBC);
+  // addBuoyancy follows advectVel and the first setConstVals directly and needs nothing but the advected density, which is
+  // final by now: pass B of advectVel may add the force itself behind the folded U pair (tfl_host.hpp BuoyFold; round 5).
+  // Asked for only when the density's own pair has been applied already (or there is none) and the U pair travels with the
+  // same kernel (or there is none); TFL_BUOY_FOLD=0 keeps the force in its own launch (A/B switch).
+  bool buoy_folded = false;
+  {
+    const char* e = getenv("TFL_BUOY_FOLD");
+    const bool rho_final = buoyant && (!s->densityBC[0] || (density_done & 1u));
+    if (rho_final && ours && is3D && !(e && atoi(e) == 0) && (!s->UBC || U_pair_asked)) {
+      // strength = -gravity * (dt / dx) in float, exactly as tfl_addBuoyancyFrom forms it (abi.cpp get_dx; tfluids.cc:1190-1192)
+      float dxf;
+      if (c->dx_dim > 0) dxf = 1.0f / (float)c->dx_dim;
+      else if (c->dx_override > 0.0f) dxf = c->dx_override;
+      else dxf = 1.0f / (float)std::max(std::max(s->flags->X, s->flags->Y), s->flags->Z);
+      const float bs = prm->dt / dxf;
+      c->buoy = tfl::BuoyFold{s->density[0]->data, -bg[0] * bs, -bg[1] * bs, -bg[2] * bs};
+    }
+    c->buoy_done = false;
+  }
   rc = tfl_advectVel(c, prm->dt, s->U, s->flags, &vfwd, &vbwd, is3D, method, 1, prm->maccormackStrength, &Uadv);
   const bool Uadv_done = fold_took(c);
+  buoy_folded = c->buoy_done;
+  c->buoy = tfl::no_buoy(); c->buoy_done = false;
   if (rc) return rc;
-  // U:copy(advected) (init.lua:216-218) is folded into the first force that writes every cell of its output: addBuoyancy
-  // (tfl_addBuoyancyFrom) or, on a 3-D grid, the fused vorticity confinement (tfl_vorticityConfinementFrom, which cannot
-  // run in place: then buoyancy / gravity work on a scratch velocity and the confinement delivers into U)
-  const bool buoyant = s->n_density > 0 && prm->buoyancyScale > 0.0;
+  // U:copy(advected) (init.lua:216-218) costs nothing: the velocity stays in the advection's scratch array (`cur`) until an
+  // operator that writes every cell of its output delivers it into U -- addBuoyancy (tfl_addBuoyancyFrom), the vorticity
+  // confinement (tfl_vorticityConfinementFrom: the fused kernel cannot run in place anyway, the two-launch form reads one
+  // array and writes the other since round 5) or the ConvNet projection (UDiv = cur, UOut = U); a copy only where none does.
   const bool vort = prm->vorticityConfinementAmp > 0.0;
   const bool vfused = vort && tfl::vorticity_confinement_fused_ok(is3D != 0, (int)z.Z, z.N / z.B);
-  // scratch of the vorticity operator (centered | curl[3] | cnorm | force): the velocity planes 3..5 are free here too
-  tfl_tensor centered = view(ws, (int)z.C), curl = view(ws + z.C * z.N, 3), cnorm = view(ws + (z.C + 3) * z.N, 1),
-             force = view(ws + (z.C + 4) * z.N, (int)z.C);
-  tfl_tensor Utmp = view(ws, (int)z.C);                    // = the advectVel `fwd` planes, dead after the advection
+  // scratch of the vorticity operator (curl[3] | cnorm) = the advectVel `fwd` / `bwd` planes, dead after the advection. It must
+  // not touch `Uadv` (planes 2C .. 3C of the workspace): the two-launch confinement may still read its velocity from there.
+  tfl_tensor curl = view(ws, 3), cnorm = view(ws + 3 * z.N, 1);
+  tfl_tensor Utmp = view(ws, (int)z.C);                    // the same planes as a scratch velocity (fused confinement: no curl arrays)
   const tfl_tensor* cur = &Uadv;                           // where the velocity of the step currently lives
-  if (!buoyant && !vfused) {
-    rc = tfl_copy(c, s->U, &Uadv);
-    if (rc) return rc;
-    cur = s->U;
-  }
   rc = set_const_vals(c, s, cur, !Uadv_done, Unchanged{false, false, false}, density_done);
   if (rc) return rc;
 
   // ---- forces (simulate.lua:204-239) -------------------------------------------------------------------------
-  const double dx = tfl_getDx(c, s->flags);
   // The setConstVals that follows the forces (below) touches only U (nothing else has been written since the first one):
   // with the ConvNet projection nothing comes between the last force and it, so the LAST force's kernel applies the U pair
   // itself where it can (fold_ask / fold_took; the other projections run setWallBcs first, outputDiv skips the call).
-  const bool fold_forces = !prm->outputDiv && method_of(prm) == "convnet";
+  const std::string sm = method_of(prm);
+  const bool fold_forces = !prm->outputDiv && sm == "convnet";
   const bool gravity_on = prm->gravityScale > 0.0;
   bool U_folded = false;
-  if (buoyant) {
-    const float sc = (float)(-(dx / 4.0) * prm->buoyancyScale);
-    const float g[3] = {prm->gravity[0] * sc, prm->gravity[1] * sc, prm->gravity[2] * sc};
+  if (buoyant && !buoy_folded) {
+    // (with the fused confinement next, or the vorticity operator / the ConvNet projection to move it later, the force may
+    // stay in scratch: in place on `cur` when nothing needs the velocity in U yet -- but every cell of U must be written by
+    // SOMEONE, and addBuoyancyFrom does that for free, so it delivers into U unless the fused confinement reads next)
     const tfl_tensor* dst = vfused ? &Utmp : s->U;
     const bool last = fold_forces && !gravity_on && !vort;
     if (last) fold_ask(c, s->UBC);
-    rc = tfl_addBuoyancyFrom(c, cur, dst, s->flags, s->density[0], g, prm->dt, is3D);
+    rc = tfl_addBuoyancyFrom(c, cur, dst, s->flags, s->density[0], bg, prm->dt, is3D);
     if (last) U_folded = fold_took(c);
     if (rc) return rc;
     cur = dst;
@@ -250,22 +272,33 @@ int tfl_simulate_step(tfl_ctx* c, const tfl_sim_params* prm, const tfl_sim_state
   if (vort) {
     const float strength = (float)(dx * prm->vorticityConfinementAmp);
     if (fold_forces) fold_ask(c, s->UBC);
-    if (vfused) rc = tfl_vorticityConfinementFrom(c, cur, s->U, s->flags, strength, &curl, &cnorm, is3D);
-    else rc = tfl_vorticityConfinement(c, s->U, s->flags, strength, &centered, &curl, &cnorm, &force, is3D);
+    if (cur != s->U) {
+      c->vort_from_two_launch = !vfused;     // below the fused kernel's size the two launches read `cur` and write U
+      rc = tfl_vorticityConfinementFrom(c, cur, s->U, s->flags, strength, &curl, &cnorm, is3D);
+      c->vort_from_two_launch = false;
+    } else {
+      tfl_tensor centered = view(ws + 4 * z.N, (int)z.C), force = view(ws + (4 + z.C) * z.N, (int)z.C);   // (unused by the kernels)
+      rc = tfl_vorticityConfinement(c, s->U, s->flags, strength, &centered, &curl, &cnorm, &force, is3D);
+    }
     if (fold_forces) U_folded = fold_took(c);
+    if (rc) return rc;
+    cur = s->U;
+  }
+  // the ConvNet projection reads its velocity from one array and writes the other; everything else wants it in U now
+  if (cur != s->U && (prm->outputDiv || sm != "convnet")) {
+    rc = tfl_copy(c, s->U, cur);
     if (rc) return rc;
     cur = s->U;
   }
   if (prm->outputDiv) return TFL_OK;
 
   // ---- projection (simulate.lua:247-304) ---------------------------------------------------------------------
-  const std::string sm = method_of(prm);
   if (sm != "convnet") {
     rc = tfl_setWallBcsForward(c, s->U, s->flags, is3D);
     if (rc) return rc;
   }
   // only U has been written since the first setConstVals
-  rc = set_const_vals(c, s, s->U, !U_folded, Unchanged{true, false, true});
+  rc = set_const_vals(c, s, cur, !U_folded, Unchanged{true, false, true});
   if (rc) return rc;
   const int max_iter = prm->maxIter > 0 ? prm->maxIter : 100;
   if (sm == "convnet") {
@@ -276,7 +309,7 @@ int tfl_simulate_step(tfl_ctx* c, const tfl_sim_params* prm, const tfl_sim_state
     const tfl_tensor* ubc = (s->UBC && !late_ubc) ? &s->UBC->bc : nullptr;
     const tfl_tensor* umask = (s->UBC && !late_ubc) ? &s->UBC->inv : nullptr;
     if (late_ubc) fold_ask(c, s->UBC);
-    rc = tfl_model_forward(c, s->model, s->p, s->U, s->flags, s->p, s->U, ws, ws_floats, ubc, umask, 1, -1e6f, 1e6f);
+    rc = tfl_model_forward(c, s->model, s->p, cur, s->flags, s->p, s->U, ws, ws_floats, ubc, umask, 1, -1e6f, 1e6f);
     const bool folded = fold_took(c);
     if (rc) return rc;
     // p was rewritten by the model, density has not changed since the second setConstVals

@@ -26,6 +26,9 @@ struct tfl_ctx {
   bool reach_pending = false;
   tfl::BcFoldArg fold = {nullptr, 0u, 0u};    // tfl_simulate_step: a setConstVals pair (device descriptor + gate) the next operator may apply to its output
   bool fold_done = false;                     // ... and whether a launcher did (tfl_host.hpp BcFold)
+  tfl::BuoyFold buoy = {nullptr, 0.0f, 0.0f, 0.0f};   // tfl_simulate_step: the buoyancy force the next advectVel may add itself (tfl_host.hpp BuoyFold)
+  bool buoy_done = false;
+  bool vort_from_two_launch = false;          // tfl_simulate_step: the next tfl_vorticityConfinementFrom skips the fused kernel (grid below its size)
   int wf_skip = 0;                            // > 0: a pipelined PCG sweep timed out on this context: the next wf_skip solves go straight to
                                               // hyperplane sweeps, then the pipelined form is tried again (a transient stall must not latch for good)
   int wf_timeouts = 0;                        // how often that happened (the back-off doubles, one warning per latch)

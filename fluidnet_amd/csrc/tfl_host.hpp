@@ -34,6 +34,19 @@ extern thread_local bool g_fold_done;
 inline BcFoldArg take_fold() { if (g_fold.dev) g_fold_done = true; return g_fold; }
 inline BcFoldArg no_fold() { return BcFoldArg{nullptr, 0u, 0u}; }
 
+// addBuoyancy (third_party/tfluids.cc:1162-1233) folded into the kernel that writes the advected velocity (round 5). In
+// simulate() the buoyancy force follows advectVel and the first setConstVals directly (lib/simulate.lua:196-226), it is
+// pointwise in U and needs the ADVECTED density -- which advectScalar has delivered (pair applied) before advectVel runs. So
+// tfl_simulate_step hands pass B of advectVel a request {rho, (sx, sy, sz) = -gravity dt / dx}; a launcher that takes it
+// (g_buoy_done) adds 0.5 s_c (rho(i) + rho(i - e_c)) on the faces between two fluid cells behind the folded pair, from two
+// to four more loads per cell, and the 32 B/cell launch of k_add_buoyancy disappears. Only taken together with the U pair
+// (or when there is none): the force must see the boundary values.
+struct BuoyFold { const float* rho; float sx, sy, sz; };      // rho == nullptr: no request
+extern thread_local BuoyFold g_buoy;
+extern thread_local bool g_buoy_done;
+inline BuoyFold no_buoy() { return BuoyFold{nullptr, 0.0f, 0.0f, 0.0f}; }
+inline BuoyFold take_buoy() { if (g_buoy.rho) g_buoy_done = true; return g_buoy; }
+
 // does row (j, k) / cell i of the field lie inside the pair's box
 __device__ __forceinline__ bool fold_row(const BcFold& f, int j, int k) {
   return j >= f.y0 && j <= f.y1 && k >= f.z0 && k <= f.z1;
@@ -124,8 +137,10 @@ void absmax(hipStream_t st, long long n, const float* x, float* out, bool reset)
 // vorticity.hip
 // stages: bit 0 = pass A (U -> curl, |curl|), bit 1 = pass B (curl, |curl|, flags, U -> U); a z-slab rank runs the two
 // passes under different z-windows
-void vorticity_confinement(hipStream_t st, bool is3d, int B, int Z, int Y, int X, float* U, const float* flags,
-                           float strength, float* curl, float* curl_norm, int stages = 3);
+// Usrc (round 5): U = Usrc + force with every cell of the window written (the four-cells-per-thread kernels only: false =
+// not possible here, nothing launched, the caller copies Usrc into U and calls again without it)
+bool vorticity_confinement(hipStream_t st, bool is3d, int B, int Z, int Y, int X, float* U, const float* flags,
+                           float strength, float* curl, float* curl_norm, int stages = 3, const float* Usrc = nullptr);
 
 // U_out = U_in + confinement(U_in), 3-D, one fused launch without curl arrays (U_out != U_in); false = not supported here
 bool vorticity_confinement_fused_ok(bool is3d, int Z, long long cells_per_item);   // does the native step use the fused kernel for this grid

@@ -202,9 +202,12 @@ __device__ __forceinline__ void force_row(const Dom& d, float strength, int i0, 
 // down (z-1) are evaluated in registers from 10 |curl| rows + 7 curl rows; force.x of cell i0-1 comes from the
 // previous lane. U is rewritten in full rows (unchanged cells get their own value back).
 template <bool IS3D>
-__global__ __launch_bounds__(256, TFL_LB_CONFINE) void k_confine_v4(Dom d, float* __restrict__ U, const float* __restrict__ flags,
+__global__ __launch_bounds__(256, TFL_LB_CONFINE) void k_confine_v4(Dom d, const float* Usrc, float* U, const float* __restrict__ flags,
                                                     const float* __restrict__ curl, const float* __restrict__ cn,
                                                     float strength, BcFoldArg folda) {
+  // U = Usrc + confinement force. Usrc == U: the reference's in-place operator; Usrc != U (round 5, tfl_vorticityConfinementFrom
+  // on grids below the fused kernel's size): every cell of the window is written, which moves the velocity out of the
+  // advection's scratch array for free
   const V4Ctx c = v4_ctx(d);
   const int j = blockIdx.y * blockDim.y + threadIdx.y;
   int b, k; dom_bk(d, b, k);
@@ -212,7 +215,7 @@ __global__ __launch_bounds__(256, TFL_LB_CONFINE) void k_confine_v4(Dom d, float
   const bool live = c.i0 < d.X && j < d.Y;
   const long long cells = d.sc;
   const int C = IS3D ? 3 : 2;
-  U += b * cells * C; flags += b * cells; curl += b * cells * 3; cn += b * cells;
+  U += b * cells * C; Usrc += b * cells * C; flags += b * cells; curl += b * cells * 3; cn += b * cells;
   const int o = TFL_AT(d, c.i0, j, k);
   const bool in = live && j >= 1 && j <= d.Y - 2 && (!IS3D || (k >= 1 && k <= d.Z - 2));   // the cells' own row
   const bool in_ym = in && j - 1 >= 1;                 // row (j-1,k) is not a border row
@@ -248,7 +251,7 @@ __global__ __launch_bounds__(256, TFL_LB_CONFINE) void k_confine_v4(Dom d, float
   v4_load(flags, o - d.sy, in, 0.0f, fl_ym);
   v4_load(flags, o - d.sz, in && IS3D, 0.0f, fl_zm);
 #pragma unroll
-  for (int a = 0; a < 3; a++) v4_load(U, o + a * d.sc, live && a < C, 0.0f, u[a]);
+  for (int a = 0; a < 3; a++) v4_load(Usrc, o + a * d.sc, live && a < C, 0.0f, u[a]);
 
   v3 f0[4], fy[4], fz[4];
   force_row<IS3D>(d, strength, c.i0, in, n_c, n_ym + 1, n_yp, n_zm + 1, n_zp, wx, wy, wz, f0);
@@ -534,12 +537,35 @@ __global__ __launch_bounds__(512) void k_vort_fused(Dom d, int cols_x, int cols_
   }
 }
 
+// block slots of k_vort_fused on the current device, asked once per device: 0 = the device cannot run it (its 78 KB of dynamic
+// LDS refused, or no resident block: ADVICE r04 -- a part with 64 KB of LDS per workgroup), and both entry points below then
+// say so instead of launching into an error
+static int vort_fused_slots() {
+  static std::atomic<int> slots_of[64];       // 0 = not asked yet, -1 = unsupported
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= 64) dev = 0;
+  int slots = slots_of[dev].load();
+  if (!slots) {
+    int cus = 256, per = 0;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const bool attr_ok = hipFuncSetAttribute((const void*)k_vort_fused, hipFuncAttributeMaxDynamicSharedMemorySize, kFusedLds) == hipSuccess;
+    if (!attr_ok || hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, (const void*)k_vort_fused, 512, kFusedLds) != hipSuccess || per <= 0) {
+      (void)hipGetLastError();                // the refusal must not surface as the next launch's error
+      slots = -1;
+    } else slots = cus * per;
+    slots_of[dev].store(slots);
+  }
+  return slots > 0 ? slots : 0;
+}
+
 // does the native step route its confinement through the fused kernel (TFL_VORT_FUSED = 1 | 0; default: see the record in
 // profiles/r04_advect_experiments.txt)
 bool vorticity_confinement_fused_ok(bool is3d, int Z, long long cells) {
   static const int mode = getenv("TFL_VORT_FUSED") ? atoi(getenv("TFL_VORT_FUSED")) : -1;
   if (!is3d || Z < 3 || mode == 0) return false;
-  return mode == 1 || cells >= 3000000ll;      // 128^3 (2.1 M): 42.6 vs 38.5 us for the two launches; 160^3 (4.1 M): 85 vs 108; 256^3: 274 vs 397
+  if (!(mode == 1 || cells >= 3000000ll)) return false;   // 128^3 (2.1 M): 42.6 vs 38.5 us for the two launches; 160^3 (4.1 M): 85 vs 108; 256^3: 274 vs 397
+  return vort_fused_slots() > 0;
 }
 
 // false = shape not supported by the fused kernel (the caller copies and runs the two-launch form)
@@ -550,20 +576,8 @@ bool vorticity_confinement_fused(hipStream_t st, int B, int Z, int Y, int X, con
   const int cxn = (X + FBX - 1) / FBX, cyn = (Y + FBY - 1) / FBY;
   const int na = d.n0, nb = d.nw - d.n0;
   if ((long long)cxn * cyn * (na + nb) * B <= 0) return true;
-  // block slots of the current device (the dynamic-LDS attribute is a per-device setting: asked once per device)
-  static std::atomic<int> slots_of[64];
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  if (dev < 0 || dev >= 64) dev = 0;
-  int slots = slots_of[dev].load();
-  if (!slots) {
-    (void)hipFuncSetAttribute((const void*)k_vort_fused, hipFuncAttributeMaxDynamicSharedMemorySize, kFusedLds);
-    int cus = 256, per = 0;
-    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, (const void*)k_vort_fused, 512, kFusedLds) != hipSuccess || per <= 0) per = 2;
-    slots = cus * per;
-    slots_of[dev].store(slots);
-  }
+  const int slots = vort_fused_slots();     // (the dynamic-LDS attribute is a per-device setting: asked once per device)
+  if (slots <= 0) return false;             // the caller copies and runs the two-launch form
   // chunk length: rounds of resident blocks x (planes written + 6 planes of pipeline fill)
   int cz = 4;
   {
@@ -582,23 +596,25 @@ bool vorticity_confinement_fused(hipStream_t st, int B, int Z, int Y, int X, con
   return true;
 }
 
-void vorticity_confinement(hipStream_t st, bool is3d, int B, int Z, int Y, int X, float* U, const float* flags,
-                           float strength, float* curl, float* curl_norm, int stages) {
+bool vorticity_confinement(hipStream_t st, bool is3d, int B, int Z, int Y, int X, float* U, const float* flags,
+                           float strength, float* curl, float* curl_norm, int stages, const float* Usrc) {
   const Dom d = make_dom(Z, Y, X);
   const dim3 blk(64, 4, 1), grd((X + 63) / 64, (Y + 3) / 4, (unsigned)(d.nw * B));
-  const Vec4Launch v = vec4_launch(B, Z, Y, X, {U, flags, curl, curl_norm});
+  const float* Uin = Usrc ? Usrc : U;
+  const Vec4Launch v = vec4_launch(B, Z, Y, X, {U, flags, curl, curl_norm, Uin});
   const bool pa = stages & 1, pb = stages & 2;
   if (v.ok) {
     const BcFoldArg fold = pb ? take_fold() : no_fold();   // pass B writes the operator's result
     if (is3d) {
-      if (pa) { TFL_TIMED_EXT("k_curl", st); TFL_LAUNCH_EXT((k_curl_v4<true>), v.grd, v.blk, 0, st, d, (const float*)U, curl, curl_norm); }
-      if (pb) { TFL_TIMED_EXT("k_confine", st); TFL_LAUNCH_EXT((k_confine_v4<true>), v.grd, v.blk, 0, st, d, U, flags, (const float*)curl, (const float*)curl_norm, strength, fold); }
+      if (pa) { TFL_TIMED_EXT("k_curl", st); TFL_LAUNCH_EXT((k_curl_v4<true>), v.grd, v.blk, 0, st, d, Uin, curl, curl_norm); }
+      if (pb) { TFL_TIMED_EXT("k_confine", st); TFL_LAUNCH_EXT((k_confine_v4<true>), v.grd, v.blk, 0, st, d, Uin, U, flags, (const float*)curl, (const float*)curl_norm, strength, fold); }
     } else {
-      if (pa) { TFL_TIMED("k_curl", st); k_curl_v4<false><<<v.grd, v.blk, 0, st>>>(d, U, curl, curl_norm); }
-      if (pb) { TFL_TIMED("k_confine", st); k_confine_v4<false><<<v.grd, v.blk, 0, st>>>(d, U, flags, curl, curl_norm, strength, fold); }
+      if (pa) { TFL_TIMED("k_curl", st); k_curl_v4<false><<<v.grd, v.blk, 0, st>>>(d, Uin, curl, curl_norm); }
+      if (pb) { TFL_TIMED("k_confine", st); k_confine_v4<false><<<v.grd, v.blk, 0, st>>>(d, Uin, U, flags, curl, curl_norm, strength, fold); }
     }
-    return;
+    return true;
   }
+  if (Usrc && Usrc != U) return false;      // the one-cell kernels update in place: the caller copies first
   if (is3d) {
     if (pa) { TFL_TIMED("k_curl", st); k_curl<true><<<grd, blk, 0, st>>>(d, U, curl, curl_norm); }
     if (pb) { TFL_TIMED("k_confine", st); k_confine<true><<<grd, blk, 0, st>>>(d, U, flags, curl, curl_norm, strength); }
@@ -606,6 +622,7 @@ void vorticity_confinement(hipStream_t st, bool is3d, int B, int Z, int Y, int X
     if (pa) { TFL_TIMED("k_curl", st); k_curl<false><<<grd, blk, 0, st>>>(d, U, curl, curl_norm); }
     if (pb) { TFL_TIMED("k_confine", st); k_confine<false><<<grd, blk, 0, st>>>(d, U, flags, curl, curl_norm, strength); }
   }
+  return true;
 }
 
 }  // namespace tfl

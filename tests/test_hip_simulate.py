@@ -54,8 +54,12 @@ def test_model_forward_matches_restatement(oracle, dims, seed, which):
     assert torch.equal(tp.cpu(), torch.from_numpy(sc["p"])) and torch.equal(tU.cpu(), torch.from_numpy(sc["U"]))
     rp, rU = scenes.rel_l2(p.cpu().numpy(), p_ref), scenes.rel_l2(U.cpu().numpy(), U_ref)
     assert rp <= TOL and rU <= TOL, (rp, rU)
-    # error bars: we must be as close to the fp64-conv answer as PyTorch-CPU fp32 is (x4 slack)
-    assert scenes.rel_l2(p.cpu().numpy(), p64) <= 4 * scenes.rel_l2(p_ref, p64) + 1e-7
+    # error bars against the fp64-conv answer. 3-D (the default path: fp32 operands as fp16 hi/lo pairs on the matrix cores,
+    # conv_mfma16.hip): at least as close as PyTorch-CPU's fp32 convolution is -- the claim DESIGN 3.3b makes for the `f32`
+    # label (the test allowed 4x); 2-D (fp32-operand MFMA, another summation order only): within 4x of it
+    e_ours, e_torch = scenes.rel_l2(p.cpu().numpy(), p64), scenes.rel_l2(p_ref, p64)
+    print("conv witness %s %s: ours %.3e, PyTorch fp32 %.3e, ratio %.2f" % (which, dims, e_ours, e_torch, e_ours / max(e_torch, 1e-300)))
+    assert e_ours <= (1.0 if which == "3d" else 4.0) * e_torch + 1e-8, (e_ours, e_torch)
     # in-place form used by simulate(): outputs alias the inputs
     model.forward([tp, tU, tf], out=[tp, tU])
     assert torch.equal(tp, p) and torch.equal(tU, U)
@@ -465,6 +469,52 @@ def _assert_slabs_equal(sims, ref, tol=1e-6):
             want = ref[k][:, :, s.lay.z0:s.lay.z1]
             rel = float((got - want).norm() / want.norm().clamp_min(1e-30))
             assert rel <= tol, (s.lay.rank, k, rel)
+
+
+_BC_FOLD_AB = r"""
+import os, sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import numpy as np, torch
+import test_hip_simulate as T
+from fluidnet_amd import FluidNetModel
+from fluidnet_amd.simulate import simulate_native
+dev = torch.device("cuda:0")
+model = FluidNetModel.default_3d(seed=1)
+mconf = dict(dt=0.1, advectionMethod="maccormackOurs", maccormackStrength=0.6, buoyancyScale=2.0, gravityScale=0,
+             vorticityConfinementAmp=3.0, simMethod="convnet")
+for dims in [(20, 40, 72), (12, 28, 128)]:
+    res = {}
+    for fold in ("1", "0"):
+        os.environ["TFL_BC_FOLD"] = fold
+        tb = T._to_dev(T._plume_batch(dims, 0.15, 1.0, obstacles_seed=5), dev)
+        for _ in range(4):
+            simulate_native(None, mconf, tb, model)
+        res[fold] = {k: tb[k].cpu().numpy() for k in ("pDiv", "UDiv", "density")}
+        assert np.isfinite(res[fold]["UDiv"]).all() and float(np.abs(res[fold]["UDiv"]).max()) > 0
+    for k in res["1"]:
+        a, b = res["1"][k], res["0"][k]
+        assert np.array_equal(a, b), (dims, k, int((a != b).sum()))      # IEEE ==: -0 and +0 compare equal
+print("BC_FOLD_AB_OK")
+"""
+
+
+@pytest.mark.parametrize("env", [{}, {"TFL_VEL3_KZ": "2", "TFL_VORT_FUSED": "1", "TFL_SCAL3_TZ": "14"}], ids=["small-grid-kernels", "big-grid-kernels"])
+def test_bc_fold_on_and_off_agree(env):
+    """the sparse setConstVals pairs are applied either by their own index-list launch or, folded, inside the
+    kernel that produces the field (pass B of the advection, the last force, the projection) -- which of the two happens
+    depends on the grid size (the big-grid advectVel / fused-confinement kernels never fold), on the alignment of the
+    pair and on TFL_BC_FOLD. The two forms must give the same state: IEEE-equal (the folded form evaluates x*inv+bc on
+    every cell of the pair's bounding box like the reference's dense cmul/add, the index list leaves identity cells alone:
+    that can turn a -0 into +0 and nothing else). Native step, 3-D plume + obstacles + vorticity, fold on and off, with the
+    small-grid and (forced: child process, the switches are read once) the big-grid kernel variants."""
+    import subprocess, sys
+    code = _BC_FOLD_AB % (os.path.dirname(HERE), HERE)
+    e = dict(os.environ)
+    for k in ("TFL_VEL3_KZ", "TFL_SCAL3_TZ", "TFL_VORT_FUSED", "TFL_BC_FOLD"):
+        e.pop(k, None)
+    e.update(env)
+    out = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "BC_FOLD_AB_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
 
 
 @pytest.mark.parametrize("world,overlap", [(1, False), (2, False), (2, True), (4, True), (3, False)])

@@ -36,7 +36,7 @@ def classify(op):
 lines = s.split("\n")
 starts = [(i, l.split(":")[0]) for i, l in enumerate(lines) if re.match(r"^_Z\S+:", l)]
 for (i0, name) in starts:
-    dem = subprocess.run(["c++filt", name], capture_output=True, text=True).stdout.strip().split("(")[0].replace("tfl::", "").replace("void ", "")
+    dem = subprocess.run(["c++filt", name], capture_output=True, text=True).stdout.strip().replace("(anonymous namespace)::", "").split("(")[0].replace("tfl::", "").replace("void ", "")
     if not re.search(pat, dem): continue
     i1 = next(j for j in range(i0, len(lines)) if lines[j].startswith(".Lfunc_end"))
     body = lines[i0 + 1:i1]

@@ -18,7 +18,7 @@ for line in sys.stdin:
     elif cur is not None and ":" in t:
         k, v = t.split(":", 1); cur[k.strip()] = v.strip()
 for r in rows:
-    try: name = subprocess.run(["c++filt", r["name"]], capture_output=True, text=True).stdout.strip().split("(")[0]
+    try: name = subprocess.run(["c++filt", r["name"]], capture_output=True, text=True).stdout.strip().replace("(anonymous namespace)::", "").split("(")[0]
     except Exception: name = r["name"]
     name = name.replace("tfl::", "").replace("void ", "")
     print("%-60s sgpr %3s vgpr %3s agpr %3s occ %s sspill %3s vspill %3s lds %s" % (name[:60], r.get("TotalSGPRs"), r.get("VGPRs"), r.get("AGPRs"), r.get("Occupancy [waves/SIMD]"), r.get("SGPRs Spill"), r.get("VGPRs Spill"), r.get("LDS Size [bytes/block]")))

@@ -37,4 +37,22 @@ out = ["# rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_
 for _, k, n, w, wa, wi, ac, mf, vw, clk in rows:
     out.append("%-46s %4d %9d %8.2f %8.2f %8.2f %9.2f %10.0f %9.0f" % (k[:46], n, w, wa, wi, ac, mf, vw, clk))
 open(os.path.join(ROOT, "profiles", tag + "_pmc_sq.txt"), "w").write("\n".join(out) + "\n")
+# the file bench.py reads for roofline.valu_issue_frac / mfma_util: per PROFILER kernel name (tools/pmc_traffic.py short()),
+# with the git blob hash of the kernel's source at measurement time (bench.py refuses the figures when it differs)
+if len(sys.argv) > 4 and sys.argv[4] == "json":
+    import json
+    sys.path.insert(0, os.path.join(ROOT, "fluidnet_amd")); sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import _kernels
+    saved_argv, sys.argv = sys.argv, sys.argv[:1]
+    from pmc_traffic import short
+    sys.argv = saved_argv
+    j = {}
+    for _, k, n, w, wa, wi, ac, mf, vw, clk in rows:
+        s = short("tfl::" + k)
+        if s and s not in j:
+            j[s] = {"pmc_name": k, "waves": w, "valu_per_wave": vw, "clocks": clk, "mfma_util": mf, "wait_any": wa, "wait_inst": wi, "active": ac}
+    conv_path = os.environ.get("TFL_CONV_PATH", "mfma16")
+    j["_meta"] = {"commit": commit, "source": tag + "_pmc_sq.txt", "simds": 1024,
+                  "source_sha": {k: list(_kernels.source_sha(k, conv_path)) for k in j}}
+    json.dump(j, open(os.path.join(ROOT, "profiles", "pmc_sq.json"), "w"), indent=1)
 print("\n".join(out[:12]))
