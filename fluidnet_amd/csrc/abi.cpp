@@ -50,6 +50,7 @@ struct tfl_model {
   bool mfma2d = false;
   float* bfrag2[4] = {nullptr, nullptr, nullptr, nullptr};
   double* d_stats = nullptr;  // [2 * kMaxBatch]: sum(u), sum(u^2) per sample
+  unsigned* d_ticket = nullptr;   // model.hip publish_and_maybe_reduce: blocks of the current k_bcs_div_stats launch that have published
   // forward-graph switches (tfl_model_opts); `custom` = any of them differs from default_conf.lua -> generic kernels only
   tfl_model_opts opts = {1, 0, 1, 1, TFL_NORM_UDIV, TFL_NORMFUNC_STD, TFL_NONLIN_RELU, 0};
   bool custom = false;
@@ -701,6 +702,8 @@ tfl_model* tfl_model_create_opts(tfl_ctx* c, int is3D, int nlayers, const int32_
                 o.norm_func == TFL_NORMFUNC_STD && o.nonlin == TFL_NONLIN_RELU && !o.pressure_skip);
   auto cleanup = [&](const char* msg) -> tfl_model* { tfl_model_destroy(c, m); return bad(msg); };
   if (hipMalloc((void**)&m->d_stats, sizeof(double) * 2 * kMaxBatch) != hipSuccess) return cleanup("hipMalloc failed");
+  if (hipMalloc((void**)&m->d_ticket, sizeof(unsigned) * (1 << 16)) != hipSuccess || hipMemset(m->d_ticket, 0, sizeof(unsigned) * (1 << 16)) != hipSuccess)   // model.hip kStatTickets
+    return cleanup("hipMalloc failed");
   // The shape-generic kernels are instantiated for 1, 2, 4, 8, 16, 32, 64 output channels. Any other width (the
   // `yang` topology of model.lua:188-205 has 6) is zero-padded to the next one: the extra channels carry
   // relu(0 + 0) = 0 into zero weights of the next layer, i.e. every sum gains exact `+ 0 * 0` terms only.
@@ -871,6 +874,7 @@ void tfl_model_destroy(tfl_ctx* c, tfl_model* m) {
   if (m->tail_pack) (void)hipFree(m->tail_pack);
   if (m->tail_w5) (void)hipFree(m->tail_w5);
   if (m->d_stats) (void)hipFree(m->d_stats);
+  if (m->d_ticket) (void)hipFree(m->d_ticket);
   delete m;
 }
 
@@ -953,7 +957,7 @@ int tfl_model_begin(tfl_ctx* c, tfl_model* m, const tfl_tensor* UDiv, const tfl_
   WindowScope win(c);
   const int stg = stages_of(c);   // tfl_set_stages: 2 = wall BCs + divergence + partial sums, 4 = reduce [zlo, zhi)
   tfl::model_pre(c->stream, m->is3d, flags->B, flags->Z, flags->Y, flags->X, UDiv->data, flags->data, UOut->data,
-                 w.div, w.partials, stats ? stats : m->d_stats, zlo, zhi, ((stg & 2) ? 1 : 0) | ((stg & 4) ? 2 : 0));
+                 w.div, w.partials, stats ? stats : m->d_stats, zlo, zhi, ((stg & 2) ? 1 : 0) | ((stg & 4) ? 2 : 0), m->d_ticket);
   return check_launch(c, "model_begin");
 }
 

@@ -75,6 +75,65 @@ __device__ __forceinline__ float u_bc_at(const Dom& d, const float* __restrict__
   return z ? 0.0f : U[o + AXIS * d.sc];
 }
 
+// stats[b] = the sum of `count` partial pairs at p, by the 256 threads of a block in a FIXED order (strided accumulate, then a
+// shared-memory tree): the scale is bit-reproducible run to run and independent of how the launches were split. COHERENT:
+// the partials were written by other blocks of the SAME launch (k_bcs_div_stats' fused tail below) -- loads that are
+// coherent across the chip (sc1), as their stores were.
+template <bool COHERENT>
+__device__ __forceinline__ void reduce_partials(const double* __restrict__ p, long long count, double* __restrict__ out, int tid) {
+  double s1 = 0.0, s2 = 0.0;
+  for (long long t = tid; t < count; t += 256) {
+    if (COHERENT) {
+      s1 += __builtin_bit_cast(double, __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p + t * 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      s2 += __builtin_bit_cast(double, __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p + t * 2 + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    } else { s1 += p[t * 2]; s2 += p[t * 2 + 1]; }
+  }
+  __shared__ double sh1[256], sh2[256];
+  sh1[tid] = s1; sh2[tid] = s2;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if (tid < w) { sh1[tid] += sh1[tid + w]; sh2[tid] += sh2[tid + w]; }
+    __syncthreads();
+  }
+  if (tid == 0) { out[0] = sh1[0]; out[1] = sh2[0]; }
+  __syncthreads();
+}
+
+// The reduction of the partials folded into the launch that produces them (round 5): every block
+// publishes its pair with chip-coherent stores, waits for their acknowledgement and takes a ticket; the block that draws the
+// last one reduces all pairs in k_reduce_stats' order (the same bits) and re-arms the counter. Only for a launch that covers
+// the whole array (tfl_model_forward); a z-slab rank's windowed launches keep the separate k_reduce_stats.
+// Two levels of tickets: ticket[1 + plane] counts the blocks of a (batch item, plane), ticket[0] the planes that are complete
+// -- one counter for all blocks serialised 2048 same-address atomics at 128^3 (+16 us on a 19 us kernel, measured); with
+// one counter per plane the atomics of different planes proceed in parallel and only 128 meet on the last one.
+struct StatTail { unsigned* ticket; double* stats; long long per_sample; unsigned per_plane, planes; int B; };
+constexpr int kStatTickets = 1 << 16;       // ticket words a model owns (abi.cpp): B * Z + 1 of them are used
+__device__ __forceinline__ void publish_and_maybe_reduce(const StatTail& tl, double* __restrict__ partials, long long blk, double p1,
+                                                         double p2, int tid) {
+  __shared__ int last;
+  if (tid == 0) {
+    if (tl.ticket) {
+      __hip_atomic_store(reinterpret_cast<unsigned long long*>(partials + blk * 2), __builtin_bit_cast(unsigned long long, p1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(reinterpret_cast<unsigned long long*>(partials + blk * 2 + 1), __builtin_bit_cast(unsigned long long, p2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // both pairs have reached the coherence point before the ticket is drawn
+      unsigned* mine = tl.ticket + 1 + (unsigned)(blk / tl.per_plane);
+      last = 0;
+      if (atomicAdd(mine, 1u) == tl.per_plane - 1u) {       // this plane is complete (its counter re-armed by the one block that sees that)
+        *mine = 0u;
+        last = atomicAdd(tl.ticket, 1u) == tl.planes - 1u;
+      }
+    } else {
+      partials[blk * 2] = p1; partials[blk * 2 + 1] = p2;
+      last = 0;
+    }
+  }
+  if (!tl.ticket) return;             // uniform
+  __syncthreads();
+  if (!last) return;                  // block-uniform
+  for (int b = 0; b < tl.B; b++) reduce_partials<true>(partials + (long long)b * tl.per_sample * 2, tl.per_sample, tl.stats + b * 2, tid);
+  if (tid == 0) *tl.ticket = 0u;      // re-armed for the next launch (which starts behind this one on the stream)
+}
+
 // partials[block*2 + {0,1}] = this block's sum u, sum u^2 of U_bc (fp64). A second tiny kernel
 // (k_reduce_stats) adds the partials of each sample in a fixed order, so the scale is bit-reproducible
 // run to run and independent of how the grid is sharded -- no atomics (8192 same-address fp64 atomics
@@ -82,7 +141,7 @@ __device__ __forceinline__ float u_bc_at(const Dom& d, const float* __restrict__
 template <bool IS3D>
 __global__ __launch_bounds__(256) void k_bcs_div_stats(Dom d, const float* __restrict__ U, const float* __restrict__ flags,
                                                        float* __restrict__ Ubc, float* __restrict__ div,
-                                                       double* __restrict__ partials) {
+                                                       double* __restrict__ partials, StatTail tl) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int j = blockIdx.y * blockDim.y + threadIdx.y;
   int b, k; dom_bk(d, b, k);
@@ -113,11 +172,8 @@ __global__ __launch_bounds__(256) void k_bcs_div_stats(Dom d, const float* __res
   const int tid = threadIdx.y * blockDim.x + threadIdx.x;
   if ((tid & 63) == 0) { part[(tid >> 6) * 2] = s1; part[(tid >> 6) * 2 + 1] = s2; }
   __syncthreads();
-  if (tid == 0) {
-    const long long blk = blockIdx.x + (long long)gridDim.x * (blockIdx.y + (long long)gridDim.y * ((long long)b * d.Z + k));
-    partials[blk * 2] = (part[0] + part[2]) + (part[4] + part[6]);
-    partials[blk * 2 + 1] = (part[1] + part[3]) + (part[5] + part[7]);
-  }
+  const long long blk = blockIdx.x + (long long)gridDim.x * (blockIdx.y + (long long)gridDim.y * ((long long)b * d.Z + k));
+  publish_and_maybe_reduce(tl, partials, blk, (part[0] + part[2]) + (part[4] + part[6]), (part[1] + part[3]) + (part[5] + part[7]), tid);
 }
 
 // k_bcs_div_stats with four x-cells per thread (tfl_vec4.hpp). The wall-BC masks of the cell's +x / +y / +z
@@ -127,7 +183,7 @@ __global__ __launch_bounds__(256) void k_bcs_div_stats(Dom d, const float* __res
 template <bool IS3D>
 __global__ __launch_bounds__(256, TFL_LB_BCS) void k_bcs_div_stats_v4(Dom d, const float* __restrict__ U, const float* __restrict__ flags,
                                                           float* __restrict__ Ubc, float* __restrict__ div,
-                                                          double* __restrict__ partials) {
+                                                          double* __restrict__ partials, StatTail tl) {
   const V4Ctx c = v4_ctx(d);
   const int j = blockIdx.y * blockDim.y + threadIdx.y;
   int b, k; dom_bk(d, b, k);
@@ -229,11 +285,8 @@ __global__ __launch_bounds__(256, TFL_LB_BCS) void k_bcs_div_stats_v4(Dom d, con
   const int tid = threadIdx.y * blockDim.x + threadIdx.x;
   if ((tid & 63) == 0) { part[(tid >> 6) * 2] = s1; part[(tid >> 6) * 2 + 1] = s2; }
   __syncthreads();
-  if (tid == 0) {
-    const long long blk = blockIdx.x + (long long)gridDim.x * (blockIdx.y + (long long)gridDim.y * ((long long)b * d.Z + k));
-    partials[blk * 2] = (part[0] + part[2]) + (part[4] + part[6]);
-    partials[blk * 2 + 1] = (part[1] + part[3]) + (part[5] + part[7]);
-  }
+  const long long blk = blockIdx.x + (long long)gridDim.x * (blockIdx.y + (long long)gridDim.y * ((long long)b * d.Z + k));
+  publish_and_maybe_reduce(tl, partials, blk, (part[0] + part[2]) + (part[4] + part[6]), (part[1] + part[3]) + (part[5] + part[7]), tid);
 }
 
 // stats[b*2 + 0] = sum u, stats[b*2 + 1] = sum u^2 over all C*Z*Y*X values of U_bc[b]; one block per
@@ -243,17 +296,7 @@ __global__ __launch_bounds__(256) void k_reduce_stats(const double* __restrict__
   // [first, first + count) = the blocks of the z-planes that take part (a z-slab rank reduces only the
   // planes it owns; the halo planes belong to its neighbours)
   const int b = blockIdx.x;
-  const double* p = partials + ((long long)b * per_sample + first) * 2;
-  double s1 = 0.0, s2 = 0.0;
-  for (long long t = threadIdx.x; t < count; t += 256) { s1 += p[t * 2]; s2 += p[t * 2 + 1]; }
-  __shared__ double sh1[256], sh2[256];
-  sh1[threadIdx.x] = s1; sh2[threadIdx.x] = s2;
-  __syncthreads();
-  for (int w = 128; w > 0; w >>= 1) {
-    if ((int)threadIdx.x < w) { sh1[threadIdx.x] += sh1[threadIdx.x + w]; sh2[threadIdx.x] += sh2[threadIdx.x + w]; }
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) { stats[b * 2] = sh1[0]; stats[b * 2 + 1] = sh2[0]; }
+  reduce_partials<false>(partials + ((long long)b * per_sample + first) * 2, count, stats + b * 2, (int)threadIdx.x);
 }
 
 // lib/modules/variance.lua:44-76 (n-1) + Sqrt; the Clamp after it is a no-op (model.lua:106 typo). One-pass form
@@ -587,20 +630,30 @@ long long model_stat_blocks(int B, int Z, int Y, int X) {
 // stages: bit 0 = k_bcs_div_stats on the current z-window (per-plane partial sums land in absolute slots, so the
 // launch may be split into boundary / interior windows), bit 1 = reduce the partials of planes [zlo, zhi) into stats
 void model_pre(hipStream_t st, bool is3d, int B, int Z, int Y, int X, const float* U, const float* flags, float* Ubc,
-               float* div, double* partials, double* stats, int zlo, int zhi, int stages) {
+               float* div, double* partials, double* stats, int zlo, int zhi, int stages, unsigned* ticket) {
   const Dom d = make_dom(Z, Y, X);
   const dim3 blk(64, 4, 1), grd = TFL_GRID3(d, B);
   const Vec4Launch v = vec4_launch(B, Z, Y, X, {U, flags, Ubc, div});
   const long long per_plane = v.ok ? (long long)v.grd.x * v.grd.y : (long long)grd.x * grd.y;   // <= model_stat_blocks / (Z*B)
+  // both stages over the whole array in one call (tfl_model_forward): the launch CAN reduce its own partials
+  // (publish_and_maybe_reduce) -- opt-in, TFL_STATS_FOLD=1: bit-identical, but measured slower than the 4-wave k_reduce_stats
+  // launch it saves (profiles/r05_step_experiments.txt: k_bcs_div_stats 15.4 -> 23.5 us with two-level tickets, 35.6 with one
+  // counter, against 4.2 us for the launch: the chip-coherent stores, their acknowledgement and the ticket sit at the end of
+  // every one of the 2048 short blocks of a streaming kernel)
+  const char* ef = getenv("TFL_STATS_FOLD");
+  const bool fused = ticket && (stages & 3) == 3 && d.nw == Z && d.n0 == Z && zlo == 0 && zhi == Z && (ef && atoi(ef) == 1) &&
+                     (long long)Z * B + 1 <= kStatTickets && per_plane < (1ll << 31);
+  StatTail tl = {nullptr, stats, per_plane * Z, (unsigned)per_plane, (unsigned)(Z * B), B};
+  if (fused) tl.ticket = ticket;
   if (stages & 1) {
     if (v.ok) {
       TFL_TIMED_EXT("k_bcs_div_stats", st);
-      if (is3d) TFL_LAUNCH_EXT((k_bcs_div_stats_v4<true>), v.grd, v.blk, 0, st, d, U, flags, Ubc, div, partials);
-      else TFL_LAUNCH_EXT((k_bcs_div_stats_v4<false>), v.grd, v.blk, 0, st, d, U, flags, Ubc, div, partials);
-    } else if (is3d) { TFL_TIMED("k_bcs_div_stats", st); k_bcs_div_stats<true><<<grd, blk, 0, st>>>(d, U, flags, Ubc, div, partials); }
-    else { TFL_TIMED("k_bcs_div_stats", st); k_bcs_div_stats<false><<<grd, blk, 0, st>>>(d, U, flags, Ubc, div, partials); }
+      if (is3d) TFL_LAUNCH_EXT((k_bcs_div_stats_v4<true>), v.grd, v.blk, 0, st, d, U, flags, Ubc, div, partials, tl);
+      else TFL_LAUNCH_EXT((k_bcs_div_stats_v4<false>), v.grd, v.blk, 0, st, d, U, flags, Ubc, div, partials, tl);
+    } else if (is3d) { TFL_TIMED("k_bcs_div_stats", st); k_bcs_div_stats<true><<<grd, blk, 0, st>>>(d, U, flags, Ubc, div, partials, tl); }
+    else { TFL_TIMED("k_bcs_div_stats", st); k_bcs_div_stats<false><<<grd, blk, 0, st>>>(d, U, flags, Ubc, div, partials, tl); }
   }
-  if (stages & 2) { TFL_TIMED_EXT("k_reduce_stats", st); TFL_LAUNCH_EXT(k_reduce_stats, B, 256, 0, st, (const double*)partials, per_plane * Z, per_plane * zlo, per_plane * (zhi - zlo), stats); }
+  if ((stages & 2) && !fused) { TFL_TIMED_EXT("k_reduce_stats", st); TFL_LAUNCH_EXT(k_reduce_stats, B, 256, 0, st, (const double*)partials, per_plane * Z, per_plane * zlo, per_plane * (zhi - zlo), stats); }
 }
 
 void model_net_input(hipStream_t st, bool is3d, int B, int Z, int Y, int X, const float* pDiv, const float* div,

@@ -167,7 +167,7 @@ int normalize_pressure_mean(hipStream_t st, bool is3d, int B, int Z, int Y, int 
 // model.hip
 long long model_stat_blocks(int B, int Z, int Y, int X);
 void model_pre(hipStream_t st, bool is3d, int B, int Z, int Y, int X, const float* U, const float* flags, float* Ubc,
-               float* div, double* partials, double* stats, int zlo, int zhi, int stages = 3);
+               float* div, double* partials, double* stats, int zlo, int zhi, int stages = 3, unsigned* ticket = nullptr);
 void model_net_input(hipStream_t st, bool is3d, int B, int Z, int Y, int X, const float* pDiv, const float* div,
                      const float* flags, const double* stats, double count, float* x3);
 // the general net input of lib/model.lua:130-148: channels {pDiv/scale?, SetWallBcs(U)/scale (C)?, div/scale?, occupancy} in

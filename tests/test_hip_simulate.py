@@ -254,6 +254,29 @@ def test_conv_fused_layers_and_mfma_tail(monkeypatch):
     assert m.range_errors(tp) > 0
 
 
+def test_stats_reduction_folded_into_its_producer(monkeypatch):
+    """Round 5: the fp64 reduction of the per-block {sum u, sum u^2} partials (the std normaliser of the net input) runs in
+    the last block of k_bcs_div_stats to finish (two-level ticket counters, chip-coherent partials) instead of a launch of
+    its own (k_reduce_stats) under TFL_STATS_FOLD=1 -- opt-in: measured slower than the launch it saves (model.hip). Same
+    summation order, so the scale -- and with it every bit of p and U -- must be identical; several calls in a row (the
+    counters re-arm), 2-D and 3-D, B = 3, ragged grids that take the one-cell kernels."""
+    import torch
+    from fluidnet_amd import FluidNetModel
+    dev = torch.device("cuda:0")
+    for dims, seed, B, which in [((24, 40, 72), 71, 1, "3d"), ((9, 13, 30), 72, 3, "3d"), ((1, 70, 90), 73, 2, "2d"),
+                                 ((64, 64, 64), 74, 1, "3d")]:
+        layers = _layers2d() if which == "2d" else S.default_3d_layers(seed=3)
+        sc = scenes.make_scene(dims, seed=seed, vel_cells=0.4, B=B)
+        tp, tU, tf = (torch.from_numpy(sc[k]).to(dev) for k in ("p", "U", "flags"))
+        monkeypatch.delenv("TFL_STATS_FOLD", raising=False)      # the default: k_reduce_stats as a launch of its own
+        p0, U0 = FluidNetModel(layers, which == "3d").forward([tp, tU, tf])
+        monkeypatch.setenv("TFL_STATS_FOLD", "1")
+        m = FluidNetModel(layers, which == "3d")
+        for rep in range(3):
+            p1, U1 = m.forward([tp, tU, tf])
+            assert torch.equal(p0, p1) and torch.equal(U0, U1), (dims, rep)
+
+
 def test_fp16_range_errors_are_counted(oracle):
     """conv_mfma16.hip clamps activations at the fp16 range and COUNTS the blocks that did (tfl_model_range_errors): a net
     input far outside it (pressure 1e9 times the velocity scale) must be reported, an ordinary one must not."""
