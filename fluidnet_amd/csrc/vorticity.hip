@@ -449,8 +449,12 @@ __global__ __launch_bounds__(512) void k_vort_fused(Dom d, int cols_x, int cols_
     const bool out_inner = out_live && f_in && zo >= 1 && zo <= d.Z - 2;
     float pu0 = 0.0f, pu1 = 0.0f, pu2 = 0.0f, pfc = 0.0f, pnx = 0.0f, pny = 0.0f, pnz = 0.0f;
     if (out_live) {
+      // the plane's own velocities are still in the ring (plane t - 3 entered it three steps ago; its slot is overwritten at
+      // the top of the NEXT step, behind this step's barriers) -- round 5: they were re-read from memory, 12 of the kernel's
+      // ~61 fetched bytes per cell at 256^3 (profiles/r04_256_pmc_traffic.txt)
+      const float* own = Ut + (zo & 3) * 3 * FUN + (ty + 3) * FUX + tx + 3;
+      pu0 = own[0]; pu1 = own[FUN]; pu2 = own[2 * FUN];
       const int o = o_xy + zo * d.sz;
-      pu0 = Uin[o]; pu1 = Uin[o + d.sc]; pu2 = Uin[o + 2 * d.sc];
       if (out_inner) { pfc = flags[o]; pnx = flags[o - 1]; pny = flags[o - d.sy]; pnz = flags[o - d.sz]; }
     }
     // ---- curl, |curl| of plane zc = t - 2 (VecGrid::curl, grid.cc:497-515, centred velocities 0 on the border shell) ----
@@ -582,7 +586,7 @@ bool vorticity_confinement_fused(hipStream_t st, int B, int Z, int Y, int X, con
   int cz = 4;
   {
     long long best = -1;
-    for (int c = 4; c <= 32; c++) {
+    for (int c = 4; c <= 64; c++) {
       const long long blocks = (long long)cxn * cyn * B * ((na + c - 1) / c + (nb + c - 1) / c);
       const long long cost = ((blocks + slots - 1) / slots) * (c + 6);
       if (best < 0 || cost < best) { best = cost; cz = c; }

@@ -450,8 +450,11 @@ print("ADV_VARIANTS_OK", done)
 
 
 @pytest.mark.parametrize("env", [{"TFL_VEL3_KZ": "2", "TFL_SCAL3_TZ": "14"}, {"TFL_VEL3_KZ": "2", "TFL_SCAL3_TZ": "12"},
-                                 {"TFL_VEL3_KZ": "1", "TFL_SCAL3_TZ": "1"}, {"TFL_ADVECT_GATHER": "1"}],
-                         ids=["big-grid-defaults", "kz2-scal-1x2", "kz1-scal-1x1", "gather-kernels"])
+                                 {"TFL_VEL3_KZ": "1", "TFL_SCAL3_TZ": "1"}, {"TFL_ADVECT_GATHER": "1"},
+                                 {"TFL_SCAL3_MARCH": "1", "TFL_SCAL3M_CZ_A": "3", "TFL_SCAL3M_CZ_B": "2"},
+                                 {"TFL_SCAL3_MARCH": "1", "TFL_SCAL3M_CZ_A": "1", "TFL_SCAL3M_CZ_B": "64"}, {"TFL_SCAL3_MARCH": "1"}],
+                         ids=["big-grid-defaults", "kz2-scal-1x2", "kz1-scal-1x1", "gather-kernels", "marched-short-chunks",
+                              "marched-1-and-64", "marched-scalar-kernels"])
 def test_advection_kernel_variants_are_bit_exact(env):
     """The advection kernels pick their block shape from the grid size: from 6 M cells per batch item on (256^3, BASELINE
     config 5) advectVel runs two planes per block (advect_vel3.inc, kz2) and advectScalar's pass A four planes per thread
@@ -463,7 +466,7 @@ def test_advection_kernel_variants_are_bit_exact(env):
     import subprocess, sys
     code = _ADV_VARIANTS % (os.path.dirname(HERE), HERE, 4242)
     e = dict(os.environ)
-    for k in ("TFL_VEL3_KZ", "TFL_SCAL3_TZ", "TFL_ADVECT_GATHER", "TFL_ADVECT_MODE"):
+    for k in ("TFL_VEL3_KZ", "TFL_SCAL3_TZ", "TFL_ADVECT_GATHER", "TFL_ADVECT_MODE", "TFL_SCAL3M_CZ_A", "TFL_SCAL3M_CZ_B", "TFL_SCAL3_MARCH"):
         e.pop(k, None)
     e.update(env)
     out = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=900)
