@@ -381,8 +381,12 @@ class GraphedSimulate:
     Only capturable configurations: convnet, or jacobi with a fixed iteration count (pTol = 0) -- both
     are what lib/simulate.lua does (simulate.lua:287-291)."""
 
-    def __init__(self, conf, mconf, batch, model=None, warmup=2):
+    def __init__(self, conf, mconf, batch, model=None, warmup=2, native=False):
+        """native=True captures the ONE-call native step (tfl_simulate_step: the sparse setConstVals pairs and, in 3-D, the
+        buoyancy force folded into the kernels that produce the fields -- fewer launches in the graph) instead of the
+        operator-by-operator Python orchestration; same results (tests/test_hip_simulate.py)."""
         self.conf, self.mconf, self.batch, self.model = conf, mconf, batch, model
+        self.native = bool(native)
         self.graph = None
         self._pinned = []     # every buffer the captured launches point into, kept alive with the graph
         self.capture(warmup)
@@ -392,7 +396,10 @@ class GraphedSimulate:
         # scratch scope of our own (no other caller can grow / replace that buffer) -- see capture()
         prev, tfluids._scratch_scope = tfluids._scratch_scope, ("graph", id(self))
         try:
-            simulate(self.conf, self.mconf, self.batch, self.model)
+            if self.native:
+                simulate_native(self.conf, self.mconf, self.batch, self.model)
+            else:
+                simulate(self.conf, self.mconf, self.batch, self.model)
         finally:
             tfluids._scratch_scope = prev
 

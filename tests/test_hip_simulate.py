@@ -644,13 +644,16 @@ def test_graphed_simulate_equals_eager(which):
         model = FluidNetModel(_layers2d(), False) if which == "2d_convnet" else None
         mconf = dict(dt=4 / 60, advectionMethod="maccormackOurs", maccormackStrength=0.75, buoyancyScale=1.0,
                      gravityScale=0, vorticityConfinementAmp=0, simMethod="convnet" if model else "jacobi", maxIter=20)
-    eager, graphed = _to_dev(b, dev), _to_dev(b, dev)
+    eager, graphed, graphed_native = _to_dev(b, dev), _to_dev(b, dev), _to_dev(b, dev)
     g = GraphedSimulate(None, mconf, graphed, model)
+    gn = GraphedSimulate(None, mconf, graphed_native, model, native=True)    # the one-call native step captured (round 5)
     for _ in range(6):
         simulate(None, mconf, eager, model)
         g.step()
+        gn.step()
     for k in ("pDiv", "UDiv", "density"):
         assert torch.equal(eager[k], graphed[k]), k
+        assert torch.equal(eager[k], graphed_native[k]), ("native", k)
     assert float(eager["UDiv"].abs().max()) > 0
 
 

@@ -21,8 +21,24 @@ class NullComm(_CommBase):
     def __init__(self, in_place=True):
         super().__init__()
         if in_place:
+            import ctypes
             from fluidnet_amd._lib import COMM_START_V
-            self._cbv = COMM_START_V(lambda *a: 0)
+            hip = ctypes.CDLL("libamdhip64.so")
+            hip.hipMemsetAsync.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_void_p]
+
+            def start_v(user, tag, n_lo, send_lo, recv_lo, n_hi, send_hi, recv_hi):
+                # the halo planes a neighbour would have delivered are ZEROED (round 5): the divergence halos
+                # live in the step's shared workspace and otherwise hold whatever the advection left there (+-inf clamp bounds),
+                # which the first conv layer reports as fp16 range errors through one atomic counter -- and since round 5 the
+                # next step is refused (TFL_ERANGE)
+                if tag not in (2, 3):   # tag 0 (U, p): the halos keep what a still scene's neighbours would have sent; tags 2 / 3
+                    return 0            # (advected U + density, divergence) land in workspace memory: garbage unless delivered
+                st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+                for n, chunks in ((n_lo, recv_lo), (n_hi, recv_hi)):
+                    for q in range(n):
+                        hip.hipMemsetAsync(ctypes.c_void_p(chunks[q].ptr), 0, int(chunks[q].n) * 4, st)
+                return 0
+            self._cbv = COMM_START_V(start_v)
             self.struct.exchange_start_v = self._cbv
 
     def start(self, tag, send_lo, recv_lo, send_hi, recv_hi):
@@ -32,7 +48,11 @@ class NullComm(_CommBase):
         pass
 
     def allreduce(self, stats):
-        pass
+        # what the other ranks would have contributed: without it a rank whose slab holds no moving cell (the plume's disc spans
+        # a third of z) has sum u^2 = 0, a scale of 0, an infinite net input -- every block of the conv stack reports a range
+        # error through one atomic counter (the "12 M range errors" of profiles/r04_slab_host_cost.txt), and since round 5 the
+        # next step is refused. One small in-place add on the step's stream, like the real all-reduce's kernel.
+        stats.view(-1, 2)[:, 1] += 1.0e5
 
 
 _pos = [a for a in sys.argv[1:] if not a.startswith("--")]
@@ -55,10 +75,17 @@ for rank in (0, world // 2):
     # (stale p halos), leave the fp16 range within a few steps, and every block of the first conv layer would report a
     # range error through one atomic counter -- 20 us of serialised atomics that no real run has
     still = "--still" in sys.argv
+    # ... and (round 5) puts U and the density back to the initial state: the confinement force is added every step whatever dt
+    # is, and with a projection that iterates on undelivered halos nothing removes it again -- the run blew up within the
+    # warm-up (the 12 M range errors of profiles/r04_slab_host_cost.txt; since round 5 a refused step, TFL_ERANGE). The three
+    # small copies are torch's, outside the library's kernel profile; they are inside the wall-clock figure.
+    saved = {k: batch[k].clone() for k in ("UDiv", "density")}
 
     def one_step():
         if still:
             batch["pDiv"].zero_()
+            for k, v in saved.items():
+                batch[k].copy_(v)
         sim.step()
 
     for _ in range(5):
