@@ -45,6 +45,7 @@
 #include <cstring>
 #include <mutex>
 #include <type_traits>
+#include <utility>
 
 namespace tfl {
 
@@ -859,6 +860,232 @@ __global__ __launch_bounds__(256, TFL_M16P_LB) void k_conv3_m16p(Dom d, int cols
 }
 
 
+// =====================================================================================================================
+// k_conv3_m16q (round 5): k_conv3_m16p SOFTWARE-PIPELINED over the planes, with the interleaving written out. A wave's own vector
+// instructions slip into the gaps between its own MFMAs; another wave's do not (tools/ubench/mfma16_coissue.hip,
+// profiles/r05_conv_experiments.txt 6) -- and in k_conv3_m16p a wave issues the 56 MFMAs of a plane in one burst and the
+// epilogue that depends on them in another, so the matrix pipe idles through every epilogue (pipe busy 0.43-0.52). Here the
+// epilogue of plane q - 1 (second accumulator set) is cut into 28 slots of 3-7 instructions, one behind every PAIR of plane q's
+// MFMAs, the order pinned with sched_barrier fences (hipcc's own scheduler and the sched_group_barrier solver both left the
+// epilogue in one block behind the MFMAs); a fragment is read from LDS two pairs before its first use. Same MFMAs in the same
+// order per accumulator, same epilogue arithmetic: bit-identical to k_conv3_m16p (TAIL: to its matrix-core tail).
+namespace q16 {
+struct Mop { int frag, w, oy; };
+struct Frag { int kind, off, first; };        // kind 0 / 1 / 2 = the A / B / C fragment pointer; off = slot offset inside the plane
+struct Tables { Mop m[56]; Frag f[32]; };
+constexpr Tables make_tables() {
+  Tables t{};
+  int im = 0, fr = 0;
+  for (int kind = 0; kind < 2; kind++)
+    for (int ry = 0; ry < 6; ry++)
+      for (int tm = 0; tm < 2; tm++) {
+        t.f[fr] = Frag{kind, (ry * 2 + tm) * kMHX, im};
+        for (int dy = 0; dy < 3; dy++) {
+          const int oy = ry - dy;
+          if (oy < 0 || oy > 3) continue;
+          t.m[im++] = Mop{fr, kind * 6 + dy * 2 + tm, oy};
+        }
+        fr++;
+      }
+  for (int ry = 0; ry < 4; ry++)
+    for (int tm = 0; tm < 2; tm++) {
+      t.f[fr] = Frag{2, (ry * 2 + tm) * kMHX, im};
+      t.m[im++] = Mop{fr, 12 + tm, ry};
+      fr++;
+    }
+  return t;
+}
+constexpr Tables kT = make_tables();
+constexpr int kAhead = 2;                     // pairs of MFMAs between a fragment's LDS read and its first use
+template <class F, int... I>
+__device__ __forceinline__ void static_for(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>()), ...); }
+}  // namespace q16
+
+#ifndef TFL_M16Q_LB
+#define TFL_M16Q_LB 2
+#endif
+template <bool TAIL>
+__global__ __launch_bounds__(256, TFL_M16Q_LB) void k_conv3_m16q(Dom d, int cols_x, int cols_y, int cz, int chunks_a, int chunks,
+                                                                int n_blocks, const uint4* __restrict__ in,
+                                                                const uint4* __restrict__ wfrag, const float* __restrict__ bias,
+                                                                void* __restrict__ outv, float post,
+                                                                unsigned long long* __restrict__ range_err) {
+  using namespace q16;
+  extern __shared__ __attribute__((aligned(16))) uint4 lds[];
+  const int per_xcd = (n_blocks + 7) / 8;
+  const int blk = (int)(blockIdx.x % 8) * per_xcd + (int)(blockIdx.x / 8);
+  if (blk >= n_blocks) return;
+  int t = blk;
+  const int cx = t % cols_x; t /= cols_x;
+  const int cy = t % cols_y; t /= cols_y;
+  const int ch = t % chunks;
+  const int b = t / chunks;
+  const int zc0 = ch < chunks_a ? d.w0 + ch * cz : d.w1 + (ch - chunks_a) * cz;
+  const int z_end = ch < chunks_a ? d.w0 + d.n0 : d.w1 + (d.nw - d.n0);
+  const int nz = min(cz, z_end - zc0);                  // output planes of this block
+  const int nsteps = nz + 2;                            // input planes zc0 - 1 .. zc0 + nz
+  const int x0 = cx * kMX, y0 = cy * kMY;
+  const long long cells = d.sc;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  h8 W[kPFrags];
+#pragma unroll
+  for (int f = 0; f < kPFrags; f++) W[f] = __builtin_bit_cast(h8, wfrag[f * 64 + lane]);
+
+  // staging (as k_conv3_m16p)
+  const uint4* src = in + (long long)b * cells * 2;
+  const uint4* zero = wfrag + kPFrags * 64;
+  int st_off[kMDma];
+  unsigned st_ok = 0;
+#pragma unroll
+  for (int j = 0; j < kMDma; j++) {
+    const int item = (wave * kMDma + j) * 64 + lane;
+    const int r = min(item, kMPlane - 1) / kMHX, hx = min(item, kMPlane - 1) - r * kMHX;
+    const int hy = r >> 1, tm = r & 1;
+    const int gx = x0 - 1 + hx, gy = y0 - 1 + hy;
+    st_off[j] = (min(max(gy, 0), d.Y - 1) * 2 + tm) * d.X + min(max(gx, 0), d.X - 1);
+    st_ok |= (item < kMPlane && gx >= 0 && gx < d.X && gy >= 0 && gy < d.Y) ? (1u << j) : 0u;
+  }
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void*)lds;
+  auto issue = [&](int q) {          // input plane q of the chunk (z = zc0 - 1 + q) -> ring slot q % kPRing
+    const int gz = zc0 - 1 + q;
+    const bool z_ok = q < nsteps && gz >= 0 && gz < d.Z;
+    const uint4* psrc = src + (long long)min(max(gz, 0), d.Z - 1) * d.Y * 2 * d.X;
+#pragma unroll
+    for (int j = 0; j < kMDma; j++) {
+      const uint4* gp = (z_ok && ((st_ok >> j) & 1)) ? psrc + st_off[j] : zero;
+      dma16(gp, __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)(((q % kPRing) * kMPitch + (wave * kMDma + j) * 64) * 16)));
+    }
+  };
+
+  const int wx = wave & 1, wy = wave >> 1;
+  const int nn = lane & 15, g = lane >> 4;
+  const int row0 = (wy * 4 * 2) * kMHX + wx * 16 + nn;
+  const int slotA = row0 + (g < 3 ? g : 0);
+  const int slotB = row0 + (g == 0 ? 1 : (g == 1 ? 2 : (g == 2 ? 0 : 1)));
+  const int slotC = row0 + 2 + (g < 3 ? g : 0) * 2 * kMHX;
+  const int x = x0 + wx * 16 + nn;
+  const int y = y0 + wy * 4 + g;                          // the row this lane group stores (after the transpose)
+  const bool live = x < d.X && y < d.Y;
+  const float bias0 = bias[2 * g], bias1 = bias[2 * g + 1];
+  float b4a = 0.0f, b4b = 0.0f, w5a = 0.0f, w5b = 0.0f, b5 = 0.0f, post4 = 0.0f;
+  h4v A4 = {0, 0, 0, 0};
+  if (TAIL) {
+    b4a = bias[kTailB4 + 2 * g]; b4b = bias[kTailB4 + 2 * g + 1]; w5a = bias[kTailW5 + 2 * g]; w5b = bias[kTailW5 + 2 * g + 1];
+    b5 = bias[kTailB5]; post4 = bias[kTailPost4];
+    A4 = __builtin_bit_cast(h4v, reinterpret_cast<const uint2*>(wfrag + (kPFrags * 64 + 1))[lane]);
+  }
+  float hmax = 0.0f;
+
+  // ---- the epilogue of one plane as 28 slots (state in registers; slot S touches the accumulators `a` of the plane before) ----
+  float h0[4], h1[4], pp[4];
+  uint32_t H[4], L[4];
+  f4 dq[4];
+  float r02 = 0.0f, r13 = 0.0f;
+  auto epi = [&](auto sc, const f4 (&a)[4], int z) {
+    constexpr int S = decltype(sc)::value;
+    if constexpr (S < 16) {
+      constexpr int r = S / 4, ph = S % 4;
+      if constexpr (ph == 0) h0[r] = __builtin_fmaxf(__builtin_fmaf(__builtin_fmaf(a[r][1], 0x1p-11f, a[r][0]), post, bias0), 0.0f);
+      if constexpr (ph == 1) h1[r] = __builtin_fmaxf(__builtin_fmaf(__builtin_fmaf(a[r][3], 0x1p-11f, a[r][2]), post, bias1), 0.0f);
+      if constexpr (ph == 2) {
+        hmax = __builtin_fmaxf(__builtin_fmaxf(hmax, h0[r]), h1[r]);
+        split_pair(__builtin_fminf(h0[r], kHalfMax), __builtin_fminf(h1[r], kHalfMax), H[r], L[r]);
+      }
+      if constexpr (ph == 3 && TAIL) {
+        const uint2 bq = make_uint2(H[r], L[r]);
+        dq[r] = __builtin_amdgcn_mfma_f32_16x16x16f16(A4, __builtin_bit_cast(h4v, bq), (f4){0.0f, 0.0f, 0.0f, 0.0f}, 0, 0, 0);
+      }
+    } else if constexpr (!TAIL) {
+      if constexpr (S == 16) transpose4(H);
+      if constexpr (S == 18) transpose4(L);
+      if constexpr (S == 20) {
+        if (live) {
+          uint4* orow = reinterpret_cast<uint4*>(outv) + (((long long)b * d.Z + z) * d.Y + y) * 2 * d.X + x;
+          orow[0] = make_uint4(H[0], H[1], H[2], H[3]);
+          orow[d.X] = make_uint4(L[0], L[1], L[2], L[3]);
+        }
+      }
+    } else {
+      if constexpr (S >= 17 && S <= 20) {
+        constexpr int r = S - 17;
+        const float ha = __builtin_fmaxf(__builtin_fmaf(__builtin_fmaf(dq[r][1], 0x1p-11f, dq[r][0]), post4, b4a), 0.0f);
+        const float hb = __builtin_fmaxf(__builtin_fmaf(__builtin_fmaf(dq[r][3], 0x1p-11f, dq[r][2]), post4, b4b), 0.0f);
+        pp[r] = __builtin_fmaf(w5a, ha, w5b * hb);
+      }
+      if constexpr (S == 21) r02 = swap_sum32(pp[0], pp[2]);
+      if constexpr (S == 22) r13 = swap_sum32(pp[1], pp[3]);
+      if constexpr (S == 23) {
+        const float psel = swap_sum16(r02, r13);
+        if (live) reinterpret_cast<float*>(outv)[(long long)b * cells + TFL_AT(d, x, y, z)] = psel + b5;
+      }
+    }
+  };
+
+  // ---- one plane step: the 56 MFMAs of plane q - 2 in 28 pairs, the epilogue slots of the plane before between them ----------
+  auto step = [&](int q, f4 (&acc)[4], const f4 (&prev)[4], auto with_epi) {
+    constexpr bool EPI = decltype(with_epi)::value;
+    const int s0 = ((q - 2) % kPRing) * kMPitch, s1 = ((q - 1) % kPRing) * kMPitch, s2 = (q % kPRing) * kMPitch;
+    const uint4* fa = lds + ((g == 3 ? s1 : s0) + slotA);
+    const uint4* fb = lds + ((g < 2 ? s1 : s2) + slotB);
+    const uint4* fc = lds + (s2 + slotC);
+    h8 F[32];
+    auto rd = [&](auto fcst) {
+      constexpr int f = decltype(fcst)::value;
+      const uint4* base = kT.f[f].kind == 0 ? fa : (kT.f[f].kind == 1 ? fb : fc);
+      F[f] = __builtin_bit_cast(h8, base[kT.f[f].off]);
+    };
+#pragma unroll
+    for (int r = 0; r < 4; r++) acc[r] = (f4){0.0f, 0.0f, 0.0f, 0.0f};
+    // the fragments of the first kAhead pairs
+    static_for([&](auto fcst) { constexpr int f = decltype(fcst)::value; if constexpr (kT.f[f].first / 2 < kAhead) rd(fcst); },
+               std::make_integer_sequence<int, 32>());
+    static_for([&](auto sc) {
+      constexpr int S = decltype(sc)::value;
+      static_for([&](auto fcst) { constexpr int f = decltype(fcst)::value; if constexpr (kT.f[f].first / 2 == S + kAhead) rd(fcst); },
+                 std::make_integer_sequence<int, 32>());
+      constexpr Mop m0 = kT.m[2 * S], m1 = kT.m[2 * S + 1];
+      acc[m0.oy] = __builtin_amdgcn_mfma_f32_16x16x32_f16(W[m0.w], F[m0.frag], acc[m0.oy], 0, 0, 0);
+      acc[m1.oy] = __builtin_amdgcn_mfma_f32_16x16x32_f16(W[m1.w], F[m1.frag], acc[m1.oy], 0, 0, 0);
+      if constexpr (EPI) {
+        __builtin_amdgcn_sched_barrier(0);
+        epi(sc, prev, zc0 + q - 3);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }, std::make_integer_sequence<int, 28>());
+  };
+  auto head = [&](int q) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // planes q - 2, q - 1, q have landed (plane q went out a whole step ago)
+    __syncthreads();                                    // ... for every wave; every wave is done reading plane q - 3
+    issue(q + 1);                                       // into the slot of plane q - 3 (past the chunk: the zero page)
+  };
+
+#pragma unroll
+  for (int q = 0; q < 3; q++) issue(q);
+  f4 accA[4], accB[4];
+  head(2);
+  step(2, accA, accB, std::false_type());
+  // two steps per trip so that the accumulator sets swap roles without register moves
+  int q = 3;
+#pragma unroll 1
+  for (; q + 1 < nsteps; q += 2) {
+    head(q);
+    step(q, accB, accA, std::true_type());
+    head(q + 1);
+    step(q + 1, accA, accB, std::true_type());
+  }
+  if (q < nsteps) {
+    head(q);
+    step(q, accB, accA, std::true_type());
+    static_for([&](auto sc) { epi(sc, accB, zc0 + nsteps - 3); }, std::make_integer_sequence<int, 28>());
+  } else {
+    static_for([&](auto sc) { epi(sc, accA, zc0 + nsteps - 3); }, std::make_integer_sequence<int, 28>());
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the trailing zero-page DMA must not outlive the block's LDS
+  if (!(hmax <= kHalfMax)) atomicAdd(range_err, 1ull);
+}
+
+
 // The FIRST layer (3 -> 8) in the same z-marched, K-packed form: the net input {pDiv / scale, div / scale, occupancy} is
 // built plane by plane while the planes before it are multiplied -- each thread loads the raw words of its one or two
 // slots of plane q + 1 at the top of step q and converts / splits / writes them to the LDS ring behind the step's MFMAs.
@@ -1403,6 +1630,14 @@ static void launch_m16p(hipStream_t st, const Dom& d, int B, const void* in, con
   // the tail's 1 x 1 x 1 layers: on the matrix cores (round 5) unless TFL_M16_TAIL_MFMA=0 (the vector-ALU epilogue, kept for A/B)
   const char* etm = getenv("TFL_M16_TAIL_MFMA");       // (read per call: the tests switch it inside one process)
   const bool tmf = !(etm && atoi(etm) == 0);
+  // the software-pipelined form (k_conv3_m16q, round 5) unless TFL_M16_PIPE=0
+  const char* epp = getenv("TFL_M16_PIPE");
+  if (!(epp && atoi(epp) == 0) && (!TAIL || tmf)) {
+    static bool attr_done[2] = {false, false};
+    if (!attr_done[TAIL]) { (void)hipFuncSetAttribute((const void*)k_conv3_m16q<TAIL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); attr_done[TAIL] = true; }
+    TFL_LAUNCH_EXT((k_conv3_m16q<TAIL>), grid, 256, lds_bytes, st, d, cxn, cyn, cz, chunks_a, chunks, n_blocks, (const uint4*)in, wp, bias, out, post, range_err);
+    return;
+  }
   if (TAIL && tmf)
     TFL_LAUNCH_EXT((k_conv3_m16p<TAIL, TAIL>), grid, 256, lds_bytes, st, d, cxn, cyn, cz, chunks_a, chunks, n_blocks, (const uint4*)in,
                    wp, bias, out, post, range_err, stagger_units("TFL_M16_STAGGER", 0));

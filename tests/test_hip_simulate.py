@@ -239,6 +239,14 @@ def test_conv_fused_layers_and_mfma_tail(monkeypatch):
             if cz:
                 monkeypatch.delenv("TFL_M16_CZ_F2")
         monkeypatch.delenv("TFL_M16_FUSE12")
+        # the software-pipelined 8 -> 8 layers (k_conv3_m16q: the epilogue of plane q - 1 between the MFMAs of plane q, the
+        # default) against a plane's epilogue behind its own MFMAs (k_conv3_m16p, TFL_M16_PIPE=0): the same MFMAs in the same
+        # order per accumulator, the same epilogue arithmetic -- bit-identical
+        monkeypatch.setenv("TFL_M16_PIPE", "0")
+        m3 = FluidNetModel(layers, True)
+        p3, U3 = m3.forward([tp, tU, tf])
+        monkeypatch.delenv("TFL_M16_PIPE")
+        assert torch.equal(p0, p3) and torch.equal(U0, U3), ("pipe", dims, scenes.rel_l2(p3.cpu().numpy(), p0.cpu().numpy()))
         monkeypatch.setenv("TFL_M16_TAIL_MFMA", "0")
         m2 = FluidNetModel(layers, True)
         p2, U2 = m2.forward([tp, tU, tf])
