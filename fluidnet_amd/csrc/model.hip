@@ -108,8 +108,15 @@ __device__ __forceinline__ void reduce_partials(const double* __restrict__ p, lo
 // one counter per plane the atomics of different planes proceed in parallel and only 128 meet on the last one.
 struct StatTail { unsigned* ticket; double* stats; long long per_sample; unsigned per_plane, planes; int B; };
 constexpr int kStatTickets = 1 << 16;       // ticket words a model owns (abi.cpp): B * Z + 1 of them are used
+// (FOLD is a template flag of the kernels: the default instantiation carries none of this -- its loads stay one batch,
+// tests/test_isa_cpu.py)
+template <bool FOLD>
 __device__ __forceinline__ void publish_and_maybe_reduce(const StatTail& tl, double* __restrict__ partials, long long blk, double p1,
                                                          double p2, int tid) {
+  if (!FOLD) {
+    if (tid == 0) { partials[blk * 2] = p1; partials[blk * 2 + 1] = p2; }
+    return;
+  }
   __shared__ int last;
   if (tid == 0) {
     if (tl.ticket) {
@@ -138,7 +145,7 @@ __device__ __forceinline__ void publish_and_maybe_reduce(const StatTail& tl, dou
 // (k_reduce_stats) adds the partials of each sample in a fixed order, so the scale is bit-reproducible
 // run to run and independent of how the grid is sharded -- no atomics (8192 same-address fp64 atomics
 // cost 0.2 ms at 128^3, 10x the kernel itself).
-template <bool IS3D>
+template <bool IS3D, bool FOLD = false>
 __global__ __launch_bounds__(256) void k_bcs_div_stats(Dom d, const float* __restrict__ U, const float* __restrict__ flags,
                                                        float* __restrict__ Ubc, float* __restrict__ div,
                                                        double* __restrict__ partials, StatTail tl) {
@@ -173,14 +180,14 @@ __global__ __launch_bounds__(256) void k_bcs_div_stats(Dom d, const float* __res
   if ((tid & 63) == 0) { part[(tid >> 6) * 2] = s1; part[(tid >> 6) * 2 + 1] = s2; }
   __syncthreads();
   const long long blk = blockIdx.x + (long long)gridDim.x * (blockIdx.y + (long long)gridDim.y * ((long long)b * d.Z + k));
-  publish_and_maybe_reduce(tl, partials, blk, (part[0] + part[2]) + (part[4] + part[6]), (part[1] + part[3]) + (part[5] + part[7]), tid);
+  publish_and_maybe_reduce<FOLD>(tl, partials, blk, (part[0] + part[2]) + (part[4] + part[6]), (part[1] + part[3]) + (part[5] + part[7]), tid);
 }
 
 // k_bcs_div_stats with four x-cells per thread (tfl_vec4.hpp). The wall-BC masks of the cell's +x / +y / +z
 // neighbours (needed for the divergence of U_bc) are rebuilt in registers from the flag rows already
 // loaded for the cell's own mask plus four more rows (the stick test of the +y / +z neighbour looks two rows
 // away); U_bc.x of cell i0+4 comes from the next lane. ~26 vector loads per 4 cells instead of ~120 dword loads.
-template <bool IS3D>
+template <bool IS3D, bool FOLD = false>
 __global__ __launch_bounds__(256, TFL_LB_BCS) void k_bcs_div_stats_v4(Dom d, const float* __restrict__ U, const float* __restrict__ flags,
                                                           float* __restrict__ Ubc, float* __restrict__ div,
                                                           double* __restrict__ partials, StatTail tl) {
@@ -286,7 +293,7 @@ __global__ __launch_bounds__(256, TFL_LB_BCS) void k_bcs_div_stats_v4(Dom d, con
   if ((tid & 63) == 0) { part[(tid >> 6) * 2] = s1; part[(tid >> 6) * 2 + 1] = s2; }
   __syncthreads();
   const long long blk = blockIdx.x + (long long)gridDim.x * (blockIdx.y + (long long)gridDim.y * ((long long)b * d.Z + k));
-  publish_and_maybe_reduce(tl, partials, blk, (part[0] + part[2]) + (part[4] + part[6]), (part[1] + part[3]) + (part[5] + part[7]), tid);
+  publish_and_maybe_reduce<FOLD>(tl, partials, blk, (part[0] + part[2]) + (part[4] + part[6]), (part[1] + part[3]) + (part[5] + part[7]), tid);
 }
 
 // stats[b*2 + 0] = sum u, stats[b*2 + 1] = sum u^2 over all C*Z*Y*X values of U_bc[b]; one block per
@@ -648,10 +655,23 @@ void model_pre(hipStream_t st, bool is3d, int B, int Z, int Y, int X, const floa
   if (stages & 1) {
     if (v.ok) {
       TFL_TIMED_EXT("k_bcs_div_stats", st);
-      if (is3d) TFL_LAUNCH_EXT((k_bcs_div_stats_v4<true>), v.grd, v.blk, 0, st, d, U, flags, Ubc, div, partials, tl);
-      else TFL_LAUNCH_EXT((k_bcs_div_stats_v4<false>), v.grd, v.blk, 0, st, d, U, flags, Ubc, div, partials, tl);
-    } else if (is3d) { TFL_TIMED("k_bcs_div_stats", st); k_bcs_div_stats<true><<<grd, blk, 0, st>>>(d, U, flags, Ubc, div, partials, tl); }
-    else { TFL_TIMED("k_bcs_div_stats", st); k_bcs_div_stats<false><<<grd, blk, 0, st>>>(d, U, flags, Ubc, div, partials, tl); }
+      if (fused) {
+        if (is3d) TFL_LAUNCH_EXT((k_bcs_div_stats_v4<true, true>), v.grd, v.blk, 0, st, d, U, flags, Ubc, div, partials, tl);
+        else TFL_LAUNCH_EXT((k_bcs_div_stats_v4<false, true>), v.grd, v.blk, 0, st, d, U, flags, Ubc, div, partials, tl);
+      } else {
+        if (is3d) TFL_LAUNCH_EXT((k_bcs_div_stats_v4<true, false>), v.grd, v.blk, 0, st, d, U, flags, Ubc, div, partials, tl);
+        else TFL_LAUNCH_EXT((k_bcs_div_stats_v4<false, false>), v.grd, v.blk, 0, st, d, U, flags, Ubc, div, partials, tl);
+      }
+    } else {
+      TFL_TIMED("k_bcs_div_stats", st);
+      if (fused) {
+        if (is3d) k_bcs_div_stats<true, true><<<grd, blk, 0, st>>>(d, U, flags, Ubc, div, partials, tl);
+        else k_bcs_div_stats<false, true><<<grd, blk, 0, st>>>(d, U, flags, Ubc, div, partials, tl);
+      } else {
+        if (is3d) k_bcs_div_stats<true, false><<<grd, blk, 0, st>>>(d, U, flags, Ubc, div, partials, tl);
+        else k_bcs_div_stats<false, false><<<grd, blk, 0, st>>>(d, U, flags, Ubc, div, partials, tl);
+      }
+    }
   }
   if ((stages & 2) && !fused) { TFL_TIMED_EXT("k_reduce_stats", st); TFL_LAUNCH_EXT(k_reduce_stats, B, 256, 0, st, (const double*)partials, per_plane * Z, per_plane * zlo, per_plane * (zhi - zlo), stats); }
 }

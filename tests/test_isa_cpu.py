@@ -17,7 +17,7 @@ CSRC = os.path.join(ROOT, "fluidnet_amd", "csrc")
 # kernel (demangled prefix) -> (source file, most full drains allowed before its last load; the value before round 4's rewrite)
 CASES = {
     "k_project_v4<true>": ("model.hip", 0, 18),
-    "k_bcs_div_stats_v4<true>": ("model.hip", 0, 17),
+    "k_bcs_div_stats_v4<true, false>": ("model.hip", 0, 17),     # (<.., true> = the opt-in ticket tail, model.hip)
     "k_curl_v4<true>": ("vorticity.hip", 0, 11),
     "k_pcg_apply<true>": ("pcg.hip", 0, 14),
     "k_jacobi<true, false>": ("jacobi.hip", 0, 1),
