@@ -48,8 +48,14 @@ F16_MFMA_PEAK_TFLOPS = 2500.0   # same guide: bf16 / fp16 MFMA, dense
 # activation term): every fp32 product is four fp16 products (hi/lo of both operands) and one K group of four is idle.
 # The 8->8 layers run K-PACKED by default (k_conv3_m16p: the 27 taps in 7 groups of <= 4 K slices): 56 per 64 voxels;
 # TFL_M16_KPACK=0 brings back k_conv3_m16z (one (dz, dy) per MFMA, 72).
-_M16_MID = (56 if os.environ.get("TFL_M16_KPACK", "1") != "0" else 72) * 16384 / 64.0
-M16_ISSUED_FLOP_PER_VOXEL = {"k_conv3_in": 72 * 16384 / 128.0, "k_conv3_mid": _M16_MID, "k_conv3_tail": _M16_MID}
+_KPACK = os.environ.get("TFL_M16_KPACK", "1")
+_M16_MID = (56 if _KPACK != "0" else 72) * 16384 / 64.0
+# the first layer K-packed (k_conv3_m16p_in, the default): 7 MFMAs per output row of 16 voxels = 28 per 64 voxels (round 5: the
+# constant still described the 32 x 4 x 4 tile kernel's 72 per 128); the tail since round 5 also issues one
+# v_mfma_f32_16x16x16_f16 (8192 flop) per output row for its 8 -> 8 (k = 1) layer
+_M16_TAIL = _M16_MID + (4 * 8192 / 64.0 if os.environ.get("TFL_M16_TAIL_MFMA", "1") != "0" and _KPACK != "0" else 0.0)
+M16_ISSUED_FLOP_PER_VOXEL = {"k_conv3_in": (28 * 16384 / 64.0 if _KPACK not in ("0", "2") else 72 * 16384 / 128.0),
+                             "k_conv3_mid": _M16_MID, "k_conv3_tail": _M16_TAIL}
 
 # Algorithmic HBM bytes per CELL per launch (fp32, 3-D; each distinct input read once, each output
 # written once) -- SURVEY.md 8d restated per kernel of the fused implementation.
@@ -599,7 +605,7 @@ def main():
     # ---- the same step with the strict-fp32 conv stack (TFL_CONV_PATH=winograd: fp32 Winograd F(2,3) on the vector ALUs, no
     # fp16 anywhere), so that the `f32` label of the default line can be audited against an exact-fp32 figure ---------------
     conv_exact = None
-    if world == 1 and conv_path == "mfma16":
+    if world == 1 and conv_path == "mfma16" and not args.no_configs:      # (--no-configs: the profiling passes want the default kernels only)
         prev = os.environ.get("TFL_CONV_PATH")
         os.environ["TFL_CONV_PATH"] = "winograd"
         try:

@@ -34,9 +34,11 @@ def short(name):
         return "k_conv3_in"
     if k in ("k_scal3_fwd", "k_scal3_bwd"):          # advect_scalar3.hip
         return "k_scalar_fwd" if k.endswith("fwd") else "k_scalar_bwd"
-    if k in ("k_conv3_m16", "k_conv3_m16z", "k_conv3_m16p"):         # conv_mfma16.hip: <0|1|2> = in / mid / tail, z-marched <false|true> = mid / tail
-        a = targs.strip("<>").strip()
+    if k in ("k_conv3_m16", "k_conv3_m16z", "k_conv3_m16p", "k_conv3_m16q"):   # conv_mfma16.hip: <0|1|2> = in / mid / tail, z-marched <TAIL, ...> = mid / tail
+        a = targs.strip("<>").split(",")[0].strip()
         return {"0": "k_conv3_in", "1": "k_conv3_mid", "2": "k_conv3_tail", "false": "k_conv3_mid", "true": "k_conv3_tail"}.get(a, k)
+    if k == "k_conv3_m16p_f2":
+        return "k_conv3_in_mid"
     if k == "k_apply_bcs_indexed_multi":
         return "k_apply_bcs_indexed"
     return k[:-3] if k.endswith("_v4") else k
@@ -80,4 +82,5 @@ def main():
     sys.stdout.write(hdr + "\n".join(rows) + "\n")
 
 
-main()
+if __name__ == "__main__":
+    main()
