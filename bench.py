@@ -569,7 +569,7 @@ def main():
                     "algorithmic_bytes_per_cell": 28 + alg_bytes["k_vel_bwd"], "ms": t,
                     "achieved_GBps": by / (t * 1e-3) / 1e9, "frac_of_hbm_peak": by / (t * 1e-3) / 1e9 / HBM_PEAK_GBS,
                     "frac_of_measured_hbm": by / (t * 1e-3) / 1e9 / hbm_meas,
-                    "bound_in_practice": "instruction issue (DESIGN.md 7): ~2.7 clocks per instruction of any kind per SIMD",
+                    "bound_in_practice": "instruction issue (DESIGN.md 3.7, profiles/r01_r04_where_the_time_went.md): ~2.7 clocks per instruction of any kind per SIMD",
                     "valu_issue_frac": {n: (sq_issue.get(n) or {}).get("valu_issue_frac") for n in ("k_vel_fwd", "k_vel_bwd")}}
     redundancy = None
     if world > 1:

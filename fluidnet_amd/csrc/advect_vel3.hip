@@ -19,7 +19,7 @@
 //    the trace's flag look-ups, the forward pass's 24 interpolation taps and the backward pass's 48 clamp corners
 //    are ds_reads with immediate offsets from one address VGPR. Only the backward pass's 24 interpolation taps of
 //    the forward field remain global gathers, issued for the three components together (one L2 round trip).
-//  * What bounds these kernels now (profiles/r03_pmc_adv.txt): instruction ISSUE -- a SIMD retires one
+//  * What bounds these kernels now (profiles/r03_pmc_adv.txt, profiles/r01_r04_where_the_time_went.md): instruction ISSUE -- a SIMD retires one
 //    instruction of any kind (VALU, SALU, LDS, VMEM) per ~2.7 clocks here, so the count of ALL instructions per
 //    wave is the budget; packed fp32 (v_pk_mul/add) issues at half rate and buys nothing (SLP vectorisation is off
 //    for this file). A z-marched variant (4-slot plane ring, 1.55x instead of 4.6x staging) issued 24 % fewer
