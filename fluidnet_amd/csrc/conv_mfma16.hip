@@ -896,7 +896,10 @@ constexpr Tables make_tables() {
   return t;
 }
 constexpr Tables kT = make_tables();
-constexpr int kAhead = 2;                     // pairs of MFMAs between a fragment's LDS read and its first use
+#ifndef TFL_M16Q_AHEAD
+#define TFL_M16Q_AHEAD 4
+#endif
+constexpr int kAhead = TFL_M16Q_AHEAD;        // pairs of MFMAs between a fragment's LDS read and its first use
 template <class F, int... I>
 __device__ __forceinline__ void static_for(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>()), ...); }
 }  // namespace q16

@@ -427,7 +427,8 @@ def test_tog_topology_pooling_and_convolution_upsample(oracle, is3d, dims):
     assert scenes.rel_l2(p.cpu().numpy(), p64) <= 4 * scenes.rel_l2(p_ref, p64) + 1e-7
 
 
-@pytest.mark.parametrize("which", ["2d_jacobi", "2d_convnet_rgb", "3d_convnet_vort_obstacle", "3d_gravity_rk2", "2d_pcg"])
+@pytest.mark.parametrize("which", ["2d_jacobi", "2d_convnet_rgb", "3d_convnet_vort_obstacle", "3d_gravity_rk2", "2d_pcg",
+                                   "3d_buoyancy_any_gravity", "3d_buoyancy_no_vorticity", "3d_buoyancy_jacobi", "3d_buoyancy_fast_mode"])
 def test_native_simulate_step_equals_python_orchestration(which):
     """tfl_simulate_step (csrc/simulate.cpp: lib/simulate.lua in native code behind one C-ABI call) against
     fluidnet_amd.simulate.simulate() over several steps: identical state, bit for bit."""
@@ -455,14 +456,35 @@ def test_native_simulate_step_equals_python_orchestration(which):
         b = _plume_batch((12, 14, 16), 0.15, 1.0)
         model = FluidNetModel(S.default_3d_layers(seed=5), True)
         mconf = dict(base, simMethod="convnet", advectionMethod="rk2Ours", gravityScale=0.3, buoyancyScale=0, gravity=[0.2, 1.0, -0.3])
+    elif which.startswith("3d_buoyancy"):
+        # round 5: the buoyancy force inside pass B of advectVel (BuoyFold) and the velocity delivered into U by whoever writes
+        # every cell next -- a gravity with three components (the generic BUOY mask), no vorticity (the ConvNet projection reads
+        # the advection's scratch array), a Jacobi projection (the copy path), and the advection's tolerance mode
+        b = _plume_batch((20, 24, 68), 0.15, 1.0, obstacles_seed=7)
+        model = FluidNetModel(S.default_3d_layers(seed=5), True)
+        if which == "3d_buoyancy_any_gravity":
+            mconf = dict(base, simMethod="convnet", buoyancyScale=1.5, gravity=[0.3, 1.0, -0.4], vorticityConfinementAmp=2.0)
+        elif which == "3d_buoyancy_no_vorticity":
+            mconf = dict(base, simMethod="convnet", buoyancyScale=1.5)
+        elif which == "3d_buoyancy_jacobi":
+            model, mconf = None, dict(base, simMethod="jacobi", maxIter=12, buoyancyScale=1.5, gravity=[0.0, 0.0, 1.0])
+        else:
+            mconf = dict(base, simMethod="convnet", buoyancyScale=1.5, vorticityConfinementAmp=1.0)
     else:
         b = _plume_batch((1, 32, 32), 0.1, 3.0, obstacles_seed=5)
         b["flags"][:, :, :, 30, 1:-1] = 4.0      # open top: a well-posed system
         mconf = dict(base, simMethod="pcg", maxIter=300, pcgPrecond="none")
     ta, tb = _to_dev(b, dev), _to_dev(b, dev)
-    for _ in range(5):
-        simulate(None, mconf, ta, model)
-        simulate_native(None, mconf, tb, model)
+    if which == "3d_buoyancy_fast_mode":
+        from fluidnet_amd import tfluids
+        tfluids.set_advect_mode(ta["UDiv"], "fast")
+    try:
+        for _ in range(5):
+            simulate(None, mconf, ta, model)
+            simulate_native(None, mconf, tb, model)
+    finally:
+        if which == "3d_buoyancy_fast_mode":
+            tfluids.set_advect_mode(ta["UDiv"], "exact")
     for k in ("pDiv", "UDiv"):
         assert torch.equal(ta[k], tb[k]), (which, k)
     da, db = ta["density"], tb["density"]
