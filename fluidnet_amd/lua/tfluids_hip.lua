@@ -401,6 +401,12 @@ function Model:forward(input)
 end
 function Model:evaluate() return self end
 function Model:cuda() return self end
+-- The default 3-D conv path multiplies fp32 values as fp16 hi / lo pairs: an activation beyond 65504 (a blown-up simulation)
+-- is clamped and counted, and the NEXT forward / simulate step is refused (check() raises, TFL_ERANGE) until the count has
+-- been read. model:rangeErrors() reads and resets it (synchronises); model:rangeFlag() peeks at what the device has reported
+-- so far (no synchronisation). TFL_CONV_PATH=winograd in the environment before hip.Model(...) is the strict-fp32 stack.
+function Model:rangeErrors() return tonumber(lib.tfl_model_range_errors(ctx, self.handle)) end
+function Model:rangeFlag() return tonumber(lib.tfl_model_range_flag(ctx, self.handle)) end
 
 -- ---- tfluids.simulate as ONE native call (lib/simulate.lua:175-327 = fluidnet_amd/csrc/simulate.cpp) -----------------
 local plans = setmetatable({}, {__mode = 'k'})    -- BC tensor -> {mask tensor, tfl_bc_plan*}: created once per pair
