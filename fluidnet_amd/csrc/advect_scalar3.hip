@@ -55,9 +55,8 @@ struct Tile {
 
 // block -> (batch item, first plane, end of its plane run): groups of TZ planes tile the window's two runs
 template <int TZ>
-__device__ __forceinline__ void group_planes(const Dom& d, int& b, int& k0, int& kend) {
+__device__ __forceinline__ void group_planes(const Dom& d, int g, int& b, int& k0, int& kend) {
   const int ga = (d.n0 + TZ - 1) / TZ, gb = (d.nw - d.n0 + TZ - 1) / TZ, G = ga + gb;
-  int g = (int)blockIdx.z;
   b = 0;
   if ((int)gridDim.z != G) { b = g / G; g -= b * G; }
   if (g < ga) { k0 = d.w0 + g * TZ; kend = d.w0 + d.n0; }
@@ -259,12 +258,13 @@ __device__ __forceinline__ float max3r(float a, float b, float c) { float r; asm
   using T = Tile<PZ, H>;                                                                           \
   __shared__ float tile[T::N];                                                                     \
   const Dom& d = a.d;                                                                              \
-  int b, k0, kend; group_planes<PZ>(d, b, k0, kend);                                               \
+  int bx_, by_, bz_; block_tile(a.ord, bx_, by_, bz_);                                             \
+  int b, k0, kend; group_planes<PZ>(d, bz_, b, k0, kend);                                          \
   const long long cells = (long long)d.sc;                                                         \
   s += b * cells; flags += b * cells; U += b * cells * 3;                                          \
   const int lane = threadIdx.x, ty = threadIdx.y, tz = threadIdx.z;                                \
   const int tid = lane + 64 * (ty + TY * tz);                                                      \
-  const int x0 = blockIdx.x * TX, y0 = blockIdx.y * TY;                                            \
+  const int x0 = bx_ * TX, y0 = by_ * TY;                                                          \
   const int i = x0 + lane, j = y0 + ty;                                                            \
   const bool inner = y0 >= H && y0 + TY + H <= d.Y && k0 >= H && k0 + PZ + H <= d.Z && x0 + TX <= d.X;   \
   const unsigned sc4 = (unsigned)d.sc * 4u;                                                        \
@@ -424,8 +424,9 @@ void launch_a(hipStream_t st, bool two_pass, const AdvArgs& a, int B, const floa
   const dim3 blk(TX, TY, TZ), grd((d.X + TX - 1) / TX, (d.Y + TY - 1) / TY, (unsigned)(G * B));
   if (grd.x * grd.y * grd.z == 0) return;
   TFL_TIMED_EXT("k_scalar_fwd", st);
-  if (two_pass) TFL_LAUNCH_EXT((k_scal3_fwd<TZ, KZ, true, FAST>), grd, blk, 0, st, a, s, U, flags, out, bounds);
-  else TFL_LAUNCH_EXT((k_scal3_fwd<TZ, KZ, false, FAST>), grd, blk, 0, st, a, s, U, flags, out, (float*)nullptr);
+  AdvArgs ao = a; ao.ord = make_block_order(grd.x, grd.y, grd.z, xcd_order_enabled(), xcd_run(grd.x, grd.y));
+  if (two_pass) TFL_LAUNCH_EXT((k_scal3_fwd<TZ, KZ, true, FAST>), grd, blk, 0, st, ao, s, U, flags, out, bounds);
+  else TFL_LAUNCH_EXT((k_scal3_fwd<TZ, KZ, false, FAST>), grd, blk, 0, st, ao, s, U, flags, out, (float*)nullptr);
 }
 template <int TZ, int KZ, bool FAST>
 void launch_b(hipStream_t st, const AdvArgs& a, int B, const float* s, const float* U, const float* flags, const float* fwd,
@@ -436,7 +437,8 @@ void launch_b(hipStream_t st, const AdvArgs& a, int B, const float* s, const flo
   const dim3 blk(TX, TY, TZ), grd((d.X + TX - 1) / TX, (d.Y + TY - 1) / TY, (unsigned)(G * B));
   if (grd.x * grd.y * grd.z == 0) return;
   TFL_TIMED_EXT("k_scalar_bwd", st);
-  TFL_LAUNCH_EXT((k_scal3_bwd<TZ, KZ, FAST>), grd, blk, 0, st, a, (double)a.strength * 0.5, s, U, flags, fwd, bounds, dst, fold);
+  AdvArgs ao = a; ao.ord = make_block_order(grd.x, grd.y, grd.z, xcd_order_enabled(), xcd_run(grd.x, grd.y));
+  TFL_LAUNCH_EXT((k_scal3_bwd<TZ, KZ, FAST>), grd, blk, 0, st, ao, (double)a.strength * 0.5, s, U, flags, fwd, bounds, dst, fold);
 }
 
 

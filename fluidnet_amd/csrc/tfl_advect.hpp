@@ -13,6 +13,7 @@ struct AdvArgs {
   int outside;  // sampleOutsideFluid
   int fast;     // tfl_set_advect_mode: 1 = the tolerance mode of the LDS-tiled 3-D kernels (advect_vel3.hip, advect_scalar3.hip)
   unsigned long long* err;
+  BlockOrder ord;   // block -> tile order of the LDS-tiled 3-D kernels (tfl_device.hpp; zero = blockIdx as it comes)
 };
 
 #define TFL_CELL_INDEX()                                             \

@@ -12,6 +12,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <cstdlib>
 
 namespace tfl {
 
@@ -43,6 +44,85 @@ struct Dom {
   // fall into different binades -- and are turned into local plane indices only to address memory.
   int zg, Zg;
 };
+
+// ---- XCD-contiguous block order (round 5) --------------------------------------------------------------------------------
+// The dispatcher deals consecutive workgroup ids (x fastest, then y, then z) round-robin over the chip's 8 XCDs, and each XCD
+// has its own L2. With the natural (blockIdx.x, blockIdx.y, blockIdx.z) -> tile map the x / y neighbours of a tile therefore run
+// on OTHER XCDs: the halo rows and the 128-byte lines two tiles share are fetched from the fabric once per tile (PMC: 1.9-2.6x
+// the algorithmic reads of the advection kernels, 2.8x for k_vort_fused at 256^3). With this order XCD k takes the k-th
+// contiguous eighth of the tiles (x fastest, then y, then z): the blocks resident on an XCD are neighbours, plane after plane.
+// Exact unsigned division by a launch constant (Granlund-Montgomery: q = (t + ((n - t) >> s1)) >> s2, t = mulhi(m, n)):
+// the decode is ~20 scalar instructions, no v_rcp sequences.
+struct Div32 { unsigned m, s1, s2; };
+inline Div32 make_div32(unsigned d) {
+  unsigned l = 0;
+  while ((1ull << l) < d) l++;
+  Div32 v;
+  v.m = (unsigned)((((1ull << l) - d) << 32) / d + 1);
+  v.s1 = l < 1 ? l : 1; v.s2 = l > 0 ? l - 1 : 0;
+  return v;
+}
+__host__ __device__ __forceinline__ unsigned div32(unsigned n, const Div32& v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const unsigned t = __umulhi(v.m, n);
+#else
+  const unsigned t = (unsigned)(((unsigned long long)v.m * n) >> 32);
+#endif
+  return (t + ((n - t) >> v.s1)) >> v.s2;
+}
+// id-th block of an n-block 1-D launch -> its place in the XCD-contiguous order (a bijection of [0, n))
+__host__ __device__ __forceinline__ unsigned xcd_contiguous(unsigned id, unsigned n) {
+  const unsigned q = n >> 3, r = n & 7, k = id & 7;
+  return k * q + (k < r ? k : r) + (id >> 3);
+}
+struct BlockOrder {       // all zero = the hardware's own order
+  unsigned on, gx, gy, P, n;
+  unsigned S, full;       // run length (tiles one XCD takes in a row before the next eight runs start); full = the blocks in whole rounds of 8 runs
+  Div32 dgx, dP, dS;
+};
+// run = tiles per run: 0 = one run per XCD (n / 8: XCD k sweeps the k-th eighth of the launch, plane after plane);
+// P / 8 = an eighth of every plane per XCD (x and most y neighbours share an L2, all XCDs advance through z together)
+inline BlockOrder make_block_order(unsigned gx, unsigned gy, unsigned gz, bool enable, unsigned run = 0) {
+  BlockOrder o{};
+  const unsigned long long n = (unsigned long long)gx * gy * gz;
+  if (!enable || n < 16 || n >= (1ull << 31)) return o;
+  o.on = 1; o.gx = gx; o.gy = gy; o.P = gx * gy; o.n = (unsigned)n;
+  o.S = run ? run : o.n >> 3;
+  if (o.S > (o.n >> 3)) o.S = o.n >> 3;
+  o.full = o.n / (8 * o.S) * (8 * o.S);
+  o.dgx = make_div32(gx); o.dP = make_div32(o.P); o.dS = make_div32(o.S);
+  return o;
+}
+// the tile (x, y, z) of this block, as blockIdx would give it under the natural order
+__device__ __forceinline__ void block_tile(const BlockOrder& o, int& bx, int& by, int& bz) {
+  if (!o.on) { bx = (int)blockIdx.x; by = (int)blockIdx.y; bz = (int)blockIdx.z; return; }
+  const unsigned L = blockIdx.x + o.gx * (blockIdx.y + o.gy * blockIdx.z);
+  unsigned T;
+  if (L < o.full) {
+    const unsigned idx = L >> 3, c = div32(idx, o.dS);
+    T = (c * 8 + (L & 7)) * o.S + (idx - c * o.S);
+  } else {
+    T = o.full + xcd_contiguous(L - o.full, o.n - o.full);
+  }
+  const unsigned z = div32(T, o.dP), p = T - z * o.P;
+  const unsigned y = div32(p, o.dgx);
+  bx = (int)(p - y * o.gx); by = (int)y; bz = (int)z;
+}
+// TFL_XCD_ORDER=0 restores the hardware order everywhere (A/B switch; read once)
+inline bool xcd_order_enabled() {
+  static const bool on = !(getenv("TFL_XCD_ORDER") && atoi(getenv("TFL_XCD_ORDER")) == 0);
+  return on;
+}
+// run length of a gx x gy (x gz) launch: an eighth of a plane per XCD (measured best, or level with one run per XCD, for the
+// scalar advection and the curl / confinement kernels at 128^3 and 256^3: profiles/r05_xcd_order.txt). TFL_XCD_RUN = tiles
+// per run and TFL_XCD_ORDER = 1 (one run per XCD) are the experiment switches.
+inline unsigned xcd_run(unsigned gx, unsigned gy) {
+  static const int run = getenv("TFL_XCD_RUN") ? atoi(getenv("TFL_XCD_RUN")) : 0;
+  static const int mode = getenv("TFL_XCD_ORDER") ? atoi(getenv("TFL_XCD_ORDER")) : 2;
+  if (run > 0) return (unsigned)run;
+  if (mode == 1) return 0;
+  return gx * gy >= 8 ? gx * gy / 8 : 1;
+}
 
 // (batch item, z-plane) of a block: blockIdx.z enumerates the window's planes, batch item by batch item
 __device__ __forceinline__ void dom_bk(const Dom& d, int& b, int& k) {

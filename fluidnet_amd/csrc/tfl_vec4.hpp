@@ -36,14 +36,21 @@ struct V4Ctx {
   bool has_l;    // cell i0-1 exists
   bool has_r;    // cell i0+4 exists
 };
-__device__ __forceinline__ V4Ctx v4_ctx(const Dom& d) {
+__device__ __forceinline__ V4Ctx v4_ctx(const Dom& d, int bx) {     // bx: the block's tile column (blockIdx.x, or block_tile's)
   V4Ctx c;
-  c.i0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  c.i0 = (bx * blockDim.x + threadIdx.x) * 4;
   c.first = threadIdx.x == 0;
   c.last = threadIdx.x == blockDim.x - 1 || c.i0 + 4 >= d.X;
   c.has_l = c.i0 > 0;
   c.has_r = c.i0 + 4 < d.X;
   return c;
+}
+__device__ __forceinline__ V4Ctx v4_ctx(const Dom& d) { return v4_ctx(d, (int)blockIdx.x); }
+// (batch item, plane) of tile row bz of the launch (dom_bk with an explicit index)
+__device__ __forceinline__ void dom_bk_of(const Dom& d, int bz, int& b, int& k) {
+  b = bz / d.nw;
+  const int r = bz - b * d.nw;
+  k = r < d.n0 ? d.w0 + r : d.w1 + (r - d.n0);
 }
 
 // r[0..3] = p[o..o+3] (pad when !ok). The load itself is UNCONDITIONAL: a predicated load compiles to a branch, and hipcc

@@ -107,10 +107,11 @@ __global__ __launch_bounds__(256) void k_confine(Dom d, float* __restrict__ U, c
 // non-border cell is on the border shell iff its moved coordinate is 0 or N-1 -> contributes 0.
 template <bool IS3D>
 __global__ __launch_bounds__(256, TFL_LB_CURL) void k_curl_v4(Dom d, const float* __restrict__ U, float* __restrict__ curl,
-                                                 float* __restrict__ cnorm) {
-  const V4Ctx c = v4_ctx(d);
-  const int j = blockIdx.y * blockDim.y + threadIdx.y;
-  int b, k; dom_bk(d, b, k);
+                                                 float* __restrict__ cnorm, BlockOrder ord) {
+  int bx_, by_, bz_; block_tile(ord, bx_, by_, bz_);
+  const V4Ctx c = v4_ctx(d, bx_);
+  const int j = by_ * blockDim.y + threadIdx.y;
+  int b, k; dom_bk_of(d, bz_, b, k);
   const bool live = c.i0 < d.X && j < d.Y;
   const long long cells = d.sc;
   U += b * cells * (IS3D ? 3 : 2); curl += b * cells * 3; cnorm += b * cells;
@@ -204,14 +205,15 @@ __device__ __forceinline__ void force_row(const Dom& d, float strength, int i0, 
 template <bool IS3D>
 __global__ __launch_bounds__(256, TFL_LB_CONFINE) void k_confine_v4(Dom d, const float* Usrc, float* U, const float* __restrict__ flags,
                                                     const float* __restrict__ curl, const float* __restrict__ cn,
-                                                    float strength, BcFoldArg folda) {
+                                                    float strength, BcFoldArg folda, BlockOrder ord) {
   // U = Usrc + confinement force. Usrc == U: the reference's in-place operator; Usrc != U (round 5, tfl_vorticityConfinementFrom
   // on grids below the fused kernel's size): every cell of the window is written, which moves the velocity out of the
   // advection's scratch array for free
-  const V4Ctx c = v4_ctx(d);
-  const int j = blockIdx.y * blockDim.y + threadIdx.y;
-  int b, k; dom_bk(d, b, k);
-  const bool fold_blk = fold_block(folda, (int)(blockIdx.y * blockDim.y), (int)(blockIdx.y * blockDim.y + blockDim.y - 1), k, k);
+  int bx_, by_, bz_; block_tile(ord, bx_, by_, bz_);
+  const V4Ctx c = v4_ctx(d, bx_);
+  const int j = by_ * blockDim.y + threadIdx.y;
+  int b, k; dom_bk_of(d, bz_, b, k);
+  const bool fold_blk = fold_block(folda, (int)(by_ * blockDim.y), (int)(by_ * blockDim.y + blockDim.y - 1), k, k);
   const bool live = c.i0 < d.X && j < d.Y;
   const long long cells = d.sc;
   const int C = IS3D ? 3 : 2;
@@ -355,13 +357,17 @@ __device__ __forceinline__ v3 normalize3_x(v3 a) {
 
 __global__ __launch_bounds__(512) void k_vort_fused(Dom d, int cols_x, int cols_y, int cz, int chunks_a, int chunks, int n_blocks,
                                                     const float* __restrict__ Uin, float* __restrict__ Uout,
-                                                    const float* __restrict__ flags, float strength) {
+                                                    const float* __restrict__ flags, float strength, int xcd_order) {
   extern __shared__ float lds[];
   float* Ut = lds;                    // [4][3][FUN]  planes t & 3
   float* Cn = Ut + 4 * 3 * FUN;       // [3][FCN]     |curl|, planes z % 3
   float* Cv = Cn + 3 * FCN;           // [2][3][FCN]  curl, planes z & 1
   float* Fe = Cv + 2 * 3 * FCN;       // [2][FEY][FEX] force.x / force.y of the plane being finished
-  const int blk = (int)blockIdx.x;
+  // XCD-aware order (round 5): consecutive block ids go round-robin over the 8 XCDs, each with its own L2 -- so x / y neighbours
+  // (blk +- 1, blk +- cols_x) never shared their 3-cell halo rings through an L2 and every block fetched its whole 70 x 14 tile,
+  // 128-byte lines and all, from the fabric (45 B/cell read at 256^3 for 16 algorithmic). XCD k now owns a contiguous run of
+  // tiles (x fastest, then y, then z chunk): its resident blocks are neighbours marching in step.
+  const int blk = xcd_order ? (int)xcd_contiguous(blockIdx.x, (unsigned)n_blocks) : (int)blockIdx.x;
   if (blk >= n_blocks) return;
   int tq = blk;
   const int bx = tq % cols_x; tq /= cols_x;
@@ -596,7 +602,8 @@ bool vorticity_confinement_fused(hipStream_t st, int B, int Z, int Y, int X, con
   const int chunks_a = (na + cz - 1) / cz, chunks = chunks_a + (nb + cz - 1) / cz;
   const int n_blocks = cxn * cyn * chunks * B;
   TFL_TIMED_EXT("k_vort_fused", st);
-  TFL_LAUNCH_EXT(k_vort_fused, n_blocks, 512, kFusedLds, st, d, cxn, cyn, cz, chunks_a, chunks, n_blocks, Uin, Uout, flags, strength);
+  const int xcd_order = xcd_order_enabled() ? 1 : 0;
+  TFL_LAUNCH_EXT(k_vort_fused, n_blocks, 512, kFusedLds, st, d, cxn, cyn, cz, chunks_a, chunks, n_blocks, Uin, Uout, flags, strength, xcd_order);
   return true;
 }
 
@@ -609,12 +616,13 @@ bool vorticity_confinement(hipStream_t st, bool is3d, int B, int Z, int Y, int X
   const bool pa = stages & 1, pb = stages & 2;
   if (v.ok) {
     const BcFoldArg fold = pb ? take_fold() : no_fold();   // pass B writes the operator's result
+    const BlockOrder ord = make_block_order(v.grd.x, v.grd.y, v.grd.z, is3d && xcd_order_enabled(), xcd_run(v.grd.x, v.grd.y));
     if (is3d) {
-      if (pa) { TFL_TIMED_EXT("k_curl", st); TFL_LAUNCH_EXT((k_curl_v4<true>), v.grd, v.blk, 0, st, d, Uin, curl, curl_norm); }
-      if (pb) { TFL_TIMED_EXT("k_confine", st); TFL_LAUNCH_EXT((k_confine_v4<true>), v.grd, v.blk, 0, st, d, Uin, U, flags, (const float*)curl, (const float*)curl_norm, strength, fold); }
+      if (pa) { TFL_TIMED_EXT("k_curl", st); TFL_LAUNCH_EXT((k_curl_v4<true>), v.grd, v.blk, 0, st, d, Uin, curl, curl_norm, ord); }
+      if (pb) { TFL_TIMED_EXT("k_confine", st); TFL_LAUNCH_EXT((k_confine_v4<true>), v.grd, v.blk, 0, st, d, Uin, U, flags, (const float*)curl, (const float*)curl_norm, strength, fold, ord); }
     } else {
-      if (pa) { TFL_TIMED("k_curl", st); k_curl_v4<false><<<v.grd, v.blk, 0, st>>>(d, Uin, curl, curl_norm); }
-      if (pb) { TFL_TIMED("k_confine", st); k_confine_v4<false><<<v.grd, v.blk, 0, st>>>(d, Uin, U, flags, curl, curl_norm, strength, fold); }
+      if (pa) { TFL_TIMED("k_curl", st); k_curl_v4<false><<<v.grd, v.blk, 0, st>>>(d, Uin, curl, curl_norm, ord); }
+      if (pb) { TFL_TIMED("k_confine", st); k_confine_v4<false><<<v.grd, v.blk, 0, st>>>(d, Uin, U, flags, curl, curl_norm, strength, fold, ord); }
     }
     return true;
   }
