@@ -62,7 +62,16 @@ bool advect_vel3(hipStream_t st, bool two_pass, const AdvArgs& a, int B, const f
   // block depth: at 128^3 the four fields' staging stays in the caches and the leaner one-plane kernels win (k_vel_bwd
   // 37.5 vs 42 us); from ~6 M cells per batch item on the two-plane kernels do (256^3: 285 vs 316 us, pass A 144 vs 175)
   const bool deep = kz_env ? kz_env >= 2 : (long long)d.sc >= 6000000ll;
-  if (deep) kz2::launch(st, two_pass, a, B, U, flags, fwd, dst, stages);
+  // ... unless pass B has been asked to add the buoyancy force (tfl_host.hpp BuoyFold): only the one-plane pass B carries that
+  // fold (and the sparse setConstVals pair's) -- in the two-plane kernel it costs the fifth wave per SIMD -- and at 256^3 the
+  // one-plane pass B with the force (~320 us) beats the two-plane one plus k_add_buoyancy and two k_apply_bcs_indexed
+  // (291 + 94 + 11 us). Pass A stays two-plane. TFL_VEL3_KZ_B=2 keeps the old split.
+  static const int kzb_env = getenv("TFL_VEL3_KZ_B") ? atoi(getenv("TFL_VEL3_KZ_B")) : 0;
+  const bool b_shallow = deep && two_pass && (stages & 4) && g_buoy.rho && kzb_env != 2;
+  if (deep && b_shallow) {
+    if (stages & 2) kz2::launch(st, two_pass, a, B, U, flags, fwd, dst, stages & ~4);
+    kz1::launch(st, two_pass, a, B, U, flags, fwd, dst, stages & ~2);
+  } else if (deep) kz2::launch(st, two_pass, a, B, U, flags, fwd, dst, stages);
   else kz1::launch(st, two_pass, a, B, U, flags, fwd, dst, stages);
   return true;
 }

@@ -570,6 +570,20 @@ def test_bc_fold_on_and_off_agree(env):
     assert out.returncode == 0 and "BC_FOLD_AB_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
 
 
+def test_native_step_equals_python_with_the_big_grid_kernels():
+    """The native step picks its kernels by grid size (two-plane advectVel from 6 M cells, the fused confinement from 3 M), and
+    with a buoyancy fold pending it sends pass B of advectVel through the ONE-plane kernel that carries the fold while pass A
+    stays two-plane (advect_vel3.hip, round 5: 256^3). Those switches are read once per process, so the 3-D scenes of
+    test_native_simulate_step_equals_python_orchestration run again in a child process with the big-grid variants forced."""
+    import subprocess, sys
+    e = dict(os.environ)
+    e.update({"TFL_VEL3_KZ": "2", "TFL_VORT_FUSED": "1", "TFL_SCAL3_TZ": "14"})
+    e.pop("TFL_VEL3_KZ_B", None)
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(HERE, "test_hip_simulate.py"), "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
+                          "-k", "test_native_simulate_step_equals_python_orchestration and 3d_"], env=e, capture_output=True, text=True, timeout=1200)
+    assert out.returncode == 0 and " passed" in out.stdout and "failed" not in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
+
+
 @pytest.mark.parametrize("world,overlap", [(1, False), (2, False), (2, True), (4, True), (3, False)])
 def test_zslab_decomposition_equals_single_gpu(world, overlap):
     """tfl_simulate_step_slab, verified on ONE GPU with virtual ranks (threads + an in-process transport): every rank
