@@ -339,20 +339,29 @@ constexpr int kFusedLds = (4 * 3 * FUN + 3 * FCN + 2 * 3 * FCN + 2 * FEY * FEX) 
 // as norm3 / normalize3 at a third of their instructions: sqrt_exact and ONE refined reciprocal for the three quotients
 // (tfl_fastmath.hpp: the root checked exhaustively on [2^-40, 2^40), the quotient on a sample; the numerators are components
 // of the vector whose norm divides them). Outside that range of the squared length, or for a NaN, the library forms.
-__device__ __forceinline__ float norm3_x(v3 a) {
+// Branches: the library fall-back is taken by the WHOLE wave when any lane that counts (`use`) needs it -- a scalar branch that is
+// never taken on real fields -- instead of a per-lane one (round 5: the kernel's 44 exec-mask branches and the register copies
+// around them were a quarter of its instruction stream, and it runs at the length of that stream).
+__device__ __forceinline__ float norm3_x(v3 a, bool use = true) {
   const float l2 = a.x * a.x + a.y * a.y + a.z * a.z;
-  if (!(l2 < 0x1p40f)) return norm3(a);
-  return (l2 > 1e-6f) ? sqrt_exact(l2) : 0.0f;
-}
-__device__ __forceinline__ v3 normalize3_x(v3 a) {
-  const float l2 = a.x * a.x + a.y * a.y + a.z * a.z;
-  if (!(l2 < 0x1p40f)) return normalize3(a);
-  const float n = (l2 > 1e-6f) ? sqrt_exact(l2) : 0.0f;
-  if (n > 1e-6f) {
-    const float r = rcp_refined(n);
-    return mk3(div_by<1>(a.x, n, r), div_by<1>(a.y, n, r), div_by<1>(a.z, n, r));
+  float n = (l2 > 1e-6f) ? sqrt_exact(l2) : 0.0f;
+  if (__builtin_expect(__any(use && !(l2 < 0x1p40f)), 0)) {
+    if (!(l2 < 0x1p40f)) n = norm3(a);
   }
-  return mk3(0.0f, 0.0f, 0.0f);
+  return n;
+}
+__device__ __forceinline__ v3 normalize3_x(v3 a, bool use = true) {
+  const float l2 = a.x * a.x + a.y * a.y + a.z * a.z;
+  const float n = (l2 > 1e-6f) ? sqrt_exact(l2) : 0.0f;
+  const bool nz = n > 1e-6f;
+  const float nn = nz ? n : 1.0f;                       // keeps the unused lanes' quotients finite
+  const float r = rcp_refined(nn);
+  v3 q = mk3(div_by<1>(a.x, nn, r), div_by<1>(a.y, nn, r), div_by<1>(a.z, nn, r));
+  q = nz ? q : mk3(0.0f, 0.0f, 0.0f);
+  if (__builtin_expect(__any(use && !(l2 < 0x1p40f)), 0)) {
+    if (!(l2 < 0x1p40f)) q = normalize3(a);
+  }
+  return q;
 }
 
 __global__ __launch_bounds__(512) void k_vort_fused(Dom d, int cols_x, int cols_y, int cz, int chunks_a, int chunks, int n_blocks,
@@ -410,7 +419,7 @@ __global__ __launch_bounds__(512) void k_vort_fused(Dom d, int cols_x, int cols_
   const bool f_in = i >= 1 && i <= d.X - 2 && j >= 1 && j <= d.Y - 2;
   const bool e_col = tid < FBY, e_row = tid >= 64 && tid < 64 + FBX;
   const int e_cx = e_col ? 1 : (tid - 64) + 2, e_cy = e_col ? tid + 2 : 1;
-  const int e_it = e_cy * FCX + e_cx;
+  const int e_it = (e_col || e_row) ? e_cy * FCX + e_cx : f_it;      // (the other lanes of waves 0 / 1 evaluate their own cell again, unused)
   const int e_gx = x0 - 2 + e_cx, e_gy = y0 - 2 + e_cy;
   const bool e_in = (e_col || e_row) && e_gx >= 1 && e_gx <= d.X - 2 && e_gy >= 1 && e_gy <= d.Y - 2;
   const int e_dst = e_col ? (tid + 1) * FEX : FEY * FEX + (tid - 64) + 1;
@@ -418,13 +427,15 @@ __global__ __launch_bounds__(512) void k_vort_fused(Dom d, int cols_x, int cols_
   const int o_xy = TFL_AT(d, min(i, d.X - 1), min(j, d.Y - 1), 0);
 
   // confinement force of the cell `it` of the curl tile in plane zf (tfluids.cc:1410-1436); n0 / np / nm: ring slots of |curl|
-  auto force = [&](int it, const float* cn0, const float* cnp, const float* cnm, const float* cv) -> v3 {
+  // (evaluated by every lane of the calling waves, `use` = the lane's value counts: the reads stay inside the rings)
+  auto force = [&](int it, bool use, const float* cn0, const float* cnp, const float* cnm, const float* cv) -> v3 {
     const float* c0 = cn0 + it;
     v3 g = mk3(0.5f * (c0[1] - c0[-1]), 0.5f * (c0[FCX] - c0[-FCX]), 0.5f * (cnp[it] - cnm[it]));
-    g = normalize3_x(g);
+    g = normalize3_x(g, use);
     const v3 w = mk3(cv[it], cv[FCN + it], cv[2 * FCN + it]);
-    return mk3(((g.y * w.z) - (g.z * w.y)) * strength, ((g.z * w.x) - (g.x * w.z)) * strength,
-               ((g.x * w.y) - (g.y * w.x)) * strength);
+    const v3 f = mk3(((g.y * w.z) - (g.z * w.y)) * strength, ((g.z * w.x) - (g.x * w.z)) * strength,
+                     ((g.x * w.y) - (g.y * w.x)) * strength);
+    return use ? f : mk3(0.0f, 0.0f, 0.0f);
   };
 
   float nu[2][3];                     // the U plane loaded one step ahead
@@ -474,34 +485,46 @@ __global__ __launch_bounds__(512) void k_vort_fused(Dom d, int cols_x, int cols_
       float* cnw = Cn + ((zc + 6) % 3) * FCN;
 #pragma unroll
       for (int r = 0; r < 2; r++) {
-        if (r == 1 && tid >= FCN - 512) continue;
-        v3 w = mk3(0.0f, 0.0f, 0.0f);
-        float nrm = 0.0f;
-        if (z_in && (c_bits[r] & 1)) {
-          const bool xpb = c_bits[r] & 2, xmb = c_bits[r] & 4, ypb = c_bits[r] & 8, ymb = c_bits[r] & 16;
-          const float* ux0 = P0 + c_base[r];
-          const float* uy0 = ux0 + FUN;
-          const float* uz0 = ux0 + 2 * FUN;
-          const float* uzp = Pp + c_base[r] + 2 * FUN;
-          const float cy_xp = xpb ? 0.0f : 0.5f * (uy0[1] + uy0[1 + FUX]);
-          const float cy_xm = xmb ? 0.0f : 0.5f * (uy0[-1] + uy0[-1 + FUX]);
-          const float cx_yp = ypb ? 0.0f : 0.5f * (ux0[FUX] + ux0[FUX + 1]);
-          const float cx_ym = ymb ? 0.0f : 0.5f * (ux0[-FUX] + ux0[-FUX + 1]);
-          w.z = 0.5f * ((cy_xp - cy_xm) - (cx_yp - cx_ym));
-          const float cz_yp = ypb ? 0.0f : 0.5f * (uz0[FUX] + uzp[FUX]);
-          const float cz_ym = ymb ? 0.0f : 0.5f * (uz0[-FUX] + uzp[-FUX]);
-          const float cy_zp = zpb ? 0.0f : 0.5f * (Pp[c_base[r] + FUN] + Pp[c_base[r] + FUN + FUX]);
-          const float cy_zm = zmb ? 0.0f : 0.5f * (Pm[c_base[r] + FUN] + Pm[c_base[r] + FUN + FUX]);
-          w.x = 0.5f * ((cz_yp - cz_ym) - (cy_zp - cy_zm));
-          const float cx_zp = zpb ? 0.0f : 0.5f * (Pp[c_base[r]] + Pp[c_base[r] + 1]);
-          const float cx_zm = zmb ? 0.0f : 0.5f * (Pm[c_base[r]] + Pm[c_base[r] + 1]);
-          const float cz_xp = xpb ? 0.0f : 0.5f * (uz0[1] + uzp[1]);
-          const float cz_xm = xmb ? 0.0f : 0.5f * (uz0[-1] + uzp[-1]);
-          w.y = 0.5f * ((cx_zp - cx_zm) - (cz_xp - cz_xm));
-          nrm = norm3_x(w);
+        if (r == 1 && (tid & ~63) >= FCN - 512) continue;      // wave-uniform: the waves with no cell in the second round
+        // every lane evaluates (its reads stay inside the ring: c_base is a tile-interior index); `ok` selects
+        const bool ok = z_in && (c_bits[r] & 1) && (r == 0 || tid < FCN - 512);
+        const bool xpb = c_bits[r] & 2, xmb = c_bits[r] & 4, ypb = c_bits[r] & 8, ymb = c_bits[r] & 16;
+        // (every tap is read first, unconditionally -- inside `cond ? 0 : f(load)` hipcc guards each load with its own
+        // exec-mask branch: twelve of them per curl cell --, the border selects follow)
+        const float* ux0 = P0 + c_base[r];
+        const float* uy0 = ux0 + FUN;
+        const float* uz0 = ux0 + 2 * FUN;
+        const float* uxp = Pp + c_base[r];
+        const float* uxm = Pm + c_base[r];
+        const float y_xp0 = uy0[1], y_xp1 = uy0[1 + FUX], y_xm0 = uy0[-1], y_xm1 = uy0[-1 + FUX];
+        const float x_yp0 = ux0[FUX], x_yp1 = ux0[FUX + 1], x_ym0 = ux0[-FUX], x_ym1 = ux0[-FUX + 1];
+        const float z_yp0 = uz0[FUX], z_yp1 = uxp[2 * FUN + FUX], z_ym0 = uz0[-FUX], z_ym1 = uxp[2 * FUN - FUX];
+        const float y_zp0 = uxp[FUN], y_zp1 = uxp[FUN + FUX], y_zm0 = uxm[FUN], y_zm1 = uxm[FUN + FUX];
+        const float x_zp0 = uxp[0], x_zp1 = uxp[1], x_zm0 = uxm[0], x_zm1 = uxm[1];
+        const float z_xp0 = uz0[1], z_xp1 = uxp[2 * FUN + 1], z_xm0 = uz0[-1], z_xm1 = uxp[2 * FUN - 1];
+        const float cy_xp = xpb ? 0.0f : 0.5f * (y_xp0 + y_xp1);
+        const float cy_xm = xmb ? 0.0f : 0.5f * (y_xm0 + y_xm1);
+        const float cx_yp = ypb ? 0.0f : 0.5f * (x_yp0 + x_yp1);
+        const float cx_ym = ymb ? 0.0f : 0.5f * (x_ym0 + x_ym1);
+        v3 w;
+        w.z = 0.5f * ((cy_xp - cy_xm) - (cx_yp - cx_ym));
+        const float cz_yp = ypb ? 0.0f : 0.5f * (z_yp0 + z_yp1);
+        const float cz_ym = ymb ? 0.0f : 0.5f * (z_ym0 + z_ym1);
+        const float cy_zp = zpb ? 0.0f : 0.5f * (y_zp0 + y_zp1);
+        const float cy_zm = zmb ? 0.0f : 0.5f * (y_zm0 + y_zm1);
+        w.x = 0.5f * ((cz_yp - cz_ym) - (cy_zp - cy_zm));
+        const float cx_zp = zpb ? 0.0f : 0.5f * (x_zp0 + x_zp1);
+        const float cx_zm = zmb ? 0.0f : 0.5f * (x_zm0 + x_zm1);
+        const float cz_xp = xpb ? 0.0f : 0.5f * (z_xp0 + z_xp1);
+        const float cz_xm = xmb ? 0.0f : 0.5f * (z_xm0 + z_xm1);
+        w.y = 0.5f * ((cx_zp - cx_zm) - (cz_xp - cz_xm));
+        float nrm = norm3_x(w, ok);            // (unconditional: the wave-wide vote inside must not sit behind a lane branch)
+        nrm = ok ? nrm : 0.0f;
+        w = ok ? w : mk3(0.0f, 0.0f, 0.0f);
+        if (r == 0 || tid < FCN - 512) {
+          cvw[c_it[r]] = w.x; cvw[FCN + c_it[r]] = w.y; cvw[2 * FCN + c_it[r]] = w.z;
+          cnw[c_it[r]] = nrm;
         }
-        cvw[c_it[r]] = w.x; cvw[FCN + c_it[r]] = w.y; cvw[2 * FCN + c_it[r]] = w.z;
-        cnw[c_it[r]] = nrm;
       }
     }
     __syncthreads();
@@ -514,36 +537,277 @@ __global__ __launch_bounds__(512) void k_vort_fused(Dom d, int cols_x, int cols_
       const float* cnp = Cn + ((zf + 7) % 3) * FCN;
       const float* cnm = Cn + ((zf + 5) % 3) * FCN;
       const float* cv = Cv + (zf & 1) * 3 * FCN;
-      if (z_in && f_in) f0 = force(f_it, cn0, cnp, cnm, cv);
+      f0 = force(f_it, z_in && f_in, cn0, cnp, cnm, cv);
       Fe[(ty + 1) * FEX + tx + 1] = f0.x;
       Fe[(FEY + ty + 1) * FEX + tx + 1] = f0.y;
-      if (e_col || e_row) {
-        v3 fe = mk3(0.0f, 0.0f, 0.0f);
-        if (z_in && e_in) fe = force(e_it, cn0, cnp, cnm, cv);
-        Fe[e_dst] = e_col ? fe.x : fe.y;
+      if (tid < 128) {                      // waves 0 and 1 (wave-uniform): the column / the row before the block
+        const v3 fe = force(e_it, z_in && e_in, cn0, cnp, cnm, cv);
+        if (e_col || e_row) Fe[e_dst] = e_col ? fe.x : fe.y;
       }
     }
     __syncthreads();
     // ---- plane zf out: AddForceField (tfluids.cc:1312-1339); every cell of the plane is written (U_out is another array) ----
     if (out_live) {
       float u0 = pu0, u1 = pu1, u2 = pu2;
-      if (out_inner) {
-        const int fc = (int)pfc;
+      {
+        const int fc = (int)pfc;           // (all zero when !out_inner: nothing is added)
         const bool cf = fc & kFluid, ce = fc & kEmpty;
-        if (cf || ce) {
-          const int nx = (int)pnx, ny = (int)pny, nz = (int)pnz;
-          const bool ax = (nx & kFluid) || (cf && (nx & kEmpty));
-          const bool ay = (ny & kFluid) || (cf && (ny & kEmpty));
-          const bool az = (nz & kFluid) || (cf && (nz & kEmpty));
-          if (ax) u0 += (0.5f * (Fe[(ty + 1) * FEX + tx] + f0.x));
-          if (ay) u1 += (0.5f * (Fe[(FEY + ty) * FEX + tx + 1] + f0.y));
-          if (az) u2 += (0.5f * (fz_prev + f0.z));
-        }
+        const int nx = (int)pnx, ny = (int)pny, nz = (int)pnz;
+        const bool any = out_inner && (cf || ce);
+        const bool ax = any && ((nx & kFluid) || (cf && (nx & kEmpty)));
+        const bool ay = any && ((ny & kFluid) || (cf && (ny & kEmpty)));
+        const bool az = any && ((nz & kFluid) || (cf && (nz & kEmpty)));
+        const float a0 = u0 + (0.5f * (Fe[(ty + 1) * FEX + tx] + f0.x));
+        const float a1 = u1 + (0.5f * (Fe[(FEY + ty) * FEX + tx + 1] + f0.y));
+        const float a2 = u2 + (0.5f * (fz_prev + f0.z));
+        u0 = ax ? a0 : u0; u1 = ay ? a1 : u1; u2 = az ? a2 : u2;
       }
       const int o = o_xy + zf * d.sz;
       Uout[o] = u0; Uout[o + d.sc] = u1; Uout[o + 2 * d.sc] = u2;
     }
     fz_prev = f0.z;
+  }
+}
+
+// =====================================================================================================================
+// k_vort_pipe (round 5): the same fused operator, software-pipelined -- ONE barrier per plane step instead of three.
+// k_vort_fused's waves spend 61 % of their cycles waiting (SQ_WAIT_ANY, profiles/r05_vort_pipe.txt): a step is three dependent
+// phases (ring <- U plane | curl from the ring | force from the curl rings | store), a barrier behind each, 4.2 clocks per
+// issued instruction and SIMD where the issue-bound kernels run at 2.5. Here every phase of step t works on data an EARLIER
+// step produced, so the phases of one step are independent instruction streams and one barrier closes the step:
+//     step t:  ring[t & 3] <- U plane t (registers, loaded during step t - 1)      planes t - 3 .. t - 1 are being read
+//              curl, |curl| of plane zc = t - 2  from ring planes t - 3, t - 2, t - 1   -> Cv[zc % 3], Cn[zc & 3]
+//              force of plane zf = t - 4          from Cn planes t - 5, t - 4, t - 3, Cv plane t - 4   -> Fe[zf & 1], registers
+//              plane zo = t - 5 out               from Fe[zo & 1] (x / y neighbours), the thread's own force of planes zo
+//                                                 and zo - 1 (registers), its own velocities (read from the ring at step
+//                                                 zo + 3, carried in registers)
+// Nothing a step writes is read in the same step, and what step t + 1 overwrites (ring plane t - 3, Cn plane t - 5, Cv plane
+// t - 4, Fe plane t - 5) was last read before step t's barrier. A block is 64 x 16 cells x a chunk of z with 1024 threads (one
+// block per CU: 154 KB of LDS): staged cells per output 1.50 (k_vort_fused: 1.91), curl cells 1.24 (1.44); the second
+// rounds of the staging / the curl tile and the edge forces go to DIFFERENT waves (8-15 / 0-3 / 4-5). Pipeline fill: 8 steps
+// per chunk (6): a kernel for big grids (chunks of 28+ planes). Per-cell arithmetic is k_vort_fused's, operation for operation.
+namespace {
+constexpr int PBX = 64, PBY = 16;
+constexpr int PUX = PBX + 6, PUY = PBY + 6, PUN = PUX * PUY;      // U tile 70 x 22, origin (x0 - 3, y0 - 3)
+constexpr int PCX = PBX + 3, PCY = PBY + 3, PCN = PCX * PCY;      // curl tile 67 x 19, origin (x0 - 2, y0 - 2)
+constexpr int PEX = PBX + 1, PEY = PBY + 1;                       // force exchange, origin (x0 - 1, y0 - 1)
+constexpr int kPipeLds = (4 * 3 * PUN + 4 * PCN + 3 * 3 * PCN + 2 * 2 * PEY * PEX) * 4;   // 157 796 bytes
+constexpr int kPipeFill = 8;
+}  // namespace
+
+__global__ __launch_bounds__(1024) void k_vort_pipe(Dom d, int cols_x, int cols_y, int cz, int chunks_a, int chunks, int n_blocks,
+                                                    const float* __restrict__ Uin, float* __restrict__ Uout,
+                                                    const float* __restrict__ flags, float strength, int xcd_order) {
+  extern __shared__ float lds[];
+  float* Ut = lds;                    // [4][3][PUN]  planes t & 3
+  float* Cn = Ut + 4 * 3 * PUN;       // [4][PCN]     |curl|, planes z & 3
+  float* Cv = Cn + 4 * PCN;           // [3][3][PCN]  curl, planes z % 3
+  float* Fe = Cv + 3 * 3 * PCN;       // [2][2][PEY][PEX] force.x / force.y, planes z & 1
+  const int blk = xcd_order ? (int)xcd_contiguous(blockIdx.x, (unsigned)n_blocks) : (int)blockIdx.x;
+  if (blk >= n_blocks) return;
+  int tq = blk;
+  const int bx = tq % cols_x; tq /= cols_x;
+  const int by = tq % cols_y; tq /= cols_y;
+  const int ch = tq % chunks;
+  const int b = tq / chunks;
+  const int za = ch < chunks_a ? d.w0 + ch * cz : d.w1 + (ch - chunks_a) * cz;
+  const int z_end = ch < chunks_a ? d.w0 + d.n0 : d.w1 + (d.nw - d.n0);
+  const int zb = min(za + cz, z_end);
+  const int x0 = bx * PBX, y0 = by * PBY;
+  const long long cells = d.sc;
+  Uin += b * cells * 3; Uout += b * cells * 3; flags += b * cells;
+  const int tid = threadIdx.x, tx = tid & 63, ty = tid >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(ty);     // (scalar: the per-wave roles below are scalar branches)
+  const int i = x0 + tx, j = y0 + ty;
+
+  // ---- per-thread geometry, fixed for the whole march --------------------------------------------------------------------
+  // staging: round 0 = cell tid of the U tile, round 1 (waves 8-15 and a few lanes of wave 7) = cell 1024 + (tid - kS1)
+  constexpr int kS1 = 1024 - (PUN - 1024);       // first thread of the second staging round (508)
+  const bool st1 = tid >= kS1;
+  int st_it[2], st_o[2];
+  st_it[0] = tid; st_it[1] = st1 ? 1024 + (tid - kS1) : tid;
+#pragma unroll
+  for (int r = 0; r < 2; r++) {
+    const int uy = st_it[r] / PUX, ux = st_it[r] - uy * PUX;
+    st_o[r] = TFL_AT(d, min(max(x0 - 3 + ux, 0), d.X - 1), min(max(y0 - 3 + uy, 0), d.Y - 1), 0);
+  }
+  // curl: round 0 = cell tid of the 67 x 19 curl tile, round 1 (waves 0-3) = cell 1024 + tid; bits as in k_vort_fused
+  constexpr int kC1 = PCN - 1024;                // cells of the second curl round (249)
+  int c_it[2], c_base[2], c_bits[2];
+#pragma unroll
+  for (int r = 0; r < 2; r++) {
+    const int it = min(tid + 1024 * r, PCN - 1);
+    const int cy = it / PCX, cx = it - cy * PCX;
+    const int gx = x0 - 2 + cx, gy = y0 - 2 + cy;
+    c_it[r] = it;
+    c_base[r] = (cy + 1) * PUX + (cx + 1);
+    const bool in = tid + 1024 * r < PCN && gx >= 1 && gx <= d.X - 2 && gy >= 1 && gy <= d.Y - 2;
+    c_bits[r] = (in ? 1 : 0) | (gx + 1 == d.X - 1 ? 2 : 0) | (gx - 1 == 0 ? 4 : 0) | (gy + 1 == d.Y - 1 ? 8 : 0) | (gy - 1 == 0 ? 16 : 0);
+  }
+  // force: the thread's own cell; waves 4 / 5: one cell of the column / the row before the block
+  const int f_it = (ty + 2) * PCX + tx + 2;
+  const bool f_in = i >= 1 && i <= d.X - 2 && j >= 1 && j <= d.Y - 2;
+  const bool e_col = tid >= 256 && tid < 256 + PBY, e_row = tid >= 320 && tid < 320 + PBX;
+  const int e_cx = e_col ? 1 : (tid - 320) + 2, e_cy = e_col ? (tid - 256) + 2 : 1;
+  const int e_it = (e_col || e_row) ? e_cy * PCX + e_cx : f_it;
+  const int e_gx = x0 - 2 + e_cx, e_gy = y0 - 2 + e_cy;
+  const bool e_in = (e_col || e_row) && e_gx >= 1 && e_gx <= d.X - 2 && e_gy >= 1 && e_gy <= d.Y - 2;
+  const int e_dst = e_col ? ((tid - 256) + 1) * PEX : PEY * PEX + (tid - 320) + 1;
+  const bool out_xy = i < d.X && j < d.Y;
+  const int o_xy = TFL_AT(d, min(i, d.X - 1), min(j, d.Y - 1), 0);
+  const int own_it = (ty + 3) * PUX + tx + 3;
+
+  auto force = [&](int it, bool use, const float* cn0, const float* cnp, const float* cnm, const float* cv) -> v3 {
+    const float* c0 = cn0 + it;
+    v3 g = mk3(0.5f * (c0[1] - c0[-1]), 0.5f * (c0[PCX] - c0[-PCX]), 0.5f * (cnp[it] - cnm[it]));
+    g = normalize3_x(g, use);
+    const v3 w = mk3(cv[it], cv[PCN + it], cv[2 * PCN + it]);
+    const v3 f = mk3(((g.y * w.z) - (g.z * w.y)) * strength, ((g.z * w.x) - (g.x * w.z)) * strength,
+                     ((g.x * w.y) - (g.y * w.x)) * strength);
+    return use ? f : mk3(0.0f, 0.0f, 0.0f);
+  };
+
+  float nu[2][3];                     // the U plane loaded one step ahead
+  auto load_plane = [&](int t) {
+    const int gz = min(max(t, 0), d.Z - 1) * d.sz;
+    const float* base = Uin + gz;
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+      if (r == 1 && wave * 64 + 63 < kS1) continue;         // waves 0-6 stage one cell
+      nu[r][0] = base[st_o[r]]; nu[r][1] = base[st_o[r] + d.sc]; nu[r][2] = base[st_o[r] + 2 * d.sc];
+    }
+  };
+  const int t0 = za - 3, t1 = zb + 4;
+  load_plane(t0);
+  float ownA[3] = {0.0f, 0.0f, 0.0f}, ownB[3] = {0.0f, 0.0f, 0.0f};    // the thread's velocities of planes t - 4 / t - 5 at the top of step t
+  v3 fcar = mk3(0.0f, 0.0f, 0.0f);    // the thread's force of plane t - 5 (computed in step t - 1)
+  float fzcar = 0.0f;                 // force.z of plane t - 6
+  int cv3 = ((t0 - 2) % 3 + 3) % 3;   // (zc % 3) of this step's curl plane, kept as a counter
+#pragma unroll 1
+  for (int t = t0; t <= t1; t++) {
+    // ---- out stage, part 1: ask for the flags of plane zo = t - 5 now ----
+    const int zo = t - 5;
+    const bool out_live = out_xy && zo >= za && zo < zb;
+    const bool out_inner = out_live && f_in && zo >= 1 && zo <= d.Z - 2;
+    float pfc = 0.0f, pnx = 0.0f, pny = 0.0f, pnz = 0.0f;
+    {
+      const int o = out_inner ? o_xy + zo * d.sz : o_xy + d.sz + d.sy + 1;     // (a valid address either way)
+      const float a = flags[o], bq = flags[o - 1], cq = flags[o - d.sy], dq = flags[o - d.sz];
+      pfc = out_inner ? a : 0.0f; pnx = out_inner ? bq : 0.0f; pny = out_inner ? cq : 0.0f; pnz = out_inner ? dq : 0.0f;
+    }
+    // ---- U plane t (in registers since the previous step) -> ring; then ask for plane t + 1 ----
+    if (t <= zb + 1) {                  // block-uniform
+      float* dst = Ut + (t & 3) * 3 * PUN;
+      dst[st_it[0]] = nu[0][0]; dst[PUN + st_it[0]] = nu[0][1]; dst[2 * PUN + st_it[0]] = nu[0][2];
+      if (wave * 64 + 63 >= kS1) {      // (the lanes of wave 7 below kS1 rewrite their own first cell)
+        dst[st_it[1]] = nu[1][0]; dst[PUN + st_it[1]] = nu[1][1]; dst[2 * PUN + st_it[1]] = nu[1][2];
+      }
+      if (t <= zb) load_plane(t + 1);
+    }
+    // ---- curl, |curl| of plane zc = t - 2 from ring planes t - 3, t - 2, t - 1 ----
+    const int zc = t - 2;
+    if (zc >= za - 2 && zc <= zb) {       // block-uniform
+      const bool z_in = zc >= 1 && zc <= d.Z - 2, zpb = zc + 1 == d.Z - 1, zmb = zc - 1 == 0;
+      const float* P0 = Ut + (zc & 3) * 3 * PUN;
+      const float* Pp = Ut + ((zc + 1) & 3) * 3 * PUN;
+      const float* Pm = Ut + ((zc - 1) & 3) * 3 * PUN;
+      float* cvw = Cv + cv3 * 3 * PCN;
+      float* cnw = Cn + (zc & 3) * PCN;
+#pragma unroll
+      for (int r = 0; r < 2; r++) {
+        if (r == 1 && wave * 64 >= kC1) continue;              // waves 4-15 have no cell in the second round
+        const bool mine = r == 0 || tid < kC1;
+        const bool ok = z_in && (c_bits[r] & 1) && mine;
+        const bool xpb = c_bits[r] & 2, xmb = c_bits[r] & 4, ypb = c_bits[r] & 8, ymb = c_bits[r] & 16;
+        // (every tap is read first, unconditionally -- inside `cond ? 0 : f(load)` hipcc guards each load with its own
+        // exec-mask branch: twelve of them per curl cell --, the border selects follow)
+        const float* ux0 = P0 + c_base[r];
+        const float* uy0 = ux0 + PUN;
+        const float* uz0 = ux0 + 2 * PUN;
+        const float* uxp = Pp + c_base[r];
+        const float* uxm = Pm + c_base[r];
+        const float y_xp0 = uy0[1], y_xp1 = uy0[1 + PUX], y_xm0 = uy0[-1], y_xm1 = uy0[-1 + PUX];
+        const float x_yp0 = ux0[PUX], x_yp1 = ux0[PUX + 1], x_ym0 = ux0[-PUX], x_ym1 = ux0[-PUX + 1];
+        const float z_yp0 = uz0[PUX], z_yp1 = uxp[2 * PUN + PUX], z_ym0 = uz0[-PUX], z_ym1 = uxp[2 * PUN - PUX];
+        const float y_zp0 = uxp[PUN], y_zp1 = uxp[PUN + PUX], y_zm0 = uxm[PUN], y_zm1 = uxm[PUN + PUX];
+        const float x_zp0 = uxp[0], x_zp1 = uxp[1], x_zm0 = uxm[0], x_zm1 = uxm[1];
+        const float z_xp0 = uz0[1], z_xp1 = uxp[2 * PUN + 1], z_xm0 = uz0[-1], z_xm1 = uxp[2 * PUN - 1];
+        const float cy_xp = xpb ? 0.0f : 0.5f * (y_xp0 + y_xp1);
+        const float cy_xm = xmb ? 0.0f : 0.5f * (y_xm0 + y_xm1);
+        const float cx_yp = ypb ? 0.0f : 0.5f * (x_yp0 + x_yp1);
+        const float cx_ym = ymb ? 0.0f : 0.5f * (x_ym0 + x_ym1);
+        v3 w;
+        w.z = 0.5f * ((cy_xp - cy_xm) - (cx_yp - cx_ym));
+        const float cz_yp = ypb ? 0.0f : 0.5f * (z_yp0 + z_yp1);
+        const float cz_ym = ymb ? 0.0f : 0.5f * (z_ym0 + z_ym1);
+        const float cy_zp = zpb ? 0.0f : 0.5f * (y_zp0 + y_zp1);
+        const float cy_zm = zmb ? 0.0f : 0.5f * (y_zm0 + y_zm1);
+        w.x = 0.5f * ((cz_yp - cz_ym) - (cy_zp - cy_zm));
+        const float cx_zp = zpb ? 0.0f : 0.5f * (x_zp0 + x_zp1);
+        const float cx_zm = zmb ? 0.0f : 0.5f * (x_zm0 + x_zm1);
+        const float cz_xp = xpb ? 0.0f : 0.5f * (z_xp0 + z_xp1);
+        const float cz_xm = xmb ? 0.0f : 0.5f * (z_xm0 + z_xm1);
+        w.y = 0.5f * ((cx_zp - cx_zm) - (cz_xp - cz_xm));
+        float nrm = norm3_x(w, ok);            // (unconditional: the wave-wide vote inside must not sit behind a lane branch)
+        nrm = ok ? nrm : 0.0f;
+        w = ok ? w : mk3(0.0f, 0.0f, 0.0f);
+        if (mine) {
+          cvw[c_it[r]] = w.x; cvw[PCN + c_it[r]] = w.y; cvw[2 * PCN + c_it[r]] = w.z;
+          cnw[c_it[r]] = nrm;
+        }
+      }
+    }
+    // the thread's own velocities of plane t - 3 (it entered the ring three steps ago; overwritten in the NEXT step)
+    float ownN[3];
+    {
+      const float* own = Ut + ((t - 3) & 3) * 3 * PUN + own_it;
+      ownN[0] = own[0]; ownN[1] = own[PUN]; ownN[2] = own[2 * PUN];
+    }
+    // ---- force of plane zf = t - 4 from Cn planes t - 5, t - 4, t - 3 and Cv plane t - 4 ----
+    const int zf = t - 4;
+    v3 f0 = mk3(0.0f, 0.0f, 0.0f);
+    if (zf >= za - 1 && zf <= zb - 1) {   // block-uniform
+      const bool z_in = zf >= 1 && zf <= d.Z - 2;
+      const float* cn0 = Cn + (zf & 3) * PCN;
+      const float* cnp = Cn + ((zf + 1) & 3) * PCN;
+      const float* cnm = Cn + ((zf - 1) & 3) * PCN;
+      const int cvf = cv3 >= 2 ? cv3 - 2 : cv3 + 1;          // (zc - 2) % 3
+      const float* cv = Cv + cvf * 3 * PCN;
+      float* fe = Fe + (zf & 1) * 2 * PEY * PEX;
+      f0 = force(f_it, z_in && f_in, cn0, cnp, cnm, cv);
+      fe[(ty + 1) * PEX + tx + 1] = f0.x;
+      fe[(PEY + ty + 1) * PEX + tx + 1] = f0.y;
+      if (wave == 4 || wave == 5) {         // the column / the row before the block
+        const v3 fq = force(e_it, z_in && e_in, cn0, cnp, cnm, cv);
+        if (e_col || e_row) fe[e_dst] = e_col ? fq.x : fq.y;
+      }
+    }
+    // ---- plane zo = t - 5 out: AddForceField (tfluids.cc:1312-1339); every cell of the plane is written ----
+    if (zo >= za && zo < zb) {            // block-uniform
+      const float* fe = Fe + (zo & 1) * 2 * PEY * PEX;
+      float u0 = ownB[0], u1 = ownB[1], u2 = ownB[2];
+      const int fc = (int)pfc;            // (all zero when !out_inner: nothing is added)
+      const bool cf = fc & kFluid, ce = fc & kEmpty;
+      const int nx = (int)pnx, ny = (int)pny, nz = (int)pnz;
+      const bool any = out_inner && (cf || ce);
+      const bool ax = any && ((nx & kFluid) || (cf && (nx & kEmpty)));
+      const bool ay = any && ((ny & kFluid) || (cf && (ny & kEmpty)));
+      const bool az = any && ((nz & kFluid) || (cf && (nz & kEmpty)));
+      const float a0 = u0 + (0.5f * (fe[(ty + 1) * PEX + tx] + fcar.x));
+      const float a1 = u1 + (0.5f * (fe[(PEY + ty) * PEX + tx + 1] + fcar.y));
+      const float a2 = u2 + (0.5f * (fzcar + fcar.z));
+      u0 = ax ? a0 : u0; u1 = ay ? a1 : u1; u2 = az ? a2 : u2;
+      if (out_live) {
+        const int o = o_xy + zo * d.sz;
+        Uout[o] = u0; Uout[o + d.sc] = u1; Uout[o + 2 * d.sc] = u2;
+      }
+    }
+    // ---- rotate the registers that travel with the planes ----
+    fzcar = fcar.z; fcar = f0;
+#pragma unroll
+    for (int a = 0; a < 3; a++) { ownB[a] = ownA[a]; ownA[a] = ownN[a]; }
+    cv3 = cv3 == 2 ? 0 : cv3 + 1;
+    __syncthreads();
   }
 }
 
@@ -578,31 +842,73 @@ bool vorticity_confinement_fused_ok(bool is3d, int Z, long long cells) {
   return vort_fused_slots() > 0;
 }
 
+// block slots of k_vort_pipe (one 1024-thread block with 154 KB of LDS per CU); 0 = this device cannot run it
+static int vort_pipe_slots() {
+  static std::atomic<int> slots_of[64];
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= 64) dev = 0;
+  int slots = slots_of[dev].load();
+  if (!slots) {
+    int cus = 256, per = 0;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const bool attr_ok = hipFuncSetAttribute((const void*)k_vort_pipe, hipFuncAttributeMaxDynamicSharedMemorySize, kPipeLds) == hipSuccess;
+    if (!attr_ok || hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, (const void*)k_vort_pipe, 1024, kPipeLds) != hipSuccess || per <= 0) {
+      (void)hipGetLastError();
+      slots = -1;
+    } else slots = cus * per;
+    slots_of[dev].store(slots);
+  }
+  return slots > 0 ? slots : 0;
+}
+
+// chunk length of a z-marched launch: rounds of resident blocks x (planes written + pipeline fill)
+static int march_chunk(long long tiles, int na, int nb, int slots, int fill, int cmin) {
+  int cz = cmin;
+  long long best = -1;
+  for (int c = cmin; c <= 64; c++) {
+    const long long blocks = tiles * ((na + c - 1) / c + (nb + c - 1) / c);
+    const long long cost = ((blocks + slots - 1) / slots) * (c + fill);
+    if (best < 0 || cost < best) { best = cost; cz = c; }
+  }
+  return cz;
+}
+
 // false = shape not supported by the fused kernel (the caller copies and runs the two-launch form)
 bool vorticity_confinement_fused(hipStream_t st, int B, int Z, int Y, int X, const float* Uin, float* Uout, const float* flags,
                                  float strength) {
   if (Z < 3 || Uin == Uout) return false;
   const Dom d = make_dom(Z, Y, X);
-  const int cxn = (X + FBX - 1) / FBX, cyn = (Y + FBY - 1) / FBY;
   const int na = d.n0, nb = d.nw - d.n0;
+  const int xcd_order = xcd_order_enabled() ? 1 : 0;
+  // the software-pipelined form (one barrier per step; 64 x 16 tiles, 8 planes of fill): the default wherever its chunks come
+  // out long enough to pay for the fill (TFL_VORT_PIPE = 0 | 1 forces; profiles/r05_vort_pipe.txt)
+  static const int pipe_mode = getenv("TFL_VORT_PIPE") ? atoi(getenv("TFL_VORT_PIPE")) : -1;
+  if (pipe_mode != 0) {
+    const int pslots = vort_pipe_slots();
+    const int pcx = (X + PBX - 1) / PBX, pcy = (Y + PBY - 1) / PBY;
+    const long long tiles = (long long)pcx * pcy * B;
+    if (pslots > 0 && tiles * (na + nb) > 0) {
+      int cz = march_chunk(tiles, na, nb, pslots, kPipeFill, 4);
+      if (const char* e = getenv("TFL_VORT_CZ")) cz = atoi(e) > 0 ? atoi(e) : cz;
+      if (pipe_mode == 1 || cz >= 24) {
+        const int chunks_a = (na + cz - 1) / cz, chunks = chunks_a + (nb + cz - 1) / cz;
+        const int n_blocks = (int)(pcx * pcy * chunks * B);
+        TFL_TIMED_EXT("k_vort_fused", st);
+        TFL_LAUNCH_EXT(k_vort_pipe, n_blocks, 1024, kPipeLds, st, d, pcx, pcy, cz, chunks_a, chunks, n_blocks, Uin, Uout, flags, strength, xcd_order);
+        return true;
+      }
+    }
+  }
+  const int cxn = (X + FBX - 1) / FBX, cyn = (Y + FBY - 1) / FBY;
   if ((long long)cxn * cyn * (na + nb) * B <= 0) return true;
   const int slots = vort_fused_slots();     // (the dynamic-LDS attribute is a per-device setting: asked once per device)
   if (slots <= 0) return false;             // the caller copies and runs the two-launch form
-  // chunk length: rounds of resident blocks x (planes written + 6 planes of pipeline fill)
-  int cz = 4;
-  {
-    long long best = -1;
-    for (int c = 4; c <= 64; c++) {
-      const long long blocks = (long long)cxn * cyn * B * ((na + c - 1) / c + (nb + c - 1) / c);
-      const long long cost = ((blocks + slots - 1) / slots) * (c + 6);
-      if (best < 0 || cost < best) { best = cost; cz = c; }
-    }
-  }
+  int cz = march_chunk((long long)cxn * cyn * B, na, nb, slots, 6, 4);
   if (const char* e = getenv("TFL_VORT_CZ")) cz = atoi(e) > 0 ? atoi(e) : cz;
   const int chunks_a = (na + cz - 1) / cz, chunks = chunks_a + (nb + cz - 1) / cz;
   const int n_blocks = cxn * cyn * chunks * B;
   TFL_TIMED_EXT("k_vort_fused", st);
-  const int xcd_order = xcd_order_enabled() ? 1 : 0;
   TFL_LAUNCH_EXT(k_vort_fused, n_blocks, 512, kFusedLds, st, d, cxn, cyn, cz, chunks_a, chunks, n_blocks, Uin, Uout, flags, strength, xcd_order);
   return true;
 }

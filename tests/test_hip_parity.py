@@ -533,6 +533,23 @@ def test_fused_vorticity_confinement_equals_the_two_launch_form(oracle, dims, se
         assert torch.equal(U, torch.from_numpy(sc["U"]).to(dev))          # the source is left alone
 
 
+@pytest.mark.parametrize("env", [{"TFL_VORT_PIPE": "1"}, {"TFL_VORT_PIPE": "1", "TFL_VORT_CZ": "5"}, {"TFL_VORT_PIPE": "0"}],
+                         ids=["pipelined", "pipelined-short-chunks", "three-barrier"])
+def test_fused_vorticity_kernel_variants(env):
+    """The fused confinement has two kernels -- k_vort_pipe (software-pipelined, one barrier per plane step; chosen when the
+    z chunks come out long: big grids) and k_vort_fused -- and the choice is read once per process: the cases of
+    test_fused_vorticity_confinement_equals_the_two_launch_form run again in child processes with each one forced, the
+    pipelined one also with chunks shorter than its pipeline (5 planes against 8 steps of fill)."""
+    import subprocess, sys
+    e = dict(os.environ)
+    for k in ("TFL_VORT_PIPE", "TFL_VORT_CZ"):
+        e.pop(k, None)
+    e.update(env)
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
+                          "-k", "test_fused_vorticity_confinement_equals_the_two_launch_form"], env=e, capture_output=True, text=True, timeout=1200)
+    assert out.returncode == 0 and " passed" in out.stdout and "failed" not in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
+
+
 def test_round4_abi_additions(hip):
     """tfl_set_advect_mode / tfl_get_advect_mode, tfl_stream_copy and the tfl_comm size check (ABI 3): argument errors
     come back as codes, the copy copies, and a slab step refuses a transport struct that does not declare its size."""
