@@ -12,6 +12,7 @@
 #include "tfl_fastmath.hpp"
 #include "tfl_host.hpp"
 #include "tfl_vec4.hpp"
+#include <type_traits>
 
 #include <atomic>
 #include <cstdlib>
@@ -570,37 +571,43 @@ __global__ __launch_bounds__(512) void k_vort_fused(Dom d, int cols_x, int cols_
 }
 
 // =====================================================================================================================
-// k_vort_pipe (round 5): the same fused operator, software-pipelined -- ONE barrier per plane step instead of three.
-// k_vort_fused's waves spend 61 % of their cycles waiting (SQ_WAIT_ANY, profiles/r05_vort_pipe.txt): a step is three dependent
-// phases (ring <- U plane | curl from the ring | force from the curl rings | store), a barrier behind each, 4.2 clocks per
-// issued instruction and SIMD where the issue-bound kernels run at 2.5. Here every phase of step t works on data an EARLIER
-// step produced, so the phases of one step are independent instruction streams and one barrier closes the step:
-//     step t:  ring[t & 3] <- U plane t (registers, loaded during step t - 1)      planes t - 3 .. t - 1 are being read
-//              curl, |curl| of plane zc = t - 2  from ring planes t - 3, t - 2, t - 1   -> Cv[zc % 3], Cn[zc & 3]
-//              force of plane zf = t - 4          from Cn planes t - 5, t - 4, t - 3, Cv plane t - 4   -> Fe[zf & 1], registers
-//              plane zo = t - 5 out               from Fe[zo & 1] (x / y neighbours), the thread's own force of planes zo
-//                                                 and zo - 1 (registers), its own velocities (read from the ring at step
-//                                                 zo + 3, carried in registers)
-// Nothing a step writes is read in the same step, and what step t + 1 overwrites (ring plane t - 3, Cn plane t - 5, Cv plane
-// t - 4, Fe plane t - 5) was last read before step t's barrier. A block is 64 x 16 cells x a chunk of z with 1024 threads (one
-// block per CU: 154 KB of LDS): staged cells per output 1.50 (k_vort_fused: 1.91), curl cells 1.24 (1.44); the second
-// rounds of the staging / the curl tile and the edge forces go to DIFFERENT waves (8-15 / 0-3 / 4-5). Pipeline fill: 8 steps
-// per chunk (6): a kernel for big grids (chunks of 28+ planes). Per-cell arithmetic is k_vort_fused's, operation for operation.
+// k_vort_pipe (round 5): the same fused operator, software-pipelined -- ONE barrier per plane step instead of three -- and
+// with the CENTRED velocities in the ring instead of the MAC ones.
+// * k_vort_fused's waves spend 61 % of their cycles waiting (SQ_WAIT_ANY, profiles/r05_vort_pipe.txt): a step is three
+//   dependent phases (ring <- U plane | curl from the ring | force from the curl rings | store), a barrier behind each, 4.2
+//   clocks per issued instruction and SIMD where the issue-bound kernels run at 2.5. Here every phase of step t works on data
+//   an EARLIER step produced, so the phases of one step are independent instruction streams and one barrier closes the step.
+// * VecGrid::curl (grid.cc:497-515) reads the centred velocity c(p) = 0.5 (u(p) + u(p + e)) of the six neighbours p of a
+//   cell, 0 where p lies on the border shell: each c(p) was evaluated by up to two cells, from two ring reads, an add, a
+//   multiply and a border select each time. The staging threads now evaluate it ONCE per staged cell (same expression: same
+//   bits), border zero included, and the curl of a cell is 12 ring reads and 12 flops.
+//     step t:  C ring[(t - 1) & 3] <- centred velocities of plane t - 1: c_x, c_y from the plane's own loads (registers since
+//                                     step t - 1), c_z from u_z of planes t - 1 (carried) and t (loaded during step t - 1)
+//              curl, |curl| of plane zc = t - 3  from C planes t - 4, t - 3, t - 2        -> Cv[zc % 3], Cn[zc & 3]
+//              force of plane zf = t - 5          from Cn planes t - 6, t - 5, t - 4, Cv plane t - 5   -> Fe[zf & 1], registers
+//              plane zo = t - 6 out               from Fe[zo & 1] (x / y neighbours), the thread's own force of planes zo and
+//                                                 zo - 1 (registers), its own velocities and flags (loaded at the top of the step)
+//   Nothing a step writes is read in the same step, and what step t + 1 overwrites (C plane t - 4, Cn plane t - 6, Cv plane
+//   t - 5, Fe plane t - 6) was last read before step t's barrier.
+// A block is 64 x 16 cells x a chunk of z with 1024 threads (one block per CU: 150 KB of LDS): staged cells per output 1.42
+// (k_vort_fused: 1.91), curl cells 1.24 (1.44); the second rounds of the staging / the curl tile and the edge forces go to
+// DIFFERENT waves (9-15 / 0-3 / 4-5). Pipeline fill: 9 steps per chunk (6). Per-cell arithmetic is k_curl / k_confine's,
+// operation for operation: bit-equal to the two-launch form (tests/test_hip_parity.py).
 namespace {
 constexpr int PBX = 64, PBY = 16;
-constexpr int PUX = PBX + 6, PUY = PBY + 6, PUN = PUX * PUY;      // U tile 70 x 22, origin (x0 - 3, y0 - 3)
 constexpr int PCX = PBX + 3, PCY = PBY + 3, PCN = PCX * PCY;      // curl tile 67 x 19, origin (x0 - 2, y0 - 2)
+constexpr int QX = PCX + 2, QY = PCY + 2, QN = QX * QY;           // centred-velocity tile 69 x 21, origin (x0 - 3, y0 - 3)
 constexpr int PEX = PBX + 1, PEY = PBY + 1;                       // force exchange, origin (x0 - 1, y0 - 1)
-constexpr int kPipeLds = (4 * 3 * PUN + 4 * PCN + 3 * 3 * PCN + 2 * 2 * PEY * PEX) * 4;   // 157 796 bytes
-constexpr int kPipeFill = 8;
+constexpr int kPipeLds = (4 * 3 * QN + 4 * PCN + 3 * 3 * PCN + 2 * 2 * PEY * PEX) * 4;   // 153 428 bytes
+constexpr int kPipeFill = 9;
 }  // namespace
 
 __global__ __launch_bounds__(1024) void k_vort_pipe(Dom d, int cols_x, int cols_y, int cz, int chunks_a, int chunks, int n_blocks,
                                                     const float* __restrict__ Uin, float* __restrict__ Uout,
-                                                    const float* __restrict__ flags, float strength, int xcd_order) {
+                                                    const float* __restrict__ flags, float strength, int xcd_order, BcFoldArg folda) {
   extern __shared__ float lds[];
-  float* Ut = lds;                    // [4][3][PUN]  planes t & 3
-  float* Cn = Ut + 4 * 3 * PUN;       // [4][PCN]     |curl|, planes z & 3
+  float* Cr = lds;                    // [4][3][QN]   centred velocities, planes z & 3
+  float* Cn = Cr + 4 * 3 * QN;        // [4][PCN]     |curl|, planes z & 3
   float* Cv = Cn + 4 * PCN;           // [3][3][PCN]  curl, planes z % 3
   float* Fe = Cv + 3 * 3 * PCN;       // [2][2][PEY][PEX] force.x / force.y, planes z & 1
   const int blk = xcd_order ? (int)xcd_contiguous(blockIdx.x, (unsigned)n_blocks) : (int)blockIdx.x;
@@ -621,28 +628,35 @@ __global__ __launch_bounds__(1024) void k_vort_pipe(Dom d, int cols_x, int cols_
   const int i = x0 + tx, j = y0 + ty;
 
   // ---- per-thread geometry, fixed for the whole march --------------------------------------------------------------------
-  // staging: round 0 = cell tid of the U tile, round 1 (waves 8-15 and a few lanes of wave 7) = cell 1024 + (tid - kS1)
-  constexpr int kS1 = 1024 - (PUN - 1024);       // first thread of the second staging round (508)
-  const bool st1 = tid >= kS1;
-  int st_it[2], st_o[2];
-  st_it[0] = tid; st_it[1] = st1 ? 1024 + (tid - kS1) : tid;
+  // staging: round 0 = cell tid of the C tile, round 1 (waves 9-15) = cell 1024 + (tid - kS1). Per cell: the offsets of the
+  // cell, its +x and its +y neighbour (clamped into the grid: cells outside it and shell cells stage 0) and the shell flag
+  constexpr int kS1 = 1024 - (QN - 1024);        // first thread of the second staging round (599)
+  const bool two_st = wave * 64 + 63 >= kS1;     // this wave stages a second cell
+  int st_it[2], st_o[2], st_ox[2], st_oy[2];
+  bool st_sh[2];
+  st_it[0] = tid; st_it[1] = tid >= kS1 ? 1024 + (tid - kS1) : tid;
 #pragma unroll
   for (int r = 0; r < 2; r++) {
-    const int uy = st_it[r] / PUX, ux = st_it[r] - uy * PUX;
-    st_o[r] = TFL_AT(d, min(max(x0 - 3 + ux, 0), d.X - 1), min(max(y0 - 3 + uy, 0), d.Y - 1), 0);
+    const int qy = st_it[r] / QX, qx = st_it[r] - qy * QX;
+    const int gx = x0 - 3 + qx, gy = y0 - 3 + qy;
+    const int xa = min(max(gx, 0), d.X - 1), ya = min(max(gy, 0), d.Y - 1);
+    st_o[r] = TFL_AT(d, xa, ya, 0);
+    st_ox[r] = TFL_AT(d, min(xa + 1, d.X - 1), ya, 0);
+    st_oy[r] = TFL_AT(d, xa, min(ya + 1, d.Y - 1), 0);
+    st_sh[r] = gx <= 0 || gx >= d.X - 1 || gy <= 0 || gy >= d.Y - 1;
   }
-  // curl: round 0 = cell tid of the 67 x 19 curl tile, round 1 (waves 0-3) = cell 1024 + tid; bits as in k_vort_fused
+  // curl: round 0 = cell tid of the 67 x 19 curl tile, round 1 (waves 0-3) = cell 1024 + tid
   constexpr int kC1 = PCN - 1024;                // cells of the second curl round (249)
-  int c_it[2], c_base[2], c_bits[2];
+  int c_it[2], c_base[2];
+  bool c_in[2];
 #pragma unroll
   for (int r = 0; r < 2; r++) {
     const int it = min(tid + 1024 * r, PCN - 1);
     const int cy = it / PCX, cx = it - cy * PCX;
     const int gx = x0 - 2 + cx, gy = y0 - 2 + cy;
     c_it[r] = it;
-    c_base[r] = (cy + 1) * PUX + (cx + 1);
-    const bool in = tid + 1024 * r < PCN && gx >= 1 && gx <= d.X - 2 && gy >= 1 && gy <= d.Y - 2;
-    c_bits[r] = (in ? 1 : 0) | (gx + 1 == d.X - 1 ? 2 : 0) | (gx - 1 == 0 ? 4 : 0) | (gy + 1 == d.Y - 1 ? 8 : 0) | (gy - 1 == 0 ? 16 : 0);
+    c_base[r] = (cy + 1) * QX + (cx + 1);
+    c_in[r] = tid + 1024 * r < PCN && gx >= 1 && gx <= d.X - 2 && gy >= 1 && gy <= d.Y - 2;
   }
   // force: the thread's own cell; waves 4 / 5: one cell of the column / the row before the block
   const int f_it = (ty + 2) * PCX + tx + 2;
@@ -655,7 +669,13 @@ __global__ __launch_bounds__(1024) void k_vort_pipe(Dom d, int cols_x, int cols_
   const int e_dst = e_col ? ((tid - 256) + 1) * PEX : PEY * PEX + (tid - 320) + 1;
   const bool out_xy = i < d.X && j < d.Y;
   const int o_xy = TFL_AT(d, min(i, d.X - 1), min(j, d.Y - 1), 0);
-  const int own_it = (ty + 3) * PUX + tx + 3;
+  const int o_safe = o_xy + (i >= 1 ? 0 : 1) + (j >= 1 ? 0 : d.sy);      // a cell whose -x / -y neighbours exist
+  // the setConstVals that follows the forces in simulate() (tfl_host.hpp BcFold): only the blocks whose rows and planes can
+  // touch the pair's box read the descriptor (for the plume's pair 1 block in 16-32)
+  const bool fold_blk = fold_block(folda, y0, y0 + PBY - 1, za, zb - 1);
+  BcFold fold = {nullptr, nullptr, 0, -1, 0, -1, 0, -1};
+  if (fold_blk) { fold = *folda.dev; fold.bc += b * cells * 3; fold.inv += b * cells * 3; }
+  const bool fold_xy = fold_blk && out_xy && j >= fold.y0 && j <= fold.y1 && fold_col(fold, i);
 
   auto force = [&](int it, bool use, const float* cn0, const float* cnp, const float* cnm, const float* cv) -> v3 {
     const float* c0 = cn0 + it;
@@ -667,86 +687,79 @@ __global__ __launch_bounds__(1024) void k_vort_pipe(Dom d, int cols_x, int cols_
     return use ? f : mk3(0.0f, 0.0f, 0.0f);
   };
 
-  float nu[2][3];                     // the U plane loaded one step ahead
+  float nl[2][5];                     // the loads of the plane one step ahead: u_x(p), u_x(p + x), u_y(p), u_y(p + y), u_z(p)
   auto load_plane = [&](int t) {
-    const int gz = min(max(t, 0), d.Z - 1) * d.sz;
-    const float* base = Uin + gz;
+    const float* bxp = Uin + (long long)min(max(t, 0), d.Z - 1) * d.sz;
+    const float* byp = bxp + d.sc;
+    const float* bzp = byp + d.sc;
 #pragma unroll
     for (int r = 0; r < 2; r++) {
-      if (r == 1 && wave * 64 + 63 < kS1) continue;         // waves 0-6 stage one cell
-      nu[r][0] = base[st_o[r]]; nu[r][1] = base[st_o[r] + d.sc]; nu[r][2] = base[st_o[r] + 2 * d.sc];
+      if (r == 1 && !two_st) continue;
+      nl[r][0] = bxp[st_o[r]]; nl[r][1] = bxp[st_ox[r]]; nl[r][2] = byp[st_o[r]]; nl[r][3] = byp[st_oy[r]]; nl[r][4] = bzp[st_o[r]];
     }
   };
-  const int t0 = za - 3, t1 = zb + 4;
+  const int t0 = za - 3, t1 = zb + 5;
   load_plane(t0);
-  float ownA[3] = {0.0f, 0.0f, 0.0f}, ownB[3] = {0.0f, 0.0f, 0.0f};    // the thread's velocities of planes t - 4 / t - 5 at the top of step t
-  v3 fcar = mk3(0.0f, 0.0f, 0.0f);    // the thread's force of plane t - 5 (computed in step t - 1)
-  float fzcar = 0.0f;                 // force.z of plane t - 6
-  int cv3 = ((t0 - 2) % 3 + 3) % 3;   // (zc % 3) of this step's curl plane, kept as a counter
-#pragma unroll 1
-  for (int t = t0; t <= t1; t++) {
-    // ---- out stage, part 1: ask for the flags of plane zo = t - 5 now ----
-    const int zo = t - 5;
-    const bool out_live = out_xy && zo >= za && zo < zb;
+  float cxp[2] = {0.0f, 0.0f}, cyp[2] = {0.0f, 0.0f}, uzp[2] = {0.0f, 0.0f};   // c_x, c_y, u_z of plane t - 1 at the top of step t
+  v3 fcar = mk3(0.0f, 0.0f, 0.0f);    // the thread's force of plane t - 6 (computed in step t - 1)
+  float fzcar = 0.0f;                 // force.z of plane t - 7
+  int cv3 = ((t0 - 3) % 3 + 3) % 3;   // (zc % 3) of this step's curl plane, kept as a counter
+  // one step; STEADY = every stage is active (no block-uniform guards: ONE basic block, so that the scheduler can run the
+  // stages' ring reads and arithmetic against each other)
+  auto step = [&](int t, auto steady_tag) {
+    constexpr bool STEADY = decltype(steady_tag)::value;
+    // ---- out stage, part 1: ask for the flags and the velocities of plane zo = t - 6 now ----
+    const int zo = t - 6;
+    const bool out_act = STEADY || (zo >= za && zo < zb);         // block-uniform
+    const bool out_live = out_xy && out_act;
     const bool out_inner = out_live && f_in && zo >= 1 && zo <= d.Z - 2;
-    float pfc = 0.0f, pnx = 0.0f, pny = 0.0f, pnz = 0.0f;
-    {
-      const int o = out_inner ? o_xy + zo * d.sz : o_xy + d.sz + d.sy + 1;     // (a valid address either way)
-      const float a = flags[o], bq = flags[o - 1], cq = flags[o - d.sy], dq = flags[o - d.sz];
+    float pfc = 0.0f, pnx = 0.0f, pny = 0.0f, pnz = 0.0f, pu0 = 0.0f, pu1 = 0.0f, pu2 = 0.0f;
+    if (out_act) {
+      const int zq = max(zo, 1);
+      const float* fp = flags + (long long)zq * d.sz;
+      const float a = fp[o_safe], bq = fp[o_safe - 1], cq = fp[o_safe - d.sy], dq = fp[o_safe - d.sz];
       pfc = out_inner ? a : 0.0f; pnx = out_inner ? bq : 0.0f; pny = out_inner ? cq : 0.0f; pnz = out_inner ? dq : 0.0f;
+      const float* up = Uin + (long long)zo * d.sz;
+      pu0 = up[o_xy]; pu1 = up[o_xy + d.sc]; pu2 = up[o_xy + 2 * d.sc];
     }
-    // ---- U plane t (in registers since the previous step) -> ring; then ask for plane t + 1 ----
-    if (t <= zb + 1) {                  // block-uniform
-      float* dst = Ut + (t & 3) * 3 * PUN;
-      dst[st_it[0]] = nu[0][0]; dst[PUN + st_it[0]] = nu[0][1]; dst[2 * PUN + st_it[0]] = nu[0][2];
-      if (wave * 64 + 63 >= kS1) {      // (the lanes of wave 7 below kS1 rewrite their own first cell)
-        dst[st_it[1]] = nu[1][0]; dst[PUN + st_it[1]] = nu[1][1]; dst[2 * PUN + st_it[1]] = nu[1][2];
+    // ---- centred velocities of plane t - 1 -> ring; then ask for plane t + 1 ----
+    if (STEADY || t <= zb + 2) {        // block-uniform
+      const bool zsh = t - 1 <= 0 || t - 1 >= d.Z - 1;
+      float* dst = Cr + ((t - 1) & 3) * 3 * QN;
+#pragma unroll
+      for (int r = 0; r < 2; r++) {
+        if (r == 1 && !two_st) continue;
+        const float cxn = 0.5f * (nl[r][0] + nl[r][1]), cyn = 0.5f * (nl[r][2] + nl[r][3]);     // plane t: next step's
+        const float czp = 0.5f * (uzp[r] + nl[r][4]);
+        const bool z0 = zsh || st_sh[r];
+        if (STEADY || t > t0) { dst[st_it[r]] = z0 ? 0.0f : cxp[r]; dst[QN + st_it[r]] = z0 ? 0.0f : cyp[r]; dst[2 * QN + st_it[r]] = z0 ? 0.0f : czp; }
+        cxp[r] = cxn; cyp[r] = cyn; uzp[r] = nl[r][4];
       }
-      if (t <= zb) load_plane(t + 1);
+      if (STEADY || t <= zb + 1) load_plane(t + 1);
     }
-    // ---- curl, |curl| of plane zc = t - 2 from ring planes t - 3, t - 2, t - 1 ----
-    const int zc = t - 2;
-    if (zc >= za - 2 && zc <= zb) {       // block-uniform
-      const bool z_in = zc >= 1 && zc <= d.Z - 2, zpb = zc + 1 == d.Z - 1, zmb = zc - 1 == 0;
-      const float* P0 = Ut + (zc & 3) * 3 * PUN;
-      const float* Pp = Ut + ((zc + 1) & 3) * 3 * PUN;
-      const float* Pm = Ut + ((zc - 1) & 3) * 3 * PUN;
+    // ---- curl, |curl| of plane zc = t - 3 from C planes t - 4, t - 3, t - 2 ----
+    const int zc = t - 3;
+    if (STEADY || (zc >= za - 2 && zc <= zb)) {       // block-uniform
+      const bool z_in = zc >= 1 && zc <= d.Z - 2;
+      const float* P0 = Cr + (zc & 3) * 3 * QN;
+      const float* Pp = Cr + ((zc + 1) & 3) * 3 * QN;
+      const float* Pm = Cr + ((zc - 1) & 3) * 3 * QN;
       float* cvw = Cv + cv3 * 3 * PCN;
       float* cnw = Cn + (zc & 3) * PCN;
 #pragma unroll
       for (int r = 0; r < 2; r++) {
         if (r == 1 && wave * 64 >= kC1) continue;              // waves 4-15 have no cell in the second round
         const bool mine = r == 0 || tid < kC1;
-        const bool ok = z_in && (c_bits[r] & 1) && mine;
-        const bool xpb = c_bits[r] & 2, xmb = c_bits[r] & 4, ypb = c_bits[r] & 8, ymb = c_bits[r] & 16;
-        // (every tap is read first, unconditionally -- inside `cond ? 0 : f(load)` hipcc guards each load with its own
-        // exec-mask branch: twelve of them per curl cell --, the border selects follow)
-        const float* ux0 = P0 + c_base[r];
-        const float* uy0 = ux0 + PUN;
-        const float* uz0 = ux0 + 2 * PUN;
-        const float* uxp = Pp + c_base[r];
-        const float* uxm = Pm + c_base[r];
-        const float y_xp0 = uy0[1], y_xp1 = uy0[1 + PUX], y_xm0 = uy0[-1], y_xm1 = uy0[-1 + PUX];
-        const float x_yp0 = ux0[PUX], x_yp1 = ux0[PUX + 1], x_ym0 = ux0[-PUX], x_ym1 = ux0[-PUX + 1];
-        const float z_yp0 = uz0[PUX], z_yp1 = uxp[2 * PUN + PUX], z_ym0 = uz0[-PUX], z_ym1 = uxp[2 * PUN - PUX];
-        const float y_zp0 = uxp[PUN], y_zp1 = uxp[PUN + PUX], y_zm0 = uxm[PUN], y_zm1 = uxm[PUN + PUX];
-        const float x_zp0 = uxp[0], x_zp1 = uxp[1], x_zm0 = uxm[0], x_zm1 = uxm[1];
-        const float z_xp0 = uz0[1], z_xp1 = uxp[2 * PUN + 1], z_xm0 = uz0[-1], z_xm1 = uxp[2 * PUN - 1];
-        const float cy_xp = xpb ? 0.0f : 0.5f * (y_xp0 + y_xp1);
-        const float cy_xm = xmb ? 0.0f : 0.5f * (y_xm0 + y_xm1);
-        const float cx_yp = ypb ? 0.0f : 0.5f * (x_yp0 + x_yp1);
-        const float cx_ym = ymb ? 0.0f : 0.5f * (x_ym0 + x_ym1);
+        const bool ok = z_in && c_in[r] && mine;
+        const float* q0 = P0 + c_base[r];
+        const float* qp = Pp + c_base[r];
+        const float* qm = Pm + c_base[r];
+        const float cy_xp = q0[QN + 1], cy_xm = q0[QN - 1], cx_yp = q0[QX], cx_ym = q0[-QX];
+        const float cz_yp = q0[2 * QN + QX], cz_ym = q0[2 * QN - QX], cy_zp = qp[QN], cy_zm = qm[QN];
+        const float cx_zp = qp[0], cx_zm = qm[0], cz_xp = q0[2 * QN + 1], cz_xm = q0[2 * QN - 1];
         v3 w;
         w.z = 0.5f * ((cy_xp - cy_xm) - (cx_yp - cx_ym));
-        const float cz_yp = ypb ? 0.0f : 0.5f * (z_yp0 + z_yp1);
-        const float cz_ym = ymb ? 0.0f : 0.5f * (z_ym0 + z_ym1);
-        const float cy_zp = zpb ? 0.0f : 0.5f * (y_zp0 + y_zp1);
-        const float cy_zm = zmb ? 0.0f : 0.5f * (y_zm0 + y_zm1);
         w.x = 0.5f * ((cz_yp - cz_ym) - (cy_zp - cy_zm));
-        const float cx_zp = zpb ? 0.0f : 0.5f * (x_zp0 + x_zp1);
-        const float cx_zm = zmb ? 0.0f : 0.5f * (x_zm0 + x_zm1);
-        const float cz_xp = xpb ? 0.0f : 0.5f * (z_xp0 + z_xp1);
-        const float cz_xm = xmb ? 0.0f : 0.5f * (z_xm0 + z_xm1);
         w.y = 0.5f * ((cx_zp - cx_zm) - (cz_xp - cz_xm));
         float nrm = norm3_x(w, ok);            // (unconditional: the wave-wide vote inside must not sit behind a lane branch)
         nrm = ok ? nrm : 0.0f;
@@ -757,16 +770,10 @@ __global__ __launch_bounds__(1024) void k_vort_pipe(Dom d, int cols_x, int cols_
         }
       }
     }
-    // the thread's own velocities of plane t - 3 (it entered the ring three steps ago; overwritten in the NEXT step)
-    float ownN[3];
-    {
-      const float* own = Ut + ((t - 3) & 3) * 3 * PUN + own_it;
-      ownN[0] = own[0]; ownN[1] = own[PUN]; ownN[2] = own[2 * PUN];
-    }
-    // ---- force of plane zf = t - 4 from Cn planes t - 5, t - 4, t - 3 and Cv plane t - 4 ----
-    const int zf = t - 4;
+    // ---- force of plane zf = t - 5 from Cn planes t - 6, t - 5, t - 4 and Cv plane t - 5 ----
+    const int zf = t - 5;
     v3 f0 = mk3(0.0f, 0.0f, 0.0f);
-    if (zf >= za - 1 && zf <= zb - 1) {   // block-uniform
+    if (STEADY || (zf >= za - 1 && zf <= zb - 1)) {   // block-uniform
       const bool z_in = zf >= 1 && zf <= d.Z - 2;
       const float* cn0 = Cn + (zf & 3) * PCN;
       const float* cnp = Cn + ((zf + 1) & 3) * PCN;
@@ -782,10 +789,10 @@ __global__ __launch_bounds__(1024) void k_vort_pipe(Dom d, int cols_x, int cols_
         if (e_col || e_row) fe[e_dst] = e_col ? fq.x : fq.y;
       }
     }
-    // ---- plane zo = t - 5 out: AddForceField (tfluids.cc:1312-1339); every cell of the plane is written ----
-    if (zo >= za && zo < zb) {            // block-uniform
+    // ---- plane zo = t - 6 out: AddForceField (tfluids.cc:1312-1339); every cell of the plane is written ----
+    if (out_act) {
       const float* fe = Fe + (zo & 1) * 2 * PEY * PEX;
-      float u0 = ownB[0], u1 = ownB[1], u2 = ownB[2];
+      float u0 = pu0, u1 = pu1, u2 = pu2;
       const int fc = (int)pfc;            // (all zero when !out_inner: nothing is added)
       const bool cf = fc & kFluid, ce = fc & kEmpty;
       const int nx = (int)pnx, ny = (int)pny, nz = (int)pnz;
@@ -797,18 +804,33 @@ __global__ __launch_bounds__(1024) void k_vort_pipe(Dom d, int cols_x, int cols_
       const float a1 = u1 + (0.5f * (fe[(PEY + ty) * PEX + tx + 1] + fcar.y));
       const float a2 = u2 + (0.5f * (fzcar + fcar.z));
       u0 = ax ? a0 : u0; u1 = ay ? a1 : u1; u2 = az ? a2 : u2;
+      if (fold_blk) {                     // block-uniform
+        const bool fq = fold_xy && out_live && zo >= fold.z0 && zo <= fold.z1;
+        const long long o = fq ? (long long)zo * d.sz + o_xy : 0;
+        const float m0 = fold.inv[o], m1 = fold.inv[o + d.sc], m2 = fold.inv[o + 2 * d.sc];
+        const float b0 = fold.bc[o], b1 = fold.bc[o + d.sc], b2 = fold.bc[o + 2 * d.sc];
+        const float g0 = u0 * m0 + b0, g1 = u1 * m1 + b1, g2 = u2 * m2 + b2;
+        u0 = fq ? g0 : u0; u1 = fq ? g1 : u1; u2 = fq ? g2 : u2;
+      }
       if (out_live) {
-        const int o = o_xy + zo * d.sz;
-        Uout[o] = u0; Uout[o + d.sc] = u1; Uout[o + 2 * d.sc] = u2;
+        float* op = Uout + (long long)zo * d.sz;
+        op[o_xy] = u0; op[o_xy + d.sc] = u1; op[o_xy + 2 * d.sc] = u2;
       }
     }
     // ---- rotate the registers that travel with the planes ----
     fzcar = fcar.z; fcar = f0;
-#pragma unroll
-    for (int a = 0; a < 3; a++) { ownB[a] = ownA[a]; ownA[a] = ownN[a]; }
     cv3 = cv3 == 2 ? 0 : cv3 + 1;
     __syncthreads();
-  }
+  };
+  // every stage is active for t in [za + 6, zb + 1]
+  const int ts = min(max(za + 6, t0), t1 + 1), te = min(zb + 1, t1);
+  int t = t0;
+#pragma unroll 1
+  for (; t < ts; t++) step(t, std::false_type{});
+#pragma unroll 1
+  for (; t <= te; t++) step(t, std::true_type{});
+#pragma unroll 1
+  for (; t <= t1; t++) step(t, std::false_type{});
 }
 
 // block slots of k_vort_fused on the current device, asked once per device: 0 = the device cannot run it (its 78 KB of dynamic
@@ -833,15 +855,6 @@ static int vort_fused_slots() {
   return slots > 0 ? slots : 0;
 }
 
-// does the native step route its confinement through the fused kernel (TFL_VORT_FUSED = 1 | 0; default: see the record in
-// profiles/r04_advect_experiments.txt)
-bool vorticity_confinement_fused_ok(bool is3d, int Z, long long cells) {
-  static const int mode = getenv("TFL_VORT_FUSED") ? atoi(getenv("TFL_VORT_FUSED")) : -1;
-  if (!is3d || Z < 3 || mode == 0) return false;
-  if (!(mode == 1 || cells >= 3000000ll)) return false;   // 128^3 (2.1 M): 42.6 vs 38.5 us for the two launches; 160^3 (4.1 M): 85 vs 108; 256^3: 274 vs 397
-  return vort_fused_slots() > 0;
-}
-
 // block slots of k_vort_pipe (one 1024-thread block with 154 KB of LDS per CU); 0 = this device cannot run it
 static int vort_pipe_slots() {
   static std::atomic<int> slots_of[64];
@@ -860,6 +873,22 @@ static int vort_pipe_slots() {
     slots_of[dev].store(slots);
   }
   return slots > 0 ? slots : 0;
+}
+
+// does the native step (and tfl_vorticityConfinementFrom) route the confinement through a fused kernel? TFL_VORT_FUSED = 1 | 0
+// forces. By measurement (profiles/r05_vort_pipe.txt, us: two launches / k_vort_pipe): 64^3 13 / 18, 96^3 24 / 23, 112^3 32 / 27,
+// 128^3 36 / 29, 160^3 80 / 50, 192^3 147 / 77, 256^3 310 / 165. The operator alone turns at ~1 M cells -- but inside the step
+// the 128^3 gain (-5 us) is given back by the kernels that follow (k_bcs_div_stats +2.5, k_project +1.5 us): k_confine_v4 writes U
+// through the same block -> XCD map its consumers read it with (their reads hit the L2 it left the lines in), the marched
+// kernel's tiles do not. So: from 3 M cells per batch item, where the gain is tens of us (k_vort_fused, where the device cannot
+// hold the pipelined kernel's block, from the same size: 160^3 69 / 80).
+bool vorticity_confinement_fused_ok(bool is3d, int Z, long long cells) {
+  static const int mode = getenv("TFL_VORT_FUSED") ? atoi(getenv("TFL_VORT_FUSED")) : -1;
+  static const int pipe_mode = getenv("TFL_VORT_PIPE") ? atoi(getenv("TFL_VORT_PIPE")) : -1;
+  if (!is3d || Z < 3 || mode == 0) return false;
+  const bool have = (pipe_mode != 0 && vort_pipe_slots() > 0) || vort_fused_slots() > 0;
+  if (mode == 1) return have;
+  return cells >= 3000000ll && have;
 }
 
 // chunk length of a z-marched launch: rounds of resident blocks x (planes written + pipeline fill)
@@ -881,8 +910,9 @@ bool vorticity_confinement_fused(hipStream_t st, int B, int Z, int Y, int X, con
   const Dom d = make_dom(Z, Y, X);
   const int na = d.n0, nb = d.nw - d.n0;
   const int xcd_order = xcd_order_enabled() ? 1 : 0;
-  // the software-pipelined form (one barrier per step; 64 x 16 tiles, 8 planes of fill): the default wherever its chunks come
-  // out long enough to pay for the fill (TFL_VORT_PIPE = 0 | 1 forces; profiles/r05_vort_pipe.txt)
+  // the software-pipelined form (one barrier per step; 64 x 16 tiles, 9 steps of fill) wherever the device can hold its block:
+  // faster than k_vort_fused at every size measured, 9-step fill and all (profiles/r05_vort_pipe.txt). TFL_VORT_PIPE=0: the
+  // three-barrier kernel
   static const int pipe_mode = getenv("TFL_VORT_PIPE") ? atoi(getenv("TFL_VORT_PIPE")) : -1;
   if (pipe_mode != 0) {
     const int pslots = vort_pipe_slots();
@@ -891,11 +921,12 @@ bool vorticity_confinement_fused(hipStream_t st, int B, int Z, int Y, int X, con
     if (pslots > 0 && tiles * (na + nb) > 0) {
       int cz = march_chunk(tiles, na, nb, pslots, kPipeFill, 4);
       if (const char* e = getenv("TFL_VORT_CZ")) cz = atoi(e) > 0 ? atoi(e) : cz;
-      if (pipe_mode == 1 || cz >= 24) {
+      {
         const int chunks_a = (na + cz - 1) / cz, chunks = chunks_a + (nb + cz - 1) / cz;
         const int n_blocks = (int)(pcx * pcy * chunks * B);
         TFL_TIMED_EXT("k_vort_fused", st);
-        TFL_LAUNCH_EXT(k_vort_pipe, n_blocks, 1024, kPipeLds, st, d, pcx, pcy, cz, chunks_a, chunks, n_blocks, Uin, Uout, flags, strength, xcd_order);
+        const BcFoldArg fold = take_fold();    // the kernel writes the operator's result: it applies the pair that follows
+        TFL_LAUNCH_EXT(k_vort_pipe, n_blocks, 1024, kPipeLds, st, d, pcx, pcy, cz, chunks_a, chunks, n_blocks, Uin, Uout, flags, strength, xcd_order, fold);
         return true;
       }
     }

@@ -1,12 +1,13 @@
 """Per-kernel times of the vorticity confinement alone at 128^3, 192^3 and 256^3: the two launches (in place) and the fused kernel
-(tfl_vorticityConfinementFrom), smooth random velocity, a border of obstacle cells. usage: [TFL_VORT_CZ=n] python tools/vort_abl.py"""
+(tfl_vorticityConfinementFrom; TFL_VORT_FUSED=1 forces it below its size threshold), smooth random velocity, a border of
+obstacle cells. usage: [RES=128,192,256] [TFL_VORT_FUSED=1] [TFL_VORT_PIPE=0|1] [TFL_VORT_CZ=n] python tools/vort_abl.py"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 from fluidnet_amd import tfluids
 dev = torch.device("cuda:0")
-for res in (128, 192, 256):
+for res in [int(x) for x in os.environ.get("RES", "128,192,256").split(",")]:
     g = torch.Generator(device=dev); g.manual_seed(1)
     U = torch.randn(1, 3, res, res, res, device=dev, generator=g)
     for _ in range(2):
