@@ -473,6 +473,25 @@ def test_advection_kernel_variants_are_bit_exact(env):
     assert out.returncode == 0 and "ADV_VARIANTS_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
 
 
+@pytest.mark.parametrize("env", [{"TFL_XCD_ORDER": "0"}, {"TFL_XCD_ORDER": "1"}, {"TFL_XCD_RUN": "3"}],
+                         ids=["hardware-order", "one-run-per-xcd", "runs-of-3-tiles"])
+def test_block_order_variants_are_bit_exact(env):
+    """The halo-reading kernels (advectScalar's passes, k_curl / k_confine, the fused confinement) map blocks to tiles through
+    tfl_device.hpp block_tile: runs of consecutive tiles per XCD (default: an eighth of a plane), decoded with exact
+    multiply-high divisions. Any run length must give the same fields: the oracle / ragged-grid / fused-confinement cases run
+    again in child processes (the switches are read once) with the hardware's order, one run per XCD, and runs of 3 tiles --
+    which leaves launches whose block count is no multiple of 8 x 3 with a partial round."""
+    import subprocess, sys
+    e = dict(os.environ)
+    for k in ("TFL_XCD_ORDER", "TFL_XCD_RUN"):
+        e.pop(k, None)
+    e.update(env)
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider", "-k",
+                          "test_hip_matches_oracle or test_maccormack_large_displacements_and_ragged_grids or "
+                          "test_fused_vorticity_confinement_equals_the_two_launch_form"], env=e, capture_output=True, text=True, timeout=1200)
+    assert out.returncode == 0 and " passed" in out.stdout and "failed" not in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
+
+
 def test_hip_pcg_errors_and_defaults(hip, oracle):
     from fluidnet_amd import TfluidsError
     sc, f, U, div = scenes.pcg_problem(oracle, (1, 12, 12), 7)
