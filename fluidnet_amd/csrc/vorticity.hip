@@ -688,6 +688,7 @@ __global__ __launch_bounds__(1024) void k_vort_pipe(Dom d, int cols_x, int cols_
   };
 
   float nl[2][5];                     // the loads of the plane one step ahead: u_x(p), u_x(p + x), u_y(p), u_y(p + y), u_z(p)
+  float on[3] = {0.0f, 0.0f, 0.0f};   // ... and the thread's own cell of that plane (see oq below)
   auto load_plane = [&](int t) {
     const float* bxp = Uin + (long long)min(max(t, 0), d.Z - 1) * d.sz;
     const float* byp = bxp + d.sc;
@@ -697,10 +698,17 @@ __global__ __launch_bounds__(1024) void k_vort_pipe(Dom d, int cols_x, int cols_
       if (r == 1 && !two_st) continue;
       nl[r][0] = bxp[st_o[r]]; nl[r][1] = bxp[st_ox[r]]; nl[r][2] = byp[st_o[r]]; nl[r][3] = byp[st_oy[r]]; nl[r][4] = bzp[st_o[r]];
     }
+    on[0] = bxp[o_xy]; on[1] = byp[o_xy]; on[2] = bzp[o_xy];
   };
   const int t0 = za - 3, t1 = zb + 5;
   load_plane(t0);
   float cxp[2] = {0.0f, 0.0f}, cyp[2] = {0.0f, 0.0f}, uzp[2] = {0.0f, 0.0f};   // c_x, c_y, u_z of plane t - 1 at the top of step t
+  // the thread's OWN velocities travel in registers from the step that stages their plane to the step that stores it (seven
+  // steps later the lines have left the XCD's L2: read again at the store they were 12 of the kernel's 43 B/cell at 256^3):
+  // oq[i] = plane t - 6 + i at the out stage of step t, on[] = plane t + 1 (asked for during step t)
+  float oq[7][3];
+#pragma unroll
+  for (int q = 0; q < 7; q++) { oq[q][0] = 0.0f; oq[q][1] = 0.0f; oq[q][2] = 0.0f; }
   v3 fcar = mk3(0.0f, 0.0f, 0.0f);    // the thread's force of plane t - 6 (computed in step t - 1)
   float fzcar = 0.0f;                 // force.z of plane t - 7
   int cv3 = ((t0 - 3) % 3 + 3) % 3;   // (zc % 3) of this step's curl plane, kept as a counter
@@ -719,9 +727,12 @@ __global__ __launch_bounds__(1024) void k_vort_pipe(Dom d, int cols_x, int cols_
       const float* fp = flags + (long long)zq * d.sz;
       const float a = fp[o_safe], bq = fp[o_safe - 1], cq = fp[o_safe - d.sy], dq = fp[o_safe - d.sz];
       pfc = out_inner ? a : 0.0f; pnx = out_inner ? bq : 0.0f; pny = out_inner ? cq : 0.0f; pnz = out_inner ? dq : 0.0f;
-      const float* up = Uin + (long long)zo * d.sz;
-      pu0 = up[o_xy]; pu1 = up[o_xy + d.sc]; pu2 = up[o_xy + 2 * d.sc];
     }
+    // the queue advances: plane t (asked for during step t - 1) enters at the back, plane t - 6 is at the front
+#pragma unroll
+    for (int q = 0; q < 6; q++) { oq[q][0] = oq[q + 1][0]; oq[q][1] = oq[q + 1][1]; oq[q][2] = oq[q + 1][2]; }
+    oq[6][0] = on[0]; oq[6][1] = on[1]; oq[6][2] = on[2];
+    pu0 = oq[0][0]; pu1 = oq[0][1]; pu2 = oq[0][2];
     // ---- centred velocities of plane t - 1 -> ring; then ask for plane t + 1 ----
     if (STEADY || t <= zb + 2) {        // block-uniform
       const bool zsh = t - 1 <= 0 || t - 1 >= d.Z - 1;
