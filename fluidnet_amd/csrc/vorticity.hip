@@ -889,10 +889,9 @@ static int vort_pipe_slots() {
 // does the native step (and tfl_vorticityConfinementFrom) route the confinement through a fused kernel? TFL_VORT_FUSED = 1 | 0
 // forces. By measurement (profiles/r05_vort_pipe.txt, us: two launches / k_vort_pipe): 64^3 13 / 18, 96^3 24 / 23, 112^3 32 / 27,
 // 128^3 36 / 29, 160^3 80 / 50, 192^3 147 / 77, 256^3 310 / 165. The operator alone turns at ~1 M cells -- but inside the step
-// the 128^3 gain (-5 us) is given back by the kernels that follow (k_bcs_div_stats +2.5, k_project +1.5 us): k_confine_v4 writes U
-// through the same block -> XCD map its consumers read it with (their reads hit the L2 it left the lines in), the marched
-// kernel's tiles do not. So: from 3 M cells per batch item, where the gain is tens of us (k_vort_fused, where the device cannot
-// hold the pipelined kernel's block, from the same size: 160^3 69 / 80).
+// the 128^3 gain (-5 us) is given back by the kernels that follow (k_bcs_div_stats +2.5, k_project +1.5 us, measured twice in
+// one session; cause not isolated -- DESIGN.md 3.8). So: from 3 M cells per batch item, where the gain is tens of us
+// (k_vort_fused, where the device cannot hold the pipelined kernel's block, from the same size: 160^3 69 / 80).
 bool vorticity_confinement_fused_ok(bool is3d, int Z, long long cells) {
   static const int mode = getenv("TFL_VORT_FUSED") ? atoi(getenv("TFL_VORT_FUSED")) : -1;
   static const int pipe_mode = getenv("TFL_VORT_PIPE") ? atoi(getenv("TFL_VORT_PIPE")) : -1;
