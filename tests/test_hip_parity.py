@@ -550,18 +550,38 @@ def test_fused_vorticity_confinement_equals_the_two_launch_form(oracle, dims, se
         oracle.vorticityConfinement(ref, sc["flags"], 0.7)
         assert np.array_equal(got.cpu().numpy(), ref), d
         assert torch.equal(U, torch.from_numpy(sc["U"]).to(dev))          # the source is left alone
+        if is3d and d[0] >= 5 and os.environ.get("TFL_VORT_FUSED") == "1":     # (the fused kernels: the two-launch route needs its curl on a wider window)
+            # under a compute window (tfl_set_z_window: two plane runs in one launch, what a z-slab rank's phases use) the
+            # planes of the window -- and only those -- are written, with the whole-array values
+            lib, ctx = tfluids._context(U)
+            Z = d[0]
+            a0, a1, b0, b1 = 1, 3, Z - 2, Z
+            win = torch.full_like(U, 7.0)
+            assert lib.tfl_set_z_window(ctx, a0, a1, b0, b1) == 0
+            try:
+                tfluids.vorticityConfinement(win, fl, 0.7, USrc=U)
+            finally:
+                assert lib.tfl_set_z_window(ctx, 0, 0, 0, 0) == 0
+            inside = torch.zeros(Z, dtype=torch.bool, device=dev)
+            inside[a0:a1] = True; inside[b0:b1] = True
+            assert torch.equal(win[:, :, inside], want[:, :, inside]), d
+            assert bool((win[:, :, ~inside] == 7.0).all()), d
 
 
-@pytest.mark.parametrize("env", [{"TFL_VORT_PIPE": "1"}, {"TFL_VORT_PIPE": "1", "TFL_VORT_CZ": "5"}, {"TFL_VORT_PIPE": "0"}],
-                         ids=["pipelined", "pipelined-short-chunks", "three-barrier"])
+@pytest.mark.parametrize("env", [{"TFL_VORT_FUSED": "1", "TFL_VORT_PIPE": "1"}, {"TFL_VORT_FUSED": "1", "TFL_VORT_PIPE": "1", "TFL_VORT_CZ": "5"},
+                                 {"TFL_VORT_FUSED": "1", "TFL_VORT_PIPE": "0"}, {"TFL_VORT_FUSED": "1", "TFL_VORT_PIPE": "0", "TFL_VORT_CZ": "5"},
+                                 {"TFL_VORT_FUSED": "1", "TFL_XCD_ORDER": "0"}],
+                         ids=["pipelined", "pipelined-short-chunks", "three-barrier", "three-barrier-short-chunks", "pipelined-hardware-block-order"])
 def test_fused_vorticity_kernel_variants(env):
     """The fused confinement has two kernels -- k_vort_pipe (software-pipelined, one barrier per plane step; chosen when the
-    z chunks come out long: big grids) and k_vort_fused -- and the choice is read once per process: the cases of
-    test_fused_vorticity_confinement_equals_the_two_launch_form run again in child processes with each one forced, the
-    pipelined one also with chunks shorter than its pipeline (5 planes against 8 steps of fill)."""
+    default where the device holds its block) and k_vort_fused -- and tfl_vorticityConfinementFrom takes the fused route only
+    from 3 M cells per batch item on (below, the two launches: the cases of the test above as they stand). The switches are
+    read once per process: the cases run again in child processes with the fused route forced (TFL_VORT_FUSED=1) onto the small
+    ragged grids, each kernel in turn, also with chunks shorter than the pipeline (5 planes against 9 / 6 steps of fill); there
+    the test also runs the operator under a two-run z-window (the slab step's form of the call)."""
     import subprocess, sys
     e = dict(os.environ)
-    for k in ("TFL_VORT_PIPE", "TFL_VORT_CZ"):
+    for k in ("TFL_VORT_PIPE", "TFL_VORT_CZ", "TFL_VORT_FUSED", "TFL_XCD_ORDER"):
         e.pop(k, None)
     e.update(env)
     out = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
