@@ -134,10 +134,14 @@ int tfl_vorticityConfinement(tfl_ctx* ctx, const tfl_tensor* U, const tfl_tensor
                              float strength, const tfl_tensor* centered, const tfl_tensor* curl,
                              const tfl_tensor* curlNorm, const tfl_tensor* force, int is3D);
 /* The same operator out of place: U = USrc + confinement(USrc), every cell of U (of the z-window) written; U must not alias
- * USrc. On a 3-D grid this is ONE fused launch that keeps curl and |curl| in LDS (vorticity.hip k_vort_fused: 72 -> ~30
- * bytes per cell of HBM traffic), bit-equal to tfl_vorticityConfinement; 2-D grids copy and run the two-launch form, for
- * which curl (3 channels) / curlNorm are the scratch. tfl_simulate_step uses it to fold simulate()'s `U:copy(advected)`
- * and the confinement into one pass. No reference counterpart (the reference op is in place). */
+ * USrc. On a 3-D grid of 3 M cells per batch item or more this is ONE fused z-marched launch that keeps the centred velocities,
+ * curl and |curl| in LDS (vorticity.hip k_vort_pipe, or k_vort_fused where the device cannot hold its block: 72 -> ~30 bytes
+ * per cell of HBM traffic; TFL_VORT_FUSED=1|0 in the environment forces the route), bit-equal to tfl_vorticityConfinement;
+ * smaller and 2-D grids run the two launches reading USrc and writing U (or, misaligned, copy first), for which curl (3
+ * channels) / curlNorm are the scratch -- under a z-window that route needs its curl on a window one plane wider each way,
+ * which tfl_simulate_step_slab arranges with tfl_set_stages; a host of its own should window only the fused route.
+ * tfl_simulate_step uses the entry to fold simulate()'s `U:copy(advected)` and the confinement into one pass. No reference
+ * counterpart (the reference op is in place). */
 int tfl_vorticityConfinementFrom(tfl_ctx* ctx, const tfl_tensor* USrc, const tfl_tensor* U, const tfl_tensor* flags,
                                  float strength, const tfl_tensor* curl, const tfl_tensor* curlNorm, int is3D);
 
