@@ -888,17 +888,19 @@ static int vort_pipe_slots() {
 
 // does the native step (and tfl_vorticityConfinementFrom) route the confinement through a fused kernel? TFL_VORT_FUSED = 1 | 0
 // forces. By measurement (profiles/r05_vort_pipe.txt, us: two launches / k_vort_pipe): 64^3 13 / 18, 96^3 24 / 23, 112^3 32 / 27,
-// 128^3 36 / 29, 160^3 80 / 50, 192^3 147 / 77, 256^3 310 / 165. The operator alone turns at ~1 M cells -- but inside the step
-// the 128^3 gain (-5 us) is given back by the kernels that follow (k_bcs_div_stats +2.5, k_project +1.5 us, measured twice in
-// one session; cause not isolated -- DESIGN.md 3.8). So: from 3 M cells per batch item, where the gain is tens of us
-// (k_vort_fused, where the device cannot hold the pipelined kernel's block, from the same size: 160^3 69 / 80).
+// 128^3 36 / 29, 160^3 80 / 50, 192^3 147 / 77, 256^3 310 / 165. Inside the 128^3 step (with the setConstVals pair folded into
+// either form: 37.5 / 35 us) the step gains 1.5 % on most boxes of the pool and nothing on one whose memory-bound kernels all
+// ran slow that day -- never a loss. So: k_vort_pipe from 2 M cells per batch item on, on arrays at least 64 planes deep (a
+// z-slab rank's 40-plane array marches chunks shorter than the 9-step pipeline: it keeps the two launches below 3 M cells);
+// where the device cannot hold the pipelined kernel's block, k_vort_fused from 3 M cells (160^3: 69 / 80).
 bool vorticity_confinement_fused_ok(bool is3d, int Z, long long cells) {
   static const int mode = getenv("TFL_VORT_FUSED") ? atoi(getenv("TFL_VORT_FUSED")) : -1;
   static const int pipe_mode = getenv("TFL_VORT_PIPE") ? atoi(getenv("TFL_VORT_PIPE")) : -1;
   if (!is3d || Z < 3 || mode == 0) return false;
-  const bool have = (pipe_mode != 0 && vort_pipe_slots() > 0) || vort_fused_slots() > 0;
-  if (mode == 1) return have;
-  return cells >= 3000000ll && have;
+  const bool pipe = pipe_mode != 0 && vort_pipe_slots() > 0;
+  if (mode == 1) return pipe || vort_fused_slots() > 0;
+  if (pipe && cells >= 2000000ll && Z >= 64) return true;
+  return cells >= 3000000ll && (pipe || vort_fused_slots() > 0);
 }
 
 // chunk length of a z-marched launch: rounds of resident blocks x (planes written + pipeline fill)

@@ -271,7 +271,7 @@ def volumetricUpSamplingNearestBackward(ratio, input, gradOutput, gradInput):
 def vorticityConfinement(U, flags, strength, USrc=None):
     """init.lua:394-430 (in place on U).
     USrc (extension): U = USrc + confinement(USrc), every cell of U written (tfl_vorticityConfinementFrom: one fused
-    z-marched launch on 3-D grids from 3 M cells per batch item on, the two launches reading USrc below); U must not alias USrc."""
+    z-marched launch on 3-D grids from 2 M cells per batch item on (arrays 64+ planes deep), the two launches reading USrc below); U must not alias USrc."""
     bsz, d, h, w, is3D = _dims(U, flags)
     _check(isinstance(strength, (int, float)), "strength must be a number")
     C = U.size(1)

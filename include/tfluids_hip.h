@@ -134,7 +134,7 @@ int tfl_vorticityConfinement(tfl_ctx* ctx, const tfl_tensor* U, const tfl_tensor
                              float strength, const tfl_tensor* centered, const tfl_tensor* curl,
                              const tfl_tensor* curlNorm, const tfl_tensor* force, int is3D);
 /* The same operator out of place: U = USrc + confinement(USrc), every cell of U (of the z-window) written; U must not alias
- * USrc. On a 3-D grid of 3 M cells per batch item or more this is ONE fused z-marched launch that keeps the centred velocities,
+ * USrc. On a 3-D grid of 2 M cells per batch item or more (64+ planes deep) this is ONE fused z-marched launch that keeps the centred velocities,
  * curl and |curl| in LDS (vorticity.hip k_vort_pipe, or k_vort_fused where the device cannot hold its block: 72 -> ~30 bytes
  * per cell of HBM traffic; TFL_VORT_FUSED=1|0 in the environment forces the route), bit-equal to tfl_vorticityConfinement;
  * smaller and 2-D grids run the two launches reading USrc and writing U (or, misaligned, copy first), for which curl (3

@@ -575,7 +575,7 @@ def test_fused_vorticity_confinement_equals_the_two_launch_form(oracle, dims, se
 def test_fused_vorticity_kernel_variants(env):
     """The fused confinement has two kernels -- k_vort_pipe (software-pipelined, one barrier per plane step; chosen when the
     default where the device holds its block) and k_vort_fused -- and tfl_vorticityConfinementFrom takes the fused route only
-    from 3 M cells per batch item on (below, the two launches: the cases of the test above as they stand). The switches are
+    from 2 M cells per batch item on (below, the two launches: the cases of the test above as they stand). The switches are
     read once per process: the cases run again in child processes with the fused route forced (TFL_VORT_FUSED=1) onto the small
     ragged grids, each kernel in turn, also with chunks shorter than the pipeline (5 planes against 9 / 6 steps of fill); there
     the test also runs the operator under a two-run z-window (the slab step's form of the call)."""

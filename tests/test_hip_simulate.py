@@ -571,7 +571,7 @@ def test_bc_fold_on_and_off_agree(env):
 
 
 def test_native_step_equals_python_with_the_big_grid_kernels():
-    """The native step picks its kernels by grid size (two-plane advectVel from 6 M cells, the fused confinement from 3 M), and
+    """The native step picks its kernels by grid size (two-plane advectVel from 6 M cells, the fused confinement from 2 M), and
     with a buoyancy fold pending it sends pass B of advectVel through the ONE-plane kernel that carries the fold while pass A
     stays two-plane (advect_vel3.hip, round 5: 256^3). Those switches are read once per process, so the 3-D scenes of
     test_native_simulate_step_equals_python_orchestration run again in a child process with the big-grid variants forced."""
