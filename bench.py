@@ -343,6 +343,51 @@ def other_configs(dev):
     return out
 
 
+def error_line(n_gpus, why):
+    """the ONE JSON line of a run that could not measure: same keys a reader of the metric looks at, value null"""
+    return {"metric": "simulate_mcells_per_s", "value": None, "unit": "Mcells/s", "n_gpus": n_gpus, "error": why,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic"}
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: re-execute this script under torch.distributed.run with N ranks on this
+    node (rendezvous on 127.0.0.1, a free port), pass its output through and return its exit code. nccl (= RCCL, the measured
+    configuration) needs one GPU per rank: with fewer visible GPUs the run is refused with rc 2 and a JSON error line --
+    unless TFL_DIST_BACKEND=gloo asks for the host-staged control-flow check, where ranks share GPUs."""
+    import socket
+    import subprocess
+    backend = os.environ.get("TFL_DIST_BACKEND", "nccl")
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have == 0 or (backend == "nccl" and have < n):
+        print(json.dumps(error_line(n, "--gpus %d over %s needs %d visible GPUs, this node shows %d%s" % (
+            n, backend, n, have, "" if have == 0 else " (TFL_DIST_BACKEND=gloo runs the control-flow check with ranks sharing GPUs)"))))
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL needs on this pool's host driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    last = ""
+    for line in proc.stdout:
+        sys.stdout.write(line)
+        sys.stdout.flush()
+        if line.strip():
+            last = line.strip()
+    rc = proc.wait()
+    measured = False
+    try:
+        measured = "metric" in json.loads(last)
+    except Exception:      # noqa: BLE001
+        pass
+    if rc != 0 and not measured:
+        print(json.dumps(error_line(n, "torch.distributed.run ended with exit code %d before rank 0 printed its line (stderr above)" % rc)))
+    return rc if rc != 0 else (0 if measured else 3)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -356,15 +401,24 @@ def main():
     ap.add_argument("--no-configs", action="store_true", help="skip BASELINE configs 1-3")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` with no launcher around it: become the launcher (one rank per GPU, this node only)
+        raise SystemExit(self_launch(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
+        if rank == 0:
+            print(json.dumps(error_line(args.gpus, "--gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))))
+        raise SystemExit(2)
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
     # TFL_DIST_BACKEND=gloo (+ ranks sharing GPUs) exists only to validate the multi-rank control flow on a box
     # with fewer GPUs than ranks; the measured configuration is one rank per GPU over nccl (= RCCL).
     backend = os.environ.get("TFL_DIST_BACKEND", "nccl")
+    if backend == "nccl" and world > torch.cuda.device_count():
+        if rank == 0:
+            print(json.dumps(error_line(world, "%d ranks over nccl need %d visible GPUs, this node shows %d" % (world, world, torch.cuda.device_count()))))
+        raise SystemExit(2)
     local = local % torch.cuda.device_count() if backend != "nccl" else local
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)

@@ -72,7 +72,7 @@ class tfl_comm(_c.Structure):
     """include/tfluids_hip.h tfl_comm: the transport callbacks of the z-slab step (exchange_start_v: optional, NULL here
     unless a transport sets it -- the Python transports move one staged buffer per neighbour)."""
     _fields_ = [("size", _c.c_int32), ("user", _c.c_void_p), ("exchange_start", COMM_START), ("exchange_wait", COMM_WAIT),
-                ("allreduce_sum", COMM_ALLREDUCE), ("exchange_start_v", COMM_START_V)]
+                ("allreduce_sum", COMM_ALLREDUCE), ("exchange_start_v", COMM_START_V), ("capturable", _c.c_int32)]
 
 
 SIGNATURES = {
@@ -170,8 +170,14 @@ SIGNATURES = {
     "tfl_rccl_comm_wrap": (_c.c_void_p, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int]),
     "tfl_rccl_comm_callbacks": (_c.POINTER(tfl_comm), [_c.c_void_p]),
     "tfl_rccl_comm_destroy": (None, [_c.c_void_p, _c.c_void_p]),
+    "tfl_rccl_comm_set_inline": (_c.c_int, [_c.c_void_p, _c.c_int]),
     "tfl_slab_drain": (_c.c_int, [_c.c_void_p, _c.POINTER(tfl_sim_state), _c.POINTER(tfl_slab), _c.POINTER(tfl_comm),
                                   _c.c_void_p, _c.c_int64]),
+    "tfl_slab_graph_create": (_c.c_void_p, [_c.c_void_p, _c.POINTER(tfl_sim_params), _c.POINTER(tfl_sim_state), _c.POINTER(tfl_slab),
+                                            _c.POINTER(tfl_comm), _c.c_void_p, _c.c_int64]),
+    "tfl_slab_graph_step": (_c.c_int, [_c.c_void_p, _c.c_void_p]),
+    "tfl_slab_graph_nodes": (_c.c_int64, [_c.c_void_p]),
+    "tfl_slab_graph_destroy": (None, [_c.c_void_p, _c.c_void_p]),
 }
 
 _lib = None

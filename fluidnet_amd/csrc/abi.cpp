@@ -896,7 +896,12 @@ int64_t tfl_model_range_flag(tfl_ctx* c, tfl_model* m) {
 
 // A forward pass after one that clamped activations at the fp16 range would build on wrong values where the reference's
 // fp32 cuDNN carries on: refuse it until the host has acknowledged the count (tfl_model_range_errors).
+// The word is written by the device whenever the projection of an earlier pass gets there (no synchronisation), so WHICH later
+// call sees it first depends on how far the host runs ahead: the gate is best-effort in time, but it is taken at ONE defined
+// point per unit of work -- the entry of a forward pass, or the entry of tfl_simulate_step[_slab] (which then marks the
+// context `in_step`, so that the model calls inside the step do not refuse half-way through it).
 static int range_gate(tfl_ctx* c, tfl_model* m, const char* who) {
+  if (c && c->in_step) return TFL_OK;
   if (m && m->h_range && *(volatile unsigned long long*)m->h_range != 0)
     return fail(c, TFL_ERANGE, "%s: an earlier forward pass of this model clamped activations at the fp16 range (|x| > 65504 after the "
                                "std normalisation: a blown-up simulation); its pressure is not the reference's. Read and reset the count with "

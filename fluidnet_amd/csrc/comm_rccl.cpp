@@ -102,6 +102,7 @@ struct tfl_rccl_comm {
   hipEvent_t ready = nullptr;            // "the step's stream has reached this point" (re-recorded per call)
   hipEvent_t done[kTags] = {};           // behind the transfers of exchange_start(tag)
   hipEvent_t reduced = nullptr;
+  bool inline_stream = false;            // tfl_rccl_comm_set_inline: every nccl* call on the context's stream, no events
   tfl_comm callbacks{};
   std::string last_error;
 };
@@ -123,21 +124,33 @@ int hip_fail(tfl_rccl_comm* q, const char* what, hipError_t e) {
 #define GCHK(call, what) do { int rc_ = (call); if (rc_ != kNcclSuccess) { (void)a->GroupEnd(); return fail(q, what, rc_); } } while (0)
 #define HCHK(call, what) do { hipError_t e_ = (call); if (e_ != hipSuccess) return hip_fail(q, what, e_); } while (0)
 
+// the stream the nccl* calls of one callback go to: the communication stream, made to wait for what the step's stream holds so
+// far -- or, inline (tfl_rccl_comm_set_inline), the step's stream itself: an event hop between two streams costs 12-15 us of
+// device-side latency on this stack (tools/ubench/host_costs.hip), eight of them per step, and a thin slab has nothing for
+// the transfer to overlap with
+int comm_stream(tfl_rccl_comm* q, hipStream_t* st) {
+  if (q->inline_stream) { *st = q->ctx->stream; return 0; }
+  HCHK(hipEventRecord(q->ready, q->ctx->stream), "hipEventRecord");
+  HCHK(hipStreamWaitEvent(q->stream, q->ready, 0), "hipStreamWaitEvent");
+  *st = q->stream;
+  return 0;
+}
+
 int cb_exchange_start(void* user, int tag, const float* send_lo, int64_t n_send_lo, float* recv_lo, int64_t n_recv_lo,
                       const float* send_hi, int64_t n_send_hi, float* recv_hi, int64_t n_recv_hi) {
   tfl_rccl_comm* q = (tfl_rccl_comm*)user;
   if (tag < 0 || tag >= kTags) { q->last_error = "tag out of range"; return 1; }
   const RcclApi* a = q->api;
   // the transfer starts behind the packing kernels already queued on the step's stream
-  HCHK(hipEventRecord(q->ready, q->ctx->stream), "hipEventRecord");
-  HCHK(hipStreamWaitEvent(q->stream, q->ready, 0), "hipStreamWaitEvent");
+  hipStream_t st;
+  if (comm_stream(q, &st)) return 1;
   RCHK(a->GroupStart(), "ncclGroupStart");
-  if (n_send_lo > 0 && q->rank > 0) GCHK(a->Send(send_lo, (size_t)n_send_lo, kNcclFloat, q->rank - 1, q->comm, q->stream), "ncclSend(lower)");
-  if (n_recv_lo > 0 && q->rank > 0) GCHK(a->Recv(recv_lo, (size_t)n_recv_lo, kNcclFloat, q->rank - 1, q->comm, q->stream), "ncclRecv(lower)");
-  if (n_send_hi > 0 && q->rank + 1 < q->world) GCHK(a->Send(send_hi, (size_t)n_send_hi, kNcclFloat, q->rank + 1, q->comm, q->stream), "ncclSend(upper)");
-  if (n_recv_hi > 0 && q->rank + 1 < q->world) GCHK(a->Recv(recv_hi, (size_t)n_recv_hi, kNcclFloat, q->rank + 1, q->comm, q->stream), "ncclRecv(upper)");
+  if (n_send_lo > 0 && q->rank > 0) GCHK(a->Send(send_lo, (size_t)n_send_lo, kNcclFloat, q->rank - 1, q->comm, st), "ncclSend(lower)");
+  if (n_recv_lo > 0 && q->rank > 0) GCHK(a->Recv(recv_lo, (size_t)n_recv_lo, kNcclFloat, q->rank - 1, q->comm, st), "ncclRecv(lower)");
+  if (n_send_hi > 0 && q->rank + 1 < q->world) GCHK(a->Send(send_hi, (size_t)n_send_hi, kNcclFloat, q->rank + 1, q->comm, st), "ncclSend(upper)");
+  if (n_recv_hi > 0 && q->rank + 1 < q->world) GCHK(a->Recv(recv_hi, (size_t)n_recv_hi, kNcclFloat, q->rank + 1, q->comm, st), "ncclRecv(upper)");
   RCHK(a->GroupEnd(), "ncclGroupEnd");
-  HCHK(hipEventRecord(q->done[tag], q->stream), "hipEventRecord");
+  if (!q->inline_stream) HCHK(hipEventRecord(q->done[tag], q->stream), "hipEventRecord");
   return 0;
 }
 
@@ -148,28 +161,28 @@ int cb_exchange_start_v(void* user, int tag, int n_lo, const tfl_comm_chunk* sen
   tfl_rccl_comm* q = (tfl_rccl_comm*)user;
   if (tag < 0 || tag >= kTags) { q->last_error = "tag out of range"; return 1; }
   const RcclApi* a = q->api;
-  HCHK(hipEventRecord(q->ready, q->ctx->stream), "hipEventRecord");
-  HCHK(hipStreamWaitEvent(q->stream, q->ready, 0), "hipStreamWaitEvent");
+  hipStream_t st;
+  if (comm_stream(q, &st)) return 1;
   RCHK(a->GroupStart(), "ncclGroupStart");
   if (q->rank > 0)
     for (int i = 0; i < n_lo; i++) {
-      if (send_lo[i].n > 0) GCHK(a->Send(send_lo[i].ptr, (size_t)send_lo[i].n, kNcclFloat, q->rank - 1, q->comm, q->stream), "ncclSend(lower)");
-      if (recv_lo[i].n > 0) GCHK(a->Recv(recv_lo[i].ptr, (size_t)recv_lo[i].n, kNcclFloat, q->rank - 1, q->comm, q->stream), "ncclRecv(lower)");
+      if (send_lo[i].n > 0) GCHK(a->Send(send_lo[i].ptr, (size_t)send_lo[i].n, kNcclFloat, q->rank - 1, q->comm, st), "ncclSend(lower)");
+      if (recv_lo[i].n > 0) GCHK(a->Recv(recv_lo[i].ptr, (size_t)recv_lo[i].n, kNcclFloat, q->rank - 1, q->comm, st), "ncclRecv(lower)");
     }
   if (q->rank + 1 < q->world)
     for (int i = 0; i < n_hi; i++) {
-      if (send_hi[i].n > 0) GCHK(a->Send(send_hi[i].ptr, (size_t)send_hi[i].n, kNcclFloat, q->rank + 1, q->comm, q->stream), "ncclSend(upper)");
-      if (recv_hi[i].n > 0) GCHK(a->Recv(recv_hi[i].ptr, (size_t)recv_hi[i].n, kNcclFloat, q->rank + 1, q->comm, q->stream), "ncclRecv(upper)");
+      if (send_hi[i].n > 0) GCHK(a->Send(send_hi[i].ptr, (size_t)send_hi[i].n, kNcclFloat, q->rank + 1, q->comm, st), "ncclSend(upper)");
+      if (recv_hi[i].n > 0) GCHK(a->Recv(recv_hi[i].ptr, (size_t)recv_hi[i].n, kNcclFloat, q->rank + 1, q->comm, st), "ncclRecv(upper)");
     }
   RCHK(a->GroupEnd(), "ncclGroupEnd");
-  HCHK(hipEventRecord(q->done[tag], q->stream), "hipEventRecord");
+  if (!q->inline_stream) HCHK(hipEventRecord(q->done[tag], q->stream), "hipEventRecord");
   return 0;
 }
 
 int cb_exchange_wait(void* user, int tag) {
   tfl_rccl_comm* q = (tfl_rccl_comm*)user;
   if (tag < 0 || tag >= kTags) { q->last_error = "tag out of range"; return 1; }
-  HCHK(hipStreamWaitEvent(q->ctx->stream, q->done[tag], 0), "hipStreamWaitEvent");
+  if (!q->inline_stream) HCHK(hipStreamWaitEvent(q->ctx->stream, q->done[tag], 0), "hipStreamWaitEvent");
   return 0;
 }
 
@@ -177,11 +190,13 @@ int cb_allreduce_sum(void* user, double* dev, int64_t n) {
   tfl_rccl_comm* q = (tfl_rccl_comm*)user;
   // one stream per communicator: the reduction queues behind the point-to-point groups issued so far, and every rank
   // issues the same sequence (the step is deterministic), which is what RCCL requires of a communicator's callers
-  HCHK(hipEventRecord(q->ready, q->ctx->stream), "hipEventRecord");
-  HCHK(hipStreamWaitEvent(q->stream, q->ready, 0), "hipStreamWaitEvent");
-  RCHK(q->api->AllReduce(dev, dev, (size_t)n, kNcclDouble, kNcclSum, q->comm, q->stream), "ncclAllReduce");
-  HCHK(hipEventRecord(q->reduced, q->stream), "hipEventRecord");
-  HCHK(hipStreamWaitEvent(q->ctx->stream, q->reduced, 0), "hipStreamWaitEvent");
+  hipStream_t st;
+  if (comm_stream(q, &st)) return 1;
+  RCHK(q->api->AllReduce(dev, dev, (size_t)n, kNcclDouble, kNcclSum, q->comm, st), "ncclAllReduce");
+  if (!q->inline_stream) {
+    HCHK(hipEventRecord(q->reduced, q->stream), "hipEventRecord");
+    HCHK(hipStreamWaitEvent(q->ctx->stream, q->reduced, 0), "hipStreamWaitEvent");
+  }
   return 0;
 }
 
@@ -205,6 +220,7 @@ tfl_rccl_comm* make(tfl_ctx* c, const RcclApi* a, NcclComm comm, bool owns, int 
   q->callbacks.allreduce_sum = cb_allreduce_sum;
   // TFL_RCCL_PACKED=1: staged messages (one send + one receive per neighbour, pack / unpack kernels) for comparison
   q->callbacks.exchange_start_v = getenv("TFL_RCCL_PACKED") ? nullptr : cb_exchange_start_v;
+  q->callbacks.capturable = 1;     // every callback above is event record / wait + nccl* calls on streams: a step records into a HIP graph
   return q;
 }
 
@@ -248,6 +264,13 @@ tfl_rccl_comm* tfl_rccl_comm_wrap(tfl_ctx* c, void* nccl_comm, int rank, int wor
 }
 
 const tfl_comm* tfl_rccl_comm_callbacks(tfl_rccl_comm* q) { return q ? &q->callbacks : nullptr; }
+
+int tfl_rccl_comm_set_inline(tfl_rccl_comm* q, int on) {
+  if (!q) return TFL_EINVAL;
+  if (q->stream) (void)hipStreamSynchronize(q->stream);      // nothing of the old mode is left in flight
+  q->inline_stream = on != 0;
+  return TFL_OK;
+}
 
 const char* tfl_rccl_comm_origin(tfl_ctx* c) { return api(c) ? g_api.origin.c_str() : ""; }
 

@@ -91,6 +91,12 @@ bool fold_took(tfl_ctx* c) {
   return d;
 }
 
+struct InStep {              // tfl_ctx::in_step for the length of a step, whatever way it ends
+  tfl_ctx* c;
+  explicit InStep(tfl_ctx* ctx) : c(ctx) { c->in_step = true; }
+  ~InStep() { c->in_step = false; }
+};
+
 struct Sizes { long long N, C; int B, Z, Y, X; bool is3d; };
 Sizes sizes_of(const tfl_sim_state* s) {
   Sizes z;
@@ -183,6 +189,7 @@ int tfl_simulate_step(tfl_ctx* c, const tfl_sim_params* prm, const tfl_sim_state
              "read the count with tfl_model_range_errors, or create the model under TFL_CONV_PATH=winograd (strict fp32)";
     return TFL_ERANGE;
   }
+  InStep in_step(c);      // the gate above is the step's only one: nothing below refuses half-way through
 
   // ---- advection (simulate.lua:183-200): every density channel with the pre-advection U, then U ----------------
   unsigned density_done = 0;
@@ -623,7 +630,7 @@ int tfl_simulate_step_slab(tfl_ctx* c, const tfl_sim_params* prm, const tfl_sim_
   msg_layout(g, m, 4, W.msg);
 
   // ---- reach check of the PREVIOUS step's velocity (no host sync: the word was copied back behind that step) ---------
-  if (sl->check_reach) {
+  if (sl->check_reach && !c->capturing) {       // (a captured step: tfl_slab_graph_step makes both checks before it launches)
     if (c->reach_pending) { (void)hipEventSynchronize(c->reach_ev); c->reach_pending = false; }   // step n-1's reduction has landed
     if (c->h_reach[0] * prm->dt >= (float)g.R) {
       char buf[160];
@@ -636,19 +643,20 @@ int tfl_simulate_step_slab(tfl_ctx* c, const tfl_sim_params* prm, const tfl_sim_
       return TFL_EINVAL;
     }
   }
-  if (s->model && tfl_model_range_flag(c, s->model) > 0) {      // as tfl_simulate_step; the neighbours' receives are finished first
+  if (!c->capturing && s->model && tfl_model_range_flag(c, s->model) > 0) {      // as tfl_simulate_step; the neighbours' receives are finished first
     for (int t = 0; t < 2; t++)
       if (multi && (sl->in_flight & (1 << t))) { (void)msg_finish(c, g, comm, m[t]); sl->in_flight &= ~(1 << t); }
     c->err = "simulate_step_slab: an earlier step's ConvNet projection clamped activations at the fp16 range (a blown-up simulation); "
              "read the count with tfl_model_range_errors, or create the model under TFL_CONV_PATH=winograd (strict fp32)";
     return TFL_ERANGE;
   }
+  InStep in_step(c);      // the range gate above is the step's only one
   if (sl->in_flight & 1) { rc = msg_finish(c, g, comm, m[0]); if (rc) return rc; sl->in_flight &= ~1; }     // U and p halos
   if (sl->check_reach) {
     for (int b = 0; b < g.B; b++)                                                                            // u_z of every batch item
       tfl::absmax(c->stream, (long long)g.Zl * g.yx, s->U->data + (3ll * b + 2) * g.Zl * g.yx, c->d_reach, b == 0);
     (void)hipMemcpyAsync(c->h_reach, c->d_reach, sizeof(float), hipMemcpyDeviceToHost, c->stream);
-    c->reach_pending = hipEventRecord(c->reach_ev, c->stream) == hipSuccess;
+    if (!c->capturing) c->reach_pending = hipEventRecord(c->reach_ev, c->stream) == hipSuccess;   // (captured: recorded behind the graph launch)
   }
   c->dx_dim = std::max(std::max(s->flags->X, s->flags->Y), sl->z_total);   // tfluids.getDx of the WHOLE grid
   (void)tfl_set_z_origin(c, sl->z_first, sl->z_total);
@@ -664,6 +672,9 @@ int tfl_simulate_step_slab(tfl_ctx* c, const tfl_sim_params* prm, const tfl_sim_
   bool rho_done = true, Uadv_done = true;
   auto adv_scalar_b = [&]() { fold_ask(c, s->densityBC[0]); const int r = adv_scalar(); rho_done = fold_took(c) && rho_done; return r; };
   auto adv_vel_b = [&]() { fold_ask(c, s->UBC); const int r = adv_vel(); Uadv_done = fold_took(c) && Uadv_done; return r; };
+  // (Round 6 measured the scalar advection on a second stream beside the velocity's -- they are independent, simulate.lua:183-200
+  // -- and dropped it: an event hop between two streams costs 12-15 us of GPU-side latency on this stack
+  // (tools/ubench/host_costs.hip), more than the overlap of two 8 us kernels returns; profiles/r06_slab_host_cost.txt.)
   if (rho) {
     (void)tfl_set_stages(c, 1); WIN(set_win(c, ext(g, 2 * g.R, 2 * g.R)));
     rc = adv_scalar(); if (rc) return rc;
@@ -798,9 +809,103 @@ int tfl_simulate_step_slab(tfl_ctx* c, const tfl_sim_params* prm, const tfl_sim_
   // the next step's U and p halos leave now; they are consumed at its start / before its first conv layer
   if (multi) {
     rc = msg_start(c, g, comm, m[0]); if (rc) return rc;
-    sl->in_flight |= 1;
+    if (c->capturing) {
+      // a captured step must end with every stream joined: the message is finished here instead of by the next call (nothing
+      // of the next step could have run beside it anyway -- its first kernels read these halos)
+      rc = msg_finish(c, g, comm, m[0]); if (rc) return rc;
+    } else {
+      sl->in_flight |= 1;
+    }
   }
   return TFL_OK;
+}
+
+// ---- the rank-step as ONE host call: a HIP graph of tfl_simulate_step_slab (round 6; include/tfluids_hip.h) -------------
+struct tfl_slab_graph {
+  hipGraphExec_t exec = nullptr;
+  hipStream_t cap = nullptr;          // the stream the step was recorded on (kept: RCCL's captured work refers to it)
+  const tfl_sim_params* prm = nullptr;
+  const tfl_sim_state* s = nullptr;
+  tfl_slab* sl = nullptr;
+  int reach = 1;
+  size_t nodes = 0;
+};
+
+tfl_slab_graph* tfl_slab_graph_create(tfl_ctx* c, const tfl_sim_params* prm, const tfl_sim_state* s, tfl_slab* sl, const tfl_comm* comm,
+                                      float* ws, int64_t ws_floats) {
+  if (!c || !prm || !s || !sl) return nullptr;
+  SlabGeom g;
+  if (slab_geom(c, s, sl, &g) != TFL_OK) return nullptr;
+  const bool multi = g.lower || g.upper;
+  if (multi) {
+    const bool can = comm && comm->size >= (int32_t)(offsetof(tfl_comm, capturable) + sizeof(comm->capturable)) && comm->capturable != 0;
+    if (!can) { c->err = "slab_graph_create: this transport's calls are not stream operations (tfl_comm.capturable = 0): step eagerly"; return nullptr; }
+  }
+  // the U / p message the last eager step left in flight is consumed now: a captured step starts and ends with none
+  if (sl->in_flight && tfl_slab_drain(c, s, sl, comm, ws, ws_floats) != TFL_OK) return nullptr;
+  tfl_slab_graph* G = new tfl_slab_graph();
+  G->prm = prm; G->s = s; G->sl = sl; G->reach = g.R;
+  if (hipStreamCreateWithFlags(&G->cap, hipStreamNonBlocking) != hipSuccess) { c->err = "slab_graph_create: hipStreamCreate failed"; delete G; return nullptr; }
+  hipStream_t user = c->stream;
+  // everything queued so far on the caller's stream happens before the recording stream is used at all (warm-up steps)
+  (void)hipStreamSynchronize(user);
+  if (c->reach_pending) { (void)hipEventSynchronize(c->reach_ev); c->reach_pending = false; }
+  hipGraph_t graph = nullptr;
+  // relaxed: the transport's library may call into the runtime from its own threads while we record
+  if (hipStreamBeginCapture(G->cap, hipStreamCaptureModeRelaxed) != hipSuccess) {
+    c->err = "slab_graph_create: hipStreamBeginCapture failed"; (void)hipStreamDestroy(G->cap); delete G; return nullptr;
+  }
+  c->stream = G->cap; c->capturing = true;
+  const int rc = tfl_simulate_step_slab(c, prm, s, sl, comm, ws, ws_floats);
+  c->capturing = false; c->stream = user;
+  const hipError_t ec = hipStreamEndCapture(G->cap, &graph);
+  std::string why;
+  if (rc != TFL_OK) why = "the step failed while being recorded: " + c->err;
+  else if (ec != hipSuccess || !graph) why = std::string("hipStreamEndCapture: ") + hipGetErrorString(ec);
+  else if (hipGraphInstantiate(&G->exec, graph, nullptr, nullptr, 0) != hipSuccess) why = "hipGraphInstantiate failed";
+  if (graph) { (void)hipGraphGetNodes(graph, nullptr, &G->nodes); (void)hipGraphDestroy(graph); }
+  (void)hipGetLastError();
+  if (!why.empty()) {
+    c->err = "slab_graph_create: " + why;
+    if (G->exec) (void)hipGraphExecDestroy(G->exec);
+    (void)hipStreamDestroy(G->cap);
+    delete G;
+    return nullptr;
+  }
+  return G;
+}
+
+int64_t tfl_slab_graph_nodes(const tfl_slab_graph* G) { return G ? (int64_t)G->nodes : 0; }
+
+int tfl_slab_graph_step(tfl_ctx* c, tfl_slab_graph* G) {
+  if (!c || !G || !G->exec) return TFL_EINVAL;
+  // the two gates of the eager call, read from the words the PREVIOUS step left in pinned memory
+  if (G->sl->check_reach) {
+    if (c->reach_pending) { (void)hipEventSynchronize(c->reach_ev); c->reach_pending = false; }
+    if (c->h_reach[0] * G->prm->dt >= (float)G->reach) {
+      char buf[160];
+      snprintf(buf, sizeof(buf), "simulate_step_slab: max|u_z|*dt = %.3f cells reached the slab's back-trace reach %d", c->h_reach[0] * G->prm->dt, G->reach);
+      c->h_reach[0] = 0.0f;
+      c->err = buf;
+      return TFL_EINVAL;
+    }
+  }
+  if (G->s->model && tfl_model_range_flag(c, G->s->model) > 0) {
+    c->err = "simulate_step_slab: an earlier step's ConvNet projection clamped activations at the fp16 range (a blown-up simulation); "
+             "read the count with tfl_model_range_errors, or create the model under TFL_CONV_PATH=winograd (strict fp32)";
+    return TFL_ERANGE;
+  }
+  if (hipGraphLaunch(G->exec, c->stream) != hipSuccess) { c->err = "slab_graph_step: hipGraphLaunch failed"; (void)hipGetLastError(); return TFL_EHIP; }
+  if (G->sl->check_reach) c->reach_pending = hipEventRecord(c->reach_ev, c->stream) == hipSuccess;
+  return TFL_OK;
+}
+
+void tfl_slab_graph_destroy(tfl_ctx* c, tfl_slab_graph* G) {
+  (void)c;
+  if (!G) return;
+  if (G->exec) (void)hipGraphExecDestroy(G->exec);
+  if (G->cap) (void)hipStreamDestroy(G->cap);
+  delete G;
 }
 
 }  // extern "C"

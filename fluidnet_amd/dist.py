@@ -192,6 +192,10 @@ class RcclComm:
     def bind(self, ws):      # the native callbacks take device pointers as they are
         pass
 
+    def set_inline(self, on):
+        """every nccl* call on the step's own stream (slabs without overlap: tfl_rccl_comm_set_inline)"""
+        self.lib.tfl_rccl_comm_set_inline(self.handle, int(bool(on)))
+
     def close(self):
         if self.handle:
             self.lib.tfl_rccl_comm_destroy(self.ctx, self.handle)
@@ -241,7 +245,11 @@ class SlabSimulation:
     step (tfl_simulate_step_slab). `batch` holds the EXTENDED local tensors (SlabLayout.extract of the global pDiv,
     UDiv, flags, density and BC tensors). With world == 1 the result is exactly simulate_native()'s."""
 
-    def __init__(self, batch, mconf, model, layout, comm=None, check_reach=True, overlap=None, own_context=False):
+    def __init__(self, batch, mconf, model, layout, comm=None, check_reach=True, overlap=None, own_context=False, graph=None):
+        """graph: True = replay the rank-step as ONE HIP-graph launch (tfl_slab_graph_create, recorded after `graph_after`
+        eager steps; raises if it cannot be recorded), False = always step eagerly, None (default) = try when the transport's
+        calls are stream operations (tfl_comm.capturable: the native RCCL transport, or a slab without neighbours) and fall
+        back to the eager step, with the reason in `graph_error`, when recording fails. mconf is frozen by the recording."""
         from .simulate import _native_args
         self.batch, self.mconf, self.model, self.lay, self.comm = batch, mconf, model, layout, comm
         U = batch["UDiv"]
@@ -268,6 +276,12 @@ class SlabSimulation:
         self.ws = torch.zeros(n, dtype=torch.float32, device=U.device)    # persistent: messages live here across steps
         if comm is not None and hasattr(comm, "struct"):
             comm.bind(self.ws)
+        if isinstance(comm, RcclComm):
+            comm.set_inline(not self.slab.overlap)     # a thin slab has nothing for a transfer to overlap with: no stream hops
+        if graph is None:      # auto: only for transports known to be stream operations end to end
+            import os
+            graph = None if (os.environ.get("TFL_SLAB_GRAPH", "1") != "0" and (comm is None or isinstance(comm, RcclComm))) else False
+        self.graph_mode, self.graph_after, self.graph, self.graph_error, self.graph_nodes, self._steps = graph, 2, None, None, 0, 0
 
     def _context(self):
         if self._own_ctx is None:
@@ -283,6 +297,8 @@ class SlabSimulation:
             # the rank's own thread / process (RcclComm)
             self.comm = self.comm(ctx)
             self.comm.bind(self.ws)
+            if isinstance(self.comm, RcclComm):
+                self.comm.set_inline(not self.slab.overlap)
         cptr = ctypes.byref(self.comm.struct) if self.comm is not None else None
         if self.comm is not None:
             self.comm.error = None
@@ -292,7 +308,38 @@ class SlabSimulation:
                 raise self.comm.error
             raise TfluidsError(lib.tfl_last_error(ctx).decode())
 
+    def _record(self):
+        """the rank-step as a HIP graph (include/tfluids_hip.h tfl_slab_graph_create); every rank reaches this at the same step"""
+        lib, ctx = self._context()
+        cptr = ctypes.byref(self.comm.struct) if self.comm is not None else None
+        h = lib.tfl_slab_graph_create(ctx, ctypes.byref(self.prm), ctypes.byref(self.st), ctypes.byref(self.slab), cptr,
+                                      ctypes.c_void_p(self.ws.data_ptr()), self.ws.numel())
+        if h:
+            self.graph, self.graph_nodes = ctypes.c_void_p(h), int(lib.tfl_slab_graph_nodes(ctypes.c_void_p(h)))
+        else:
+            self.graph_error = lib.tfl_last_error(ctx).decode()
+            if self.graph_mode is True:
+                raise TfluidsError(self.graph_error)
+        self.graph_mode = False if not h else self.graph_mode
+
+    def _capturable(self):
+        if self.comm is None or not (self.lay.has_lower or self.lay.has_upper):
+            return True
+        return hasattr(self.comm, "struct") and bool(getattr(self.comm.struct, "capturable", 0))
+
     def step(self):
+        if self.graph is None and self.graph_mode is not False and self._steps >= self.graph_after:
+            if self.graph_mode is True or self._capturable():
+                self._record()
+            else:
+                self.graph_mode, self.graph_error = False, "the transport runs host code per message (tfl_comm.capturable = 0)"
+        self._steps += 1
+        if self.graph is not None:
+            lib, ctx = self._context()
+            rc = lib.tfl_slab_graph_step(ctx, self.graph)
+            if rc != 0:
+                raise TfluidsError(lib.tfl_last_error(ctx).decode())
+            return
         self._call(self.lib.tfl_simulate_step_slab, ctypes.byref(self.prm), ctypes.byref(self.st))
 
     def drain(self):
@@ -301,6 +348,10 @@ class SlabSimulation:
             self._call(self.lib.tfl_slab_drain, ctypes.byref(self.st))
 
     def close(self):
+        if self.graph is not None:
+            lib, ctx = self._context()
+            lib.tfl_slab_graph_destroy(ctx, self.graph)
+            self.graph = None
         if isinstance(self.comm, RcclComm):
             self.comm.close()
         if self._own_ctx is not None:

@@ -205,6 +205,7 @@ typedef struct tfl_comm {
   int (*allreduce_sum)(void* user, double* dev, int64_t n);
   int (*exchange_start_v)(void* user, int tag, int n_lo, const tfl_comm_chunk* send_lo, const tfl_comm_chunk* recv_lo,
                           int n_hi, const tfl_comm_chunk* send_hi, const tfl_comm_chunk* recv_hi);
+  int32_t capturable;
 } tfl_comm;
 int32_t tfl_slab_halo(int32_t reach);
 int64_t tfl_simulate_slab_workspace_floats(tfl_ctx* ctx, const tfl_sim_params* params, const tfl_sim_state* state,
@@ -213,6 +214,12 @@ int tfl_simulate_step_slab(tfl_ctx* ctx, const tfl_sim_params* params, const tfl
                            const tfl_comm* comm, float* workspace, int64_t workspace_floats);
 int tfl_slab_drain(tfl_ctx* ctx, const tfl_sim_state* state, tfl_slab* slab, const tfl_comm* comm, float* workspace,
                    int64_t workspace_floats);
+typedef struct tfl_slab_graph tfl_slab_graph;
+tfl_slab_graph* tfl_slab_graph_create(tfl_ctx* ctx, const tfl_sim_params* params, const tfl_sim_state* state, tfl_slab* slab,
+                                      const tfl_comm* comm, float* workspace, int64_t workspace_floats);
+int tfl_slab_graph_step(tfl_ctx* ctx, tfl_slab_graph* graph);
+int64_t tfl_slab_graph_nodes(const tfl_slab_graph* graph);
+void tfl_slab_graph_destroy(tfl_ctx* ctx, tfl_slab_graph* graph);
 typedef struct tfl_rccl_comm tfl_rccl_comm;
 int tfl_rccl_available(tfl_ctx* ctx);
 const char* tfl_rccl_comm_origin(tfl_ctx* ctx);
@@ -220,6 +227,7 @@ int tfl_rccl_get_unique_id(tfl_ctx* ctx, void* id);
 tfl_rccl_comm* tfl_rccl_comm_create(tfl_ctx* ctx, const void* id, int rank, int world);
 tfl_rccl_comm* tfl_rccl_comm_wrap(tfl_ctx* ctx, void* nccl_comm, int rank, int world);
 const tfl_comm* tfl_rccl_comm_callbacks(tfl_rccl_comm* comm);
+int tfl_rccl_comm_set_inline(tfl_rccl_comm* comm, int on);
 void tfl_rccl_comm_destroy(tfl_ctx* ctx, tfl_rccl_comm* comm);
 ]]
 -- END generated cdef
@@ -535,7 +543,7 @@ end
 function M.install(tfluids, opts)
   opts = opts or {}
   lib = ffi.load(opts.lib or 'tfluids_hip')
-  assert(lib.tfl_abi_version() == 3, 'libtfluids_hip.so / tfluids_hip.lua ABI version mismatch')
+  assert(lib.tfl_abi_version() == 4, 'libtfluids_hip.so / tfluids_hip.lua ABI version mismatch')
   ctx = lib.tfl_create(opts.device or (cutorch.getDevice() - 1))
   assert(ctx ~= nil, 'tfl_create failed')
   if opts.stream then check(lib.tfl_set_stream(ctx, opts.stream)) end

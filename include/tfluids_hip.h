@@ -33,7 +33,8 @@
 extern "C" {
 #endif
 
-#define TFL_ABI_VERSION 3   /* 3: tfl_comm starts with its own size; tfl_set_advect_mode, tfl_stream_copy */
+#define TFL_ABI_VERSION 4   /* 3: tfl_comm starts with its own size; tfl_set_advect_mode, tfl_stream_copy. 4: tfl_comm.capturable,
+                              tfl_slab_graph_* (the rank-step as one HIP-graph launch) */
 
 typedef enum tfl_status {
   TFL_OK = 0,
@@ -493,6 +494,11 @@ typedef struct tfl_comm {
    * exchange_wait(tag); the step never reads them in that window. */
   int (*exchange_start_v)(void* user, int tag, int n_lo, const tfl_comm_chunk* send_lo, const tfl_comm_chunk* recv_lo,
                           int n_hi, const tfl_comm_chunk* send_hi, const tfl_comm_chunk* recv_hi);
+  /* Optional (ABI 4; 0 or absent: no). Non-zero: every callback only ENQUEUES stream operations ordered against the
+   * context's stream (kernels, copies, event record / wait, RCCL calls) and never waits on the host or reads device
+   * results -- so a whole rank-step can be recorded into a HIP graph (tfl_slab_graph_create). The native RCCL transport
+   * sets it; a transport that runs host code per message (the torch.distributed ones of fluidnet_amd/dist.py) must not. */
+  int32_t capturable;
 } tfl_comm;
 
 /* Halo depth a slab must store next to each neighbour for reach R (>= 4). */
@@ -521,6 +527,24 @@ int tfl_simulate_step_slab(tfl_ctx* ctx, const tfl_sim_params* params, const tfl
 int tfl_slab_drain(tfl_ctx* ctx, const tfl_sim_state* state, tfl_slab* slab, const tfl_comm* comm, float* workspace,
                    int64_t workspace_floats);
 
+/* ---- the rank-step as ONE host call (round 6). tfl_simulate_step_slab costs the host a dozen kernel launches plus the
+ * transport's calls per step -- on a 16-plane slab about as long as the GPU needs to run them. tfl_slab_graph_create records
+ * one step (same arguments; they, the tensors they point to and the workspace must stay where they are while the graph lives)
+ * on a stream of its own into an executable HIP graph: kernels, the transport's sends / receives / all-reduce and the
+ * stream forks between them. tfl_slab_graph_step replays it on the context's stream: it makes the two host-side checks of the
+ * eager call first (the reach word and the fp16 range word the previous step left in pinned memory; same error codes), then
+ * ONE hipGraphLaunch. Differences from the eager step: the U / p message is started AND finished inside the step (no message
+ * in flight between calls: slab->in_flight stays 0, tfl_slab_drain is a no-op), and the scalar parameters are frozen.
+ * Needs tfl_comm.capturable (or a slab without neighbours); call it after at least one eager tfl_simulate_step_slab on
+ * the same arguments (allocations, RCCL's connection set-up). NULL + tfl_last_error when the step cannot be recorded --
+ * the caller keeps stepping eagerly. Results are those of the eager step bit for bit. */
+typedef struct tfl_slab_graph tfl_slab_graph;
+tfl_slab_graph* tfl_slab_graph_create(tfl_ctx* ctx, const tfl_sim_params* params, const tfl_sim_state* state, tfl_slab* slab,
+                                      const tfl_comm* comm, float* workspace, int64_t workspace_floats);
+int tfl_slab_graph_step(tfl_ctx* ctx, tfl_slab_graph* graph);
+int64_t tfl_slab_graph_nodes(const tfl_slab_graph* graph);   /* nodes of the recorded graph (kernels, copies, events) */
+void tfl_slab_graph_destroy(tfl_ctx* ctx, tfl_slab_graph* graph);
+
 /* ---- native transport for the z-slab step: RCCL send/recv over xGMI inside the library (csrc/comm_rccl.cpp) ------------
  * For hosts without a communication layer of their own (the LuaJIT loop, plain C): one process per GPU, ranks ordered
  * along z (rank r's upper neighbour is r+1). Rank 0 obtains a unique id and hands the 128 bytes to the other ranks by
@@ -542,6 +566,12 @@ tfl_rccl_comm* tfl_rccl_comm_create(tfl_ctx* ctx, const void* id, int rank, int 
 /* The same around a communicator the host already has (an ncclComm_t); it is not destroyed by tfl_rccl_comm_destroy. */
 tfl_rccl_comm* tfl_rccl_comm_wrap(tfl_ctx* ctx, void* nccl_comm, int rank, int world);
 const tfl_comm* tfl_rccl_comm_callbacks(tfl_rccl_comm* comm);
+/* 1: issue every send / receive / all-reduce on the CONTEXT's stream instead of the communication stream (no events between the
+ * two). For slabs run with tfl_slab.overlap = 0 -- nothing there for a transfer to overlap with, and an event hop between
+ * two streams costs 12-15 us of device-side latency on this stack, eight of them per eager step. 0 (default): the
+ * communication stream. Call between steps with no message in flight (after tfl_slab_drain). A recorded step
+ * (tfl_slab_graph_create) does not care: inside a graph the hops are dependencies, not events. */
+int tfl_rccl_comm_set_inline(tfl_rccl_comm* comm, int on);
 void tfl_rccl_comm_destroy(tfl_ctx* ctx, tfl_rccl_comm* comm);
 
 #ifdef __cplusplus

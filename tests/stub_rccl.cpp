@@ -6,7 +6,14 @@
 // was issued, nothing blocks on the device from the host. Point-to-point ops are matched FIFO per (source, destination)
 // at ncclGroupEnd; the all-reduce goes through the host (it moves 2*B doubles).
 // Built by tests with: hipcc -shared -fPIC -o libstub_rccl.so stub_rccl.cpp ; selected with TFL_RCCL_LIBRARY.
+//
+// STUB_RCCL_NULL=1 (round 6, tools/slab_host_cost.py): ONE rank of an N-rank world with neighbours that are not there -- a send
+// is dropped, a receive is a zero-fill of its buffer on the stream, the all-reduce adds what the other ranks would have
+// contributed (1e5 to every sum of squares). Pure stream operations, so the rank-step -- the library's native transport
+// included -- can be timed and recorded into a HIP graph on one GPU; the results are wrong by construction.
 #include <hip/hip_runtime.h>
+
+#include <cstdlib>
 
 #include <condition_variable>
 #include <cstring>
@@ -37,6 +44,24 @@ thread_local int t_depth = 0;
 thread_local std::vector<Op> t_ops;
 
 size_t dtype_bytes(int dt) { return dt == 8 ? 8 : 4; }
+
+bool null_mode() { static const bool on = getenv("STUB_RCCL_NULL") && atoi(getenv("STUB_RCCL_NULL")) != 0; return on; }
+__global__ void k_null_allreduce(double* x, size_t n) { const size_t i = 2 * (size_t)threadIdx.x + 1; if (i < n) x[i] += 1.0e5; }
+// RCCL runs all the sends / receives of a group as ONE kernel: the null mode's stand-in is one zero-fill kernel over the
+// group's receive buffers (the sends are dropped)
+struct NullGroup { float* p[32]; unsigned n4[32]; int count; };
+__global__ void k_null_group(NullGroup g) {
+  float4* q = (float4*)g.p[blockIdx.y];
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < g.n4[blockIdx.y]; i += gridDim.x * blockDim.x) q[i] = float4{0.f, 0.f, 0.f, 0.f};
+}
+thread_local NullGroup t_null = {{}, {}, 0};
+thread_local hipStream_t t_null_st = nullptr;
+int null_flush() {
+  if (t_null.count == 0) return 0;
+  hipLaunchKernelGGL(k_null_group, dim3(32, t_null.count), dim3(256), 0, t_null_st, t_null);
+  t_null.count = 0;
+  return hipGetLastError() == hipSuccess ? 0 : 1;
+}
 
 int flush() {
   // 1. publish the sends
@@ -100,7 +125,7 @@ int ncclCommInitRank(void** comm, int nranks, IdByValue id, int rank) {
     if (it == g_worlds.end()) { w = new World(); w->nranks = nranks; w->red.resize(nranks); g_worlds[key] = w; }
     else w = it->second;
   }
-  {
+  if (!null_mode()) {
     std::unique_lock<std::mutex> l(w->m);
     w->joined++;
     w->cv.notify_all();
@@ -112,19 +137,31 @@ int ncclCommInitRank(void** comm, int nranks, IdByValue id, int rank) {
 
 int ncclCommDestroy(void* comm) { delete (Comm*)comm; return 0; }
 int ncclGroupStart() { t_depth++; return 0; }
-int ncclGroupEnd() { if (--t_depth == 0) return flush(); return 0; }
+int ncclGroupEnd() { if (--t_depth == 0) return null_mode() ? null_flush() : flush(); return 0; }
 
 int ncclSend(const void* buf, size_t count, int dt, int peer, void* comm, hipStream_t st) {
+  if (null_mode()) return 0;
   t_ops.push_back(Op{true, buf, nullptr, count * dtype_bytes(dt), peer, (Comm*)comm, st, nullptr});
   return t_depth == 0 ? flush() : 0;
 }
 int ncclRecv(void* buf, size_t count, int dt, int peer, void* comm, hipStream_t st) {
+  if (null_mode()) {
+    const size_t bytes = count * dtype_bytes(dt);
+    if (t_null.count >= 32 || (bytes & 15) || ((size_t)buf & 15) || bytes >= (1ull << 34)) return 3;
+    t_null.p[t_null.count] = (float*)buf; t_null.n4[t_null.count] = (unsigned)(bytes / 16); t_null.count++; t_null_st = st;
+    return t_depth == 0 ? null_flush() : 0;
+  }
   t_ops.push_back(Op{false, nullptr, buf, count * dtype_bytes(dt), peer, (Comm*)comm, st, nullptr});
   return t_depth == 0 ? flush() : 0;
 }
 
 int ncclAllReduce(const void* sbuf, void* rbuf, size_t count, int dt, int op, void* comm, hipStream_t st) {
   if (dt != 8 || op != 0) return 3;
+  if (null_mode()) {
+    if (sbuf != rbuf || count > 2048) return 3;
+    hipLaunchKernelGGL(k_null_allreduce, dim3(1), dim3(1024), 0, st, (double*)rbuf, count);
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+  }
   Comm* c = (Comm*)comm; World* w = c->w;
   std::vector<double> mine(count);
   if (hipMemcpyAsync(mine.data(), sbuf, count * 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return 1;

@@ -41,7 +41,7 @@ def test_binding_covers_header(lib_path):
     from fluidnet_amd import _lib
     assert sorted(_lib.SIGNATURES) == _declared()
     lib = _lib.load()
-    assert lib.tfl_abi_version() == 3
+    assert lib.tfl_abi_version() == 4
 
 
 def test_library_has_gfx950_code_object(lib_path):

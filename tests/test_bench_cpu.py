@@ -38,3 +38,47 @@ def test_pmc_traffic_json_carries_source_hashes():
         if k.startswith("_"):
             continue
         assert v > 0 and k in meta["source_sha"], k
+
+
+def test_bench_gpus_n_without_a_launcher_refuses_cleanly_without_gpus():
+    """`python bench.py --gpus 2` started with no launcher around it becomes its own launcher; on a box
+    without enough GPUs it must end with rc != 0 AND one JSON error line, not a traceback."""
+    import sys
+    import torch
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        import pytest
+        pytest.skip("this box could really run it")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "TFL_DIST_BACKEND")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0
+    line = json.loads(p.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["value"] is None and "GPUs" in line["error"]
+
+
+def test_bench_refuses_a_launcher_with_the_wrong_world_size():
+    import sys
+    env = dict(os.environ, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0
+    line = json.loads(p.stdout.strip().splitlines()[-1])
+    assert line["value"] is None and "WORLD_SIZE=3" in line["error"]
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_bench_gpus_2_launches_itself_over_gloo_on_one_gpu():
+    """`python bench.py --gpus 2` with NO launcher spawns its own two ranks; under TFL_DIST_BACKEND=gloo
+    they share this box's GPU (host-staged messages: the control-flow check) and rank 0 prints ONE line with n_gpus = 2."""
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["TFL_DIST_BACKEND"] = "gloo"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--preroll", "2",
+                        "--blocks", "1", "--res", "64", "--no-config5", "--no-configs"], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["value"] > 0 and "gloo" in line["config"]["decomposition"]

@@ -597,7 +597,7 @@ def test_round4_abi_additions(hip):
     from fluidnet_amd import _lib, tfluids, TfluidsError
     dev = hip.dev
     lib, ctx = tfluids._context(torch.zeros(1, device=dev))
-    assert lib.tfl_abi_version() == 3
+    assert lib.tfl_abi_version() == 4
     assert lib.tfl_get_advect_mode(ctx) == 0
     assert lib.tfl_set_advect_mode(ctx, 7) != 0 and b"unknown mode" in lib.tfl_last_error(ctx)
     assert lib.tfl_set_advect_mode(ctx, 1) == 0 and lib.tfl_get_advect_mode(ctx) == 1

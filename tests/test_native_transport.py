@@ -32,6 +32,17 @@ def test_native_transport_between_virtual_ranks(stub_so, world, overlap):
 
 
 @pytest.mark.gpu
+def test_rank_step_graph_equals_eager_step(stub_so):
+    """the rank-step recorded into a HIP graph with the transport's sends / receives / all-reduce inside
+    (tfl_slab_graph_create) replays to the same bits as the eager step -- middle and end rank of a 4-rank layout, with and
+    without the boundary-strip / interior split, through the native transport over the stub in STUB_RCCL_NULL mode."""
+    env = dict(os.environ, TFL_RCCL_LIBRARY=stub_so, STUB_RCCL_NULL="1")
+    r = subprocess.run([sys.executable, os.path.join(HERE, "slab_graph_run.py")], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "slab graph ok" in r.stdout
+
+
+@pytest.mark.gpu
 def test_real_rccl_world_of_one():
     """Binds the real RCCL (the copy PyTorch already loaded, else librccl.so.1), creates a communicator of one rank and
     drives the three callbacks the slab step uses: an empty neighbour exchange and a 4-double all-reduce."""
@@ -59,5 +70,6 @@ def test_real_rccl_world_of_one():
 def test_transport_symbols_are_exported():
     lib = ctypes.CDLL(os.path.join(ROOT, "fluidnet_amd", "libtfluids_hip.so"))
     for n in ("tfl_rccl_available", "tfl_rccl_comm_origin", "tfl_rccl_get_unique_id", "tfl_rccl_comm_create",
-              "tfl_rccl_comm_wrap", "tfl_rccl_comm_callbacks", "tfl_rccl_comm_destroy"):
+              "tfl_rccl_comm_wrap", "tfl_rccl_comm_callbacks", "tfl_rccl_comm_destroy", "tfl_rccl_comm_set_inline", "tfl_slab_graph_create",
+              "tfl_slab_graph_step", "tfl_slab_graph_nodes", "tfl_slab_graph_destroy"):
         assert hasattr(lib, n), n

@@ -1,6 +1,11 @@
-"""Host cost of one z-slab rank-step: rank 0 of a W-rank layout with a transport that does NOTHING (results are wrong,
-the enqueue path is the real one). With a 16-plane slab the GPU work is ~0.07 ms, so wall time per step ~ host time of
-the native step + its four transport callbacks (without the transport's own cost). usage: slab_host_cost.py [res] [world]"""
+"""Cost of one z-slab rank-step on ONE GPU: rank r of a W-rank layout whose neighbours are not there (results are wrong, the
+enqueue path and the kernels are the real ones). Round 6: the transport is the library's own (csrc/comm_rccl.cpp) over
+tests/stub_rccl.cpp in STUB_RCCL_NULL mode -- a send is dropped, a receive is a zero-fill on the stream, the all-reduce adds
+the other ranks' share -- so the host path is the one a real run takes (event record / wait, group calls) minus RCCL's own
+enqueue cost, and the step can be recorded into a HIP graph (tfl_slab_graph_create): both the eager and the replayed step are
+timed. --python-null = the round-5 transport (Python callbacks, in-place chunks; --packed = staged buffers): its callbacks
+cost the host ~50 us per step that no native host pays.
+usage: slab_host_cost.py [res] [world] [--still] [--kernels] [--python-null [--packed]] [--no-graph]"""
 import os
 import sys
 import time
@@ -60,49 +65,83 @@ res = int(_pos[0]) if len(_pos) > 0 else 128
 world = int(_pos[1]) if len(_pos) > 1 else 8
 dev = torch.device("cuda:0")
 model = FluidNetModel.default_3d(seed=1)
-for rank in (0, world // 2):
+python_null = "--python-null" in sys.argv
+if not python_null:
+    import subprocess
+    import tempfile
+    so = os.path.join(tempfile.mkdtemp(prefix="stub_rccl_"), "libstub_rccl.so")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-shared", "-fPIC", "-O2", "-o", so, os.path.join(ROOT, "tests", "stub_rccl.cpp")])
+    os.environ["TFL_RCCL_LIBRARY"], os.environ["STUB_RCCL_NULL"] = so, "1"
+    from fluidnet_amd import tfluids  # noqa: E402
+    from fluidnet_amd.dist import RcclComm  # noqa: E402
+
+
+def run(rank, graph):
     lay = SlabLayout(res, world, rank)
     batch, mconf = bench.build_scene(res, res, lay, dev)
     mconf = dict(mconf, buoyancyScale=0.0)          # keep the (wrong) state tame: nothing rises into the missing halos
-    if "--still" in sys.argv:
+    still = "--still" in sys.argv
+    if still:
         # dt = 0: nothing moves, so the halos the null transport never refreshes stay what the neighbours would have sent
         # (except p, which only feeds the conv stack) and every kernel runs on the data it would see in a real run.
         # Without it the in-place exchange leaves stale velocities in the halos and the advection kernels take their
         # slow paths there, which is an artefact of the null transport, not of the step.
         mconf = dict(mconf, dt=0.0)
-    sim = SlabSimulation(batch, mconf, model, lay, NullComm("--packed" not in sys.argv), check_reach=False)
+    if python_null:
+        comm = NullComm("--packed" not in sys.argv)
+    else:
+        lib, ctx = tfluids._context(batch["UDiv"])
+        comm = RcclComm(ctx, RcclComm.unique_id(ctx), rank, world)
+    sim = SlabSimulation(batch, mconf, model, lay, comm, check_reach=False, graph=graph)
     # --still also zeroes p before every step: with the null transport the net would otherwise iterate on its own output
     # (stale p halos), leave the fp16 range within a few steps, and every block of the first conv layer would report a
-    # range error through one atomic counter -- 20 us of serialised atomics that no real run has
-    still = "--still" in sys.argv
-    # ... and (round 5) puts U and the density back to the initial state: the confinement force is added every step whatever dt
-    # is, and with a projection that iterates on undelivered halos nothing removes it again -- the run blew up within the
-    # warm-up (the 12 M range errors of profiles/r04_slab_host_cost.txt; since round 5 a refused step, TFL_ERANGE). The three
-    # small copies are torch's, outside the library's kernel profile; they are inside the wall-clock figure.
+    # range error through one atomic counter -- 20 us of serialised atomics that no real run has -- and puts U and the
+    # density back to the initial state (the confinement force is added every step whatever dt is, and with a projection that
+    # iterates on undelivered halos nothing removes it again). The three small copies run as ONE captured torch graph so that
+    # their host cost (3 x ~6 us of dispatch) stays out of the enqueue figure; their GPU time (~6 us) is inside the drained one.
     saved = {k: batch[k].clone() for k in ("UDiv", "density")}
-
-    def one_step():
-        if still:
+    restore = None
+    if still:
+        restore = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(restore):
             batch["pDiv"].zero_()
             for k, v in saved.items():
                 batch[k].copy_(v)
-        sim.step()
 
-    for _ in range(5):
+    host = [0.0]
+
+    def one_step():
+        if restore is not None:
+            restore.replay()
+        t = time.perf_counter()
+        sim.step()
+        host[0] += time.perf_counter() - t      # the library's call alone (the restore graph's replay is the tool's, not the step's)
+
+    for _ in range(6):
         one_step()
     torch.cuda.synchronize()
-    for n in (50,):
-        t0 = time.time()
-        for _ in range(n):
-            one_step()
-        t_host = (time.time() - t0) / n
+    # what the tool's own restore graph costs the GPU per step (three small copies), to be taken off the drained figure
+    t_restore = 0.0
+    if restore is not None:
+        t0 = time.perf_counter()
+        for _ in range(100):
+            restore.replay()
         torch.cuda.synchronize()
-        t_all = (time.time() - t0) / n
-    print("res %d, rank %d of %d (%d planes): enqueue %.3f ms per step, with GPU drain %.3f ms per step"
-          % (res, rank, world, lay.hi - lay.lo, t_host * 1e3, t_all * 1e3))
-    if rank == world // 2 and "--kernels" in sys.argv:
-        from fluidnet_amd import tfluids
-        with tfluids.profile(batch["UDiv"]) as prof:
+        t_restore = (time.perf_counter() - t0) / 100
+    n = 200
+    host[0] = 0.0
+    t0 = time.perf_counter()
+    for _ in range(n):
+        one_step()
+    t_host = host[0] / n
+    torch.cuda.synchronize()
+    t_all = (time.perf_counter() - t0) / n - t_restore
+    how = ("HIP graph, %d nodes" % sim.graph_nodes) if sim.graph is not None else ("eager" + (" (graph refused: %s)" % sim.graph_error if sim.graph_error else ""))
+    print("res %d, rank %d of %d (%d planes), %s: host %.3f ms per step() call, rank-step %.3f ms (wall per step with the GPU drained, minus %.3f ms of the tool's restore copies)"
+          % (res, rank, world, lay.hi - lay.lo, how, t_host * 1e3, t_all * 1e3, t_restore * 1e3))
+    if rank == world // 2 and "--kernels" in sys.argv and sim.graph is None:
+        from fluidnet_amd import tfluids as T
+        with T.profile(batch["UDiv"]) as prof:
             for _ in range(10):
                 one_step()
         print("   fp16 range errors reported by the conv stack: %d" % model.range_errors(batch["pDiv"]))
@@ -110,5 +149,10 @@ for rank in (0, world // 2):
         for name, rec in sorted(prof.kernels.items(), key=lambda kv: -kv[1]["ms"]):
             print("   %-26s %5.1f launches/step  %7.1f us/step  (%.1f us each)" % (name, rec["calls"] / 10, rec["ms"] * 100, rec["ms"] / rec["calls"] * 1e3))
             tot += rec["ms"] * 100; cnt += rec["calls"] / 10
-        print("   sum %.1f us/step over %.0f launches" % (tot, cnt))
+        print("   sum %.1f us/step over %.0f launches (the scalar and the velocity advection run on two streams: their times overlap)" % (tot, cnt))
     sim.close()
+
+
+for rank in (0, world // 2):
+    for graph in ((False,) if (python_null or "--no-graph" in sys.argv) else (False, True)):
+        run(rank, graph)
