@@ -50,6 +50,7 @@ struct tfl_model {
   bool mfma2d = false;
   float* bfrag2[4] = {nullptr, nullptr, nullptr, nullptr};
   double* d_stats = nullptr;  // [2 * kMaxBatch]: sum(u), sum(u^2) per sample
+  long long stat_pairs_per_plane = 0;   // partial pairs per z-plane the last tfl_model_begin wrote (model.hip model_pre's layout)
   unsigned* d_ticket = nullptr;   // model.hip publish_and_maybe_reduce: blocks of the current k_bcs_div_stats launch that have published
   // forward-graph switches (tfl_model_opts); `custom` = any of them differs from default_conf.lua -> generic kernels only
   tfl_model_opts opts = {1, 0, 1, 1, TFL_NORM_UDIV, TFL_NORMFUNC_STD, TFL_NONLIN_RELU, 0};
@@ -960,7 +961,9 @@ int tfl_model_begin(tfl_ctx* c, tfl_model* m, const tfl_tensor* UDiv, const tfl_
   // neighbour values are re-derived from the flags, so a neighbour already holding the BC-applied
   // value gives the identical result (the BC is idempotent).
   WindowScope win(c);
-  const int stg = stages_of(c);   // tfl_set_stages: 2 = wall BCs + divergence + partial sums, 4 = reduce [zlo, zhi)
+  int stg = stages_of(c);   // tfl_set_stages: 2 = wall BCs + divergence + partial sums, 4 = reduce [zlo, zhi)
+  if (c->defer_stats) stg &= ~4;  // tfl_model_forward: the first conv layer reduces the partials itself (round 6)
+  m->stat_pairs_per_plane = tfl::model_stat_pairs_per_plane(flags->B, flags->Z, flags->Y, flags->X, UDiv->data, flags->data, UOut->data, w.div);
   tfl::model_pre(c->stream, m->is3d, flags->B, flags->Z, flags->Y, flags->X, UDiv->data, flags->data, UOut->data,
                  w.div, w.partials, stats ? stats : m->d_stats, zlo, zhi, ((stg & 2) ? 1 : 0) | ((stg & 4) ? 2 : 0), m->d_ticket);
   return check_launch(c, "model_begin");
@@ -1016,9 +1019,14 @@ int tfl_model_finish(tfl_ctx* c, tfl_model* m, const tfl_tensor* pDiv, const tfl
                          tfl::conv3_m16_first2_fused(st, B, Z, Y, X, pDiv->data, w.div, flags->data, st_in, count, m->wfrag16[0],
                                                      m->layers[0].b, m->post16[0], m->wfrag16[1], m->layers[1].b, m->post16[1],
                                                      w.act[1], m->d_range_err);
-    if ((stg & 1) && !fused12)
-      tfl::conv3_m16_first_fused(st, B, Z, Y, X, pDiv->data, w.div, flags->data, st_in, count, m->wfrag16[0], m->layers[0].b,
-                                 m->post16[0], w.act[0], m->d_range_err);
+    if ((stg & 1) && !fused12) {
+      if (c->defer_stats)      // (tfl_model_forward only: whole array, the model's own stats buffer)
+        tfl::conv3_m16_first_fused(st, B, Z, Y, X, pDiv->data, w.div, flags->data, st_in, count, m->wfrag16[0], m->layers[0].b,
+                                   m->post16[0], w.act[0], m->d_range_err, w.partials, m->stat_pairs_per_plane * Z, m->d_stats);
+      else
+        tfl::conv3_m16_first_fused(st, B, Z, Y, X, pDiv->data, w.div, flags->data, st_in, count, m->wfrag16[0], m->layers[0].b,
+                                   m->post16[0], w.act[0], m->d_range_err);
+    }
     if ((stg & 2) && !fused12)
       tfl::conv3_m16_mid(st, B, Z, Y, X, w.act[0], m->wfrag16[1], m->layers[1].b, m->post16[1], w.act[1], m->d_range_err);
     if (stg & 4)
@@ -1100,6 +1108,11 @@ int tfl_model_forward(tfl_ctx* c, tfl_model* m, const tfl_tensor* pDiv, const tf
   TRY(check_flags(c, "model_forward", flags));
   if (c->stages || c->zwin.a1 > c->zwin.a0 || c->zwin.b1 > c->zwin.b0)
     return fail(c, TFL_EINVAL, "model_forward: clear the z-window / stage mask first (use tfl_model_begin / _finish)");
+  // round 6: with the default 3-D conv path the first layer's blocks sum k_bcs_div_stats' partial pairs themselves (the same
+  // order, the same bits) -- no k_reduce_stats launch between the two kernels (4.3 us of pure latency at 128^3)
+  struct Defer { tfl_ctx* c; ~Defer() { c->defer_stats = false; } } defer{c};
+  c->defer_stats = m && m->mfma3d && m->m16 && !m->custom && tfl::conv3_m16_first_sums_partials() &&
+                   !(getenv("TFL_M16_FUSE12") && atoi(getenv("TFL_M16_FUSE12")) == 1) && !(getenv("TFL_STATS_FOLD") && atoi(getenv("TFL_STATS_FOLD")) == 1);
   TRY(tfl_model_begin(c, m, UDiv, flags, UOut, workspace, workspace_floats, 0, flags->Z, nullptr));
   const double count = (double)flags->Z * flags->Y * flags->X * (m->is3d ? 3 : 2);
   return tfl_model_finish(c, m, pDiv, flags, pOut, UOut, workspace, workspace_floats, nullptr, count, UBC, UBCInvMask,

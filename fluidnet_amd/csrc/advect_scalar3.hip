@@ -167,8 +167,9 @@ __device__ __forceinline__ bool trace_fast(const float* __restrict__ mt, int LX,
     p.x = nz ? ctr.x + dx : ctr.x; p.y = nz ? ctr.y + dy : ctr.y; p.z = nz ? ctr.z + dz : ctr.z;
     shortd = l2 <= kFastLen * kFastLen;
   } else {
-    const float len = nz ? sqrt_exact(l2) : 0.0f;
-    const float r = nz ? rcp_refined(len) : 0.0f;                 // len == 0: direction 0, p = ctr (the reference returns pos)
+    float len_, r_;
+    sqrt_rcp_exact(l2, len_, r_);          // ONE transcendental (v_rsq) for the root and the reciprocal (tfl_fastmath.hpp; bit-equal, profiles/r03_exact_math.txt)
+    const float len = nz ? len_ : 0.0f, r = nz ? r_ : 0.0f;                 // len == 0: direction 0, p = ctr (the reference returns pos)
     const float qx = div_by<1>(dx, len, r), qy = div_by<1>(dy, len, r), qz = div_by<1>(dz, len, r);
     p.x = ctr.x + qx * len;                                       // next = pos + dt * step, step = min(length, 1) = length
     p.y = ctr.y + qy * len;
@@ -533,8 +534,9 @@ __device__ __forceinline__ bool trace_ring(const float* __restrict__ ring, int c
     p.x = nz ? ctr.x + dx : ctr.x; p.y = nz ? ctr.y + dy : ctr.y; p.z = nz ? ctr.z + dz : ctr.z;
     shortd = l2 <= kFastLen * kFastLen;
   } else {
-    const float len = nz ? sqrt_exact(l2) : 0.0f;
-    const float r = nz ? rcp_refined(len) : 0.0f;
+    float len_, r_;
+    sqrt_rcp_exact(l2, len_, r_);          // ONE transcendental (v_rsq) for the root and the reciprocal (tfl_fastmath.hpp; bit-equal, profiles/r03_exact_math.txt)
+    const float len = nz ? len_ : 0.0f, r = nz ? r_ : 0.0f;
     const float qx = div_by<1>(dx, len, r), qy = div_by<1>(dy, len, r), qz = div_by<1>(dz, len, r);
     p.x = ctr.x + qx * len;
     p.y = ctr.y + qy * len;

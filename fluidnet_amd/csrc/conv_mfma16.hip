@@ -84,6 +84,12 @@ struct MIn {            // fused network input (first layer): {pDiv/scale, div/s
   const float* flags;
   const double* stats;  // [B][2] = sum u, sum u^2 (model.hip)
   double count;
+  // round 6 (k_conv3_m16p_in only): non-null = the per-block partial pairs of k_bcs_div_stats, `per_sample` of them per batch
+  // item -- every block sums its item's pairs itself, in k_reduce_stats' order (block_sum_pairs: the same bits), and the launch
+  // of k_reduce_stats between the two kernels is gone; block 0 of each item leaves the sums in stats_out for k_project
+  const double* partials;
+  long long per_sample;
+  double* stats_out;
 };
 
 // a -> (fp16(a), fp16((a - fp16(a)) * 2^11)); |a| <= 65504
@@ -1130,7 +1136,14 @@ __global__ __launch_bounds__(256, TFL_M16PI_LB) void k_conv3_m16p_in(Dom d, int 
   for (int f = 0; f < kIFrags; f++) W[f] = __builtin_bit_cast(h8, wfrag[f * 64 + lane]);
 
   // lib/modules/variance.lua:44-76 (n-1) + Sqrt, as model.hip scale_from_stats
-  const double s1 = cin.stats[b * 2], s2 = cin.stats[b * 2 + 1], n = cin.count;
+  double s1, s2;
+  if (cin.partials) {     // (uniform) the block's own reduction of the partial sums; the ring is not in use yet
+    block_sum_pairs(cin.partials + (long long)b * cin.per_sample * 2, cin.per_sample, reinterpret_cast<double*>(lds), tid, s1, s2);
+    if (tid == 0 && cx == 0 && cy == 0 && ch == 0) { cin.stats_out[b * 2] = s1; cin.stats_out[b * 2 + 1] = s2; }
+  } else {
+    s1 = cin.stats[b * 2]; s2 = cin.stats[b * 2 + 1];
+  }
+  const double n = cin.count;
   const float in_scale = (float)sqrt(fmax(n * s2 - s1 * s1, 0.0) / (n * (n - 1.0)));
   const bool scale_in_range = in_scale >= 0x1p-12f && in_scale <= 0x1p21f;     // wave-uniform
   const float inv_scale = scale_in_range ? rcp_refined(in_scale) : 0.0f;
@@ -1742,10 +1755,16 @@ static void launch_m16(hipStream_t st, const Dom& d, int B, const void* in, cons
                  bias, out, post, cin, range_err);
 }
 
+bool conv3_m16_first_sums_partials() {
+  static const bool kpack = !(getenv("TFL_M16_KPACK") && (atoi(getenv("TFL_M16_KPACK")) == 0 || atoi(getenv("TFL_M16_KPACK")) == 2));
+  const char* e = getenv("TFL_STATS_CONSUMER");     // A/B switch (read per call: the parity test flips it inside one process): 0 = k_reduce_stats as its own launch
+  const bool off = e && atoi(e) == 0;
+  return kpack && !off;
+}
 void conv3_m16_first_fused(hipStream_t st, int B, int Z, int Y, int X, const float* pDiv, const float* div, const float* flags,
                            const double* stats, double count, const void* wfrag, const float* bias, float post, void* out_h2,
-                           unsigned long long* range_err) {
-  MIn ci = {pDiv, div, flags, stats, count};
+                           unsigned long long* range_err, const double* partials, long long per_sample, double* stats_out) {
+  MIn ci = {pDiv, div, flags, stats, count, partials, per_sample, stats_out};
   static const bool kpack = !(getenv("TFL_M16_KPACK") && (atoi(getenv("TFL_M16_KPACK")) == 0 || atoi(getenv("TFL_M16_KPACK")) == 2));   // 0 / 2: the tile kernel
   if (kpack) { launch_m16p_in(st, make_dom(Z, Y, X), B, ci, wfrag, bias, out_h2, post, range_err); return; }
   launch_m16<kModeIn>(st, make_dom(Z, Y, X), B, nullptr, wfrag, bias, out_h2, post, ci, range_err);
@@ -1755,7 +1774,7 @@ bool conv3_m16_first2_fused(hipStream_t st, int B, int Z, int Y, int X, const fl
                             const void* wfrag2, const float* bias2, float post2, void* out_h2, unsigned long long* range_err) {
   static const bool kpack = !(getenv("TFL_M16_KPACK") && (atoi(getenv("TFL_M16_KPACK")) == 0 || atoi(getenv("TFL_M16_KPACK")) == 2));
   if (!kpack || (getenv("TFL_M16_TILED") && atoi(getenv("TFL_M16_TILED")) != 0)) return false;
-  MIn ci = {pDiv, div, flags, stats, count};
+  MIn ci = {pDiv, div, flags, stats, count, nullptr, 0, nullptr};
   return launch_m16p_f2(st, make_dom(Z, Y, X), B, ci, wfrag1, bias1, post1, wfrag2, bias2, post2, out_h2, range_err);
 }
 void conv3_m16_mid(hipStream_t st, int B, int Z, int Y, int X, const void* in_h2, const void* wfrag, const float* bias, float post,
@@ -1764,7 +1783,7 @@ void conv3_m16_mid(hipStream_t st, int B, int Z, int Y, int X, const void* in_h2
   static const bool kpack = !(getenv("TFL_M16_KPACK") && atoi(getenv("TFL_M16_KPACK")) == 0);   // 0: k_conv3_m16z
   if (!tiled && kpack) { launch_m16p<false>(st, make_dom(Z, Y, X), B, in_h2, wfrag, bias, out_h2, post, range_err); return; }
   if (!tiled) { launch_m16z<false>(st, make_dom(Z, Y, X), B, in_h2, wfrag, bias, out_h2, post, range_err); return; }
-  MIn noin = {nullptr, nullptr, nullptr, nullptr, 0.0};
+  MIn noin = {nullptr, nullptr, nullptr, nullptr, 0.0, nullptr, 0, nullptr};
   launch_m16<kModeMid>(st, make_dom(Z, Y, X), B, in_h2, wfrag, bias, out_h2, post, noin, range_err);
 }
 void conv3_m16_tail(hipStream_t st, int B, int Z, int Y, int X, const void* in_h2, const void* wfrag, const float* tail_pack,
@@ -1773,7 +1792,7 @@ void conv3_m16_tail(hipStream_t st, int B, int Z, int Y, int X, const void* in_h
   static const bool kpack = !(getenv("TFL_M16_KPACK") && atoi(getenv("TFL_M16_KPACK")) == 0);
   if (!tiled && kpack) { launch_m16p<true>(st, make_dom(Z, Y, X), B, in_h2, wfrag, tail_pack, p_out, post, range_err); return; }
   if (!tiled) { launch_m16z<true>(st, make_dom(Z, Y, X), B, in_h2, wfrag, tail_pack, p_out, post, range_err); return; }
-  MIn noin = {nullptr, nullptr, nullptr, nullptr, 0.0};
+  MIn noin = {nullptr, nullptr, nullptr, nullptr, 0.0, nullptr, 0, nullptr};
   launch_m16<kModeTail>(st, make_dom(Z, Y, X), B, in_h2, wfrag, tail_pack, p_out, post, noin, range_err);
 }
 

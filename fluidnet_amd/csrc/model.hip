@@ -81,14 +81,19 @@ __device__ __forceinline__ float u_bc_at(const Dom& d, const float* __restrict__
 // coherent across the chip (sc1), as their stores were.
 template <bool COHERENT>
 __device__ __forceinline__ void reduce_partials(const double* __restrict__ p, long long count, double* __restrict__ out, int tid) {
+  __shared__ double sh[512];
+  if (!COHERENT) {      // the plain form shares its summation order with the first conv layer's own reduction (tfl_device.hpp)
+    double r1, r2;
+    block_sum_pairs(p, count, sh, tid, r1, r2);
+    if (tid == 0) { out[0] = r1; out[1] = r2; }
+    return;
+  }
   double s1 = 0.0, s2 = 0.0;
   for (long long t = tid; t < count; t += 256) {
-    if (COHERENT) {
-      s1 += __builtin_bit_cast(double, __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p + t * 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-      s2 += __builtin_bit_cast(double, __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p + t * 2 + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    } else { s1 += p[t * 2]; s2 += p[t * 2 + 1]; }
+    s1 += __builtin_bit_cast(double, __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p + t * 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    s2 += __builtin_bit_cast(double, __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p + t * 2 + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
   }
-  __shared__ double sh1[256], sh2[256];
+  double* sh1 = sh; double* sh2 = sh + 256;
   sh1[tid] = s1; sh2[tid] = s2;
   __syncthreads();
   for (int w = 128; w > 0; w >>= 1) {
@@ -632,6 +637,13 @@ __global__ __launch_bounds__(256) void k_pack_planes(PackArgs a, long long zstri
 
 long long model_stat_blocks(int B, int Z, int Y, int X) {
   return (long long)((X + 63) / 64) * ((Y + 3) / 4) * Z * B;
+}
+
+long long model_stat_pairs_per_plane(int B, int Z, int Y, int X, const float* U, const float* flags, const float* Ubc, const float* div) {
+  const Dom d = make_dom(Z, Y, X);
+  const dim3 grd = TFL_GRID3(d, B);
+  const Vec4Launch v = vec4_launch(B, Z, Y, X, {U, flags, Ubc, div});
+  return v.ok ? (long long)v.grd.x * v.grd.y : (long long)grd.x * grd.y;
 }
 
 // stages: bit 0 = k_bcs_div_stats on the current z-window (per-plane partial sums land in absolute slots, so the

@@ -32,6 +32,7 @@ struct tfl_ctx {
   int wf_skip = 0;                            // > 0: a pipelined PCG sweep timed out on this context: the next wf_skip solves go straight to
                                               // hyperplane sweeps, then the pipelined form is tried again (a transient stall must not latch for good)
   int wf_timeouts = 0;                        // how often that happened (the back-off doubles, one warning per latch)
+  bool defer_stats = false;                   // tfl_model_forward: the first conv layer sums k_bcs_div_stats' partials itself (no k_reduce_stats launch)
   bool in_step = false;                       // inside tfl_simulate_step[_slab]: the fp16 range gate was taken at the step's entry, tfl_model_begin /
                                               // tfl_model_forward do not take it again mid-step (a half-stepped state otherwise)
   bool capturing = false;                     // tfl_slab_graph_create is recording the step on `stream`: no host waits, no host reads

@@ -444,4 +444,42 @@ __device__ __forceinline__ void count_trace_error(int rc, unsigned long long* er
   if (rc < 0) atomicAdd(err, 1ull);
 }
 
+// Sum of `count` (sum u, sum u^2) pairs at p by the 256 threads of a block in a FIXED order -- thread t accumulates pairs
+// t, t + 256, ... in that order, then the tree sh[t] += sh[t + w], w = 128 ... 1 over the 256 partial sums: bit-reproducible
+// run to run and the same bits whoever evaluates it (k_reduce_stats, or every block of the first conv layer for itself:
+// round 6). The association is that of the round-2 shared-memory tree; what changed in round 6 is how it is evaluated: the
+// pairs of a thread are loaded eight at a time (16-byte loads, all in flight together: the runtime-length loop made them
+// eight dependent L2 round trips) and levels 32 ... 1 of the tree run inside wave 0 by lane shifts instead of six more
+// block barriers. sh = 512 doubles of LDS; on return EVERY thread holds the two sums and sh may be reused.
+// (lib/modules/variance.lua:44-76 sums in fp32 THC reductions; here fp64, order fixed.)
+__device__ __forceinline__ void block_sum_pairs(const double* __restrict__ p, long long count, double* sh, int tid, double& o1, double& o2) {
+  double s1 = 0.0, s2 = 0.0;
+  const double2* p2 = reinterpret_cast<const double2*>(p);
+  for (long long base = 0; base < count; base += 2048) {
+    double2 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {      // unconditional loads (a lane past the end reads the last pair and drops it)
+      const long long t = base + tid + 256 * u;
+      v[u] = p2[t < count ? t : count - 1];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const bool ok = base + tid + 256 * u < count;
+      s1 += ok ? v[u].x : 0.0; s2 += ok ? v[u].y : 0.0;      // (+ 0.0 leaves a sum unchanged)
+    }
+  }
+  sh[tid] = s1; sh[256 + tid] = s2;
+  __syncthreads();
+  if (tid < 64) {                        // levels 128 and 64 of the tree, then 32 ... 1 inside the wave
+    double a1 = (sh[tid] + sh[tid + 128]) + (sh[tid + 64] + sh[tid + 192]);
+    double a2 = (sh[256 + tid] + sh[256 + tid + 128]) + (sh[256 + tid + 64] + sh[256 + tid + 192]);
+#pragma unroll
+    for (int w = 32; w > 0; w >>= 1) { a1 += __shfl_down(a1, w, 64); a2 += __shfl_down(a2, w, 64); }
+    if (tid == 0) { sh[0] = a1; sh[256] = a2; }
+  }
+  __syncthreads();
+  o1 = sh[0]; o2 = sh[256];
+  __syncthreads();
+}
+
 }  // namespace tfl

@@ -166,6 +166,7 @@ int normalize_pressure_mean(hipStream_t st, bool is3d, int B, int Z, int Y, int 
 
 // model.hip
 long long model_stat_blocks(int B, int Z, int Y, int X);
+long long model_stat_pairs_per_plane(int B, int Z, int Y, int X, const float* U, const float* flags, const float* Ubc, const float* div);   // as model_pre lays them out
 void model_pre(hipStream_t st, bool is3d, int B, int Z, int Y, int X, const float* U, const float* flags, float* Ubc,
                float* div, double* partials, double* stats, int zlo, int zhi, int stages = 3, unsigned* ticket = nullptr);
 void model_net_input(hipStream_t st, bool is3d, int B, int Z, int Y, int X, const float* pDiv, const float* div,
@@ -232,7 +233,11 @@ void conv3_valu_tail(hipStream_t st, int B, int Z, int Y, int X, const float* in
 // "h2": per (b, z, y) two rows [x][8] of fp16 (hi, lo): 32 B per voxel. wfrag / post from conv3_m16_pack_weights.
 void conv3_m16_first_fused(hipStream_t st, int B, int Z, int Y, int X, const float* pDiv, const float* div, const float* flags,
                            const double* stats, double count, const void* wfrag, const float* bias, float post, void* out_h2,
-                           unsigned long long* range_err);
+                           unsigned long long* range_err, const double* partials = nullptr, long long per_sample = 0,
+                           double* stats_out = nullptr);
+// round 6: can the first layer sum k_bcs_div_stats' partial pairs itself (partials / per_sample / stats_out above)? Then
+// tfl_model_forward skips the launch of k_reduce_stats between the two kernels.
+bool conv3_m16_first_sums_partials();
 void conv3_m16_mid(hipStream_t st, int B, int Z, int Y, int X, const void* in_h2, const void* wfrag, const float* bias, float post,
                    void* out_h2, unsigned long long* range_err);
 void conv3_m16_tail(hipStream_t st, int B, int Z, int Y, int X, const void* in_h2, const void* wfrag, const float* tail_pack,

@@ -268,7 +268,11 @@ class SlabSimulation:
         self.prm, self.st, self._keep = _native_args(lib, ctx, mconf, batch, model)
         cells = (layout.c1 - layout.c0) * U.size(3) * U.size(4)
         self.slab = tfl_slab(layout.z_total, layout.lo, layout.c0, layout.c1, layout.reach,
-                             int(cells >= (1 << 20)) if overlap is None else int(bool(overlap)), int(bool(check_reach)), 0)
+                             int(cells >= (1 << 22)) if overlap is None else int(bool(overlap)), int(bool(check_reach)), 0)
+        # (overlap: boundary strips first so that a message travels beside the interior's kernels. It doubles the launches of
+        # three phases and needs the communication stream -- eight event hops per step at 12-15 us of device-side latency each
+        # (tools/ubench/host_costs.hip) -- so it pays only where a message is long against ~100 us: from 4 M cells per rank on.
+        # Round 6, profiles/r06_slab_host_cost.txt: 128^3 on 2 ranks 0.254 ms with it, kernels 0.177; 256^3 on 8 0.379 / 0.292.)
         n = int(lib.tfl_simulate_slab_workspace_floats(ctx, ctypes.byref(self.prm), ctypes.byref(self.st),
                                                        ctypes.byref(self.slab)))
         if n <= 0:

@@ -285,6 +285,31 @@ def test_stats_reduction_folded_into_its_producer(monkeypatch):
             assert torch.equal(p0, p1) and torch.equal(U0, U1), (dims, rep)
 
 
+def test_first_conv_layer_sums_the_stat_partials_itself(monkeypatch):
+    """Round 6: in tfl_model_forward the blocks of the first conv layer reduce k_bcs_div_stats' partial
+    pairs themselves, in k_reduce_stats' order (tfl_device.hpp block_sum_pairs) -- the launch between the two kernels is gone.
+    Same bits as with the separate launch (TFL_STATS_CONSUMER=0), B = 1 and 3, ragged grids (one-cell kernels), repeated
+    calls; and the launch really is gone from the profile."""
+    import torch
+    from fluidnet_amd import FluidNetModel, tfluids
+    dev = torch.device("cuda:0")
+    for dims, seed, B in [((24, 40, 72), 71, 1), ((9, 13, 30), 72, 3), ((64, 64, 64), 74, 1), ((40, 128, 128), 75, 2)]:
+        layers = S.default_3d_layers(seed=3)
+        sc = scenes.make_scene(dims, seed=seed, vel_cells=0.4, B=B)
+        tp, tU, tf = (torch.from_numpy(sc[k]).to(dev) for k in ("p", "U", "flags"))
+        monkeypatch.setenv("TFL_STATS_CONSUMER", "0")
+        m0 = FluidNetModel(layers, True)
+        with tfluids.profile(tU) as prof0:
+            p0, U0 = m0.forward([tp, tU, tf])
+        monkeypatch.delenv("TFL_STATS_CONSUMER")
+        m = FluidNetModel(layers, True)
+        for rep in range(3):
+            with tfluids.profile(tU) as prof1:
+                p1, U1 = m.forward([tp, tU, tf])
+            assert torch.equal(p0, p1) and torch.equal(U0, U1), (dims, rep)
+        assert "k_reduce_stats" in prof0.kernels and "k_reduce_stats" not in prof1.kernels, (sorted(prof0.kernels), sorted(prof1.kernels))
+
+
 def test_fp16_range_errors_are_counted(oracle):
     """conv_mfma16.hip clamps activations at the fp16 range and COUNTS the blocks that did (tfl_model_range_errors): a net
     input far outside it (pressure 1e9 times the velocity scale) must be reported, an ordinary one must not."""
