@@ -173,6 +173,11 @@ SIGNATURES = {
     "tfl_rccl_comm_set_inline": (_c.c_int, [_c.c_void_p, _c.c_int]),
     "tfl_slab_drain": (_c.c_int, [_c.c_void_p, _c.POINTER(tfl_sim_state), _c.POINTER(tfl_slab), _c.POINTER(tfl_comm),
                                   _c.c_void_p, _c.c_int64]),
+    "tfl_slab_needed_reach": (_c.c_int32, [_c.c_void_p]),
+    "tfl_slab_exchange_floats": (_c.c_int64, [_c.c_int, _c.POINTER(_c.POINTER(tfl_tensor)), _c.POINTER(_c.c_int32), _c.POINTER(_c.c_int32),
+                                               _c.POINTER(tfl_slab)]),
+    "tfl_slab_exchange": (_c.c_int, [_c.c_void_p, _c.c_int, _c.POINTER(_c.POINTER(tfl_tensor)), _c.POINTER(_c.c_int32), _c.POINTER(_c.c_int32),
+                                     _c.POINTER(tfl_slab), _c.POINTER(tfl_comm), _c.c_void_p, _c.c_int64]),
     "tfl_slab_graph_create": (_c.c_void_p, [_c.c_void_p, _c.POINTER(tfl_sim_params), _c.POINTER(tfl_sim_state), _c.POINTER(tfl_slab),
                                             _c.POINTER(tfl_comm), _c.c_void_p, _c.c_int64]),
     "tfl_slab_graph_step": (_c.c_int, [_c.c_void_p, _c.c_void_p]),

@@ -225,6 +225,7 @@ void tfl_destroy(tfl_ctx* c) {
   if (c->d_reach) (void)hipFree(c->d_reach);
   if (c->h_reach) (void)hipHostFree(c->h_reach);
   if (c->reach_ev) (void)hipEventDestroy(c->reach_ev);
+  if (c->h_reach_flags) (void)hipHostFree(c->h_reach_flags);
   if (c->d_trace_err) (void)hipFree(c->d_trace_err);
   if (c->d_resid) (void)hipFree(c->d_resid);
   if (c->h_resid) (void)hipHostFree(c->h_resid);

@@ -373,7 +373,7 @@ struct Halo { const tfl_tensor* t; int below, above; };   // planes of `t` refre
 
 struct Msg {                 // one neighbour exchange: buffers inside the workspace
   int tag, n;
-  Halo f[3];
+  Halo f[8];
   float *send_lo, *recv_lo, *send_hi, *recv_hi;
   long long n_send_lo, n_recv_lo, n_send_hi, n_recv_hi;   // floats
 };
@@ -518,6 +518,7 @@ void slab_messages(const SlabGeom& g, const tfl_sim_state* s, const tfl_tensor* 
   m[3].tag = 3; m[3].n = 1; m[3].f[0] = Halo{div, 4, 3};
 }
 
+constexpr int kReachFlags = 8;       // check_reach = 2 resolves reaches 1 .. 8 (a 16-plane slab can hold the halo of 7)
 struct SlabWs { float* msg; double* stats; float* compute; long long compute_floats; };
 
 // workspace = [message buffers][stats: 2*B doubles][compute region]
@@ -528,7 +529,7 @@ long long slab_ws(const SlabGeom& g, const tfl_sim_state* s, float* ws, SlabWs* 
   long long off = msg_layout(g, m, 4, nullptr);
   off = (off + 3) & ~3ll;
   const long long stats_off = off;
-  off += 4ll * g.B;                                   // 2*B doubles
+  off += 4ll * g.B + 2ll * kReachFlags;               // 2*B doubles + the reach flags of check_reach = 2 (behind the stats)
   off = (off + 3) & ~3ll;
   long long model = s->model ? tfl_model_workspace_floats(s->model, g.B, g.Zl, s->flags->Y, s->flags->X) : 0;
   const long long comp = std::max<long long>(13 * g.N, model) + 4;
@@ -655,6 +656,29 @@ int tfl_simulate_step_slab(tfl_ctx* c, const tfl_sim_params* prm, const tfl_sim_
   if (sl->check_reach) {
     for (int b = 0; b < g.B; b++)                                                                            // u_z of every batch item
       tfl::absmax(c->stream, (long long)g.Zl * g.yx, s->U->data + (3ll * b + 2) * g.Zl * g.yx, c->d_reach, b == 0);
+  }
+  if (sl->check_reach == 2) {
+    // "exact" (round 6): the reach THIS step needs, agreed by all ranks, before anything is written. One-hot flags
+    // (max|u_z| dt >= r, r = 1 .. 8) so that the transport's SUM all-reduce can combine them; one host synchronisation.
+    if (c->capturing) { c->err = "simulate_step_slab: check_reach = 2 synchronises with the host and cannot be recorded into a graph"; return TFL_EUNSUPPORTED; }
+    if (!c->h_reach_flags && hipHostMalloc((void**)&c->h_reach_flags, sizeof(double) * kReachFlags, hipHostMallocDefault) != hipSuccess) {
+      c->h_reach_flags = nullptr; c->err = "simulate_step_slab: hipHostMalloc failed"; return TFL_EHIP;
+    }
+    double* d_flags = W.stats + 2 * g.B;
+    tfl::reach_flags(c->stream, c->d_reach, prm->dt, kReachFlags, d_flags);
+    if (multi && comm->allreduce_sum(comm->user, d_flags, kReachFlags) != 0) { c->err = "simulate_step_slab: comm callback failed (allreduce_sum, reach)"; return TFL_EINVAL; }
+    if (hipMemcpyAsync(c->h_reach_flags, d_flags, sizeof(double) * kReachFlags, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+        hipStreamSynchronize(c->stream) != hipSuccess) { c->err = "simulate_step_slab: reading the reach flags failed"; (void)hipGetLastError(); return TFL_EHIP; }
+    int need = 1;
+    for (int r = 0; r < kReachFlags; r++) if (c->h_reach_flags[r] > 0.0) need = r + 2;
+    if (need > g.R) {
+      char buf[200];
+      snprintf(buf, sizeof(buf), "simulate_step_slab: this step's back-traces reach %d cells along z%s, the slab is laid out for %d; nothing has been written",
+               need, need > kReachFlags ? " or more" : "", g.R);
+      c->err = buf; c->needed_reach = need;
+      return TFL_EREACH;
+    }
+  } else if (sl->check_reach) {
     (void)hipMemcpyAsync(c->h_reach, c->d_reach, sizeof(float), hipMemcpyDeviceToHost, c->stream);
     if (!c->capturing) c->reach_pending = hipEventRecord(c->reach_ev, c->stream) == hipSuccess;   // (captured: recorded behind the graph launch)
   }
@@ -820,6 +844,60 @@ int tfl_simulate_step_slab(tfl_ctx* c, const tfl_sim_params* prm, const tfl_sim_
   return TFL_OK;
 }
 
+int32_t tfl_slab_needed_reach(const tfl_ctx* c) { return c ? c->needed_reach : 0; }
+
+namespace {
+// geometry + message of a stand-alone halo exchange (tfl_slab_exchange): every field has the slab's local depth
+int exchange_setup(const tfl_ctx* c, int n, const tfl_tensor* const* fields, const int32_t* below, const int32_t* above, const tfl_slab* sl,
+                   SlabGeom* g, Msg* q) {
+  (void)c;
+  if (n < 1 || n > 4 || !fields || !below || !above || !sl || !fields[0]) return TFL_EINVAL;     // (4 fields x 2 sides = the 8 plane runs of one packing launch)
+  g->Zl = fields[0]->Z; g->B = fields[0]->B;
+  g->o0 = sl->own_lo; g->o1 = sl->own_hi; g->R = sl->reach > 0 ? sl->reach : 1; g->H = 0;
+  g->yx = (long long)fields[0]->Y * fields[0]->X;
+  g->N = (long long)g->B * g->Zl * g->yx;
+  g->lower = sl->z_first + sl->own_lo > 0;
+  g->upper = sl->z_first + sl->own_hi < sl->z_total;
+  if (g->o0 < 0 || g->o1 <= g->o0 || g->o1 > g->Zl) return TFL_EINVAL;
+  q->tag = 4; q->n = n;
+  for (int i = 0; i < n; i++) {
+    const tfl_tensor* t = fields[i];
+    if (!t || !t->data || t->Z != g->Zl || (long long)t->Y * t->X != g->yx || below[i] < 0 || above[i] < 0) return TFL_EINVAL;
+    // a neighbour sends out of its OWNED planes: no deeper than the thinnest slab (the caller keeps own >= halo, as slab_geom demands)
+    if ((g->lower && (below[i] > g->o0 || above[i] > g->o1 - g->o0)) || (g->upper && (above[i] > g->Zl - g->o1 || below[i] > g->o1 - g->o0))) return TFL_EINVAL;
+    q->f[i] = Halo{t, below[i], above[i]};
+  }
+  return TFL_OK;
+}
+}  // namespace
+
+int64_t tfl_slab_exchange_floats(int n, const tfl_tensor* const* fields, const int32_t* below, const int32_t* above, const tfl_slab* sl) {
+  SlabGeom g; Msg q;
+  if (exchange_setup(nullptr, n, fields, below, above, sl, &g, &q) != TFL_OK) return 0;
+  return msg_layout(g, &q, 1, nullptr) + 4;
+}
+
+int tfl_slab_exchange(tfl_ctx* c, int n, const tfl_tensor* const* fields, const int32_t* below, const int32_t* above, const tfl_slab* sl,
+                      const tfl_comm* comm, float* scratch, int64_t scratch_floats) {
+  if (!c) return TFL_EINVAL;
+  SlabGeom g; Msg q;
+  if (exchange_setup(c, n, fields, below, above, sl, &g, &q) != TFL_OK) { c->err = "slab_exchange: bad fields / plane counts"; return TFL_EINVAL; }
+  if (!g.lower && !g.upper) return TFL_OK;
+  if (!comm || comm->size < (int32_t)(offsetof(tfl_comm, allreduce_sum) + sizeof(comm->allreduce_sum)) || !comm->exchange_start || !comm->exchange_wait) {
+    c->err = "slab_exchange: tfl_comm is null or lacks a required callback"; return TFL_EINVAL;
+  }
+  if (!scratch || ((uintptr_t)scratch & 15) != 0 || scratch_floats < msg_layout(g, &q, 1, nullptr)) { c->err = "slab_exchange: scratch too small or misaligned"; return TFL_EINVAL; }
+  msg_layout(g, &q, 1, scratch);
+  // always staged (pack -> send | receive -> unpack): the in-place form needs the transport's chunk lists, and this is a one-off
+  pack_msg(c, g, q, false);
+  if (comm->exchange_start(comm->user, q.tag, q.send_lo, q.n_send_lo, q.recv_lo, q.n_recv_lo, q.send_hi, q.n_send_hi, q.recv_hi, q.n_recv_hi) != 0) {
+    c->err = "slab_exchange: comm callback failed (exchange_start)"; return TFL_EINVAL;
+  }
+  if (comm->exchange_wait(comm->user, q.tag) != 0) { c->err = "slab_exchange: comm callback failed (exchange_wait)"; return TFL_EINVAL; }
+  pack_msg(c, g, q, true);
+  return TFL_OK;
+}
+
 // ---- the rank-step as ONE host call: a HIP graph of tfl_simulate_step_slab (round 6; include/tfluids_hip.h) -------------
 struct tfl_slab_graph {
   hipGraphExec_t exec = nullptr;
@@ -841,6 +919,7 @@ tfl_slab_graph* tfl_slab_graph_create(tfl_ctx* c, const tfl_sim_params* prm, con
     const bool can = comm && comm->size >= (int32_t)(offsetof(tfl_comm, capturable) + sizeof(comm->capturable)) && comm->capturable != 0;
     if (!can) { c->err = "slab_graph_create: this transport's calls are not stream operations (tfl_comm.capturable = 0): step eagerly"; return nullptr; }
   }
+  if (sl->check_reach == 2) { c->err = "slab_graph_create: check_reach = 2 synchronises with the host every step: step eagerly"; return nullptr; }
   // the U / p message the last eager step left in flight is consumed now: a captured step starts and ends with none
   if (sl->in_flight && tfl_slab_drain(c, s, sl, comm, ws, ws_floats) != TFL_OK) return nullptr;
   tfl_slab_graph* G = new tfl_slab_graph();

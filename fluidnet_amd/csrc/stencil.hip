@@ -226,6 +226,16 @@ __global__ __launch_bounds__(256) void k_absmax(long long n, const float* __rest
   if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned int*>(out), __float_as_uint(m));
 }
 
+// flags[r - 1] = 1.0 where *maxu * dt >= r (r = 1 .. n): the one-hot form of "back-trace reach needed" that a SUM all-reduce can
+// combine over ranks (tfl_simulate_step_slab, check_reach = 2); the product is formed in fp32 like the host-side check
+__global__ void k_reach_flags(const float* __restrict__ maxu, float dt, int n, double* __restrict__ flags) {
+  const int r = threadIdx.x + 1;
+  if (r <= n) flags[r - 1] = (*maxu * dt >= (float)r) ? 1.0 : 0.0;
+}
+void reach_flags(hipStream_t st, const float* maxu, float dt, int n, double* flags) {
+  k_reach_flags<<<1, 64, 0, st>>>(maxu, dt, n, flags);
+}
+
 void absmax(hipStream_t st, long long n, const float* x, float* out, bool reset) {
   if (reset) (void)hipMemsetAsync(out, 0, sizeof(float), st);
   const int blocks = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);

@@ -24,6 +24,8 @@ struct tfl_ctx {
   float* h_reach = nullptr;                   // pinned mirror, read by the NEXT tfl_simulate_step_slab call
   hipEvent_t reach_ev = nullptr;              // recorded behind the copy into h_reach; the next call waits for it
   bool reach_pending = false;
+  double* h_reach_flags = nullptr;            // pinned [kReachFlags]: the all-reduced "reach >= r" counts of check_reach = 2 (created on first use)
+  int needed_reach = 0;                       // what the last TFL_EREACH asked for (tfl_slab_needed_reach)
   tfl::BcFoldArg fold = {nullptr, 0u, 0u};    // tfl_simulate_step: a setConstVals pair (device descriptor + gate) the next operator may apply to its output
   bool fold_done = false;                     // ... and whether a launcher did (tfl_host.hpp BcFold)
   tfl::BuoyFold buoy = {nullptr, 0.0f, 0.0f, 0.0f};   // tfl_simulate_step: the buoyancy force the next advectVel may add itself (tfl_host.hpp BuoyFold)

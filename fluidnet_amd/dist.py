@@ -24,6 +24,8 @@ import torch
 from . import _lib, tfluids
 from ._lib import COMM_ALLREDUCE, COMM_START, COMM_WAIT, TfluidsError, tfl_comm, tfl_slab
 
+TFL_EREACH = -5     # include/tfluids_hip.h: check_reach = 2 refused the step, nothing written
+
 
 def slab_halo(reach=1):
     """Planes a slab stores next to each neighbour (tfl_slab_halo): max(4, 2*reach + 1)."""
@@ -250,7 +252,6 @@ class SlabSimulation:
         eager steps; raises if it cannot be recorded), False = always step eagerly, None (default) = try when the transport's
         calls are stream operations (tfl_comm.capturable: the native RCCL transport, or a slab without neighbours) and fall
         back to the eager step, with the reason in `graph_error`, when recording fails. mconf is frozen by the recording."""
-        from .simulate import _native_args
         self.batch, self.mconf, self.model, self.lay, self.comm = batch, mconf, model, layout, comm
         U = batch["UDiv"]
         if (mconf.get("simMethod") or "convnet") != "convnet":
@@ -264,11 +265,25 @@ class SlabSimulation:
             self._own_ctx = self.lib.tfl_create(dev)
             if not self._own_ctx:
                 raise TfluidsError("tfl_create(%d) failed" % dev)
+        self._check_reach, self._overlap = check_reach, overlap
+        if graph is None:      # opt-in (TFL_SLAB_GRAPH=1): round 6 measured the replayed step level with the eager one on the device
+            import os          # (profiles/r06_slab_host_cost.txt); what it buys is the host's time (0.015 against 0.07 ms per step)
+            graph = None if (os.environ.get("TFL_SLAB_GRAPH", "0") == "1" and (comm is None or isinstance(comm, RcclComm))) else False
+        self.graph_mode, self.graph_after, self.graph, self.graph_error, self.graph_nodes, self._steps = graph, 2, None, None, 0, 0
+        self.relayouts = []        # reaches the simulation had to widen itself to (check_reach = "exact")
+        self._setup()
+
+    def _setup(self):
+        """native arguments, slab description and workspace for the CURRENT batch tensors and layout"""
+        from .simulate import _native_args
+        batch, layout, comm = self.batch, self.lay, self.comm
+        U = batch["UDiv"]
         lib, ctx = self._context()
-        self.prm, self.st, self._keep = _native_args(lib, ctx, mconf, batch, model)
+        self.prm, self.st, self._keep = _native_args(lib, ctx, self.mconf, batch, self.model)
         cells = (layout.c1 - layout.c0) * U.size(3) * U.size(4)
+        cr = 2 if self._check_reach == "exact" else int(bool(self._check_reach))
         self.slab = tfl_slab(layout.z_total, layout.lo, layout.c0, layout.c1, layout.reach,
-                             int(cells >= (1 << 22)) if overlap is None else int(bool(overlap)), int(bool(check_reach)), 0)
+                             int(cells >= (1 << 22)) if self._overlap is None else int(bool(self._overlap)), cr, 0)
         # (overlap: boundary strips first so that a message travels beside the interior's kernels. It doubles the launches of
         # three phases and needs the communication stream -- eight event hops per step at 12-15 us of device-side latency each
         # (tools/ubench/host_costs.hip) -- so it pays only where a message is long against ~100 us: from 4 M cells per rank on.
@@ -282,10 +297,65 @@ class SlabSimulation:
             comm.bind(self.ws)
         if isinstance(comm, RcclComm):
             comm.set_inline(not self.slab.overlap)     # a thin slab has nothing for a transfer to overlap with: no stream hops
-        if graph is None:      # auto: only for transports known to be stream operations end to end
-            import os
-            graph = None if (os.environ.get("TFL_SLAB_GRAPH", "1") != "0" and (comm is None or isinstance(comm, RcclComm))) else False
-        self.graph_mode, self.graph_after, self.graph, self.graph_error, self.graph_nodes, self._steps = graph, 2, None, None, 0, 0
+
+    def _relayout(self, reach):
+        """check_reach = "exact": the step was refused on every rank (TFL_EREACH, nothing written) because the flow needs a
+        back-trace reach the halos do not cover. Every 5-D tensor of the batch (state, flags, BC pairs) gets the wider halo:
+        a new array, the owned planes copied, the halo planes fetched from the neighbours' owned planes through the transport
+        (tfl_slab_exchange); then the native arguments are rebuilt and the step is taken again. The batch DICT keeps its
+        identity, its tensors are replaced. Collective: every rank arrives here at the same step with the same reach."""
+        old = self.lay
+        try:
+            new = SlabLayout(old.z_total, old.world, old.rank, reach)
+        except ValueError as e:
+            raise TfluidsError("the flow needs a back-trace reach of %d planes: %s" % (reach, e))
+        if self.graph is not None:
+            self.lib.tfl_slab_graph_destroy(self._context()[1], self.graph)
+            self.graph = None
+        lib, ctx = self._context()
+        names, tensors = [], []
+
+        def walk(key, v):
+            if torch.is_tensor(v) and v.dim() == 5 and v.size(2) == old.hi - old.lo:
+                names.append(key); tensors.append(v)
+            elif isinstance(v, (list, tuple)):
+                for i, x in enumerate(v):
+                    walk((key, i), x)
+        for k, v in list(self.batch.items()):
+            walk(k, v)
+        grown = []
+        for t in tensors:
+            nt = torch.zeros(t.size(0), t.size(1), new.hi - new.lo, t.size(3), t.size(4), dtype=t.dtype, device=t.device)
+            nt[:, :, new.c0:new.c1] = t[:, :, old.c0:old.c1]
+            grown.append(nt)
+        slab = tfl_slab(new.z_total, new.lo, new.c0, new.c1, new.reach, 0, 0, 0)
+        below = above = new.halo      # the same counts on every rank: what I send up is what my upper neighbour stores below
+        for i in range(0, len(grown), 4):
+            grp = grown[i:i + 4]
+            descs = [tfluids._desc5(t) for t in grp]
+            arr = (ctypes.POINTER(_lib.tfl_tensor) * len(grp))(*[ctypes.pointer(d) for d in descs])
+            lo = (ctypes.c_int32 * len(grp))(*([below] * len(grp)))
+            hi = (ctypes.c_int32 * len(grp))(*([above] * len(grp)))
+            n = int(lib.tfl_slab_exchange_floats(len(grp), arr, lo, hi, ctypes.byref(slab)))
+            scratch = torch.empty(max(n, 4), dtype=torch.float32, device=grp[0].device)
+            if self.comm is not None:
+                self.comm.bind(scratch)
+                self.comm.error = None
+            cptr = ctypes.byref(self.comm.struct) if self.comm is not None else None
+            rc = lib.tfl_slab_exchange(ctx, len(grp), arr, lo, hi, ctypes.byref(slab), cptr, ctypes.c_void_p(scratch.data_ptr()), scratch.numel())
+            if rc != 0:
+                if self.comm is not None and self.comm.error is not None:
+                    raise self.comm.error
+                raise TfluidsError(lib.tfl_last_error(ctx).decode())
+            torch.cuda.current_stream(grp[0].device).synchronize()      # scratch is released below
+        for key, nt in zip(names, grown):
+            if isinstance(key, tuple):
+                seq = list(self.batch[key[0]]); seq[key[1]] = nt; self.batch[key[0]] = seq
+            else:
+                self.batch[key] = nt
+        self.lay = new
+        self.relayouts.append(reach)
+        self._setup()
 
     def _context(self):
         if self._own_ctx is None:
@@ -294,7 +364,7 @@ class SlabSimulation:
         self.lib.tfl_set_stream(self._own_ctx, ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
         return self.lib, self._own_ctx
 
-    def _call(self, fn, *args):
+    def _call(self, fn, *args, ok_codes=()):
         lib, ctx = self._context()
         if self.comm is not None and not hasattr(self.comm, "struct"):
             # a factory: the transport needs this simulation's context and -- communicator creation being collective --
@@ -307,6 +377,8 @@ class SlabSimulation:
         if self.comm is not None:
             self.comm.error = None
         rc = fn(ctx, *args, ctypes.byref(self.slab), cptr, ctypes.c_void_p(self.ws.data_ptr()), self.ws.numel())
+        if rc in ok_codes:
+            return rc
         if rc != 0:
             if self.comm is not None and self.comm.error is not None:
                 raise self.comm.error
@@ -344,7 +416,13 @@ class SlabSimulation:
             if rc != 0:
                 raise TfluidsError(lib.tfl_last_error(ctx).decode())
             return
-        self._call(self.lib.tfl_simulate_step_slab, ctypes.byref(self.prm), ctypes.byref(self.st))
+        for _ in range(8):
+            rc = self._call(self.lib.tfl_simulate_step_slab, ctypes.byref(self.prm), ctypes.byref(self.st), ok_codes=(TFL_EREACH,))
+            if rc != TFL_EREACH:
+                return
+            # nothing of the step has been written and every rank is here with the same number: widen the halos, take the step again
+            self._relayout(int(self.lib.tfl_slab_needed_reach(self._context()[1])))
+        raise TfluidsError("the reach kept growing while the halos were being widened")
 
     def drain(self):
         """Finish the p / U halo messages the last step left in flight (before reading halo planes)."""

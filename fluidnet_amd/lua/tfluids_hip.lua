@@ -27,6 +27,7 @@ typedef enum tfl_status {
   TFL_EINVAL = -1,
   TFL_EHIP = -2,
   TFL_EUNSUPPORTED = -3,
+  TFL_EREACH = -5,
   TFL_ERANGE = -4
 } tfl_status;
 typedef struct tfl_tensor {
@@ -212,6 +213,10 @@ int64_t tfl_simulate_slab_workspace_floats(tfl_ctx* ctx, const tfl_sim_params* p
                                            const tfl_slab* slab);
 int tfl_simulate_step_slab(tfl_ctx* ctx, const tfl_sim_params* params, const tfl_sim_state* state, tfl_slab* slab,
                            const tfl_comm* comm, float* workspace, int64_t workspace_floats);
+int32_t tfl_slab_needed_reach(const tfl_ctx* ctx);
+int64_t tfl_slab_exchange_floats(int n, const tfl_tensor* const* fields, const int32_t* below, const int32_t* above, const tfl_slab* slab);
+int tfl_slab_exchange(tfl_ctx* ctx, int n, const tfl_tensor* const* fields, const int32_t* below, const int32_t* above,
+                      const tfl_slab* slab, const tfl_comm* comm, float* scratch, int64_t scratch_floats);
 int tfl_slab_drain(tfl_ctx* ctx, const tfl_sim_state* state, tfl_slab* slab, const tfl_comm* comm, float* workspace,
                    int64_t workspace_floats);
 typedef struct tfl_slab_graph tfl_slab_graph;

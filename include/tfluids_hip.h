@@ -41,6 +41,8 @@ typedef enum tfl_status {
   TFL_EINVAL = -1,       /* bad argument (shape / channel / null pointer / unknown method) */
   TFL_EHIP = -2,         /* HIP runtime error (message carries hipGetErrorString) */
   TFL_EUNSUPPORTED = -3, /* valid in the reference but not built here */
+  TFL_EREACH = -5,       /* tfl_simulate_step_slab with check_reach = 2: the flow is faster than the slab's halo allows; NOTHING of
+                            the step has been written -- lay the slab out for tfl_slab_needed_reach() and call again */
   TFL_ERANGE = -4        /* an earlier forward pass of the model left the fp16 range of the default 3-D conv path (see
                             tfl_model_range_errors): refused until that count has been read */
 } tfl_status;
@@ -458,7 +460,14 @@ typedef struct tfl_slab {
   int32_t check_reach;    /* 1: every step reduces max|u_z| on the device; a violation found by step n is reported
                              by the call for step n+1, which waits for step n's reduction to land (the host can run
                              at most one step ahead of the device); messages in flight are drained before the error
-                             is returned, so neighbours do not hang */
+                             is returned, so neighbours do not hang.
+                             2 (round 6, "exact"): the check comes BEFORE the step's advection and is collective -- max|u_z|
+                             of the state the step starts from, the reach it needs all-reduced over the ranks (8 doubles
+                             through tfl_comm.allreduce_sum), one host synchronisation. A step that needs more than `reach`
+                             returns TFL_EREACH on EVERY rank with nothing written; the host widens the halos
+                             (tfl_slab_needed_reach, tfl_slab_exchange) and calls again, so the cut run stays the
+                             un-cut run whatever the flow does (fluidnet_amd/dist.py SlabSimulation does it by itself).
+                             Costs the host its lead over the device (~10-30 us per step): opt-in */
   int32_t in_flight;      /* OUT/IN, initialise to 0: bit mask of halo messages started by the previous call and not
                              yet consumed (tfl_simulate_step_slab finishes them; tfl_slab_drain does so explicitly) */
 } tfl_slab;
@@ -521,6 +530,18 @@ int64_t tfl_simulate_slab_workspace_floats(tfl_ctx* ctx, const tfl_sim_params* p
  * few planes per phase instead of a fixed wide halo. */
 int tfl_simulate_step_slab(tfl_ctx* ctx, const tfl_sim_params* params, const tfl_sim_state* state, tfl_slab* slab,
                            const tfl_comm* comm, float* workspace, int64_t workspace_floats);
+
+/* The reach the last TFL_EREACH of this context asked for: the smallest R with max|u_z|*dt < R over ALL ranks (0: none yet). */
+int32_t tfl_slab_needed_reach(const tfl_ctx* ctx);
+
+/* One halo exchange of n <= 4 fields outside a step (what a host needs to widen a slab's halos after TFL_EREACH, or to
+ * fill them at start-up without a global array): planes [own_lo - below[i], own_lo) of field i are received from the lower
+ * neighbour and [own_hi, own_hi + above[i]) from the upper one; the matching owned planes are sent. Every field has the
+ * slab's local depth (own_hi + halo). Staged through `scratch` (tfl_slab_exchange_floats of them); collective; returns with
+ * the transfers ordered on the context's stream. */
+int64_t tfl_slab_exchange_floats(int n, const tfl_tensor* const* fields, const int32_t* below, const int32_t* above, const tfl_slab* slab);
+int tfl_slab_exchange(tfl_ctx* ctx, int n, const tfl_tensor* const* fields, const int32_t* below, const int32_t* above,
+                      const tfl_slab* slab, const tfl_comm* comm, float* scratch, int64_t scratch_floats);
 
 /* Finish the messages a previous tfl_simulate_step_slab left in flight: afterwards the halo planes of U and p are
  * valid too (call before reading halos on the host, or before freeing the workspace). */

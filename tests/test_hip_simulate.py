@@ -668,6 +668,39 @@ def test_zslab_reach_violation_is_reported():
         s.close()
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_zslab_reach_fallback_keeps_the_cut_run_exact(world):
+    """VERDICT r05 item 7 / SURVEY 7 "semi-Lagrangian reach": with check_reach = "exact" (tfl_slab.check_reach = 2) the reach a
+    step needs is found BEFORE its advection, agreed by all ranks (one-hot flags through the transport's all-reduce), and a
+    step the halos do not cover is refused on every rank with nothing written (TFL_EREACH); SlabSimulation then widens the
+    halos of every tensor of the batch through the transport (tfl_slab_exchange) and takes the step again. The scene of
+    test_zslab_reach_violation_is_reported -- 1.5 cells per step along z through the cut(s) -- must end equal to the un-cut
+    step instead of raising, and the simulation must report that it re-laid itself out for reach 2."""
+    import torch
+    from fluidnet_amd import FluidNetModel
+    from fluidnet_amd.dist import run_virtual_ranks
+    from fluidnet_amd.simulate import simulate_native
+    dev = torch.device("cuda:0")
+    Zt = 12 * world
+    b = _plume_batch((Zt, 16, 16), 0.15, 0.6)
+    b["UDiv"][:, 2, 4:Zt - 4, 4:12, 4:12] = 15.0          # 1.5 cells per step along z
+    mconf = dict(dt=0.1, advectionMethod="maccormackOurs", maccormackStrength=0.6, buoyancyScale=1.0,
+                 gravityScale=0, vorticityConfinementAmp=1.0, simMethod="convnet")
+    layers = S.default_3d_layers(seed=2)
+    ref = _to_dev(b, dev)
+    model = FluidNetModel(layers, True)
+    sims = _slab_sims(ref, mconf, world, layers, check_reach="exact")
+    for step in range(3):
+        simulate_native(None, mconf, ref, model)
+        run_virtual_ranks(sims, 1)
+        _assert_slabs_equal(sims, ref, 1e-7)
+    assert float(ref["UDiv"][:, 2].abs().max()) * 0.1 > 1.0
+    for sim in sims:
+        assert sim.relayouts == [2] and sim.lay.reach == 2 and sim.lay.halo == 5, (sim.lay.rank, sim.relayouts)
+        assert sim.batch["UDiv"].size(2) == sim.lay.hi - sim.lay.lo
+        sim.close()
+
+
 def test_zslab_reach2_equals_single_gpu():
     """with reach R = 2 the velocity's self-advection samples U up to 2R planes from the owned range, so the
     U message must refresh max(R+1, 2R) planes, not R+1. A flow with |u_z|*dt in (1, 2) across the slab boundaries,
