@@ -1113,7 +1113,7 @@ int tfl_model_forward(tfl_ctx* c, tfl_model* m, const tfl_tensor* pDiv, const tf
   // order, the same bits) -- no k_reduce_stats launch between the two kernels (4.3 us of pure latency at 128^3)
   struct Defer { tfl_ctx* c; ~Defer() { c->defer_stats = false; } } defer{c};
   c->defer_stats = m && m->mfma3d && m->m16 && !m->custom && tfl::conv3_m16_first_sums_partials() &&
-                   !(getenv("TFL_M16_FUSE12") && atoi(getenv("TFL_M16_FUSE12")) == 1) && !(getenv("TFL_STATS_FOLD") && atoi(getenv("TFL_STATS_FOLD")) == 1);
+                   !tfl::conv3_m16_fuse12_requested() && !tfl::model_stats_fold_requested();
   TRY(tfl_model_begin(c, m, UDiv, flags, UOut, workspace, workspace_floats, 0, flags->Z, nullptr));
   const double count = (double)flags->Z * flags->Y * flags->X * (m->is3d ? 3 : 2);
   return tfl_model_finish(c, m, pDiv, flags, pOut, UOut, workspace, workspace_floats, nullptr, count, UBC, UBCInvMask,

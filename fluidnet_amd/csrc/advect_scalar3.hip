@@ -443,392 +443,9 @@ void launch_b(hipStream_t st, const AdvArgs& a, int B, const float* s, const flo
 }
 
 
-// =====================================================================================================================
-// z-MARCHED form of the two passes (round 5). The tile kernels above are bound by the latency of a
-// block's life -- loads, barrier, dependent LDS reads, stores: SQ wait_any 0.45-0.48, every ablation >= 17 us at 128^3
-// (profiles/r04_advect_experiments.txt 9) -- and re-stage 6.4 (pass A, halo 2) / 3.1 (pass B) words per cell and field, which
-// at 256^3 reaches HBM as 2.1-2.35 x the algorithmic traffic. Here a block of 64 x 4 threads owns a column and walks a chunk
-// of z: the masked scalar lives in a RING of planes in LDS (pass A: halo 2, 68 x 8 words per plane, 8 slots; pass B: halo 1,
-// 66 x 6, 4 slots), every plane of the column is staged ONCE (2.1 / 1.5 words per cell), the next plane's words and the next
-// cell's own operands (its value, the six faces of its centred velocity, pass B: the forward value and the clamp bounds) are
-// loaded a step ahead into registers, so no load latency is exposed inside the march, and there is ONE barrier per plane.
-// Per-cell arithmetic is the tile kernels' (trace_fast, the plain-then-fluid-aware trilinear form, the 27-tap bounds search,
-// the fp64 correction): the only change is that a tap's plane is a ring slot, (plane & mask) * plane size, instead of a
-// multiple of the plane size. Bit-identical results (tests/test_hip_parity.py, the golden files).
-namespace zm {
-
-template <int H, int R>
-struct Ring {
-  static constexpr int LX = TX + 2 * H, LY = TY + 2 * H, LP = LX * LY, NS = (LP + 255) / 256, N = R * LP;
-  static_assert((R & (R - 1)) == 0, "ring slots are addressed with a mask");
-  static __device__ __forceinline__ int slot(int plane) { return __mul24(plane & (R - 1), LP); }
-};
-
-// block -> (column, chunk of the window's plane runs, batch item)
-struct Col { int x0, y0, za, zb, b; };
-__device__ __forceinline__ Col column_of(const Dom& d, int cols_x, int cols_y, int cz, int chunks_a, int chunks) {
-  int t = (int)blockIdx.x;
-  Col c;
-  c.x0 = (t % cols_x) * TX; t /= cols_x;
-  c.y0 = (t % cols_y) * TY; t /= cols_y;
-  const int ch = t % chunks;
-  c.b = t / chunks;
-  c.za = ch < chunks_a ? d.w0 + ch * cz : d.w1 + (ch - chunks_a) * cz;
-  const int z_end = ch < chunks_a ? d.w0 + d.n0 : d.w1 + (d.nw - d.n0);
-  c.zb = min(c.za + cz, z_end);
-  return c;
-}
-
-// the thread's NS words of a plane of the ring: where they come from (byte offset inside a plane of the array, clamped) and
-// whether they lie inside the grid in x / y
-template <class RG>
-struct Stager {
-  unsigned off[RG::NS];
-  unsigned in;        // bit q: slot q exists and lies inside the grid
-  __device__ __forceinline__ void init(const Dom& d, int x0, int y0, int tid, int H) {
-    in = 0;
-#pragma unroll
-    for (int q = 0; q < RG::NS; q++) {
-      const int it = tid + 256 * q, itc = min(it, RG::LP - 1);
-      const int hy = itc / RG::LX, hx = itc - hy * RG::LX;
-      const int gx = x0 - H + hx, gy = y0 - H + hy;
-      off[q] = (unsigned)(min(max(gx, 0), d.X - 1) + __mul24(min(max(gy, 0), d.Y - 1), d.sy)) * 4u;
-      in |= (it < RG::LP && gx >= 0 && gx < d.X && gy >= 0 && gy < d.Y) ? (1u << q) : 0u;
-    }
-  }
-};
-template <class RG>
-struct PlaneRegs { float s[RG::NS], f[RG::NS]; };
-// words of plane p (array index; any integer: a plane outside the array is read at the nearest one and masked when written)
-template <class RG>
-__device__ __forceinline__ void load_plane(const Dom& d, const Stager<RG>& st, const float* __restrict__ g, const float* __restrict__ flags,
-                                           int p, int tid, PlaneRegs<RG>& r) {
-  const long long po = (long long)min(max(p, 0), d.Z - 1) * d.sz;      // uniform
-#pragma unroll
-  for (int q = 0; q < RG::NS; q++) {
-    if ((RG::LP % 256) != 0 && q == RG::NS - 1 && tid >= RG::LP - 256 * (RG::NS - 1)) continue;
-    r.s[q] = ldg(g + po, st.off[q]); r.f[q] = ldg(flags + po, st.off[q]);
-  }
-}
-template <class RG>
-__device__ __forceinline__ void write_plane(const Dom& d, const Stager<RG>& st, float* __restrict__ ring, int p, int tid, const PlaneRegs<RG>& r) {
-  const bool z_ok = p >= 0 && p < d.Z;                                    // uniform
-  float* dst = ring + RG::slot(p);
-#pragma unroll
-  for (int q = 0; q < RG::NS; q++) {
-    if ((RG::LP % 256) != 0 && q == RG::NS - 1 && tid >= RG::LP - 256 * (RG::NS - 1)) continue;
-    dst[tid + 256 * q] = mask_word(r.s[q], r.f[q], z_ok && ((st.in >> q) & 1u));
-  }
-}
-
-// trace_fast / lerp_tile of the tile kernels on a ring: `cb` = in-plane index of the thread's cell minus (i + j LX), zg = the
-// array's first plane in the whole grid (positions are global in z)
-template <class RG, bool FAST>
-__device__ __forceinline__ bool trace_ring(const float* __restrict__ ring, int cb, int zg, int own_idx, v3 ctr, v3 u, float ndt, v3& p,
-                                           int& e_in, int& e_plane) {
-  const float dx = u.x * ndt, dy = u.y * ndt, dz = u.z * ndt;     // scale3(u, -dt)
-  const float l2 = dx * dx + dy * dy + dz * dz;                   // vec3::norm, vec3.h:119-127
-  const bool nz = l2 > 1e-6f;
-  bool shortd;
-  if (FAST) {
-    p.x = nz ? ctr.x + dx : ctr.x; p.y = nz ? ctr.y + dy : ctr.y; p.z = nz ? ctr.z + dz : ctr.z;
-    shortd = l2 <= kFastLen * kFastLen;
-  } else {
-    float len_, r_;
-    sqrt_rcp_exact(l2, len_, r_);          // ONE transcendental (v_rsq) for the root and the reciprocal (tfl_fastmath.hpp; bit-equal, profiles/r03_exact_math.txt)
-    const float len = nz ? len_ : 0.0f, r = nz ? r_ : 0.0f;
-    const float qx = div_by<1>(dx, len, r), qy = div_by<1>(dy, len, r), qz = div_by<1>(dz, len, r);
-    p.x = ctr.x + qx * len;
-    p.y = ctr.y + qy * len;
-    p.z = ctr.z + qz * len;
-    shortd = len <= kFastLen;
-  }
-  const bool fin = shortd && p.x == p.x && p.y == p.y && p.z == p.z;
-  e_in = fin ? __mul24((int)p.y, RG::LX) + (int)p.x + cb : 0;
-  e_plane = fin ? (int)p.z - zg : 0;
-  const float w = ring[fin ? RG::slot(e_plane) + e_in : own_idx];
-  return fin && !is_mask(w);
-}
-template <class RG, bool FAST>
-__device__ __forceinline__ float lerp_ring(const float* __restrict__ ring, int cb, int zg, v3 p) {
-  const float px = p.x - 0.5f, py = p.y - 0.5f, pz = p.z - 0.5f;
-  const float s1 = __builtin_amdgcn_fractf(px), t1 = __builtin_amdgcn_fractf(py), f1 = __builtin_amdgcn_fractf(pz);
-  const float s0 = 1.0f - s1, t0 = 1.0f - t1, f0 = 1.0f - f1;
-  const int in = __mul24((int)py, RG::LX) + (int)px + cb, zl = (int)pz - zg;
-  const float* q0 = ring + (RG::slot(zl) + in);
-  const float* q1 = ring + (RG::slot(zl + 1) + in);
-  const float g000 = q0[0], g010 = q0[RG::LX], g100 = q0[1], g110 = q0[1 + RG::LX];
-  const float g001 = q1[0], g011 = q1[RG::LX], g101 = q1[1], g111 = q1[1 + RG::LX];
-  const float lo = lerp1<FAST>(lerp1<FAST>(g000, g010, t0, t1), lerp1<FAST>(g100, g110, t0, t1), s0, s1);
-  const float hi = lerp1<FAST>(lerp1<FAST>(g001, g011, t0, t1), lerp1<FAST>(g101, g111, t0, t1), s0, s1);
-  float r = lerp1<FAST>(lo, hi, f0, f1);
-  if (r != r) {
-    const float lo2 = lerp1_fluid<FAST>(lerp1_fluid<FAST>(g000, g010, t0, t1), lerp1_fluid<FAST>(g100, g110, t0, t1), s0, s1);
-    const float hi2 = lerp1_fluid<FAST>(lerp1_fluid<FAST>(g001, g011, t0, t1), lerp1_fluid<FAST>(g101, g111, t0, t1), s0, s1);
-    r = lerp1_fluid<FAST>(lo2, hi2, f0, f1);
-  }
-  return r;
-}
-
-// the operands of a cell that do not come from the ring, loaded one step ahead
-struct OwnA { float s, ux0, ux1, uy0, uy1, uz0, uz1; };
-struct OwnB { float s, f, lo, hi, ux0, ux1, uy0, uy1, uz0, uz1; };
-// (k: array plane; `deep` false -> the +1 faces read the cell itself: valid addresses, unused values)
-__device__ __forceinline__ void load_faces(const Dom& d, const float* __restrict__ U, unsigned o4, bool deep, float& ux0, float& ux1,
-                                           float& uy0, float& uy1, float& uz0, float& uz1) {
-  const unsigned sc4 = (unsigned)d.sc * 4u;
-  const unsigned ex = deep ? 4u : 0u, ey = deep ? (unsigned)d.sy * 4u : 0u, ez = deep ? (unsigned)d.sz * 4u : 0u;
-  ux0 = ldg(U, o4); ux1 = ldg(U, o4 + ex);
-  uy0 = ldg(U, o4 + sc4); uy1 = ldg(U, o4 + sc4 + ey);
-  uz0 = ldg(U, o4 + 2u * sc4); uz1 = ldg(U, o4 + 2u * sc4 + ez);
-}
-
-constexpr int HA = 2, RA = 8, HB = 1, RB = 4;
-
-// ---- pass A / the single-pass method ---------------------------------------------------------------------------------------
-template <bool BOUNDS, bool FAST>
-__global__ __launch_bounds__(256) void k_scal3m_fwd(AdvArgs a, int cols_x, int cols_y, int cz, int chunks_a, int chunks,
-                                                    const float* __restrict__ s, const float* __restrict__ U,
-                                                    const float* __restrict__ flags, float* __restrict__ out,
-                                                    float* __restrict__ bounds) {
-  using RG = Ring<HA, RA>;
-  __shared__ float ring[RG::N];
-  const Dom& d = a.d;
-  const Col c = column_of(d, cols_x, cols_y, cz, chunks_a, chunks);
-  const long long cells = (long long)d.sc;
-  s += c.b * cells; flags += c.b * cells; U += c.b * cells * 3; out += c.b * cells;
-  if (BOUNDS) bounds += c.b * cells * 3;
-  const int lane = threadIdx.x, ty = threadIdx.y, tid = lane + 64 * ty;
-  const int i = c.x0 + lane, j = c.y0 + ty;
-  const bool live_xy = (i < d.X) & (j < d.Y);
-  const bool border_xy = ((unsigned)(i - 1) >= (unsigned)(d.X - 2)) | ((unsigned)(j - 1) >= (unsigned)(d.Y - 2));
-  const unsigned oxy4 = (unsigned)(min(i, d.X - 1) + __mul24(min(j, d.Y - 1), d.sy)) * 4u, sc4 = (unsigned)d.sc * 4u;
-  const int c_in = (ty + HA) * RG::LX + lane + HA;          // the cell's in-plane index
-  const int cb = c_in - (i + j * RG::LX);
-  Stager<RG> st; st.init(d, c.x0, c.y0, tid, HA);
-
-  // is the cell of plane k (array index) `deep`: inside the grid, no border cell of the array or of the whole grid
-  auto deep_at = [&](int k) { return live_xy & !border_xy & ((unsigned)(k - 1) < (unsigned)(d.Z - 2)) & ((unsigned)(k + d.zg - 1) < (unsigned)(d.Zg - 2)); };
-  auto load_own = [&](int k, OwnA& o) {
-    const int kc = min(k, d.Z - 1);
-    const unsigned o4 = oxy4 + (unsigned)__mul24(kc, d.sz) * 4u;
-    o.s = ldg(s, o4);
-    load_faces(d, U, o4, deep_at(k) && k < c.zb, o.ux0, o.ux1, o.uy0, o.uy1, o.uz0, o.uz1);
-  };
-
-  // ---- fill: planes za - 2 .. za + 2 into the ring, plane za + 3 and the first cell's operands in registers ----------------
-  PlaneRegs<RG> pr[6];
-#pragma unroll
-  for (int q = 0; q < 6; q++) load_plane<RG>(d, st, s, flags, c.za - 2 + q, tid, pr[q]);
-  OwnA own;
-  load_own(c.za, own);
-#pragma unroll
-  for (int q = 0; q < 5; q++) write_plane<RG>(d, st, ring, c.za - 2 + q, tid, pr[q]);
-  PlaneRegs<RG> nxt = pr[5];
-
-#pragma unroll 1
-  for (int k = c.za; k < c.zb; k++) {
-    __syncthreads();                  // planes <= k + 2 are in the ring; every wave is done with step k - 1 (which read planes >= k - 3)
-    write_plane<RG>(d, st, ring, k + 3, tid, nxt);      // into the slot of plane k - 5; needed from step k + 1 on
-    load_plane<RG>(d, st, s, flags, k + 4, tid, nxt);
-    const OwnA cur = own;
-    load_own(k + 1, own);
-    if (!live_xy) continue;
-    const unsigned o4 = oxy4 + (unsigned)__mul24(k, d.sz) * 4u;
-    const bool border = border_xy | ((unsigned)(k - 1) >= (unsigned)(d.Z - 2));
-    if (border) { stg(out, o4, 0.0f); continue; }
-    const int kg = k + d.zg;
-    const bool deep = deep_at(k);
-    const v3 ctr = mk3((float)i + 0.5f, (float)j + 0.5f, (float)kg + 0.5f);
-    const v3 u = mk3(0.5f * (cur.ux0 + cur.ux1), 0.5f * (cur.uy0 + cur.uy1), 0.5f * (cur.uz0 + cur.uz1));   // getCentered, grid.cc:346-377
-    const int own_idx = RG::slot(k) + c_in;
-    const bool fl = !is_mask(ring[own_idx]);
-    float v = cur.s;
-    int e_in = c_in, e_plane = k;   // cell of the forward position: the cell itself where nothing is advected (tfluids.cc:159-163)
-    bool slow = false;
-    if (fl) {
-      slow = true;
-      if (deep) {
-        v3 p; int ei, ep;
-        const bool ok = trace_ring<RG, FAST>(ring, cb, d.zg, own_idx, ctr, u, -a.dt, p, ei, ep);
-        const float r = lerp_ring<RG, FAST>(ring, cb, d.zg, ok ? p : ctr);
-        if (ok && !is_mask(r)) { v = r; slow = false; e_in = ei; e_plane = ep; }
-      }
-    }
-    float lo = __builtin_inff(), hi = -__builtin_inff();
-    if (BOUNDS && !slow) {
-      float t[27];
-#pragma unroll
-      for (int z = 0; z < 3; z++) {
-        const float* qq = ring + (RG::slot(e_plane - 1 + z) + e_in - 1 - RG::LX);
-#pragma unroll
-        for (int n = 0; n < 9; n++) t[z * 9 + n] = qq[(n / 3) * RG::LX + (n % 3)];
-      }
-#pragma unroll
-      for (int n = 0; n < 26; n += 2) { lo = min3r(lo, t[n], t[n + 1]); hi = max3r(hi, t[n], t[n + 1]); }
-      lo = min3r(lo, t[26], t[26]); hi = max3r(hi, t[26], t[26]);
-    }
-    if (slow) {   // rare lanes: the generic trace + fluid-aware sampler on global memory
-      v3 back;
-      v = sl_euler_ours<true>(a, flags, U, s, a.dt, i, j, k, back);
-      if (BOUNDS) clamp_bounds_global(d, s, flags, back, lo, hi);
-    }
-    stg(out, o4, v);
-    if (BOUNDS) { stg(bounds, o4, lo); stg(bounds, o4 + sc4, hi); }
-  }
-}
-
-// ---- pass B ----------------------------------------------------------------------------------------------------------------
-template <bool FAST>
-__global__ __launch_bounds__(256) void k_scal3m_bwd(AdvArgs a, int cols_x, int cols_y, int cz, int chunks_a, int chunks, double half_strength,
-                                                    const float* __restrict__ s, const float* __restrict__ U,
-                                                    const float* __restrict__ flags, const float* __restrict__ fwd,
-                                                    const float* __restrict__ bounds, float* dst, BcFoldArg folda) {
-  using RG = Ring<HB, RB>;
-  __shared__ float ring[RG::N];
-  const Dom& d = a.d;
-  const Col c = column_of(d, cols_x, cols_y, cz, chunks_a, chunks);
-  const long long cells = (long long)d.sc;
-  s += c.b * cells; flags += c.b * cells; U += c.b * cells * 3; fwd += c.b * cells; dst += c.b * cells; bounds += c.b * cells * 3;
-  const int lane = threadIdx.x, ty = threadIdx.y, tid = lane + 64 * ty;
-  const int i = c.x0 + lane, j = c.y0 + ty;
-  const bool live_xy = (i < d.X) & (j < d.Y);
-  const bool border_xy = ((unsigned)(i - 1) >= (unsigned)(d.X - 2)) | ((unsigned)(j - 1) >= (unsigned)(d.Y - 2));
-  const unsigned oxy4 = (unsigned)(min(i, d.X - 1) + __mul24(min(j, d.Y - 1), d.sy)) * 4u, sc4 = (unsigned)d.sc * 4u;
-  const int c_in = (ty + HB) * RG::LX + lane + HB;
-  const int cb = c_in - (i + j * RG::LX);
-  const bool fold_blk = fold_block(folda, c.y0, c.y0 + TY - 1, c.za, c.zb - 1);
-  Stager<RG> st; st.init(d, c.x0, c.y0, tid, HB);
-  auto deep_at = [&](int k) { return live_xy & !border_xy & ((unsigned)(k - 1) < (unsigned)(d.Z - 2)) & ((unsigned)(k + d.zg - 1) < (unsigned)(d.Zg - 2)); };
-  auto load_own = [&](int k, OwnB& o) {
-    const int kc = min(k, d.Z - 1);
-    const unsigned o4 = oxy4 + (unsigned)__mul24(kc, d.sz) * 4u;
-    o.s = ldg(s, o4); o.f = ldg(fwd, o4); o.lo = ldg(bounds, o4); o.hi = ldg(bounds, o4 + sc4);
-    load_faces(d, U, o4, deep_at(k) && k < c.zb, o.ux0, o.ux1, o.uy0, o.uy1, o.uz0, o.uz1);
-  };
-
-  // ---- fill: planes za - 1 .. za + 1 into the ring, plane za + 2 and the first cell's operands in registers -----------------
-  PlaneRegs<RG> pr[4];
-#pragma unroll
-  for (int q = 0; q < 4; q++) load_plane<RG>(d, st, fwd, flags, c.za - 1 + q, tid, pr[q]);
-  OwnB own;
-  load_own(c.za, own);
-#pragma unroll
-  for (int q = 0; q < 3; q++) write_plane<RG>(d, st, ring, c.za - 1 + q, tid, pr[q]);
-  PlaneRegs<RG> nxt = pr[3];
-
-#pragma unroll 1
-  for (int k = c.za; k < c.zb; k++) {
-    __syncthreads();                  // planes <= k + 1 are in the ring; every wave is done with plane k - 2 (the slot of k + 2)
-    write_plane<RG>(d, st, ring, k + 2, tid, nxt);
-    load_plane<RG>(d, st, fwd, flags, k + 3, tid, nxt);
-    const OwnB cur = own;
-    load_own(k + 1, own);
-    if (!live_xy) continue;
-    const unsigned o4 = oxy4 + (unsigned)__mul24(k, d.sz) * 4u;
-    const bool border = border_xy | ((unsigned)(k - 1) >= (unsigned)(d.Z - 2));
-    const int kg = k + d.zg;
-    const bool deep = deep_at(k);
-    const v3 ctr = mk3((float)i + 0.5f, (float)j + 0.5f, (float)kg + 0.5f);
-    const v3 u = mk3(0.5f * (cur.ux0 + cur.ux1), 0.5f * (cur.uy0 + cur.uy1), 0.5f * (cur.uz0 + cur.uz1));
-    const int own_idx = RG::slot(k) + c_in;
-    const float sv = cur.s, f = cur.f, blo = cur.lo, bhi = cur.hi;
-    // fluid cell <=> its word of the masked ring is not the mask word -- for a border cell of the array too (the tile kernel
-    // reads those cells' flags from memory: a predicated load, whose join would drain this loop's prefetches in every wave
-    // that holds the column x = 0)
-    const bool fl = !is_mask(ring[own_idx]);
-    float bwd = border ? 0.0f : f;
-    if (fl && !border) {
-      bool slow = true;
-      if (deep) {
-        v3 p; int ei, ep;
-        const bool ok = trace_ring<RG, FAST>(ring, cb, d.zg, own_idx, ctr, u, a.dt, p, ei, ep);
-        const float r = lerp_ring<RG, FAST>(ring, cb, d.zg, ok ? p : ctr);
-        if (ok && !is_mask(r)) { bwd = r; slow = false; }
-      }
-      if (slow) { v3 back; bwd = sl_euler_ours<true>(a, flags, U, fwd, -a.dt, i, j, k, back); }
-    }
-    // MacCormackCorrect has no border test; the unsuffixed 0.5 makes the reference evaluate the correction in double and
-    // round once (tfluids.cc:231)
-    float v = f;
-    if (fl) v = FAST ? __builtin_fmaf((float)half_strength, sv - bwd, f) : (float)((double)f + half_strength * (double)(sv - bwd));
-    if (!border) v = (blo > bhi) ? f : fclampf(v, blo, bhi);
-    stg(dst, o4, v);
-  }
-  // the setConstVals that follows the advection in simulate() (tfl_host.hpp BcFold): a fix-up pass over the block's own cells
-  // inside the pair's box, behind the march -- a descriptor load inside the plane loop drains its prefetches, and
-  // 1 block in 16-32 gets here. A thread re-reads what it has stored itself (program order).
-  if (fold_blk && live_xy) {
-    const BcFold fold = *folda.dev;
-    if (fold_col(fold, i) && j >= fold.y0 && j <= fold.y1) {
-      const float* fb = fold.bc + c.b * cells;
-      const float* fm = fold.inv + c.b * cells;
-      for (int k = max(c.za, fold.z0); k <= min(c.zb - 1, fold.z1); k++) {
-        const unsigned o4 = oxy4 + (unsigned)__mul24(k, d.sz) * 4u;
-        stg(dst, o4, ldg(dst, o4) * ldg(fm, o4) + ldg(fb, o4));
-      }
-    }
-  }
-}
-
-// resident blocks of a kernel per CU (asked once per kernel and device)
-static int blocks_per_cu(const void* fn) {
-  struct Rec { const void* fn; int dev, n; };
-  static Rec recs[16];
-  static int nrec = 0;
-  int dev = 0; (void)hipGetDevice(&dev);
-  for (int q = 0; q < nrec; q++) if (recs[q].fn == fn && recs[q].dev == dev) return recs[q].n;
-  int n = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, 256, 0) != hipSuccess || n <= 0) n = 4;
-  if (nrec < 16) { recs[nrec].fn = fn; recs[nrec].dev = dev; recs[nrec].n = n; nrec++; }
-  return n;
-}
-static int device_cus() {
-  int dev = 0, n = 0; (void)hipGetDevice(&dev);
-  if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-  return n;
-}
-// chunk length: the blocks of a launch occupy the chip in rounds of `slots`; a block of c planes costs c plane steps + `fill`
-// staging-only planes (a sixth of a step each) + ~2 steps of prologue latency
-static int pick_chunk(long long cols, int na, int nb, int slots, int fill, const char* env) {
-  if (const char* e = getenv(env)) if (atoi(e) > 0) return atoi(e);
-  int best_c = 8; double best = -1.0;
-  for (int c = 2; c <= 128; c++) {
-    const long long blocks = cols * ((na + c - 1) / c + (nb + c - 1) / c);
-    const double cost = (double)((blocks + slots - 1) / slots) * (c + fill / 6.0 + 2.0);
-    if (best < 0.0 || cost < best) { best = cost; best_c = c; }
-  }
-  return best_c;
-}
-
-template <bool FAST>
-void launch(hipStream_t st, bool two_pass, const AdvArgs& a, int B, const float* s, const float* U, const float* flags, float* fwd,
-            float* bounds, float* dst, int stages) {
-  const Dom& d = a.d;
-  const bool pa = stages & 2, pb = two_pass && (stages & 4);
-  float* outA = two_pass ? fwd : dst;
-  const int cxn = (d.X + TX - 1) / TX, cyn = (d.Y + TY - 1) / TY, na = d.n0, nb = d.nw - d.n0;
-  if ((long long)cxn * cyn * (na + nb) * B <= 0) return;
-  const long long cols = (long long)cxn * cyn * B;
-  if (pa) {
-    const void* fn = two_pass ? (const void*)k_scal3m_fwd<true, FAST> : (const void*)k_scal3m_fwd<false, FAST>;
-    const int cz = pick_chunk(cols, na, nb, device_cus() * blocks_per_cu(fn), 5, "TFL_SCAL3M_CZ_A");
-    const int chunks_a = (na + cz - 1) / cz, chunks = chunks_a + (nb + cz - 1) / cz;
-    TFL_TIMED_EXT("k_scalar_fwd", st);
-    if (two_pass) TFL_LAUNCH_EXT((k_scal3m_fwd<true, FAST>), (unsigned)(cols * chunks), dim3(TX, TY, 1), 0, st, a, cxn, cyn, cz, chunks_a, chunks, s, U, flags, outA, bounds);
-    else TFL_LAUNCH_EXT((k_scal3m_fwd<false, FAST>), (unsigned)(cols * chunks), dim3(TX, TY, 1), 0, st, a, cxn, cyn, cz, chunks_a, chunks, s, U, flags, outA, (float*)nullptr);
-  }
-  const BcFoldArg fold = pb ? take_fold() : no_fold();   // pass B writes the operator's result
-  if (pb) {
-    const int cz = pick_chunk(cols, na, nb, device_cus() * blocks_per_cu((const void*)k_scal3m_bwd<FAST>), 3, "TFL_SCAL3M_CZ_B");
-    const int chunks_a = (na + cz - 1) / cz, chunks = chunks_a + (nb + cz - 1) / cz;
-    TFL_TIMED_EXT("k_scalar_bwd", st);
-    TFL_LAUNCH_EXT((k_scal3m_bwd<FAST>), (unsigned)(cols * chunks), dim3(TX, TY, 1), 0, st, a, cxn, cyn, cz, chunks_a, chunks, (double)a.strength * 0.5,
-                   s, U, flags, (const float*)fwd, (const float*)bounds, dst, fold);
-  }
-}
-
-}  // namespace zm
+#ifdef TFL_EXPERIMENTS
+#include "advect_scalar3_march.inc"      // the z-marched form of the two passes (round 5: bit-identical, slower)
+#endif
 
 template <bool FAST>
 void launch(hipStream_t st, int shape, bool two_pass, const AdvArgs& a, int B, const float* s, const float* U, const float* flags,
@@ -859,12 +476,13 @@ void launch(hipStream_t st, int shape, bool two_pass, const AdvArgs& a, int B, c
 
 bool advect_scalar3(hipStream_t st, bool two_pass, const AdvArgs& a, int B, const float* s, const float* U, const float* flags,
                     float* fwd, float* bounds, float* dst, int stages) {
-  static const bool off = getenv("TFL_ADVECT_GATHER") != nullptr || getenv("TFL_SCALAR_GATHER") != nullptr;   // A/B switch: the round-2 gather kernels
+  static const bool off = exp_env("TFL_ADVECT_GATHER") != nullptr || exp_env("TFL_SCALAR_GATHER") != nullptr;   // A/B switch: the round-2 gather kernels
   static const int tzsel = getenv("TFL_SCAL3_TZ") ? atoi(getenv("TFL_SCAL3_TZ")) : 0;   // 0 = per pass and grid size (launch)
   const Dom& d = a.d;
   // 24-bit multiplies address the tile and the planes; 32-bit BYTE offsets the cells of the three velocity channels
   if (off || a.outside || d.Z < 3 || (long long)d.X * d.Y * 4 >= (1 << 24) || 12ll * d.sc >= (1ll << 32)) return false;
-  // the z-marched kernels (round 5): opt-in, TFL_SCAL3_MARCH=1 -- bit-identical, one staging pass per plane, and SLOWER than the
+#ifdef TFL_EXPERIMENTS
+  // the z-marched kernels (round 5): TFL_SCAL3_MARCH=1 -- bit-identical, one staging pass per plane, and SLOWER than the
   // tile kernels (profiles/r05_advect_experiments.txt: pass A 29.5 vs 25.3 us at 128^3, 176 vs 162 at 256^3; pass B 21.3 vs
   // 20.8, 143 vs 141): these passes run at the length of their instruction streams, and the ring addressing + the per-plane
   // staging bookkeeping make the marched stream LONGER per cell (345 against 274 vector instructions in pass A)
@@ -874,6 +492,7 @@ bool advect_scalar3(hipStream_t st, bool two_pass, const AdvArgs& a, int B, cons
     else zm::launch<false>(st, two_pass, a, B, s, U, flags, fwd, bounds, dst, stages);
     return true;
   }
+#endif
   if (a.fast) launch<true>(st, tzsel, two_pass, a, B, s, U, flags, fwd, bounds, dst, stages);
   else launch<false>(st, tzsel, two_pass, a, B, s, U, flags, fwd, bounds, dst, stages);
   return true;

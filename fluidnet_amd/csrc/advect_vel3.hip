@@ -53,7 +53,7 @@ namespace {
 
 bool advect_vel3(hipStream_t st, bool two_pass, const AdvArgs& a, int B, const float* U, const float* flags, float* fwd,
                  float* dst, int stages) {
-  static const bool off = getenv("TFL_ADVECT_GATHER") != nullptr;   // A/B switch: the round-2 gather kernels
+  static const bool off = exp_env("TFL_ADVECT_GATHER") != nullptr;   // A/B switch: the round-2 gather kernels
   static const int kz_env = getenv("TFL_VEL3_KZ") ? atoi(getenv("TFL_VEL3_KZ")) : 0;
   const Dom& d = a.d;
   // 24-bit multiplies address the planes (4*X*Y < 2^24); 32-bit BYTE offsets address the cells of all three channels
@@ -66,7 +66,7 @@ bool advect_vel3(hipStream_t st, bool two_pass, const AdvArgs& a, int B, const f
   // fold (and the sparse setConstVals pair's) -- in the two-plane kernel it costs the fifth wave per SIMD -- and at 256^3 the
   // one-plane pass B with the force (~320 us) beats the two-plane one plus k_add_buoyancy and two k_apply_bcs_indexed
   // (291 + 94 + 11 us). Pass A stays two-plane. TFL_VEL3_KZ_B=2 keeps the old split.
-  static const int kzb_env = getenv("TFL_VEL3_KZ_B") ? atoi(getenv("TFL_VEL3_KZ_B")) : 0;
+  static const int kzb_env = exp_env("TFL_VEL3_KZ_B") ? atoi(exp_env("TFL_VEL3_KZ_B")) : 0;
   const bool b_shallow = deep && two_pass && (stages & 4) && g_buoy.rho && kzb_env != 2;
   if (deep && b_shallow) {
     if (stages & 2) kz2::launch(st, two_pass, a, B, U, flags, fwd, dst, stages & ~4);

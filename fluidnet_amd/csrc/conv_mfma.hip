@@ -281,8 +281,8 @@ static void launch_mfma(hipStream_t st, const Dom& d, int B, const float* in, co
     }
   }
   TFL_TIMED_EXT(TAIL ? "k_conv3_mfma_tail" : (IN_PLANAR ? "k_conv3_mfma_in" : "k_conv3_mfma"), st);
-  static const int dbg = getenv("TFL_CONV_DEBUG") ? atoi(getenv("TFL_CONV_DEBUG")) : 0;
-  static const bool want_trace = getenv("TFL_CONV_TRACE") != nullptr;
+  static const int dbg = exp_env("TFL_CONV_DEBUG") ? atoi(exp_env("TFL_CONV_DEBUG")) : 0;
+  static const bool want_trace = exp_env("TFL_CONV_TRACE") != nullptr;
   if (want_trace) {
     // development aid: per-block phase timestamps of this launch, summarised on stderr (synchronises!)
     unsigned long long* dev = nullptr;

@@ -58,11 +58,13 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void glb_void;
 
+#ifdef TFL_EXPERIMENTS      // geometry of the tile kernel (conv_mfma16_exp.inc)
 constexpr int kTX = 32, kTY = 4, kTZ = 4;                 // block tile (voxels)
 constexpr int kNY = 4, kNZ = 2;                           // output rows of a wave: 16 x kNY x kNZ
 constexpr int kHX = kTX + 2, kHY = kTY + 2, kHZ = kTZ + 2;
 constexpr int kPlane2 = kHY * 2 * kHX;                    // 16-byte slots of one staged h2 plane (two row-terms per row)
 constexpr int kDma = (kPlane2 + 63) / 64;                 // LDS-DMA instructions (64 slots each) per plane
+#endif
 constexpr float kHalfMax = 65504.0f;
 
 enum { kModeIn = 0, kModeMid = 1, kModeTail = 2 };
@@ -76,7 +78,7 @@ enum { kModeIn = 0, kModeMid = 1, kModeTail = 2 };
 #endif
 
 // tail pack (tfl_model::tail_pack): {bias3[8], w4[8][8] (out, in), b4[8], w5[8], b5[1]}
-constexpr int kTailW4 = 8, kTailB4 = 72, kTailW5 = 80, kTailB5 = 88, kTailPost4 = 89;   // + post4 (conv3_m16_pack_tail)
+[[maybe_unused]] constexpr int kTailW4 = 8, kTailB4 = 72, kTailW5 = 80, kTailB5 = 88, kTailPost4 = 89;   // + post4 (conv3_m16_pack_tail)
 
 struct MIn {            // fused network input (first layer): {pDiv/scale, div/scale, occupancy(flags)}
   const float* pDiv;    // [B][1][Z][Y][X]
@@ -135,10 +137,12 @@ __device__ __forceinline__ void stagger_start(int units, uint4* lds) {
   __syncthreads();
   for (int i = 0; i < n; i++) __builtin_amdgcn_s_sleep(1);
 }
+#ifdef TFL_EXPERIMENTS
 static int stagger_units(const char* name, int dflt) {
   const char* e = getenv(name);
   return e ? atoi(e) : dflt;
 }
+#endif
 
 // a + b after v_permlane32_swap / v_permlane16_swap of the pair: the sum over the two lane halves (32) or over the odd /
 // even 16-lane row pairs (16) of a in the lanes that keep their a, of b in the others (the tail's reduce-scatter).
@@ -155,244 +159,6 @@ __device__ __forceinline__ float swap_sum16(float a, float b) {
   return __builtin_bit_cast(float, u0) + __builtin_bit_cast(float, u1);
 }
 
-// MODE: kModeIn (inputs built from pDiv / div / flags, 1 row-term per input row), kModeMid (h2 in, h2 out),
-// kModeTail (h2 in, + the two 1x1x1 layers, planar fp32 pressure out).
-// wfrag: [9 (dz, dy)][RT][64 lanes] x 16 B -- the A fragments (weights), built by conv3_m16_pack_weights.
-// A block works through `nt` consecutive z-tiles of one (x, y) tile column: the weight fragments (18 KB per wave) are
-// fetched once per block instead of once per tile.
-template <int MODE>
-__global__ __launch_bounds__(256, TFL_M16_LB) void k_conv3_m16(Dom d, int tiles_x, int tiles_y, int tiles_z, int nt, int n_chunks,
-                                                      const uint4* __restrict__ in, const uint4* __restrict__ wfrag,
-                                                      const float* __restrict__ bias, void* __restrict__ outv, float post,
-                                                      MIn cin, unsigned long long* __restrict__ range_err) {
-  extern __shared__ __attribute__((aligned(16))) uint4 lds[];
-  constexpr bool FIRST = MODE == kModeIn, TAIL = MODE == kModeTail;
-  constexpr int RT = FIRST ? 1 : 2;                       // row-terms per input row
-  constexpr int kRows = kHZ * kHY * RT, kItems = kRows * kHX;
-  constexpr int kIter = (kItems + 255) / 256;
-  // XCD-aware order: consecutive block ids go round-robin over the 8 XCDs; give each XCD a contiguous run of chunks
-  const int per_xcd = (n_chunks + 7) / 8;
-  const int chunk = (int)(blockIdx.x % 8) * per_xcd + (int)(blockIdx.x / 8);
-  if (chunk >= n_chunks) return;
-  int t = chunk;
-  const int tx = t % tiles_x; t /= tiles_x;
-  const int ty = t % tiles_y; t /= tiles_y;
-  const int chunks_z = (tiles_z + nt - 1) / nt;
-  const int tzc = t % chunks_z;
-  const int b = t / chunks_z;
-  const int x0 = tx * kTX, y0 = ty * kTY;
-  const long long cells = d.sc;
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  bool clipped = false;
-
-  // ---- weights: 9 * RT A fragments per lane -----------------------------------------------------------------------------
-  h8 W[9][RT];
-#pragma unroll
-  for (int p = 0; p < 9; p++)
-#pragma unroll
-    for (int r = 0; r < RT; r++) {
-      const uint4 v = wfrag[(p * RT + r) * 64 + lane];
-      W[p][r] = __builtin_bit_cast(h8, v);
-    }
-  float in_scale = 1.0f, inv_scale = 0.0f;
-  bool scale_in_range = false;
-  if (FIRST) {
-    // lib/modules/variance.lua:44-76 (n-1) + Sqrt, as model.hip scale_from_stats
-    const double s1 = cin.stats[b * 2], s2 = cin.stats[b * 2 + 1], n = cin.count;
-    in_scale = (float)sqrt(fmax(n * s2 - s1 * s1, 0.0) / (n * (n - 1.0)));
-    scale_in_range = in_scale >= 0x1p-12f && in_scale <= 0x1p21f;     // wave-uniform
-    inv_scale = scale_in_range ? rcp_refined(in_scale) : 0.0f;
-  }
-  const int wx = wave & 1, wz = wave >> 1;
-  const int nn = lane & 15, g = lane >> 4;
-  const int lane_slot = wx * 16 + nn + (g < 3 ? g : 0);
-  const int x = x0 + wx * 16 + nn;
-  const int c0 = 2 * g, c1 = 2 * g + 1;
-  const float bias0 = bias[c0], bias1 = bias[c1];
-  // z-window (tfl_device.hpp Dom): the z-tiles cover the plane run [w0, w0 + n0) and then [w1, w1 + nw - n0)
-  const int tz_a = (d.n0 + kTZ - 1) / kTZ;
-  const int tz_hi = min(tiles_z, (tzc + 1) * nt);
-  // staging geometry of a lane's kDma slots of a plane (the same for every tile of the block's column)
-  int st_off[kDma];
-  unsigned st_ok = 0;
-  if (!FIRST) {
-#pragma unroll
-    for (int j = 0; j < kDma; j++) {
-      const int item = min(j * 64 + lane, kPlane2 - 1);
-      const int r = item / kHX, hx = item - r * kHX;
-      const int hy = r >> 1, tm = r & 1;
-      const int gx = x0 - 1 + hx, gy = y0 - 1 + hy;
-      st_off[j] = (min(max(gy, 0), d.Y - 1) * 2 + tm) * d.X + min(max(gx, 0), d.X - 1);
-      st_ok |= (gx >= 0 && gx < d.X && gy >= 0 && gy < d.Y) ? (1u << j) : 0u;
-    }
-  }
-  int ring = 0, prev_z0 = -0x40000000;
-
-#pragma unroll 1
-  for (int tz = tzc * nt; tz < tz_hi; tz++) {
-    const int z0 = tz < tz_a ? d.w0 + tz * kTZ : d.w1 + (tz - tz_a) * kTZ;
-    const int z_end = tz < tz_a ? d.w0 + d.n0 : d.w1 + (d.nw - d.n0);
-    if (tz > tzc * nt) __syncthreads();       // every wave is done with the previous tile's fragments
-    // ---- staging: halo tile [kHZ][kHY][RT][kHX] of 16-byte slots, zero outside the grid ----------------------------------
-    if (FIRST) {
-      float ld[kIter][3];
-      bool okv[kIter];
-#pragma unroll
-      for (int i = 0; i < kIter; i++) {
-        const int item = min(tid + 256 * i, kItems - 1);
-        const int r = item / kHX, hx = item - r * kHX;
-        const int hz = r / kHY, hy = r - hz * kHY;
-        const int gx = x0 - 1 + hx, gy = y0 - 1 + hy, gz = z0 - 1 + hz;
-        okv[i] = gx >= 0 && gx < d.X && gy >= 0 && gy < d.Y && gz >= 0 && gz < d.Z;
-        const long long o = (long long)b * cells + TFL_AT(d, min(max(gx, 0), d.X - 1), min(max(gy, 0), d.Y - 1), min(max(gz, 0), d.Z - 1));
-        ld[i][0] = cin.pDiv[o]; ld[i][1] = cin.div[o]; ld[i][2] = cin.flags[o];
-      }
-#pragma unroll
-      for (int i = 0; i < kIter; i++) {
-        const int item = tid + 256 * i;
-        // the net input is built here: ApplyScale(true) = CDivTable (apply_scale.lua:24-30), FlagsToOccupancy
-        // (generic/tfluids.cu:355-371); x / scale bit-equal to `/` as in conv_valu.hip
-        float v0, v1;
-        if (scale_in_range) { v0 = div_by<1>(ld[i][0], in_scale, inv_scale); v1 = div_by<1>(ld[i][1], in_scale, inv_scale); }
-        else { v0 = ld[i][0] / in_scale; v1 = ld[i][1] / in_scale; }
-        const int f = (int)ld[i][2];
-        const float occ = (f == kFluid) ? 0.0f : ((f == kObstacle) ? 1.0f : -1.0f);
-        const float k0 = __builtin_fminf(__builtin_fmaxf(v0, -kHalfMax), kHalfMax), k1 = __builtin_fminf(__builtin_fmaxf(v1, -kHalfMax), kHalfMax);
-        clipped = clipped || (okv[i] && (k0 != v0 || k1 != v1));
-        h8 s = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (okv[i]) {
-          _Float16 ph, pl, dh, dl;
-          split_h(k0, ph, pl); split_h(k1, dh, dl);
-          s[0] = ph; s[1] = dh; s[2] = (_Float16)occ; s[3] = pl; s[4] = dl;
-        }
-        if (item < kItems) lds[item] = __builtin_bit_cast(uint4, s);
-      }
-    } else {
-      // LDS-DMA (global_load_lds_dwordx4: 64 consecutive slots per instruction, no staging registers): wave w brings in
-      // the new plane hz = 2 + w; planes 0 and 1 are the previous tile's planes 4 and 5 and stay where they are (ring
-      // of 6 plane slots) unless the tile does not continue the previous one
-      const bool fresh = z0 != prev_z0 + kTZ;
-      const uint4* src = in + (long long)b * cells * 2;
-      const uint4* zero = wfrag + 9 * RT * 64;             // 16 zero bytes behind the fragments
-#pragma unroll
-      for (int pass = 0; pass < 2; pass++) {
-        if (pass == 0 && !(fresh && wave < 2)) continue;   // wave-uniform
-        const int hz = pass == 0 ? wave : 2 + wave;
-        const int gz = z0 - 1 + hz;
-        const bool z_ok = gz >= 0 && gz < d.Z;
-        const uint4* psrc = src + (long long)min(max(gz, 0), d.Z - 1) * d.Y * 2 * d.X;
-        uint4* pdst = lds + ((ring + hz) % kHZ) * kPlane2;
-#pragma unroll
-        for (int j = 0; j < kDma; j++) {
-          const uint4* gp = (z_ok && ((st_ok >> j) & 1)) ? psrc + st_off[j] : zero;
-          if (j * 64 + lane < kPlane2)
-            __builtin_amdgcn_global_load_lds((glb_void*)gp, (lds_void*)(pdst + j * 64), 16, 0, 0);
-        }
-      }
-    }
-    __syncthreads();
-
-    // ---- main loop: wave = (x half, z pair); every (input row, term) fragment feeds up to 9 MFMAs ----------------------
-    const uint4* fb[kNZ + 2];                 // the wave's four input planes (ring slots)
-#pragma unroll
-    for (int rz = 0; rz < kNZ + 2; rz++)
-      fb[rz] = lds + (FIRST ? wz * kNZ + rz : (ring + wz * kNZ + rz) % kHZ) * (kHY * RT * kHX) + lane_slot;
-    f4 acc[kNZ][kNY];
-#pragma unroll
-    for (int a = 0; a < kNZ; a++)
-#pragma unroll
-      for (int c = 0; c < kNY; c++) acc[a][c] = (f4){0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-    for (int rz = 0; rz < kNZ + 2; rz++)
-#pragma unroll
-      for (int ry = 0; ry < kNY + 2; ry++)
-#pragma unroll
-        for (int tm = 0; tm < RT; tm++) {
-          const h8 f = (TFL_M16_ABL & 8) ? W[(rz + ry) % 9][tm] : __builtin_bit_cast(h8, fb[rz][(ry * RT + tm) * kHX]);
-#pragma unroll
-          for (int dz = 0; dz < 3; dz++)
-#pragma unroll
-            for (int dy = 0; dy < 3; dy++) {
-              const int oz = rz - dz, oy = ry - dy;
-              if (oz >= 0 && oz < kNZ && oy >= 0 && oy < kNY) {
-                if (TFL_M16_ABL & 2) { if (dz == 0 && dy == 0) acc[oz][oy] += __builtin_bit_cast(f4, f) + __builtin_bit_cast(f4, W[dz * 3 + dy][tm]); }
-                else acc[oz][oy] = __builtin_amdgcn_mfma_f32_16x16x32_f16(W[dz * 3 + dy][tm], f, acc[oz][oy], 0, 0, 0);
-              }
-            }
-        }
-
-    // ---- epilogue: recombine, bias, ReLU; split again (h2 out) or run the 1x1x1 tail; the four rows of a plane are
-    // transposed across the lane groups so that a lane stores the 16 bytes of one (row, voxel, term) -----------------------
-    static_assert(kNY == 4, "the epilogue transposes four rows across the four lane groups");
-#pragma unroll
-    for (int oz = 0; oz < kNZ; oz++) {
-      const int z = z0 + wz * kNZ + oz;
-      const int y = y0 + g;
-      const bool live = x < d.X && y < d.Y && z < z_end && (!(TFL_M16_ABL & 4) || post == 12345.0f);
-      float h0[kNY], h1[kNY];
-#pragma unroll
-      for (int oy = 0; oy < kNY; oy++) {
-        const f4 a = acc[oz][oy];
-        h0[oy] = __builtin_fmaxf((a[0] + a[1] * 0x1p-11f) * post + bias0, 0.0f);
-        h1[oy] = __builtin_fmaxf((a[2] + a[3] * 0x1p-11f) * post + bias1, 0.0f);
-      }
-      if (!TAIL) {
-        uint32_t H[4], L[4];
-        bool over = false;
-#pragma unroll
-        for (int oy = 0; oy < kNY; oy++) {
-          const float k0 = __builtin_fminf(h0[oy], kHalfMax), k1 = __builtin_fminf(h1[oy], kHalfMax);
-          over = over || ((k0 != h0[oy] || k1 != h1[oy]) && x < d.X && y0 + oy < d.Y && z < z_end);
-          _Float16 hh0, hl0, hh1, hl1;
-          split_h(k0, hh0, hl0); split_h(k1, hh1, hl1);
-          const h2v ph = {hh0, hh1}, pl = {hl0, hl1};
-          H[oy] = __builtin_bit_cast(uint32_t, ph); L[oy] = __builtin_bit_cast(uint32_t, pl);
-        }
-        clipped = clipped || over;
-        transpose4(H); transpose4(L);
-        if (live) {
-          uint4* orow = reinterpret_cast<uint4*>(outv) + (((long long)b * d.Z + z) * d.Y + y) * 2 * d.X + x;
-          orow[0] = make_uint4(H[0], H[1], H[2], H[3]);
-          orow[d.X] = make_uint4(L[0], L[1], L[2], L[3]);
-        }
-      } else {
-        // tail pack (tfl_model::tail_pack): w4 [8][8] (out, in), b4, w5, b5 behind the k3 layer's bias
-        // reduce-scatter of the 8 partial sums q_j over the four lane groups: after the exchange with lane ^ 32 a lane
-        // keeps j in {4 (g >> 1) .. +3}, after lane ^ 16 the two j = 4 (g >> 1) + 2 (g & 1) + {0, 1}
-        const int j0 = 4 * (g >> 1) + 2 * (g & 1);
-        const float b4a = bias[kTailB4 + j0], b4b = bias[kTailB4 + j0 + 1], w5a = bias[kTailW5 + j0], w5b = bias[kTailW5 + j0 + 1];
-        float psel = 0.0f;
-#pragma unroll
-        for (int oy = 0; oy < kNY; oy++) {
-          float q[8];
-#pragma unroll
-          for (int j = 0; j < 8; j++) q[j] = bias[kTailW4 + j * 8 + c0] * h0[oy] + bias[kTailW4 + j * 8 + c1] * h1[oy];
-          float r4[4];
-#pragma unroll
-          for (int j = 0; j < 4; j++) {       // lanes g >> 1 == 0 keep j 0..3 and send 4..7; the others the reverse
-            const float send = (g >> 1) ? q[j] : q[4 + j];
-            const float keep = (g >> 1) ? q[4 + j] : q[j];
-            r4[j] = keep + __shfl_xor(send, 32);
-          }
-          float r2[2];
-#pragma unroll
-          for (int j = 0; j < 2; j++) {
-            const float send = (g & 1) ? r4[j] : r4[2 + j];
-            const float keep = (g & 1) ? r4[2 + j] : r4[j];
-            r2[j] = keep + __shfl_xor(send, 16);
-          }
-          float pp = w5a * __builtin_fmaxf(r2[0] + b4a, 0.0f) + w5b * __builtin_fmaxf(r2[1] + b4b, 0.0f);
-          pp += __shfl_xor(pp, 16);
-          pp += __shfl_xor(pp, 32);
-          psel = g == oy ? pp : psel;         // lane group g stores row g
-        }
-        if (live) reinterpret_cast<float*>(outv)[(long long)b * cells + TFL_AT(d, x, y, z)] = psel + bias[kTailB5];
-      }
-    }
-    ring = (ring + kTZ) % kHZ; prev_z0 = z0;
-  }
-  if (clipped) atomicAdd(range_err, 1ull);
-}
 
 // =====================================================================================================================
 // z-MARCHED form of the 8 -> 8 layers (h2 in): a block owns a 32 x 8 column of the plane and walks a chunk of z. Input
@@ -406,7 +172,7 @@ constexpr int kMHX = kMX + 2, kMHY = kMY + 2;
 constexpr int kMPlane = kMHY * 2 * kMHX;                  // 680 slots of a staged plane: [row][term][x]
 constexpr int kMDma = 3;                                  // DMA instructions per wave and plane: 4 x 3 x 64 = 768 slots
 constexpr int kMPitch = 4 * kMDma * 64;                   // ring pitch (the 88 slots behind the plane take the idle lanes)
-constexpr int kMRing = 4, kMAhead = 3;
+[[maybe_unused]] constexpr int kMRing = 4, kMAhead = 3;      // (k_conv3_m16z's ring, conv_mfma16_exp.inc)
 
 // one LDS-DMA instruction: 64 lanes x 16 bytes from per-lane global addresses to LDS bytes [lds_byte, lds_byte + 1024)
 __device__ __forceinline__ void dma16(const void* gsrc, uint32_t lds_byte) {
@@ -415,199 +181,6 @@ __device__ __forceinline__ void dma16(const void* gsrc, uint32_t lds_byte) {
                : "=&s"(keep) : "v"(gsrc), "s"(lds_byte) : "memory");
 }
 
-#ifndef TFL_M16Z_LB
-#define TFL_M16Z_LB 2
-#endif
-template <bool TAIL>
-__global__ __launch_bounds__(256, TFL_M16Z_LB) void k_conv3_m16z(Dom d, int cols_x, int cols_y, int cz, int chunks_a, int chunks,
-                                                                int n_blocks, const uint4* __restrict__ in,
-                                                                const uint4* __restrict__ wfrag, const float* __restrict__ bias,
-                                                                void* __restrict__ outv, float post,
-                                                                unsigned long long* __restrict__ range_err) {
-  extern __shared__ __attribute__((aligned(16))) uint4 lds[];
-  const int per_xcd = (n_blocks + 7) / 8;
-  const int blk = (int)(blockIdx.x % 8) * per_xcd + (int)(blockIdx.x / 8);
-  if (blk >= n_blocks) return;
-  int t = blk;
-  const int cx = t % cols_x; t /= cols_x;
-  const int cy = t % cols_y; t /= cols_y;
-  const int ch = t % chunks;
-  const int b = t / chunks;
-  // z-window: chunks [0, chunks_a) tile the plane run [w0, w0 + n0), the others [w1, w1 + nw - n0)
-  const int zc0 = ch < chunks_a ? d.w0 + ch * cz : d.w1 + (ch - chunks_a) * cz;
-  const int z_end = ch < chunks_a ? d.w0 + d.n0 : d.w1 + (d.nw - d.n0);
-  const int nz = min(cz, z_end - zc0);                  // output planes of this block
-  const int nsteps = nz + 2;
-  const int x0 = cx * kMX, y0 = cy * kMY;
-  const long long cells = d.sc;
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  bool clipped = false;
-
-  h8 W[9][2];
-#pragma unroll
-  for (int p = 0; p < 9; p++)
-#pragma unroll
-    for (int r = 0; r < 2; r++) W[p][r] = __builtin_bit_cast(h8, wfrag[(p * 2 + r) * 64 + lane]);
-
-  // staging geometry of the lane's kMDma slots of a plane
-  const uint4* src = in + (long long)b * cells * 2;
-  const uint4* zero = wfrag + 9 * 2 * 64;                // 16 zero bytes behind the fragments
-  int st_off[kMDma];
-  unsigned st_ok = 0;
-#pragma unroll
-  for (int j = 0; j < kMDma; j++) {
-    const int item = (wave * kMDma + j) * 64 + lane;
-    const int r = min(item, kMPlane - 1) / kMHX, hx = min(item, kMPlane - 1) - r * kMHX;
-    const int hy = r >> 1, tm = r & 1;
-    const int gx = x0 - 1 + hx, gy = y0 - 1 + hy;
-    st_off[j] = (min(max(gy, 0), d.Y - 1) * 2 + tm) * d.X + min(max(gx, 0), d.X - 1);
-    st_ok |= (item < kMPlane && gx >= 0 && gx < d.X && gy >= 0 && gy < d.Y) ? (1u << j) : 0u;
-  }
-  const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void*)lds;
-  auto issue = [&](int q) {          // input plane q of the chunk (z = zc0 - 1 + q) -> ring slot q % kMRing
-    const int gz = zc0 - 1 + q;
-    const bool z_ok = q < nsteps && gz >= 0 && gz < d.Z;
-    const uint4* psrc = src + (long long)min(max(gz, 0), d.Z - 1) * d.Y * 2 * d.X;
-#pragma unroll
-    for (int j = 0; j < kMDma; j++) {
-      if ((TFL_M16_ABL & 1) && q >= kMAhead) break;
-      const uint4* gp = (z_ok && ((st_ok >> j) & 1)) ? psrc + st_off[j] : zero;
-      dma16(gp, __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)(((q % kMRing) * kMPitch + (wave * kMDma + j) * 64) * 16)));
-    }
-  };
-
-  const int wx = wave & 1, wy = wave >> 1;
-  const int nn = lane & 15, g = lane >> 4;
-  const int lane_slot = (wy * 4 * 2) * kMHX + wx * 16 + nn + (g < 3 ? g : 0);
-  const int x = x0 + wx * 16 + nn;
-  const int y = y0 + wy * 4 + g;                          // the row this lane group stores (after the transpose)
-  const int c0 = 2 * g, c1 = 2 * g + 1;
-  const float bias0 = bias[c0], bias1 = bias[c1];
-  const int j0 = 4 * (g >> 1) + 2 * (g & 1);              // TAIL: the two hidden channels this lane finishes
-  float b4a = 0.0f, b4b = 0.0f, w5a = 0.0f, w5b = 0.0f, b5 = 0.0f;
-  if (TAIL) {
-    b4a = bias[kTailB4 + j0]; b4b = bias[kTailB4 + j0 + 1]; w5a = bias[kTailW5 + j0]; w5b = bias[kTailW5 + j0 + 1];
-    b5 = bias[kTailB5];
-  }
-
-  f4 A0[4], A1[4], A2[4];
-#pragma unroll
-  for (int r = 0; r < 4; r++) A0[r] = A1[r] = A2[r] = (f4){0.0f, 0.0f, 0.0f, 0.0f};
-
-  // finish output plane z from A2: recombine, bias, ReLU, then split + transposed 16-byte stores, or the 1x1x1 tail
-  auto finish = [&](int z) {
-    const bool live = x < d.X && y < d.Y && (!(TFL_M16_ABL & 4) || post == 12345.0f);
-    if (TFL_M16_ABL & 32) {           // stores only (one accumulator word keeps the MFMAs alive)
-      if (live) {
-        const uint32_t w0 = __builtin_bit_cast(uint32_t, A2[0][0] + A2[1][1] + A2[2][2] + A2[3][3]);
-        if (!TAIL) {
-          uint4* orow = reinterpret_cast<uint4*>(outv) + (((long long)b * d.Z + z) * d.Y + y) * 2 * d.X + x;
-          orow[0] = make_uint4(w0, 0, 0, 0); orow[d.X] = make_uint4(w0, 0, 0, 0);
-        } else {
-          reinterpret_cast<float*>(outv)[(long long)b * cells + TFL_AT(d, x, y, z)] = __builtin_bit_cast(float, w0);
-        }
-      }
-      return;
-    }
-    float h0[4], h1[4];
-#pragma unroll
-    for (int oy = 0; oy < 4; oy++) {
-      h0[oy] = __builtin_fmaxf((A2[oy][0] + A2[oy][1] * 0x1p-11f) * post + bias0, 0.0f);
-      h1[oy] = __builtin_fmaxf((A2[oy][2] + A2[oy][3] * 0x1p-11f) * post + bias1, 0.0f);
-    }
-    if (!TAIL) {
-      uint32_t H[4], L[4];
-      bool over = false;
-#pragma unroll
-      for (int oy = 0; oy < 4; oy++) {
-        const float k0 = __builtin_fminf(h0[oy], kHalfMax), k1 = __builtin_fminf(h1[oy], kHalfMax);
-        over = over || ((k0 != h0[oy] || k1 != h1[oy]) && x < d.X && y0 + wy * 4 + oy < d.Y);
-        _Float16 hh0, hl0, hh1, hl1;
-        split_h(k0, hh0, hl0); split_h(k1, hh1, hl1);
-        const h2v ph = {hh0, hh1}, pl = {hl0, hl1};
-        H[oy] = __builtin_bit_cast(uint32_t, ph); L[oy] = __builtin_bit_cast(uint32_t, pl);
-      }
-      clipped = clipped || over;
-      transpose4(H); transpose4(L);
-      if (live) {
-        uint4* orow = reinterpret_cast<uint4*>(outv) + (((long long)b * d.Z + z) * d.Y + y) * 2 * d.X + x;
-        orow[0] = make_uint4(H[0], H[1], H[2], H[3]);
-        orow[d.X] = make_uint4(L[0], L[1], L[2], L[3]);
-      }
-    } else {
-      // 8 -> 8 (k = 1) + ReLU, 8 -> 1: a lane holds two of the eight channels of its voxel. Partial sums q_j over its two
-      // channels, then a reduce-scatter over the four lane groups by register swaps: v_permlane32_swap(a, b) exchanges
-      // a's upper half with b's lower half, so (q_j, q_{4+j}) -> new_a + new_b = the two-group sum of q_j in the lower
-      // lanes and of q_{4+j} in the upper ones; v_permlane16_swap does the same between odd and even 16-lane rows.
-      float psel = 0.0f;
-#pragma unroll
-      for (int oy = 0; oy < 4; oy++) {
-        float r4[4];
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-          const float qa = bias[kTailW4 + j * 8 + c0] * h0[oy] + bias[kTailW4 + j * 8 + c1] * h1[oy];
-          const float qb = bias[kTailW4 + (4 + j) * 8 + c0] * h0[oy] + bias[kTailW4 + (4 + j) * 8 + c1] * h1[oy];
-          r4[j] = swap_sum32(qa, qb);
-        }
-        float r2[2];
-#pragma unroll
-        for (int j = 0; j < 2; j++) r2[j] = swap_sum16(r4[j], r4[2 + j]);
-        float pp = w5a * __builtin_fmaxf(r2[0] + b4a, 0.0f) + w5b * __builtin_fmaxf(r2[1] + b4b, 0.0f);
-        pp = swap_sum16(pp, pp);
-        pp = swap_sum32(pp, pp);
-        psel = g == oy ? pp : psel;           // lane group g stores row g
-      }
-      if (live) reinterpret_cast<float*>(outv)[(long long)b * cells + TFL_AT(d, x, y, z)] = psel + b5;
-    }
-  };
-
-  // one input plane: its 12 fragments against the weights of the output planes it reaches (MASK bit dz: plane q - dz)
-  auto plane = [&](auto mask_c, int q) {
-    constexpr int MASK = decltype(mask_c)::value;
-    const uint4* fb = lds + (q % kMRing) * kMPitch + lane_slot;
-#pragma unroll
-    for (int ry = 0; ry < 6; ry++)
-#pragma unroll
-      for (int tm = 0; tm < 2; tm++) {
-        const h8 f = (TFL_M16_ABL & 8) ? W[ry][tm] : __builtin_bit_cast(h8, fb[(ry * 2 + tm) * kMHX]);
-#pragma unroll
-        for (int dy = 0; dy < 3; dy++) {
-          const int oy = ry - dy;
-          if (oy < 0 || oy > 3) continue;
-          if (TFL_M16_ABL & 2) { if (dy == 0) A0[oy] += __builtin_bit_cast(f4, f); continue; }
-          if (MASK & 1) A0[oy] = __builtin_amdgcn_mfma_f32_16x16x32_f16(W[0 * 3 + dy][tm], f, A0[oy], 0, 0, 0);
-          if (MASK & 2) A1[oy] = __builtin_amdgcn_mfma_f32_16x16x32_f16(W[1 * 3 + dy][tm], f, A1[oy], 0, 0, 0);
-          if (MASK & 4) A2[oy] = __builtin_amdgcn_mfma_f32_16x16x32_f16(W[2 * 3 + dy][tm], f, A2[oy], 0, 0, 0);
-        }
-      }
-  };
-
-#pragma unroll
-  for (int q = 0; q < kMAhead; q++) issue(q);
-#pragma unroll 1
-  for (int q = 0; q < nsteps; q++) {
-    // plane q has landed once at most the (kMAhead - 1) younger planes' DMAs are outstanding (loads retire in order; the
-    // epilogue's stores share the counter and only make the wait stricter)
-    if (!(TFL_M16_ABL & 1)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((kMAhead - 1) * kMDma) : "memory");
-    if (!(TFL_M16_ABL & 64)) __syncthreads();   // every wave's part of plane q is in LDS; every wave is done reading plane q - 1
-    issue(q + kMAhead);               // into the slot of plane q - 1 (past the chunk: the zero page, keeps the count uniform)
-#pragma unroll
-    for (int r = 0; r < 4; r++) { A2[r] = A1[r]; A1[r] = A0[r]; A0[r] = (f4){0.0f, 0.0f, 0.0f, 0.0f}; }
-    const int mask = (q < nz ? 1 : 0) | ((q >= 1 && q <= nz) ? 2 : 0) | (q >= 2 ? 4 : 0);
-    switch (mask) {
-      case 1: plane(std::integral_constant<int, 1>(), q); break;
-      case 2: plane(std::integral_constant<int, 2>(), q); break;
-      case 3: plane(std::integral_constant<int, 3>(), q); break;
-      case 4: plane(std::integral_constant<int, 4>(), q); break;
-      case 5: plane(std::integral_constant<int, 5>(), q); break;
-      case 6: plane(std::integral_constant<int, 6>(), q); break;
-      default: plane(std::integral_constant<int, 7>(), q); break;
-    }
-    if (q >= 2) finish(zc0 + q - 2);
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the trailing zero-page DMAs must not outlive the block's LDS
-  if (clipped) atomicAdd(range_err, 1ull);
-}
 
 
 // =====================================================================================================================
@@ -627,243 +200,6 @@ constexpr int kPFrags = 14;                               // weight fragments: A
 #ifndef TFL_M16P_LB
 #define TFL_M16P_LB 2
 #endif
-#ifndef TFL_M16P_DEFER
-#define TFL_M16P_DEFER 0
-#endif
-// timing ablations of k_conv3_m16p (tools/ab_build.sh; results are garbage): 1 = no staging DMA after the first planes,
-// 2 = no MFMAs, 4 = no stores, 8 = no LDS fragment reads, 16 = no per-plane barrier / DMA wait, 32 = no epilogue arithmetic
-#ifndef TFL_M16P_ABL
-#define TFL_M16P_ABL 0
-#endif
-// TMF (TAIL only, round 5): the 8 -> 8 (k = 1) layer of the tail as ONE v_mfma_f32_16x16x16_f16 per output row instead of
-// 16 multiply-adds and a six-swap reduce-scatter per row on the vector ALUs (see finish below)
-template <bool TAIL, bool TMF = false>
-__global__ __launch_bounds__(256, TFL_M16P_LB) void k_conv3_m16p(Dom d, int cols_x, int cols_y, int cz, int chunks_a, int chunks,
-                                                                int n_blocks, const uint4* __restrict__ in,
-                                                                const uint4* __restrict__ wfrag, const float* __restrict__ bias,
-                                                                void* __restrict__ outv, float post,
-                                                                unsigned long long* __restrict__ range_err, int stag) {
-  extern __shared__ __attribute__((aligned(16))) uint4 lds[];
-  const int per_xcd = (n_blocks + 7) / 8;
-  const int blk = (int)(blockIdx.x % 8) * per_xcd + (int)(blockIdx.x / 8);
-  if (blk >= n_blocks) return;
-  stagger_start(stag, lds);
-  int t = blk;
-  const int cx = t % cols_x; t /= cols_x;
-  const int cy = t % cols_y; t /= cols_y;
-  const int ch = t % chunks;
-  const int b = t / chunks;
-  const int zc0 = ch < chunks_a ? d.w0 + ch * cz : d.w1 + (ch - chunks_a) * cz;
-  const int z_end = ch < chunks_a ? d.w0 + d.n0 : d.w1 + (d.nw - d.n0);
-  const int nz = min(cz, z_end - zc0);                  // output planes of this block
-  const int nsteps = nz + 2;                            // input planes zc0 - 1 .. zc0 + nz
-  const int x0 = cx * kMX, y0 = cy * kMY;
-  const long long cells = d.sc;
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  bool clipped = false;
-
-  h8 W[kPFrags];
-#pragma unroll
-  for (int f = 0; f < kPFrags; f++) W[f] = __builtin_bit_cast(h8, wfrag[f * 64 + lane]);
-
-  // staging geometry of the lane's kMDma slots of a plane (as k_conv3_m16z)
-  const uint4* src = in + (long long)b * cells * 2;
-  const uint4* zero = wfrag + kPFrags * 64;             // 16 zero bytes behind the fragments
-  int st_off[kMDma];
-  unsigned st_ok = 0;
-#pragma unroll
-  for (int j = 0; j < kMDma; j++) {
-    const int item = (wave * kMDma + j) * 64 + lane;
-    const int r = min(item, kMPlane - 1) / kMHX, hx = min(item, kMPlane - 1) - r * kMHX;
-    const int hy = r >> 1, tm = r & 1;
-    const int gx = x0 - 1 + hx, gy = y0 - 1 + hy;
-    st_off[j] = (min(max(gy, 0), d.Y - 1) * 2 + tm) * d.X + min(max(gx, 0), d.X - 1);
-    st_ok |= (item < kMPlane && gx >= 0 && gx < d.X && gy >= 0 && gy < d.Y) ? (1u << j) : 0u;
-  }
-  const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void*)lds;
-  auto issue = [&](int q) {          // input plane q of the chunk (z = zc0 - 1 + q) -> ring slot q % kPRing
-    const int gz = zc0 - 1 + q;
-    const bool z_ok = q < nsteps && gz >= 0 && gz < d.Z;
-    const uint4* psrc = src + (long long)min(max(gz, 0), d.Z - 1) * d.Y * 2 * d.X;
-#pragma unroll
-    for (int j = 0; j < kMDma; j++) {
-      const uint4* gp = (z_ok && ((st_ok >> j) & 1)) ? psrc + st_off[j] : zero;
-      dma16(gp, __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)(((q % kPRing) * kMPitch + (wave * kMDma + j) * 64) * 16)));
-    }
-  };
-
-  const int wx = wave & 1, wy = wave >> 1;
-  const int nn = lane & 15, g = lane >> 4;
-  // a lane's slot inside a plane for the three fragment kinds (input row 0 of the wave, term 0): K group g stands for
-  //   A: dx = g of the first plane (g = 3: dx 0 of the second)   B: dx 1, 2 of the second plane, dx 0, 1 of the third
-  //   C: dx 2 of the third plane, input rows +0, +1, +2 (g = 3: idle)
-  const int row0 = (wy * 4 * 2) * kMHX + wx * 16 + nn;
-  const int slotA = row0 + (g < 3 ? g : 0);
-  const int slotB = row0 + (g == 0 ? 1 : (g == 1 ? 2 : (g == 2 ? 0 : 1)));
-  const int slotC = row0 + 2 + (g < 3 ? g : 0) * 2 * kMHX;
-  const int x = x0 + wx * 16 + nn;
-  const int y = y0 + wy * 4 + g;                          // the row this lane group stores (after the transpose)
-  const int c0 = 2 * g, c1 = 2 * g + 1;
-  const float bias0 = bias[c0], bias1 = bias[c1];
-  const int j0 = 4 * (g >> 1) + 2 * (g & 1);              // TAIL: the two hidden channels this lane finishes
-  float b4a = 0.0f, b4b = 0.0f, w5a = 0.0f, w5b = 0.0f, b5 = 0.0f;
-  float w4lo[4][2], w4hi[4][2];       // TAIL: the lane's 16 weights of the 8 -> 8 (k = 1) layer, fetched ONCE (round 4, late: they
-  h4v A4 = {0, 0, 0, 0};              // TMF: the lane's A fragment of that layer (conv3_m16_pack_tail) and its post-scale
-  float post4 = 0.0f;
-  if (TAIL) {                         // were re-read from memory in every plane step, 16 loads + their waits behind the MFMAs)
-    b4a = bias[kTailB4 + j0]; b4b = bias[kTailB4 + j0 + 1]; w5a = bias[kTailW5 + j0]; w5b = bias[kTailW5 + j0 + 1];
-    b5 = bias[kTailB5];
-    if (TMF) {
-      A4 = __builtin_bit_cast(h4v, reinterpret_cast<const uint2*>(wfrag + (kPFrags * 64 + 1))[lane]);
-      post4 = bias[kTailPost4];
-    } else {
-#pragma unroll
-      for (int j = 0; j < 4; j++) {
-        w4lo[j][0] = bias[kTailW4 + j * 8 + c0]; w4lo[j][1] = bias[kTailW4 + j * 8 + c1];
-        w4hi[j][0] = bias[kTailW4 + (4 + j) * 8 + c0]; w4hi[j][1] = bias[kTailW4 + (4 + j) * 8 + c1];
-      }
-    }
-  }
-
-  // finish output plane z from its accumulators: recombine, bias, ReLU, then split + transposed 16-byte stores, or the tail
-  float hmax = 0.0f;                  // TMF: the largest activation the lane split for the matrix cores (range check at the end)
-  // TFL_M16P_DEFER (A/B build): a plane's stores are issued behind the NEXT step's barrier instead of at the end of its own
-  // step, where the `s_waitcnt vmcnt(0)` that guards the DMA of the next plane would wait for their acknowledgement too
-  uint4 dH = make_uint4(0u, 0u, 0u, 0u), dL = dH;
-  float dP = 0.0f;
-  int dz = -1;
-  auto flush = [&]() {
-    if (dz < 0 || !(x < d.X && y < d.Y)) return;
-    if (!TAIL) {
-      uint4* orow = reinterpret_cast<uint4*>(outv) + (((long long)b * d.Z + dz) * d.Y + y) * 2 * d.X + x;
-      orow[0] = dH; orow[d.X] = dL;
-    } else {
-      reinterpret_cast<float*>(outv)[(long long)b * cells + TFL_AT(d, x, y, dz)] = dP;
-    }
-  };
-  auto finish = [&](f4 (&A2)[4], int z) {
-    const bool live = x < d.X && y < d.Y;
-    float h0[4], h1[4];
-#pragma unroll
-    for (int oy = 0; oy < 4; oy++) {
-      h0[oy] = __builtin_fmaxf(__builtin_fmaf(__builtin_fmaf(A2[oy][1], 0x1p-11f, A2[oy][0]), post, bias0), 0.0f);
-      h1[oy] = __builtin_fmaxf(__builtin_fmaf(__builtin_fmaf(A2[oy][3], 0x1p-11f, A2[oy][2]), post, bias1), 0.0f);
-    }
-    if (!TAIL) {
-      uint32_t H[4], L[4];
-#pragma unroll                        // (hmax: cells outside the grid see zero inputs: their activations are ReLU(bias)-sized
-      for (int oy = 0; oy < 4; oy++) {   // and cannot fake a range error)
-        hmax = __builtin_fmaxf(__builtin_fmaxf(hmax, h0[oy]), h1[oy]);
-        split_pair(__builtin_fminf(h0[oy], kHalfMax), __builtin_fminf(h1[oy], kHalfMax), H[oy], L[oy]);
-      }
-      transpose4(H); transpose4(L);
-      if (TFL_M16P_DEFER) { dH = make_uint4(H[0], H[1], H[2], H[3]); dL = make_uint4(L[0], L[1], L[2], L[3]); dz = z; }
-      else if ((TFL_M16P_ABL & 4) ? (post == 12345.0f) : live) {
-        uint4* orow = reinterpret_cast<uint4*>(outv) + (((long long)b * d.Z + z) * d.Y + y) * 2 * d.X + x;
-        orow[0] = make_uint4(H[0], H[1], H[2], H[3]);
-        orow[d.X] = make_uint4(L[0], L[1], L[2], L[3]);
-      }
-    } else if (TMF) {
-      // 8 -> 8 (k = 1) + ReLU on the matrix cores, the split riding on the recombination: after it the lane holds channels
-      // 2g, 2g + 1 of ONE voxel -- exactly K elements 4g .. 4g + 3 = {c_h, c'_h, c_l, c'_l} of column n of a 16 x 16 x 16
-      // B operand. A (conv3_m16_pack_tail): row 2 j + t = w4[j][.] 2^e4 as {w_h, w_l}, the columns of the hi terms times
-      // 2^11, so D[2 j] + 2^-11 D[2 j + 1] = 2^(11 + e4) sum_c w4[j][c] a_c as in the k = 3 layers; the lane gets rows
-      // 4g .. 4g + 3 = both halves of hidden channels 2g, 2g + 1 of its voxel. Then 8 -> 1: two products per lane and a
-      // reduce-scatter of the four rows over the four lane groups (3 swaps: group g ends up with row g, the row it stores).
-      float pp[4];
-#pragma unroll
-      for (int oy = 0; oy < 4; oy++) {
-        hmax = __builtin_fmaxf(__builtin_fmaxf(hmax, h0[oy]), h1[oy]);
-        uint32_t H, L;
-        split_pair(__builtin_fminf(h0[oy], kHalfMax), __builtin_fminf(h1[oy], kHalfMax), H, L);
-        const uint2 bq = make_uint2(H, L);
-        const f4 dq = __builtin_amdgcn_mfma_f32_16x16x16f16(A4, __builtin_bit_cast(h4v, bq), (f4){0.0f, 0.0f, 0.0f, 0.0f}, 0, 0, 0);
-        const float ha = __builtin_fmaxf(__builtin_fmaf(__builtin_fmaf(dq[1], 0x1p-11f, dq[0]), post4, b4a), 0.0f);
-        const float hb = __builtin_fmaxf(__builtin_fmaf(__builtin_fmaf(dq[3], 0x1p-11f, dq[2]), post4, b4b), 0.0f);
-        pp[oy] = __builtin_fmaf(w5a, ha, w5b * hb);
-      }
-      const float r02 = swap_sum32(pp[0], pp[2]), r13 = swap_sum32(pp[1], pp[3]);   // lower half: rows 0 / 1, upper: rows 2 / 3
-      const float psel = swap_sum16(r02, r13);                                       // group g: row g, summed over the groups
-      if (TFL_M16P_DEFER) { dP = psel + b5; dz = z; }
-      else if (live) reinterpret_cast<float*>(outv)[(long long)b * cells + TFL_AT(d, x, y, z)] = psel + b5;
-    } else {
-      // 8 -> 8 (k = 1) + ReLU, 8 -> 1 on the vector ALUs (see k_conv3_m16z)
-      float psel = 0.0f;
-#pragma unroll
-      for (int oy = 0; oy < 4; oy++) {
-        float r4[4];
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-          const float qa = __builtin_fmaf(w4lo[j][0], h0[oy], w4lo[j][1] * h1[oy]);
-          const float qb = __builtin_fmaf(w4hi[j][0], h0[oy], w4hi[j][1] * h1[oy]);
-          r4[j] = swap_sum32(qa, qb);
-        }
-        float r2[2];
-#pragma unroll
-        for (int j = 0; j < 2; j++) r2[j] = swap_sum16(r4[j], r4[2 + j]);
-        float pp = __builtin_fmaf(w5a, __builtin_fmaxf(r2[0] + b4a, 0.0f), w5b * __builtin_fmaxf(r2[1] + b4b, 0.0f));
-        pp = swap_sum16(pp, pp);
-        pp = swap_sum32(pp, pp);
-        psel = g == oy ? pp : psel;           // lane group g stores row g
-      }
-      if (live) reinterpret_cast<float*>(outv)[(long long)b * cells + TFL_AT(d, x, y, z)] = psel + b5;
-    }
-  };
-
-#pragma unroll
-  for (int q = 0; q < 3; q++) issue(q);
-#pragma unroll 1
-  for (int q = 2; q < nsteps; q++) {
-    // planes q - 2, q - 1, q: everything issued so far has to have landed (plane q went out a whole step ago)
-    if (!(TFL_M16P_ABL & 16)) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();                // every wave's part of plane q is in LDS; every wave is done reading plane q - 3
-    }
-    if (!(TFL_M16P_ABL & 1)) issue(q + 1);   // into the slot of plane q - 3 (past the chunk: the zero page)
-    if (TFL_M16P_DEFER) flush();      // the previous plane's stores: a whole step to complete before the next vmcnt(0)
-    const int s0 = ((q - 2) % kPRing) * kMPitch, s1 = ((q - 1) % kPRing) * kMPitch, s2 = (q % kPRing) * kMPitch;
-    const uint4* fa = lds + ((g == 3 ? s1 : s0) + slotA);
-    const uint4* fb = lds + ((g < 2 ? s1 : s2) + slotB);
-    const uint4* fc = lds + (s2 + slotC);
-    f4 acc[4];
-#pragma unroll
-    for (int r = 0; r < 4; r++) acc[r] = (f4){0.0f, 0.0f, 0.0f, 0.0f};
-    // issue order: the A fragments of all rows, then the B fragments, then C -- two MFMAs on the same accumulator are at
-    // least two MFMAs apart almost everywhere (a dependent MFMA right behind its producer stalls the pipe)
-#pragma unroll
-    for (int kind = 0; kind < 2; kind++)
-#pragma unroll
-      for (int ry = 0; ry < 6; ry++)
-#pragma unroll
-        for (int tm = 0; tm < 2; tm++) {
-          const h8 v = (TFL_M16P_ABL & 8) ? W[(ry * 2 + tm + kind) % kPFrags] : __builtin_bit_cast(h8, (kind == 0 ? fa : fb)[(ry * 2 + tm) * kMHX]);
-#pragma unroll
-          for (int dy = 0; dy < 3; dy++) {
-            const int oy = ry - dy;
-            if (oy < 0 || oy > 3) continue;
-            if (TFL_M16P_ABL & 2) { if (dy == 0) acc[oy] += __builtin_bit_cast(f4, v); continue; }
-            acc[oy] = __builtin_amdgcn_mfma_f32_16x16x32_f16(W[kind * 6 + dy * 2 + tm], v, acc[oy], 0, 0, 0);
-          }
-        }
-#pragma unroll
-    for (int ry = 0; ry < 4; ry++)
-#pragma unroll
-      for (int tm = 0; tm < 2; tm++) {
-        const h8 vc = (TFL_M16P_ABL & 8) ? W[(ry + tm) % kPFrags] : __builtin_bit_cast(h8, fc[(ry * 2 + tm) * kMHX]);
-        if (TFL_M16P_ABL & 2) { acc[ry] += __builtin_bit_cast(f4, vc); continue; }
-        acc[ry] = __builtin_amdgcn_mfma_f32_16x16x32_f16(W[12 + tm], vc, acc[ry], 0, 0, 0);
-      }
-    if (TFL_M16P_ABL & 32) {          // one word per lane keeps the accumulators alive
-      if ((TFL_M16P_ABL & 4) ? post == 12345.0f : (x < d.X && y < d.Y))
-        reinterpret_cast<float*>(outv)[((long long)b * cells + TFL_AT(d, x, y, zc0 + q - 2)) * (TAIL ? 1 : 8)] = acc[0][0] + acc[1][1] + acc[2][2] + acc[3][3];
-    } else {
-      finish(acc, zc0 + q - 2);
-    }
-  }
-  if (TFL_M16P_DEFER) flush();
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the trailing zero-page DMA must not outlive the block's LDS
-  if (clipped || !(hmax <= kHalfMax)) atomicAdd(range_err, 1ull);
-}
 
 
 // =====================================================================================================================
@@ -1266,265 +602,13 @@ __global__ __launch_bounds__(256, TFL_M16PI_LB) void k_conv3_m16p_in(Dom d, int 
   if (clipped) atomicAdd(range_err, 1ull);
 }
 
-// =====================================================================================================================
-// Layers 1 AND 2 in one z-marched launch (round 5). The split activations between the first two layers
-// -- 64 of the stack's 144 bytes per voxel, the traffic that bounds k_conv3_in / k_conv3_mid at 4.2-4.9 TB/s -- never reach
-// HBM: a block owns a 32 x 8 column, walks a chunk of z, and keeps TWO rings in LDS:
-//   R0  raw net input {p_h, d_h, occ, p_l, d_l, 0, 0, 0}, 36 x 12 voxels per plane (the column + 2), built plane by plane from
-//       pDiv / div / flags exactly as k_conv3_m16p_in builds it;
-//   R1  layer 1's output in the h2 form k_conv3_m16p stages ([row][term][x], 34 x 10 voxels = the column + 1).
-// Per step one raw plane arrives, ONE layer-1 plane (34 x 10 voxels: the x / y halo of layer 2's input is recomputed, 1.33 x
-// the layer's small MFMA work) is evaluated into R1 and ONE layer-2 plane leaves for HBM. Layer 1 runs on "free" tiles: an
-// MFMA's 16 columns are the 16 consecutive voxels v = 16 tile + n of the 340-voxel plane in row-major order, every lane
-// addresses its own voxel's taps (7 reads per 7 MFMAs instead of the row-shared 16 per 28; the layer is 7 MFMAs per tile),
-// and after the recombination a lane holds two channels of ONE voxel -- 4 bytes of the hi slot and 4 of the lo slot, stored
-// as two ds_write_b32 without the cross-lane transpose the 16-byte global stores need. Layer 2 is k_conv3_m16p's step on R1.
-// One barrier per step: layer 1 of step t writes the plane layer 2 reads from step t + 1 on (rings of four).
-//   step t:  raw plane t + 1 -> R0 (its words were loaded in step t - 1);  loads of raw plane t + 2 issued;
-//            layer 1 plane s = t - 2 from raw planes s, s + 1, s + 2;  layer 2 plane o = t - 5 from layer-1 planes o, o + 1, o + 2
-// Results are bit-identical to k_conv3_m16p_in + k_conv3_m16p<false> (the same MFMAs in the same order per voxel).
-constexpr int kF2RX = kMX + 4, kF2RY = kMY + 4;           // raw plane: 36 x 12 voxels, origin (x0 - 2, y0 - 2)
-constexpr int kF2RPlane = kF2RX * kF2RY;                  // 432 16-byte slots
-constexpr int kF2L1 = kMHX * kMHY;                        // 340 voxels of a layer-1 plane, origin (x0 - 1, y0 - 1)
-constexpr int kF2Tiles = (kF2L1 + 15) / 16;               // 22 tiles of 16 voxels: waves 0, 1 take six, waves 2, 3 five
-constexpr int kF2Ring = 4;
-constexpr int kF2Fill = 5;                                // steps of a chunk beyond its output planes
-constexpr size_t kF2Lds = (size_t)16 * kF2Ring * (kF2RPlane + kMPlane);    // 71 168 bytes: two blocks per CU
 
-#ifndef TFL_M16F2_LB
-#define TFL_M16F2_LB 2
+#ifdef TFL_EXPERIMENTS
+// the tile kernel, the un-packed and the un-pipelined z-marched kernels, layers 1 + 2 in one launch: conv_mfma16_exp.inc
+#define TFL_M16_EXP_SECTION 1
+#include "conv_mfma16_exp.inc"
+#undef TFL_M16_EXP_SECTION
 #endif
-__global__ __launch_bounds__(256, TFL_M16F2_LB) void k_conv3_m16p_f2(Dom d, int cols_x, int cols_y, int cz, int chunks_a, int chunks,
-                                                                    int n_blocks, MIn cin, const uint4* __restrict__ wf1,
-                                                                    const float* __restrict__ bias1, float post1,
-                                                                    const uint4* __restrict__ wf2, const float* __restrict__ bias2,
-                                                                    float post2, void* __restrict__ outv,
-                                                                    unsigned long long* __restrict__ range_err, int stag) {
-  extern __shared__ __attribute__((aligned(16))) uint4 lds[];
-  uint4* const R0 = lds;                                  // [kF2Ring][kF2RPlane]
-  uint4* const R1 = lds + kF2Ring * kF2RPlane;            // [kF2Ring][kMPlane]
-  const int per_xcd = (n_blocks + 7) / 8;
-  const int blk = (int)(blockIdx.x % 8) * per_xcd + (int)(blockIdx.x / 8);
-  if (blk >= n_blocks) return;
-  stagger_start(stag, lds);
-  int t0 = blk;
-  const int cx = t0 % cols_x; t0 /= cols_x;
-  const int cy = t0 % cols_y; t0 /= cols_y;
-  const int ch = t0 % chunks;
-  const int b = t0 / chunks;
-  const int zc0 = ch < chunks_a ? d.w0 + ch * cz : d.w1 + (ch - chunks_a) * cz;
-  const int z_end = ch < chunks_a ? d.w0 + d.n0 : d.w1 + (d.nw - d.n0);
-  const int nz = min(cz, z_end - zc0);                  // layer-2 planes this block writes
-  const int x0 = cx * kMX, y0 = cy * kMY;
-  const long long cells = d.sc;
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  float hmax = 0.0f;                  // the largest activation this lane has produced (range check at the end)
-  bool clipped = false;
-
-  h8 W1[kIFrags], W2[kPFrags];
-#pragma unroll
-  for (int f = 0; f < kIFrags; f++) W1[f] = __builtin_bit_cast(h8, wf1[f * 64 + lane]);
-#pragma unroll
-  for (int f = 0; f < kPFrags; f++) W2[f] = __builtin_bit_cast(h8, wf2[f * 64 + lane]);
-
-  // lib/modules/variance.lua:44-76 (n-1) + Sqrt, as model.hip scale_from_stats
-  const double s1 = cin.stats[b * 2], s2 = cin.stats[b * 2 + 1], n = cin.count;
-  const float in_scale = (float)sqrt(fmax(n * s2 - s1 * s1, 0.0) / (n * (n - 1.0)));
-  const bool scale_in_range = in_scale >= 0x1p-12f && in_scale <= 0x1p21f;     // wave-uniform
-  const float inv_scale = scale_in_range ? rcp_refined(in_scale) : 0.0f;
-
-  // ---- raw planes: the thread's two slots (the second one only for tid < kF2RPlane - 256) ------------------------------
-  int st_off[2];
-  bool st_in[2];
-#pragma unroll
-  for (int j = 0; j < 2; j++) {
-    const int item = min(tid + 256 * j, kF2RPlane - 1);
-    const int hy = item / kF2RX, hx = item - hy * kF2RX;
-    const int gx = x0 - 2 + hx, gy = y0 - 2 + hy;
-    st_off[j] = min(max(gy, 0), d.Y - 1) * d.sy + min(max(gx, 0), d.X - 1);
-    st_in[j] = gx >= 0 && gx < d.X && gy >= 0 && gy < d.Y;
-  }
-  const float* pP = cin.pDiv + (long long)b * cells;
-  const float* pD = cin.div + (long long)b * cells;
-  const float* pF = cin.flags + (long long)b * cells;
-  float raw[2][3];
-  auto load_raw = [&](int r) {        // words of raw plane r of the chunk (z = zc0 - 2 + r)
-    const int gz = min(max(zc0 - 2 + r, 0), d.Z - 1);
-#pragma unroll
-    for (int j = 0; j < 2; j++) {
-      if (j == 1 && tid >= kF2RPlane - 256) continue;
-      const int o = gz * d.sz + st_off[j];
-      raw[j][0] = pP[o]; raw[j][1] = pD[o]; raw[j][2] = pF[o];
-    }
-  };
-  auto write_raw = [&](int r) {       // -> R0 slot r & 3; the net input is built here (as k_conv3_m16p_in's write_plane)
-    const int gz = zc0 - 2 + r;
-    const bool z_ok = gz >= 0 && gz < d.Z;
-#pragma unroll
-    for (int j = 0; j < 2; j++) {
-      if (j == 1 && tid >= kF2RPlane - 256) continue;
-      float v0, v1;
-      if (scale_in_range) { v0 = div_by<1>(raw[j][0], in_scale, inv_scale); v1 = div_by<1>(raw[j][1], in_scale, inv_scale); }
-      else { v0 = raw[j][0] / in_scale; v1 = raw[j][1] / in_scale; }
-      const int f = (int)raw[j][2];
-      const float occ = (f == kFluid) ? 0.0f : ((f == kObstacle) ? 1.0f : -1.0f);
-      const float k0 = __builtin_fminf(__builtin_fmaxf(v0, -kHalfMax), kHalfMax), k1 = __builtin_fminf(__builtin_fmaxf(v1, -kHalfMax), kHalfMax);
-      const bool ok = z_ok && st_in[j];
-      clipped = clipped || (ok && (k0 != v0 || k1 != v1));
-      h8 sv = {0, 0, 0, 0, 0, 0, 0, 0};
-      if (ok) {
-        _Float16 ph, pl, dh, dl;
-        split_h(k0, ph, pl); split_h(k1, dh, dl);
-        sv[0] = ph; sv[1] = dh; sv[2] = (_Float16)occ; sv[3] = pl; sv[4] = dl;
-      }
-      R0[(r & 3) * kF2RPlane + tid + 256 * j] = __builtin_bit_cast(uint4, sv);
-    }
-  };
-
-  // ---- layer 1: the lane's voxel of each of the wave's tiles ----------------------------------------------------------------
-  const int nn = lane & 15, g = lane >> 4;
-  constexpr int kTPW = 6;
-  int l1_base[kTPW], l1_out[kTPW];    // slot of the voxel's first tap in a raw plane; byte offset of its 4 bytes in an R1 plane
-  unsigned l1_keep = 0, l1_live = 0;  // bit i: the voxel exists / lies inside the grid (outside: layer 2's zero padding)
-#pragma unroll
-  for (int i = 0; i < kTPW; i++) {
-    const int tl = wave + 4 * i, v = tl * 16 + nn;
-    const bool ok = tl < kF2Tiles && v < kF2L1;
-    const int vc = min(v, kF2L1 - 1);
-    const int ry = vc / kMHX, rx = vc - ry * kMHX;
-    l1_base[i] = ry * kF2RX + rx;
-    l1_out[i] = ((ry * 2) * kMHX + rx) * 16 + 4 * g;
-    const int gx = x0 - 1 + rx, gy = y0 - 1 + ry;
-    l1_keep |= ok ? (1u << i) : 0u;
-    l1_live |= (ok && gx >= 0 && gx < d.X && gy >= 0 && gy < d.Y) ? (1u << i) : 0u;
-  }
-  const bool six = wave < 2;          // 22 tiles: waves 0 and 1 own a sixth one
-  // K group g of the three fragment kinds (as k_conv3_m16p_in): A = {(dz 0; dx 0, 1, 2), (dz 1; dx 0)},
-  // B = {(dz 1; dx 1, 2), (dz 2; dx 0, 1)}, C = {(dz 2, dx 2) of dy = 0, 1, 2}
-  const int cA = g < 3 ? g : 0;
-  const int cB = g == 0 ? 1 : (g == 1 ? 2 : (g == 2 ? 0 : 1));
-  const int cC = 2 + (g < 3 ? g : 0) * kF2RX;
-  const float b1a = bias1[2 * g], b1b = bias1[2 * g + 1];
-
-  // ---- layer 2 (k_conv3_m16p's geometry on R1) ----------------------------------------------------------------------------
-  const int wx = wave & 1, wy = wave >> 1;
-  const int row0 = (wy * 4 * 2) * kMHX + wx * 16 + nn;
-  const int slotA = row0 + (g < 3 ? g : 0);
-  const int slotB = row0 + (g == 0 ? 1 : (g == 1 ? 2 : (g == 2 ? 0 : 1)));
-  const int slotC = row0 + 2 + (g < 3 ? g : 0) * 2 * kMHX;
-  const int x = x0 + wx * 16 + nn;
-  const int y = y0 + wy * 4 + g;                          // the row this lane group stores (after the transpose)
-  const float b2a = bias2[2 * g], b2b = bias2[2 * g + 1];
-
-  // tiles I0 .. I0 + N - 1 of the wave: 7 MFMAs each, interleaved over the tiles (a dependent MFMA right behind its producer
-  // stalls the pipe), then recombine / bias / ReLU / zero outside the grid / split / two 4-byte LDS stores
-  auto l1_tiles = [&](auto i0_c, auto n_c, const uint4* pA, const uint4* pB, const uint4* pC, char* r1p) {
-    constexpr int I0 = decltype(i0_c)::value, N = decltype(n_c)::value;
-    f4 a[N];
-#pragma unroll
-    for (int u = 0; u < N; u++) a[u] = (f4){0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-    for (int dy = 0; dy < 3; dy++)
-#pragma unroll
-      for (int u = 0; u < N; u++)
-        a[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(W1[dy], __builtin_bit_cast(h8, pA[l1_base[I0 + u] + dy * kF2RX]), a[u], 0, 0, 0);
-#pragma unroll
-    for (int dy = 0; dy < 3; dy++)
-#pragma unroll
-      for (int u = 0; u < N; u++)
-        a[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(W1[3 + dy], __builtin_bit_cast(h8, pB[l1_base[I0 + u] + dy * kF2RX]), a[u], 0, 0, 0);
-#pragma unroll
-    for (int u = 0; u < N; u++)
-      a[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(W1[6], __builtin_bit_cast(h8, pC[l1_base[I0 + u]]), a[u], 0, 0, 0);
-#pragma unroll
-    for (int u = 0; u < N; u++) {
-      const bool live = (l1_live >> (I0 + u)) & 1u;
-      float h0 = __builtin_fmaxf(__builtin_fmaf(__builtin_fmaf(a[u][1], 0x1p-11f, a[u][0]), post1, b1a), 0.0f);
-      float h1 = __builtin_fmaxf(__builtin_fmaf(__builtin_fmaf(a[u][3], 0x1p-11f, a[u][2]), post1, b1b), 0.0f);
-      h0 = live ? h0 : 0.0f; h1 = live ? h1 : 0.0f;
-      hmax = __builtin_fmaxf(__builtin_fmaxf(hmax, h0), h1);
-      uint32_t H, L;
-      split_pair(__builtin_fminf(h0, kHalfMax), __builtin_fminf(h1, kHalfMax), H, L);
-      if ((l1_keep >> (I0 + u)) & 1u) {
-        *reinterpret_cast<uint32_t*>(r1p + l1_out[I0 + u]) = H;
-        *reinterpret_cast<uint32_t*>(r1p + l1_out[I0 + u] + kMHX * 16) = L;
-      }
-    }
-  };
-
-  load_raw(0); write_raw(0); load_raw(1);
-#pragma unroll 1
-  for (int t = 0; t < nz + kF2Fill; t++) {
-    __syncthreads();                  // raw planes <= t and layer-1 planes <= t - 3 are in LDS; every wave is done with step t - 1
-    write_raw(t + 1);                 // slot of raw plane t - 3
-    load_raw(t + 2);                  // in flight for a whole step
-    const int o = t - 5, s = t - 2;
-    f4 acc[4];
-#pragma unroll
-    for (int r = 0; r < 4; r++) acc[r] = (f4){0.0f, 0.0f, 0.0f, 0.0f};
-    if (o >= 0) {                     // block-uniform: layer 2, plane o (as k_conv3_m16p)
-      const int q0 = (o & 3) * kMPlane, q1 = ((o + 1) & 3) * kMPlane, q2 = ((o + 2) & 3) * kMPlane;
-      const uint4* fa = R1 + ((g == 3 ? q1 : q0) + slotA);
-      const uint4* fb = R1 + ((g < 2 ? q1 : q2) + slotB);
-      const uint4* fc = R1 + (q2 + slotC);
-#pragma unroll
-      for (int kind = 0; kind < 2; kind++)
-#pragma unroll
-        for (int ry = 0; ry < 6; ry++)
-#pragma unroll
-          for (int tm = 0; tm < 2; tm++) {
-            const h8 v = __builtin_bit_cast(h8, (kind == 0 ? fa : fb)[(ry * 2 + tm) * kMHX]);
-#pragma unroll
-            for (int dy = 0; dy < 3; dy++) {
-              const int oy = ry - dy;
-              if (oy < 0 || oy > 3) continue;
-              acc[oy] = __builtin_amdgcn_mfma_f32_16x16x32_f16(W2[kind * 6 + dy * 2 + tm], v, acc[oy], 0, 0, 0);
-            }
-          }
-#pragma unroll
-      for (int ry = 0; ry < 4; ry++)
-#pragma unroll
-        for (int tm = 0; tm < 2; tm++) {
-          const h8 vc = __builtin_bit_cast(h8, fc[(ry * 2 + tm) * kMHX]);
-          acc[ry] = __builtin_amdgcn_mfma_f32_16x16x32_f16(W2[12 + tm], vc, acc[ry], 0, 0, 0);
-        }
-    }
-    if (s >= 0 && s <= nz + 1) {      // block-uniform: layer 1, plane s (z = zc0 - 1 + s)
-      const int z1 = zc0 - 1 + s;
-      char* r1p = reinterpret_cast<char*>(R1 + (s & 3) * kMPlane);
-      if (z1 >= 0 && z1 < d.Z) {
-        const int p0 = (s & 3) * kF2RPlane, p1 = ((s + 1) & 3) * kF2RPlane, p2 = ((s + 2) & 3) * kF2RPlane;
-        const uint4* pA = R0 + ((g == 3 ? p1 : p0) + cA);
-        const uint4* pB = R0 + ((g < 2 ? p1 : p2) + cB);
-        const uint4* pC = R0 + (p2 + cC);
-        l1_tiles(std::integral_constant<int, 0>(), std::integral_constant<int, 3>(), pA, pB, pC, r1p);
-        if (six) l1_tiles(std::integral_constant<int, 3>(), std::integral_constant<int, 3>(), pA, pB, pC, r1p);
-        else l1_tiles(std::integral_constant<int, 3>(), std::integral_constant<int, 2>(), pA, pB, pC, r1p);
-      } else {                        // a plane outside the grid is layer 2's zero padding, not conv(0) = ReLU(bias)
-        for (int it = tid; it < kMPlane; it += 256) reinterpret_cast<uint4*>(r1p)[it] = make_uint4(0u, 0u, 0u, 0u);
-      }
-    }
-    if (o >= 0) {                     // layer 2's epilogue: recombine, bias, ReLU, split, transposed 16-byte stores
-      const int z = zc0 + o;
-      uint32_t H[4], L[4];
-#pragma unroll
-      for (int oy = 0; oy < 4; oy++) {
-        const float h0 = __builtin_fmaxf(__builtin_fmaf(__builtin_fmaf(acc[oy][1], 0x1p-11f, acc[oy][0]), post2, b2a), 0.0f);
-        const float h1 = __builtin_fmaxf(__builtin_fmaf(__builtin_fmaf(acc[oy][3], 0x1p-11f, acc[oy][2]), post2, b2b), 0.0f);
-        hmax = __builtin_fmaxf(__builtin_fmaxf(hmax, h0), h1);
-        split_pair(__builtin_fminf(h0, kHalfMax), __builtin_fminf(h1, kHalfMax), H[oy], L[oy]);
-      }
-      transpose4(H); transpose4(L);
-      if (x < d.X && y < d.Y) {
-        uint4* orow = reinterpret_cast<uint4*>(outv) + (((long long)b * d.Z + z) * d.Y + y) * 2 * d.X + x;
-        orow[0] = make_uint4(H[0], H[1], H[2], H[3]);
-        orow[d.X] = make_uint4(L[0], L[1], L[2], L[3]);
-      }
-    }
-  }
-  if (clipped || !(hmax <= kHalfMax)) atomicAdd(range_err, 1ull);
-}
-
 // compute units of the current device (cached per device)
 static int device_cus() {
   static std::atomic<int> cus[64];
@@ -1578,47 +662,17 @@ static int pick_chunk(long long cols, int na, int nb, int slots, int cus, float 
   return cz;
 }
 
-template <bool TAIL>
-static void launch_m16z(hipStream_t st, const Dom& d, int B, const void* in, const void* wfrag, const float* bias, void* out,
-                        float post, unsigned long long* range_err) {
-  const int cxn = (d.X + kMX - 1) / kMX, cyn = (d.Y + kMY - 1) / kMY;
-  const int na = d.n0, nb = d.nw - d.n0;
-  if (cxn * cyn * (na + nb) * B <= 0) return;
-  // chunk length: all blocks of a launch wait for each other's CU slots in ROUNDS of (CUs x blocks per CU); a block of cz
-  // output planes walks cz + 2 input planes (+ ~2 plane-times of weight fetch and pipeline fill). Take the cz in [8, 32]
-  // that minimises rounds x (cz + 4): at 128^3 that is 16 planes (512 blocks = ONE round on 256 CUs x 2) where "three
-  // blocks per CU" gave 768 blocks = two rounds of 13 planes.
-  const size_t lds_bytes = (size_t)16 * kMRing * kMPitch;
-  const int slots = device_cus() * blocks_per_cu((const void*)k_conv3_m16z<TAIL>, lds_bytes, TFL_M16Z_LB);
-  int cz = 8;
-  {
-    long long best = -1;
-    for (int c = 8; c <= 32; c++) {
-      const long long blocks = (long long)cxn * cyn * B * ((na + c - 1) / c + (nb + c - 1) / c);
-      const long long cost = ((blocks + slots - 1) / slots) * (c + 4);
-      if (best < 0 || cost < best) { best = cost; cz = c; }
-    }
-  }
-  if (const char* e = getenv("TFL_M16_CZ")) cz = atoi(e) > 0 ? atoi(e) : cz;
-  const int chunks_a = (na + cz - 1) / cz, chunks = chunks_a + (nb + cz - 1) / cz;
-  const int n_blocks = cxn * cyn * chunks * B;
-  const int grid = ((n_blocks + 7) / 8) * 8;
-  static int attr_dev = -1;
-  int dev = 0; (void)hipGetDevice(&dev);
-  if (attr_dev != dev) {
-    (void)hipFuncSetAttribute((const void*)k_conv3_m16z<TAIL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    attr_dev = dev;
-    if (getenv("TFL_DEBUG")) {
-      int nbk = -1;
-      (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nbk, (const void*)k_conv3_m16z<TAIL>, 256, lds_bytes);
-      fprintf(stderr, "[tfl] k_conv3_m16z<%d>: dynamic LDS %zu B, occupancy %d blocks/CU, grid %d, chunks of %d planes\n", (int)TAIL, lds_bytes, nbk, grid, cz);
-    }
-  }
-  TFL_TIMED_EXT(TAIL ? "k_conv3_tail" : "k_conv3_mid", st);
-  TFL_LAUNCH_EXT((k_conv3_m16z<TAIL>), grid, 256, lds_bytes, st, d, cxn, cyn, cz, chunks_a, chunks, n_blocks, (const uint4*)in,
-                 (const uint4*)wfrag, bias, out, post, range_err);
-}
 
+
+// A development switch of the EXPERIMENTS flavour (chunk lengths, the de-phased block starts): the default library reads none
+static int exp_int(const char* name, int dflt) {
+#ifdef TFL_EXPERIMENTS
+  if (const char* e = getenv(name)) return atoi(e);
+#else
+  (void)name;
+#endif
+  return dflt;
+}
 
 template <bool TAIL>
 static void launch_m16p(hipStream_t st, const Dom& d, int B, const void* in, const void* wfrag, const float* bias, void* out,
@@ -1627,9 +681,11 @@ static void launch_m16p(hipStream_t st, const Dom& d, int B, const void* in, con
   const int na = d.n0, nb = d.nw - d.n0;
   if (cxn * cyn * (na + nb) * B <= 0) return;
   const size_t lds_bytes = (size_t)16 * kPRing * kMPitch;
-  const int slots = device_cus() * blocks_per_cu((const void*)k_conv3_m16p<TAIL>, lds_bytes, TFL_M16P_LB);
+  static bool attr_done[2] = {false, false};
+  if (!attr_done[TAIL]) { (void)hipFuncSetAttribute((const void*)k_conv3_m16q<TAIL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); attr_done[TAIL] = true; }
+  const int slots = device_cus() * blocks_per_cu((const void*)k_conv3_m16q<TAIL>, lds_bytes, TFL_M16Q_LB);
   int cz = pick_chunk((long long)cxn * cyn * B, na, nb, slots, device_cus(), 0.70f, 0.35f);
-  if (const char* e = getenv("TFL_M16_CZ")) cz = atoi(e) > 0 ? atoi(e) : cz;
+  if (const int e = exp_int("TFL_M16_CZ", 0); e > 0) cz = e;
   const int chunks_a = (na + cz - 1) / cz, chunks = chunks_a + (nb + cz - 1) / cz;
   const int n_blocks = cxn * cyn * chunks * B;
   const int grid = ((n_blocks + 7) / 8) * 8;
@@ -1637,63 +693,30 @@ static void launch_m16p(hipStream_t st, const Dom& d, int B, const void* in, con
     static bool said[2] = {false, false};
     if (!said[TAIL]) {
       said[TAIL] = true;
-      fprintf(stderr, "[tfl] k_conv3_m16p<%d>: dynamic LDS %zu B, %d block slots, grid %d, chunks of %d planes\n", (int)TAIL, lds_bytes, slots, grid, cz);
+      fprintf(stderr, "[tfl] k_conv3_m16q<%d>: dynamic LDS %zu B, %d block slots, grid %d, chunks of %d planes\n", (int)TAIL, lds_bytes, slots, grid, cz);
     }
   }
   // the fragments of this kernel lie behind those of k_conv3_m16z in the layer's buffer (conv3_m16_pack_weights)
   const uint4* wp = (const uint4*)wfrag + (9 * 2 * 64 + 1);
   TFL_TIMED_EXT(TAIL ? "k_conv3_tail" : "k_conv3_mid", st);
-  // the tail's 1 x 1 x 1 layers: on the matrix cores (round 5) unless TFL_M16_TAIL_MFMA=0 (the vector-ALU epilogue, kept for A/B)
+#ifdef TFL_EXPERIMENTS
+  // the tail's 1 x 1 x 1 layers on the vector ALUs (TFL_M16_TAIL_MFMA=0) / the un-pipelined kernel (TFL_M16_PIPE=0): k_conv3_m16p
   const char* etm = getenv("TFL_M16_TAIL_MFMA");       // (read per call: the tests switch it inside one process)
   const bool tmf = !(etm && atoi(etm) == 0);
-  // the software-pipelined form (k_conv3_m16q, round 5) unless TFL_M16_PIPE=0
   const char* epp = getenv("TFL_M16_PIPE");
-  if (!(epp && atoi(epp) == 0) && (!TAIL || tmf)) {
-    static bool attr_done[2] = {false, false};
-    if (!attr_done[TAIL]) { (void)hipFuncSetAttribute((const void*)k_conv3_m16q<TAIL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); attr_done[TAIL] = true; }
-    TFL_LAUNCH_EXT((k_conv3_m16q<TAIL>), grid, 256, lds_bytes, st, d, cxn, cyn, cz, chunks_a, chunks, n_blocks, (const uint4*)in, wp, bias, out, post, range_err);
+  if ((epp && atoi(epp) == 0) || (TAIL && !tmf)) {
+    if (TAIL && tmf)
+      TFL_LAUNCH_EXT((k_conv3_m16p<TAIL, TAIL>), grid, 256, lds_bytes, st, d, cxn, cyn, cz, chunks_a, chunks, n_blocks, (const uint4*)in,
+                     wp, bias, out, post, range_err, stagger_units("TFL_M16_STAGGER", 0));
+    else
+      TFL_LAUNCH_EXT((k_conv3_m16p<TAIL, false>), grid, 256, lds_bytes, st, d, cxn, cyn, cz, chunks_a, chunks, n_blocks, (const uint4*)in,
+                     wp, bias, out, post, range_err, stagger_units("TFL_M16_STAGGER", 0));
     return;
   }
-  if (TAIL && tmf)
-    TFL_LAUNCH_EXT((k_conv3_m16p<TAIL, TAIL>), grid, 256, lds_bytes, st, d, cxn, cyn, cz, chunks_a, chunks, n_blocks, (const uint4*)in,
-                   wp, bias, out, post, range_err, stagger_units("TFL_M16_STAGGER", 0));
-  else
-    TFL_LAUNCH_EXT((k_conv3_m16p<TAIL, false>), grid, 256, lds_bytes, st, d, cxn, cyn, cz, chunks_a, chunks, n_blocks, (const uint4*)in,
-                   wp, bias, out, post, range_err, stagger_units("TFL_M16_STAGGER", 0));
+#endif
+  // the 8 -> 8 layers software-pipelined over the planes, the tail's 1 x 1 x 1 layers on the matrix cores (round 5)
+  TFL_LAUNCH_EXT((k_conv3_m16q<TAIL>), grid, 256, lds_bytes, st, d, cxn, cyn, cz, chunks_a, chunks, n_blocks, (const uint4*)in, wp, bias, out, post, range_err);
 }
-
-// layers 1 + 2 in one launch (k_conv3_m16p_f2): false = not taken. OFF unless TFL_M16_FUSE12=1: measured SLOWER than the two
-// launches (profiles/r05_conv_experiments.txt: 72 us against 27 + 32.5 at 128^3, 532 against 200 + 263 at 256^3 -- these
-// kernels run at the SUM of their instruction streams, and the recomputed halo + the generic tiles make the fused stream
-// 15 % longer than the two it replaces; the 64 B/voxel it keeps out of HBM do not bind). Never taken under a z-window (the
-// slab step runs every layer under its own window; the fused kernel would recompute layer 1 where the window says it is
-// not valid).
-static bool launch_m16p_f2(hipStream_t st, const Dom& d, int B, MIn cin, const void* wfrag1, const float* bias1, float post1,
-                           const void* wfrag2, const float* bias2, float post2, void* out, unsigned long long* range_err) {
-  const char* ef = getenv("TFL_M16_FUSE12");           // (read per call: the tests switch it inside one process)
-  if (!(ef && atoi(ef) == 1) || d.nw != d.Z || d.n0 != d.Z) return false;
-  const int cxn = (d.X + kMX - 1) / kMX, cyn = (d.Y + kMY - 1) / kMY;
-  if ((long long)cxn * cyn * d.Z * B <= 0) return true;
-  const int slots = device_cus() * blocks_per_cu((const void*)k_conv3_m16p_f2, kF2Lds, TFL_M16F2_LB);
-  if (slots <= 0) return false;
-  // a step carries both layers (~1.7 x the 8 -> 8 layer's) and a chunk has five fill steps: longer chunks than k_conv3_m16p's
-  int cz = pick_chunk((long long)cxn * cyn * B, d.Z, 0, slots, device_cus(), 1.10f, 0.55f, kF2Fill + 2, 128);
-  if (const char* e = getenv("TFL_M16_CZ_F2")) cz = atoi(e) > 0 ? atoi(e) : cz;
-  const int chunks_a = (d.Z + cz - 1) / cz, chunks = chunks_a;
-  const int n_blocks = cxn * cyn * chunks * B;
-  const int grid = ((n_blocks + 7) / 8) * 8;
-  if (getenv("TFL_DEBUG")) {
-    static bool said = false;
-    if (!said) { said = true; fprintf(stderr, "[tfl] k_conv3_m16p_f2: dynamic LDS %zu B, %d block slots, grid %d, chunks of %d planes\n", kF2Lds, slots, grid, cz); }
-  }
-  const uint4* w1 = (const uint4*)wfrag1 + (9 * 64 + 1);          // the K-packed fragments (conv3_m16_pack_weights)
-  const uint4* w2 = (const uint4*)wfrag2 + (9 * 2 * 64 + 1);
-  TFL_TIMED_EXT("k_conv3_in_mid", st);
-  TFL_LAUNCH_EXT(k_conv3_m16p_f2, grid, 256, kF2Lds, st, d, cxn, cyn, cz, chunks_a, chunks, n_blocks, cin, w1, bias1, post1, w2, bias2,
-                 post2, out, range_err, stagger_units("TFL_M16_STAGGER_F2", 0));
-  return true;
-}
-
 
 static void launch_m16p_in(hipStream_t st, const Dom& d, int B, MIn cin, const void* wfrag, const float* bias, void* out, float post,
                            unsigned long long* range_err) {
@@ -1702,7 +725,7 @@ static void launch_m16p_in(hipStream_t st, const Dom& d, int B, MIn cin, const v
   if (cxn * cyn * (na + nb) * B <= 0) return;
   const int slots = device_cus() * blocks_per_cu((const void*)k_conv3_m16p_in, 0, TFL_M16PI_LB);
   int cz = pick_chunk((long long)cxn * cyn * B, na, nb, slots, device_cus(), 0.95f, 0.24f);
-  if (const char* e = getenv("TFL_M16_CZ_IN")) cz = atoi(e) > 0 ? atoi(e) : cz;
+  if (const int e = exp_int("TFL_M16_CZ_IN", 0); e > 0) cz = e;
   const int chunks_a = (na + cz - 1) / cz, chunks = chunks_a + (nb + cz - 1) / cz;
   const int n_blocks = cxn * cyn * chunks * B;
   const int grid = ((n_blocks + 7) / 8) * 8;
@@ -1713,87 +736,73 @@ static void launch_m16p_in(hipStream_t st, const Dom& d, int B, MIn cin, const v
   const uint4* wp = (const uint4*)wfrag + (9 * 64 + 1);     // behind the tile kernel's fragments (conv3_m16_pack_weights)
   TFL_TIMED_EXT("k_conv3_in", st);
   TFL_LAUNCH_EXT(k_conv3_m16p_in, grid, 256, 0, st, d, cxn, cyn, cz, chunks_a, chunks, n_blocks, cin, wp, bias, out, post, range_err,
-                 stagger_units("TFL_M16_STAGGER_IN", 0));
+                 exp_int("TFL_M16_STAGGER_IN", 0));
 }
 
-template <int MODE>
-static void launch_m16(hipStream_t st, const Dom& d, int B, const void* in, const void* wfrag, const float* bias, void* out,
-                       float post, MIn cin, unsigned long long* range_err) {
-  const int tx = (d.X + kTX - 1) / kTX, ty = (d.Y + kTY - 1) / kTY;
-  const int tz = (d.n0 + kTZ - 1) / kTZ + (d.nw - d.n0 + kTZ - 1) / kTZ;   // z-tiles of the compute window's two plane runs
-  if (tx * ty * tz * B <= 0) return;
-  // z-tiles per block (the weight fragments are fetched once per block): the nt in [1, 8] that minimises
-  // rounds x (nt + 1/2), rounds = blocks / (CUs x blocks per CU) rounded up -- 128^3: 6 (768 blocks, one round)
-  const size_t lds_bytes = (size_t)16 * kHZ * kHY * (MODE == kModeIn ? 1 : 2) * kHX;
-  const int slots = device_cus() * blocks_per_cu((const void*)k_conv3_m16<MODE>, lds_bytes, TFL_M16_LB);
-  int nt = 1;
-  {
-    long long best = -1;
-    for (int c = 1; c <= 8 && c <= (tz > 0 ? tz : 1); c++) {
-      const long long blocks = (long long)tx * ty * B * ((tz + c - 1) / c);
-      const long long cost = ((blocks + slots - 1) / slots) * (2 * c + 1);
-      if (best < 0 || cost < best) { best = cost; nt = c; }
-    }
-  }
-  if (const char* e = getenv("TFL_M16_NT")) nt = atoi(e) > 0 ? atoi(e) : nt;
-  if (nt > tz) nt = tz;
-  const int n_chunks = tx * ty * ((tz + nt - 1) / nt) * B;
-  const int grid = ((n_chunks + 7) / 8) * 8;
-  static int attr_dev = -1;                    // the attribute is per device
-  int dev = 0; (void)hipGetDevice(&dev);
-  if (attr_dev != dev) {
-    (void)hipFuncSetAttribute((const void*)k_conv3_m16<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    attr_dev = dev;
-    if (getenv("TFL_DEBUG")) {
-      int nb = -1;
-      (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)k_conv3_m16<MODE>, 256, lds_bytes);
-      fprintf(stderr, "[tfl] k_conv3_m16<%d>: dynamic LDS %zu B, occupancy %d blocks/CU, grid %d, %d z-tiles per block\n", MODE, lds_bytes, nb, grid, nt);
-    }
-  }
-  TFL_TIMED_EXT(MODE == kModeTail ? "k_conv3_tail" : (MODE == kModeIn ? "k_conv3_in" : "k_conv3_mid"), st);
-  TFL_LAUNCH_EXT((k_conv3_m16<MODE>), grid, 256, lds_bytes, st, d, tx, ty, tz, nt, n_chunks, (const uint4*)in, (const uint4*)wfrag,
-                 bias, out, post, cin, range_err);
-}
+#ifdef TFL_EXPERIMENTS
+#define TFL_M16_EXP_SECTION 2
+#include "conv_mfma16_exp.inc"
+#undef TFL_M16_EXP_SECTION
+// which of the earlier forms the switches of this flavour ask for: TFL_M16_KPACK = 0 (k_conv3_m16z; first layer: the tile kernel) or
+// 2 (first layer only), TFL_M16_TILED bit 0 / 1 = the tile kernel for the mid / tail layer
+static int exp_kpack() { static const int v = getenv("TFL_M16_KPACK") ? atoi(getenv("TFL_M16_KPACK")) : 1; return v; }
+static int exp_tiled() { const char* e = getenv("TFL_M16_TILED"); return e ? atoi(e) : 0; }
+#endif
 
 bool conv3_m16_first_sums_partials() {
-  static const bool kpack = !(getenv("TFL_M16_KPACK") && (atoi(getenv("TFL_M16_KPACK")) == 0 || atoi(getenv("TFL_M16_KPACK")) == 2));
+#ifdef TFL_EXPERIMENTS
+  if (exp_kpack() == 0 || exp_kpack() == 2) return false;      // the tile kernel reads the reduced sums
+#endif
   const char* e = getenv("TFL_STATS_CONSUMER");     // A/B switch (read per call: the parity test flips it inside one process): 0 = k_reduce_stats as its own launch
-  const bool off = e && atoi(e) == 0;
-  return kpack && !off;
+  return !(e && atoi(e) == 0);
 }
 void conv3_m16_first_fused(hipStream_t st, int B, int Z, int Y, int X, const float* pDiv, const float* div, const float* flags,
                            const double* stats, double count, const void* wfrag, const float* bias, float post, void* out_h2,
                            unsigned long long* range_err, const double* partials, long long per_sample, double* stats_out) {
   MIn ci = {pDiv, div, flags, stats, count, partials, per_sample, stats_out};
-  static const bool kpack = !(getenv("TFL_M16_KPACK") && (atoi(getenv("TFL_M16_KPACK")) == 0 || atoi(getenv("TFL_M16_KPACK")) == 2));   // 0 / 2: the tile kernel
-  if (kpack) { launch_m16p_in(st, make_dom(Z, Y, X), B, ci, wfrag, bias, out_h2, post, range_err); return; }
-  launch_m16<kModeIn>(st, make_dom(Z, Y, X), B, nullptr, wfrag, bias, out_h2, post, ci, range_err);
+#ifdef TFL_EXPERIMENTS
+  if (exp_kpack() == 0 || exp_kpack() == 2) { launch_m16<kModeIn>(st, make_dom(Z, Y, X), B, nullptr, wfrag, bias, out_h2, post, ci, range_err); return; }
+#endif
+  launch_m16p_in(st, make_dom(Z, Y, X), B, ci, wfrag, bias, out_h2, post, range_err);
 }
+// layers 1 + 2 in ONE launch (k_conv3_m16p_f2, conv_mfma16_exp.inc): measured slower than the two launches (round 5), so only
+// the EXPERIMENTS flavour carries it (TFL_M16_FUSE12=1); false = not taken, the caller runs the two layers
 bool conv3_m16_first2_fused(hipStream_t st, int B, int Z, int Y, int X, const float* pDiv, const float* div, const float* flags,
                             const double* stats, double count, const void* wfrag1, const float* bias1, float post1,
                             const void* wfrag2, const float* bias2, float post2, void* out_h2, unsigned long long* range_err) {
-  static const bool kpack = !(getenv("TFL_M16_KPACK") && (atoi(getenv("TFL_M16_KPACK")) == 0 || atoi(getenv("TFL_M16_KPACK")) == 2));
-  if (!kpack || (getenv("TFL_M16_TILED") && atoi(getenv("TFL_M16_TILED")) != 0)) return false;
+#ifdef TFL_EXPERIMENTS
+  if (exp_kpack() != 1 || exp_tiled() != 0) return false;
   MIn ci = {pDiv, div, flags, stats, count, nullptr, 0, nullptr};
   return launch_m16p_f2(st, make_dom(Z, Y, X), B, ci, wfrag1, bias1, post1, wfrag2, bias2, post2, out_h2, range_err);
+#else
+  (void)st; (void)B; (void)Z; (void)Y; (void)X; (void)pDiv; (void)div; (void)flags; (void)stats; (void)count; (void)wfrag1; (void)bias1; (void)post1;
+  (void)wfrag2; (void)bias2; (void)post2; (void)out_h2; (void)range_err;
+  return false;
+#endif
+}
+bool conv3_m16_fuse12_requested() {
+#ifdef TFL_EXPERIMENTS
+  const char* ef = getenv("TFL_M16_FUSE12");
+  return ef && atoi(ef) == 1;
+#else
+  return false;
+#endif
 }
 void conv3_m16_mid(hipStream_t st, int B, int Z, int Y, int X, const void* in_h2, const void* wfrag, const float* bias, float post,
                    void* out_h2, unsigned long long* range_err) {
-  const bool tiled = getenv("TFL_M16_TILED") && (atoi(getenv("TFL_M16_TILED")) & 1);      // the tile kernel, kept for comparison
-  static const bool kpack = !(getenv("TFL_M16_KPACK") && atoi(getenv("TFL_M16_KPACK")) == 0);   // 0: k_conv3_m16z
-  if (!tiled && kpack) { launch_m16p<false>(st, make_dom(Z, Y, X), B, in_h2, wfrag, bias, out_h2, post, range_err); return; }
-  if (!tiled) { launch_m16z<false>(st, make_dom(Z, Y, X), B, in_h2, wfrag, bias, out_h2, post, range_err); return; }
-  MIn noin = {nullptr, nullptr, nullptr, nullptr, 0.0, nullptr, 0, nullptr};
-  launch_m16<kModeMid>(st, make_dom(Z, Y, X), B, in_h2, wfrag, bias, out_h2, post, noin, range_err);
+#ifdef TFL_EXPERIMENTS
+  if (exp_tiled() & 1) { MIn noin = {nullptr, nullptr, nullptr, nullptr, 0.0, nullptr, 0, nullptr}; launch_m16<kModeMid>(st, make_dom(Z, Y, X), B, in_h2, wfrag, bias, out_h2, post, noin, range_err); return; }
+  if (exp_kpack() == 0) { launch_m16z<false>(st, make_dom(Z, Y, X), B, in_h2, wfrag, bias, out_h2, post, range_err); return; }
+#endif
+  launch_m16p<false>(st, make_dom(Z, Y, X), B, in_h2, wfrag, bias, out_h2, post, range_err);
 }
 void conv3_m16_tail(hipStream_t st, int B, int Z, int Y, int X, const void* in_h2, const void* wfrag, const float* tail_pack,
                     float post, float* p_out, unsigned long long* range_err) {
-  const bool tiled = getenv("TFL_M16_TILED") && (atoi(getenv("TFL_M16_TILED")) & 2);
-  static const bool kpack = !(getenv("TFL_M16_KPACK") && atoi(getenv("TFL_M16_KPACK")) == 0);
-  if (!tiled && kpack) { launch_m16p<true>(st, make_dom(Z, Y, X), B, in_h2, wfrag, tail_pack, p_out, post, range_err); return; }
-  if (!tiled) { launch_m16z<true>(st, make_dom(Z, Y, X), B, in_h2, wfrag, tail_pack, p_out, post, range_err); return; }
-  MIn noin = {nullptr, nullptr, nullptr, nullptr, 0.0, nullptr, 0, nullptr};
-  launch_m16<kModeTail>(st, make_dom(Z, Y, X), B, in_h2, wfrag, tail_pack, p_out, post, noin, range_err);
+#ifdef TFL_EXPERIMENTS
+  if (exp_tiled() & 2) { MIn noin = {nullptr, nullptr, nullptr, nullptr, 0.0, nullptr, 0, nullptr}; launch_m16<kModeTail>(st, make_dom(Z, Y, X), B, in_h2, wfrag, tail_pack, p_out, post, noin, range_err); return; }
+  if (exp_kpack() == 0) { launch_m16z<true>(st, make_dom(Z, Y, X), B, in_h2, wfrag, tail_pack, p_out, post, range_err); return; }
+#endif
+  launch_m16p<true>(st, make_dom(Z, Y, X), B, in_h2, wfrag, tail_pack, p_out, post, range_err);
 }
 
 // ---- host: weights [8][cin][3][3][3] (cudnn order) -> A fragments ----------------------------------------------------

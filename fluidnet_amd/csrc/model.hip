@@ -112,7 +112,7 @@ __device__ __forceinline__ void reduce_partials(const double* __restrict__ p, lo
 // -- one counter for all blocks serialised 2048 same-address atomics at 128^3 (+16 us on a 19 us kernel, measured); with
 // one counter per plane the atomics of different planes proceed in parallel and only 128 meet on the last one.
 struct StatTail { unsigned* ticket; double* stats; long long per_sample; unsigned per_plane, planes; int B; };
-constexpr int kStatTickets = 1 << 16;       // ticket words a model owns (abi.cpp): B * Z + 1 of them are used
+[[maybe_unused]] constexpr int kStatTickets = 1 << 16;       // ticket words a model owns (abi.cpp): B * Z + 1 of them are used
 // (FOLD is a template flag of the kernels: the default instantiation carries none of this -- its loads stay one batch,
 // tests/test_isa_cpu.py)
 template <bool FOLD>
@@ -639,6 +639,15 @@ long long model_stat_blocks(int B, int Z, int Y, int X) {
   return (long long)((X + 63) / 64) * ((Y + 3) / 4) * Z * B;
 }
 
+bool model_stats_fold_requested() {       // EXPERIMENTS flavour + TFL_STATS_FOLD=1: k_reduce_stats folded into the last block of k_bcs_div_stats
+#ifdef TFL_EXPERIMENTS
+  const char* ef = getenv("TFL_STATS_FOLD");
+  return ef && atoi(ef) == 1;
+#else
+  return false;
+#endif
+}
+
 long long model_stat_pairs_per_plane(int B, int Z, int Y, int X, const float* U, const float* flags, const float* Ubc, const float* div) {
   const Dom d = make_dom(Z, Y, X);
   const dim3 grd = TFL_GRID3(d, B);
@@ -659,27 +668,37 @@ void model_pre(hipStream_t st, bool is3d, int B, int Z, int Y, int X, const floa
   // launch it saves (profiles/r05_step_experiments.txt: k_bcs_div_stats 15.4 -> 23.5 us with two-level tickets, 35.6 with one
   // counter, against 4.2 us for the launch: the chip-coherent stores, their acknowledgement and the ticket sit at the end of
   // every one of the 2048 short blocks of a streaming kernel)
-  const char* ef = getenv("TFL_STATS_FOLD");
-  const bool fused = ticket && (stages & 3) == 3 && d.nw == Z && d.n0 == Z && zlo == 0 && zhi == Z && (ef && atoi(ef) == 1) &&
+#ifdef TFL_EXPERIMENTS
+  const bool fused = ticket && (stages & 3) == 3 && d.nw == Z && d.n0 == Z && zlo == 0 && zhi == Z && model_stats_fold_requested() &&
                      (long long)Z * B + 1 <= kStatTickets && per_plane < (1ll << 31);
+#else
+  const bool fused = false;      // (the producer-side fold exists only in the EXPERIMENTS flavour: measured slower, round 5)
+  (void)ticket; (void)zlo; (void)zhi;
+#endif
   StatTail tl = {nullptr, stats, per_plane * Z, (unsigned)per_plane, (unsigned)(Z * B), B};
   if (fused) tl.ticket = ticket;
   if (stages & 1) {
     if (v.ok) {
       TFL_TIMED_EXT("k_bcs_div_stats", st);
+#ifdef TFL_EXPERIMENTS
       if (fused) {
         if (is3d) TFL_LAUNCH_EXT((k_bcs_div_stats_v4<true, true>), v.grd, v.blk, 0, st, d, U, flags, Ubc, div, partials, tl);
         else TFL_LAUNCH_EXT((k_bcs_div_stats_v4<false, true>), v.grd, v.blk, 0, st, d, U, flags, Ubc, div, partials, tl);
-      } else {
+      } else
+#endif
+      {
         if (is3d) TFL_LAUNCH_EXT((k_bcs_div_stats_v4<true, false>), v.grd, v.blk, 0, st, d, U, flags, Ubc, div, partials, tl);
         else TFL_LAUNCH_EXT((k_bcs_div_stats_v4<false, false>), v.grd, v.blk, 0, st, d, U, flags, Ubc, div, partials, tl);
       }
     } else {
       TFL_TIMED("k_bcs_div_stats", st);
+#ifdef TFL_EXPERIMENTS
       if (fused) {
         if (is3d) k_bcs_div_stats<true, true><<<grd, blk, 0, st>>>(d, U, flags, Ubc, div, partials, tl);
         else k_bcs_div_stats<false, true><<<grd, blk, 0, st>>>(d, U, flags, Ubc, div, partials, tl);
-      } else {
+      } else
+#endif
+      {
         if (is3d) k_bcs_div_stats<true, false><<<grd, blk, 0, st>>>(d, U, flags, Ubc, div, partials, tl);
         else k_bcs_div_stats<false, false><<<grd, blk, 0, st>>>(d, U, flags, Ubc, div, partials, tl);
       }
@@ -728,7 +747,7 @@ void model_project(hipStream_t st, bool is3d, int B, int Z, int Y, int X, const 
   bc.UBC = UBC; bc.UInvMask = UInvMask; bc.fold = UBC ? no_fold() : take_fold();
   const uintptr_t al = (uintptr_t)pPred | (uintptr_t)flags | (uintptr_t)Uio | (uintptr_t)pOut | (uintptr_t)UBC |
                        (uintptr_t)UInvMask;
-  if (X % 4 == 0 && (al & 15) == 0 && !getenv("TFL_NO_VEC4")) {
+  if (X % 4 == 0 && (al & 15) == 0 && !exp_env("TFL_NO_VEC4")) {
     const dim3 vb(32, 8, 1), vg((X / 4 + 31) / 32, (Y + 7) / 8, (unsigned)(d.nw * B));
     TFL_TIMED_EXT("k_project", st);
     if (is3d) TFL_LAUNCH_EXT((k_project_v4<true>), vg, vb, 0, st, d, pPred, flags, stats, count, Uio, pOut, bc);

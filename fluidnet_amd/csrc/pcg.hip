@@ -805,10 +805,10 @@ int pcg_solve(hipStream_t st, bool is3d, int B, int Z, int Y, int X, float* p, c
   float2* wf_hs = wf ? reinterpret_cast<float2*>(cs + 4 * wtot + wf_handoff_k(wg)) + kWfGuard : nullptr;
   int* wferr = wf ? reinterpret_cast<int*>(cs + 4 * wtot + wf_handoff_k(wg) + wf_handoff_s(wg)) : nullptr;
   int epoch = 0;                                // tag of the next sweep; the skewed arrays are zeroed with it
-  static const int wf_cap = getenv("TFL_WF_MAX_BLOCKS") ? std::max(1, atoi(getenv("TFL_WF_MAX_BLOCKS"))) : kWfMaxBlocks;     // (tests: small launches)
+  static const int wf_cap = exp_env("TFL_WF_MAX_BLOCKS") ? std::max(1, atoi(exp_env("TFL_WF_MAX_BLOCKS"))) : kWfMaxBlocks;     // (tests: small launches)
   const int wf_slabs = std::max(1, std::min(wf_cap, kWfMaxBlocks) / std::max(wg.ns, 1));      // slabs per launch
   // development aid: TFL_WF_TRACE=1 prints when every sub-box of the last forward / backward sweep started and finished
-  static const bool wf_trace_on = getenv("TFL_WF_TRACE") != nullptr;
+  static const bool wf_trace_on = exp_env("TFL_WF_TRACE") != nullptr;
   long long* wf_trace = nullptr;
   if (wf && wf_trace_on && precond && hipMalloc(&wf_trace, sizeof(long long) * 4 * wg.ns * wg.nb) != hipSuccess) wf_trace = nullptr;
   struct TraceGuard { long long*& p; ~TraceGuard() { if (p) { (void)hipFree(p); p = nullptr; } } } trace_guard{wf_trace};   // every exit frees it
@@ -952,7 +952,7 @@ int pcg_solve(hipStream_t st, bool is3d, int B, int Z, int Y, int X, float* p, c
         if (wf && pc) {
           int e = 0;
           if (!hip_ok(hipMemcpy(&e, wferr, sizeof(int), hipMemcpyDeviceToHost), "memcpy")) return -4;
-          static const bool pretend = getenv("TFL_WF_TEST_TIMEOUT") != nullptr;     // tests: exercise the caller's fallback
+          static const bool pretend = exp_env("TFL_WF_TEST_TIMEOUT") != nullptr;     // tests: exercise the caller's fallback
           if (pretend) e = 1;
           // (its sub-boxes wait for each other, so all of them must be resident at once: not the case when something else holds
           // part of the GPU. The caller repeats the solve with one launch per hyperplane.)

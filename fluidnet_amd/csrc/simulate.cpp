@@ -540,7 +540,7 @@ long long slab_ws(const SlabGeom& g, const tfl_sim_state* s, float* ws, SlabWs* 
 struct Win { int a, b; };
 Win ext(const SlabGeom& g, int below, int above) {
   Win w;
-  static const int widen = getenv("TFL_SLAB_WIDEN") ? atoi(getenv("TFL_SLAB_WIDEN")) : 0;   // development aid
+  static const int widen = tfl::exp_env("TFL_SLAB_WIDEN") ? atoi(tfl::exp_env("TFL_SLAB_WIDEN")) : 0;   // development aid
   below += widen; above += widen; w.a = g.o0 - below < 0 ? 0 : g.o0 - below; w.b = g.o1 + above > g.Zl ? g.Zl : g.o1 + above; return w;
 }
 int set_win(tfl_ctx* c, Win w) { return tfl_set_z_window(c, w.a, w.b, 0, 0); }

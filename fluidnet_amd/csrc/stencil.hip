@@ -286,7 +286,7 @@ void velocity_update(hipStream_t st, bool is3d, int B, int Z, int Y, int X, floa
 void add_buoyancy(hipStream_t st, bool is3d, int B, int Z, int Y, int X, const float* Usrc, float* U, const float* flags,
                   const float* density, float sx, float sy, float sz) {
   const bool vec = (X % 4 == 0) && ((((uintptr_t)U | (uintptr_t)Usrc | (uintptr_t)flags | (uintptr_t)density) & 15) == 0) &&
-                   !getenv("TFL_NO_VEC4");
+                   !exp_env("TFL_NO_VEC4");
   if (vec) {
     const Dom d = make_dom(Z, Y, X);
     const dim3 blk(32, 8, 1), grd((X / 4 + 31) / 32, (Y + 7) / 8, (unsigned)(d.nw * B));

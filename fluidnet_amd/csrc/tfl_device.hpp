@@ -108,19 +108,25 @@ __device__ __forceinline__ void block_tile(const BlockOrder& o, int& bx, int& by
   const unsigned y = div32(p, o.dgx);
   bx = (int)(p - y * o.gx); by = (int)y; bz = (int)z;
 }
-// TFL_XCD_ORDER=0 restores the hardware order everywhere (A/B switch; read once)
+// EXPERIMENTS flavour: TFL_XCD_ORDER=0 restores the hardware order everywhere (A/B switch; read once)
 inline bool xcd_order_enabled() {
+#ifdef TFL_EXPERIMENTS
   static const bool on = !(getenv("TFL_XCD_ORDER") && atoi(getenv("TFL_XCD_ORDER")) == 0);
   return on;
+#else
+  return true;
+#endif
 }
 // run length of a gx x gy (x gz) launch: an eighth of a plane per XCD (measured best, or level with one run per XCD, for the
 // scalar advection and the curl / confinement kernels at 128^3 and 256^3: profiles/r05_xcd_order.txt). TFL_XCD_RUN = tiles
-// per run and TFL_XCD_ORDER = 1 (one run per XCD) are the experiment switches.
+// per run and TFL_XCD_ORDER = 1 (one run per XCD) are the switches of the EXPERIMENTS flavour.
 inline unsigned xcd_run(unsigned gx, unsigned gy) {
+#ifdef TFL_EXPERIMENTS
   static const int run = getenv("TFL_XCD_RUN") ? atoi(getenv("TFL_XCD_RUN")) : 0;
   static const int mode = getenv("TFL_XCD_ORDER") ? atoi(getenv("TFL_XCD_ORDER")) : 2;
   if (run > 0) return (unsigned)run;
   if (mode == 1) return 0;
+#endif
   return gx * gy >= 8 ? gx * gy / 8 : 1;
 }
 

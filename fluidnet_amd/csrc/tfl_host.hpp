@@ -3,9 +3,22 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 
+#include <cstdlib>
+
 #include "tfl_device.hpp"
 
 namespace tfl {
+
+// A switch that only the EXPERIMENTS flavour of the library reads (-DTFL_EXPERIMENTS, `make exp`: the earlier and the
+// measured-slower kernel forms, chunk-length / block-order overrides, test hooks); in the product library it is always unset.
+inline const char* exp_env(const char* name) {
+#ifdef TFL_EXPERIMENTS
+  return getenv(name);
+#else
+  (void)name;
+  return nullptr;
+#endif
+}
 
 // The z-window of the calling thread's current operator (set by abi.cpp from tfl_set_z_window, cleared after the
 // launch): planes [a0, a1) and [b0, b1) in array indices; all zero = the whole array.
@@ -167,6 +180,7 @@ int normalize_pressure_mean(hipStream_t st, bool is3d, int B, int Z, int Y, int 
 
 // model.hip
 long long model_stat_blocks(int B, int Z, int Y, int X);
+bool model_stats_fold_requested();
 long long model_stat_pairs_per_plane(int B, int Z, int Y, int X, const float* U, const float* flags, const float* Ubc, const float* div);   // as model_pre lays them out
 void model_pre(hipStream_t st, bool is3d, int B, int Z, int Y, int X, const float* U, const float* flags, float* Ubc,
                float* div, double* partials, double* stats, int zlo, int zhi, int stages = 3, unsigned* ticket = nullptr);
@@ -248,6 +262,7 @@ void conv3_m16_tail(hipStream_t st, int B, int Z, int Y, int X, const void* in_h
 bool conv3_m16_first2_fused(hipStream_t st, int B, int Z, int Y, int X, const float* pDiv, const float* div, const float* flags,
                             const double* stats, double count, const void* wfrag1, const float* bias1, float post1,
                             const void* wfrag2, const float* bias2, float post2, void* out_h2, unsigned long long* range_err);
+bool conv3_m16_fuse12_requested();      // EXPERIMENTS flavour + TFL_M16_FUSE12=1 (the default library: always false)
 size_t conv3_m16_frag_halves(int cin);
 float conv3_m16_pack_tail(const float* w4 /* [8][8] (out, in) */, uint16_t* frag_buf_of_a_cin8_layer);
 float conv3_m16_pack_weights(const float* w, int cin, uint16_t* out);

@@ -94,7 +94,7 @@ __device__ __forceinline__ void v4_load6(const V4Ctx& c, const float* __restrict
 struct Vec4Launch { bool ok; dim3 blk, grd; };
 inline Vec4Launch vec4_launch(int B, int Z, int Y, int X, std::initializer_list<const void*> ptrs) {
   Vec4Launch l; l.ok = false;
-  static const bool disabled = getenv("TFL_NO_VEC4") != nullptr;
+  static const bool disabled = exp_env("TFL_NO_VEC4") != nullptr;
   uintptr_t al = 0;
   for (const void* q : ptrs) al |= (uintptr_t)q;
   if (disabled || X % 4 != 0 || (al & 15) != 0) return l;

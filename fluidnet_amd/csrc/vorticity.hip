@@ -932,7 +932,7 @@ bool vorticity_confinement_fused(hipStream_t st, int B, int Z, int Y, int X, con
     const long long tiles = (long long)pcx * pcy * B;
     if (pslots > 0 && tiles * (na + nb) > 0) {
       int cz = march_chunk(tiles, na, nb, pslots, kPipeFill, 4);
-      if (const char* e = getenv("TFL_VORT_CZ")) cz = atoi(e) > 0 ? atoi(e) : cz;
+      if (const char* e = exp_env("TFL_VORT_CZ")) cz = atoi(e) > 0 ? atoi(e) : cz;
       {
         const int chunks_a = (na + cz - 1) / cz, chunks = chunks_a + (nb + cz - 1) / cz;
         const int n_blocks = (int)(pcx * pcy * chunks * B);
@@ -948,7 +948,7 @@ bool vorticity_confinement_fused(hipStream_t st, int B, int Z, int Y, int X, con
   const int slots = vort_fused_slots();     // (the dynamic-LDS attribute is a per-device setting: asked once per device)
   if (slots <= 0) return false;             // the caller copies and runs the two-launch form
   int cz = march_chunk((long long)cxn * cyn * B, na, nb, slots, 6, 4);
-  if (const char* e = getenv("TFL_VORT_CZ")) cz = atoi(e) > 0 ? atoi(e) : cz;
+  if (const char* e = exp_env("TFL_VORT_CZ")) cz = atoi(e) > 0 ? atoi(e) : cz;
   const int chunks_a = (na + cz - 1) / cz, chunks = chunks_a + (nb + cz - 1) / cz;
   const int n_blocks = cxn * cyn * chunks * B;
   TFL_TIMED_EXT("k_vort_fused", st);

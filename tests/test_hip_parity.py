@@ -15,6 +15,8 @@ import pytest
 import scenes
 from golden.make_golden import run_ops
 
+from flavours import child_env  # noqa: E402
+
 pytestmark = pytest.mark.gpu
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -327,7 +329,7 @@ def test_vec4_kernels_and_their_fallbacks_match_the_oracle(no_vec4):
     env = dict(os.environ)
     env.pop("TFL_NO_VEC4", None)
     if no_vec4:
-        env["TFL_NO_VEC4"] = "1"
+        env = child_env(env, {"TFL_NO_VEC4": "1"})      # (a switch of the EXPERIMENTS flavour of the library)
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and "VEC4_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
 
@@ -406,9 +408,9 @@ def test_pcg_triangular_solves_both_schedules(mode):
         env["TFL_PCG_HYPERPLANES"] = "1"
     env.pop("TFL_WF_MAX_BLOCKS", None)
     if mode == "timeout":
-        env["TFL_WF_TEST_TIMEOUT"] = "1"
+        env = child_env(env, {"TFL_WF_TEST_TIMEOUT": "1"})      # (test hooks of the EXPERIMENTS flavour of the library)
     if mode == "chunks":
-        env["TFL_WF_MAX_BLOCKS"] = "4"
+        env = child_env(env, {"TFL_WF_MAX_BLOCKS": "4"})
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and "PCG_PATH_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
 
@@ -468,7 +470,7 @@ def test_advection_kernel_variants_are_bit_exact(env):
     e = dict(os.environ)
     for k in ("TFL_VEL3_KZ", "TFL_SCAL3_TZ", "TFL_ADVECT_GATHER", "TFL_ADVECT_MODE", "TFL_SCAL3M_CZ_A", "TFL_SCAL3M_CZ_B", "TFL_SCAL3_MARCH"):
         e.pop(k, None)
-    e.update(env)
+    e = child_env(e, env)
     out = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and "ADV_VARIANTS_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
 
@@ -485,7 +487,7 @@ def test_block_order_variants_are_bit_exact(env):
     e = dict(os.environ)
     for k in ("TFL_XCD_ORDER", "TFL_XCD_RUN"):
         e.pop(k, None)
-    e.update(env)
+    e = child_env(e, env)
     out = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider", "-k",
                           "test_hip_matches_oracle or test_maccormack_large_displacements_and_ragged_grids or "
                           "test_fused_vorticity_confinement_equals_the_two_launch_form"], env=e, capture_output=True, text=True, timeout=1200)
@@ -583,7 +585,7 @@ def test_fused_vorticity_kernel_variants(env):
     e = dict(os.environ)
     for k in ("TFL_VORT_PIPE", "TFL_VORT_CZ", "TFL_VORT_FUSED", "TFL_XCD_ORDER"):
         e.pop(k, None)
-    e.update(env)
+    e = child_env(e, env)
     out = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
                           "-k", "test_fused_vorticity_confinement_equals_the_two_launch_form"], env=e, capture_output=True, text=True, timeout=1200)
     assert out.returncode == 0 and " passed" in out.stdout and "failed" not in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]

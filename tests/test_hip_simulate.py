@@ -15,6 +15,8 @@ import pytest
 import scenes
 from oracle import simulate_np as S
 
+from flavours import child_env, experiments_flavour  # noqa: E402
+
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 TOL = 1e-5
@@ -172,6 +174,7 @@ def test_simulate_gravity_and_rgb_density(oracle):
         assert np.array_equal(tb["density"][i].cpu().numpy(), nb["density"][i])
 
 
+@experiments_flavour
 def test_conv_paths_agree_3d(oracle, monkeypatch):
     """The split-operand fp16 MFMA kernels of conv_mfma16.hip (the default: z-marched 32x8 columns, and the 32x4x4 tile
     form kept beside them), the vector-ALU kernels of conv_valu.hip (Winograd F(2,3) along x), the fp32-MFMA implicit GEMM
@@ -210,6 +213,7 @@ def test_conv_paths_agree_3d(oracle, monkeypatch):
         assert scenes.rel_l2(pm.cpu().numpy(), p_ref) <= TOL and scenes.rel_l2(Um.cpu().numpy(), U_ref) <= TOL
 
 
+@experiments_flavour
 def test_conv_fused_layers_and_mfma_tail(monkeypatch):
     """Round 5: layers 1 + 2 of the 3-D default net in ONE launch (k_conv3_m16p_f2: layer 1's planes stay in an LDS ring, its
     x / y halo is recomputed) issue the same MFMAs in the same order per voxel as k_conv3_m16p_in + k_conv3_m16p -- the
@@ -262,6 +266,7 @@ def test_conv_fused_layers_and_mfma_tail(monkeypatch):
     assert m.range_errors(tp) > 0
 
 
+@experiments_flavour
 def test_stats_reduction_folded_into_its_producer(monkeypatch):
     """Round 5: the fp64 reduction of the per-block {sum u, sum u^2} partials (the std normaliser of the net input) runs in
     the last block of k_bcs_div_stats to finish (two-level ticket counters, chip-coherent partials) instead of a launch of
