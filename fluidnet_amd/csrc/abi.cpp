@@ -5,6 +5,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -436,9 +437,29 @@ int tfl_vorticityConfinementFrom(tfl_ctx* c, const tfl_tensor* USrc, const tfl_t
       tfl::vorticity_confinement_fused(c->stream, flags->B, flags->Z, flags->Y, flags->X, USrc->data, U->data, flags->data, strength))
     return check_launch(c, "vorticityConfinementFrom");
   // 2-D, a grid below the fused kernel's size, or TFL_VORT_FUSED=0: the two launches read USrc and write U (round 5) ...
-  if (tfl::vorticity_confinement(c->stream, is3D != 0, flags->B, flags->Z, flags->Y, flags->X, U->data, flags->data, strength,
-                                 curl->data, curlNorm->data, 3, USrc->data))
+  // Under a z-window pass A must cover what pass B taps: |curl| two planes below / one above, curl one below -- the
+  // window widened by two planes either way, its two runs merged where they meet; pass B then runs on the window itself.
+  const tfl::ZWin w0 = tfl::g_zwin;
+  const bool windowed = w0.a1 > w0.a0 || w0.b1 > w0.b0;
+  if (windowed) {
+    tfl::ZWin wa = {std::max(w0.a0 - 2, 0), std::min(w0.a1 + 2, (int)flags->Z), 0, 0};
+    if (w0.b1 > w0.b0) { wa.b0 = std::max(w0.b0 - 2, 0); wa.b1 = std::min(w0.b1 + 2, (int)flags->Z); }
+    if (w0.a1 <= w0.a0) { wa.a0 = wa.b0; wa.a1 = wa.b1; wa.b0 = wa.b1 = 0; }
+    else if (wa.b1 > wa.b0 && wa.b0 <= wa.a1) { wa.a1 = wa.b1; wa.b0 = wa.b1 = 0; }
+    tfl::g_zwin = wa;
+    const bool a_ok = tfl::vorticity_confinement(c->stream, is3D != 0, flags->B, flags->Z, flags->Y, flags->X, U->data, flags->data, strength,
+                                                 curl->data, curlNorm->data, 1, USrc->data);
+    tfl::g_zwin = w0;
+    if (a_ok && tfl::vorticity_confinement(c->stream, is3D != 0, flags->B, flags->Z, flags->Y, flags->X, U->data, flags->data, strength,
+                                           curl->data, curlNorm->data, 2, USrc->data))
+      return check_launch(c, "vorticityConfinementFrom");
+    if (a_ok) return fail(c, TFL_EUNSUPPORTED, "vorticityConfinementFrom: pass B could not read USrc on this grid under a z-window");
+  } else if (tfl::vorticity_confinement(c->stream, is3D != 0, flags->B, flags->Z, flags->Y, flags->X, U->data, flags->data, strength,
+                                        curl->data, curlNorm->data, 3, USrc->data))
     return check_launch(c, "vorticityConfinementFrom");
+  if (windowed)      // (the one-cell kernels below run in place on a copy: the same two windows are needed there -- not built)
+    return fail(c, TFL_EUNSUPPORTED, "vorticityConfinementFrom: this grid takes the one-cell kernels, which do not run from USrc under a z-window; "
+                                     "copy USrc into U and call tfl_vorticityConfinement per pass (tfl_set_stages) with the passes' own windows");
   // ... or, where only the one-cell kernels apply (X % 4 != 0, misaligned views), the planes of the window are copied and the
   // two-launch form runs in place
   {
@@ -704,8 +725,10 @@ tfl_model* tfl_model_create_opts(tfl_ctx* c, int is3D, int nlayers, const int32_
                 o.norm_func == TFL_NORMFUNC_STD && o.nonlin == TFL_NONLIN_RELU && !o.pressure_skip);
   auto cleanup = [&](const char* msg) -> tfl_model* { tfl_model_destroy(c, m); return bad(msg); };
   if (hipMalloc((void**)&m->d_stats, sizeof(double) * 2 * kMaxBatch) != hipSuccess) return cleanup("hipMalloc failed");
-  if (hipMalloc((void**)&m->d_ticket, sizeof(unsigned) * (1 << 16)) != hipSuccess || hipMemset(m->d_ticket, 0, sizeof(unsigned) * (1 << 16)) != hipSuccess)   // model.hip kStatTickets
+#ifdef TFL_EXPERIMENTS      // the ticket words of the producer-side stats fold (model.hip kStatTickets): EXPERIMENTS flavour only
+  if (hipMalloc((void**)&m->d_ticket, sizeof(unsigned) * (1 << 16)) != hipSuccess || hipMemset(m->d_ticket, 0, sizeof(unsigned) * (1 << 16)) != hipSuccess)
     return cleanup("hipMalloc failed");
+#endif
   // The shape-generic kernels are instantiated for 1, 2, 4, 8, 16, 32, 64 output channels. Any other width (the
   // `yang` topology of model.lua:188-205 has 6) is zero-padded to the next one: the extra channels carry
   // relu(0 + 0) = 0 into zero weights of the next layer, i.e. every sum gains exact `+ 0 * 0` terms only.
@@ -890,6 +913,9 @@ int64_t tfl_model_range_errors(tfl_ctx* c, tfl_model* m) {
   if (m->h_range) *(volatile unsigned long long*)m->h_range = 0;      // acknowledged: the next forward runs again
   return (int64_t)v;
 }
+
+// (library-internal: the device word itself, for the z-slab step's collective gate -- simulate.cpp)
+const unsigned long long* tfl_model_range_counter_dev(const tfl_model* m) { return m ? m->d_range_err : nullptr; }
 
 int64_t tfl_model_range_flag(tfl_ctx* c, tfl_model* m) {
   if (!c || !m) return -1;

@@ -15,6 +15,8 @@
 #include <cstring>
 #include <string>
 
+extern "C" const unsigned long long* tfl_model_range_counter_dev(const tfl_model* m);      // abi.cpp (library-internal)
+
 struct tfl_bc_plan {
   tfl_tensor bc, inv;      // the dense pair (pointers kept, not owned)
   int* d_idx = nullptr;    // device list of non-identity elements
@@ -244,8 +246,10 @@ int tfl_simulate_step(tfl_ctx* c, const tfl_sim_params* prm, const tfl_sim_state
   const bool vfused = vort && tfl::vorticity_confinement_fused_ok(is3D != 0, (int)z.Z, z.N / z.B);
   // scratch of the vorticity operator (curl[3] | cnorm) = the advectVel `fwd` / `bwd` planes, dead after the advection. It must
   // not touch `Uadv` (planes 2C .. 3C of the workspace): the two-launch confinement may still read its velocity from there.
-  tfl_tensor curl = view(ws, 3), cnorm = view(ws + 3 * z.N, 1);
-  tfl_tensor Utmp = view(ws, (int)z.C);                    // the same planes as a scratch velocity (fused confinement: no curl arrays)
+  // 3-D: curl on the `bwd` planes and |curl| behind `Uadv` -- disjoint from the scratch velocity `Utmp` below as well,
+  // so that the two-launch confinement is safe whichever array the velocity sits in (the workspace holds (2C + 4) N floats)
+  tfl_tensor curl = z.is3d ? view(ws + 3 * z.N, 3) : view(ws, 3), cnorm = z.is3d ? view(ws + 9 * z.N, 1) : view(ws + 3 * z.N, 1);
+  tfl_tensor Utmp = view(ws, (int)z.C);                    // the `fwd` planes as a scratch velocity (fused confinement: no curl arrays)
   const tfl_tensor* cur = &Uadv;                           // where the velocity of the step currently lives
   rc = set_const_vals(c, s, cur, !Uadv_done, Unchanged{false, false, false}, density_done);
   if (rc) return rc;
@@ -529,7 +533,7 @@ long long slab_ws(const SlabGeom& g, const tfl_sim_state* s, float* ws, SlabWs* 
   long long off = msg_layout(g, m, 4, nullptr);
   off = (off + 3) & ~3ll;
   const long long stats_off = off;
-  off += 4ll * g.B + 2ll * kReachFlags;               // 2*B doubles + the reach flags of check_reach = 2 (behind the stats)
+  off += 4ll * g.B + 2ll * (kReachFlags + 1);         // 2*B doubles + the reach / range flags of check_reach = 2 (behind the stats)
   off = (off + 3) & ~3ll;
   long long model = s->model ? tfl_model_workspace_floats(s->model, g.B, g.Zl, s->flags->Y, s->flags->X) : 0;
   const long long comp = std::max<long long>(13 * g.N, model) + 4;
@@ -644,7 +648,10 @@ int tfl_simulate_step_slab(tfl_ctx* c, const tfl_sim_params* prm, const tfl_sim_
       return TFL_EINVAL;
     }
   }
-  if (!c->capturing && s->model && tfl_model_range_flag(c, s->model) > 0) {      // as tfl_simulate_step; the neighbours' receives are finished first
+  // The fp16 range gate of tfl_simulate_step -- only where refusing cannot strand a neighbour: a slab WITHOUT
+  // neighbours, or (below) collectively under check_reach = 2. A rank that refused on its own word would leave the others
+  // waiting for its halos; the host of a cut run polls tfl_model_range_flag / tfl_model_range_errors and stops every rank.
+  if (!c->capturing && !multi && s->model && tfl_model_range_flag(c, s->model) > 0) {
     for (int t = 0; t < 2; t++)
       if (multi && (sl->in_flight & (1 << t))) { (void)msg_finish(c, g, comm, m[t]); sl->in_flight &= ~(1 << t); }
     c->err = "simulate_step_slab: an earlier step's ConvNet projection clamped activations at the fp16 range (a blown-up simulation); "
@@ -661,14 +668,19 @@ int tfl_simulate_step_slab(tfl_ctx* c, const tfl_sim_params* prm, const tfl_sim_
     // "exact" (round 6): the reach THIS step needs, agreed by all ranks, before anything is written. One-hot flags
     // (max|u_z| dt >= r, r = 1 .. 8) so that the transport's SUM all-reduce can combine them; one host synchronisation.
     if (c->capturing) { c->err = "simulate_step_slab: check_reach = 2 synchronises with the host and cannot be recorded into a graph"; return TFL_EUNSUPPORTED; }
-    if (!c->h_reach_flags && hipHostMalloc((void**)&c->h_reach_flags, sizeof(double) * kReachFlags, hipHostMallocDefault) != hipSuccess) {
+    if (!c->h_reach_flags && hipHostMalloc((void**)&c->h_reach_flags, sizeof(double) * (kReachFlags + 1), hipHostMallocDefault) != hipSuccess) {
       c->h_reach_flags = nullptr; c->err = "simulate_step_slab: hipHostMalloc failed"; return TFL_EHIP;
     }
     double* d_flags = W.stats + 2 * g.B;
-    tfl::reach_flags(c->stream, c->d_reach, prm->dt, kReachFlags, d_flags);
-    if (multi && comm->allreduce_sum(comm->user, d_flags, kReachFlags) != 0) { c->err = "simulate_step_slab: comm callback failed (allreduce_sum, reach)"; return TFL_EINVAL; }
-    if (hipMemcpyAsync(c->h_reach_flags, d_flags, sizeof(double) * kReachFlags, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+    tfl::reach_flags(c->stream, c->d_reach, prm->dt, kReachFlags, d_flags, tfl_model_range_counter_dev(s->model));
+    if (multi && comm->allreduce_sum(comm->user, d_flags, kReachFlags + 1) != 0) { c->err = "simulate_step_slab: comm callback failed (allreduce_sum, reach)"; return TFL_EINVAL; }
+    if (hipMemcpyAsync(c->h_reach_flags, d_flags, sizeof(double) * (kReachFlags + 1), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
         hipStreamSynchronize(c->stream) != hipSuccess) { c->err = "simulate_step_slab: reading the reach flags failed"; (void)hipGetLastError(); return TFL_EHIP; }
+    if (c->h_reach_flags[kReachFlags] > 0.0) {      // some rank's conv stack left the fp16 range: EVERY rank refuses this step
+      c->err = "simulate_step_slab: an earlier step's ConvNet projection clamped activations at the fp16 range on some rank (a blown-up "
+               "simulation); read the counts with tfl_model_range_errors, or create the model under TFL_CONV_PATH=winograd (strict fp32)";
+      return TFL_ERANGE;
+    }
     int need = 1;
     for (int r = 0; r < kReachFlags; r++) if (c->h_reach_flags[r] > 0.0) need = r + 2;
     if (need > g.R) {
@@ -906,6 +918,7 @@ struct tfl_slab_graph {
   const tfl_sim_state* s = nullptr;
   tfl_slab* sl = nullptr;
   int reach = 1;
+  bool multi = false;                 // the slab has neighbours
   size_t nodes = 0;
 };
 
@@ -923,7 +936,7 @@ tfl_slab_graph* tfl_slab_graph_create(tfl_ctx* c, const tfl_sim_params* prm, con
   // the U / p message the last eager step left in flight is consumed now: a captured step starts and ends with none
   if (sl->in_flight && tfl_slab_drain(c, s, sl, comm, ws, ws_floats) != TFL_OK) return nullptr;
   tfl_slab_graph* G = new tfl_slab_graph();
-  G->prm = prm; G->s = s; G->sl = sl; G->reach = g.R;
+  G->prm = prm; G->s = s; G->sl = sl; G->reach = g.R; G->multi = multi;
   if (hipStreamCreateWithFlags(&G->cap, hipStreamNonBlocking) != hipSuccess) { c->err = "slab_graph_create: hipStreamCreate failed"; delete G; return nullptr; }
   hipStream_t user = c->stream;
   // everything queued so far on the caller's stream happens before the recording stream is used at all (warm-up steps)
@@ -969,7 +982,7 @@ int tfl_slab_graph_step(tfl_ctx* c, tfl_slab_graph* G) {
       return TFL_EINVAL;
     }
   }
-  if (G->s->model && tfl_model_range_flag(c, G->s->model) > 0) {
+  if (!G->multi && G->s->model && tfl_model_range_flag(c, G->s->model) > 0) {     // (a slab with neighbours never refuses on its own word: see the eager step)
     c->err = "simulate_step_slab: an earlier step's ConvNet projection clamped activations at the fp16 range (a blown-up simulation); "
              "read the count with tfl_model_range_errors, or create the model under TFL_CONV_PATH=winograd (strict fp32)";
     return TFL_ERANGE;

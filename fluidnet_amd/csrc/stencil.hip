@@ -228,12 +228,14 @@ __global__ __launch_bounds__(256) void k_absmax(long long n, const float* __rest
 
 // flags[r - 1] = 1.0 where *maxu * dt >= r (r = 1 .. n): the one-hot form of "back-trace reach needed" that a SUM all-reduce can
 // combine over ranks (tfl_simulate_step_slab, check_reach = 2); the product is formed in fp32 like the host-side check
-__global__ void k_reach_flags(const float* __restrict__ maxu, float dt, int n, double* __restrict__ flags) {
+// flags[n] (range_count given) = this rank's conv stack has clamped activations at the fp16 range since the count was last read
+__global__ void k_reach_flags(const float* __restrict__ maxu, float dt, int n, double* __restrict__ flags, const unsigned long long* __restrict__ range_count) {
   const int r = threadIdx.x + 1;
   if (r <= n) flags[r - 1] = (*maxu * dt >= (float)r) ? 1.0 : 0.0;
+  if (r == n + 1) flags[n] = (range_count && *range_count != 0ull) ? 1.0 : 0.0;
 }
-void reach_flags(hipStream_t st, const float* maxu, float dt, int n, double* flags) {
-  k_reach_flags<<<1, 64, 0, st>>>(maxu, dt, n, flags);
+void reach_flags(hipStream_t st, const float* maxu, float dt, int n, double* flags, const unsigned long long* range_count) {
+  k_reach_flags<<<1, 64, 0, st>>>(maxu, dt, n, flags, range_count);
 }
 
 void absmax(hipStream_t st, long long n, const float* x, float* out, bool reset) {

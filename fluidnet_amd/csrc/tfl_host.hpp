@@ -146,7 +146,7 @@ void rectangular_blur(hipStream_t st, bool is3d, int B, int C, int Z, int Y, int
 void signed_distance_field(hipStream_t st, int B, int Z, int Y, int X, int rad, const float* flags, float* dst);
 void stream_copy(hipStream_t st, long long n4, const float* src, float* dst);   // n4 float4s, 16-byte aligned
 void absmax(hipStream_t st, long long n, const float* x, float* out, bool reset);   // *out = max(*out, max |x|)
-void reach_flags(hipStream_t st, const float* maxu, float dt, int n, double* flags);   // flags[r-1] = (*maxu * dt >= r), r = 1..n (n <= 64)
+void reach_flags(hipStream_t st, const float* maxu, float dt, int n, double* flags, const unsigned long long* range_count = nullptr);   // flags[r-1] = (*maxu * dt >= r), r = 1..n (n <= 62); flags[n] = (*range_count != 0) when given
 
 // vorticity.hip
 // stages: bit 0 = pass A (U -> curl, |curl|), bit 1 = pass B (curl, |curl|, flags, U -> U); a z-slab rank runs the two

@@ -467,6 +467,9 @@ typedef struct tfl_slab {
                              returns TFL_EREACH on EVERY rank with nothing written; the host widens the halos
                              (tfl_slab_needed_reach, tfl_slab_exchange) and calls again, so the cut run stays the
                              un-cut run whatever the flow does (fluidnet_amd/dist.py SlabSimulation does it by itself).
+                             The same all-reduce carries every rank's fp16 range word, so TFL_ERANGE is collective too
+                             in this mode; with check_reach 0 / 1 a slab that has neighbours never returns TFL_ERANGE on
+                             its own (the others would wait for its halos): poll tfl_model_range_flag on the host.
                              Costs the host its lead over the device (~10-30 us per step): opt-in */
   int32_t in_flight;      /* OUT/IN, initialise to 0: bit mask of halo messages started by the previous call and not
                              yet consumed (tfl_simulate_step_slab finishes them; tfl_slab_drain does so explicitly) */
