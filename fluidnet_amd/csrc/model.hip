@@ -13,6 +13,7 @@
 //                     U_bc/scale, pPred) * scale), optionally fused with simulate()'s trailing
 //                     setConstVals + clamp (lib/simulate.lua:321-326)
 #include "tfl_device.hpp"
+#include "tfl_fastmath.hpp"
 #include "tfl_host.hpp"
 #include "tfl_vec4.hpp"
 
@@ -517,13 +518,21 @@ __global__ __launch_bounds__(256, TFL_LB_PROJECT) void k_project_v4(Dom d, const
   }
   float po[4];
   const bool row_border = j < 1 || j > d.Y - 2 || (IS3D && (k < 1 || k > d.Z - 2));
+  const bool scale_ok = scale >= 0x1p-12f && scale <= 0x1p21f;      // (one batch item per block: uniform)
+  const float inv_scale = scale_ok ? rcp_refined(scale) : 0.0f;
 #pragma unroll
   for (int q = 0; q < 4; q++) {
     const int i = i0 + q;
     const int f = (int)fc[q];
     const int fxm = q > 0 ? (int)fc[q - 1] : (int)f_left, fxp = q < 3 ? (int)fc[q + 1] : (int)f_right;
     const float pxm = q > 0 ? pc[q - 1] : p_left;
-    float v[3] = {u[0][q] / scale, u[1][q] / scale, IS3D ? u[2][q] / scale : 0.0f};
+    // nn.ApplyScale(true) = CDivTable (apply_scale.lua:24-30). The twelve quotients of a thread share their denominator: one
+    // refined reciprocal + an exact-remainder step each (tfl_fastmath.hpp div_by<1>: bit-equal to `/` for a scale in
+    // [2^-12, 2^21] and |u| in [2^-40, 2^40], profiles/r03_exact_math.txt; u = -0 gives +0; round 6: the IEEE divisions were a
+    // fifth of this kernel's 674 vector instructions per wave) -- `/` itself for a scale outside that range (block-uniform)
+    float v[3];
+    if (scale_ok) { v[0] = div_by<1>(u[0][q], scale, inv_scale); v[1] = div_by<1>(u[1][q], scale, inv_scale); v[2] = IS3D ? div_by<1>(u[2][q], scale, inv_scale) : 0.0f; }
+    else { v[0] = u[0][q] / scale; v[1] = u[1][q] / scale; v[2] = IS3D ? u[2][q] / scale : 0.0f; }
     if (!(row_border || i < 1 || i > d.X - 2)) {   // velocityUpdateForward, tfluids.cc:1072-1156
       const int fn[3] = {fxm, (int)fym[q], IS3D ? (int)fzm[q] : 0};
       const float pn[3] = {pxm, pym[q], pzm[q]};
