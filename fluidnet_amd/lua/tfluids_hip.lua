@@ -507,25 +507,47 @@ function M.Slab(o)
   self.desc.z_total, self.desc.z_first = o.zTotal, o.zFirst
   self.desc.own_lo, self.desc.own_hi = o.ownLo, o.ownHi
   self.desc.reach, self.desc.overlap = o.reach or 1, b2i(o.overlap)
-  self.desc.check_reach, self.desc.in_flight = b2i(o.checkReach ~= false), 0
+  -- checkReach: true (default) = a violation is reported by the NEXT step; 'exact' = found before the step, collectively,
+  -- nothing written (tfl_slab.check_reach = 2: the error names the reach to lay the slab out for); false = unchecked
+  self.desc.check_reach, self.desc.in_flight = (o.checkReach == 'exact') and 2 or b2i(o.checkReach ~= false), 0
   if (o.world or 1) > 1 then
     assert(type(o.id) == 'string' and #o.id == 128, 'Slab: id = the 128 bytes of M.rcclUniqueId() of rank 0')
     self.comm = lib.tfl_rccl_comm_create(ctx, o.id, o.rank, o.world)
     if self.comm == nil then error('tfluids_hip: ' .. ffi.string(lib.tfl_last_error(ctx))) end
     self.comm = ffi.gc(self.comm, function(c) lib.tfl_rccl_comm_destroy(ctx, c) end)
     self.callbacks = lib.tfl_rccl_comm_callbacks(self.comm)
+    -- a slab without the strip / interior split has nothing for a transfer to overlap with: RCCL on the step's own stream
+    -- (an event hop between two streams costs 12-15 us on the device, eight of them per step)
+    if not o.overlap then check(lib.tfl_rccl_comm_set_inline(self.comm, 1)) end
   end
   return self
 end
+-- Record the rank-step into a HIP graph (tfl_slab_graph_create): call after a few slab:simulate() steps; from then on
+-- slab:simulate() is ONE hipGraphLaunch with mconf / batch / model frozen as they were. false + the reason when the step
+-- cannot be recorded (the steps stay eager).
+function Slab:record()
+  if self.st == nil then return false, 'call slab:simulate() at least once first' end
+  local g = lib.tfl_slab_graph_create(ctx, self.prm, self.st, self.desc, self.callbacks, self.ws, self.n)
+  if g == nil then return false, ffi.string(lib.tfl_last_error(ctx)) end
+  self.graph = ffi.gc(g, function(h) lib.tfl_slab_graph_destroy(ctx, h) end)
+  return true
+end
 function Slab:simulate(conf, mconf, batch, model)
+  if self.graph ~= nil then check(lib.tfl_slab_graph_step(ctx, self.graph)); return end
   local prm, st, keep = sim_args(mconf, batch, model, false)
   if self.ws == nil then   -- the SAME buffer on every call: messages started by one step are consumed by the next
     self.n = tonumber(lib.tfl_simulate_slab_workspace_floats(ctx, prm, st, self.desc))
     self.buf = batch.UDiv.new():resize(self.n):zero()     -- private: the shared scratch may be re-allocated by other operators
     self.ws = ffi.cast('float*', torch.data(self.buf))
   end
-  self.st, self.keep = st, keep
-  check(lib.tfl_simulate_step_slab(ctx, prm, st, self.desc, self.callbacks, self.ws, self.n))
+  self.prm, self.st, self.keep = prm, st, keep
+  local rc = lib.tfl_simulate_step_slab(ctx, prm, st, self.desc, self.callbacks, self.ws, self.n)
+  if rc == -5 then      -- TFL_EREACH (checkReach = 'exact'): every rank is here, nothing has been written
+    error(string.format('tfluids_hip: the flow needs a back-trace reach of %d planes: re-cut the local tensors with tfl_slab_halo(%d) halo planes ' ..
+                        '(tfl_slab_exchange fetches them) and create the Slab again with reach = %d', lib.tfl_slab_needed_reach(ctx),
+                        lib.tfl_slab_needed_reach(ctx), lib.tfl_slab_needed_reach(ctx)))
+  end
+  check(rc)
 end
 function Slab:drain()
   if self.st ~= nil and self.desc.in_flight ~= 0 then
