@@ -188,6 +188,9 @@ float get_dx(const tfl_ctx* c, const tfl_tensor* f) {  // grid.cc:37-40
 
 }  // namespace
 
+// (library-internal, C++ linkage: the device word of a model's fp16 range counter, for the z-slab step's collective gate -- simulate.cpp)
+namespace tfl { const unsigned long long* model_range_counter(const tfl_model* m) { return m ? m->d_range_err : nullptr; } }
+
 extern "C" {
 
 int tfl_abi_version(void) { return TFL_ABI_VERSION; }
@@ -914,8 +917,6 @@ int64_t tfl_model_range_errors(tfl_ctx* c, tfl_model* m) {
   return (int64_t)v;
 }
 
-// (library-internal: the device word itself, for the z-slab step's collective gate -- simulate.cpp)
-const unsigned long long* tfl_model_range_counter_dev(const tfl_model* m) { return m ? m->d_range_err : nullptr; }
 
 int64_t tfl_model_range_flag(tfl_ctx* c, tfl_model* m) {
   if (!c || !m) return -1;

@@ -15,7 +15,7 @@
 #include <cstring>
 #include <string>
 
-extern "C" const unsigned long long* tfl_model_range_counter_dev(const tfl_model* m);      // abi.cpp (library-internal)
+namespace tfl { const unsigned long long* model_range_counter(const tfl_model* m); }      // abi.cpp (library-internal)
 
 struct tfl_bc_plan {
   tfl_tensor bc, inv;      // the dense pair (pointers kept, not owned)
@@ -672,7 +672,7 @@ int tfl_simulate_step_slab(tfl_ctx* c, const tfl_sim_params* prm, const tfl_sim_
       c->h_reach_flags = nullptr; c->err = "simulate_step_slab: hipHostMalloc failed"; return TFL_EHIP;
     }
     double* d_flags = W.stats + 2 * g.B;
-    tfl::reach_flags(c->stream, c->d_reach, prm->dt, kReachFlags, d_flags, tfl_model_range_counter_dev(s->model));
+    tfl::reach_flags(c->stream, c->d_reach, prm->dt, kReachFlags, d_flags, tfl::model_range_counter(s->model));
     if (multi && comm->allreduce_sum(comm->user, d_flags, kReachFlags + 1) != 0) { c->err = "simulate_step_slab: comm callback failed (allreduce_sum, reach)"; return TFL_EINVAL; }
     if (hipMemcpyAsync(c->h_reach_flags, d_flags, sizeof(double) * (kReachFlags + 1), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
         hipStreamSynchronize(c->stream) != hipSuccess) { c->err = "simulate_step_slab: reading the reach flags failed"; (void)hipGetLastError(); return TFL_EHIP; }

@@ -76,3 +76,25 @@ def test_plain_c_host_links_against_the_abi(lib_path, tmp_path):
 def test_plain_c_host_runs(lib_path, tmp_path):
     out = subprocess.run([_build_c_example(tmp_path)], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "OK" in out.stdout, out.stdout + out.stderr
+
+
+def test_product_library_carries_one_kernel_per_job_and_few_switches():
+    """the earlier / measured-slower kernel forms and their switches live only in the EXPERIMENTS flavour
+    (libtfluids_hip_exp.so, -DTFL_EXPERIMENTS). Checked on the binaries: the product library names none of those kernels and
+    reads at most 15 TFL_* variables; the second flavour has them."""
+    import subprocess
+    here = os.path.join(ROOT, "fluidnet_amd")
+    prod, exp = os.path.join(here, "libtfluids_hip.so"), os.path.join(here, "libtfluids_hip_exp.so")
+    if not os.path.exists(exp):
+        pytest.skip("libtfluids_hip_exp.so is not built (make -C fluidnet_amd/csrc exp)")
+    s_prod = subprocess.run(["strings", prod], capture_output=True, text=True).stdout
+    s_exp = subprocess.run(["strings", exp], capture_output=True, text=True).stdout
+    for k in ("k_conv3_m16p_f2", "k_conv3_m16z", "k_scal3m_fwd", "k_scal3m_bwd"):
+        assert k not in s_prod and k in s_exp, k
+    for k in ("k_conv3_m16q", "k_conv3_m16p_in", "k_vel3_bwd", "k_vort_pipe"):
+        assert k in s_prod, k
+    import re
+    switches = sorted(set(re.findall(r"^TFL_[A-Z0-9_]+$", s_prod, flags=re.M)))
+    assert 5 <= len(switches) <= 15, switches
+    for k in ("TFL_M16_FUSE12", "TFL_STATS_FOLD", "TFL_SCAL3_MARCH", "TFL_XCD_ORDER"):
+        assert k not in switches and k in s_exp, k
