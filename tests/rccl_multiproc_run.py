@@ -77,6 +77,51 @@ def main(rank, world, rdv):
         assert float(ref["UDiv"].abs().max()) > 0.05
         sim.close()
         print("rank %d/%d %s: owned planes equal the single-GPU step (origin %s)" % (rank, world, mode, lib.tfl_rccl_comm_origin(ctx).decode()))
+    # ---- round 6: the rank-step RECORDED into a HIP graph with the real ncclSend / ncclRecv / ncclAllReduce inside
+    # (tfl_slab_graph_create). Recording is collective in effect (every rank records at the same step index); a rank whose
+    # recording fails keeps stepping eagerly -- the two forms post the same messages in the same order, so mixed ranks stay in
+    # step. The result must equal the single-GPU step either way; how each rank stepped is printed.
+    os.environ.pop("TFL_RCCL_PACKED", None)
+    ref = T._to_dev(b, dev)
+    lib, ctx = tfluids._context(ref["flags"])
+    uid = exchange_id(rdv, "uid_graph", rank, lambda: RcclComm.unique_id(ctx))
+    lay = SlabLayout(Zt, world, rank)
+    loc = {k: (lay.extract(v) if torch.is_tensor(v) else v) for k, v in ref.items()}
+    sim = SlabSimulation(loc, mconf, FluidNetModel(layers, True), lay, RcclComm(ctx, uid, rank, world), overlap=0, graph=None)
+    sim.graph_mode = None          # "try, fall back to eager" (what TFL_SLAB_GRAPH=1 selects)
+    model = FluidNetModel(layers, True)
+    for n in range(6):
+        simulate_native(None, mconf, ref, model)
+        sim.step()
+    sim.drain()
+    torch.cuda.synchronize()
+    for k in ("pDiv", "UDiv", "density"):
+        got, want = lay.owned(sim.batch[k]), ref[k][:, :, lay.z0:lay.z1]
+        rel = float((got - want).norm() / want.norm().clamp_min(1e-30))
+        assert rel <= 1e-7, ("graph", rank, k, rel)
+    print("rank %d/%d recorded step: %s" % (rank, world, ("HIP graph of %d nodes" % sim.graph_nodes) if sim.graph is not None else ("eager (%s)" % sim.graph_error)))
+    sim.close()
+    # ---- round 6: the exact reach mode over real RCCL -- a flow of 1.5 cells per step through the cuts: every rank is refused
+    # before the step (the reach flags go through ncclAllReduce), widens its halos through ncclSend / ncclRecv
+    # (tfl_slab_exchange) and ends equal to the single-GPU step
+    b2 = T._plume_batch((Zt, Y, X), 0.15, 0.6)
+    b2["UDiv"][:, 2, 4:Zt - 4, 4:Y - 4, 4:X - 4] = 15.0
+    m2 = dict(mconf, gravityScale=0, vorticityConfinementAmp=1.0)
+    ref = T._to_dev(b2, dev)
+    uid = exchange_id(rdv, "uid_reach", rank, lambda: RcclComm.unique_id(ctx))
+    loc = {k: (lay.extract(v) if torch.is_tensor(v) else v) for k, v in ref.items()}
+    sim = SlabSimulation(loc, m2, FluidNetModel(layers, True), lay, RcclComm(ctx, uid, rank, world), overlap=0, check_reach="exact", graph=False)
+    for n in range(3):
+        simulate_native(None, m2, ref, model)
+        sim.step()
+    sim.drain()
+    torch.cuda.synchronize()
+    assert sim.relayouts == [2], sim.relayouts
+    for k in ("pDiv", "UDiv", "density"):
+        got, want = sim.lay.owned(sim.batch[k]), ref[k][:, :, sim.lay.z0:sim.lay.z1]
+        rel = float((got - want).norm() / want.norm().clamp_min(1e-30))
+        assert rel <= 1e-7, ("exact reach", rank, k, rel)
+    sim.close()
     print("rccl multiproc ok rank %d" % rank)
 
 
