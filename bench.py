@@ -240,11 +240,38 @@ def make_stepper(res, world, rank, dev, model, scene):
                 if comm is not None:
                     comm.close()
                 comm = None
+        want_graph = None if os.environ.get("TFL_SLAB_GRAPH", "0") == "1" else False     # the recorded rank-step: opt-in
+        sim = None
+        if comm is not None:
+            # the native transport has never run between real GPUs (no multi-GPU box in any round): ONE trial step decides, on every
+            # rank together, whether the run stays on it -- a failure anywhere sends all ranks to the torch.distributed transport
+            ok = 1
+            try:
+                sim = SlabSimulation(batch, mconf, model, layout, comm, graph=want_graph)
+                sim.step()
+                sim.drain()
+                torch.cuda.synchronize()
+            except Exception as e:      # noqa: BLE001
+                sys.stderr.write("rank %d: the native RCCL transport failed its trial step (%s)\n" % (rank, e))
+                ok = 0
+            flag = torch.tensor([ok], device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) != 1:
+                try:
+                    if sim is not None:
+                        sim.close()
+                    else:
+                        comm.close()
+                except Exception:      # noqa: BLE001
+                    pass
+                sim, comm = None, None
+                batch, mconf = scene(res, layout, dev)      # the trial step may have touched the state
         if comm is None:
             comm = DistComm(rank, world)
             TRANSPORT["name"] = ("torch.distributed nccl (RCCL) batch_isend_irecv" if dist.get_backend() == "nccl" else
                                  "torch.distributed %s, staged through the host (control-flow check, not a measurement)" % dist.get_backend())
-        sim = SlabSimulation(batch, mconf, model, layout, comm)
+        if sim is None:
+            sim = SlabSimulation(batch, mconf, model, layout, comm, graph=False)
         return batch, mconf, sim.step, sim
     batch, mconf = scene(res, None, dev)
 
@@ -677,6 +704,11 @@ def main():
             else:
                 os.environ["TFL_CONV_PATH"] = prev
 
+    sim_info = None
+    if sim is not None:
+        sim_info = {"overlap": int(sim.slab.overlap), "check_reach": int(sim.slab.check_reach),
+                    "issued_as": ("HIP graph of %d nodes (tfl_slab_graph_step)" % sim.graph_nodes) if sim.graph is not None else
+                                 ("eager tfl_simulate_step_slab" + (" (recording refused: %s)" % sim.graph_error if sim.graph_error else ""))}
     # ---- BASELINE config 5: 256^3 cut into `world` z-slabs (after the timed region; its own short timing) -------------
     config5 = None
     if not args.no_config5 and res == 128 and 256 % world == 0:
@@ -711,6 +743,7 @@ def main():
                                "strong scaling: %d z-slabs of %d planes" % (world, owned_planes)),
                    "grid_zyx": [res, res, res], "per_gpu_grid_zyx": [owned_planes, res, res],
                    "decomposition": "single GPU" if world == 1 else "z-slabs, %d ranks, transport: %s" % (world, TRANSPORT["name"]),
+                   "rank_step": None if sim_info is None else sim_info,
                    "preroll_steps": args.preroll, "slab": redundancy, "strong_scaling": single},
         "range_errors": range_errors, "trace_errors": trace_errors, "conv_exact_fp32": conv_exact,
         "roofline": roofline, "advection_headline": headline, "hbm_measured_peak_GBps": hbm_meas,

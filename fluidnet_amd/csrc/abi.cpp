@@ -206,8 +206,12 @@ tfl_ctx* tfl_create(int device) {
       hipMalloc((void**)&c->d_resid, sizeof(double) * kMaxBatch) != hipSuccess ||
       hipHostMalloc((void**)&c->h_resid, sizeof(double) * kMaxBatch, hipHostMallocDefault) != hipSuccess ||
       hipMalloc((void**)&c->d_reach, sizeof(float)) != hipSuccess ||
-      hipHostMalloc((void**)&c->h_reach, sizeof(float), hipHostMallocDefault) != hipSuccess ||
-      hipEventCreateWithFlags(&c->reach_ev, hipEventDisableTiming) != hipSuccess) {
+      hipHostMalloc((void**)&c->h_reach, sizeof(float), hipHostMallocMapped) != hipSuccess ||
+      hipHostGetDevicePointer((void**)&c->d_reach_host, c->h_reach, 0) != hipSuccess ||
+      hipEventCreateWithFlags(&c->reach_ev[0], hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->reach_ev[1], hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->reach_ev[2], hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->reach_ev[3], hipEventDisableTiming) != hipSuccess) {
     tfl_destroy(c);
     return nullptr;
   }
@@ -228,7 +232,7 @@ void tfl_destroy(tfl_ctx* c) {
   if (!c) return;
   if (c->d_reach) (void)hipFree(c->d_reach);
   if (c->h_reach) (void)hipHostFree(c->h_reach);
-  if (c->reach_ev) (void)hipEventDestroy(c->reach_ev);
+  for (int i = 0; i < 4; i++) if (c->reach_ev[i]) (void)hipEventDestroy(c->reach_ev[i]);
   if (c->h_reach_flags) (void)hipHostFree(c->h_reach_flags);
   if (c->d_trace_err) (void)hipFree(c->d_trace_err);
   if (c->d_resid) (void)hipFree(c->d_resid);
@@ -1125,7 +1129,8 @@ int tfl_model_finish(tfl_ctx* c, tfl_model* m, const tfl_tensor* pDiv, const tfl
   if (stg & 8)
     tfl::model_project(st, m->is3d, B, Z, Y, X, w.pPred, flags->data, st_in, count, UOut->data, pOut->data,
                        UBC ? UBC->data : nullptr, UBC ? UBCInvMask->data : nullptr, doClamp, lo, hi,
-                       m->d_range_host ? m->d_range_err : nullptr, m->d_range_host);
+                       m->d_range_host ? m->d_range_err : nullptr, m->d_range_host,
+                       c->reach_sink ? c->d_reach : nullptr, c->reach_sink ? c->d_reach_host : nullptr);
   return check_launch(c, "model_finish");
 }
 

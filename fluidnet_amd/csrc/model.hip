@@ -400,6 +400,9 @@ struct BcArgs {  // optional fused tail of simulate(): setConstVals + clamp, sim
   // the fp16 conv path's range-error count (device word, final once the conv kernels are done) and the pinned host word a
   // non-zero count is copied to, so that the host sees it at its next call without a stream sync (abi.cpp range_gate)
   const unsigned long long* range_src; unsigned long long* range_dst;
+  // the z-slab step's reach word (sticky max|u_z|, device) and its mapped pinned mirror: the same thread copies it, every step
+  // (round 6: an async 4-byte D2H copy on the stream blocks the host until the stream has drained on this stack)
+  const float* reach_src; float* reach_dst;
 };
 // one thread of the launch forwards a non-zero count (the host word is only written when something went wrong)
 __device__ __forceinline__ void forward_range_count(const BcArgs& bc, bool first_thread) {
@@ -407,6 +410,7 @@ __device__ __forceinline__ void forward_range_count(const BcArgs& bc, bool first
     const unsigned long long v = *bc.range_src;
     if (v) *bc.range_dst = v;
   }
+  if (bc.reach_src && first_thread) *bc.reach_dst = *bc.reach_src;
 }
 
 template <bool IS3D>
@@ -747,12 +751,14 @@ void model_skip_channel(hipStream_t st, int B, long long cells, const float* pDi
 
 void model_project(hipStream_t st, bool is3d, int B, int Z, int Y, int X, const float* pPred, const float* flags,
                    const double* stats, double count, float* Uio, float* pOut, const float* UBC, const float* UInvMask,
-                   int do_clamp, float lo, float hi, const unsigned long long* range_src, unsigned long long* range_dst) {
+                   int do_clamp, float lo, float hi, const unsigned long long* range_src, unsigned long long* range_dst,
+                   const float* reach_src, float* reach_dst) {
   const Dom d = make_dom(Z, Y, X);
   const dim3 blk(64, 4, 1), grd = TFL_GRID3(d, B);
   // a dense pair acts everywhere; without one, tfl_simulate_step's sparse pair (if it asked: tfl_host.hpp BcFold) in its box
   BcArgs bc; bc.enable_clamp = do_clamp; bc.lo = lo; bc.hi = hi;
   bc.range_src = range_dst ? range_src : nullptr; bc.range_dst = range_dst;
+  bc.reach_src = reach_dst ? reach_src : nullptr; bc.reach_dst = reach_dst;
   bc.UBC = UBC; bc.UInvMask = UInvMask; bc.fold = UBC ? no_fold() : take_fold();
   const uintptr_t al = (uintptr_t)pPred | (uintptr_t)flags | (uintptr_t)Uio | (uintptr_t)pOut | (uintptr_t)UBC |
                        (uintptr_t)UInvMask;

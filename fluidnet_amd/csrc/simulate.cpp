@@ -565,8 +565,32 @@ Split split_owned(const SlabGeom& g, int k) {
 struct StageGuard {          // whatever happens, leave the context with no window / stage mask / dx override
   tfl_ctx* c;
   explicit StageGuard(tfl_ctx* ctx) : c(ctx) {}
-  ~StageGuard() { (void)tfl_set_z_window(c, 0, 0, 0, 0); (void)tfl_set_stages(c, 0); c->dx_dim = 0; (void)tfl_set_z_origin(c, 0, 0); }
+  ~StageGuard() { (void)tfl_set_z_window(c, 0, 0, 0, 0); (void)tfl_set_stages(c, 0); c->dx_dim = 0; (void)tfl_set_z_origin(c, 0, 0); c->reach_sink = false; }
 };
+
+// check_reach = 1, host side: has a step that the device has certainly started (two calls back) -- or any later one it has got
+// to since -- found max|u_z| dt >= R? Waits only when the host is more than two steps ahead of the device.
+bool reach_violated(tfl_ctx* c, float dt, int R, char* msg, size_t msg_len) {
+  if (c->reach_n >= 2) (void)hipEventSynchronize(c->reach_ev[(c->reach_n - 2) & 3]);
+  const float v = *(volatile float*)c->h_reach;
+  if (!(v * dt >= (float)R)) return false;
+  snprintf(msg, msg_len, "simulate_step_slab: max|u_z|*dt = %.3f cells reached the slab's back-trace reach %d (found up to two steps after the fact: "
+                         "check_reach = 2 refuses such a step BEFORE it runs)", v * dt, R);
+  // acknowledged: the sticky maximum starts again (the state is past saving; a host that carries on gets the next report afresh)
+  c->h_reach[0] = 0.0f;
+  (void)hipMemsetAsync(c->d_reach, 0, sizeof(float), c->stream);
+  return true;
+}
+// ... device side: the sticky word reaches the host through the step's LAST kernel (k_project copies it into the mapped pinned
+// mirror: tfl_ctx::reach_sink) -- not through hipMemcpyAsync: a 4-byte D2H copy on the stream made the host wait until the stream
+// had drained (+55 us per step measured, tools/slab_host_cost.py --check-reach)
+void reach_mark(tfl_ctx* c) {      // (outside a capture: after the eager step's copy, or behind the launch of a recorded step)
+  if (hipEventRecord(c->reach_ev[c->reach_n & 3], c->stream) == hipSuccess) { c->reach_n++; c->reach_pending = true; }
+}
+void reach_quiesce(tfl_ctx* c) {   // every copy of the ring has landed
+  if (c->reach_pending && c->reach_n > 0) (void)hipEventSynchronize(c->reach_ev[(c->reach_n - 1) & 3]);
+  c->reach_pending = false;
+}
 
 }  // namespace
 
@@ -635,12 +659,9 @@ int tfl_simulate_step_slab(tfl_ctx* c, const tfl_sim_params* prm, const tfl_sim_
   msg_layout(g, m, 4, W.msg);
 
   // ---- reach check of the PREVIOUS step's velocity (no host sync: the word was copied back behind that step) ---------
-  if (sl->check_reach && !c->capturing) {       // (a captured step: tfl_slab_graph_step makes both checks before it launches)
-    if (c->reach_pending) { (void)hipEventSynchronize(c->reach_ev); c->reach_pending = false; }   // step n-1's reduction has landed
-    if (c->h_reach[0] * prm->dt >= (float)g.R) {
-      char buf[160];
-      snprintf(buf, sizeof(buf), "simulate_step_slab: max|u_z|*dt = %.3f cells reached the slab's back-trace reach %d", c->h_reach[0] * prm->dt, g.R);
-      c->h_reach[0] = 0.0f;
+  if (sl->check_reach == 1 && !c->capturing) {  // (a captured step: tfl_slab_graph_step makes both checks before it launches)
+    char buf[256];
+    if (reach_violated(c, prm->dt, g.R, buf, sizeof(buf))) {
       // the neighbours' matching receives of the U / p messages are already posted: finish ours before giving up
       for (int t = 0; t < 2; t++)
         if (multi && (sl->in_flight & (1 << t))) { (void)msg_finish(c, g, comm, m[t]); sl->in_flight &= ~(1 << t); }
@@ -662,7 +683,8 @@ int tfl_simulate_step_slab(tfl_ctx* c, const tfl_sim_params* prm, const tfl_sim_
   if (sl->in_flight & 1) { rc = msg_finish(c, g, comm, m[0]); if (rc) return rc; sl->in_flight &= ~1; }     // U and p halos
   if (sl->check_reach) {
     for (int b = 0; b < g.B; b++)                                                                            // u_z of every batch item
-      tfl::absmax(c->stream, (long long)g.Zl * g.yx, s->U->data + (3ll * b + 2) * g.Zl * g.yx, c->d_reach, b == 0);
+      tfl::absmax(c->stream, (long long)g.Zl * g.yx, s->U->data + (3ll * b + 2) * g.Zl * g.yx, c->d_reach,
+                  sl->check_reach == 2 && b == 0);      // (mode 1: a sticky maximum over the steps, see tfl_ctx.hpp)
   }
   if (sl->check_reach == 2) {
     // "exact" (round 6): the reach THIS step needs, agreed by all ranks, before anything is written. One-hot flags
@@ -691,8 +713,7 @@ int tfl_simulate_step_slab(tfl_ctx* c, const tfl_sim_params* prm, const tfl_sim_
       return TFL_EREACH;
     }
   } else if (sl->check_reach) {
-    (void)hipMemcpyAsync(c->h_reach, c->d_reach, sizeof(float), hipMemcpyDeviceToHost, c->stream);
-    if (!c->capturing) c->reach_pending = hipEventRecord(c->reach_ev, c->stream) == hipSuccess;   // (captured: recorded behind the graph launch)
+    c->reach_sink = true;                  // the projection kernel of THIS step publishes the word (cleared by the guard below)
   }
   c->dx_dim = std::max(std::max(s->flags->X, s->flags->Y), sl->z_total);   // tfluids.getDx of the WHOLE grid
   (void)tfl_set_z_origin(c, sl->z_first, sl->z_total);
@@ -842,6 +863,7 @@ int tfl_simulate_step_slab(tfl_ctx* c, const tfl_sim_params* prm, const tfl_sim_
   (void)tfl_set_stages(c, 0); (void)tfl_set_z_window(c, 0, 0, 0, 0);
   rc = set_const_vals(c, s, s->U, late_ubc && !U_late_folded, Unchanged{false, false, true});
   if (rc) return rc;
+  if (sl->check_reach == 1 && !c->capturing) reach_mark(c);      // behind the kernel that published this step's reach word
   // the next step's U and p halos leave now; they are consumed at its start / before its first conv layer
   if (multi) {
     rc = msg_start(c, g, comm, m[0]); if (rc) return rc;
@@ -941,7 +963,7 @@ tfl_slab_graph* tfl_slab_graph_create(tfl_ctx* c, const tfl_sim_params* prm, con
   hipStream_t user = c->stream;
   // everything queued so far on the caller's stream happens before the recording stream is used at all (warm-up steps)
   (void)hipStreamSynchronize(user);
-  if (c->reach_pending) { (void)hipEventSynchronize(c->reach_ev); c->reach_pending = false; }
+  reach_quiesce(c);
   hipGraph_t graph = nullptr;
   // relaxed: the transport's library may call into the runtime from its own threads while we record
   if (hipStreamBeginCapture(G->cap, hipStreamCaptureModeRelaxed) != hipSuccess) {
@@ -973,14 +995,8 @@ int tfl_slab_graph_step(tfl_ctx* c, tfl_slab_graph* G) {
   if (!c || !G || !G->exec) return TFL_EINVAL;
   // the two gates of the eager call, read from the words the PREVIOUS step left in pinned memory
   if (G->sl->check_reach) {
-    if (c->reach_pending) { (void)hipEventSynchronize(c->reach_ev); c->reach_pending = false; }
-    if (c->h_reach[0] * G->prm->dt >= (float)G->reach) {
-      char buf[160];
-      snprintf(buf, sizeof(buf), "simulate_step_slab: max|u_z|*dt = %.3f cells reached the slab's back-trace reach %d", c->h_reach[0] * G->prm->dt, G->reach);
-      c->h_reach[0] = 0.0f;
-      c->err = buf;
-      return TFL_EINVAL;
-    }
+    char buf[256];
+    if (reach_violated(c, G->prm->dt, G->reach, buf, sizeof(buf))) { c->err = buf; return TFL_EINVAL; }
   }
   if (!G->multi && G->s->model && tfl_model_range_flag(c, G->s->model) > 0) {     // (a slab with neighbours never refuses on its own word: see the eager step)
     c->err = "simulate_step_slab: an earlier step's ConvNet projection clamped activations at the fp16 range (a blown-up simulation); "
@@ -988,7 +1004,7 @@ int tfl_slab_graph_step(tfl_ctx* c, tfl_slab_graph* G) {
     return TFL_ERANGE;
   }
   if (hipGraphLaunch(G->exec, c->stream) != hipSuccess) { c->err = "slab_graph_step: hipGraphLaunch failed"; (void)hipGetLastError(); return TFL_EHIP; }
-  if (G->sl->check_reach) c->reach_pending = hipEventRecord(c->reach_ev, c->stream) == hipSuccess;
+  if (G->sl->check_reach) reach_mark(c);
   return TFL_OK;
 }
 

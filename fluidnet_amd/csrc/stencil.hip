@@ -217,13 +217,24 @@ __global__ __launch_bounds__(256) void k_flags_to_occupancy(long long n, const f
 
 // *out = max(*out, max_i |x[i]|): the z-slab reach check (max |u_z| * dt bounds how many planes a back-trace crosses).
 // Non-negative floats order like their bit patterns, so the maximum is one integer atomic per block.
+// (Round 6: ONE atomic per block of at most 256 blocks, 16-byte loads -- the first form issued one same-address atomic per WAVE of
+// 1024 blocks, 4096 of them serialised in L2: 55 us on a 24-plane slab, more than half of the rank-step it was guarding.)
 __global__ __launch_bounds__(256) void k_absmax(long long n, const float* __restrict__ x, float* __restrict__ out) {
   float m = 0.0f;
-  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x)
+  const long long n4 = ((reinterpret_cast<uintptr_t>(x) & 15) == 0) ? n / 4 : 0;
+  const float4* x4 = reinterpret_cast<const float4*>(x);
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n4; t += (long long)gridDim.x * blockDim.x) {
+    const float4 v = x4[t];
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+  }
+  for (long long t = n4 * 4 + (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x)
     m = fmaxf(m, fabsf(x[t]));
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_down(m, off, 64));
-  if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned int*>(out), __float_as_uint(m));
+  __shared__ float wm[4];
+  if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicMax(reinterpret_cast<unsigned int*>(out), __float_as_uint(fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]))));
 }
 
 // flags[r - 1] = 1.0 where *maxu * dt >= r (r = 1 .. n): the one-hot form of "back-trace reach needed" that a SUM all-reduce can
@@ -240,7 +251,8 @@ void reach_flags(hipStream_t st, const float* maxu, float dt, int n, double* fla
 
 void absmax(hipStream_t st, long long n, const float* x, float* out, bool reset) {
   if (reset) (void)hipMemsetAsync(out, 0, sizeof(float), st);
-  const int blocks = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
+  const long long want = (n / 4 + 255) / 256;
+  const int blocks = (int)(want < 256 ? want : 256);
   { TFL_TIMED("k_absmax", st); k_absmax<<<blocks > 0 ? blocks : 1, 256, 0, st>>>(n, x, out); }
 }
 

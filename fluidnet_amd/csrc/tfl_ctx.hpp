@@ -22,8 +22,15 @@ struct tfl_ctx {
   int stages = 0;                             // tfl_set_stages: which passes of a multi-pass operator run (0 = all)
   float* d_reach = nullptr;                   // z-slab reach check: max|u_z| of the current step (device word)
   float* h_reach = nullptr;                   // pinned mirror, read by the NEXT tfl_simulate_step_slab call
-  hipEvent_t reach_ev = nullptr;              // recorded behind the copy into h_reach; the next call waits for it
-  bool reach_pending = false;
+  // check_reach = 1 (round 6): the device word is a STICKY maximum (never reset by a step: a violation cannot be overwritten before
+  // the host has seen it); each step copies it to h_reach and records reach_ev[n & 3] behind the copy; the call for step n waits
+  // for the event of step n - 2 -- complete unless the host is more than two steps ahead, so the wait bounds the host's lead and
+  // costs nothing (waiting for step n - 1's event cost 60 us per step: the host slept through half of the device's step)
+  float* d_reach_host = nullptr;              // the device address of h_reach (mapped pinned memory): the step's LAST kernel copies the
+  bool reach_sink = false;                    // word there when reach_sink is set -- an async 4-byte D2H copy BLOCKS the host on this stack
+  hipEvent_t reach_ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  unsigned reach_n = 0;                       // steps whose reach copy has been enqueued
+  bool reach_pending = false;                 // (check_reach = 2 / graph creation: something of the ring may still be in flight)
   double* h_reach_flags = nullptr;            // pinned [kReachFlags]: the all-reduced "reach >= r" counts of check_reach = 2 (created on first use)
   int needed_reach = 0;                       // what the last TFL_EREACH asked for (tfl_slab_needed_reach)
   tfl::BcFoldArg fold = {nullptr, 0u, 0u};    // tfl_simulate_step: a setConstVals pair (device descriptor + gate) the next operator may apply to its output

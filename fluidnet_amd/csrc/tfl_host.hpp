@@ -200,7 +200,7 @@ void model_skip_channel(hipStream_t st, int B, long long cells, const float* pDi
 void model_project(hipStream_t st, bool is3d, int B, int Z, int Y, int X, const float* pPred, const float* flags,
                    const double* stats, double count, float* Uio, float* pOut, const float* UBC, const float* UInvMask,
                    int do_clamp, float lo, float hi, const unsigned long long* range_src = nullptr,
-                   unsigned long long* range_dst = nullptr);
+                   unsigned long long* range_dst = nullptr, const float* reach_src = nullptr, float* reach_dst = nullptr);
 void apply_bcs(hipStream_t st, long long n, float* x, const float* bcv, const float* inv, int do_clamp, float lo,
                float hi);
 

@@ -457,10 +457,12 @@ typedef struct tfl_slab {
                              0 = 1. Halo depth needed = max(4, 2R + 1) */
   int32_t overlap;        /* 1: split the phases that feed a message into boundary strips + interior so that the
                              transfer overlaps compute (worth it when a slab holds >~ 1M cells); 0: one launch each */
-  int32_t check_reach;    /* 1: every step reduces max|u_z| on the device; a violation found by step n is reported
-                             by the call for step n+1, which waits for step n's reduction to land (the host can run
-                             at most one step ahead of the device); messages in flight are drained before the error
-                             is returned, so neighbours do not hang.
+  int32_t check_reach;    /* 1: every step reduces max|u_z| on the device into a sticky maximum and copies it to pinned
+                             memory; a violation by the state step n starts from is reported by the call for step n+2
+                             at the latest (that call waits for step n's copy, which has long landed unless the host is
+                             more than two steps ahead of the device: round 6 -- waiting for step n+1's cost 60 us per
+                             step); messages in flight are drained before the error is returned. The report is per
+                             rank: stop every rank when one reports (or use 2).
                              2 (round 6, "exact"): the check comes BEFORE the step's advection and is collective -- max|u_z|
                              of the state the step starts from, the reach it needs all-reduced over the ranks (8 doubles
                              through tfl_comm.allreduce_sum), one host synchronisation. A step that needs more than `reach`

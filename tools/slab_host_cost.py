@@ -5,7 +5,7 @@ the other ranks' share -- so the host path is the one a real run takes (event re
 enqueue cost, and the step can be recorded into a HIP graph (tfl_slab_graph_create): both the eager and the replayed step are
 timed. --python-null = the round-5 transport (Python callbacks, in-place chunks; --packed = staged buffers): its callbacks
 cost the host ~50 us per step that no native host pays.
-usage: slab_host_cost.py [res] [world] [--still] [--kernels] [--python-null [--packed]] [--no-graph]"""
+usage: slab_host_cost.py [res] [world] [--still] [--kernels] [--python-null [--packed]] [--no-graph] [--check-reach]"""
 import os
 import sys
 import time
@@ -92,7 +92,7 @@ def run(rank, graph):
     else:
         lib, ctx = tfluids._context(batch["UDiv"])
         comm = RcclComm(ctx, RcclComm.unique_id(ctx), rank, world)
-    sim = SlabSimulation(batch, mconf, model, lay, comm, check_reach=False, graph=graph)
+    sim = SlabSimulation(batch, mconf, model, lay, comm, check_reach=("--check-reach" in sys.argv), graph=graph)
     # --still also zeroes p before every step: with the null transport the net would otherwise iterate on its own output
     # (stale p halos), leave the fp16 range within a few steps, and every block of the first conv layer would report a
     # range error through one atomic counter -- 20 us of serialised atomics that no real run has -- and puts U and the
