@@ -582,8 +582,8 @@ bool reach_violated(tfl_ctx* c, float dt, int R, char* msg, size_t msg_len) {
   return true;
 }
 // ... device side: the sticky word reaches the host through the step's LAST kernel (k_project copies it into the mapped pinned
-// mirror: tfl_ctx::reach_sink) -- not through hipMemcpyAsync: a 4-byte D2H copy on the stream made the host wait until the stream
-// had drained (+55 us per step measured, tools/slab_host_cost.py --check-reach)
+// mirror: tfl_ctx::reach_sink) -- not through hipMemcpyAsync: a 4-byte D2H copy on the stream makes the HOST wait until the stream
+// has drained on this stack (tools/ubench/host_costs.hip)
 void reach_mark(tfl_ctx* c) {      // (outside a capture: after the eager step's copy, or behind the launch of a recorded step)
   if (hipEventRecord(c->reach_ev[c->reach_n & 3], c->stream) == hipSuccess) { c->reach_n++; c->reach_pending = true; }
 }

@@ -25,7 +25,7 @@ struct tfl_ctx {
   // check_reach = 1 (round 6): the device word is a STICKY maximum (never reset by a step: a violation cannot be overwritten before
   // the host has seen it); each step copies it to h_reach and records reach_ev[n & 3] behind the copy; the call for step n waits
   // for the event of step n - 2 -- complete unless the host is more than two steps ahead, so the wait bounds the host's lead and
-  // costs nothing (waiting for step n - 1's event cost 60 us per step: the host slept through half of the device's step)
+  // costs nothing
   float* d_reach_host = nullptr;              // the device address of h_reach (mapped pinned memory): the step's LAST kernel copies the
   bool reach_sink = false;                    // word there when reach_sink is set -- an async 4-byte D2H copy BLOCKS the host on this stack
   hipEvent_t reach_ev[4] = {nullptr, nullptr, nullptr, nullptr};
