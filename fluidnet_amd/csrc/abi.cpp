@@ -206,6 +206,7 @@ tfl_ctx* tfl_create(int device) {
       hipMalloc((void**)&c->d_resid, sizeof(double) * kMaxBatch) != hipSuccess ||
       hipHostMalloc((void**)&c->h_resid, sizeof(double) * kMaxBatch, hipHostMallocDefault) != hipSuccess ||
       hipMalloc((void**)&c->d_reach, sizeof(float)) != hipSuccess ||
+      hipMemset(c->d_reach, 0, sizeof(float)) != hipSuccess ||      // (a sticky maximum since round 6: nothing resets it per step)
       hipHostMalloc((void**)&c->h_reach, sizeof(float), hipHostMallocMapped) != hipSuccess ||
       hipHostGetDevicePointer((void**)&c->d_reach_host, c->h_reach, 0) != hipSuccess ||
       hipEventCreateWithFlags(&c->reach_ev[0], hipEventDisableTiming) != hipSuccess ||
