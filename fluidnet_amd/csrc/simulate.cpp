@@ -522,6 +522,7 @@ void slab_messages(const SlabGeom& g, const tfl_sim_state* s, const tfl_tensor* 
   m[3].tag = 3; m[3].n = 1; m[3].f[0] = Halo{div, 4, 3};
 }
 
+constexpr int kReachPrimed = 0x100;  // tfl_slab::in_flight, beside the message bits: this run has reset the context's sticky reach word
 constexpr int kReachFlags = 8;       // check_reach = 2 resolves reaches 1 .. 8 (a 16-plane slab can hold the halo of 7)
 struct SlabWs { float* msg; double* stats; float* compute; long long compute_floats; };
 
@@ -681,6 +682,13 @@ int tfl_simulate_step_slab(tfl_ctx* c, const tfl_sim_params* prm, const tfl_sim_
   }
   InStep in_step(c);      // the range gate above is the step's only one
   if (sl->in_flight & 1) { rc = msg_finish(c, g, comm, m[0]); if (rc) return rc; sl->in_flight &= ~1; }     // U and p halos
+  if (sl->check_reach == 1 && !(sl->in_flight & kReachPrimed)) {
+    // the first step of a run on this context (the host initialised in_flight to 0): the sticky maximum of whatever ran on the
+    // context before must not speak for this run
+    c->h_reach[0] = 0.0f;
+    (void)hipMemsetAsync(c->d_reach, 0, sizeof(float), c->stream);
+    sl->in_flight |= kReachPrimed;
+  }
   if (sl->check_reach) {
     for (int b = 0; b < g.B; b++)                                                                            // u_z of every batch item
       tfl::absmax(c->stream, (long long)g.Zl * g.yx, s->U->data + (3ll * b + 2) * g.Zl * g.yx, c->d_reach,
@@ -956,7 +964,7 @@ tfl_slab_graph* tfl_slab_graph_create(tfl_ctx* c, const tfl_sim_params* prm, con
   }
   if (sl->check_reach == 2) { c->err = "slab_graph_create: check_reach = 2 synchronises with the host every step: step eagerly"; return nullptr; }
   // the U / p message the last eager step left in flight is consumed now: a captured step starts and ends with none
-  if (sl->in_flight && tfl_slab_drain(c, s, sl, comm, ws, ws_floats) != TFL_OK) return nullptr;
+  if ((sl->in_flight & 0xF) && tfl_slab_drain(c, s, sl, comm, ws, ws_floats) != TFL_OK) return nullptr;
   tfl_slab_graph* G = new tfl_slab_graph();
   G->prm = prm; G->s = s; G->sl = sl; G->reach = g.R; G->multi = multi;
   if (hipStreamCreateWithFlags(&G->cap, hipStreamNonBlocking) != hipSuccess) { c->err = "slab_graph_create: hipStreamCreate failed"; delete G; return nullptr; }

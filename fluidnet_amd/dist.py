@@ -426,7 +426,7 @@ class SlabSimulation:
 
     def drain(self):
         """Finish the p / U halo messages the last step left in flight (before reading halo planes)."""
-        if self.slab.in_flight:
+        if self.slab.in_flight & 0xF:      # (bits 0-3: messages; bit 8 is the library's own)
             self._call(self.lib.tfl_slab_drain, ctypes.byref(self.st))
 
     def close(self):

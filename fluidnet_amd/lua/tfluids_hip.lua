@@ -19,6 +19,7 @@
 -- the executed host mirror of the same calls is fluidnet_amd/{tfluids,simulate,model}.py. Tensors must be contiguous
 -- float tensors whose storage is device memory (cutorch CudaTensor on a ROCm build of cutorch).
 local ffi = require('ffi')
+local bit = require('bit')
 
 -- BEGIN generated cdef (tools/gen_lua_cdef.py)
 ffi.cdef[[
@@ -550,7 +551,7 @@ function Slab:simulate(conf, mconf, batch, model)
   check(rc)
 end
 function Slab:drain()
-  if self.st ~= nil and self.desc.in_flight ~= 0 then
+  if self.st ~= nil and bit.band(self.desc.in_flight, 15) ~= 0 then      -- (bits 0-3: messages in flight)
     check(lib.tfl_slab_drain(ctx, self.st, self.desc, self.callbacks, self.ws, self.n))
   end
 end

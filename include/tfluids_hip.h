@@ -473,8 +473,9 @@ typedef struct tfl_slab {
                              in this mode; with check_reach 0 / 1 a slab that has neighbours never returns TFL_ERANGE on
                              its own (the others would wait for its halos): poll tfl_model_range_flag on the host.
                              Costs the host its lead over the device (~10-30 us per step): opt-in */
-  int32_t in_flight;      /* OUT/IN, initialise to 0: bit mask of halo messages started by the previous call and not
-                             yet consumed (tfl_simulate_step_slab finishes them; tfl_slab_drain does so explicitly) */
+  int32_t in_flight;      /* OUT/IN, initialise to 0 for a new run: bits 0-3 = halo messages started by the previous call and
+                             not yet consumed (tfl_simulate_step_slab finishes them; tfl_slab_drain does so explicitly);
+                             bit 8 = this run has reset the context's reach word (library-internal) */
 } tfl_slab;
 
 /* Transport supplied by the host (RCCL send/recv through torch.distributed in fluidnet_amd/dist.py; any MPI-like
