@@ -3,6 +3,7 @@
 // (3) the same chains replayed as HIP graphs, (4) tiny memsets / a 4-byte D2H copy into pinned memory.
 // build: hipcc --offload-arch=gfx950 -O3 host_costs.hip -o host_costs
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <chrono>
 #include <cstdio>
 #include <vector>
@@ -76,6 +77,17 @@ int main() {
   for (int i = 0; i < N; i++) { hipLaunchKernelGGL(k_tiny, dim3(1), dim3(64), 0, s0, d); hipMemcpyAsync(h, d, 4, hipMemcpyDeviceToHost, s0); }
   t1 = now(); CK(hipStreamSynchronize(s0)); t2 = now();
   printf("kernel + 4 B D2H alternating: host %.2f us, drained %.2f us per pair\n", (t1 - t0) / N * 1e6, (t2 - t0) / N * 1e6);
+  // 4b. hipExtAnyOrderLaunch: may the second of two independent kernels start before the first has finished? (hip_ext.h says the
+  // flag is not supported on gfx9xx; measured anyway: a pair of 64-block spin kernels, each a quarter of the chip)
+  for (int flag : {0, 1}) {
+    t0 = now();
+    for (int i = 0; i < 500; i++) {
+      hipExtLaunchKernelGGL(k_spin, dim3(64), dim3(256), 0, s0, nullptr, nullptr, 0, d, 20000ll);
+      hipExtLaunchKernelGGL(k_spin, dim3(64), dim3(256), 0, s0, nullptr, nullptr, flag, d + 64, 20000ll);
+    }
+    t1 = now(); CK(hipStreamSynchronize(s0)); t2 = now();
+    printf("pairs of quarter-chip 10 us kernels, second one with flags = %d: host %.2f us, drained %.2f us per pair\n", flag, (t1 - t0) / 500 * 1e6, (t2 - t0) / 500 * 1e6);
+  }
   // 5. the null stream (what a torch host hands the library by default)
   t0 = now();
   for (int i = 0; i < N; i++) hipLaunchKernelGGL(k_tiny, dim3(1), dim3(64), 0, 0, d);
