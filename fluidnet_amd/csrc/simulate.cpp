@@ -965,6 +965,12 @@ tfl_slab_graph* tfl_slab_graph_create(tfl_ctx* c, const tfl_sim_params* prm, con
   if (sl->check_reach == 2) { c->err = "slab_graph_create: check_reach = 2 synchronises with the host every step: step eagerly"; return nullptr; }
   // the U / p message the last eager step left in flight is consumed now: a captured step starts and ends with none
   if ((sl->in_flight & 0xF) && tfl_slab_drain(c, s, sl, comm, ws, ws_floats) != TFL_OK) return nullptr;
+  if (sl->check_reach == 1 && !(sl->in_flight & kReachPrimed)) {
+    // (a host that records before its first eager step: the reset of the sticky reach word must not become a node of the graph)
+    c->h_reach[0] = 0.0f;
+    (void)hipMemsetAsync(c->d_reach, 0, sizeof(float), c->stream);
+    sl->in_flight |= kReachPrimed;
+  }
   tfl_slab_graph* G = new tfl_slab_graph();
   G->prm = prm; G->s = s; G->sl = sl; G->reach = g.R; G->multi = multi;
   if (hipStreamCreateWithFlags(&G->cap, hipStreamNonBlocking) != hipSuccess) { c->err = "slab_graph_create: hipStreamCreate failed"; delete G; return nullptr; }
