@@ -66,6 +66,34 @@ def _build_c_example(tmp_path):
     return exe
 
 
+def _build_c_slab_example(tmp_path):
+    exe = str(tmp_path / "slab_from_c")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-D__HIP_PLATFORM_AMD__", os.path.join(ROOT, "examples", "slab_from_c.c"),
+                           "-I" + os.path.join(ROOT, "include"), "-I/opt/rocm/include",
+                           "-L" + os.path.join(ROOT, "fluidnet_amd"), "-ltfluids_hip", "-L/opt/rocm/lib", "-lamdhip64", "-lm", "-lpthread",
+                           "-Wl,-rpath," + os.path.join(ROOT, "fluidnet_amd"), "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+    return exe
+
+
+def test_plain_c_multi_rank_host_links_against_the_abi(lib_path, tmp_path):
+    """examples/slab_from_c.c -- the z-slab step, the native transport, the recorded rank-step and the exact reach mode from
+    plain C99 (round 6): compiles with gcc and links against the library."""
+    assert os.path.exists(_build_c_slab_example(tmp_path))
+
+
+@pytest.mark.gpu
+def test_plain_c_multi_rank_host_runs(lib_path, tmp_path):
+    """Two ranks as threads of ONE C process (own contexts and streams) step a cut plume grid through the library's native
+    transport (over tests/stub_rccl.cpp: RCCL refuses two ranks on one device) and end equal to the un-cut step; then the
+    recorded rank-step against the eager one (identical bits) and TFL_EREACH with the state untouched."""
+    stub = str(tmp_path / "libstub_rccl.so")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-shared", "-fPIC", "-O2", "-o", stub, os.path.join(ROOT, "tests", "stub_rccl.cpp")])
+    env = dict(os.environ, TFL_RCCL_LIBRARY=stub)
+    env.pop("STUB_RCCL_NULL", None)
+    out = subprocess.run([_build_c_slab_example(tmp_path)], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and out.stdout.strip().endswith("OK"), out.stdout + out.stderr
+
+
 def test_plain_c_host_links_against_the_abi(lib_path, tmp_path):
     """A C99 translation unit that includes only tfluids_hip.h compiles (gcc, not hipcc) and links: the boundary
     has no C++/torch types in it (what a cgo / JNI / LuaJIT-FFI binding relies on)."""
