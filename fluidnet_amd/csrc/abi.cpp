@@ -17,6 +17,7 @@
 
 #include "tfl_device.hpp"
 #include "tfl_host.hpp"
+#include "tfl_advect.hpp"
 
 struct tfl_layer {
   int cin = 0, cout = 0, k = 0;
@@ -388,6 +389,36 @@ int tfl_advectVel(tfl_ctx* c, float dt, const tfl_tensor* U, const tfl_tensor* f
                   c->d_trace_err, U->data, flags->data, fwd_p, UDst->data, stages_of(c));
   return check_launch(c, "advectVel");
 }
+
+}  // extern "C"
+// Library-internal (simulate.cpp's z-slab step; C++ linkage): the MacCormack(Ours) advection of one density channel AND of the
+// velocity on a 3-D grid, their passes A as one launch (stage bit 2) and their passes B as one launch (stage bit 4) --
+// advect_pair3.hip. Honours the z-window / z-origin / advect mode of the context like the two operators. fold_s / fold_v: the
+// setConstVals pairs the passes B apply (tfl_host.hpp BcFold; dev == nullptr: none). TFL_EUNSUPPORTED = not taken, nothing
+// launched: the caller runs tfl_advectScalar and tfl_advectVel.
+namespace tfl {
+int advect_pair(tfl_ctx* c, float dt, float strength, const tfl_tensor* s, const tfl_tensor* U, const tfl_tensor* flags,
+                const tfl_tensor* sfwd, const tfl_tensor* sbounds, const tfl_tensor* sDst, const tfl_tensor* vfwd, const tfl_tensor* UDst,
+                const BcFoldArg& fold_s, const BcFoldArg& fold_v) {
+  TRY(check_flags(c, "advectPair", flags));
+  TRY(check_vel(c, "advectPair", "U", U, flags, 1));
+  TRY(check_vel(c, "advectPair", "UDst", UDst, flags, 1));
+  TRY(check_vel(c, "advectPair", "vfwd", vfwd, flags, 1));
+  TRY(check_scalar(c, "advectPair", "s", s, flags));
+  TRY(check_scalar(c, "advectPair", "sDst", sDst, flags));
+  TRY(check_scalar(c, "advectPair", "sfwd", sfwd, flags));
+  if (!sbounds || !sbounds->data || sbounds->C < 2 || !same_dims(sbounds, flags)) return fail(c, TFL_EINVAL, "advectPair: bounds needs two planes of the flags size");
+  if (UDst->data == U->data) return fail(c, TFL_EINVAL, "advectPair: UDst must not alias U");
+  WindowScope win(c);
+  AdvArgs a; a.d = make_dom(flags->Z, flags->Y, flags->X); a.dt = dt; a.strength = strength; a.outside = 0; a.err = c->d_trace_err; a.fast = g_advect_fast;
+  a.ord = BlockOrder{};
+  if (!advect_pair3(c->stream, a, flags->B, s->data, U->data, flags->data, sfwd->data, sbounds->data, sDst->data, vfwd->data, UDst->data,
+                    stages_of(c), fold_s, fold_v))
+    return TFL_EUNSUPPORTED;
+  return check_launch(c, "advectPair");
+}
+}  // namespace tfl
+extern "C" {
 
 int tfl_setWallBcsForward(tfl_ctx* c, const tfl_tensor* U, const tfl_tensor* flags, int is3D) {
   TRY(check_flags(c, "setWallBcsForward", flags));

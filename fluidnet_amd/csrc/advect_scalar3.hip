@@ -42,6 +42,7 @@ namespace {
 #endif
 constexpr int TX = 64, TY = 4;
 constexpr float kFastLen = 0.99f;
+struct SBlock { int L, gx, gy, gz; };      // L < 0: the block is blockIdx of its own 3-D launch
 // the "not a fluid cell" word of the masked tile: a quiet NaN with a payload no arithmetic produces (hardware NaNs are
 // 0x7fc00000 or carry an input's payload), recognised by its BIT PATTERN -- so a NaN that really sits in the advected
 // field of a fluid cell stays a value, as in the reference
@@ -55,10 +56,10 @@ struct Tile {
 
 // block -> (batch item, first plane, end of its plane run): groups of TZ planes tile the window's two runs
 template <int TZ>
-__device__ __forceinline__ void group_planes(const Dom& d, int g, int& b, int& k0, int& kend) {
+__device__ __forceinline__ void group_planes(const Dom& d, int g, int gz, int& b, int& k0, int& kend) {      // gz = plane groups x batch items of the launch
   const int ga = (d.n0 + TZ - 1) / TZ, gb = (d.nw - d.n0 + TZ - 1) / TZ, G = ga + gb;
   b = 0;
-  if ((int)gridDim.z != G) { b = g / G; g -= b * G; }
+  if (gz != G) { b = g / G; g -= b * G; }
   if (g < ga) { k0 = d.w0 + g * TZ; kend = d.w0 + d.n0; }
   else { k0 = d.w1 + (g - ga) * TZ; kend = d.w1 + (d.nw - d.n0); }
 }
@@ -254,13 +255,16 @@ __device__ __forceinline__ float max3r(float a, float b, float c) { float r; asm
 #define TFL_SCAL3_BLOCK(H, SRC) TFL_SCAL3_GEOM(H); TFL_SCAL3_STAGE(H, SRC)
 /* the geometry first: a kernel issues its own per-cell loads between GEOM and STAGE, so that they travel with the tile's */ \
 /* loads instead of costing a memory round trip of their own behind them (round 4) */
+/* (round 6: `sb` = the block's place -- SBlock{-1, ...}: blockIdx as it comes (the kernels below); SBlock{L, gx, gy, gz}: the */ \
+/* L-th block of a gx x gy x gz launch, for the pair kernels of advect_pair3.hip -- and `tile` a pointer to T::N floats of LDS) */
 #define TFL_SCAL3_GEOM(H)                                                                          \
   constexpr int PZ = TZ * KZ;                                                                      \
   using T = Tile<PZ, H>;                                                                           \
-  __shared__ float tile[T::N];                                                                     \
   const Dom& d = a.d;                                                                              \
-  int bx_, by_, bz_; block_tile(a.ord, bx_, by_, bz_);                                             \
-  int b, k0, kend; group_planes<PZ>(d, bz_, b, k0, kend);                                          \
+  int bx_, by_, bz_;                                                                               \
+  if (sb.L < 0) block_tile(a.ord, bx_, by_, bz_);                                                  \
+  else block_tile_linear(a.ord, (unsigned)sb.L, (unsigned)sb.gx, (unsigned)sb.gy, bx_, by_, bz_);  \
+  int b, k0, kend; group_planes<PZ>(d, bz_, sb.L < 0 ? (int)gridDim.z : sb.gz, b, k0, kend);       \
   const long long cells = (long long)d.sc;                                                         \
   s += b * cells; flags += b * cells; U += b * cells * 3;                                          \
   const int lane = threadIdx.x, ty = threadIdx.y, tz = threadIdx.z;                                \
@@ -291,9 +295,9 @@ __device__ __forceinline__ float max3r(float a, float b, float c) { float r; asm
 
 // ---- pass A / the single-pass method: SemiLagrangeEulerOurs[SavePos] + getClampBounds of the forward position ----------
 template <int TZ, int KZ, bool BOUNDS, bool FAST>
-__global__ __launch_bounds__(256 * TZ) void k_scal3_fwd(AdvArgs a, const float* __restrict__ s, const float* __restrict__ U,
-                                                        const float* __restrict__ flags, float* __restrict__ out,
-                                                        float* __restrict__ bounds) {
+__device__ __forceinline__ void scal3_fwd_body(const SBlock sb, float* __restrict__ tile, const AdvArgs& a, const float* __restrict__ s,
+                                               const float* __restrict__ U, const float* __restrict__ flags, float* __restrict__ out,
+                                               float* __restrict__ bounds) {
   constexpr int HH = BOUNDS ? 2 : 1;
   TFL_SCAL3_GEOM(HH);
   out += b * cells;
@@ -354,13 +358,20 @@ __global__ __launch_bounds__(256 * TZ) void k_scal3_fwd(AdvArgs a, const float* 
     if (BOUNDS) { stg(bounds, o4, lo); stg(bounds, o4 + sc4, hi); }
   }
 }
+template <int TZ, int KZ, bool BOUNDS, bool FAST>
+__global__ __launch_bounds__(256 * TZ) void k_scal3_fwd(AdvArgs a, const float* __restrict__ s, const float* __restrict__ U,
+                                                        const float* __restrict__ flags, float* __restrict__ out,
+                                                        float* __restrict__ bounds) {
+  __shared__ float tile[Tile<TZ * KZ, BOUNDS ? 2 : 1>::N];
+  scal3_fwd_body<TZ, KZ, BOUNDS, FAST>(SBlock{-1, 0, 0, 0}, tile, a, s, U, flags, out, bounds);
+}
 
 // ---- pass B: backward trace on fwd + MacCormackCorrect + MacCormackClampOurs ---------------------------------------------
 template <int TZ, int KZ, bool FAST>
-__global__ __launch_bounds__(256 * TZ) void k_scal3_bwd(AdvArgs a, double half_strength, const float* __restrict__ s,
-                                                        const float* __restrict__ U, const float* __restrict__ flags,
-                                                        const float* __restrict__ fwd, const float* __restrict__ bounds,
-                                                        float* __restrict__ dst, BcFoldArg folda) {
+__device__ __forceinline__ void scal3_bwd_body(const SBlock sb, float* __restrict__ tile, const AdvArgs& a, double half_strength,
+                                               const float* __restrict__ s, const float* __restrict__ U, const float* __restrict__ flags,
+                                               const float* __restrict__ fwd, const float* __restrict__ bounds, float* __restrict__ dst,
+                                               const BcFoldArg& folda) {
   TFL_SCAL3_GEOM(1);
   fwd += b * cells; dst += b * cells; bounds += b * cells * 3;
   const bool fold_blk = fold_block(folda, y0, y0 + TY - 1, k0, kend - 1);
@@ -413,6 +424,14 @@ __global__ __launch_bounds__(256 * TZ) void k_scal3_bwd(AdvArgs a, double half_s
     }
     stg(dst, o4, v);
   }
+}
+template <int TZ, int KZ, bool FAST>
+__global__ __launch_bounds__(256 * TZ) void k_scal3_bwd(AdvArgs a, double half_strength, const float* __restrict__ s,
+                                                        const float* __restrict__ U, const float* __restrict__ flags,
+                                                        const float* __restrict__ fwd, const float* __restrict__ bounds,
+                                                        float* __restrict__ dst, BcFoldArg folda) {
+  __shared__ float tile[Tile<TZ * KZ, 1>::N];
+  scal3_bwd_body<TZ, KZ, FAST>(SBlock{-1, 0, 0, 0}, tile, a, half_strength, s, U, flags, fwd, bounds, dst, folda);
 }
 
 // pass A (or the single-pass method) / pass B with a block of 64 x 4 x TZ threads and KZ planes per thread
@@ -474,6 +493,7 @@ void launch(hipStream_t st, int shape, bool two_pass, const AdvArgs& a, int B, c
 
 }  // namespace
 
+#ifndef TFL_SCAL3_NO_ENTRY      // (advect_pair3.hip includes this file for the kernels' bodies only)
 bool advect_scalar3(hipStream_t st, bool two_pass, const AdvArgs& a, int B, const float* s, const float* U, const float* flags,
                     float* fwd, float* bounds, float* dst, int stages) {
   static const bool off = exp_env("TFL_ADVECT_GATHER") != nullptr || exp_env("TFL_SCALAR_GATHER") != nullptr;   // A/B switch: the round-2 gather kernels
@@ -497,5 +517,6 @@ bool advect_scalar3(hipStream_t st, bool two_pass, const AdvArgs& a, int B, cons
   else launch<false>(st, tzsel, two_pass, a, B, s, U, flags, fwd, bounds, dst, stages);
   return true;
 }
+#endif
 
 }  // namespace tfl

@@ -16,6 +16,11 @@
 #include <string>
 
 namespace tfl { const unsigned long long* model_range_counter(const tfl_model* m); }      // abi.cpp (library-internal)
+namespace tfl {      // abi.cpp (library-internal): both advections' passes A / passes B as one launch each (advect_pair3.hip)
+int advect_pair(tfl_ctx* c, float dt, float strength, const tfl_tensor* s, const tfl_tensor* U, const tfl_tensor* flags,
+                const tfl_tensor* sfwd, const tfl_tensor* sbounds, const tfl_tensor* sDst, const tfl_tensor* vfwd, const tfl_tensor* UDst,
+                const BcFoldArg& fold_s, const BcFoldArg& fold_v);
+}
 
 struct tfl_bc_plan {
   tfl_tensor bc, inv;      // the dense pair (pointers kept, not owned)
@@ -85,6 +90,12 @@ bool fold_ask(tfl_ctx* c, const tfl_bc_plan* p) {
   if (off || !p || !p->sparse || !p->boxed || !p->d_fold || p->n_idx == 0) { c->fold = tfl::no_fold(); return false; }
   c->fold = tfl::BcFoldArg{p->d_fold, (unsigned)p->box[2] | ((unsigned)p->box[4] << 16), (unsigned)p->box[3] | ((unsigned)p->box[5] << 16)};
   return true;
+}
+// the same request as a value (the pair kernels of advect_pair3.hip take two of them as arguments)
+tfl::BcFoldArg fold_arg(const tfl_bc_plan* p) {
+  const char* e = getenv("TFL_BC_FOLD");
+  if ((e && atoi(e) == 0) || !p || !p->sparse || !p->boxed || !p->d_fold || p->n_idx == 0) return tfl::no_fold();
+  return tfl::BcFoldArg{p->d_fold, (unsigned)p->box[2] | ((unsigned)p->box[4] << 16), (unsigned)p->box[3] | ((unsigned)p->box[5] << 16)};
 }
 bool fold_took(tfl_ctx* c) {
   const bool d = c->fold_done;
@@ -740,29 +751,52 @@ int tfl_simulate_step_slab(tfl_ctx* c, const tfl_sim_params* prm, const tfl_sim_
   // (Round 6 measured the scalar advection on a second stream beside the velocity's -- they are independent, simulate.lua:183-200
   // -- and dropped it: an event hop between two streams costs 12-15 us of GPU-side latency on this stack
   // (tools/ubench/host_costs.hip), more than the overlap of two 8 us kernels returns; profiles/r06_slab_host_cost.txt.)
-  if (rho) {
+  // Round 6: the two advections' passes as PAIRS -- passes A in one launch, passes B in one launch (advect_pair3.hip; they are
+  // independent here: the slab step does not fold the buoyancy force into pass B). false once = the shape is not the pair
+  // kernels': the four launches as before.
+  bool paired = rho != nullptr;
+  auto adv_pair = [&](bool with_folds) {
+    const tfl::BcFoldArg fs = with_folds ? fold_arg(s->densityBC[0]) : tfl::no_fold(), fv = with_folds ? fold_arg(s->UBC) : tfl::no_fold();
+    const int r = tfl::advect_pair(c, prm->dt, prm->maccormackStrength, rho, s->U, s->flags, &fwd, &fwdPos, rho, &vfwd, &Uadv, fs, fv);
+    if (r == TFL_OK && with_folds) { rho_done = rho_done && fs.dev != nullptr; Uadv_done = Uadv_done && fv.dev != nullptr; }
+    return r;
+  };
+  if (rho && !paired) {
     (void)tfl_set_stages(c, 1); WIN(set_win(c, ext(g, 2 * g.R, 2 * g.R)));
     rc = adv_scalar(); if (rc) return rc;
   }
   (void)tfl_set_stages(c, 2); WIN(set_win(c, ext(g, g.R, g.R)));
-  if (rho) { rc = adv_scalar(); if (rc) return rc; }
-  rc = adv_vel(); if (rc) return rc;
+  if (paired) {
+    rc = adv_pair(false);
+    if (rc == TFL_EUNSUPPORTED) {
+      paired = false;
+      (void)tfl_set_stages(c, 1); WIN(set_win(c, ext(g, 2 * g.R, 2 * g.R)));
+      rc = adv_scalar(); if (rc) return rc;
+      (void)tfl_set_stages(c, 2); WIN(set_win(c, ext(g, g.R, g.R)));
+    } else if (rc) return rc;
+  }
+  if (!paired) {
+    if (rho) { rc = adv_scalar(); if (rc) return rc; }
+    rc = adv_vel(); if (rc) return rc;
+  }
   (void)tfl_set_stages(c, 4);
   const int strip = 4 > 2 * g.R + 1 ? 4 : 2 * g.R + 1;        // deepest plane count message T2 sends
   const Split spB = split_owned(g, strip);
   const bool ovl = sl->overlap && multi;
+  auto pass_b = [&]() -> int {      // the passes B of both operators on the current window
+    if (paired) { const int r = adv_pair(true); if (r != TFL_EUNSUPPORTED) return r; paired = false; }
+    if (rho) { const int r = adv_scalar_b(); if (r) return r; }
+    return adv_vel_b();
+  };
   if (ovl && spB.has_strips && spB.has_interior) {
     WIN(tfl_set_z_window(c, spB.a0, spB.a1, spB.b0, spB.b1));
-    if (rho) { rc = adv_scalar_b(); if (rc) return rc; }
-    rc = adv_vel_b(); if (rc) return rc;
+    rc = pass_b(); if (rc) return rc;
     rc = msg_start(c, g, comm, m[2]); if (rc) return rc;
     WIN(tfl_set_z_window(c, spB.i0, spB.i1, 0, 0));
-    if (rho) { rc = adv_scalar_b(); if (rc) return rc; }
-    rc = adv_vel_b(); if (rc) return rc;
+    rc = pass_b(); if (rc) return rc;
   } else {
     WIN(set_win(c, ext(g, 0, 0)));
-    if (rho) { rc = adv_scalar_b(); if (rc) return rc; }
-    rc = adv_vel_b(); if (rc) return rc;
+    rc = pass_b(); if (rc) return rc;
     rc = msg_start(c, g, comm, m[2]); if (rc) return rc;
   }
   rc = msg_finish(c, g, comm, m[2]); if (rc) return rc;

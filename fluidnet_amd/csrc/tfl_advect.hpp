@@ -129,4 +129,8 @@ bool advect_vel3(hipStream_t st, bool two_pass, const AdvArgs& a, int B, const f
 bool advect_scalar3(hipStream_t st, bool two_pass, const AdvArgs& a, int B, const float* s, const float* U, const float* flags,
                     float* fwd, float* bounds, float* dst, int stages);
 
+// advect_pair3.hip (round 6): the passes A (stages & 2) / the passes B (stages & 4) of advectScalar AND advectVel in one launch each
+bool advect_pair3(hipStream_t st, const AdvArgs& a, int B, const float* s, const float* U, const float* flags, float* sfwd, float* sbounds,
+                  float* sdst, float* vfwd, float* vdst, int stages, const BcFoldArg& fold_s, const BcFoldArg& fold_v);
+
 }  // namespace tfl

@@ -108,6 +108,21 @@ __device__ __forceinline__ void block_tile(const BlockOrder& o, int& bx, int& by
   const unsigned y = div32(p, o.dgx);
   bx = (int)(p - y * o.gx); by = (int)y; bz = (int)z;
 }
+// the same for a block that is the L-th of a gx x gy x gz launch in the natural order (x fastest) WITHOUT being one: the pair
+// kernels of advect_pair3.hip run two launches' blocks as two ranges of one 1-D grid (round 6)
+__device__ __forceinline__ void block_tile_linear(const BlockOrder& o, unsigned L, unsigned gx, unsigned gy, int& bx, int& by, int& bz) {
+  if (!o.on) { const unsigned r = L / gx; bx = (int)(L - r * gx); bz = (int)(r / gy); by = (int)(r - (unsigned)bz * gy); return; }
+  unsigned T;
+  if (L < o.full) {
+    const unsigned idx = L >> 3, c = div32(idx, o.dS);
+    T = (c * 8 + (L & 7)) * o.S + (idx - c * o.S);
+  } else {
+    T = o.full + xcd_contiguous(L - o.full, o.n - o.full);
+  }
+  const unsigned z = div32(T, o.dP), p = T - z * o.P;
+  const unsigned y = div32(p, o.dgx);
+  bx = (int)(p - y * o.gx); by = (int)y; bz = (int)z;
+}
 // EXPERIMENTS flavour: TFL_XCD_ORDER=0 restores the hardware order everywhere (A/B switch; read once)
 inline bool xcd_order_enabled() {
 #ifdef TFL_EXPERIMENTS
