@@ -74,6 +74,8 @@ ALG_BYTES_PER_CELL = {
     "k_project": 36,         # pPred, flags, U3 -> U3, p  (the plume's U pair is sparse: applied on its four rows, the dense
                              # UBC3 / mask3 tensors -- 24 B/cell more -- are not read; round 3 counted them: 60)
     "k_set_wall_bcs": 28, "k_divergence": 20, "k_velocity_update": 32, "k_jacobi": 16,
+    # round 6, z-slab step only (advect_pair3.hip): the passes A / the passes B of advectScalar AND advectVel as one launch each
+    "k_adv_fwd_pair": 24 + 28, "k_adv_bwd_pair": 28 + 40,
 }
 
 
@@ -191,7 +193,7 @@ def cpu_baseline(batch, mconf, layers, max_seconds=25.0, max_steps=6, model=None
 
 # Planes a slab rank computes beyond its own, per kernel (below + above), from the z-windows of tfl_simulate_step_slab
 # (fluidnet_amd/csrc/simulate.cpp); kernels not listed run on the owned planes only.
-SLAB_EXTRA_PLANES = {"k_minmax3": (2, 2), "k_scalar_fwd": (1, 1), "k_vel_fwd": (1, 1), "k_add_buoyancy": (3, 4),
+SLAB_EXTRA_PLANES = {"k_minmax3": (2, 2), "k_scalar_fwd": (1, 1), "k_vel_fwd": (1, 1), "k_adv_fwd_pair": (1, 1), "k_add_buoyancy": (3, 4),
                      "k_add_gravity": (3, 4), "k_curl": (2, 2), "k_confine": (0, 1), "k_conv3_mfma_in": (3, 2),
                      "k_conv3_mfma": (2, 1), "k_conv3_mfma_tail": (1, 0), "k_conv3_in": (3, 2), "k_conv3_mid": (2, 1),
                      "k_conv3_tail": (1, 0)}
