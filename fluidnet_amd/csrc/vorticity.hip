@@ -890,8 +890,8 @@ static int vort_pipe_slots() {
 // forces. By measurement (profiles/r05_vort_pipe.txt, us: two launches / k_vort_pipe): 64^3 13 / 18, 96^3 24 / 23, 112^3 32 / 27,
 // 128^3 36 / 29, 160^3 80 / 50, 192^3 147 / 77, 256^3 310 / 165. Inside the 128^3 step (with the setConstVals pair folded into
 // either form: 37.5 / 35 us) the step gains 1.5 % on most boxes of the pool and nothing on one whose memory-bound kernels all
-// ran slow that day -- never a loss. So: k_vort_pipe from 2 M cells per batch item on, on arrays at least 64 planes deep (a
-// z-slab rank's 40-plane array marches chunks shorter than the 9-step pipeline: it keeps the two launches below 3 M cells);
+// ran slow that day -- never a loss. So: k_vort_pipe from 2 M cells per batch item on, on arrays at least 32 planes deep (round 6: a
+// z-slab rank's 40-plane array of 256^3 on 8 ranks was measured too -- 35.8 us against 40.7, the rank-step 0.293 -> 0.279 ms);
 // where the device cannot hold the pipelined kernel's block, k_vort_fused from 3 M cells (160^3: 69 / 80).
 bool vorticity_confinement_fused_ok(bool is3d, int Z, long long cells) {
   static const int mode = getenv("TFL_VORT_FUSED") ? atoi(getenv("TFL_VORT_FUSED")) : -1;
@@ -899,7 +899,7 @@ bool vorticity_confinement_fused_ok(bool is3d, int Z, long long cells) {
   if (!is3d || Z < 3 || mode == 0) return false;
   const bool pipe = pipe_mode != 0 && vort_pipe_slots() > 0;
   if (mode == 1) return pipe || vort_fused_slots() > 0;
-  if (pipe && cells >= 2000000ll && Z >= 64) return true;
+  if (pipe && cells >= 2000000ll && Z >= 32) return true;      // (round 6: a 40-plane slab of 256^3 on 8 ranks: 35.8 us against 40.7 for the two launches)
   return cells >= 3000000ll && (pipe || vort_fused_slots() > 0);
 }
 

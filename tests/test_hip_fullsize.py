@@ -79,9 +79,10 @@ def test_simulate_parity_at_baseline_size(request, advect_mode, res, config, pre
         assert np.isfinite(got).all() and r <= TOL, (res, kind, k, r)
 
 
-@pytest.mark.parametrize("res,world,config", [(256, 8, 5), (128, 8, 4), (128, 2, 4)])
+@pytest.mark.parametrize("res,world,config", [(256, 8, 5), (256, 8, 4), (128, 8, 4), (128, 2, 4)])
 def test_zslab_decomposition_at_baseline_size(res, world, config):
-    """BASELINE config 5 (256^3 in 8 z-slabs of 32 planes) and the metric's 128^3 strong-scaling series (8 slabs of 16,
+    """BASELINE config 5 (256^3 in 8 z-slabs of 32 planes; once more with config 4's obstacle and confinement, where a rank's
+    40-plane array takes the windowed k_vort_pipe) and the metric's 128^3 strong-scaling series (8 slabs of 16,
     2 of 64): the native slab step on virtual ranks of ONE GPU vs the unsplit step, from a developed plume. The unsplit
     step is itself held to the reference at these sizes by test_simulate_parity_at_baseline_size."""
     import torch
