@@ -378,6 +378,14 @@ def error_line(n_gpus, why):
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic"}
 
 
+def SHARE_GPU():
+    """TFL_RANKS_SHARE_GPU=1: more nccl ranks than GPUs (a control-flow check of the WHOLE --gpus N path against the real RCCL on
+    a one-GPU box, never a measurement). RCCL refuses two ranks of one host on one device ("Duplicate GPU detected": host hash +
+    bus id), so each rank calls itself a host of its own (NCCL_HOSTID) and RCCL moves the messages through its socket transport
+    over the loopback interface: same ncclSend / ncclRecv / ncclAllReduce calls, same stream semantics, another wire."""
+    return os.environ.get("TFL_RANKS_SHARE_GPU", "0") == "1"
+
+
 def self_launch(n):
     """`python bench.py --gpus N` without a launcher: re-execute this script under torch.distributed.run with N ranks on this
     node (rendezvous on 127.0.0.1, a free port), pass its output through and return its exit code. nccl (= RCCL, the measured
@@ -387,9 +395,10 @@ def self_launch(n):
     import subprocess
     backend = os.environ.get("TFL_DIST_BACKEND", "nccl")
     have = torch.cuda.device_count() if torch.cuda.is_available() else 0
-    if have == 0 or (backend == "nccl" and have < n):
+    if have == 0 or (backend == "nccl" and have < n and not SHARE_GPU()):
         print(json.dumps(error_line(n, "--gpus %d over %s needs %d visible GPUs, this node shows %d%s" % (
-            n, backend, n, have, "" if have == 0 else " (TFL_DIST_BACKEND=gloo runs the control-flow check with ranks sharing GPUs)"))))
+            n, backend, n, have, "" if have == 0 else " (control-flow checks with ranks sharing GPUs: TFL_RANKS_SHARE_GPU=1 keeps "
+            "RCCL -- its socket transport between the ranks --, TFL_DIST_BACKEND=gloo stages the messages through the host)"))))
         return 2
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -444,11 +453,17 @@ def main():
     # TFL_DIST_BACKEND=gloo (+ ranks sharing GPUs) exists only to validate the multi-rank control flow on a box
     # with fewer GPUs than ranks; the measured configuration is one rank per GPU over nccl (= RCCL).
     backend = os.environ.get("TFL_DIST_BACKEND", "nccl")
-    if backend == "nccl" and world > torch.cuda.device_count():
+    shared = backend == "nccl" and world > torch.cuda.device_count() and SHARE_GPU()
+    if backend == "nccl" and world > torch.cuda.device_count() and not shared:
         if rank == 0:
             print(json.dumps(error_line(world, "%d ranks over nccl need %d visible GPUs, this node shows %d" % (world, world, torch.cuda.device_count()))))
         raise SystemExit(2)
-    local = local % torch.cuda.device_count() if backend != "nccl" else local
+    if shared:      # before anything loads RCCL: see SHARE_GPU()
+        os.environ["NCCL_HOSTID"] = "tfl-bench-rank%d" % rank
+        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+        os.environ.setdefault("NCCL_IB_DISABLE", "1")
+        TRANSPORT["shared"] = "%d ranks share %d GPU(s), RCCL's socket transport between them (TFL_RANKS_SHARE_GPU=1): a control-flow check, not a measurement" % (world, torch.cuda.device_count())
+    local = local % torch.cuda.device_count() if (backend != "nccl" or shared) else local
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
@@ -512,9 +527,11 @@ def main():
 
     # ---- per-kernel HIP-event timing over further steps (outside the timed region; rank 0's kernels) --------------
     nprof = max(3, min(10, args.steps))
+    # (a recorded rank-step -- TFL_SLAB_GRAPH=1 -- is one graph launch to the profiler: these steps go through the eager call)
+    prof_step = (lambda: sim.step(eager=True)) if sim is not None else step
     with tfluids.profile(batch["UDiv"]) as prof:
         for _ in range(nprof):
-            step()
+            prof_step()
     if sim is not None:
         sim.drain()
     kernels = {}
@@ -744,7 +761,8 @@ def main():
                                "(3-D default topology, seeded weights); %s" % (res, "single GPU" if world == 1 else
                                "strong scaling: %d z-slabs of %d planes" % (world, owned_planes)),
                    "grid_zyx": [res, res, res], "per_gpu_grid_zyx": [owned_planes, res, res],
-                   "decomposition": "single GPU" if world == 1 else "z-slabs, %d ranks, transport: %s" % (world, TRANSPORT["name"]),
+                   "decomposition": "single GPU" if world == 1 else "z-slabs, %d ranks, transport: %s%s" % (
+                       world, TRANSPORT["name"], ("; " + TRANSPORT["shared"]) if TRANSPORT.get("shared") else ""),
                    "rank_step": None if sim_info is None else sim_info,
                    "preroll_steps": args.preroll, "slab": redundancy, "strong_scaling": single},
         "range_errors": range_errors, "trace_errors": trace_errors, "conv_exact_fp32": conv_exact,

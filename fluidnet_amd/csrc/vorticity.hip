@@ -594,17 +594,29 @@ __global__ __launch_bounds__(512) void k_vort_fused(Dom d, int cols_x, int cols_
 // DIFFERENT waves (9-15 / 0-3 / 4-5). Pipeline fill: 9 steps per chunk (6). Per-cell arithmetic is k_curl / k_confine's,
 // operation for operation: bit-equal to the two-launch form (tests/test_hip_parity.py).
 namespace {
-constexpr int PBX = 64, PBY = 16;
-constexpr int PCX = PBX + 3, PCY = PBY + 3, PCN = PCX * PCY;      // curl tile 67 x 19, origin (x0 - 2, y0 - 2)
-constexpr int QX = PCX + 2, QY = PCY + 2, QN = QX * QY;           // centred-velocity tile 69 x 21, origin (x0 - 3, y0 - 3)
-constexpr int PEX = PBX + 1, PEY = PBY + 1;                       // force exchange, origin (x0 - 1, y0 - 1)
-constexpr int kPipeLds = (4 * 3 * QN + 4 * PCN + 3 * 3 * PCN + 2 * 2 * PEY * PEX) * 4;   // 153 428 bytes
+// a block = BX x BY cells (one thread each) x a chunk of z. 64 x 16: 1024 threads, 153 428 bytes of LDS, one block per CU;
+// 32 x 16 (round 6): 512 threads, 80 852 bytes -- TWO blocks per CU, whose barrier and load waits overlap
+template <int BX, int BY>
+struct PipeGeo {
+  static constexpr int PBX = BX, PBY = BY, NT = BX * BY;
+  static constexpr int PCX = PBX + 3, PCY = PBY + 3, PCN = PCX * PCY;      // curl tile (67 x 19), origin (x0 - 2, y0 - 2)
+  static constexpr int QX = PCX + 2, QY = PCY + 2, QN = QX * QY;           // centred-velocity tile (69 x 21), origin (x0 - 3, y0 - 3)
+  static constexpr int PEX = PBX + 1, PEY = PBY + 1;                       // force exchange, origin (x0 - 1, y0 - 1)
+  static constexpr int kLds = (4 * 3 * QN + 4 * PCN + 3 * 3 * PCN + 2 * 2 * PEY * PEX) * 4;
+  // the threads that evaluate the column / the row of forces before the block: [kE, kE + PBY) and [kER, kER + PBX), in waves
+  // that have no second curl round and as little of the second staging round as the block allows
+  static constexpr int kE = BX == 64 ? 256 : 192, kER = BX == 64 ? 320 : kE + PBY;
+  static_assert(QN <= 2 * NT && PCN <= 2 * NT && NT % 64 == 0, "two rounds cover the tiles");
+};
 constexpr int kPipeFill = 9;
 }  // namespace
 
-__global__ __launch_bounds__(1024) void k_vort_pipe(Dom d, int cols_x, int cols_y, int cz, int chunks_a, int chunks, int n_blocks,
+template <int BX, int BY>
+__global__ __launch_bounds__(BX * BY) void k_vort_pipe(Dom d, int cols_x, int cols_y, int cz, int chunks_a, int chunks, int n_blocks,
                                                     const float* __restrict__ Uin, float* __restrict__ Uout,
                                                     const float* __restrict__ flags, float strength, int xcd_order, BcFoldArg folda) {
+  using G = PipeGeo<BX, BY>;
+  constexpr int PBX = G::PBX, PBY = G::PBY, NT = G::NT, PCX = G::PCX, PCN = G::PCN, QX = G::QX, QN = G::QN, PEX = G::PEX, PEY = G::PEY;
   extern __shared__ float lds[];
   float* Cr = lds;                    // [4][3][QN]   centred velocities, planes z & 3
   float* Cn = Cr + 4 * 3 * QN;        // [4][PCN]     |curl|, planes z & 3
@@ -623,18 +635,18 @@ __global__ __launch_bounds__(1024) void k_vort_pipe(Dom d, int cols_x, int cols_
   const int x0 = bx * PBX, y0 = by * PBY;
   const long long cells = d.sc;
   Uin += b * cells * 3; Uout += b * cells * 3; flags += b * cells;
-  const int tid = threadIdx.x, tx = tid & 63, ty = tid >> 6;
-  const int wave = __builtin_amdgcn_readfirstlane(ty);     // (scalar: the per-wave roles below are scalar branches)
+  const int tid = threadIdx.x, tx = tid % PBX, ty = tid / PBX;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // (scalar: the per-wave roles below are scalar branches)
   const int i = x0 + tx, j = y0 + ty;
 
   // ---- per-thread geometry, fixed for the whole march --------------------------------------------------------------------
   // staging: round 0 = cell tid of the C tile, round 1 (waves 9-15) = cell 1024 + (tid - kS1). Per cell: the offsets of the
   // cell, its +x and its +y neighbour (clamped into the grid: cells outside it and shell cells stage 0) and the shell flag
-  constexpr int kS1 = 1024 - (QN - 1024);        // first thread of the second staging round (599)
+  constexpr int kS1 = NT - (QN - NT);        // first thread of the second staging round (599)
   const bool two_st = wave * 64 + 63 >= kS1;     // this wave stages a second cell
   int st_it[2], st_o[2], st_ox[2], st_oy[2];
   bool st_sh[2];
-  st_it[0] = tid; st_it[1] = tid >= kS1 ? 1024 + (tid - kS1) : tid;
+  st_it[0] = tid; st_it[1] = tid >= kS1 ? NT + (tid - kS1) : tid;
 #pragma unroll
   for (int r = 0; r < 2; r++) {
     const int qy = st_it[r] / QX, qx = st_it[r] - qy * QX;
@@ -646,27 +658,29 @@ __global__ __launch_bounds__(1024) void k_vort_pipe(Dom d, int cols_x, int cols_
     st_sh[r] = gx <= 0 || gx >= d.X - 1 || gy <= 0 || gy >= d.Y - 1;
   }
   // curl: round 0 = cell tid of the 67 x 19 curl tile, round 1 (waves 0-3) = cell 1024 + tid
-  constexpr int kC1 = PCN - 1024;                // cells of the second curl round (249)
+  constexpr int kC1 = PCN - NT;                // cells of the second curl round (249)
   int c_it[2], c_base[2];
   bool c_in[2];
 #pragma unroll
   for (int r = 0; r < 2; r++) {
-    const int it = min(tid + 1024 * r, PCN - 1);
+    const int it = min(tid + NT * r, PCN - 1);
     const int cy = it / PCX, cx = it - cy * PCX;
     const int gx = x0 - 2 + cx, gy = y0 - 2 + cy;
     c_it[r] = it;
     c_base[r] = (cy + 1) * QX + (cx + 1);
-    c_in[r] = tid + 1024 * r < PCN && gx >= 1 && gx <= d.X - 2 && gy >= 1 && gy <= d.Y - 2;
+    c_in[r] = tid + NT * r < PCN && gx >= 1 && gx <= d.X - 2 && gy >= 1 && gy <= d.Y - 2;
   }
   // force: the thread's own cell; waves 4 / 5: one cell of the column / the row before the block
   const int f_it = (ty + 2) * PCX + tx + 2;
   const bool f_in = i >= 1 && i <= d.X - 2 && j >= 1 && j <= d.Y - 2;
-  const bool e_col = tid >= 256 && tid < 256 + PBY, e_row = tid >= 320 && tid < 320 + PBX;
-  const int e_cx = e_col ? 1 : (tid - 320) + 2, e_cy = e_col ? (tid - 256) + 2 : 1;
+  constexpr int kE = G::kE, kER = G::kER;
+  const bool e_col = tid >= kE && tid < kE + PBY, e_row = tid >= kER && tid < kER + PBX;
+  const bool e_wave = wave >= kE / 64 && wave <= (kER + PBX - 1) / 64;       // scalar
+  const int e_cx = e_col ? 1 : (tid - kER) + 2, e_cy = e_col ? (tid - kE) + 2 : 1;
   const int e_it = (e_col || e_row) ? e_cy * PCX + e_cx : f_it;
   const int e_gx = x0 - 2 + e_cx, e_gy = y0 - 2 + e_cy;
   const bool e_in = (e_col || e_row) && e_gx >= 1 && e_gx <= d.X - 2 && e_gy >= 1 && e_gy <= d.Y - 2;
-  const int e_dst = e_col ? ((tid - 256) + 1) * PEX : PEY * PEX + (tid - 320) + 1;
+  const int e_dst = e_col ? ((tid - kE) + 1) * PEX : PEY * PEX + (tid - kER) + 1;
   const bool out_xy = i < d.X && j < d.Y;
   const int o_xy = TFL_AT(d, min(i, d.X - 1), min(j, d.Y - 1), 0);
   const int o_safe = o_xy + (i >= 1 ? 0 : 1) + (j >= 1 ? 0 : d.sy);      // a cell whose -x / -y neighbours exist
@@ -795,7 +809,7 @@ __global__ __launch_bounds__(1024) void k_vort_pipe(Dom d, int cols_x, int cols_
       f0 = force(f_it, z_in && f_in, cn0, cnp, cnm, cv);
       fe[(ty + 1) * PEX + tx + 1] = f0.x;
       fe[(PEY + ty + 1) * PEX + tx + 1] = f0.y;
-      if (wave == 4 || wave == 5) {         // the column / the row before the block
+      if (e_wave) {         // the column / the row before the block
         const v3 fq = force(e_it, z_in && e_in, cn0, cnp, cnm, cv);
         if (e_col || e_row) fe[e_dst] = e_col ? fq.x : fq.y;
       }
@@ -836,12 +850,24 @@ __global__ __launch_bounds__(1024) void k_vort_pipe(Dom d, int cols_x, int cols_
   // every stage is active for t in [za + 6, zb + 1]
   const int ts = min(max(za + 6, t0), t1 + 1), te = min(zb + 1, t1);
   int t = t0;
+#ifdef TFL_VORT_TIMING
+  long long tk[40]; int nk = 0;
+  tk[nk++] = wall_clock64();
+#define TFL_VT() if (nk < 40) tk[nk++] = wall_clock64()
+#else
+#define TFL_VT()
+#endif
 #pragma unroll 1
-  for (; t < ts; t++) step(t, std::false_type{});
+  for (; t < ts; t++) { step(t, std::false_type{}); TFL_VT(); }
 #pragma unroll 1
-  for (; t <= te; t++) step(t, std::true_type{});
+  for (; t <= te; t++) { step(t, std::true_type{}); TFL_VT(); }
 #pragma unroll 1
-  for (; t <= t1; t++) step(t, std::false_type{});
+  for (; t <= t1; t++) { step(t, std::false_type{}); TFL_VT(); }
+#ifdef TFL_VORT_TIMING
+  if (tid == 0 && (blk == 0 || blk == n_blocks / 2 + 3)) {
+    for (int q = 1; q < nk; q++) printf("vt blk %d step %d (t-za %d) %lld\n", blk, q - 1, t0 + q - 1 - za, tk[q] - tk[q - 1]);
+  }
+#endif
 }
 
 // block slots of k_vort_fused on the current device, asked once per device: 0 = the device cannot run it (its 78 KB of dynamic
@@ -866,8 +892,10 @@ static int vort_fused_slots() {
   return slots > 0 ? slots : 0;
 }
 
-// block slots of k_vort_pipe (one 1024-thread block with 154 KB of LDS per CU); 0 = this device cannot run it
-static int vort_pipe_slots() {
+// block slots of k_vort_pipe<BX, BY> on the current device (64 x 16: one 1024-thread block with 154 KB of LDS per CU; 32 x 16: two
+// 512-thread blocks with 81 KB each); 0 = this device cannot run it
+template <int BX, int BY>
+static int vort_pipe_slots_of() {
   static std::atomic<int> slots_of[64];
   int dev = 0;
   (void)hipGetDevice(&dev);
@@ -876,14 +904,49 @@ static int vort_pipe_slots() {
   if (!slots) {
     int cus = 256, per = 0;
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    const bool attr_ok = hipFuncSetAttribute((const void*)k_vort_pipe, hipFuncAttributeMaxDynamicSharedMemorySize, kPipeLds) == hipSuccess;
-    if (!attr_ok || hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, (const void*)k_vort_pipe, 1024, kPipeLds) != hipSuccess || per <= 0) {
+    using G = PipeGeo<BX, BY>;
+    const bool attr_ok = hipFuncSetAttribute((const void*)k_vort_pipe<BX, BY>, hipFuncAttributeMaxDynamicSharedMemorySize, G::kLds) == hipSuccess;
+    if (!attr_ok || hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, (const void*)k_vort_pipe<BX, BY>, G::NT, G::kLds) != hipSuccess || per <= 0) {
       (void)hipGetLastError();
       slots = -1;
     } else slots = cus * per;
     slots_of[dev].store(slots);
   }
   return slots > 0 ? slots : 0;
+}
+
+static int vort_pipe_slots() { return vort_pipe_slots_of<64, 16>(); }
+
+// chunk length of a z-marched launch: rounds of resident blocks x (planes written + pipeline fill)
+static int march_chunk(long long tiles, int na, int nb, int slots, int fill, int cmin) {
+  int cz = cmin;
+  long long best = -1;
+  for (int c = cmin; c <= 64; c++) {
+    const long long blocks = tiles * ((na + c - 1) / c + (nb + c - 1) / c);
+    const long long cost = ((blocks + slots - 1) / slots) * (c + fill);
+    if (best < 0 || cost < best) { best = cost; cz = c; }
+  }
+  return cz;
+}
+
+
+template <int BX, int BY>
+static bool launch_vort_pipe(hipStream_t st, const Dom& d, int B, int X, int Y, int na, int nb, const float* Uin, float* Uout,
+                             const float* flags, float strength, int xcd_order) {
+  using G = PipeGeo<BX, BY>;
+  const int pslots = vort_pipe_slots_of<BX, BY>();
+  const int pcx = (X + BX - 1) / BX, pcy = (Y + BY - 1) / BY;
+  const long long tiles = (long long)pcx * pcy * B;
+  if (pslots <= 0 || tiles * (na + nb) <= 0) return false;
+  int cz = march_chunk(tiles, na, nb, pslots, kPipeFill, 4);
+  if (const char* e = exp_env("TFL_VORT_CZ")) cz = atoi(e) > 0 ? atoi(e) : cz;
+  if (const char* e = getenv("TFL_VORT_CZ2")) cz = atoi(e) > 0 ? atoi(e) : cz;
+  const int chunks_a = (na + cz - 1) / cz, chunks = chunks_a + (nb + cz - 1) / cz;
+  const int n_blocks = (int)(pcx * pcy * chunks * B);
+  TFL_TIMED_EXT("k_vort_fused", st);
+  const BcFoldArg fold = take_fold();    // the kernel writes the operator's result: it applies the pair that follows
+  TFL_LAUNCH_EXT((k_vort_pipe<BX, BY>), n_blocks, G::NT, G::kLds, st, d, pcx, pcy, cz, chunks_a, chunks, n_blocks, Uin, Uout, flags, strength, xcd_order, fold);
+  return true;
 }
 
 // does the native step (and tfl_vorticityConfinementFrom) route the confinement through a fused kernel? TFL_VORT_FUSED = 1 | 0
@@ -903,18 +966,6 @@ bool vorticity_confinement_fused_ok(bool is3d, int Z, long long cells) {
   return cells >= 3000000ll && (pipe || vort_fused_slots() > 0);
 }
 
-// chunk length of a z-marched launch: rounds of resident blocks x (planes written + pipeline fill)
-static int march_chunk(long long tiles, int na, int nb, int slots, int fill, int cmin) {
-  int cz = cmin;
-  long long best = -1;
-  for (int c = cmin; c <= 64; c++) {
-    const long long blocks = tiles * ((na + c - 1) / c + (nb + c - 1) / c);
-    const long long cost = ((blocks + slots - 1) / slots) * (c + fill);
-    if (best < 0 || cost < best) { best = cost; cz = c; }
-  }
-  return cz;
-}
-
 // false = shape not supported by the fused kernel (the caller copies and runs the two-launch form)
 bool vorticity_confinement_fused(hipStream_t st, int B, int Z, int Y, int X, const float* Uin, float* Uout, const float* flags,
                                  float strength) {
@@ -927,21 +978,9 @@ bool vorticity_confinement_fused(hipStream_t st, int B, int Z, int Y, int X, con
   // three-barrier kernel
   static const int pipe_mode = getenv("TFL_VORT_PIPE") ? atoi(getenv("TFL_VORT_PIPE")) : -1;
   if (pipe_mode != 0) {
-    const int pslots = vort_pipe_slots();
-    const int pcx = (X + PBX - 1) / PBX, pcy = (Y + PBY - 1) / PBY;
-    const long long tiles = (long long)pcx * pcy * B;
-    if (pslots > 0 && tiles * (na + nb) > 0) {
-      int cz = march_chunk(tiles, na, nb, pslots, kPipeFill, 4);
-      if (const char* e = exp_env("TFL_VORT_CZ")) cz = atoi(e) > 0 ? atoi(e) : cz;
-      {
-        const int chunks_a = (na + cz - 1) / cz, chunks = chunks_a + (nb + cz - 1) / cz;
-        const int n_blocks = (int)(pcx * pcy * chunks * B);
-        TFL_TIMED_EXT("k_vort_fused", st);
-        const BcFoldArg fold = take_fold();    // the kernel writes the operator's result: it applies the pair that follows
-        TFL_LAUNCH_EXT(k_vort_pipe, n_blocks, 1024, kPipeLds, st, d, pcx, pcy, cz, chunks_a, chunks, n_blocks, Uin, Uout, flags, strength, xcd_order, fold);
-        return true;
-      }
-    }
+    static const int tile = getenv("TFL_VORT_TILE") ? atoi(getenv("TFL_VORT_TILE")) : 64;
+    if (tile == 32 && launch_vort_pipe<32, 16>(st, d, B, X, Y, na, nb, Uin, Uout, flags, strength, xcd_order)) return true;
+    if (launch_vort_pipe<64, 16>(st, d, B, X, Y, na, nb, Uin, Uout, flags, strength, xcd_order)) return true;
   }
   const int cxn = (X + FBX - 1) / FBX, cyn = (Y + FBY - 1) / FBY;
   if ((long long)cxn * cyn * (na + nb) * B <= 0) return true;

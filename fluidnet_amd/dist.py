@@ -403,14 +403,18 @@ class SlabSimulation:
             return True
         return hasattr(self.comm, "struct") and bool(getattr(self.comm.struct, "capturable", 0))
 
-    def step(self):
-        if self.graph is None and self.graph_mode is not False and self._steps >= self.graph_after:
+    def step(self, eager=False):
+        """One rank-step. eager=True: through tfl_simulate_step_slab even when a recorded step exists (the per-kernel profiler
+        sees nothing inside a graph launch); every rank must make the same choice, and `drain()` comes before the next recorded
+        step (a recorded step starts and ends with no message in flight, an eager one leaves the p / U halos travelling)."""
+        if not eager and self.graph is None and self.graph_mode is not False and self._steps >= self.graph_after:
             if self.graph_mode is True or self._capturable():
                 self._record()
             else:
                 self.graph_mode, self.graph_error = False, "the transport runs host code per message (tfl_comm.capturable = 0)"
         self._steps += 1
-        if self.graph is not None:
+        if self.graph is not None and not eager:
+            self.drain()
             lib, ctx = self._context()
             rc = lib.tfl_slab_graph_step(ctx, self.graph)
             if rc != 0:

@@ -36,8 +36,11 @@ def main(rank, world, rdv):
     from fluidnet_amd.dist import RcclComm, SlabLayout, SlabSimulation
     from fluidnet_amd.simulate import simulate_native
     from oracle import simulate_np as S
-    torch.cuda.set_device(rank)
-    dev = torch.device("cuda", rank)
+    # TFL_RCCL_ONE_GPU=1 (tests/test_rccl_multiproc.py on a one-GPU box): every rank on device 0, each with its own NCCL_HOSTID, so
+    # that RCCL takes the ranks for processes of different hosts and moves the messages through its socket transport
+    index = 0 if os.environ.get("TFL_RCCL_ONE_GPU") == "1" else rank
+    torch.cuda.set_device(index)
+    dev = torch.device("cuda", index)
     Zt, Y, X = 16 * world, 24, 32
     b = T._plume_batch((Zt, Y, X), 0.15, 0.6, obstacles_seed=11)
     mconf = dict(dt=0.1, advectionMethod="maccormackOurs", maccormackStrength=0.6, buoyancyScale=1.0,

@@ -82,3 +82,29 @@ def test_bench_gpus_2_launches_itself_over_gloo_on_one_gpu():
     assert len(lines) == 1
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["value"] > 0 and "gloo" in line["config"]["decomposition"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("graph", ["0", "1"], ids=["eager-rank-step", "recorded-rank-step"])
+def test_bench_gpus_2_over_real_rccl_with_ranks_sharing_the_gpu(graph):
+    """The whole `--gpus N` path against the REAL RCCL on a one-GPU box (round 6): TFL_RANKS_SHARE_GPU=1 puts both ranks on device
+    0, each under its own NCCL_HOSTID (RCCL's duplicate-GPU test passes, its socket transport carries the messages). The line
+    must name the library's native transport (comm_rccl.cpp: the trial step on every rank succeeded) -- and, with
+    TFL_SLAB_GRAPH=1, a rank-step recorded with the ncclSend / ncclRecv / ncclAllReduce inside the graph. A box with two GPUs
+    runs the same thing one rank per GPU."""
+    import sys
+    import torch
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "TFL_DIST_BACKEND")}
+    if torch.cuda.device_count() < 2:
+        env["TFL_RANKS_SHARE_GPU"] = "1"
+    env["TFL_SLAB_GRAPH"] = graph
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--preroll", "2",
+                        "--blocks", "1", "--res", "64", "--no-config5", "--no-configs"], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["value"] > 0 and line["range_errors"] == 0
+    assert "native RCCL send/recv" in line["config"]["decomposition"], line["config"]["decomposition"]
+    issued = line["config"]["rank_step"]["issued_as"]
+    assert ("HIP graph" in issued) == (graph == "1"), issued
