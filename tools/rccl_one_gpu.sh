@@ -13,5 +13,5 @@ for r in $(seq 0 $((W-1))); do
 done
 rc=0
 for p in "${pids[@]}"; do wait $p || rc=$?; done
-for r in $(seq 0 $((W-1))); do echo "---- rank $r"; grep -v amdgpu.ids $R/out$r.txt | tail -${TAIL:-12}; done
+for r in $(seq 0 $((W-1))); do echo "---- rank $r"; if [ -n "$SUMMARY" ]; then grep -E "owned planes|recorded step|multiproc ok|rror|Traceback|RCCL_INIT" $R/out$r.txt; else grep -v amdgpu.ids $R/out$r.txt | tail -${TAIL:-12}; fi; done
 echo "rc=$rc"
