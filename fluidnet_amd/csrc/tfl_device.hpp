@@ -123,13 +123,27 @@ __device__ __forceinline__ void block_tile_linear(const BlockOrder& o, unsigned 
   const unsigned y = div32(p, o.dgx);
   bx = (int)(p - y * o.gx); by = (int)y; bz = (int)z;
 }
-// EXPERIMENTS flavour: TFL_XCD_ORDER=0 restores the hardware order everywhere (A/B switch; read once)
+// The decode above assumes EIGHT XCDs fed round-robin: an MI355X / MI350X (and gfx942's MI300X) in SPX mode. A partitioned part
+// (DPX / QPX / CPX: 4 / 2 / 1 XCDs behind one device) or a one-die part would pay for the decode and gain nothing, so the order
+// is taken only where the device shows the CU count of a whole eight-XCD package (>= 200 CUs; asked once per device -- ADVICE
+// r05). EXPERIMENTS flavour: TFL_XCD_ORDER=0 restores the hardware order everywhere (A/B switch; read once)
+inline bool device_has_8_xcds() {
+  static int known[64];       // 0 = not asked yet, 1 = yes, -1 = no (benign race: every thread writes the same value)
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  if (!known[dev]) {
+    int cus = 0;
+    const bool ok = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess;
+    known[dev] = (ok && cus >= 200) ? 1 : -1;
+  }
+  return known[dev] > 0;
+}
 inline bool xcd_order_enabled() {
 #ifdef TFL_EXPERIMENTS
   static const bool on = !(getenv("TFL_XCD_ORDER") && atoi(getenv("TFL_XCD_ORDER")) == 0);
-  return on;
+  return on && device_has_8_xcds();
 #else
-  return true;
+  return device_has_8_xcds();
 #endif
 }
 // run length of a gx x gy (x gz) launch: an eighth of a plane per XCD (measured best, or level with one run per XCD, for the

@@ -940,7 +940,6 @@ static bool launch_vort_pipe(hipStream_t st, const Dom& d, int B, int X, int Y, 
   if (pslots <= 0 || tiles * (na + nb) <= 0) return false;
   int cz = march_chunk(tiles, na, nb, pslots, kPipeFill, 4);
   if (const char* e = exp_env("TFL_VORT_CZ")) cz = atoi(e) > 0 ? atoi(e) : cz;
-  if (const char* e = getenv("TFL_VORT_CZ2")) cz = atoi(e) > 0 ? atoi(e) : cz;
   const int chunks_a = (na + cz - 1) / cz, chunks = chunks_a + (nb + cz - 1) / cz;
   const int n_blocks = (int)(pcx * pcy * chunks * B);
   TFL_TIMED_EXT("k_vort_fused", st);
@@ -978,8 +977,12 @@ bool vorticity_confinement_fused(hipStream_t st, int B, int Z, int Y, int X, con
   // three-barrier kernel
   static const int pipe_mode = getenv("TFL_VORT_PIPE") ? atoi(getenv("TFL_VORT_PIPE")) : -1;
   if (pipe_mode != 0) {
-    static const int tile = getenv("TFL_VORT_TILE") ? atoi(getenv("TFL_VORT_TILE")) : 64;
+#ifdef TFL_EXPERIMENTS
+    // 32 x 16 tiles, two 512-thread blocks per CU (round 6): level with 64 x 16 at 128^3 (34.9 against 34.3 us) and at 256^3
+    // (182.6 / 180.5) -- a CU issues the two blocks' steps no faster than the one big block's; kept for A/B only
+    static const int tile = exp_env("TFL_VORT_TILE") ? atoi(exp_env("TFL_VORT_TILE")) : 64;
     if (tile == 32 && launch_vort_pipe<32, 16>(st, d, B, X, Y, na, nb, Uin, Uout, flags, strength, xcd_order)) return true;
+#endif
     if (launch_vort_pipe<64, 16>(st, d, B, X, Y, na, nb, Uin, Uout, flags, strength, xcd_order)) return true;
   }
   const int cxn = (X + FBX - 1) / FBX, cyn = (Y + FBY - 1) / FBY;

@@ -12,7 +12,7 @@ EXP_LIB = os.path.join(ROOT, "fluidnet_amd", "libtfluids_hip_exp.so")
 
 # switches only the EXPERIMENTS flavour reads (tfl_host.hpp exp_env, conv_mfma16_exp.inc, advect_scalar3_march.inc, ...)
 EXPERIMENT_SWITCHES = ("TFL_ADVECT_GATHER", "TFL_SCALAR_GATHER", "TFL_M16_", "TFL_NO_VEC4", "TFL_SCAL3_MARCH", "TFL_SCAL3M_CZ_",
-                       "TFL_STATS_FOLD", "TFL_VEL3_KZ_B", "TFL_VORT_CZ", "TFL_WF_", "TFL_XCD_", "TFL_SLAB_WIDEN", "TFL_CONV_DEBUG",
+                       "TFL_STATS_FOLD", "TFL_VEL3_KZ_B", "TFL_VORT_CZ", "TFL_VORT_TILE", "TFL_WF_", "TFL_XCD_", "TFL_SLAB_WIDEN", "TFL_CONV_DEBUG",
                        "TFL_CONV_TRACE")
 
 

@@ -585,8 +585,10 @@ def test_fused_vorticity_confinement_equals_the_two_launch_form(oracle, dims, se
 
 @pytest.mark.parametrize("env", [{"TFL_VORT_FUSED": "1", "TFL_VORT_PIPE": "1"}, {"TFL_VORT_FUSED": "1", "TFL_VORT_PIPE": "1", "TFL_VORT_CZ": "5"},
                                  {"TFL_VORT_FUSED": "1", "TFL_VORT_PIPE": "0"}, {"TFL_VORT_FUSED": "1", "TFL_VORT_PIPE": "0", "TFL_VORT_CZ": "5"},
-                                 {"TFL_VORT_FUSED": "1", "TFL_XCD_ORDER": "0"}],
-                         ids=["pipelined", "pipelined-short-chunks", "three-barrier", "three-barrier-short-chunks", "pipelined-hardware-block-order"])
+                                 {"TFL_VORT_FUSED": "1", "TFL_XCD_ORDER": "0"}, {"TFL_VORT_FUSED": "1", "TFL_VORT_TILE": "32"},
+                                 {"TFL_VORT_FUSED": "1", "TFL_VORT_TILE": "32", "TFL_VORT_CZ": "5"}],
+                         ids=["pipelined", "pipelined-short-chunks", "three-barrier", "three-barrier-short-chunks", "pipelined-hardware-block-order",
+                              "pipelined-32x16-tiles", "pipelined-32x16-short-chunks"])
 def test_fused_vorticity_kernel_variants(env):
     """The fused confinement has two kernels -- k_vort_pipe (software-pipelined, one barrier per plane step; chosen when the
     default where the device holds its block) and k_vort_fused -- and tfl_vorticityConfinementFrom takes the fused route only
@@ -596,7 +598,7 @@ def test_fused_vorticity_kernel_variants(env):
     the test also runs the operator under a two-run z-window (the slab step's form of the call)."""
     import subprocess, sys
     e = dict(os.environ)
-    for k in ("TFL_VORT_PIPE", "TFL_VORT_CZ", "TFL_VORT_FUSED", "TFL_XCD_ORDER"):
+    for k in ("TFL_VORT_PIPE", "TFL_VORT_CZ", "TFL_VORT_FUSED", "TFL_XCD_ORDER", "TFL_VORT_TILE"):
         e.pop(k, None)
     e = child_env(e, env)
     out = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
