@@ -715,7 +715,6 @@ __global__ __launch_bounds__(BX * BY) void k_vort_pipe(Dom d, int cols_x, int co
     on[0] = bxp[o_xy]; on[1] = byp[o_xy]; on[2] = bzp[o_xy];
   };
   const int t0 = za - 3, t1 = zb + 5;
-  load_plane(t0);
   float cxp[2] = {0.0f, 0.0f}, cyp[2] = {0.0f, 0.0f}, uzp[2] = {0.0f, 0.0f};   // c_x, c_y, u_z of plane t - 1 at the top of step t
   // the thread's OWN velocities travel in registers from the step that stages their plane to the step that stores it (seven
   // steps later the lines have left the XCD's L2: read again at the store they were 12 of the kernel's 43 B/cell at 256^3):
@@ -849,7 +848,6 @@ __global__ __launch_bounds__(BX * BY) void k_vort_pipe(Dom d, int cols_x, int co
   };
   // every stage is active for t in [za + 6, zb + 1]
   const int ts = min(max(za + 6, t0), t1 + 1), te = min(zb + 1, t1);
-  int t = t0;
 #ifdef TFL_VORT_TIMING
   long long tk[40]; int nk = 0;
   tk[nk++] = wall_clock64();
@@ -857,6 +855,48 @@ __global__ __launch_bounds__(BX * BY) void k_vort_pipe(Dom d, int cols_x, int co
 #else
 #define TFL_VT()
 #endif
+  // ---- prologue (round 6): what the steps t0 .. za would do -- nothing but staging: C planes za - 3, za - 2, za - 1 into the ring,
+  // plane za's c_x, c_y, u_z into the carry registers -- with the loads of all four planes in flight TOGETHER and one barrier
+  // instead of four (those four steps were 4.8 of a 128^3 chunk's 30.7 us: each waited out a memory round trip on its own)
+  {
+    float pl[4][2][5];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const float* bxp = Uin + (long long)min(max(t0 + q, 0), d.Z - 1) * d.sz;
+      const float* byp = bxp + d.sc;
+      const float* bzp = byp + d.sc;
+#pragma unroll
+      for (int r = 0; r < 2; r++) {
+        if (r == 1 && !two_st) continue;
+        pl[q][r][0] = bxp[st_o[r]]; pl[q][r][1] = bxp[st_ox[r]]; pl[q][r][2] = byp[st_o[r]]; pl[q][r][3] = byp[st_oy[r]]; pl[q][r][4] = bzp[st_o[r]];
+      }
+      if (q == 3) { oq[6][0] = bxp[o_xy]; oq[6][1] = byp[o_xy]; oq[6][2] = bzp[o_xy]; }      // plane za's own cell: enters the queue's back
+    }
+    load_plane(za + 1);
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+      const int pz = t0 + q;
+      const bool zsh = pz <= 0 || pz >= d.Z - 1;
+      float* dst = Cr + (pz & 3) * 3 * QN;
+#pragma unroll
+      for (int r = 0; r < 2; r++) {
+        if (r == 1 && !two_st) continue;
+        const float cx = 0.5f * (pl[q][r][0] + pl[q][r][1]), cy = 0.5f * (pl[q][r][2] + pl[q][r][3]);
+        const float cz = 0.5f * (pl[q][r][4] + pl[q + 1][r][4]);
+        const bool z0 = zsh || st_sh[r];
+        dst[st_it[r]] = z0 ? 0.0f : cx; dst[QN + st_it[r]] = z0 ? 0.0f : cy; dst[2 * QN + st_it[r]] = z0 ? 0.0f : cz;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+      if (r == 1 && !two_st) continue;
+      cxp[r] = 0.5f * (pl[3][r][0] + pl[3][r][1]); cyp[r] = 0.5f * (pl[3][r][2] + pl[3][r][3]); uzp[r] = pl[3][r][4];
+    }
+    cv3 = (cv3 + 4) % 3;
+    __syncthreads();
+  }
+  TFL_VT();
+  int t = za + 1;
 #pragma unroll 1
   for (; t < ts; t++) { step(t, std::false_type{}); TFL_VT(); }
 #pragma unroll 1
@@ -865,7 +905,7 @@ __global__ __launch_bounds__(BX * BY) void k_vort_pipe(Dom d, int cols_x, int co
   for (; t <= t1; t++) { step(t, std::false_type{}); TFL_VT(); }
 #ifdef TFL_VORT_TIMING
   if (tid == 0 && (blk == 0 || blk == n_blocks / 2 + 3)) {
-    for (int q = 1; q < nk; q++) printf("vt blk %d step %d (t-za %d) %lld\n", blk, q - 1, t0 + q - 1 - za, tk[q] - tk[q - 1]);
+    for (int q = 1; q < nk; q++) printf("vt blk %d step %d (t-za %d) %lld\n", blk, q - 1, q - 1, tk[q] - tk[q - 1]);     // (step 0 = the prologue)
   }
 #endif
 }
