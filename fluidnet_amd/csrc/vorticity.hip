@@ -722,6 +722,7 @@ __global__ __launch_bounds__(BX * BY) void k_vort_pipe(Dom d, int cols_x, int co
   float oq[7][3];
 #pragma unroll
   for (int q = 0; q < 7; q++) { oq[q][0] = 0.0f; oq[q][1] = 0.0f; oq[q][2] = 0.0f; }
+  float fn[3] = {0.0f, 0.0f, 0.0f}, fzc = 0.0f;      // flags of the out stage's NEXT plane (cell, -x, -y) and the cell's own of the plane before it
   v3 fcar = mk3(0.0f, 0.0f, 0.0f);    // the thread's force of plane t - 6 (computed in step t - 1)
   float fzcar = 0.0f;                 // force.z of plane t - 7
   int cv3 = ((t0 - 3) % 3 + 3) % 3;   // (zc % 3) of this step's curl plane, kept as a counter
@@ -735,11 +736,13 @@ __global__ __launch_bounds__(BX * BY) void k_vort_pipe(Dom d, int cols_x, int co
     const bool out_live = out_xy && out_act;
     const bool out_inner = out_live && f_in && zo >= 1 && zo <= d.Z - 2;
     float pfc = 0.0f, pnx = 0.0f, pny = 0.0f, pnz = 0.0f, pu0 = 0.0f, pu1 = 0.0f, pu2 = 0.0f;
-    if (out_act) {
-      const int zq = max(zo, 1);
-      const float* fp = flags + (long long)zq * d.sz;
-      const float a = fp[o_safe], bq = fp[o_safe - 1], cq = fp[o_safe - d.sy], dq = fp[o_safe - d.sz];
-      pfc = out_inner ? a : 0.0f; pnx = out_inner ? bq : 0.0f; pny = out_inner ? cq : 0.0f; pnz = out_inner ? dq : 0.0f;
+    // (round 6) the flags of plane zo were asked for a step ago (fn[]: the cell, its -x, its -y neighbour); the -z neighbour's is
+    // the cell's own flag of the plane before (fzc: carried). This step asks for plane zo + 1's.
+    if (out_act) { pfc = out_inner ? fn[0] : 0.0f; pnx = out_inner ? fn[1] : 0.0f; pny = out_inner ? fn[2] : 0.0f; pnz = out_inner ? fzc : 0.0f; }
+    if (STEADY || (zo + 1 >= za && zo + 1 < zb)) {      // block-uniform
+      fzc = fn[0];
+      const float* fp = flags + (long long)min(max(zo + 1, 0), d.Z - 1) * d.sz;
+      fn[0] = fp[o_safe]; fn[1] = fp[o_safe - 1]; fn[2] = fp[o_safe - d.sy];
     }
     // the queue advances: plane t (asked for during step t - 1) enters at the back, plane t - 6 is at the front
 #pragma unroll
@@ -873,6 +876,7 @@ __global__ __launch_bounds__(BX * BY) void k_vort_pipe(Dom d, int cols_x, int co
       if (q == 3) { oq[6][0] = bxp[o_xy]; oq[6][1] = byp[o_xy]; oq[6][2] = bzp[o_xy]; }      // plane za's own cell: enters the queue's back
     }
     load_plane(za + 1);
+    fn[0] = flags[(long long)min(max(za - 1, 0), d.Z - 1) * d.sz + o_safe];      // becomes fzc when the step before the first store asks for plane za's flags
 #pragma unroll
     for (int q = 0; q < 3; q++) {
       const int pz = t0 + q;
