@@ -472,7 +472,7 @@ int tfl_vorticityConfinementFrom(tfl_ctx* c, const tfl_tensor* USrc, const tfl_t
     return fail(c, TFL_EINVAL, "vorticityConfinementFrom: curl must be a 3-channel grid of the flags size");
   TRY(check_scalar(c, "vorticityConfinementFrom", "curlNorm", curlNorm, flags));
   WindowScope win(c);
-  if (is3D && !c->vort_from_two_launch && tfl::vorticity_confinement_fused_ok(true, flags->Z, (long long)flags->Z * flags->Y * flags->X) &&
+  if (is3D && !c->vort_from_two_launch && tfl::vorticity_confinement_fused_ok(true, flags->Z, flags->Y, flags->X) &&
       tfl::vorticity_confinement_fused(c->stream, flags->B, flags->Z, flags->Y, flags->X, USrc->data, U->data, flags->data, strength))
     return check_launch(c, "vorticityConfinementFrom");
   // 2-D, a grid below the fused kernel's size, or TFL_VORT_FUSED=0: the two launches read USrc and write U (round 5) ...

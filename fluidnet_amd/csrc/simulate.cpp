@@ -254,7 +254,7 @@ int tfl_simulate_step(tfl_ctx* c, const tfl_sim_params* prm, const tfl_sim_state
   // confinement (tfl_vorticityConfinementFrom: the fused kernel cannot run in place anyway, the two-launch form reads one
   // array and writes the other since round 5) or the ConvNet projection (UDiv = cur, UOut = U); a copy only where none does.
   const bool vort = prm->vorticityConfinementAmp > 0.0;
-  const bool vfused = vort && tfl::vorticity_confinement_fused_ok(is3D != 0, (int)z.Z, z.N / z.B);
+  const bool vfused = vort && tfl::vorticity_confinement_fused_ok(is3D != 0, (int)z.Z, (int)z.Y, (int)z.X);
   // scratch of the vorticity operator (curl[3] | cnorm) = the advectVel `fwd` / `bwd` planes, dead after the advection. It must
   // not touch `Uadv` (planes 2C .. 3C of the workspace): the two-launch confinement may still read its velocity from there.
   // 3-D: curl on the `bwd` planes and |curl| behind `Uadv` -- disjoint from the scratch velocity `Utmp` below as well,
@@ -803,7 +803,7 @@ int tfl_simulate_step_slab(tfl_ctx* c, const tfl_sim_params* prm, const tfl_sim_
   (void)tfl_set_stages(c, 0); (void)tfl_set_z_window(c, 0, 0, 0, 0);
   // as tfl_simulate_step: the fused vorticity confinement delivers into U, so buoyancy / gravity work on a scratch velocity
   const bool vort = prm->vorticityConfinementAmp > 0.0;
-  const bool vfused = vort && tfl::vorticity_confinement_fused_ok(true, g.Zl, (long long)g.Zl * g.yx);
+  const bool vfused = vort && tfl::vorticity_confinement_fused_ok(true, g.Zl, s->flags->Y, s->flags->X);
   tfl_tensor Utmp = view(cw + 4 * N, 3);                   // the scalar advection's bwdPos planes, dead by now
   const tfl_tensor* cur = &Uadv;
   if (!buoyant && !vfused) { rc = tfl_copy(c, s->U, &Uadv); if (rc) return rc; cur = s->U; }

@@ -157,7 +157,7 @@ bool vorticity_confinement(hipStream_t st, bool is3d, int B, int Z, int Y, int X
                            float strength, float* curl, float* curl_norm, int stages = 3, const float* Usrc = nullptr);
 
 // U_out = U_in + confinement(U_in), 3-D, one fused launch without curl arrays (U_out != U_in); false = not supported here
-bool vorticity_confinement_fused_ok(bool is3d, int Z, long long cells_per_item);   // does the native step use the fused kernel for this grid
+bool vorticity_confinement_fused_ok(bool is3d, int Z, int Y, int X);   // does the native step use the fused kernel for this grid
 bool vorticity_confinement_fused(hipStream_t st, int B, int Z, int Y, int X, const float* Uin, float* Uout, const float* flags,
                                  float strength);
 

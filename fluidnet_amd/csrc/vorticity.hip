@@ -999,13 +999,20 @@ static bool launch_vort_pipe(hipStream_t st, const Dom& d, int B, int X, int Y, 
 // ran slow that day -- never a loss. So: k_vort_pipe from 2 M cells per batch item on, on arrays at least 32 planes deep (round 6: a
 // z-slab rank's 40-plane array of 256^3 on 8 ranks was measured too -- 35.8 us against 40.7, the rank-step 0.293 -> 0.279 ms);
 // where the device cannot hold the pipelined kernel's block, k_vort_fused from 3 M cells (160^3: 69 / 80).
-bool vorticity_confinement_fused_ok(bool is3d, int Z, long long cells) {
+bool vorticity_confinement_fused_ok(bool is3d, int Z, int Y, int X) {
   static const int mode = getenv("TFL_VORT_FUSED") ? atoi(getenv("TFL_VORT_FUSED")) : -1;
   static const int pipe_mode = getenv("TFL_VORT_PIPE") ? atoi(getenv("TFL_VORT_PIPE")) : -1;
   if (!is3d || Z < 3 || mode == 0) return false;
+  const long long cells = (long long)Z * Y * X;
   const bool pipe = pipe_mode != 0 && vort_pipe_slots() > 0;
   if (mode == 1) return pipe || vort_fused_slots() > 0;
   if (pipe && cells >= 2000000ll && Z >= 32) return true;      // (round 6: a 40-plane slab of 256^3 on 8 ranks: 35.8 us against 40.7 for the two launches)
+  // round 6, after the kernel's prologue: planes that fill the 64 x 16 tiles exactly, from 0.6 M cells on -- the z-slab ranks of
+  // the metric's 128^3 series: 36-40 planes on 4 ranks (rank-step 0.115 -> 0.112 / 0.121 -> 0.118 ms), 68 planes on 2 (0.169 ->
+  // 0.159: one launch less, and k_bcs_div_stats runs 12.7 -> 9.1 us behind this kernel); 24 planes on 8 ranks stay with the two
+  // launches (0.094 / 0.095). Whole grids with ragged tiles keep the 2 M rule (80^3 0.1240 / 0.1253 ms, 96^3 0.1537 / 0.1542,
+  // 112^3 0.2114 / 0.2084 two launches / fused).
+  if (pipe && cells >= 600000ll && Z >= 32 && X % PipeGeo<64, 16>::PBX == 0 && Y % PipeGeo<64, 16>::PBY == 0) return true;
   return cells >= 3000000ll && (pipe || vort_fused_slots() > 0);
 }
 
