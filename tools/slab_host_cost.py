@@ -131,14 +131,19 @@ def run(rank, graph):
             torch.cuda.synchronize()
             reps.append((time.perf_counter() - t0) / 40)
         t_restore = min(reps)
-    n = 200
-    host[0] = 0.0
-    t0 = time.perf_counter()
-    for _ in range(n):
-        one_step()
-    t_host = host[0] / n
-    torch.cuda.synchronize()
-    t_all = (time.perf_counter() - t0) / n - t_restore
+    # the fastest of five blocks of 60 steps: one pause of the box (a scheduler hiccup of 50-100 ms on these shared hosts showed
+    # up as a rank-step of 0.3-0.5 ms in a single 200-step block) must not go into either figure
+    n, hosts, walls = 60, [], []
+    for _ in range(5):
+        host[0] = 0.0
+        t0 = time.perf_counter()
+        for _ in range(n):
+            one_step()
+        hosts.append(host[0] / n)
+        torch.cuda.synchronize()
+        walls.append((time.perf_counter() - t0) / n)
+    t_host = min(hosts)
+    t_all = min(walls) - t_restore
     how = ("HIP graph, %d nodes" % sim.graph_nodes) if sim.graph is not None else ("eager" + (" (graph refused: %s)" % sim.graph_error if sim.graph_error else ""))
     print("res %d, rank %d of %d (%d planes), %s: host %.3f ms per step() call, rank-step %.3f ms (wall per step with the GPU drained, minus %.3f ms of the tool's restore copies)"
           % (res, rank, world, lay.hi - lay.lo, how, t_host * 1e3, t_all * 1e3, t_restore * 1e3))
