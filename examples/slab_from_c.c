@@ -12,13 +12,23 @@
  *   gcc -std=c99 -D__HIP_PLATFORM_AMD__ examples/slab_from_c.c -Iinclude -I/opt/rocm/include -Lfluidnet_amd -ltfluids_hip \
  *       -L/opt/rocm/lib -lamdhip64 -lm -lpthread -Wl,-rpath,$PWD/fluidnet_amd -Wl,-rpath,/opt/rocm/lib -o /tmp/slab_from_c
  *   TFL_RCCL_LIBRARY=/path/to/libstub_rccl.so /tmp/slab_from_c
+ *
+ * `slab_from_c --processes` (round 6) is the same two-rank run as a real node does it: one PROCESS per rank, the REAL librccl
+ * (no TFL_RCCL_LIBRARY), the communicator's unique id handed from rank 0 to rank 1 through a file. With two GPUs in the box each
+ * rank takes its own; with one, both ranks share device 0 and each process is started under its own NCCL_HOSTID, so that RCCL
+ * takes them for two hosts (its "Duplicate GPU detected" test compares host hash and bus id) and carries the messages through
+ * its socket transport over the loopback interface. Every rank checks its owned planes against the un-cut step itself.
  */
+#define _DEFAULT_SOURCE      /* mkdtemp, usleep, setenv under -std=c99 */
 #include <hip/hip_runtime_api.h>
 #include <math.h>
 #include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/stat.h>
+#include <sys/wait.h>
+#include <unistd.h>
 
 #include "tfluids_hip.h"
 
@@ -117,12 +127,12 @@ static int make_dev(tfl_ctx* ctx, const HostState* h, int lo, int hi, tfl_model*
   return 0;
 }
 
-typedef struct { int rank; const HostState* h; const char* uid; float* owned[3]; int rc; char err[512]; } RankArg;
+typedef struct { int rank; const HostState* h; const char* uid; float* owned[3]; int rc; char err[512]; int device; } RankArg;
 
 static void* rank_main(void* vp) {
   RankArg* a = vp;
   a->rc = 1;
-  tfl_ctx* ctx = tfl_create(0);
+  tfl_ctx* ctx = tfl_create(a->device);
   hipStream_t st = NULL;
   if (!ctx || hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { snprintf(a->err, sizeof a->err, "tfl_create / stream"); return NULL; }
   tfl_set_stream(ctx, st);
@@ -161,26 +171,112 @@ static double rel_l2(const float* a, const float* b, size_t n) {
   return sqrt(num) / (sqrt(den) > 1e-30 ? sqrt(den) : 1e-30);
 }
 
-int main(void) {
-  if (!getenv("TFL_RCCL_LIBRARY")) { fprintf(stderr, "set TFL_RCCL_LIBRARY to tests/stub_rccl.cpp built as a shared library (two ranks share one GPU here)\n"); return 3; }
+/* the un-cut run: STEPS steps of tfl_simulate_step on the whole grid; p, U, rho back on the host */
+static int run_uncut(tfl_ctx* ctx, const HostState* h, tfl_model** model, DevState* g, float* rp, float* rU, float* rr) {
+  *model = make_model(ctx);
+  if (!*model || make_dev(ctx, h, 0, Z, *model, g)) { fprintf(stderr, "set-up: %s\n", tfl_last_error(ctx)); return 5; }
+  tfl_sim_params prm; set_params(&prm);
+  const long long nws = (long long)tfl_simulate_workspace_floats(ctx, &prm, &g->st);
+  float* ws = dev_alloc((size_t)nws);
+  for (int s = 0; s < STEPS; s++)
+    if (tfl_simulate_step(ctx, &prm, &g->st, ws, nws) != 0) { fprintf(stderr, "tfl_simulate_step: %s\n", tfl_last_error(ctx)); return 6; }
+  tfl_synchronize(ctx);
+  const size_t N = (size_t)Z * YX;
+  (void)hipMemcpy(rp, g->p.data, N * 4, hipMemcpyDeviceToHost); (void)hipMemcpy(rU, g->U.data, 3 * N * 4, hipMemcpyDeviceToHost);
+  (void)hipMemcpy(rr, g->rho.data, N * 4, hipMemcpyDeviceToHost);
+  return 0;
+}
+
+/* worst rel-L2 of a rank's owned planes (p, the three components of U, rho) against the un-cut fields */
+static double owned_error(const RankArg* a, const float* rp, const float* rU, const float* rr) {
+  const int per = Z / WORLD;
+  const size_t N = (size_t)Z * YX, n = (size_t)per * YX, off = (size_t)a->rank * per * YX;
+  double e = rel_l2(a->owned[0], rp + off, n);
+  for (int c = 0; c < 3; c++) { const double ec = rel_l2(a->owned[1] + c * n, rU + c * N + off, n); if (ec > e) e = ec; }
+  const double er = rel_l2(a->owned[2], rr + off, n);
+  return er > e ? er : e;
+}
+
+/* ---- `--rank r dir`: one rank of the process mode -------------------------------------------------------------------- */
+static int rank_process(int rank, const char* dir) {
+  HostState h; make_state(&h);
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { fprintf(stderr, "rank %d: no GPU\n", rank); return 3; }
+  const int dev = ndev >= WORLD ? rank : 0;
+  tfl_ctx* ctx = tfl_create(dev);
+  if (!ctx) { fprintf(stderr, "rank %d: tfl_create failed\n", rank); return 3; }
+  char uid[TFL_RCCL_UNIQUE_ID_BYTES], path[1024], tmp[1100];
+  snprintf(path, sizeof path, "%s/uid", dir); snprintf(tmp, sizeof tmp, "%s.tmp", path);
+  if (rank == 0) {                      /* the id is made by ONE rank and handed to the others: here through a file */
+    if (tfl_rccl_get_unique_id(ctx, uid) != 0) { fprintf(stderr, "tfl_rccl_get_unique_id: %s\n", tfl_last_error(ctx)); return 7; }
+    FILE* f = fopen(tmp, "wb");
+    if (!f || fwrite(uid, 1, sizeof uid, f) != sizeof uid) { fprintf(stderr, "rank 0: cannot write %s\n", tmp); return 7; }
+    fclose(f); rename(tmp, path);
+  } else {
+    FILE* f = NULL;
+    for (int t = 0; t < 1200 && !(f = fopen(path, "rb")); t++) usleep(50000);
+    if (!f || fread(uid, 1, sizeof uid, f) != sizeof uid) { fprintf(stderr, "rank %d: no unique id from rank 0\n", rank); return 7; }
+    fclose(f);
+  }
+  RankArg a; memset(&a, 0, sizeof a);
+  a.rank = rank; a.h = &h; a.uid = uid; a.device = dev;
+  rank_main(&a);
+  if (a.rc) { fprintf(stderr, "rank %d failed: %s\n", rank, a.err); return 8; }
+  const size_t N = (size_t)Z * YX;
+  float *rp = malloc(N * 4), *rU = malloc(3 * N * 4), *rr = malloc(N * 4);
+  tfl_model* model; DevState g;
+  const int rc = run_uncut(ctx, &h, &model, &g, rp, rU, rr);
+  if (rc) return rc;
+  const double e = owned_error(&a, rp, rU, rr);
+  printf("process %d of %d (device %d, %s): owned planes against the un-cut step after %d steps over %s: rel-L2 %.3e\n", rank, WORLD, dev,
+         ndev >= WORLD ? "one GPU per rank" : "ranks share the GPU", STEPS, tfl_rccl_comm_origin(ctx), e);
+  return e <= 1e-7 ? 0 : 9;
+}
+
+/* ---- `--processes`: start the ranks, wait for them ------------------------------------------------------------------- */
+static int run_processes(const char* self) {
+  char dir[] = "/tmp/slab_from_c.XXXXXX";
+  if (!mkdtemp(dir)) { perror("mkdtemp"); return 3; }
+  int ndev = 0;
+  pid_t pid[WORLD];
+  for (int r = 0; r < WORLD; r++) {
+    pid[r] = fork();                      /* (no HIP call has been made in this process: the children start clean) */
+    if (pid[r] == 0) {
+      char rs[16], host[64];
+      snprintf(rs, sizeof rs, "%d", r); snprintf(host, sizeof host, "slab-from-c-rank%d", r);
+      unsetenv("TFL_RCCL_LIBRARY");       /* the real library */
+      setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0", 0);
+      if (!getenv("SLAB_FROM_C_ONE_GPU_PER_RANK")) {      /* harmless with one GPU per rank too: RCCL then uses its network transport */
+        setenv("NCCL_HOSTID", host, 1); setenv("NCCL_SOCKET_IFNAME", "lo", 0); setenv("NCCL_IB_DISABLE", "1", 0);
+      }
+      execl(self, self, "--rank", rs, dir, (char*)NULL);
+      perror("execl"); _exit(127);
+    }
+  }
+  (void)ndev;
+  int bad = 0;
+  for (int r = 0; r < WORLD; r++) {
+    int stw = 0;
+    if (waitpid(pid[r], &stw, 0) < 0 || !WIFEXITED(stw) || WEXITSTATUS(stw) != 0) { fprintf(stderr, "process of rank %d ended with status 0x%x\n", r, stw); bad = 1; }
+  }
+  printf(bad ? "FAILED\n" : "OK (two processes over the real RCCL)\n");
+  return bad ? 9 : 0;
+}
+
+int main(int argc, char** argv) {
+  if (argc >= 2 && strcmp(argv[1], "--processes") == 0) return run_processes(argv[0]);
+  if (argc >= 4 && strcmp(argv[1], "--rank") == 0) return rank_process(atoi(argv[2]), argv[3]);
+  if (!getenv("TFL_RCCL_LIBRARY")) { fprintf(stderr, "set TFL_RCCL_LIBRARY to tests/stub_rccl.cpp built as a shared library (two ranks share one GPU here), or run `--processes`\n"); return 3; }
   HostState h; make_state(&h);
   tfl_ctx* ctx = tfl_create(0);
   if (!ctx) { fprintf(stderr, "tfl_create failed (no GPU?)\n"); return 3; }
   if (tfl_abi_version() != TFL_ABI_VERSION) { fprintf(stderr, "ABI mismatch\n"); return 4; }
   /* ---- the un-cut run ------------------------------------------------------------------------------------------ */
-  tfl_model* model = make_model(ctx);
-  DevState g;
-  if (!model || make_dev(ctx, &h, 0, Z, model, &g)) { fprintf(stderr, "set-up: %s\n", tfl_last_error(ctx)); return 5; }
-  tfl_sim_params prm; set_params(&prm);
-  const long long nws = (long long)tfl_simulate_workspace_floats(ctx, &prm, &g.st);
-  float* ws = dev_alloc((size_t)nws);
-  for (int s = 0; s < STEPS; s++)
-    if (tfl_simulate_step(ctx, &prm, &g.st, ws, nws) != 0) { fprintf(stderr, "tfl_simulate_step: %s\n", tfl_last_error(ctx)); return 6; }
-  tfl_synchronize(ctx);
   const size_t N = (size_t)Z * YX;
   float *rp = malloc(N * 4), *rU = malloc(3 * N * 4), *rr = malloc(N * 4);
-  (void)hipMemcpy(rp, g.p.data, N * 4, hipMemcpyDeviceToHost); (void)hipMemcpy(rU, g.U.data, 3 * N * 4, hipMemcpyDeviceToHost);
-  (void)hipMemcpy(rr, g.rho.data, N * 4, hipMemcpyDeviceToHost);
+  tfl_model* model; DevState g;
+  { const int rc0 = run_uncut(ctx, &h, &model, &g, rp, rU, rr); if (rc0) return rc0; }
+  tfl_sim_params prm; set_params(&prm);
   /* ---- the two ranks ---------------------------------------------------------------------------------------------- */
   char uid[TFL_RCCL_UNIQUE_ID_BYTES];
   if (tfl_rccl_get_unique_id(ctx, uid) != 0) { fprintf(stderr, "tfl_rccl_get_unique_id: %s\n", tfl_last_error(ctx)); return 7; }
@@ -191,11 +287,7 @@ int main(void) {
   double worst = 0.0;
   for (int r = 0; r < WORLD; r++) {
     if (ra[r].rc) { fprintf(stderr, "rank %d failed: %s\n", r, ra[r].err); return 8; }
-    const size_t n = (size_t)per * YX, off = (size_t)r * per * YX;
-    double e = rel_l2(ra[r].owned[0], rp + off, n);
-    for (int c = 0; c < 3; c++) { const double ec = rel_l2(ra[r].owned[1] + c * n, rU + c * N + off, n); if (ec > e) e = ec; }
-    const double er = rel_l2(ra[r].owned[2], rr + off, n);
-    if (er > e) e = er;
+    const double e = owned_error(&ra[r], rp, rU, rr);
     printf("rank %d of %d: owned planes [%d, %d) against the un-cut step after %d steps: rel-L2 %.3e\n", r, WORLD, r * per, (r + 1) * per, STEPS, e);
     if (e > worst) worst = e;
   }

@@ -94,6 +94,20 @@ def test_plain_c_multi_rank_host_runs(lib_path, tmp_path):
     assert out.returncode == 0 and out.stdout.strip().endswith("OK"), out.stdout + out.stderr
 
 
+@pytest.mark.gpu
+def test_plain_c_multi_process_host_runs_over_the_real_rccl(lib_path, tmp_path):
+    """`slab_from_c --processes` (round 6): one C PROCESS per rank, no Python and no stand-in -- the library's native transport
+    binds the real librccl, the unique id travels through a file, and each rank checks its owned planes against the un-cut step.
+    With one GPU the two processes share it under their own NCCL_HOSTID (RCCL's socket transport, tests/test_rccl_multiproc.py);
+    with two, each rank takes its own."""
+    env = {k: v for k, v in os.environ.items() if k not in ("TFL_RCCL_LIBRARY", "STUB_RCCL_NULL")}
+    out = subprocess.run([_build_c_slab_example(tmp_path), "--processes"], env=env, capture_output=True, text=True, timeout=600)
+    if "tfl_rccl_comm_create" in out.stderr and ("ncclCommInitRank" in out.stderr or "rccl transport" in out.stderr):
+        pytest.skip("RCCL could not initialise between processes here: " + out.stderr.strip().splitlines()[-1])
+    assert out.returncode == 0 and "OK (two processes over the real RCCL)" in out.stdout, out.stdout + out.stderr
+    assert out.stdout.count("rel-L2") == 2
+
+
 def test_plain_c_host_links_against_the_abi(lib_path, tmp_path):
     """A C99 translation unit that includes only tfluids_hip.h compiles (gcc, not hipcc) and links: the boundary
     has no C++/torch types in it (what a cgo / JNI / LuaJIT-FFI binding relies on)."""
