@@ -42,7 +42,7 @@ def test_slab_steps_over_real_rccl(tmp_path, world):
     outs = []
     try:
         for p in procs:
-            outs.append(p.communicate(timeout=600)[0])
+            outs.append(p.communicate(timeout=240)[0])      # (a healthy run takes 10-20 s)
     finally:
         for p in procs:
             if p.poll() is None:
