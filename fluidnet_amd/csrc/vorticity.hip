@@ -702,7 +702,6 @@ __global__ __launch_bounds__(BX * BY) void k_vort_pipe(Dom d, int cols_x, int co
   };
 
   float nl[2][5];                     // the loads of the plane one step ahead: u_x(p), u_x(p + x), u_y(p), u_y(p + y), u_z(p)
-  float on[3] = {0.0f, 0.0f, 0.0f};   // ... and the thread's own cell of that plane (see oq below)
   auto load_plane = [&](int t) {
     const float* bxp = Uin + (long long)min(max(t, 0), d.Z - 1) * d.sz;
     const float* byp = bxp + d.sc;
@@ -712,17 +711,13 @@ __global__ __launch_bounds__(BX * BY) void k_vort_pipe(Dom d, int cols_x, int co
       if (r == 1 && !two_st) continue;
       nl[r][0] = bxp[st_o[r]]; nl[r][1] = bxp[st_ox[r]]; nl[r][2] = byp[st_o[r]]; nl[r][3] = byp[st_oy[r]]; nl[r][4] = bzp[st_o[r]];
     }
-    on[0] = bxp[o_xy]; on[1] = byp[o_xy]; on[2] = bzp[o_xy];
   };
   const int t0 = za - 3, t1 = zb + 5;
   float cxp[2] = {0.0f, 0.0f}, cyp[2] = {0.0f, 0.0f}, uzp[2] = {0.0f, 0.0f};   // c_x, c_y, u_z of plane t - 1 at the top of step t
-  // the thread's OWN velocities travel in registers from the step that stages their plane to the step that stores it (seven
-  // steps later the lines have left the XCD's L2: read again at the store they were 12 of the kernel's 43 B/cell at 256^3):
-  // oq[i] = plane t - 6 + i at the out stage of step t, on[] = plane t + 1 (asked for during step t)
-  float oq[7][3];
-#pragma unroll
-  for (int q = 0; q < 7; q++) { oq[q][0] = 0.0f; oq[q][1] = 0.0f; oq[q][2] = 0.0f; }
-  float fn[3] = {0.0f, 0.0f, 0.0f}, fzc = 0.0f;      // flags of the out stage's NEXT plane (cell, -x, -y) and the cell's own of the plane before it
+  // the store stage's inputs of its NEXT plane, asked for a step ahead: the flags of the cell, its -x and its -y neighbour, and the
+  // thread's own velocities (un[]; round 5 carried those in a 7-deep register queue from the staging step -- 21 registers and
+  // 21 moves per step); fzc = the cell's own flag of the plane before (the -z neighbour's)
+  float fn[3] = {0.0f, 0.0f, 0.0f}, fzc = 0.0f, un[3] = {0.0f, 0.0f, 0.0f};
   v3 fcar = mk3(0.0f, 0.0f, 0.0f);    // the thread's force of plane t - 6 (computed in step t - 1)
   float fzcar = 0.0f;                 // force.z of plane t - 7
   int cv3 = ((t0 - 3) % 3 + 3) % 3;   // (zc % 3) of this step's curl plane, kept as a counter
@@ -739,16 +734,15 @@ __global__ __launch_bounds__(BX * BY) void k_vort_pipe(Dom d, int cols_x, int co
     // (round 6) the flags of plane zo were asked for a step ago (fn[]: the cell, its -x, its -y neighbour); the -z neighbour's is
     // the cell's own flag of the plane before (fzc: carried). This step asks for plane zo + 1's.
     if (out_act) { pfc = out_inner ? fn[0] : 0.0f; pnx = out_inner ? fn[1] : 0.0f; pny = out_inner ? fn[2] : 0.0f; pnz = out_inner ? fzc : 0.0f; }
+    pu0 = un[0]; pu1 = un[1]; pu2 = un[2];
     if (STEADY || (zo + 1 >= za && zo + 1 < zb)) {      // block-uniform
       fzc = fn[0];
-      const float* fp = flags + (long long)min(max(zo + 1, 0), d.Z - 1) * d.sz;
+      const long long pz = (long long)min(max(zo + 1, 0), d.Z - 1) * d.sz;
+      const float* fp = flags + pz;
       fn[0] = fp[o_safe]; fn[1] = fp[o_safe - 1]; fn[2] = fp[o_safe - d.sy];
+      const float* up = Uin + pz;
+      un[0] = up[o_xy]; un[1] = up[d.sc + o_xy]; un[2] = up[2 * d.sc + o_xy];
     }
-    // the queue advances: plane t (asked for during step t - 1) enters at the back, plane t - 6 is at the front
-#pragma unroll
-    for (int q = 0; q < 6; q++) { oq[q][0] = oq[q + 1][0]; oq[q][1] = oq[q + 1][1]; oq[q][2] = oq[q + 1][2]; }
-    oq[6][0] = on[0]; oq[6][1] = on[1]; oq[6][2] = on[2];
-    pu0 = oq[0][0]; pu1 = oq[0][1]; pu2 = oq[0][2];
     // ---- centred velocities of plane t - 1 -> ring; then ask for plane t + 1 ----
     if (STEADY || t <= zb + 2) {        // block-uniform
       const bool zsh = t - 1 <= 0 || t - 1 >= d.Z - 1;
@@ -873,7 +867,6 @@ __global__ __launch_bounds__(BX * BY) void k_vort_pipe(Dom d, int cols_x, int co
         if (r == 1 && !two_st) continue;
         pl[q][r][0] = bxp[st_o[r]]; pl[q][r][1] = bxp[st_ox[r]]; pl[q][r][2] = byp[st_o[r]]; pl[q][r][3] = byp[st_oy[r]]; pl[q][r][4] = bzp[st_o[r]];
       }
-      if (q == 3) { oq[6][0] = bxp[o_xy]; oq[6][1] = byp[o_xy]; oq[6][2] = bzp[o_xy]; }      // plane za's own cell: enters the queue's back
     }
     load_plane(za + 1);
     fn[0] = flags[(long long)min(max(za - 1, 0), d.Z - 1) * d.sz + o_safe];      // becomes fzc when the step before the first store asks for plane za's flags
