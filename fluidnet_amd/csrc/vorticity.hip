@@ -594,6 +594,22 @@ __global__ __launch_bounds__(512) void k_vort_fused(Dom d, int cols_x, int cols_
 // DIFFERENT waves (9-15 / 0-3 / 4-5). Pipeline fill: 9 steps per chunk (6). Per-cell arithmetic is k_curl / k_confine's,
 // operation for operation: bit-equal to the two-launch form (tests/test_hip_parity.py).
 namespace {
+// k_vort_pipe's global accesses are BUFFER loads / stores: resource (the batch item's array) + the lane's 32-bit byte offset, fixed
+// for the whole march, + the plane's byte offset in a scalar register. Written as pointers, the loop optimiser turns "moving
+// base + fixed lane offset" into one 64-bit pointer PER LANE and advances it every step -- a v_lshl_add_u64 per access, 25 per
+// step (round 6). An item's array must stay below 4 GiB (launch_vort_pipe checks).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t gbuf(const void* p, long long bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)(unsigned)bytes, 0x00020000);
+}
+__device__ __forceinline__ float ldb(__amdgpu_buffer_rsrc_t r, unsigned lane_off, unsigned plane_off) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)lane_off, (int)plane_off, 0));
+}
+__device__ __forceinline__ void stb(__amdgpu_buffer_rsrc_t r, unsigned lane_off, unsigned plane_off, float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)lane_off, (int)plane_off, 0);
+}
+}  // namespace
+
+namespace {
 // a block = BX x BY cells (one thread each) x a chunk of z. 64 x 16: 1024 threads, 153 428 bytes of LDS, one block per CU;
 // 32 x 16 (round 6): 512 threads, 80 852 bytes -- TWO blocks per CU, whose barrier and load waits overlap
 template <int BX, int BY>
@@ -684,6 +700,12 @@ __global__ __launch_bounds__(BX * BY) void k_vort_pipe(Dom d, int cols_x, int co
   const bool out_xy = i < d.X && j < d.Y;
   const int o_xy = TFL_AT(d, min(i, d.X - 1), min(j, d.Y - 1), 0);
   const int o_safe = o_xy + (i >= 1 ? 0 : 1) + (j >= 1 ? 0 : d.sy);      // a cell whose -x / -y neighbours exist
+  // the same as byte offsets of the lane inside a plane, and the arrays as buffer resources (see ldb / stb above)
+  const unsigned st_o4[2] = {(unsigned)st_o[0] * 4u, (unsigned)st_o[1] * 4u}, st_ox4[2] = {(unsigned)st_ox[0] * 4u, (unsigned)st_ox[1] * 4u};
+  const unsigned st_oy4[2] = {(unsigned)st_oy[0] * 4u, (unsigned)st_oy[1] * 4u};
+  const unsigned o_xy4 = (unsigned)o_xy * 4u, o_safe4 = (unsigned)o_safe * 4u, o_safe_x4 = (unsigned)(o_safe - 1) * 4u, o_safe_y4 = (unsigned)(o_safe - d.sy) * 4u;
+  const unsigned sc4 = (unsigned)d.sc * 4u, sz4 = (unsigned)d.sz * 4u;
+  const __amdgpu_buffer_rsrc_t rU = gbuf(Uin, cells * 12), rF = gbuf(flags, cells * 4), wU = gbuf(Uout, cells * 12);
   // the setConstVals that follows the forces in simulate() (tfl_host.hpp BcFold): only the blocks whose rows and planes can
   // touch the pair's box read the descriptor (for the plume's pair 1 block in 16-32)
   const bool fold_blk = fold_block(folda, y0, y0 + PBY - 1, za, zb - 1);
@@ -703,13 +725,12 @@ __global__ __launch_bounds__(BX * BY) void k_vort_pipe(Dom d, int cols_x, int co
 
   float nl[2][5];                     // the loads of the plane one step ahead: u_x(p), u_x(p + x), u_y(p), u_y(p + y), u_z(p)
   auto load_plane = [&](int t) {
-    const float* bxp = Uin + (long long)min(max(t, 0), d.Z - 1) * d.sz;
-    const float* byp = bxp + d.sc;
-    const float* bzp = byp + d.sc;
+    const unsigned px = (unsigned)min(max(t, 0), d.Z - 1) * sz4, py = px + sc4, pzc = py + sc4;      // (scalar)
 #pragma unroll
     for (int r = 0; r < 2; r++) {
       if (r == 1 && !two_st) continue;
-      nl[r][0] = bxp[st_o[r]]; nl[r][1] = bxp[st_ox[r]]; nl[r][2] = byp[st_o[r]]; nl[r][3] = byp[st_oy[r]]; nl[r][4] = bzp[st_o[r]];
+      nl[r][0] = ldb(rU, st_o4[r], px); nl[r][1] = ldb(rU, st_ox4[r], px); nl[r][2] = ldb(rU, st_o4[r], py); nl[r][3] = ldb(rU, st_oy4[r], py);
+      nl[r][4] = ldb(rU, st_o4[r], pzc);
     }
   };
   const int t0 = za - 3, t1 = zb + 5;
@@ -737,11 +758,9 @@ __global__ __launch_bounds__(BX * BY) void k_vort_pipe(Dom d, int cols_x, int co
     pu0 = un[0]; pu1 = un[1]; pu2 = un[2];
     if (STEADY || (zo + 1 >= za && zo + 1 < zb)) {      // block-uniform
       fzc = fn[0];
-      const long long pz = (long long)min(max(zo + 1, 0), d.Z - 1) * d.sz;
-      const float* fp = flags + pz;
-      fn[0] = fp[o_safe]; fn[1] = fp[o_safe - 1]; fn[2] = fp[o_safe - d.sy];
-      const float* up = Uin + pz;
-      un[0] = up[o_xy]; un[1] = up[d.sc + o_xy]; un[2] = up[2 * d.sc + o_xy];
+      const unsigned pz = (unsigned)min(max(zo + 1, 0), d.Z - 1) * sz4;      // (scalar)
+      fn[0] = ldb(rF, o_safe4, pz); fn[1] = ldb(rF, o_safe_x4, pz); fn[2] = ldb(rF, o_safe_y4, pz);
+      un[0] = ldb(rU, o_xy4, pz); un[1] = ldb(rU, o_xy4, pz + sc4); un[2] = ldb(rU, o_xy4, pz + 2u * sc4);
     }
     // ---- centred velocities of plane t - 1 -> ring; then ask for plane t + 1 ----
     if (STEADY || t <= zb + 2) {        // block-uniform
@@ -834,8 +853,8 @@ __global__ __launch_bounds__(BX * BY) void k_vort_pipe(Dom d, int cols_x, int co
         u0 = fq ? g0 : u0; u1 = fq ? g1 : u1; u2 = fq ? g2 : u2;
       }
       if (out_live) {
-        float* op = Uout + (long long)zo * d.sz;
-        op[o_xy] = u0; op[o_xy + d.sc] = u1; op[o_xy + 2 * d.sc] = u2;
+        const unsigned po = (unsigned)zo * sz4;      // (scalar)
+        stb(wU, o_xy4, po, u0); stb(wU, o_xy4, po + sc4, u1); stb(wU, o_xy4, po + 2u * sc4, u2);
       }
     }
     // ---- rotate the registers that travel with the planes ----
@@ -859,17 +878,16 @@ __global__ __launch_bounds__(BX * BY) void k_vort_pipe(Dom d, int cols_x, int co
     float pl[4][2][5];
 #pragma unroll
     for (int q = 0; q < 4; q++) {
-      const float* bxp = Uin + (long long)min(max(t0 + q, 0), d.Z - 1) * d.sz;
-      const float* byp = bxp + d.sc;
-      const float* bzp = byp + d.sc;
+      const unsigned px = (unsigned)min(max(t0 + q, 0), d.Z - 1) * sz4, py = px + sc4, pzc = py + sc4;
 #pragma unroll
       for (int r = 0; r < 2; r++) {
         if (r == 1 && !two_st) continue;
-        pl[q][r][0] = bxp[st_o[r]]; pl[q][r][1] = bxp[st_ox[r]]; pl[q][r][2] = byp[st_o[r]]; pl[q][r][3] = byp[st_oy[r]]; pl[q][r][4] = bzp[st_o[r]];
+        pl[q][r][0] = ldb(rU, st_o4[r], px); pl[q][r][1] = ldb(rU, st_ox4[r], px); pl[q][r][2] = ldb(rU, st_o4[r], py); pl[q][r][3] = ldb(rU, st_oy4[r], py);
+        pl[q][r][4] = ldb(rU, st_o4[r], pzc);
       }
     }
     load_plane(za + 1);
-    fn[0] = flags[(long long)min(max(za - 1, 0), d.Z - 1) * d.sz + o_safe];      // becomes fzc when the step before the first store asks for plane za's flags
+    fn[0] = ldb(rF, o_safe4, (unsigned)min(max(za - 1, 0), d.Z - 1) * sz4);      // becomes fzc when the step before the first store asks for plane za's flags
 #pragma unroll
     for (int q = 0; q < 3; q++) {
       const int pz = t0 + q;
@@ -975,6 +993,7 @@ static bool launch_vort_pipe(hipStream_t st, const Dom& d, int B, int X, int Y, 
   const int pcx = (X + BX - 1) / BX, pcy = (Y + BY - 1) / BY;
   const long long tiles = (long long)pcx * pcy * B;
   if (pslots <= 0 || tiles * (na + nb) <= 0) return false;
+  if ((long long)d.Z * Y * X * 12 >= (1ll << 32)) return false;      // the kernel addresses an item's array with 32-bit byte offsets (buffer accesses)
   int cz = march_chunk(tiles, na, nb, pslots, kPipeFill, 4);
   if (const char* e = exp_env("TFL_VORT_CZ")) cz = atoi(e) > 0 ? atoi(e) : cz;
   const int chunks_a = (na + cz - 1) / cz, chunks = chunks_a + (nb + cz - 1) / cz;
