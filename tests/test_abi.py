@@ -102,7 +102,7 @@ def test_plain_c_multi_process_host_runs_over_the_real_rccl(lib_path, tmp_path):
     with two, each rank takes its own."""
     env = {k: v for k, v in os.environ.items() if k not in ("TFL_RCCL_LIBRARY", "STUB_RCCL_NULL")}
     out = subprocess.run([_build_c_slab_example(tmp_path), "--processes"], env=env, capture_output=True, text=True, timeout=240)
-    if "tfl_rccl_comm_create" in out.stderr and ("ncclCommInitRank" in out.stderr or "rccl transport" in out.stderr):
+    if ("tfl_rccl_comm_create" in out.stderr and ("ncclCommInitRank" in out.stderr or "rccl transport" in out.stderr)) or "Duplicate GPU detected" in out.stderr:
         pytest.skip("RCCL could not initialise between processes here: " + out.stderr.strip().splitlines()[-1])
     assert out.returncode == 0 and "OK (two processes over the real RCCL)" in out.stdout, out.stdout + out.stderr
     assert out.stdout.count("rel-L2") == 2
