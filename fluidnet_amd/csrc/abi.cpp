@@ -1158,11 +1158,14 @@ int tfl_model_finish(tfl_ctx* c, tfl_model* m, const tfl_tensor* pDiv, const tfl
       }
     }
   }
-  if (stg & 8)
-    tfl::model_project(st, m->is3d, B, Z, Y, X, w.pPred, flags->data, st_in, count, UOut->data, pOut->data,
-                       UBC ? UBC->data : nullptr, UBC ? UBCInvMask->data : nullptr, doClamp, lo, hi,
-                       m->d_range_host ? m->d_range_err : nullptr, m->d_range_host,
-                       c->reach_sink ? c->d_reach : nullptr, c->reach_sink ? c->d_reach_host : nullptr);
+  if (stg & 8) {
+    const bool folded = tfl::model_project(st, m->is3d, B, Z, Y, X, w.pPred, flags->data, st_in, count, UOut->data, pOut->data,
+                                           UBC ? UBC->data : nullptr, UBC ? UBCInvMask->data : nullptr, doClamp, lo, hi,
+                                           m->d_range_host ? m->d_range_err : nullptr, m->d_range_host,
+                                           c->reach_sink ? c->d_reach : nullptr, c->reach_sink ? c->d_reach_host : nullptr,
+                                           c->reach_sink ? c->d_reach : nullptr);
+    if (c->reach_sink) c->reach_folded = folded;
+  }
   return check_launch(c, "model_finish");
 }
 

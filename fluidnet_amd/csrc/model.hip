@@ -403,6 +403,10 @@ struct BcArgs {  // optional fused tail of simulate(): setConstVals + clamp, sim
   // the z-slab step's reach word (sticky max|u_z|, device) and its mapped pinned mirror: the same thread copies it, every step
   // (round 6: an async 4-byte D2H copy on the stream blocks the host until the stream has drained on this stack)
   const float* reach_src; float* reach_dst;
+  // round 6: non-null = every block also folds max |u_z| of the cells it WRITES into that word (one atomic per block, and only
+  // where the block's maximum exceeds the word) -- the slab step's next reach check then needs no k_absmax launch of its own.
+  // Only in launches whose blocks are all full (model_project decides): the block reduction has no dead lanes to care for.
+  float* reach_acc;
 };
 // one thread of the launch forwards a non-zero count (the host word is only written when something went wrong)
 __device__ __forceinline__ void forward_range_count(const BcArgs& bc, bool first_thread) {
@@ -566,6 +570,20 @@ __global__ __launch_bounds__(256, TFL_LB_PROJECT) void k_project_v4(Dom d, const
 #pragma unroll
   for (int c = 0; c < 3; c++)
     if (c < C) *reinterpret_cast<float4*>(Uio + o + c * d.sc) = make_float4(u[c][0], u[c][1], u[c][2], u[c][3]);
+  if (IS3D && bc.reach_acc) {       // (kernel-uniform; every thread of the block is here: model_project)
+    float m = fmaxf(fmaxf(fabsf(u[2][0]), fabsf(u[2][1])), fmaxf(fabsf(u[2][2]), fabsf(u[2][3])));
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    __shared__ float wm[4];
+    const int tid = threadIdx.y * blockDim.x + threadIdx.x;
+    if ((tid & 63) == 0) wm[tid >> 6] = m;
+    __syncthreads();
+    if (tid == 0) {
+      const float bm = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
+      // (a stale read of the word can only be too LOW: one atomic more, never one less; non-negative floats order like their bits)
+      if (bm > *bc.reach_acc) atomicMax(reinterpret_cast<unsigned int*>(bc.reach_acc), __float_as_uint(bm));
+    }
+  }
 }
 
 // x = clamp(x * invMask + bc): setConstVals (+ the final U:clamp) of lib/simulate.lua:130-160,326
@@ -749,28 +767,33 @@ void model_skip_channel(hipStream_t st, int B, long long cells, const float* pDi
   k_skip_channel<<<dim3((unsigned)((cells + 255) / 256), (unsigned)B), 256, 0, st>>>(cells, pDiv, stats, count, dst, och, ch);
 }
 
-void model_project(hipStream_t st, bool is3d, int B, int Z, int Y, int X, const float* pPred, const float* flags,
+bool model_project(hipStream_t st, bool is3d, int B, int Z, int Y, int X, const float* pPred, const float* flags,
                    const double* stats, double count, float* Uio, float* pOut, const float* UBC, const float* UInvMask,
                    int do_clamp, float lo, float hi, const unsigned long long* range_src, unsigned long long* range_dst,
-                   const float* reach_src, float* reach_dst) {
+                   const float* reach_src, float* reach_dst, float* reach_acc) {
   const Dom d = make_dom(Z, Y, X);
   const dim3 blk(64, 4, 1), grd = TFL_GRID3(d, B);
   // a dense pair acts everywhere; without one, tfl_simulate_step's sparse pair (if it asked: tfl_host.hpp BcFold) in its box
   BcArgs bc; bc.enable_clamp = do_clamp; bc.lo = lo; bc.hi = hi;
   bc.range_src = range_dst ? range_src : nullptr; bc.range_dst = range_dst;
   bc.reach_src = reach_dst ? reach_src : nullptr; bc.reach_dst = reach_dst;
+  bc.reach_acc = nullptr;
   bc.UBC = UBC; bc.UInvMask = UInvMask; bc.fold = UBC ? no_fold() : take_fold();
   const uintptr_t al = (uintptr_t)pPred | (uintptr_t)flags | (uintptr_t)Uio | (uintptr_t)pOut | (uintptr_t)UBC |
                        (uintptr_t)UInvMask;
   if (X % 4 == 0 && (al & 15) == 0 && !exp_env("TFL_NO_VEC4")) {
     const dim3 vb(32, 8, 1), vg((X / 4 + 31) / 32, (Y + 7) / 8, (unsigned)(d.nw * B));
+    // the reach maximum rides along where every block of the launch is full (128 x 8 cells: no thread leaves the kernel early)
+    const bool acc = is3d && reach_acc && X % 128 == 0 && Y % 8 == 0;
+    if (acc) bc.reach_acc = reach_acc;
     TFL_TIMED_EXT("k_project", st);
     if (is3d) TFL_LAUNCH_EXT((k_project_v4<true>), vg, vb, 0, st, d, pPred, flags, stats, count, Uio, pOut, bc);
     else TFL_LAUNCH_EXT((k_project_v4<false>), vg, vb, 0, st, d, pPred, flags, stats, count, Uio, pOut, bc);
-    return;
+    return acc;
   }
   if (is3d) { TFL_TIMED("k_project", st); k_project<true><<<grd, blk, 0, st>>>(d, pPred, flags, stats, count, Uio, pOut, bc); }
   else { TFL_TIMED("k_project", st); k_project<false><<<grd, blk, 0, st>>>(d, pPred, flags, stats, count, Uio, pOut, bc); }
+  return false;
 }
 
 void apply_bcs(hipStream_t st, long long n, float* x, const float* bcv, const float* inv, int do_clamp, float lo,

@@ -586,7 +586,7 @@ bool reach_violated(tfl_ctx* c, float dt, int R, char* msg, size_t msg_len) {
   if (c->reach_n >= 2) (void)hipEventSynchronize(c->reach_ev[(c->reach_n - 2) & 3]);
   const float v = *(volatile float*)c->h_reach;
   if (!(v * dt >= (float)R)) return false;
-  snprintf(msg, msg_len, "simulate_step_slab: max|u_z|*dt = %.3f cells reached the slab's back-trace reach %d (found up to two steps after the fact: "
+  snprintf(msg, msg_len, "simulate_step_slab: max|u_z|*dt = %.3f cells reached the slab's back-trace reach %d (found up to three steps after the fact: "
                          "check_reach = 2 refuses such a step BEFORE it runs)", v * dt, R);
   // acknowledged: the sticky maximum starts again (the state is past saving; a host that carries on gets the next report afresh)
   c->h_reach[0] = 0.0f;
@@ -699,8 +699,14 @@ int tfl_simulate_step_slab(tfl_ctx* c, const tfl_sim_params* prm, const tfl_sim_
     c->h_reach[0] = 0.0f;
     (void)hipMemsetAsync(c->d_reach, 0, sizeof(float), c->stream);
     sl->in_flight |= kReachPrimed;
+    c->reach_folded = false;               // the state this run starts from has been through no projection of ours
   }
-  if (sl->check_reach) {
+  // mode 1, from the second step on: the projection kernel of the step before has folded max |u_z| of the planes it wrote -- this
+  // rank's OWNED planes; the halo planes are their owners' to report -- into the sticky word (k_project_v4, reach_acc): no launch
+  // of our own (round 6: k_absmax was 5-6 us of a 0.1 ms rank-step). Mode 2 needs THIS step's exact maximum and keeps it.
+  const bool reach_known = sl->check_reach == 1 && c->reach_folded;
+  c->reach_folded = false;
+  if (sl->check_reach && !reach_known) {
     for (int b = 0; b < g.B; b++)                                                                            // u_z of every batch item
       tfl::absmax(c->stream, (long long)g.Zl * g.yx, s->U->data + (3ll * b + 2) * g.Zl * g.yx, c->d_reach,
                   sl->check_reach == 2 && b == 0);      // (mode 1: a sticky maximum over the steps, see tfl_ctx.hpp)

@@ -28,6 +28,7 @@ struct tfl_ctx {
   // costs nothing
   float* d_reach_host = nullptr;              // the device address of h_reach (mapped pinned memory): the step's LAST kernel copies the
   bool reach_sink = false;                    // word there when reach_sink is set -- an async 4-byte D2H copy BLOCKS the host on this stack
+  bool reach_folded = false;                  // the last projection launch of a slab step folded max|u_z| of the planes it wrote into d_reach: the next step's k_absmax is not needed
   hipEvent_t reach_ev[4] = {nullptr, nullptr, nullptr, nullptr};
   unsigned reach_n = 0;                       // steps whose reach copy has been enqueued
   bool reach_pending = false;                 // (check_reach = 2 / graph creation: something of the ring may still be in flight)

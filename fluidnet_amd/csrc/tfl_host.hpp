@@ -197,10 +197,12 @@ void model_field_stats(hipStream_t st, int B, long long n, const float* field, i
 // dst[b][ch][cell] = pDiv[b][cell] / scale_b: the joined pressure-skip channel (model.lua:356-360); dst has `och` planes per item
 void model_skip_channel(hipStream_t st, int B, long long cells, const float* pDiv, const double* stats, double count,
                         float* dst, int och, int ch);
-void model_project(hipStream_t st, bool is3d, int B, int Z, int Y, int X, const float* pPred, const float* flags,
+// returns true when the launch also folded max |u_z| of what it wrote into *reach_acc (round 6: k_project_v4 on full blocks)
+bool model_project(hipStream_t st, bool is3d, int B, int Z, int Y, int X, const float* pPred, const float* flags,
                    const double* stats, double count, float* Uio, float* pOut, const float* UBC, const float* UInvMask,
                    int do_clamp, float lo, float hi, const unsigned long long* range_src = nullptr,
-                   unsigned long long* range_dst = nullptr, const float* reach_src = nullptr, float* reach_dst = nullptr);
+                   unsigned long long* range_dst = nullptr, const float* reach_src = nullptr, float* reach_dst = nullptr,
+                   float* reach_acc = nullptr);
 void apply_bcs(hipStream_t st, long long n, float* x, const float* bcv, const float* inv, int do_clamp, float lo,
                float hi);
 

@@ -462,7 +462,11 @@ typedef struct tfl_slab {
                              at the latest (that call waits for step n's copy, which has long landed unless the host is
                              more than two steps ahead of the device: round 6 -- waiting for step n+1's cost 60 us per
                              step); messages in flight are drained before the error is returned. The report is per
-                             rank: stop every rank when one reports (or use 2).
+                             rank: stop every rank when one reports (or use 2). Where the planes fill the projection
+                             kernel's blocks (X % 128 == 0, Y % 8 == 0, ConvNet projection) the maximum is taken by that
+                             kernel over the planes it writes -- the rank's OWNED planes; its halo planes are their owners'
+                             to report -- and the step launches no reduction of its own from the second step on; the report
+                             then comes one call later still (round 6).
                              2 (round 6, "exact"): the check comes BEFORE the step's advection and is collective -- max|u_z|
                              of the state the step starts from, the reach it needs all-reduced over the ranks (8 doubles
                              through tfl_comm.allreduce_sum), one host synchronisation. A step that needs more than `reach`

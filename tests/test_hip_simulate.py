@@ -673,6 +673,36 @@ def test_zslab_reach_violation_is_reported():
         s.close()
 
 
+def test_zslab_reach_check_rides_on_the_projection_kernel():
+    """Round 6: on grids whose planes fill k_project's blocks (X a multiple of 128, Y of 8) the step's own projection kernel folds
+    max |u_z| of the planes it writes into the sticky reach word, and from the second step on the slab step launches no k_absmax
+    of its own. A flow that only becomes too fast LATER in the run (written into the state after two quiet steps) must still
+    be reported -- through that route --, and a quiet run must stay equal to the un-cut one."""
+    import torch
+    from fluidnet_amd import FluidNetModel, tfluids
+    from fluidnet_amd.dist import run_virtual_ranks
+    from fluidnet_amd.simulate import simulate_native
+    dev = torch.device("cuda:0")
+    b = _plume_batch((24, 16, 128), 0.15, 0.6)
+    mconf = dict(dt=0.1, advectionMethod="maccormackOurs", maccormackStrength=0.6, buoyancyScale=1.0,
+                 gravityScale=0, vorticityConfinementAmp=0, simMethod="convnet")
+    layers = S.default_3d_layers(seed=2)
+    ref = _to_dev(b, dev)
+    model = FluidNetModel(layers, True)
+    sims = _slab_sims(ref, mconf, 2, layers)
+    for _ in range(3):
+        simulate_native(None, mconf, ref, model)
+        run_virtual_ranks(sims, 1)
+        _assert_slabs_equal(sims, ref, 1e-7)
+    torch.cuda.synchronize()
+    for s in sims:
+        s.batch["UDiv"][:, 2, :, 4:12, 32:96] = 15.0          # 1.5 cells per step along z from now on
+    with pytest.raises(tfluids.TfluidsError, match="reach"):
+        run_virtual_ranks(sims, 8)
+    for s in sims:
+        s.close()
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_zslab_reach_fallback_keeps_the_cut_run_exact(world):
     """VERDICT r05 item 7 / SURVEY 7 "semi-Lagrangian reach": with check_reach = "exact" (tfl_slab.check_reach = 2) the reach a
