@@ -482,6 +482,8 @@ __global__ __launch_bounds__(256, TFL_LB_PROJECT) void k_project_v4(Dom d, const
   const long long cells = d.sc;
   const int C = IS3D ? 3 : 2;
   const float scale = scale_from_stats(stats, b, count);
+  // the sticky reach word as it stands when the block starts (a uniform load, issued with the kernel's other loads: see the end)
+  const float reach_seen = (IS3D && bc.reach_acc) ? *bc.reach_acc : 0.0f;
   pPred += b * cells; flags += b * cells; pOut += b * cells; Uio += b * cells * C;
   const int o = TFL_AT(d, i0, j, k);
   const float4 z4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -580,8 +582,9 @@ __global__ __launch_bounds__(256, TFL_LB_PROJECT) void k_project_v4(Dom d, const
     __syncthreads();
     if (tid == 0) {
       const float bm = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
-      // (a stale read of the word can only be too LOW: one atomic more, never one less; non-negative floats order like their bits)
-      if (bm > *bc.reach_acc) atomicMax(reinterpret_cast<unsigned int*>(bc.reach_acc), __float_as_uint(bm));
+      // (the word was read when the block started and can only have GROWN since: one atomic more, never one less; non-negative
+      // floats order like their bits)
+      if (bm > reach_seen) atomicMax(reinterpret_cast<unsigned int*>(bc.reach_acc), __float_as_uint(bm));
     }
   }
 }

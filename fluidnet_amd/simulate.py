@@ -289,9 +289,29 @@ def simulate(conf, mconf, batch, model, outputDiv=False):
         _apply(U, None, None, clamp=(-1e6, 1e6))
 
 
+_dead_plans = []      # plans whose tensors have died, waiting for a safe moment
+
+
 def _destroy_plan(payload):
-    lib, ctx, plan = payload
-    lib.tfl_bc_plan_destroy(ctx, plan)
+    """Called from a weak-reference callback, i.e. whenever the garbage collector gets round to a dead BC tensor -- possibly in
+    the middle of somebody's HIP-graph capture (GraphedSimulate, SlabSimulation's recorded rank-step, the user's own), where the
+    hipFree inside tfl_bc_plan_destroy invalidates the capture (round 6: the whole GPU suite in ONE process failed its 153rd
+    test that way). So the plan is only queued here; _flush_dead_plans() frees the queue at the next plan look-up outside a
+    capture."""
+    _dead_plans.append(payload)
+
+
+def _flush_dead_plans():
+    if not _dead_plans:
+        return
+    try:
+        if torch.cuda.is_current_stream_capturing():
+            return
+    except Exception:      # noqa: BLE001  (no device: nothing can be capturing)
+        pass
+    while _dead_plans:
+        lib, ctx, plan = _dead_plans.pop()
+        lib.tfl_bc_plan_destroy(ctx, plan)
 
 
 _plan_cache = _PairCache(on_evict=_destroy_plan)   # -> (lib, ctx, tfl_bc_plan*)
@@ -303,6 +323,7 @@ def _bc_plan(lib, ctx, bc, inv):
     place, destroyed (tfl_bc_plan_destroy) when either is freed or replaced."""
     if bc is None or inv is None:
         return None
+    _flush_dead_plans()
     # plans are context-independent (they hold device pointers and an index list; tfl_bc_plan_destroy ignores ctx):
     # a second context on the same tensors (SlabSimulation(own_context=True)) shares the plan instead of evicting it
     # from under a holder of the raw pointer (ADVICE r02)
