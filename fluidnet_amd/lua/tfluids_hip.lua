@@ -430,6 +430,8 @@ local function plan(bc, mask)
   if hit == nil or hit[1] ~= mask then
     local h = lib.tfl_bc_plan_create(ctx, T(bc), T(mask))
     if h == nil then error('tfl_bc_plan_create failed', 3) end
+    -- (the finalizer ends in hipFree: a host that records HIP graphs ITSELF must keep collections out of its capture -- the
+    -- Python binding learnt that in round 6; Slab:record() captures inside one library call, where no collection can run)
     ffi.gc(h, function(q) lib.tfl_bc_plan_destroy(ctx, q) end)
     hit = {mask, h}
     plans[bc] = hit
