@@ -69,7 +69,7 @@ ALG_BYTES_PER_CELL = {
     "k_curl": 28,            # U3 -> curl3, |curl|                      (vorticity pass A)
     "k_confine": 44,         # curl3, |curl|, flags, U3 -> U3           (vorticity pass B)     A+B = 72
     "k_vort_fused": 28,      # U3, flags -> U3                          (curl + confinement in one launch, curl in LDS)
-    "k_bcs_div_stats": 32,   # U3, flags -> U3_bc, div (+ 2 scalars)
+    "k_bcs_div_stats": 29 if os.environ.get("TFL_WALL_PLAN", "1") != "0" else 32,   # U3, wall codes (1 B; round 6: tfl_wall_plan) | flags (4 B) -> U3_bc, div (+ 2 scalars)
     "k_net_input": 24,       # pDiv, div, flags -> 3 input planes
     "k_project": 36,         # pPred, flags, U3 -> U3, p  (the plume's U pair is sparse: applied on its four rows, the dense
                              # UBC3 / mask3 tensors -- 24 B/cell more -- are not read; round 3 counted them: 60)

@@ -114,13 +114,14 @@ static void set_params(tfl_sim_params* prm) {
   prm->vorticityConfinementAmp = 1.0; prm->simMethod = "convnet";
 }
 
-typedef struct { tfl_tensor p, U, flags, rho, UBC, UMask, rhoBC, rhoMask; tfl_bc_plan *planU, *planR; tfl_sim_state st; } DevState;
+typedef struct { tfl_tensor p, U, flags, rho, UBC, UMask, rhoBC, rhoMask; tfl_bc_plan *planU, *planR; tfl_wall_plan* wall; tfl_sim_state st; } DevState;
 static int make_dev(tfl_ctx* ctx, const HostState* h, int lo, int hi, tfl_model* model, DevState* d) {
   d->p = cut(h->p, 1, lo, hi); d->U = cut(h->U, 3, lo, hi); d->flags = cut(h->flags, 1, lo, hi); d->rho = cut(h->rho, 1, lo, hi);
   d->UBC = cut(h->UBC, 3, lo, hi); d->UMask = cut(h->UMask, 3, lo, hi); d->rhoBC = cut(h->rhoBC, 1, lo, hi); d->rhoMask = cut(h->rhoMask, 1, lo, hi);
   d->planU = tfl_bc_plan_create(ctx, &d->UBC, &d->UMask);
   d->planR = tfl_bc_plan_create(ctx, &d->rhoBC, &d->rhoMask);
   if (!d->planU || !d->planR) return 1;
+  d->wall = tfl_wall_plan_create(ctx, &d->flags);      /* optional: the scene's wall decisions as one byte per cell, found by the step through the flags' address */
   memset(&d->st, 0, sizeof(d->st));
   d->st.p = &d->p; d->st.U = &d->U; d->st.flags = &d->flags; d->st.n_density = 1; d->st.density[0] = &d->rho;
   d->st.UBC = d->planU; d->st.densityBC[0] = d->planR; d->st.model = model;
@@ -159,7 +160,7 @@ static void* rank_main(void* vp) {
   for (int c = 0; c < 3; c++) (void)hipMemcpy(a->owned[1] + c * n, d.U.data + c * nl + (size_t)(z0 - lo) * YX, n * 4, hipMemcpyDeviceToHost);
   (void)hipMemcpy(a->owned[2], d.rho.data + (size_t)(z0 - lo) * YX, n * 4, hipMemcpyDeviceToHost);
   tfl_rccl_comm_destroy(ctx, rc);
-  tfl_bc_plan_destroy(ctx, d.planU); tfl_bc_plan_destroy(ctx, d.planR); tfl_model_destroy(ctx, model);
+  tfl_bc_plan_destroy(ctx, d.planU); tfl_bc_plan_destroy(ctx, d.planR); tfl_wall_plan_destroy(ctx, d.wall); tfl_model_destroy(ctx, model);
   tfl_destroy(ctx);
   a->rc = 0;
   return NULL;
@@ -333,7 +334,7 @@ int main(int argc, char** argv) {
     if (rc != TFL_EREACH || tfl_slab_needed_reach(ctx) != 3 || memcmp(Ug, Ue, 3 * N * 4) != 0) { printf("FAILED\n"); return 15; }
     free(fast); free(Ug); free(Ue);
   }
-  tfl_bc_plan_destroy(ctx, g.planU); tfl_bc_plan_destroy(ctx, g.planR); tfl_model_destroy(ctx, model);
+  tfl_bc_plan_destroy(ctx, g.planU); tfl_bc_plan_destroy(ctx, g.planR); tfl_wall_plan_destroy(ctx, g.wall); tfl_model_destroy(ctx, model);
   tfl_destroy(ctx);
   printf("OK\n");
   return 0;

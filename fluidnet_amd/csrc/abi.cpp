@@ -232,6 +232,7 @@ int tfl_get_advect_mode(const tfl_ctx* c) { return c ? (c->advect_fast ? TFL_ADV
 
 void tfl_destroy(tfl_ctx* c) {
   if (!c) return;
+  for (tfl_wall_plan* p : c->wall_plans) p->owner = nullptr;      // the host still owns (and frees) them
   if (c->d_reach) (void)hipFree(c->d_reach);
   if (c->h_reach) (void)hipHostFree(c->h_reach);
   for (int i = 0; i < 4; i++) if (c->reach_ev[i]) (void)hipEventDestroy(c->reach_ev[i]);
@@ -1028,9 +1029,40 @@ int tfl_model_begin(tfl_ctx* c, tfl_model* m, const tfl_tensor* UDiv, const tfl_
   int stg = stages_of(c);   // tfl_set_stages: 2 = wall BCs + divergence + partial sums, 4 = reduce [zlo, zhi)
   if (c->defer_stats) stg &= ~4;  // tfl_model_forward: the first conv layer reduces the partials itself (round 6)
   m->stat_pairs_per_plane = tfl::model_stat_pairs_per_plane(flags->B, flags->Z, flags->Y, flags->X, UDiv->data, flags->data, UOut->data, w.div);
+  const unsigned char* code = nullptr;      // the wall codes of THESE flags, if the host registered them (tfl_wall_plan_create)
+  for (const tfl_wall_plan* wp : c->wall_plans)
+    if (wp->flags == flags->data && wp->is3d == m->is3d && wp->B == flags->B && wp->Z == flags->Z && wp->Y == flags->Y && wp->X == flags->X) { code = wp->code; break; }
   tfl::model_pre(c->stream, m->is3d, flags->B, flags->Z, flags->Y, flags->X, UDiv->data, flags->data, UOut->data,
-                 w.div, w.partials, stats ? stats : m->d_stats, zlo, zhi, ((stg & 2) ? 1 : 0) | ((stg & 4) ? 2 : 0), m->d_ticket);
+                 w.div, w.partials, stats ? stats : m->d_stats, zlo, zhi, ((stg & 2) ? 1 : 0) | ((stg & 4) ? 2 : 0), m->d_ticket, code);
   return check_launch(c, "model_begin");
+}
+
+tfl_wall_plan* tfl_wall_plan_create(tfl_ctx* c, const tfl_tensor* flags) {
+  if (!c || !flags || !flags->data) return nullptr;
+  if (check_flags(c, "wall_plan_create", flags) != TFL_OK) return nullptr;
+  const long long n = (long long)flags->B * flags->Z * flags->Y * flags->X;
+  tfl_wall_plan* p = new tfl_wall_plan();
+  p->flags = flags->data; p->B = flags->B; p->Z = flags->Z; p->Y = flags->Y; p->X = flags->X;
+  if (hipMalloc((void**)&p->code, (size_t)n) != hipSuccess) { (void)hipGetLastError(); c->err = "wall_plan_create: hipMalloc failed"; delete p; return nullptr; }
+  (void)hipDeviceSynchronize();               // one-time set-up: whoever filled the flags (any stream) is done
+  p->is3d = flags->Z > 1; p->owner = c;
+  // (outside a WindowScope the thread's z-window is empty: the launch covers every plane, whatever window the host has set)
+  tfl::wall_code(c->stream, p->is3d, flags->B, flags->Z, flags->Y, flags->X, flags->data, p->code);
+  if (hipStreamSynchronize(c->stream) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(p->code); c->err = "wall_plan_create: the code kernel failed"; delete p; return nullptr; }
+  for (tfl_wall_plan*& q : c->wall_plans)     // a new plan for the same array replaces the old registration (its owner still frees it)
+    if (q->flags == p->flags) { q->owner = nullptr; q = p; return p; }
+  c->wall_plans.push_back(p);
+  return p;
+}
+
+void tfl_wall_plan_destroy(tfl_ctx* c, tfl_wall_plan* p) {
+  if (!p) return;
+  (void)c;                                    // (the plan knows its context, and whether that context still exists)
+  if (tfl_ctx* o = p->owner)
+    for (size_t i = 0; i < o->wall_plans.size(); i++)
+      if (o->wall_plans[i] == p) { o->wall_plans.erase(o->wall_plans.begin() + (long)i); break; }
+  if (p->code) (void)hipFree(p->code);
+  delete p;
 }
 
 int tfl_model_finish(tfl_ctx* c, tfl_model* m, const tfl_tensor* pDiv, const tfl_tensor* flags,

@@ -193,6 +193,104 @@ __global__ __launch_bounds__(256) void k_bcs_div_stats(Dom d, const float* __res
 // neighbours (needed for the divergence of U_bc) are rebuilt in registers from the flag rows already
 // loaded for the cell's own mask plus four more rows (the stick test of the +y / +z neighbour looks two rows
 // away); U_bc.x of cell i0+4 comes from the next lane. ~26 vector loads per 4 cells instead of ~120 dword loads.
+// ---- round 6: the wall code of a cell -- the setWallBcs decision for its three face components and "is fluid" in ONE byte, a
+// pure function of the flags (wall_mask_from of the cell's word and its six neighbours'): bits 0 / 1 / 2 = zero u_x / u_y / u_z,
+// bit 3 = fluid. The flags of a scene are set once; k_bcs_div_stats evaluates wall_mask_from three times per cell per step from ten
+// rows of flag words (and is, with 650 vector instructions per wave, a flag-decoding kernel more than a streaming one): with a
+// tfl_wall_plan (tfl_wall_plan_create: this kernel, once) it reads three rows of bytes instead. Same decisions: same bits.
+template <bool IS3D>
+__global__ __launch_bounds__(256) void k_wall_code(Dom d, const float* __restrict__ flags, unsigned char* __restrict__ code) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y;
+  int b, k; dom_bk(d, b, k);
+  if (i >= d.X || j >= d.Y) return;
+  flags += b * d.sc; code += b * d.sc;
+  const int o = TFL_AT(d, i, j, k);
+  const int fc = (int)flags[o];
+  const int fxm = i > 0 ? (int)flags[o - 1] : 0, fxp = i < d.X - 1 ? (int)flags[o + 1] : 0;
+  const int fym = j > 0 ? (int)flags[o - d.sy] : 0, fyp = j < d.Y - 1 ? (int)flags[o + d.sy] : 0;
+  const int fzm = (IS3D && k > 0) ? (int)flags[o - d.sz] : 0, fzp = (IS3D && k < d.Z - 1) ? (int)flags[o + d.sz] : 0;
+  bool zx, zy, zz;
+  wall_mask_from<IS3D>(fc, fxm, fxp, fym, fyp, fzm, fzp, zx, zy, zz);
+  code[o] = (unsigned char)((zx ? 1 : 0) | (zy ? 2 : 0) | (zz ? 4 : 0) | ((fc & kFluid) ? 8 : 0));
+}
+
+// k_bcs_div_stats_v4 on wall codes: the same loads of U, the same arithmetic and summation order, the same stores -- the flag
+// rows replaced by the code bytes of the cell's row, the row above (y + 1) and the plane above (z + 1)
+template <bool IS3D>
+__global__ __launch_bounds__(256, TFL_LB_BCS) void k_bcs_div_stats_code(Dom d, const float* __restrict__ U, const unsigned char* __restrict__ code,
+                                                                       float* __restrict__ Ubc, float* __restrict__ div,
+                                                                       double* __restrict__ partials, StatTail tl) {
+  const V4Ctx c = v4_ctx(d);
+  const int j = blockIdx.y * blockDim.y + threadIdx.y;
+  int b, k; dom_bk(d, b, k);
+  const bool live = c.i0 < d.X && j < d.Y;
+  const long long cells = d.sc;
+  const int C = IS3D ? 3 : 2;
+  U += b * cells * C; Ubc += b * cells * C; code += b * cells; div += b * cells;
+  const int o = TFL_AT(d, c.i0, j, k);
+  const bool yp = live && j < d.Y - 1, zp = live && IS3D && k < d.Z - 1;
+  // unconditional loads (tfl_vec4.hpp): a lane that must not read takes word 0 and drops it
+  const unsigned cc_v = *reinterpret_cast<const unsigned*>(code + (live ? o : 0));
+  const unsigned cy_v = *reinterpret_cast<const unsigned*>(code + (yp ? o + d.sy : 0));
+  const unsigned cz_v = *reinterpret_cast<const unsigned*>(code + (zp ? o + d.sz : 0));
+  const unsigned cc = live ? cc_v : 0u, cy = yp ? cy_v : 0u, cz = zp ? cz_v : 0u;
+  float u[3][4], uyp[4], uzp[4];
+#pragma unroll
+  for (int a = 0; a < 3; a++) v4_load(U, o + a * d.sc, live && a < C, 0.0f, u[a]);
+  v4_load(U, o + d.sc + d.sy, yp, 0.0f, uyp);
+  v4_load(U, o + 2 * d.sc + d.sz, zp, 0.0f, uzp);
+  const bool need = c.last && live && c.has_r;
+  const int oo = o + 4;
+  const unsigned gcode = code[need ? oo : 0];
+  const float gu = U[need ? oo : 0];
+  double s1 = 0.0, s2 = 0.0;
+  float ubx[5];
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const unsigned m = cc >> (8 * q);
+    if (m & 1u) u[0][q] = 0.0f;
+    if (m & 2u) u[1][q] = 0.0f;
+    if (!IS3D || (m & 4u)) u[2][q] = 0.0f;
+    ubx[q] = u[0][q];
+    if (live) {
+      s1 += (double)u[0][q] + (double)u[1][q] + (double)u[2][q];
+      s2 += (double)u[0][q] * u[0][q] + (double)u[1][q] * u[1][q] + (double)u[2][q] * u[2][q];
+    }
+  }
+  ubx[4] = from_lane_above(ubx[0]);
+  if (c.last) ubx[4] = (need && !(gcode & 1u)) ? gu : 0.0f;
+  float dv[4];
+  const bool row_inner = live && j >= 1 && j <= d.Y - 2 && (!IS3D || (k >= 1 && k <= d.Z - 2));
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const int i = c.i0 + q;
+    dv[q] = 0.0f;
+    if (row_inner && i >= 1 && i <= d.X - 2 && ((cc >> (8 * q)) & 8u)) {   // tfluids.cc:1008-1066 on U_bc
+      const float by = ((cy >> (8 * q)) & 2u) ? 0.0f : uyp[q];
+      float t = u[0][q] - ubx[q + 1] + u[1][q] - by;
+      if (IS3D) {
+        const float bz = ((cz >> (8 * q)) & 4u) ? 0.0f : uzp[q];
+        t += (u[2][q] - bz);
+      }
+      dv[q] = t;
+    }
+  }
+  if (live) {
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+      if (a < C) v4_store(Ubc, o + a * d.sc, u[a]);
+    v4_store(div, o, dv);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { s1 += __shfl_down(s1, off, 64); s2 += __shfl_down(s2, off, 64); }
+  __shared__ double part[8];
+  const int tid = threadIdx.y * blockDim.x + threadIdx.x;
+  if ((tid & 63) == 0) { part[(tid >> 6) * 2] = s1; part[(tid >> 6) * 2 + 1] = s2; }
+  __syncthreads();
+  const long long blk = blockIdx.x + (long long)gridDim.x * (blockIdx.y + (long long)gridDim.y * ((long long)b * d.Z + k));
+  publish_and_maybe_reduce<false>(tl, partials, blk, (part[0] + part[2]) + (part[4] + part[6]), (part[1] + part[3]) + (part[5] + part[7]), tid);
+}
+
 template <bool IS3D, bool FOLD = false>
 __global__ __launch_bounds__(256, TFL_LB_BCS) void k_bcs_div_stats_v4(Dom d, const float* __restrict__ U, const float* __restrict__ flags,
                                                           float* __restrict__ Ubc, float* __restrict__ div,
@@ -691,8 +789,16 @@ long long model_stat_pairs_per_plane(int B, int Z, int Y, int X, const float* U,
 
 // stages: bit 0 = k_bcs_div_stats on the current z-window (per-plane partial sums land in absolute slots, so the
 // launch may be split into boundary / interior windows), bit 1 = reduce the partials of planes [zlo, zhi) into stats
+// the wall codes of a whole flags array (tfl_wall_plan_create; no z-window: the caller clears it)
+void wall_code(hipStream_t st, bool is3d, int B, int Z, int Y, int X, const float* flags, unsigned char* code) {
+  const Dom d = make_dom(Z, Y, X);
+  const dim3 blk(64, 4, 1), grd = TFL_GRID3(d, B);
+  if (is3d) k_wall_code<true><<<grd, blk, 0, st>>>(d, flags, code);
+  else k_wall_code<false><<<grd, blk, 0, st>>>(d, flags, code);
+}
+
 void model_pre(hipStream_t st, bool is3d, int B, int Z, int Y, int X, const float* U, const float* flags, float* Ubc,
-               float* div, double* partials, double* stats, int zlo, int zhi, int stages, unsigned* ticket) {
+               float* div, double* partials, double* stats, int zlo, int zhi, int stages, unsigned* ticket, const unsigned char* code) {
   const Dom d = make_dom(Z, Y, X);
   const dim3 blk(64, 4, 1), grd = TFL_GRID3(d, B);
   const Vec4Launch v = vec4_launch(B, Z, Y, X, {U, flags, Ubc, div});
@@ -712,7 +818,11 @@ void model_pre(hipStream_t st, bool is3d, int B, int Z, int Y, int X, const floa
   StatTail tl = {nullptr, stats, per_plane * Z, (unsigned)per_plane, (unsigned)(Z * B), B};
   if (fused) tl.ticket = ticket;
   if (stages & 1) {
-    if (v.ok) {
+    if (v.ok && code && !fused) {      // round 6: the scene's wall codes instead of its flag words (tfl_wall_plan)
+      TFL_TIMED_EXT("k_bcs_div_stats", st);
+      if (is3d) TFL_LAUNCH_EXT((k_bcs_div_stats_code<true>), v.grd, v.blk, 0, st, d, U, code, Ubc, div, partials, tl);
+      else TFL_LAUNCH_EXT((k_bcs_div_stats_code<false>), v.grd, v.blk, 0, st, d, U, code, Ubc, div, partials, tl);
+    } else if (v.ok) {
       TFL_TIMED_EXT("k_bcs_div_stats", st);
 #ifdef TFL_EXPERIMENTS
       if (fused) {

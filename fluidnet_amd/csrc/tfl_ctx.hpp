@@ -4,10 +4,21 @@
 #include <hip/hip_runtime.h>
 
 #include <string>
+#include <vector>
 
 #include "tfl_host.hpp"
 
+// the wall codes of one flags array (include/tfluids_hip.h tfl_wall_plan): found again by the array's address and shape
+struct tfl_wall_plan {
+  const float* flags = nullptr;
+  unsigned char* code = nullptr;
+  int B = 0, Z = 0, Y = 0, X = 0;
+  bool is3d = false;
+  struct tfl_ctx* owner = nullptr;            // the context it is registered with (cleared by tfl_destroy: the plan may outlive it)
+};
+
 struct tfl_ctx {
+  std::vector<tfl_wall_plan*> wall_plans;     // registered by tfl_wall_plan_create, looked up by tfl_model_begin
   int device = 0;
   hipStream_t stream = nullptr;
   std::string err;

@@ -183,7 +183,9 @@ long long model_stat_blocks(int B, int Z, int Y, int X);
 bool model_stats_fold_requested();
 long long model_stat_pairs_per_plane(int B, int Z, int Y, int X, const float* U, const float* flags, const float* Ubc, const float* div);   // as model_pre lays them out
 void model_pre(hipStream_t st, bool is3d, int B, int Z, int Y, int X, const float* U, const float* flags, float* Ubc,
-               float* div, double* partials, double* stats, int zlo, int zhi, int stages = 3, unsigned* ticket = nullptr);
+               float* div, double* partials, double* stats, int zlo, int zhi, int stages = 3, unsigned* ticket = nullptr,
+               const unsigned char* wall_code = nullptr);      // wall_code: the flags' tfl_wall_plan (round 6), or null
+void wall_code(hipStream_t st, bool is3d, int B, int Z, int Y, int X, const float* flags, unsigned char* code);
 void model_net_input(hipStream_t st, bool is3d, int B, int Z, int Y, int X, const float* pDiv, const float* div,
                      const float* flags, const double* stats, double count, float* x3);
 // the general net input of lib/model.lua:130-148: channels {pDiv/scale?, SetWallBcs(U)/scale (C)?, div/scale?, occupancy} in

@@ -152,6 +152,9 @@ int tfl_stream_copy(tfl_ctx* ctx, float* dst, const float* src, int64_t n);
 typedef struct tfl_bc_plan tfl_bc_plan;
 tfl_bc_plan* tfl_bc_plan_create(tfl_ctx* ctx, const tfl_tensor* bc, const tfl_tensor* invMask);
 void tfl_bc_plan_destroy(tfl_ctx* ctx, tfl_bc_plan* plan);
+typedef struct tfl_wall_plan tfl_wall_plan;
+tfl_wall_plan* tfl_wall_plan_create(tfl_ctx* ctx, const tfl_tensor* flags);
+void tfl_wall_plan_destroy(tfl_ctx* ctx, tfl_wall_plan* plan);
 typedef struct tfl_sim_params {
   float dt;
   const char* advectionMethod;
@@ -441,6 +444,19 @@ end
 --- Call after editing BC tensors in place (the 2-D demo's interactive edits): plans are keyed by tensor identity.
 function M.invalidateBCs() plans = setmetatable({}, {__mode = 'k'}) end
 
+-- the scene's flags as one code byte per cell (include/tfluids_hip.h tfl_wall_plan, round 6): registered once with the context, found
+-- again by the flags' address inside tfl_model_begin. lib/simulate.lua never writes batch.flags; call M.invalidateFlags() after
+-- editing them (a moving obstacle, the 2-D demo's mouse)
+local wallPlans = setmetatable({}, {__mode = 'k'})    -- flags tensor -> tfl_wall_plan*
+local function wallPlan(flags)
+  if wallPlans[flags] == nil then
+    local h = lib.tfl_wall_plan_create(ctx, T(flags))
+    if h == nil then return end                        -- not fatal: the step decodes the flag words itself
+    wallPlans[flags] = ffi.gc(h, function(q) lib.tfl_wall_plan_destroy(ctx, q) end)
+  end
+end
+function M.invalidateFlags() wallPlans = setmetatable({}, {__mode = 'k'}); collectgarbage() end
+
 -- `model` may be a hip.Model, or an nn.gModule (wrapped on first use), or nil for the Jacobi / PCG projections.
 local wrapped = setmetatable({}, {__mode = 'k'})
 local function sim_args(mconf, batch, model, outputDiv)
@@ -462,6 +478,7 @@ local function sim_args(mconf, batch, model, outputDiv)
   prm.outputDiv = b2i(outputDiv)
   local st = ffi.new('tfl_sim_state')
   st.p, st.U, st.flags = D(batch.pDiv), D(batch.UDiv), D(batch.flags)
+  if model ~= nil and (mconf.simMethod or 'convnet') == 'convnet' then wallPlan(batch.flags) end
   local dens = batch.density
   local chans = (dens == nil) and {} or (torch.isTensor(dens) and {dens} or dens)   -- RGB table in the 2-D demo
   st.n_density = #chans

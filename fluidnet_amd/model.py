@@ -160,6 +160,8 @@ class FluidNetModel:
         else:
             p, U = out
         lo, hi = clamp if clamp is not None else (0.0, 0.0)
+        from .simulate import wall_plan
+        wall_plan(lib, ctx, flags)      # (the context finds it again by the flags' address: include/tfluids_hip.h tfl_wall_plan)
         rc = lib.tfl_model_forward(ctx, h, tfluids._tt(pDiv), tfluids._tt(UDiv), tfluids._tt(flags),
                                    tfluids._tt(p), tfluids._tt(U), ctypes.c_void_p(work.data_ptr()),
                                    work.numel(), tfluids._tt(UBC) if UBC is not None else None,
@@ -206,6 +208,8 @@ class FluidNetModel:
         tfluids._check(stats.dtype == torch.float64 and stats.is_contiguous() and stats.numel() >= 2 * U.size(0),
                        "stats must be a contiguous float64 [B, 2] tensor")
         lib, ctx, h, work = self._prep(flags)
+        from .simulate import wall_plan
+        wall_plan(lib, ctx, flags)
         tfluids._call(lib, ctx, lib.tfl_model_begin(ctx, h, tfluids._tt(U), tfluids._tt(flags), tfluids._tt(U),
                                                     ctypes.c_void_p(work.data_ptr()), work.numel(), int(zlo),
                                                     int(zhi), ctypes.c_void_p(stats.data_ptr())))

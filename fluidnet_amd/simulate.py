@@ -7,6 +7,7 @@ gravityScale, vorticityConfinementAmp, simMethod, maxIter, gravity). State is up
 *Div slots exactly like the Lua (simulate.lua:180).
 """
 import ctypes
+import os
 import math
 
 import torch
@@ -290,6 +291,7 @@ def simulate(conf, mconf, batch, model, outputDiv=False):
 
 
 _dead_plans = []      # plans whose tensors have died, waiting for a safe moment
+_WALL_PLANS = os.environ.get("TFL_WALL_PLAN", "1") != "0"
 
 
 def _destroy_plan(payload):
@@ -310,8 +312,11 @@ def _flush_dead_plans():
     except Exception:      # noqa: BLE001  (no device: nothing can be capturing)
         pass
     while _dead_plans:
-        lib, ctx, plan = _dead_plans.pop()
-        lib.tfl_bc_plan_destroy(ctx, plan)
+        ent = _dead_plans.pop()
+        if len(ent) == 4:
+            ent[0].tfl_wall_plan_destroy(ent[1], ent[2])
+        else:
+            ent[0].tfl_bc_plan_destroy(ent[1], ent[2])
 
 
 _plan_cache = _PairCache(on_evict=_destroy_plan)   # -> (lib, ctx, tfl_bc_plan*)
@@ -335,6 +340,41 @@ def _bc_plan(lib, ctx, bc, inv):
         raise TfluidsError("tfl_bc_plan_create failed")
     _plan_cache.put(bc, inv, (lib, ctx, plan))
     return plan
+
+
+def _destroy_wall_plans(payload):
+    for (lib, ctx, plan) in payload.values():
+        _dead_plans.append((lib, ctx, plan, "wall"))
+
+
+_wall_cache = _PairCache(on_evict=_destroy_wall_plans)   # flags tensor -> {ctx: (lib, ctx, tfl_wall_plan*)}
+
+
+def wall_plan(lib, ctx, flags):
+    """The tfl_wall_plan of a flags tensor on this context (include/tfluids_hip.h: the setWallBcs decisions of the scene as one
+    byte per cell, computed once; the projection's first kernel then reads bytes instead of re-deriving them from ten rows of flag
+    words every step). Cached by the tensor's identity and torch's in-place version counter like the BC plans, so an edited or a
+    new flags tensor gets a new plan; tfluids.emptyDomain (which writes flags through the library) drops the entry itself.
+    TFL_WALL_PLAN=0 switches the plans off (every step decodes the flags, as before round 6)."""
+    if not _WALL_PLANS or flags is None or not flags.is_cuda:
+        return None
+    _flush_dead_plans()
+    hit = _wall_cache.get(flags, flags)
+    if hit is None:
+        hit = {}
+        _wall_cache.put(flags, flags, hit)
+    ent = hit.get(ctx)
+    if ent is None:
+        plan = lib.tfl_wall_plan_create(ctx, tfluids._tt(flags))
+        if not plan:
+            return None          # (not fatal: the step decodes the flags itself)
+        ent = hit[ctx] = (lib, ctx, plan)
+    return ent[2]
+
+
+def drop_wall_plan(flags):
+    """Forget the plan of a flags tensor that was just written through a raw pointer (torch's version counter does not see it)."""
+    _wall_cache._drop((id(flags), id(flags)))
 
 
 def _native_args(lib, ctx, mconf, batch, model, outputDiv=False):
@@ -365,6 +405,8 @@ def _native_args(lib, ctx, mconf, batch, model, outputDiv=False):
     st.n_density = len(chans)
     for i in range(len(chans)):
         st.density[i] = ctypes.pointer(keep[3 + i])
+    if model is not None and str(mconf.get("simMethod") or "") == "convnet":
+        wall_plan(lib, ctx, flags)      # registered with the context: tfl_model_begin finds it by the flags' address
     st.pBC = _bc_plan(lib, ctx, batch.get("pBC"), batch.get("pBCInvMask"))
     st.UBC = _bc_plan(lib, ctx, batch.get("UBC"), batch.get("UBCInvMask"))
     if chans and batch.get("densityBC") is not None:

@@ -331,6 +331,8 @@ def emptyDomain(flags, is3D, bnd=None):
     _check(flags.is_contiguous(), "Input is not contiguous")
     lib, ctx = _context(flags)
     _call(lib, ctx, lib.tfl_emptyDomain(ctx, _tt(flags), int(bool(is3D)), int(bnd)))
+    from .simulate import drop_wall_plan
+    drop_wall_plan(flags)      # written through the library: torch's version counter has not moved
     return flags
 
 

@@ -764,6 +764,53 @@ def test_zslab_reach2_equals_single_gpu():
         s.close()
 
 
+@pytest.mark.parametrize("dims", [(1, 24, 32), (12, 16, 24), (20, 24, 128)], ids=["2d", "3d-ragged-blocks", "3d-full-blocks"])
+def test_wall_plan_gives_the_same_bits(dims):
+    """Round 6: with a tfl_wall_plan registered for the scene's flags (fluidnet_amd.simulate.wall_plan: created on first use,
+    cached by the tensor's identity and version) the projection's first kernel reads one code byte per cell instead of decoding
+    ten rows of flag words -- the same setWallBcs decisions, so every field of the step must come out bit for bit the same as
+    without a plan. Obstacles with and without the stick bit, an outflow face, several steps; then an in-place edit of the flags
+    must be noticed (a new plan), and the edited scene must again equal its plan-less twin."""
+    import torch
+    from fluidnet_amd import FluidNetModel, simulate as SIM
+    from fluidnet_amd.simulate import simulate_native
+    dev = torch.device("cuda:0")
+    Z, Y, X = dims
+    is3d = Z > 1
+    b = _plume_batch(dims, 0.15, 0.6, obstacles_seed=7)
+    rng = np.random.RandomState(3)
+    scenes.add_obstacles(b["flags"][:, :, :, Y // 2:, :], is3d, rng, n_sphere=1, n_box=1, stick=True)
+    b["flags"][:, :, :, -1, 1:-1][b["flags"][:, :, :, -1, 1:-1] == scenes.OBSTACLE] = scenes.EMPTY | scenes.OUTFLOW      # an open top
+    mconf = dict(dt=0.1, advectionMethod="maccormackOurs", maccormackStrength=0.6, buoyancyScale=1.0, gravityScale=0,
+                 vorticityConfinementAmp=1.0 if is3d else 0, simMethod="convnet")
+    layers = S.default_3d_layers(seed=2) if is3d else _layers2d()
+    model = FluidNetModel(layers, is3d)
+    plain, planned = _to_dev(b, dev), _to_dev(b, dev)
+
+    def steps(batch, with_plans, n):
+        prev, SIM._WALL_PLANS = SIM._WALL_PLANS, with_plans
+        try:
+            for _ in range(n):
+                simulate_native(None, mconf, batch, model)
+        finally:
+            SIM._WALL_PLANS = prev
+    steps(plain, False, 3)
+    steps(planned, True, 3)
+    assert SIM._wall_cache.get(planned["flags"], planned["flags"]) and not SIM._wall_cache.get(plain["flags"], plain["flags"])
+    for k in ("pDiv", "UDiv", "density"):
+        assert torch.equal(plain[k], planned[k]), k
+    assert float(planned["UDiv"].abs().max()) > 0
+    first = dict(SIM._wall_cache.get(planned["flags"], planned["flags"]))
+    for batch in (plain, planned):      # an obstacle appears: torch's version counter moves, the plan must follow
+        batch["flags"][:, :, :, Y // 4:Y // 4 + 2, X // 4:X // 2] = float(scenes.OBSTACLE)
+    steps(plain, False, 2)
+    steps(planned, True, 2)
+    second = SIM._wall_cache.get(planned["flags"], planned["flags"])
+    assert second and list(second.values())[0][2] != list(first.values())[0][2]
+    for k in ("pDiv", "UDiv", "density"):
+        assert torch.equal(plain[k], planned[k]), k
+
+
 @pytest.mark.parametrize("which", ["2d_convnet", "2d_jacobi", "3d_convnet"])
 def test_graphed_simulate_equals_eager(which):
     """GraphedSimulate (one HIP-graph replay per step) must be bit-identical to eager simulate()."""
