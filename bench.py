@@ -69,9 +69,9 @@ ALG_BYTES_PER_CELL = {
     "k_curl": 28,            # U3 -> curl3, |curl|                      (vorticity pass A)
     "k_confine": 44,         # curl3, |curl|, flags, U3 -> U3           (vorticity pass B)     A+B = 72
     "k_vort_fused": 28,      # U3, flags -> U3                          (curl + confinement in one launch, curl in LDS)
-    "k_bcs_div_stats": 29 if os.environ.get("TFL_WALL_PLAN", "1") != "0" else 32,   # U3, wall codes (1 B; round 6: tfl_wall_plan) | flags (4 B) -> U3_bc, div (+ 2 scalars)
+    "k_bcs_div_stats": 30 if os.environ.get("TFL_WALL_PLAN", "1") != "0" else 32,   # U3, wall codes (2 B; round 6: tfl_wall_plan) | flags (4 B) -> U3_bc, div (+ 2 scalars)
     "k_net_input": 24,       # pDiv, div, flags -> 3 input planes
-    "k_project": 36,         # pPred, flags, U3 -> U3, p  (the plume's U pair is sparse: applied on its four rows, the dense
+    "k_project": 34 if os.environ.get("TFL_WALL_PLAN", "1") != "0" else 36,   # pPred, wall codes (2 B) | flags (4 B), U3 -> U3, p  (the plume's U pair is sparse: applied on its four rows, the dense
                              # UBC3 / mask3 tensors -- 24 B/cell more -- are not read; round 3 counted them: 60)
     "k_set_wall_bcs": 28, "k_divergence": 20, "k_velocity_update": 32, "k_jacobi": 16,
     # round 6, z-slab step only (advect_pair3.hip): the passes A / the passes B of advectScalar AND advectVel as one launch each

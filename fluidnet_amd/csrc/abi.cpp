@@ -1011,6 +1011,13 @@ float* tfl_model_div(const tfl_model* m, int B, int Z, int Y, int X, float* work
   return workspace + 4 * tfl::model_stat_blocks(B, Z, Y, X);
 }
 
+// the wall codes of THESE flags, if the host registered them with this context (tfl_wall_plan_create), else null
+static const unsigned short* wall_code_of(const tfl_ctx* c, const tfl_model* m, const tfl_tensor* flags) {
+  for (const tfl_wall_plan* wp : c->wall_plans)
+    if (wp->flags == flags->data && wp->is3d == m->is3d && wp->B == flags->B && wp->Z == flags->Z && wp->Y == flags->Y && wp->X == flags->X) return wp->code;
+  return nullptr;
+}
+
 int tfl_model_begin(tfl_ctx* c, tfl_model* m, const tfl_tensor* UDiv, const tfl_tensor* flags, const tfl_tensor* UOut,
                     float* workspace, int64_t workspace_floats, int zlo, int zhi, double* stats) {
   TRY(check_flags(c, "model_begin", flags));
@@ -1029,9 +1036,7 @@ int tfl_model_begin(tfl_ctx* c, tfl_model* m, const tfl_tensor* UDiv, const tfl_
   int stg = stages_of(c);   // tfl_set_stages: 2 = wall BCs + divergence + partial sums, 4 = reduce [zlo, zhi)
   if (c->defer_stats) stg &= ~4;  // tfl_model_forward: the first conv layer reduces the partials itself (round 6)
   m->stat_pairs_per_plane = tfl::model_stat_pairs_per_plane(flags->B, flags->Z, flags->Y, flags->X, UDiv->data, flags->data, UOut->data, w.div);
-  const unsigned char* code = nullptr;      // the wall codes of THESE flags, if the host registered them (tfl_wall_plan_create)
-  for (const tfl_wall_plan* wp : c->wall_plans)
-    if (wp->flags == flags->data && wp->is3d == m->is3d && wp->B == flags->B && wp->Z == flags->Z && wp->Y == flags->Y && wp->X == flags->X) { code = wp->code; break; }
+  const unsigned short* code = wall_code_of(c, m, flags);
   tfl::model_pre(c->stream, m->is3d, flags->B, flags->Z, flags->Y, flags->X, UDiv->data, flags->data, UOut->data,
                  w.div, w.partials, stats ? stats : m->d_stats, zlo, zhi, ((stg & 2) ? 1 : 0) | ((stg & 4) ? 2 : 0), m->d_ticket, code);
   return check_launch(c, "model_begin");
@@ -1043,7 +1048,7 @@ tfl_wall_plan* tfl_wall_plan_create(tfl_ctx* c, const tfl_tensor* flags) {
   const long long n = (long long)flags->B * flags->Z * flags->Y * flags->X;
   tfl_wall_plan* p = new tfl_wall_plan();
   p->flags = flags->data; p->B = flags->B; p->Z = flags->Z; p->Y = flags->Y; p->X = flags->X;
-  if (hipMalloc((void**)&p->code, (size_t)n) != hipSuccess) { (void)hipGetLastError(); c->err = "wall_plan_create: hipMalloc failed"; delete p; return nullptr; }
+  if (hipMalloc((void**)&p->code, (size_t)n * sizeof(unsigned short)) != hipSuccess) { (void)hipGetLastError(); c->err = "wall_plan_create: hipMalloc failed"; delete p; return nullptr; }
   (void)hipDeviceSynchronize();               // one-time set-up: whoever filled the flags (any stream) is done
   p->is3d = flags->Z > 1; p->owner = c;
   // (outside a WindowScope the thread's z-window is empty: the launch covers every plane, whatever window the host has set)
@@ -1195,7 +1200,7 @@ int tfl_model_finish(tfl_ctx* c, tfl_model* m, const tfl_tensor* pDiv, const tfl
                                            UBC ? UBC->data : nullptr, UBC ? UBCInvMask->data : nullptr, doClamp, lo, hi,
                                            m->d_range_host ? m->d_range_err : nullptr, m->d_range_host,
                                            c->reach_sink ? c->d_reach : nullptr, c->reach_sink ? c->d_reach_host : nullptr,
-                                           c->reach_sink ? c->d_reach : nullptr);
+                                           c->reach_sink ? c->d_reach : nullptr, wall_code_of(c, m, flags));
     if (c->reach_sink) c->reach_folded = folded;
   }
   return check_launch(c, "model_finish");

@@ -195,11 +195,11 @@ __global__ __launch_bounds__(256) void k_bcs_div_stats(Dom d, const float* __res
 // away); U_bc.x of cell i0+4 comes from the next lane. ~26 vector loads per 4 cells instead of ~120 dword loads.
 // ---- round 6: the wall code of a cell -- the setWallBcs decision for its three face components and "is fluid" in ONE byte, a
 // pure function of the flags (wall_mask_from of the cell's word and its six neighbours'): bits 0 / 1 / 2 = zero u_x / u_y / u_z,
-// bit 3 = fluid. The flags of a scene are set once; k_bcs_div_stats evaluates wall_mask_from three times per cell per step from ten
+// bit 3 = fluid (and, for k_project, what velocityUpdateForward asks of the cell and its three minus-neighbours: 16 bits in all). The flags of a scene are set once; k_bcs_div_stats evaluates wall_mask_from three times per cell per step from ten
 // rows of flag words (and is, with 650 vector instructions per wave, a flag-decoding kernel more than a streaming one): with a
 // tfl_wall_plan (tfl_wall_plan_create: this kernel, once) it reads three rows of bytes instead. Same decisions: same bits.
 template <bool IS3D>
-__global__ __launch_bounds__(256) void k_wall_code(Dom d, const float* __restrict__ flags, unsigned char* __restrict__ code) {
+__global__ __launch_bounds__(256) void k_wall_code(Dom d, const float* __restrict__ flags, unsigned short* __restrict__ code) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y;
   int b, k; dom_bk(d, b, k);
   if (i >= d.X || j >= d.Y) return;
@@ -211,13 +211,18 @@ __global__ __launch_bounds__(256) void k_wall_code(Dom d, const float* __restric
   const int fzm = (IS3D && k > 0) ? (int)flags[o - d.sz] : 0, fzp = (IS3D && k < d.Z - 1) ? (int)flags[o + d.sz] : 0;
   bool zx, zy, zz;
   wall_mask_from<IS3D>(fc, fxm, fxp, fym, fyp, fzm, fzp, zx, zy, zz);
-  code[o] = (unsigned char)((zx ? 1 : 0) | (zy ? 2 : 0) | (zz ? 4 : 0) | ((fc & kFluid) ? 8 : 0));
+  // bits 0-2: zero u_x / u_y / u_z (setWallBcs); 3: fluid; 4: empty and not outflow; 5-7: the -x / -y / -z neighbour is fluid;
+  // 8-10: it is empty (what velocityUpdateForward asks of the flags, tfluids.cc:1072-1156)
+  unsigned m = (zx ? 1u : 0u) | (zy ? 2u : 0u) | (zz ? 4u : 0u) | ((fc & kFluid) ? 8u : 0u) | (((fc & kEmpty) && !(fc & kOutflow)) ? 16u : 0u);
+  m |= ((fxm & kFluid) ? 32u : 0u) | ((fym & kFluid) ? 64u : 0u) | ((fzm & kFluid) ? 128u : 0u);
+  m |= ((fxm & kEmpty) ? 256u : 0u) | ((fym & kEmpty) ? 512u : 0u) | ((fzm & kEmpty) ? 1024u : 0u);
+  code[o] = (unsigned short)m;
 }
 
 // k_bcs_div_stats_v4 on wall codes: the same loads of U, the same arithmetic and summation order, the same stores -- the flag
 // rows replaced by the code bytes of the cell's row, the row above (y + 1) and the plane above (z + 1)
 template <bool IS3D>
-__global__ __launch_bounds__(256, TFL_LB_BCS) void k_bcs_div_stats_code(Dom d, const float* __restrict__ U, const unsigned char* __restrict__ code,
+__global__ __launch_bounds__(256, TFL_LB_BCS) void k_bcs_div_stats_code(Dom d, const float* __restrict__ U, const unsigned short* __restrict__ code,
                                                                        float* __restrict__ Ubc, float* __restrict__ div,
                                                                        double* __restrict__ partials, StatTail tl) {
   const V4Ctx c = v4_ctx(d);
@@ -230,10 +235,10 @@ __global__ __launch_bounds__(256, TFL_LB_BCS) void k_bcs_div_stats_code(Dom d, c
   const int o = TFL_AT(d, c.i0, j, k);
   const bool yp = live && j < d.Y - 1, zp = live && IS3D && k < d.Z - 1;
   // unconditional loads (tfl_vec4.hpp): a lane that must not read takes word 0 and drops it
-  const unsigned cc_v = *reinterpret_cast<const unsigned*>(code + (live ? o : 0));
-  const unsigned cy_v = *reinterpret_cast<const unsigned*>(code + (yp ? o + d.sy : 0));
-  const unsigned cz_v = *reinterpret_cast<const unsigned*>(code + (zp ? o + d.sz : 0));
-  const unsigned cc = live ? cc_v : 0u, cy = yp ? cy_v : 0u, cz = zp ? cz_v : 0u;
+  const unsigned long long cc_v = *reinterpret_cast<const unsigned long long*>(code + (live ? o : 0));      // four 16-bit codes
+  const unsigned long long cy_v = *reinterpret_cast<const unsigned long long*>(code + (yp ? o + d.sy : 0));
+  const unsigned long long cz_v = *reinterpret_cast<const unsigned long long*>(code + (zp ? o + d.sz : 0));
+  const unsigned long long cc = live ? cc_v : 0ull, cy = yp ? cy_v : 0ull, cz = zp ? cz_v : 0ull;
   float u[3][4], uyp[4], uzp[4];
 #pragma unroll
   for (int a = 0; a < 3; a++) v4_load(U, o + a * d.sc, live && a < C, 0.0f, u[a]);
@@ -247,7 +252,7 @@ __global__ __launch_bounds__(256, TFL_LB_BCS) void k_bcs_div_stats_code(Dom d, c
   float ubx[5];
 #pragma unroll
   for (int q = 0; q < 4; q++) {
-    const unsigned m = cc >> (8 * q);
+    const unsigned m = (unsigned)(cc >> (16 * q));
     if (m & 1u) u[0][q] = 0.0f;
     if (m & 2u) u[1][q] = 0.0f;
     if (!IS3D || (m & 4u)) u[2][q] = 0.0f;
@@ -265,11 +270,11 @@ __global__ __launch_bounds__(256, TFL_LB_BCS) void k_bcs_div_stats_code(Dom d, c
   for (int q = 0; q < 4; q++) {
     const int i = c.i0 + q;
     dv[q] = 0.0f;
-    if (row_inner && i >= 1 && i <= d.X - 2 && ((cc >> (8 * q)) & 8u)) {   // tfluids.cc:1008-1066 on U_bc
-      const float by = ((cy >> (8 * q)) & 2u) ? 0.0f : uyp[q];
+    if (row_inner && i >= 1 && i <= d.X - 2 && ((unsigned)(cc >> (16 * q)) & 8u)) {   // tfluids.cc:1008-1066 on U_bc
+      const float by = ((unsigned)(cy >> (16 * q)) & 2u) ? 0.0f : uyp[q];
       float t = u[0][q] - ubx[q + 1] + u[1][q] - by;
       if (IS3D) {
-        const float bz = ((cz >> (8 * q)) & 4u) ? 0.0f : uzp[q];
+        const float bz = ((unsigned)(cz >> (16 * q)) & 4u) ? 0.0f : uzp[q];
         t += (u[2][q] - bz);
       }
       dv[q] = t;
@@ -505,6 +510,9 @@ struct BcArgs {  // optional fused tail of simulate(): setConstVals + clamp, sim
   // where the block's maximum exceeds the word) -- the slab step's next reach check then needs no k_absmax launch of its own.
   // Only in launches whose blocks are all full (model_project decides): the block reduction has no dead lanes to care for.
   float* reach_acc;
+  // round 6: the flags' tfl_wall_plan (16-bit codes: k_wall_code), or null -- k_project_v4<., true> reads ONE row of codes where
+  // the plain form loads five rows of flag words and two single cells
+  const unsigned short* wall_code;
 };
 // one thread of the launch forwards a non-zero count (the host word is only written when something went wrong)
 __device__ __forceinline__ void forward_range_count(const BcArgs& bc, bool first_thread) {
@@ -568,7 +576,7 @@ __global__ __launch_bounds__(256) void k_project(Dom d, const float* __restrict_
 // a 16-byte vector, the x-1 / x+4 neighbours are single scalar loads. Same per-cell arithmetic (bit-exact).
 __device__ __forceinline__ void unpack4(const float4 v, float* o) { o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
 
-template <bool IS3D>
+template <bool IS3D, bool CODE = false>
 __global__ __launch_bounds__(256, TFL_LB_PROJECT) void k_project_v4(Dom d, const float* __restrict__ pPred, const float* __restrict__ flags,
                                                     const double* __restrict__ stats, double count,
                                                     float* __restrict__ Uio, float* __restrict__ pOut, BcArgs bc) {
@@ -593,13 +601,19 @@ __global__ __launch_bounds__(256, TFL_LB_PROJECT) void k_project_v4(Dom d, const
   };
   // flags: the row itself (+ one cell either side) and the four neighbouring rows
   float fc[4], fym[4], fyp[4], fzm[4], fzp[4], pc[4], pym[4], pzm[4];
-  unpack4(ld4(flags, o, true), fc);
-  unpack4(ld4(flags, o - d.sy, j > 0), fym);
-  unpack4(ld4(flags, o + d.sy, j < d.Y - 1), fyp);
-  unpack4(ld4(flags, o - d.sz, IS3D && k > 0), fzm);
-  unpack4(ld4(flags, o + d.sz, IS3D && k < d.Z - 1), fzp);
-  const float f_left_v = flags[i0 > 0 ? o - 1 : o], f_right_v = flags[i0 + 4 < d.X ? o + 4 : o];
-  const float f_left = i0 > 0 ? f_left_v : 0.0f, f_right = i0 + 4 < d.X ? f_right_v : 0.0f;
+  float f_left = 0.0f, f_right = 0.0f;
+  unsigned long long cw = 0ull;      // CODE: the four cells' 16-bit wall codes
+  if (CODE) {
+    cw = *reinterpret_cast<const unsigned long long*>(bc.wall_code + b * cells + o);
+  } else {
+    unpack4(ld4(flags, o, true), fc);
+    unpack4(ld4(flags, o - d.sy, j > 0), fym);
+    unpack4(ld4(flags, o + d.sy, j < d.Y - 1), fyp);
+    unpack4(ld4(flags, o - d.sz, IS3D && k > 0), fzm);
+    unpack4(ld4(flags, o + d.sz, IS3D && k < d.Z - 1), fzp);
+    const float f_left_v = flags[i0 > 0 ? o - 1 : o], f_right_v = flags[i0 + 4 < d.X ? o + 4 : o];
+    f_left = i0 > 0 ? f_left_v : 0.0f; f_right = i0 + 4 < d.X ? f_right_v : 0.0f;
+  }
   unpack4(ld4(pPred, o, true), pc);
   unpack4(ld4(pPred, o - d.sy, j > 0), pym);
   unpack4(ld4(pPred, o - d.sz, IS3D && k > 0), pzm);
@@ -631,8 +645,9 @@ __global__ __launch_bounds__(256, TFL_LB_PROJECT) void k_project_v4(Dom d, const
 #pragma unroll
   for (int q = 0; q < 4; q++) {
     const int i = i0 + q;
-    const int f = (int)fc[q];
-    const int fxm = q > 0 ? (int)fc[q - 1] : (int)f_left, fxp = q < 3 ? (int)fc[q + 1] : (int)f_right;
+    const unsigned m = CODE ? (unsigned)(cw >> (16 * q)) : 0u;
+    const int f = CODE ? 0 : (int)fc[q];
+    const int fxm = CODE ? 0 : (q > 0 ? (int)fc[q - 1] : (int)f_left), fxp = CODE ? 0 : (q < 3 ? (int)fc[q + 1] : (int)f_right);
     const float pxm = q > 0 ? pc[q - 1] : p_left;
     // nn.ApplyScale(true) = CDivTable (apply_scale.lua:24-30). The twelve quotients of a thread share their denominator: one
     // refined reciprocal + an exact-remainder step each (tfl_fastmath.hpp div_by<1>: bit-equal to `/` for a scale in
@@ -642,21 +657,30 @@ __global__ __launch_bounds__(256, TFL_LB_PROJECT) void k_project_v4(Dom d, const
     if (scale_ok) { v[0] = div_by<1>(u[0][q], scale, inv_scale); v[1] = div_by<1>(u[1][q], scale, inv_scale); v[2] = IS3D ? div_by<1>(u[2][q], scale, inv_scale) : 0.0f; }
     else { v[0] = u[0][q] / scale; v[1] = u[1][q] / scale; v[2] = IS3D ? u[2][q] / scale : 0.0f; }
     if (!(row_border || i < 1 || i > d.X - 2)) {   // velocityUpdateForward, tfluids.cc:1072-1156
-      const int fn[3] = {fxm, (int)fym[q], IS3D ? (int)fzm[q] : 0};
+      const int fn[3] = {fxm, CODE ? 0 : (int)fym[q], (!CODE && IS3D) ? (int)fzm[q] : 0};
       const float pn[3] = {pxm, pym[q], pzm[q]};
-      if (f & kFluid) {
+      // (CODE: the same questions answered by the cell's code -- bit 3 fluid, 4 empty and not outflow, 5 + c / 8 + c the
+      // minus-neighbour along c is fluid / empty)
+      const bool cell_fluid = CODE ? (m & 8u) != 0 : (f & kFluid) != 0;
+      const bool cell_open = CODE ? (m & 16u) != 0 : ((f & kEmpty) && !(f & kOutflow));
+      if (cell_fluid) {
 #pragma unroll
         for (int c = 0; c < C; c++) {
-          if (fn[c] & kFluid) v[c] -= (pc[q] - pn[c]);
-          if (fn[c] & kEmpty) v[c] -= pc[q];
+          const bool nf = CODE ? (m & (32u << c)) != 0 : (fn[c] & kFluid) != 0, ne = CODE ? (m & (256u << c)) != 0 : (fn[c] & kEmpty) != 0;
+          if (nf) v[c] -= (pc[q] - pn[c]);
+          if (ne) v[c] -= pc[q];
         }
-      } else if ((f & kEmpty) && !(f & kOutflow)) {
+      } else if (cell_open) {
 #pragma unroll
-        for (int c = 0; c < C; c++) v[c] = (fn[c] & kFluid) ? v[c] + pn[c] : 0.0f;
+        for (int c = 0; c < C; c++) {
+          const bool nf = CODE ? (m & (32u << c)) != 0 : (fn[c] & kFluid) != 0;
+          v[c] = nf ? v[c] + pn[c] : 0.0f;
+        }
       }
     }
     bool z[3];
-    wall_mask_from<IS3D>(f, fxm, fxp, (int)fym[q], (int)fyp[q], (int)fzm[q], (int)fzp[q], z[0], z[1], z[2]);
+    if (CODE) { z[0] = m & 1u; z[1] = m & 2u; z[2] = m & 4u; }
+    else wall_mask_from<IS3D>(f, fxm, fxp, (int)fym[q], (int)fyp[q], (int)fzm[q], (int)fzp[q], z[0], z[1], z[2]);
     po[q] = pc[q] * scale;
 #pragma unroll
     for (int c = 0; c < C; c++) {
@@ -790,7 +814,7 @@ long long model_stat_pairs_per_plane(int B, int Z, int Y, int X, const float* U,
 // stages: bit 0 = k_bcs_div_stats on the current z-window (per-plane partial sums land in absolute slots, so the
 // launch may be split into boundary / interior windows), bit 1 = reduce the partials of planes [zlo, zhi) into stats
 // the wall codes of a whole flags array (tfl_wall_plan_create; no z-window: the caller clears it)
-void wall_code(hipStream_t st, bool is3d, int B, int Z, int Y, int X, const float* flags, unsigned char* code) {
+void wall_code(hipStream_t st, bool is3d, int B, int Z, int Y, int X, const float* flags, unsigned short* code) {
   const Dom d = make_dom(Z, Y, X);
   const dim3 blk(64, 4, 1), grd = TFL_GRID3(d, B);
   if (is3d) k_wall_code<true><<<grd, blk, 0, st>>>(d, flags, code);
@@ -798,7 +822,7 @@ void wall_code(hipStream_t st, bool is3d, int B, int Z, int Y, int X, const floa
 }
 
 void model_pre(hipStream_t st, bool is3d, int B, int Z, int Y, int X, const float* U, const float* flags, float* Ubc,
-               float* div, double* partials, double* stats, int zlo, int zhi, int stages, unsigned* ticket, const unsigned char* code) {
+               float* div, double* partials, double* stats, int zlo, int zhi, int stages, unsigned* ticket, const unsigned short* code) {
   const Dom d = make_dom(Z, Y, X);
   const dim3 blk(64, 4, 1), grd = TFL_GRID3(d, B);
   const Vec4Launch v = vec4_launch(B, Z, Y, X, {U, flags, Ubc, div});
@@ -883,14 +907,14 @@ void model_skip_channel(hipStream_t st, int B, long long cells, const float* pDi
 bool model_project(hipStream_t st, bool is3d, int B, int Z, int Y, int X, const float* pPred, const float* flags,
                    const double* stats, double count, float* Uio, float* pOut, const float* UBC, const float* UInvMask,
                    int do_clamp, float lo, float hi, const unsigned long long* range_src, unsigned long long* range_dst,
-                   const float* reach_src, float* reach_dst, float* reach_acc) {
+                   const float* reach_src, float* reach_dst, float* reach_acc, const unsigned short* wall_code) {
   const Dom d = make_dom(Z, Y, X);
   const dim3 blk(64, 4, 1), grd = TFL_GRID3(d, B);
   // a dense pair acts everywhere; without one, tfl_simulate_step's sparse pair (if it asked: tfl_host.hpp BcFold) in its box
   BcArgs bc; bc.enable_clamp = do_clamp; bc.lo = lo; bc.hi = hi;
   bc.range_src = range_dst ? range_src : nullptr; bc.range_dst = range_dst;
   bc.reach_src = reach_dst ? reach_src : nullptr; bc.reach_dst = reach_dst;
-  bc.reach_acc = nullptr;
+  bc.reach_acc = nullptr; bc.wall_code = nullptr;
   bc.UBC = UBC; bc.UInvMask = UInvMask; bc.fold = UBC ? no_fold() : take_fold();
   const uintptr_t al = (uintptr_t)pPred | (uintptr_t)flags | (uintptr_t)Uio | (uintptr_t)pOut | (uintptr_t)UBC |
                        (uintptr_t)UInvMask;
@@ -900,7 +924,11 @@ bool model_project(hipStream_t st, bool is3d, int B, int Z, int Y, int X, const 
     const bool acc = is3d && reach_acc && X % 128 == 0 && Y % 8 == 0;
     if (acc) bc.reach_acc = reach_acc;
     TFL_TIMED_EXT("k_project", st);
-    if (is3d) TFL_LAUNCH_EXT((k_project_v4<true>), vg, vb, 0, st, d, pPred, flags, stats, count, Uio, pOut, bc);
+    if (wall_code) {
+      bc.wall_code = wall_code;
+      if (is3d) TFL_LAUNCH_EXT((k_project_v4<true, true>), vg, vb, 0, st, d, pPred, flags, stats, count, Uio, pOut, bc);
+      else TFL_LAUNCH_EXT((k_project_v4<false, true>), vg, vb, 0, st, d, pPred, flags, stats, count, Uio, pOut, bc);
+    } else if (is3d) TFL_LAUNCH_EXT((k_project_v4<true>), vg, vb, 0, st, d, pPred, flags, stats, count, Uio, pOut, bc);
     else TFL_LAUNCH_EXT((k_project_v4<false>), vg, vb, 0, st, d, pPred, flags, stats, count, Uio, pOut, bc);
     return acc;
   }

@@ -11,7 +11,7 @@
 // the wall codes of one flags array (include/tfluids_hip.h tfl_wall_plan): found again by the array's address and shape
 struct tfl_wall_plan {
   const float* flags = nullptr;
-  unsigned char* code = nullptr;
+  unsigned short* code = nullptr;             // 16 bits per cell (model.hip k_wall_code)
   int B = 0, Z = 0, Y = 0, X = 0;
   bool is3d = false;
   struct tfl_ctx* owner = nullptr;            // the context it is registered with (cleared by tfl_destroy: the plan may outlive it)

@@ -184,8 +184,8 @@ bool model_stats_fold_requested();
 long long model_stat_pairs_per_plane(int B, int Z, int Y, int X, const float* U, const float* flags, const float* Ubc, const float* div);   // as model_pre lays them out
 void model_pre(hipStream_t st, bool is3d, int B, int Z, int Y, int X, const float* U, const float* flags, float* Ubc,
                float* div, double* partials, double* stats, int zlo, int zhi, int stages = 3, unsigned* ticket = nullptr,
-               const unsigned char* wall_code = nullptr);      // wall_code: the flags' tfl_wall_plan (round 6), or null
-void wall_code(hipStream_t st, bool is3d, int B, int Z, int Y, int X, const float* flags, unsigned char* code);
+               const unsigned short* wall_code = nullptr);      // wall_code: the flags' tfl_wall_plan (round 6), or null
+void wall_code(hipStream_t st, bool is3d, int B, int Z, int Y, int X, const float* flags, unsigned short* code);
 void model_net_input(hipStream_t st, bool is3d, int B, int Z, int Y, int X, const float* pDiv, const float* div,
                      const float* flags, const double* stats, double count, float* x3);
 // the general net input of lib/model.lua:130-148: channels {pDiv/scale?, SetWallBcs(U)/scale (C)?, div/scale?, occupancy} in
@@ -204,7 +204,7 @@ bool model_project(hipStream_t st, bool is3d, int B, int Z, int Y, int X, const 
                    const double* stats, double count, float* Uio, float* pOut, const float* UBC, const float* UInvMask,
                    int do_clamp, float lo, float hi, const unsigned long long* range_src = nullptr,
                    unsigned long long* range_dst = nullptr, const float* reach_src = nullptr, float* reach_dst = nullptr,
-                   float* reach_acc = nullptr);
+                   float* reach_acc = nullptr, const unsigned short* wall_code = nullptr);
 void apply_bcs(hipStream_t st, long long n, float* x, const float* bcv, const float* inv, int do_clamp, float lo,
                float hi);
 

@@ -381,9 +381,9 @@ typedef struct tfl_bc_plan tfl_bc_plan;
 tfl_bc_plan* tfl_bc_plan_create(tfl_ctx* ctx, const tfl_tensor* bc, const tfl_tensor* invMask);
 void tfl_bc_plan_destroy(tfl_ctx* ctx, tfl_bc_plan* plan);
 
-/* tfl_wall_plan (round 6, optional): the setWallBcs decisions of a scene's flags as one byte per cell (zero u_x / u_y / u_z,
- * is-fluid), computed once. The flags of a simulation are set when the scene is built (lib/simulate.lua never writes them);
- * the projection's first kernel otherwise re-derives those decisions from ten rows of flag words per cell row, every step.
+/* tfl_wall_plan (round 6, optional): what the projection asks of a scene's flags as one 16-bit code per cell (the setWallBcs
+ * decisions: zero u_x / u_y / u_z; is-fluid, is-open, and the same of the three minus-neighbours), computed once. The flags of a simulation are set when the scene is built (lib/simulate.lua never writes them);
+ * the projection's first and last kernel otherwise re-derive all that from up to ten rows of flag words per cell row, every step.
  * Create one per flags array ([B][1][Z][Y][X]) on the context that steps it: tfl_model_begin / tfl_model_forward /
  * tfl_simulate_step[_slab] find it again by the array's address and shape and read the bytes instead -- the same decisions,
  * the same bits out. Destroy it (and create a new one) whenever the flags change, and before the array is freed. */

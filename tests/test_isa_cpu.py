@@ -16,7 +16,9 @@ CSRC = os.path.join(ROOT, "fluidnet_amd", "csrc")
 
 # kernel (demangled prefix) -> (source file, most full drains allowed before its last load; the value before round 4's rewrite)
 CASES = {
-    "k_project_v4<true>": ("model.hip", 0, 18),
+    "k_project_v4<true, false>": ("model.hip", 0, 18),
+    "k_project_v4<true, true>": ("model.hip", 0, 18),             # (round 6: on the flags' wall codes, tfl_wall_plan)
+    "k_bcs_div_stats_code<true>": ("model.hip", 0, 17),
     "k_bcs_div_stats_v4<true, false>": ("model.hip", 0, 17),     # (<.., true> = the opt-in ticket tail, model.hip)
     "k_curl_v4<true>": ("vorticity.hip", 0, 11),
     "k_pcg_apply<true>": ("pcg.hip", 0, 14),
