@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "fluidnet_amd"))
 import _kernels  # noqa: E402  (fluidnet_amd/_kernels.py, without importing the package and torch)
 ALG = {"k_stream_copy": 8, "k_conv3_mfma": 64, "k_conv3_mfma_tail": 36, "k_conv3_mfma_in": 44, "k_conv3_mid": 64, "k_conv3_tail": 36, "k_conv3_in": 44, "k_vel_bwd": 40, "k_vel_fwd": 28,
-       "k_scalar_fwd": 24, "k_scalar_bwd": 28, "k_confine": 44, "k_curl": 28, "k_vort_fused": 28, "k_bcs_div_stats": 32, "k_minmax3": 16,
+       "k_scalar_fwd": 24, "k_scalar_bwd": 28, "k_confine": 44, "k_curl": 28, "k_vort_fused": 28, "k_bcs_div_stats": 30, "k_minmax3": 16,
        "k_project": 60, "k_add_buoyancy": 32}
 
 
@@ -23,7 +23,7 @@ def short(name):
     if not m:
         return None
     k, targs = m.group(1), m.group(2) or ""
-    k = {"k_vel3_fwd": "k_vel_fwd", "k_vel3_bwd": "k_vel_bwd", "k_vort_pipe": "k_vort_fused"}.get(k, k)     # profiler names of advect_vel3.hip's launches; the pipelined fused confinement
+    k = {"k_vel3_fwd": "k_vel_fwd", "k_vel3_bwd": "k_vel_bwd", "k_vort_pipe": "k_vort_fused", "k_bcs_div_stats_code": "k_bcs_div_stats"}.get(k, k)     # profiler names of advect_vel3.hip's launches; the pipelined fused confinement
     if k == "k_conv3_mfma":
         a = [t.strip() for t in targs.strip("<>").split(",")]
         return "k_conv3_mfma_in" if a[1] == "true" else ("k_conv3_mfma_tail" if a[2] == "true" else "k_conv3_mfma")
