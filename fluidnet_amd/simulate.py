@@ -352,8 +352,8 @@ _wall_cache = _PairCache(on_evict=_destroy_wall_plans)   # flags tensor -> {ctx:
 
 def wall_plan(lib, ctx, flags):
     """The tfl_wall_plan of a flags tensor on this context (include/tfluids_hip.h: the setWallBcs decisions of the scene as one
-    byte per cell, computed once; the projection's first kernel then reads bytes instead of re-deriving them from ten rows of flag
-    words every step). Cached by the tensor's identity and torch's in-place version counter like the BC plans, so an edited or a
+    code per cell, computed once; the projection's first and last kernel then read codes instead of re-deriving them from ten rows
+    of flag words every step). Created at the SECOND call with the same flags, cached by the tensor's identity and torch's in-place version counter like the BC plans, so an edited or a
     new flags tensor gets a new plan; tfluids.emptyDomain (which writes flags through the library) drops the entry itself.
     TFL_WALL_PLAN=0 switches the plans off (every step decodes the flags, as before round 6)."""
     if not _WALL_PLANS or flags is None or not flags.is_cuda:
@@ -361,10 +361,15 @@ def wall_plan(lib, ctx, flags):
     _flush_dead_plans()
     hit = _wall_cache.get(flags, flags)
     if hit is None:
-        hit = {}
-        _wall_cache.put(flags, flags, hit)
+        # first sighting of this tensor (or of this version of it): only remember it. A plan costs an allocation, a kernel and a
+        # device synchronisation -- worth it for a scene that is stepped again and again, a loss for a caller that brings new
+        # flags with every call (a training loop over random batches); the SECOND call with the same flags creates the plan
+        _wall_cache.put(flags, flags, {})
+        return None
     ent = hit.get(ctx)
     if ent is None:
+        if torch.cuda.is_current_stream_capturing():
+            return None          # (creating one allocates and synchronises: not inside somebody's graph capture)
         plan = lib.tfl_wall_plan_create(ctx, tfluids._tt(flags))
         if not plan:
             return None          # (not fatal: the step decodes the flags itself)
