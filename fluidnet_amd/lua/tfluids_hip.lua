@@ -449,7 +449,10 @@ function M.invalidateBCs() plans = setmetatable({}, {__mode = 'k'}) end
 -- editing them (a moving obstacle, the 2-D demo's mouse)
 local wallPlans = setmetatable({}, {__mode = 'k'})    -- flags tensor -> tfl_wall_plan*
 local function wallPlan(flags)
-  if wallPlans[flags] == nil then
+  local seen = wallPlans[flags]
+  if seen == nil then
+    wallPlans[flags] = false                           -- first sighting: only remembered (a plan costs an allocation and a device
+  elseif seen == false then                            -- synchronisation: not for flags that come fresh with every call)
     local h = lib.tfl_wall_plan_create(ctx, T(flags))
     if h == nil then return end                        -- not fatal: the step decodes the flag words itself
     wallPlans[flags] = ffi.gc(h, function(q) lib.tfl_wall_plan_destroy(ctx, q) end)
