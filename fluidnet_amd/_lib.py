@@ -147,6 +147,7 @@ SIGNATURES = {
     "tfl_bc_plan_destroy": (None, [_c.c_void_p, _c.c_void_p]),
     "tfl_wall_plan_create": (_c.c_void_p, [_c.c_void_p, _T]),
     "tfl_wall_plan_destroy": (None, [_c.c_void_p, _c.c_void_p]),
+    "tfl_wall_plan_retire": (None, [_c.c_void_p]),
     "tfl_simulate_workspace_floats": (_c.c_int64, [_c.c_void_p, _c.POINTER(tfl_sim_params), _c.POINTER(tfl_sim_state)]),
     "tfl_simulate_step": (_c.c_int, [_c.c_void_p, _c.POINTER(tfl_sim_params), _c.POINTER(tfl_sim_state), _c.c_void_p,
                                      _c.c_int64]),

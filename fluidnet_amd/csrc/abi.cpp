@@ -232,7 +232,7 @@ int tfl_get_advect_mode(const tfl_ctx* c) { return c ? (c->advect_fast ? TFL_ADV
 
 void tfl_destroy(tfl_ctx* c) {
   if (!c) return;
-  for (tfl_wall_plan* p : c->wall_plans) p->owner = nullptr;      // the host still owns (and frees) them
+  { std::lock_guard<std::mutex> lock(c->wall_mu); for (tfl_wall_plan* p : c->wall_plans) p->owner = nullptr; c->wall_plans.clear(); }      // the host still owns (and frees) them
   if (c->d_reach) (void)hipFree(c->d_reach);
   if (c->h_reach) (void)hipHostFree(c->h_reach);
   for (int i = 0; i < 4; i++) if (c->reach_ev[i]) (void)hipEventDestroy(c->reach_ev[i]);
@@ -1012,7 +1012,8 @@ float* tfl_model_div(const tfl_model* m, int B, int Z, int Y, int X, float* work
 }
 
 // the wall codes of THESE flags, if the host registered them with this context (tfl_wall_plan_create), else null
-static const unsigned short* wall_code_of(const tfl_ctx* c, const tfl_model* m, const tfl_tensor* flags) {
+static const unsigned short* wall_code_of(tfl_ctx* c, const tfl_model* m, const tfl_tensor* flags) {
+  std::lock_guard<std::mutex> lock(c->wall_mu);
   for (const tfl_wall_plan* wp : c->wall_plans)
     if (wp->flags == flags->data && wp->is3d == m->is3d && wp->B == flags->B && wp->Z == flags->Z && wp->Y == flags->Y && wp->X == flags->X) return wp->code;
   return nullptr;
@@ -1054,18 +1055,30 @@ tfl_wall_plan* tfl_wall_plan_create(tfl_ctx* c, const tfl_tensor* flags) {
   // (outside a WindowScope the thread's z-window is empty: the launch covers every plane, whatever window the host has set)
   tfl::wall_code(c->stream, p->is3d, flags->B, flags->Z, flags->Y, flags->X, flags->data, p->code);
   if (hipStreamSynchronize(c->stream) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(p->code); c->err = "wall_plan_create: the code kernel failed"; delete p; return nullptr; }
+  std::lock_guard<std::mutex> lock(c->wall_mu);
   for (tfl_wall_plan*& q : c->wall_plans)     // a new plan for the same array replaces the old registration (its owner still frees it)
     if (q->flags == p->flags) { q->owner = nullptr; q = p; return p; }
   c->wall_plans.push_back(p);
   return p;
 }
 
+// Take the plan out of its context's registry WITHOUT freeing it: no HIP call, safe from a finalizer (where the hipFree of
+// tfl_wall_plan_destroy could invalidate a graph capture in progress). The step stops finding it at once -- which matters when the
+// flags array has died and its address may be handed out again before the host gets round to tfl_wall_plan_destroy.
+void tfl_wall_plan_retire(tfl_wall_plan* p) {
+  if (!p) return;
+  tfl_ctx* o = p->owner;
+  if (!o) return;
+  std::lock_guard<std::mutex> lock(o->wall_mu);
+  for (size_t i = 0; i < o->wall_plans.size(); i++)
+    if (o->wall_plans[i] == p) { o->wall_plans.erase(o->wall_plans.begin() + (long)i); break; }
+  p->owner = nullptr;
+}
+
 void tfl_wall_plan_destroy(tfl_ctx* c, tfl_wall_plan* p) {
   if (!p) return;
   (void)c;                                    // (the plan knows its context, and whether that context still exists)
-  if (tfl_ctx* o = p->owner)
-    for (size_t i = 0; i < o->wall_plans.size(); i++)
-      if (o->wall_plans[i] == p) { o->wall_plans.erase(o->wall_plans.begin() + (long)i); break; }
+  tfl_wall_plan_retire(p);
   if (p->code) (void)hipFree(p->code);
   delete p;
 }

@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -19,6 +20,7 @@ struct tfl_wall_plan {
 
 struct tfl_ctx {
   std::vector<tfl_wall_plan*> wall_plans;     // registered by tfl_wall_plan_create, looked up by tfl_model_begin
+  std::mutex wall_mu;                         // (a binding may retire a plan from a finalizer thread while this context steps)
   int device = 0;
   hipStream_t stream = nullptr;
   std::string err;

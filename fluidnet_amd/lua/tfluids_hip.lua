@@ -155,6 +155,7 @@ void tfl_bc_plan_destroy(tfl_ctx* ctx, tfl_bc_plan* plan);
 typedef struct tfl_wall_plan tfl_wall_plan;
 tfl_wall_plan* tfl_wall_plan_create(tfl_ctx* ctx, const tfl_tensor* flags);
 void tfl_wall_plan_destroy(tfl_ctx* ctx, tfl_wall_plan* plan);
+void tfl_wall_plan_retire(tfl_wall_plan* plan);
 typedef struct tfl_sim_params {
   float dt;
   const char* advectionMethod;

@@ -344,7 +344,8 @@ def _bc_plan(lib, ctx, bc, inv):
 
 def _destroy_wall_plans(payload):
     for (lib, ctx, plan) in payload.values():
-        _dead_plans.append((lib, ctx, plan, "wall"))
+        lib.tfl_wall_plan_retire(plan)      # out of the context's registry NOW (no HIP call): the flags' address may be handed out again
+        _dead_plans.append((lib, ctx, plan, "wall"))      # ... and freed at the next safe moment
 
 
 _wall_cache = _PairCache(on_evict=_destroy_wall_plans)   # flags tensor -> {ctx: (lib, ctx, tfl_wall_plan*)}

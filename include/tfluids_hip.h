@@ -390,6 +390,9 @@ void tfl_bc_plan_destroy(tfl_ctx* ctx, tfl_bc_plan* plan);
 typedef struct tfl_wall_plan tfl_wall_plan;
 tfl_wall_plan* tfl_wall_plan_create(tfl_ctx* ctx, const tfl_tensor* flags);
 void tfl_wall_plan_destroy(tfl_ctx* ctx, tfl_wall_plan* plan);
+/* Unregister without freeing (no HIP call: safe from a garbage collector's finalizer, where a hipFree could invalidate a graph
+ * capture in progress); tfl_wall_plan_destroy still has to follow. */
+void tfl_wall_plan_retire(tfl_wall_plan* plan);
 
 typedef struct tfl_sim_params {      /* mconf of lib/simulate.lua (defaults of lib/default_conf.lua in brackets) */
   float dt;
