@@ -140,3 +140,56 @@ def test_conv_stack_against_fp64_direct_sum(is3d):
     # conv_stack returns float32 even for the fp64 run: one rounding of the final value
     assert scenes.rel_l2(got64, want) <= 1e-7
     assert scenes.rel_l2(got32, want) <= 2e-6
+
+
+def test_wall_plan_cache_host_logic(monkeypatch):
+    """fluidnet_amd.simulate.wall_plan on the host side alone (a stand-in for the library): nothing is created at the first
+    sighting of a flags tensor, the plan at the second; an in-place edit (torch's version counter) retires the old plan at once --
+    without a HIP call -- and queues its destruction; a dead tensor does the same from its weak-reference callback; the queue is
+    emptied at the next look-up outside a graph capture and never inside one; TFL_WALL_PLAN=0 creates nothing."""
+    import gc
+    from fluidnet_amd import simulate as SIM, tfluids
+
+    class Lib:
+        def __init__(self):
+            self.created, self.retired, self.destroyed, self.next = [], [], [], 1000
+        def tfl_wall_plan_create(self, ctx, t):
+            self.next += 8
+            self.created.append(self.next)
+            return self.next
+        def tfl_wall_plan_retire(self, plan):
+            self.retired.append(plan)
+        def tfl_wall_plan_destroy(self, ctx, plan):
+            self.destroyed.append(plan)
+
+    class Flags:      # what wall_plan asks of a tensor: identity, a version counter, is_cuda
+        is_cuda = True
+        def __init__(self):
+            self._version = 0
+
+    capturing = [False]
+    monkeypatch.setattr(tfluids, "_tt", lambda t: t)
+    monkeypatch.setattr(torch.cuda, "is_current_stream_capturing", lambda: capturing[0])
+    monkeypatch.setattr(SIM, "_WALL_PLANS", True)
+    lib, ctx, f = Lib(), 77, Flags()
+    assert SIM.wall_plan(lib, ctx, f) is None and lib.created == []          # first sighting: remembered only
+    p1 = SIM.wall_plan(lib, ctx, f)
+    assert p1 == lib.created[0] and SIM.wall_plan(lib, ctx, f) == p1 and len(lib.created) == 1
+    f._version += 1                                                          # an in-place edit
+    assert SIM.wall_plan(lib, ctx, f) is None                                # ... is a first sighting of the new version
+    assert lib.retired == [p1] and lib.destroyed == []                       # out of the registry at once, freed later
+    capturing[0] = True
+    assert SIM.wall_plan(lib, ctx, f) is None and lib.destroyed == [] and len(lib.created) == 1      # nothing inside a capture
+    capturing[0] = False
+    p2 = SIM.wall_plan(lib, ctx, f)
+    assert p2 == lib.created[1] and lib.destroyed == [p1]                    # the queue was emptied on the way
+    del f
+    gc.collect()
+    assert lib.retired == [p1, p2] and lib.destroyed == [p1]                 # the dead tensor's plan: retired by the callback ...
+    g = Flags()
+    SIM.wall_plan(lib, ctx, g)
+    assert lib.destroyed == [p1, p2]                                         # ... and freed at the next look-up
+    monkeypatch.setattr(SIM, "_WALL_PLANS", False)
+    h = Flags()
+    assert SIM.wall_plan(lib, ctx, h) is None and SIM.wall_plan(lib, ctx, h) is None and len(lib.created) == 2
+    SIM.drop_wall_plan(g)
