@@ -208,16 +208,14 @@ tfl_ctx* tfl_create(int device) {
       hipHostMalloc((void**)&c->h_resid, sizeof(double) * kMaxBatch, hipHostMallocDefault) != hipSuccess ||
       hipMalloc((void**)&c->d_reach, sizeof(float)) != hipSuccess ||
       hipMemset(c->d_reach, 0, sizeof(float)) != hipSuccess ||      // (a sticky maximum since round 6: nothing resets it per step)
-      hipHostMalloc((void**)&c->h_reach, sizeof(float), hipHostMallocMapped) != hipSuccess ||
+      hipHostMalloc((void**)&c->h_reach, 2 * sizeof(float), hipHostMallocMapped) != hipSuccess ||
       hipHostGetDevicePointer((void**)&c->d_reach_host, c->h_reach, 0) != hipSuccess ||
-      hipEventCreateWithFlags(&c->reach_ev[0], hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&c->reach_ev[1], hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&c->reach_ev[2], hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&c->reach_ev[3], hipEventDisableTiming) != hipSuccess) {
+      hipMalloc((void**)&c->d_reach_tick, sizeof(unsigned)) != hipSuccess ||
+      hipMemset(c->d_reach_tick, 0, sizeof(unsigned)) != hipSuccess) {
     tfl_destroy(c);
     return nullptr;
   }
-  c->h_reach[0] = 0.0f;
+  c->h_reach[0] = 0.0f; reinterpret_cast<unsigned*>(c->h_reach)[1] = 0u;
   if (const char* m = getenv("TFL_ADVECT_MODE")) c->advect_fast = (strcmp(m, "fast") == 0 || strcmp(m, "1") == 0) ? 1 : 0;
   return c;
 }
@@ -235,7 +233,7 @@ void tfl_destroy(tfl_ctx* c) {
   { std::lock_guard<std::mutex> lock(c->wall_mu); for (tfl_wall_plan* p : c->wall_plans) p->owner = nullptr; c->wall_plans.clear(); }      // the host still owns (and frees) them
   if (c->d_reach) (void)hipFree(c->d_reach);
   if (c->h_reach) (void)hipHostFree(c->h_reach);
-  for (int i = 0; i < 4; i++) if (c->reach_ev[i]) (void)hipEventDestroy(c->reach_ev[i]);
+  if (c->d_reach_tick) (void)hipFree(c->d_reach_tick);
   if (c->h_reach_flags) (void)hipHostFree(c->h_reach_flags);
   if (c->d_trace_err) (void)hipFree(c->d_trace_err);
   if (c->d_resid) (void)hipFree(c->d_resid);
@@ -1213,8 +1211,9 @@ int tfl_model_finish(tfl_ctx* c, tfl_model* m, const tfl_tensor* pDiv, const tfl
                                            UBC ? UBC->data : nullptr, UBC ? UBCInvMask->data : nullptr, doClamp, lo, hi,
                                            m->d_range_host ? m->d_range_err : nullptr, m->d_range_host,
                                            c->reach_sink ? c->d_reach : nullptr, c->reach_sink ? c->d_reach_host : nullptr,
-                                           c->reach_sink ? c->d_reach : nullptr, wall_code_of(c, m, flags));
-    if (c->reach_sink) c->reach_folded = folded;
+                                           c->reach_sink ? c->d_reach : nullptr, wall_code_of(c, m, flags),
+                                           c->reach_sink ? c->d_reach_tick : nullptr);
+    if (c->reach_sink) { c->reach_folded = folded; c->reach_issued++; }
   }
   return check_launch(c, "model_finish");
 }

@@ -513,6 +513,9 @@ struct BcArgs {  // optional fused tail of simulate(): setConstVals + clamp, sim
   // round 6: the flags' tfl_wall_plan (16-bit codes: k_wall_code), or null -- k_project_v4<., true> reads ONE row of codes where
   // the plain form loads five rows of flag words and two single cells
   const unsigned short* wall_code;
+  // round 6: the device count of reach publications; the publishing thread increments it and leaves the new value beside the
+  // maximum in the pinned mirror (reach_dst[1]) -- what the host waits on instead of an event
+  unsigned* reach_tick;
 };
 // one thread of the launch forwards a non-zero count (the host word is only written when something went wrong)
 __device__ __forceinline__ void forward_range_count(const BcArgs& bc, bool first_thread) {
@@ -520,7 +523,20 @@ __device__ __forceinline__ void forward_range_count(const BcArgs& bc, bool first
     const unsigned long long v = *bc.range_src;
     if (v) *bc.range_dst = v;
   }
-  if (bc.reach_src && first_thread) *bc.reach_dst = *bc.reach_src;
+}
+// ... and the z-slab reach word with its publication count -- at the END of the kernel (its loads and the fence must not sit
+// between the kernel's own loads: tests/test_isa_cpu.py)
+__device__ __forceinline__ void publish_reach(const BcArgs& bc, bool first_thread) {
+  if (bc.reach_src && first_thread) {
+    // (read through atomics: the word as every block's atomicMax has left it so far, past any cache line this CU may hold)
+    const unsigned v = atomicOr(reinterpret_cast<unsigned*>(const_cast<float*>(bc.reach_src)), 0u);
+    *reinterpret_cast<unsigned*>(bc.reach_dst) = v;
+    if (bc.reach_tick) {
+      const unsigned t = atomicAdd(bc.reach_tick, 1u) + 1u;       // (one launch at a time: the launches of a stream run in order)
+      __threadfence_system();                       // the maximum is visible to the host before the count that announces it
+      reinterpret_cast<volatile unsigned*>(bc.reach_dst)[1] = t;
+    }
+  }
 }
 
 template <bool IS3D>
@@ -570,6 +586,7 @@ __global__ __launch_bounds__(256) void k_project(Dom d, const float* __restrict_
     if (bc.enable_clamp) v = fminf(fmaxf(v, bc.lo), bc.hi);
     Uio[o + c * d.sc] = v;
   }
+  publish_reach(bc, (blockIdx.x | blockIdx.y | blockIdx.z | threadIdx.x | threadIdx.y) == 0);
 }
 
 // k_project with four consecutive x cells per thread (X % 4 == 0, 16-byte aligned rows): every access is
@@ -709,6 +726,7 @@ __global__ __launch_bounds__(256, TFL_LB_PROJECT) void k_project_v4(Dom d, const
       if (bm > reach_seen) atomicMax(reinterpret_cast<unsigned int*>(bc.reach_acc), __float_as_uint(bm));
     }
   }
+  publish_reach(bc, (blockIdx.x | blockIdx.y | blockIdx.z | threadIdx.x | threadIdx.y) == 0);
 }
 
 // x = clamp(x * invMask + bc): setConstVals (+ the final U:clamp) of lib/simulate.lua:130-160,326
@@ -907,14 +925,14 @@ void model_skip_channel(hipStream_t st, int B, long long cells, const float* pDi
 bool model_project(hipStream_t st, bool is3d, int B, int Z, int Y, int X, const float* pPred, const float* flags,
                    const double* stats, double count, float* Uio, float* pOut, const float* UBC, const float* UInvMask,
                    int do_clamp, float lo, float hi, const unsigned long long* range_src, unsigned long long* range_dst,
-                   const float* reach_src, float* reach_dst, float* reach_acc, const unsigned short* wall_code) {
+                   const float* reach_src, float* reach_dst, float* reach_acc, const unsigned short* wall_code, unsigned* reach_tick) {
   const Dom d = make_dom(Z, Y, X);
   const dim3 blk(64, 4, 1), grd = TFL_GRID3(d, B);
   // a dense pair acts everywhere; without one, tfl_simulate_step's sparse pair (if it asked: tfl_host.hpp BcFold) in its box
   BcArgs bc; bc.enable_clamp = do_clamp; bc.lo = lo; bc.hi = hi;
   bc.range_src = range_dst ? range_src : nullptr; bc.range_dst = range_dst;
   bc.reach_src = reach_dst ? reach_src : nullptr; bc.reach_dst = reach_dst;
-  bc.reach_acc = nullptr; bc.wall_code = nullptr;
+  bc.reach_acc = nullptr; bc.wall_code = nullptr; bc.reach_tick = bc.reach_src ? reach_tick : nullptr;
   bc.UBC = UBC; bc.UInvMask = UInvMask; bc.fold = UBC ? no_fold() : take_fold();
   const uintptr_t al = (uintptr_t)pPred | (uintptr_t)flags | (uintptr_t)Uio | (uintptr_t)pOut | (uintptr_t)UBC |
                        (uintptr_t)UInvMask;

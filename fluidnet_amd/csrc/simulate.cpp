@@ -12,7 +12,9 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
+#include <thread>
 #include <string>
 
 namespace tfl { const unsigned long long* model_range_counter(const tfl_model* m); }      // abi.cpp (library-internal)
@@ -580,10 +582,22 @@ struct StageGuard {          // whatever happens, leave the context with no wind
   ~StageGuard() { (void)tfl_set_z_window(c, 0, 0, 0, 0); (void)tfl_set_stages(c, 0); c->dx_dim = 0; (void)tfl_set_z_origin(c, 0, 0); c->reach_sink = false; }
 };
 
+// the pinned publication count has reached `target` (wrap-safe); spins without an API call, gives the core away after a while,
+// and gives up after 30 s (a dead device must not hang the host here: the next HIP call reports it)
+void reach_wait(tfl_ctx* c, unsigned target) {
+  volatile unsigned* tick = reinterpret_cast<volatile unsigned*>(c->h_reach) + 1;
+  if ((int)(*tick - target) >= 0) return;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (unsigned long i = 0; (int)(*tick - target) < 0; i++) {
+    if (i < 4096) { __builtin_ia32_pause(); continue; }
+    std::this_thread::yield();
+    if ((i & 1023) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(30)) return;
+  }
+}
 // check_reach = 1, host side: has a step that the device has certainly started (two calls back) -- or any later one it has got
 // to since -- found max|u_z| dt >= R? Waits only when the host is more than two steps ahead of the device.
 bool reach_violated(tfl_ctx* c, float dt, int R, char* msg, size_t msg_len) {
-  if (c->reach_n >= 2) (void)hipEventSynchronize(c->reach_ev[(c->reach_n - 2) & 3]);
+  if (c->reach_hist[0]) reach_wait(c, c->reach_hist[0]);
   const float v = *(volatile float*)c->h_reach;
   if (!(v * dt >= (float)R)) return false;
   snprintf(msg, msg_len, "simulate_step_slab: max|u_z|*dt = %.3f cells reached the slab's back-trace reach %d (found up to three steps after the fact: "
@@ -593,15 +607,16 @@ bool reach_violated(tfl_ctx* c, float dt, int R, char* msg, size_t msg_len) {
   (void)hipMemsetAsync(c->d_reach, 0, sizeof(float), c->stream);
   return true;
 }
-// ... device side: the sticky word reaches the host through the step's LAST kernel (k_project copies it into the mapped pinned
-// mirror: tfl_ctx::reach_sink) -- not through hipMemcpyAsync: a 4-byte D2H copy on the stream makes the HOST wait until the stream
-// has drained on this stack (tools/ubench/host_costs.hip)
-void reach_mark(tfl_ctx* c) {      // (outside a capture: after the eager step's copy, or behind the launch of a recorded step)
-  if (hipEventRecord(c->reach_ev[c->reach_n & 3], c->stream) == hipSuccess) { c->reach_n++; c->reach_pending = true; }
+// ... device side: the sticky word and the publication count reach the host through the step's LAST kernel (k_project writes
+// them into the mapped pinned mirror: tfl_ctx::reach_sink) -- not through hipMemcpyAsync (a 4-byte D2H copy on the stream makes
+// the HOST wait until the stream has drained on this stack, tools/ubench/host_costs.hip) and not behind an event (4 us of
+// device time per hipEventRecord): the host counts the publishing launches it has enqueued (tfl_model_finish) and keeps the
+// count as it stood at the end of the last two steps
+void reach_mark(tfl_ctx* c) {      // at the end of a step whose projection published (eager, or behind the launch of a recorded step)
+  c->reach_hist[0] = c->reach_hist[1]; c->reach_hist[1] = c->reach_issued;
 }
-void reach_quiesce(tfl_ctx* c) {   // every copy of the ring has landed
-  if (c->reach_pending && c->reach_n > 0) (void)hipEventSynchronize(c->reach_ev[(c->reach_n - 1) & 3]);
-  c->reach_pending = false;
+void reach_quiesce(tfl_ctx* c) {   // every publication enqueued so far has landed
+  if (c->reach_issued) reach_wait(c, c->reach_issued);
 }
 
 }  // namespace
@@ -989,6 +1004,7 @@ struct tfl_slab_graph {
   tfl_slab* sl = nullptr;
   int reach = 1;
   bool multi = false;                 // the slab has neighbours
+  unsigned reach_pubs = 0;            // reach publications one replay makes (counted while recording)
   size_t nodes = 0;
 };
 
@@ -1024,7 +1040,9 @@ tfl_slab_graph* tfl_slab_graph_create(tfl_ctx* c, const tfl_sim_params* prm, con
     c->err = "slab_graph_create: hipStreamBeginCapture failed"; (void)hipStreamDestroy(G->cap); delete G; return nullptr;
   }
   c->stream = G->cap; c->capturing = true;
+  const unsigned issued0 = c->reach_issued;
   const int rc = tfl_simulate_step_slab(c, prm, s, sl, comm, ws, ws_floats);
+  G->reach_pubs = c->reach_issued - issued0; c->reach_issued = issued0;      // recorded, not run: every REPLAY makes them
   c->capturing = false; c->stream = user;
   const hipError_t ec = hipStreamEndCapture(G->cap, &graph);
   std::string why;
@@ -1058,7 +1076,7 @@ int tfl_slab_graph_step(tfl_ctx* c, tfl_slab_graph* G) {
     return TFL_ERANGE;
   }
   if (hipGraphLaunch(G->exec, c->stream) != hipSuccess) { c->err = "slab_graph_step: hipGraphLaunch failed"; (void)hipGetLastError(); return TFL_EHIP; }
-  if (G->sl->check_reach) reach_mark(c);
+  if (G->sl->check_reach) { c->reach_issued += G->reach_pubs; reach_mark(c); }
   return TFL_OK;
 }
 

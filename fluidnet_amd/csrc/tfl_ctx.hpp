@@ -34,17 +34,19 @@ struct tfl_ctx {
   int advect_fast = 0;                        // tfl_set_advect_mode (initialised from TFL_ADVECT_MODE by tfl_create)
   int stages = 0;                             // tfl_set_stages: which passes of a multi-pass operator run (0 = all)
   float* d_reach = nullptr;                   // z-slab reach check: max|u_z| of the current step (device word)
-  float* h_reach = nullptr;                   // pinned mirror, read by the NEXT tfl_simulate_step_slab call
+  float* h_reach = nullptr;                   // pinned mirror (TWO words: the maximum, and the publication count), read by later calls
   // check_reach = 1 (round 6): the device word is a STICKY maximum (never reset by a step: a violation cannot be overwritten before
-  // the host has seen it); each step copies it to h_reach and records reach_ev[n & 3] behind the copy; the call for step n waits
-  // for the event of step n - 2 -- complete unless the host is more than two steps ahead, so the wait bounds the host's lead and
-  // costs nothing
-  float* d_reach_host = nullptr;              // the device address of h_reach (mapped pinned memory): the step's LAST kernel copies the
-  bool reach_sink = false;                    // word there when reach_sink is set -- an async 4-byte D2H copy BLOCKS the host on this stack
+  // the host has seen it). The step's LAST kernel (k_project) copies it into the mapped pinned mirror -- an async 4-byte D2H copy
+  // BLOCKS the host on this stack -- and, behind a system-scope fence, the count of such publications (a device word it
+  // increments) beside it. The call for step n + 1 waits, spinning on that pinned count, for the publication of step n - 1:
+  // there unless the host is more than two steps ahead, so the wait bounds the host's lead and costs nothing. No API call
+  // and no event on either side: the hipEventRecord per step of the first form cost the device 4 us of a 0.1 ms rank-step.
+  float* d_reach_host = nullptr;              // the device address of h_reach
+  unsigned* d_reach_tick = nullptr;           // device word: publications made so far
+  bool reach_sink = false;                    // the projection launches of THIS step publish (set by the slab step, cleared by its guard)
   bool reach_folded = false;                  // the last projection launch of a slab step folded max|u_z| of the planes it wrote into d_reach: the next step's k_absmax is not needed
-  hipEvent_t reach_ev[4] = {nullptr, nullptr, nullptr, nullptr};
-  unsigned reach_n = 0;                       // steps whose reach copy has been enqueued
-  bool reach_pending = false;                 // (check_reach = 2 / graph creation: something of the ring may still be in flight)
+  unsigned reach_issued = 0;                  // publishing launches enqueued so far (host side)
+  unsigned reach_hist[2] = {0, 0};            // reach_issued as it stood at the end of the step before last / of the last step
   double* h_reach_flags = nullptr;            // pinned [kReachFlags]: the all-reduced "reach >= r" counts of check_reach = 2 (created on first use)
   int needed_reach = 0;                       // what the last TFL_EREACH asked for (tfl_slab_needed_reach)
   tfl::BcFoldArg fold = {nullptr, 0u, 0u};    // tfl_simulate_step: a setConstVals pair (device descriptor + gate) the next operator may apply to its output

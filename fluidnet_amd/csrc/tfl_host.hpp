@@ -204,7 +204,7 @@ bool model_project(hipStream_t st, bool is3d, int B, int Z, int Y, int X, const 
                    const double* stats, double count, float* Uio, float* pOut, const float* UBC, const float* UInvMask,
                    int do_clamp, float lo, float hi, const unsigned long long* range_src = nullptr,
                    unsigned long long* range_dst = nullptr, const float* reach_src = nullptr, float* reach_dst = nullptr,
-                   float* reach_acc = nullptr, const unsigned short* wall_code = nullptr);
+                   float* reach_acc = nullptr, const unsigned short* wall_code = nullptr, unsigned* reach_tick = nullptr);
 void apply_bcs(hipStream_t st, long long n, float* x, const float* bcv, const float* inv, int do_clamp, float lo,
                float hi);
 

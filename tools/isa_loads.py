@@ -42,5 +42,16 @@ for f in files:
             if t.startswith(("global_load", "flat_load", "buffer_load")): seq.append("L")
             elif t.startswith(("global_store", "flat_store")): seq.append("S")
             elif t.startswith("s_waitcnt") and "vmcnt" in t: seq.append("w" + re.search(r"vmcnt\((\d+)\)", t).group(1))
-        drains = sum(1 for n, x in enumerate(seq) if x == "w0" and "L" in seq[n + 1:])
-        print("%-34s %3d loads, %2d full drains before the last load:  %s" % (dn[:34], seq.count("L"), drains, " ".join(seq)[:260]))
+        # the kernel's main batch of loads = the stretch between two stores that holds the most loads (a kernel may read a word or
+        # two more after its stores: k_project publishes the z-slab reach word at its very end); a full drain counts when further
+        # loads of THAT stretch follow it
+        runs, cur_run = [], []
+        for x in seq:
+            if x == "S":
+                runs.append(cur_run); cur_run = []
+            else:
+                cur_run.append(x)
+        runs.append(cur_run)
+        main = max(runs, key=lambda r: r.count("L"))
+        drains = sum(1 for n, x in enumerate(main) if x == "w0" and "L" in main[n + 1:])
+        print("%-34s %3d loads, %2d full drains before the last load:  %s" % (dn[:34], main.count("L"), drains, " ".join(seq)[:260]))
